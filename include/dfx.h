@@ -1,0 +1,314 @@
+/*
+ * dfx.h -- C ABI of the MI355X-native filter / projection / aggregate execution path.
+ *
+ * This is the drop-in boundary for andygrove/datafusion-archive's src/execution::{filter,
+ * projection,aggregate} and its RecordBatch expression evaluator.  Every entry point below
+ * names the reference interface it replaces (paths relative to the reference repo root).
+ *
+ * Conventions
+ *  - plain C, no C++/HIP/torch types in any signature;
+ *  - RecordBatches cross the boundary as Arrow C Data Interface structs; the pull-based
+ *    `trait Relation { next(); schema() }` (src/execution/relation.rs:27-32) crosses it as the
+ *    Arrow C Stream Interface: get_next()==Relation::next() (a released array == Ok(None)),
+ *    get_schema()==Relation::schema();
+ *  - every function returns a dfx_status (0 = OK); the code mirrors the variant of
+ *    `ExecutionError` (src/execution/error.rs:26-36) the reference would have produced.  Message
+ *    text goes to the caller-provided `err` buffer (or ArrowArrayStream.get_last_error for
+ *    stream callbacks).  No C++ exception, HIP error or panic crosses this ABI;
+ *  - handles are thread-confined (the reference is Rc<RefCell<..>>, i.e. !Send + !Sync).
+ */
+#ifndef DFX_H
+#define DFX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------------------------
+ * Arrow C Data / C Stream / C Device interfaces (standard ABI, verbatim struct layouts).
+ * ---------------------------------------------------------------------------------------- */
+#ifndef ARROW_C_DATA_INTERFACE
+#define ARROW_C_DATA_INTERFACE
+#define ARROW_FLAG_DICTIONARY_ORDERED 1
+#define ARROW_FLAG_NULLABLE 2
+#define ARROW_FLAG_MAP_KEYS_SORTED 4
+struct ArrowSchema {
+  const char* format;
+  const char* name;
+  const char* metadata;
+  int64_t flags;
+  int64_t n_children;
+  struct ArrowSchema** children;
+  struct ArrowSchema* dictionary;
+  void (*release)(struct ArrowSchema*);
+  void* private_data;
+};
+struct ArrowArray {
+  int64_t length;
+  int64_t null_count;
+  int64_t offset;
+  int64_t n_buffers;
+  int64_t n_children;
+  const void** buffers;
+  struct ArrowArray** children;
+  struct ArrowArray* dictionary;
+  void (*release)(struct ArrowArray*);
+  void* private_data;
+};
+#endif
+
+#ifndef ARROW_C_STREAM_INTERFACE
+#define ARROW_C_STREAM_INTERFACE
+struct ArrowArrayStream {
+  int (*get_schema)(struct ArrowArrayStream*, struct ArrowSchema* out);
+  int (*get_next)(struct ArrowArrayStream*, struct ArrowArray* out);
+  const char* (*get_last_error)(struct ArrowArrayStream*);
+  void (*release)(struct ArrowArrayStream*);
+  void* private_data;
+};
+#endif
+
+/* ------------------------------------------------------------------------------------------
+ * Status codes == ExecutionError variants (src/execution/error.rs:26-36), same order.
+ * ---------------------------------------------------------------------------------------- */
+typedef enum dfx_status {
+  DFX_OK = 0,
+  DFX_IO_ERROR = 1,        /* ExecutionError::IoError        */
+  DFX_PARSER_ERROR = 2,    /* ExecutionError::ParserError    */
+  DFX_GENERAL = 3,         /* ExecutionError::General        */
+  DFX_INVALID_COLUMN = 4,  /* ExecutionError::InvalidColumn  */
+  DFX_NOT_IMPLEMENTED = 5, /* ExecutionError::NotImplemented (also the reference's unimplemented!()) */
+  DFX_INTERNAL_ERROR = 6,  /* ExecutionError::InternalError  (also the reference's panic!()/unwrap()) */
+  DFX_ARROW_ERROR = 7,     /* ExecutionError::ArrowError     (e.g. arrow DivideByZero) */
+  DFX_EXECUTION_ERROR = 8  /* ExecutionError::ExecutionError (also HIP / RCCL failures) */
+} dfx_status;
+
+/* arrow::datatypes::DataType subset used by the path (expression.rs:135-166). */
+typedef enum dfx_dtype {
+  DFX_TYPE_NONE = 0,
+  DFX_BOOLEAN = 1,
+  DFX_INT8 = 2,
+  DFX_INT16 = 3,
+  DFX_INT32 = 4,
+  DFX_INT64 = 5,
+  DFX_UINT8 = 6,
+  DFX_UINT16 = 7,
+  DFX_UINT32 = 8,
+  DFX_UINT64 = 9,
+  DFX_FLOAT32 = 10,
+  DFX_FLOAT64 = 11,
+  DFX_UTF8 = 12
+} dfx_dtype;
+
+/* logicalplan::Operator (src/logicalplan.rs:67-84), same order. */
+typedef enum dfx_operator {
+  DFX_OP_EQ = 0,
+  DFX_OP_NOT_EQ = 1,
+  DFX_OP_LT = 2,
+  DFX_OP_LT_EQ = 3,
+  DFX_OP_GT = 4,
+  DFX_OP_GT_EQ = 5,
+  DFX_OP_PLUS = 6,
+  DFX_OP_MINUS = 7,
+  DFX_OP_MULTIPLY = 8,
+  DFX_OP_DIVIDE = 9,
+  DFX_OP_MODULUS = 10,
+  DFX_OP_AND = 11,
+  DFX_OP_OR = 12,
+  DFX_OP_NOT = 13,
+  DFX_OP_LIKE = 14,
+  DFX_OP_NOT_LIKE = 15
+} dfx_operator;
+
+/* logicalplan::Expr variants (src/logicalplan.rs:136-167), same order. */
+typedef enum dfx_expr_kind {
+  DFX_EXPR_COLUMN = 0,
+  DFX_EXPR_LITERAL = 1,
+  DFX_EXPR_BINARY = 2,
+  DFX_EXPR_IS_NOT_NULL = 3,
+  DFX_EXPR_IS_NULL = 4,
+  DFX_EXPR_CAST = 5,
+  DFX_EXPR_SORT = 6,
+  DFX_EXPR_SCALAR_FUNCTION = 7,
+  DFX_EXPR_AGGREGATE_FUNCTION = 8
+} dfx_expr_kind;
+
+/*
+ * One node of a serialised logicalplan::Expr tree.  A tree is an array of nodes in any order
+ * with child links by index; `root` selects the top node.  This is what a Rust shim derives
+ * from the `&Expr` it is handed by ExecutionContext::execute (src/execution/context.rs:132,
+ * :155,:174,:180) -- the reference's RuntimeExpr holds opaque closures, so the tree itself has
+ * to cross the boundary.
+ */
+typedef struct dfx_expr_node {
+  int32_t kind;   /* dfx_expr_kind */
+  int32_t op;     /* BINARY: dfx_operator */
+  int32_t dtype;  /* LITERAL: literal's type (DFX_TYPE_NONE == ScalarValue::Null);
+                     CAST: target type; AGGREGATE_FUNCTION / SCALAR_FUNCTION: return_type */
+  int32_t left;   /* BINARY: left child; CAST / AGGREGATE / IS_NULL / IS_NOT_NULL / SORT: the child; else -1 */
+  int32_t right;  /* BINARY: right child; else -1 */
+  int32_t column; /* COLUMN: column index */
+  int32_t n_args; /* AGGREGATE_FUNCTION / SCALAR_FUNCTION: number of arguments (reference asserts 1,
+                     expression.rs:91); the first argument is `left` */
+  int32_t reserved;
+  union {
+    int64_t i64;  /* Int8..Int64 literals, sign-extended */
+    uint64_t u64; /* UInt8..UInt64 literals, zero-extended; Boolean: 0/1 */
+    double f64;   /* Float64 literal */
+    float f32;    /* Float32 literal */
+  } lit;
+  const char* name; /* AGGREGATE_FUNCTION / SCALAR_FUNCTION: function name (matched case-insensitively,
+                       expression.rs:98); Utf8 literal: the string; else NULL */
+} dfx_expr_node;
+
+/* ------------------------------------------------------------------------------------------
+ * Library / device
+ * ---------------------------------------------------------------------------------------- */
+/* ABI version of this header. */
+#define DFX_ABI_VERSION 1
+int32_t dfx_abi_version(void);
+
+/* Bind the calling process to one GPU (one process per GPU).  Must precede any other call that
+ * touches the device; default device is 0.  No reference equivalent (reference is CPU-only). */
+int32_t dfx_init(int32_t device_ordinal, char* err, size_t errlen);
+/* Device facts for reports: name, CU count, HBM bytes, wavefront size. */
+int32_t dfx_device_info(char* name, size_t namelen, int32_t* n_cu, int64_t* hbm_bytes,
+                        int32_t* wavefront, char* err, size_t errlen);
+/* Block until every stream of the library is idle (bench bracketing). */
+int32_t dfx_synchronize(char* err, size_t errlen);
+
+/* ------------------------------------------------------------------------------------------
+ * Expression compiler.
+ *   replaces: compile_scalar_expr (src/execution/expression.rs:283-505)
+ *             compile_expr        (src/execution/expression.rs:80-121)
+ *             RuntimeExpr::{get_name,get_type} (expression.rs:56-77)
+ * Validation errors map 1:1 on the reference's Err cases (unsupported literal type :306-309,
+ * unsupported operator :494-497, unsupported expression :500-503, cast rules :316-379,
+ * unsupported aggregate :103-106).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct dfx_runtime_expr dfx_runtime_expr;
+
+int32_t dfx_compile_scalar_expr(const dfx_expr_node* nodes, int32_t n_nodes, int32_t root,
+                                const struct ArrowSchema* input_schema, dfx_runtime_expr** out,
+                                char* err, size_t errlen);
+int32_t dfx_compile_expr(const dfx_expr_node* nodes, int32_t n_nodes, int32_t root,
+                         const struct ArrowSchema* input_schema, dfx_runtime_expr** out, char* err,
+                         size_t errlen);
+const char* dfx_runtime_expr_name(const dfx_runtime_expr* e); /* RuntimeExpr::get_name */
+int32_t dfx_runtime_expr_type(const dfx_runtime_expr* e);     /* RuntimeExpr::get_type -> dfx_dtype */
+int32_t dfx_runtime_expr_is_aggregate(const dfx_runtime_expr* e);
+void dfx_runtime_expr_free(dfx_runtime_expr* e);
+
+/* ------------------------------------------------------------------------------------------
+ * Operators.  Each consumes (takes ownership of) an input stream and fills `out` with the
+ * operator's own stream; out->release frees the whole sub-tree, like dropping the
+ * Rc<RefCell<Relation>>.  When `input` is itself a stream produced by this library the operators
+ * are chained on the device (no host round trip) and Filter feeding Aggregate is fused into one
+ * kernel.  The runtime exprs are borrowed for the duration of the call only.
+ * ---------------------------------------------------------------------------------------- */
+
+/* replaces FilterRelation::new(input, expr, schema) + impl Relation (src/execution/filter.rs:36-77)
+ * and fn filter (filter.rs:79-110). */
+int32_t dfx_filter_relation_new(struct ArrowArrayStream* input, const dfx_runtime_expr* expr,
+                                const struct ArrowSchema* schema, struct ArrowArrayStream* out,
+                                char* err, size_t errlen);
+
+/* replaces ProjectRelation::new(input, expr, schema) + impl Relation (src/execution/projection.rs:36-71). */
+int32_t dfx_project_relation_new(struct ArrowArrayStream* input, const dfx_runtime_expr* const* exprs,
+                                 int32_t n_exprs, const struct ArrowSchema* schema,
+                                 struct ArrowArrayStream* out, char* err, size_t errlen);
+
+/* replaces AggregateRelation::new(schema, input, group_expr, aggr_expr) + impl Relation
+ * (src/execution/aggregate.rs:47-61, :614-631, :703-952).  `schema` may be NULL or empty
+ * (context.rs:185 passes Schema::empty()). */
+int32_t dfx_aggregate_relation_new(const struct ArrowSchema* schema, struct ArrowArrayStream* input,
+                                   const dfx_runtime_expr* const* group_exprs, int32_t n_group,
+                                   const dfx_runtime_expr* const* aggr_exprs, int32_t n_aggr,
+                                   struct ArrowArrayStream* out, char* err, size_t errlen);
+
+/* ------------------------------------------------------------------------------------------
+ * HBM-resident tables: the in-memory DataSource (src/execution/datasource.rs:27-30 trait
+ * DataSource; relation.rs:34-54 DataSourceRelation).  A table is uploaded (or generated) once
+ * into HBM and can be scanned many times; the scan is a library stream, so operators stacked on
+ * it never leave the device.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct dfx_table dfx_table;
+
+/* Drain `input` (host Arrow batches), copy every column to HBM. Consumes the stream. */
+int32_t dfx_table_from_stream(struct ArrowArrayStream* input, dfx_table** out, char* err,
+                              size_t errlen);
+
+/* Synthetic column generators (deterministic per (seed, column id, global row index); the CPU
+ * oracle reproduces any slice -- SURVEY.md section 8(d)). */
+typedef enum dfx_synth_kind {
+  DFX_SYNTH_F64_UNIFORM = 0, /* p0 + p1 * u,  u in [0,1) 53-bit          (dtype Float64) */
+  DFX_SYNTH_F64_EXACT = 1,   /* m * 2^-10, m uniform integer in [0,2^20)  (dtype Float64) */
+  DFX_SYNTH_I64_UNIFORM = 2, /* uniform integer in [0, (int64)p0)          (dtype Int64)   */
+  DFX_SYNTH_I64_ZIPF = 3     /* floor(p0 ^ u) - 1 clipped to [0,p0): log-uniform skew (dtype Int64) */
+} dfx_synth_kind;
+typedef struct dfx_synth_column {
+  const char* name;
+  int32_t kind;      /* dfx_synth_kind */
+  int32_t column_id; /* stream id mixed into the generator */
+  double p0, p1;
+} dfx_synth_column;
+int32_t dfx_table_synth(const dfx_synth_column* cols, int32_t n_cols, uint64_t seed,
+                        int64_t row_begin, int64_t n_rows, dfx_table** out, char* err,
+                        size_t errlen);
+
+int64_t dfx_table_num_rows(const dfx_table* t);
+int32_t dfx_table_num_columns(const dfx_table* t);
+/* Raw device pointer of a column's values buffer (for torch/RCCL plumbing and debugging). */
+const void* dfx_table_column_device_ptr(const dfx_table* t, int32_t column);
+
+/* DataSourceRelation over a resident table: yields slices of `batch_rows` rows (<=0: one batch).
+ * The table must outlive the stream. */
+int32_t dfx_table_scan_new(const dfx_table* t, int64_t batch_rows, struct ArrowArrayStream* out,
+                           char* err, size_t errlen);
+void dfx_table_free(dfx_table* t);
+
+/* ------------------------------------------------------------------------------------------
+ * Multi-GPU GROUP BY exchange (no reference equivalent: the reference is single-process).
+ * One process per GPU.  After draining its local input, an aggregate stream exports its partial
+ * groups bucketed by hash(key) % world into one contiguous device buffer per payload word; the
+ * host plumbing (torch.distributed / RCCL all-to-all) moves the buckets; the receiving side
+ * imports them and merges.  Then get_next() on the stream emits the groups this rank owns.
+ * ---------------------------------------------------------------------------------------- */
+/* Drain the input and build the local partial table.  Fills n_words = key words + accumulator
+ * words per group, and counts[world] = groups destined to each rank. */
+int32_t dfx_aggregate_partial_build(struct ArrowArrayStream* agg, int32_t world, int32_t* n_words,
+                                    int64_t* counts, char* err, size_t errlen);
+/* Write the bucketed partials: `dst` is a device buffer of n_words * total int64 words laid out
+ * word-major within each destination bucket: for rank r, bucket base = n_words * prefix(r), and
+ * word w of group g of that bucket at base + w * counts[r] + g. */
+int32_t dfx_aggregate_partial_export(struct ArrowArrayStream* agg, void* dst_device, int64_t dst_words,
+                                     char* err, size_t errlen);
+/* Replace the stream's state by the merge of `n_buckets` received buckets (same layout as
+ * export: bucket b holds counts[b] groups starting at word offset n_words * prefix(b)). */
+int32_t dfx_aggregate_partial_import(struct ArrowArrayStream* agg, const void* src_device,
+                                     const int64_t* counts, int32_t n_buckets, char* err,
+                                     size_t errlen);
+
+/* ------------------------------------------------------------------------------------------
+ * Measurement hooks (used by bench.py; not part of the drop-in surface).
+ * ---------------------------------------------------------------------------------------- */
+/* When enabled every tracked kernel launch is bracketed by HIP events on its launch stream. */
+int32_t dfx_profile_enable(int32_t on);
+int32_t dfx_profile_reset(void);
+/* Number of distinct kernels recorded so far; then per index: name, launches, total ms,
+ * algorithmic bytes the launches covered. */
+int32_t dfx_profile_count(void);
+int32_t dfx_profile_get(int32_t index, char* name, size_t namelen, int64_t* launches,
+                        double* total_ms, double* algo_bytes);
+
+/* Tunables (bench/test only).  Known keys: "agg.strategy" (0 auto, 1 global-atomic table,
+ * 2 LDS partial tables, 3 partitioned), "agg.capacity_log2", "batch.rows". */
+int32_t dfx_set_option(const char* key, int64_t value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DFX_H */
