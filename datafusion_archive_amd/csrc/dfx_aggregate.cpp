@@ -1,0 +1,727 @@
+// dfx_aggregate.cpp -- AggregateRelation (src/execution/aggregate.rs) on the device.
+//
+//   without_group_by (aggregate.rs:703-785): per input batch ONE fused kernel (predicate +
+//     argument expressions + per-aggregate reduction, K5) produces the batch scalars, a one-thread
+//     fold kernel applies AccumulatorSet::accumulate_scalar; one row comes back at end of input.
+//   with_group_by (aggregate.rs:787-952): per input batch ONE fused kernel (K7 = predicate + key
+//     and argument expressions + hash aggregation into an HBM-resident open-addressing table with
+//     an LDS front cache); the table grows by rehash when it passes its load limit (rows that do
+//     not fit are spilled and replayed); K8 emits dense arrays at end of input.
+//   A FilterRelation feeding the aggregate (context.rs:126-139,162-192) is absorbed: its predicate
+//   becomes part of the fused program and no filtered batch is ever materialised.
+#include <string.h>
+
+#include <algorithm>
+
+#include "dfx_relation.hpp"
+
+namespace dfx {
+
+AggOptions& agg_options() {
+  static AggOptions o;
+  return o;
+}
+
+namespace {
+int ceil_log2(uint64_t v) {
+  int l = 0;
+  while ((1ull << l) < v && l < 62) ++l;
+  return l;
+}
+}  // namespace
+
+struct AggregateRelation::Impl {
+  std::unique_ptr<Relation> input;
+  bool has_pred = false;
+  dfx_runtime_expr pred;
+  std::vector<dfx_runtime_expr> group, aggr;
+  std::unique_ptr<ProgramBuilder> builder;
+  DevAggPlan plan;
+  Status deferred;
+  bool done = false;
+  bool built = false;
+  int kw = 0, na = 0;
+  std::vector<int> key_dtype, arg_dtype, out_dtype, func;
+  uint8_t acc_kind[kMaxAggs], val_xform[kMaxAggs];
+  uint64_t acc_init[kMaxAggs];
+  // grouped state
+  DevTable T;
+  std::vector<std::shared_ptr<void>> table_owners;
+  std::shared_ptr<void> ctrl;
+  DevRows spill;
+  std::shared_ptr<void> spill_owner;
+  bool lds_enabled = true;
+  bool lds_calibrated = false;
+  int64_t rows_seen = 0;
+  uint64_t occupied_known = 0;
+  // ungrouped state
+  std::shared_ptr<void> partial, state, dev_arg_dtype, dev_func;
+  // export
+  std::vector<uint64_t> export_counts;
+
+  Status setup(const SchemaInfo& input_schema);
+  Status alloc_table(int cap_log2, DevTable* T, std::vector<std::shared_ptr<void>>* owners, bool new_ctrl);
+  Status ensure_spill(int64_t rows);
+  Status grow_and_replay(uint64_t occupied, uint64_t spilled);
+  Status consume_batch(const DeviceBatch& b);
+  Status launch_rows(const DeviceBatch& b, const DevProgram& prog, const DevColumns& cols, int64_t row0, int64_t n);
+  Status drain();
+  Status emit_grouped(DeviceBatch* out);
+  Status emit_ungrouped(DeviceBatch* out);
+  Status read_ctrl(uint32_t* host_ctrl);
+};
+
+// ---- setup ---------------------------------------------------------------------------------------
+Status AggregateRelation::Impl::setup(const SchemaInfo& input_schema) {
+  builder.reset(new ProgramBuilder(input_schema));
+  memset(&plan, 0, sizeof(plan));
+  plan.pred = kNoOperand;
+  kw = (int)group.size();
+  na = (int)aggr.size();
+  if (kw > kMaxKeys) return Status::Err(DFX_NOT_IMPLEMENTED, strfmt("more than %d GROUP BY expressions", kMaxKeys));
+  if (na > kMaxAggs) return Status::Err(DFX_NOT_IMPLEMENTED, strfmt("more than %d aggregate expressions", kMaxAggs));
+  if (has_pred) {
+    int dt = 0;
+    DFX_RETURN_IF_ERROR(builder->add(pred, pred.root, &plan.pred, &dt));
+    if (dt != DFX_BOOLEAN) return Status::Err(DFX_EXECUTION_ERROR, "Filter expression did not evaluate to boolean");
+  }
+  key_dtype.assign(kw, 0);
+  for (int k = 0; k < kw; ++k) {
+    if (group[k].is_aggregate) return Status::Err(DFX_INTERNAL_ERROR, "explicit panic: get_func() on an aggregate expression");
+    int dt = 0;
+    Status st = builder->add(group[k], group[k].root, &plan.key[k], &dt);
+    if (!st.ok()) {
+      const dfx_expr_node& r = group[k].nodes[group[k].root];
+      if (r.kind == DFX_EXPR_COLUMN && input_schema.fields[r.column].dtype == DFX_UTF8)
+        return Status::Err(DFX_NOT_IMPLEMENTED, "GROUP BY on a Utf8 column is not implemented on the device yet");
+      return st;
+    }
+    if (!dtype_is_int(dt))  // aggregate.rs:848-850 (floats and booleans are rejected)
+      return Status::Err(DFX_EXECUTION_ERROR, "Unsupported GROUP BY data type");
+    key_dtype[k] = dt;
+    plan.key_dtype[k] = (uint8_t)dt;
+  }
+  arg_dtype.assign(na, 0);
+  out_dtype.assign(na, 0);
+  func.assign(na, 0);
+  for (int a = 0; a < na; ++a) {
+    const dfx_runtime_expr& e = aggr[a];
+    if (!e.is_aggregate)  // create_accumulators (aggregate.rs:335-337)
+      return Status::Err(DFX_EXECUTION_ERROR, "invalid aggregate expression");
+    int dt = 0;
+    DFX_RETURN_IF_ERROR(builder->add(e, e.agg_arg, &plan.arg[a], &dt));
+    arg_dtype[a] = dt;
+    plan.arg_dtype[a] = (uint8_t)dt;
+    func[a] = e.agg_func;
+    const int t = e.agg_type;
+    if (e.agg_func == AGG_COUNT) {  // deviation D3 (reference: "unsupported aggregate function")
+      out_dtype[a] = DFX_UINT64;
+      acc_kind[a] = ACC_ADD_U64;
+      val_xform[a] = VT_COUNT_VALID;
+      acc_init[a] = 0;
+      continue;
+    }
+    if (!dtype_is_numeric(t)) {  // array_min/max/sum `_ =>` arms (aggregate.rs:406-408 ...)
+      const char* fn = e.agg_func == AGG_MIN ? "MIN" : e.agg_func == AGG_MAX ? "MAX" : "SUM";
+      return Status::Err(DFX_EXECUTION_ERROR, std::string("Unsupported data type for ") + fn);
+    }
+    if (dt != t)  // downcast_ref::<T>().unwrap() by the declared type (aggregate.rs:347, :563)
+      return Status::Err(DFX_INTERNAL_ERROR, strfmt("called `Option::unwrap()` on a `None` value (aggregate argument is %s, declared %s)",
+                                                    dtype_name(dt), dtype_name(t)));
+    out_dtype[a] = t;
+    const bool grouped = kw > 0;
+    if (e.agg_func == AGG_SUM) {
+      val_xform[a] = VT_RAW;
+      if (t == DFX_FLOAT64) {
+        acc_kind[a] = ACC_ADD_F64;
+        // grouped: the first value initialises the accumulator => identity is -0.0 (x + -0.0 == x
+        // bit for bit); ungrouped: array_ops::sum starts from 0.0 (aggregate.rs:480-546)
+        acc_init[a] = grouped ? 0x8000000000000000ull : 0ull;
+      } else if (t == DFX_FLOAT32) {
+        acc_kind[a] = ACC_ADD_F32;
+        acc_init[a] = grouped ? 0x80000000ull : 0ull;
+      } else {
+        acc_kind[a] = ACC_ADD_U64;
+        acc_init[a] = 0;
+      }
+    } else {
+      const bool is_min = e.agg_func == AGG_MIN;
+      if (t == DFX_FLOAT64 || t == DFX_FLOAT32) {
+        val_xform[a] = t == DFX_FLOAT64 ? (is_min ? VT_F64_ORD_MIN : VT_F64_ORD_MAX) : (is_min ? VT_F32_ORD_MIN : VT_F32_ORD_MAX);
+        acc_kind[a] = is_min ? ACC_MIN_U64 : ACC_MAX_U64;
+        acc_init[a] = is_min ? ~0ull : 0ull;
+      } else if (dtype_is_signed(t)) {
+        val_xform[a] = VT_RAW;
+        acc_kind[a] = is_min ? ACC_MIN_S64 : ACC_MAX_S64;
+        acc_init[a] = is_min ? 0x7FFFFFFFFFFFFFFFull : 0x8000000000000000ull;
+      } else {
+        val_xform[a] = VT_RAW;
+        acc_kind[a] = is_min ? ACC_MIN_U64 : ACC_MAX_U64;
+        acc_init[a] = is_min ? ~0ull : 0ull;
+      }
+    }
+  }
+  return Status::OK();
+}
+
+// ---- table management ------------------------------------------------------------------------------
+Status AggregateRelation::Impl::alloc_table(int cap_log2, DevTable* Tn, std::vector<std::shared_ptr<void>>* owners,
+                                            bool new_ctrl) {
+  hipStream_t s = ctx().stream;
+  memset(Tn, 0, sizeof(*Tn));
+  const uint64_t cap = 1ull << cap_log2;
+  Tn->stride = cap + 64;
+  Tn->mask = cap - 1;
+  Tn->shift = 64 - cap_log2;
+  Tn->kw = kw;
+  Tn->na = na;
+  Tn->load_limit = cap / 2;
+  Tn->max_probe = (int)std::min<uint64_t>(cap, 1u << 30);
+  for (int a = 0; a < na; ++a) {
+    Tn->acc_kind[a] = acc_kind[a];
+    Tn->val_xform[a] = val_xform[a];
+    Tn->acc_init[a] = acc_init[a];
+  }
+  Status st;
+  auto keys = device_alloc(sizeof(uint64_t) * Tn->stride * (size_t)std::max(kw, 1), &st);
+  if (!keys) return st;
+  auto accs = device_alloc(sizeof(uint64_t) * Tn->stride * (size_t)std::max(na, 1), &st);
+  if (!accs) return st;
+  Tn->keys = (uint64_t*)keys.get();
+  Tn->accs = (uint64_t*)accs.get();
+  owners->clear();
+  owners->push_back(keys);
+  owners->push_back(accs);
+  if (kw > 1) {
+    auto state = device_alloc(sizeof(uint32_t) * Tn->stride, &st);
+    if (!state) return st;
+    Tn->state = (uint32_t*)state.get();
+    owners->push_back(state);
+    DFX_HIP(hipMemsetAsync(Tn->state, 0, sizeof(uint32_t) * Tn->stride, s));
+  } else {
+    DFX_HIP(launch_fill_u64(Tn->keys, kEmptyKey, (int64_t)Tn->stride, s));
+  }
+  for (int a = 0; a < na; ++a) DFX_HIP(launch_fill_u64(Tn->accs + (size_t)a * Tn->stride, acc_init[a], (int64_t)Tn->stride, s));
+  if (new_ctrl) {
+    ctrl = device_alloc(sizeof(uint32_t) * CTRL_WORDS, &st);
+    if (!ctrl) return st;
+    DFX_HIP(hipMemsetAsync(ctrl.get(), 0, sizeof(uint32_t) * CTRL_WORDS, s));
+  }
+  Tn->ctrl = (uint32_t*)ctrl.get();
+  return Status::OK();
+}
+
+Status AggregateRelation::Impl::ensure_spill(int64_t rows) {
+  if (rows <= 0) {
+    return Status::OK();
+  }
+  if (spill.words && spill.capacity >= (uint64_t)rows) return Status::OK();
+  Status st;
+  spill_owner = device_alloc(sizeof(uint64_t) * (size_t)rows * (size_t)(kw + na), &st);
+  if (!spill_owner) return st;
+  spill.words = (uint64_t*)spill_owner.get();
+  spill.capacity = (uint64_t)rows;
+  return Status::OK();
+}
+
+Status AggregateRelation::Impl::read_ctrl(uint32_t* host_ctrl) {
+  hipStream_t s = ctx().stream;
+  DFX_HIP(hipMemcpyAsync(host_ctrl, ctrl.get(), sizeof(uint32_t) * CTRL_WORDS, hipMemcpyDeviceToHost, s));
+  DFX_HIP(hipStreamSynchronize(s));
+  return Status::OK();
+}
+
+// The table passed its load limit (or a probe sequence was exhausted): build a table at least 4x
+// larger, rehash, then replay the spilled rows into it.  Afterwards occupancy <= 1/4.
+Status AggregateRelation::Impl::grow_and_replay(uint64_t occupied, uint64_t spilled) {
+  hipStream_t s = ctx().stream;
+  if (spilled > spill.capacity)
+    return Status::Err(DFX_INTERNAL_ERROR, strfmt("group spill list overflow (%llu rows > capacity %llu)",
+                                                  (unsigned long long)spilled, (unsigned long long)spill.capacity));
+  const int cur_log2 = 64 - T.shift;
+  const int need_log2 = ceil_log2(4 * (occupied + spilled + 1));
+  const int new_log2 = std::max(cur_log2 + 2, need_log2);
+  if (new_log2 > 34) return Status::Err(DFX_EXECUTION_ERROR, "GROUP BY table would exceed 2^34 slots");
+  DevTable Tn;
+  std::vector<std::shared_ptr<void>> owners;
+  DFX_RETURN_IF_ERROR(alloc_table(new_log2, &Tn, &owners, false));
+  // reset the shared control words that describe the (new) table
+  uint32_t zeros[CTRL_WORDS];
+  memset(zeros, 0, sizeof(zeros));
+  uint32_t host_ctrl[CTRL_WORDS];
+  DFX_RETURN_IF_ERROR(read_ctrl(host_ctrl));
+  host_ctrl[CTRL_OCCUPIED] = 0;
+  host_ctrl[CTRL_SPILL_LO] = host_ctrl[CTRL_SPILL_HI] = 0;
+  host_ctrl[CTRL_SENTINEL] = 0;
+  host_ctrl[CTRL_SATURATED] = 0;
+  const uint32_t had_sentinel = 0;  // rehash re-raises it when it meets the sentinel slot
+  (void)had_sentinel;
+  DevRows no_spill;
+  no_spill.words = nullptr;
+  no_spill.capacity = 0;
+  // `from` still needs the old CTRL_SENTINEL to know whether slot `cap` is occupied: give the old
+  // table a private copy of the control block for the duration of the rehash
+  Status st;
+  auto old_ctrl = device_alloc(sizeof(uint32_t) * CTRL_WORDS, &st);
+  if (!old_ctrl) return st;
+  DFX_HIP(hipMemcpyAsync(old_ctrl.get(), ctrl.get(), sizeof(uint32_t) * CTRL_WORDS, hipMemcpyDeviceToDevice, s));
+  DFX_HIP(hipMemcpyAsync(ctrl.get(), host_ctrl, sizeof(uint32_t) * CTRL_WORDS, hipMemcpyHostToDevice, s));
+  DFX_HIP(hipStreamSynchronize(s));  // host_ctrl is a stack buffer
+  DevTable Told = T;
+  Told.ctrl = (uint32_t*)old_ctrl.get();
+  DFX_HIP(launch_rehash(Told, Tn, no_spill, s));
+  if (spilled > 0) DFX_HIP(launch_merge_rows(spill, 0, (int64_t)spilled, Tn, no_spill, s));
+  T = Tn;
+  table_owners = owners;  // old buffers return to the pool once the stream has passed them
+  DFX_HIP(hipStreamSynchronize(s));
+  return Status::OK();
+}
+
+Status AggregateRelation::Impl::launch_rows(const DeviceBatch& b, const DevProgram& prog_in, const DevColumns& cols_in,
+                                            int64_t row0, int64_t n) {
+  hipStream_t s = ctx().stream;
+  DevProgram prog = prog_in;
+  DevColumns cols = cols_in;
+  double bytes = 0;
+  for (int i = 0; i < prog.n_cols; ++i) {  // advance the bound columns to row0 (row0 is a multiple of 64)
+    const int w = prog.col_dtype[i] == T_BOOL ? 0 : dtype_width(prog.col_dtype[i]);
+    if (w) cols.c[i].values = (const uint8_t*)cols.c[i].values + (size_t)row0 * w;
+    else cols.c[i].bit_offset += row0;
+    if (cols.c[i].validity && w) cols.c[i].bit_offset += row0;
+    bytes += (double)n * (w ? w : 0.125);
+  }
+  DevAggPlan p = plan;
+  if (lds_enabled && agg_options().strategy != 1) {
+    const AggOptions& o = agg_options();
+    int slots = o.lds_slots >= 0 ? o.lds_slots : 4096;
+    while (slots > 64 && (size_t)slots * (size_t)(kw + na) * 8 > 64 * 1024) slots >>= 1;
+    int copies = o.lds_copies > 0 ? o.lds_copies : 1;
+    if (o.lds_copies <= 0 && lds_calibrated) {  // few groups: lane-replicated sub-tables
+      if (occupied_known <= 16) copies = 16;
+      else if (occupied_known <= 128) copies = 4;
+    }
+    while (copies > 1 && slots / copies < 64) copies >>= 1;
+    p.lds_slots = slots;
+    p.lds_copies = copies;
+  } else {
+    p.lds_slots = 0;
+    p.lds_copies = 1;
+  }
+  DFX_HIP(launch_hash_agg(prog, cols, p, T, spill, n, bytes, s));
+  (void)b;
+  return Status::OK();
+}
+
+Status AggregateRelation::Impl::consume_batch(const DeviceBatch& b) {
+  const int64_t n = b.num_rows;
+  if (n == 0 && kw > 0) return Status::OK();  // (ungrouped: an empty batch still folds Some(0) into COUNT)
+  hipStream_t s = ctx().stream;
+  DevProgram prog;
+  DevColumns cols;
+  DFX_RETURN_IF_ERROR(builder->bind(b, &prog, &cols));
+  if (kw == 0) {
+    double bytes = 0;
+    for (int i = 0; i < prog.n_cols; ++i) bytes += (double)n * (prog.col_dtype[i] == T_BOOL ? 0.125 : dtype_width(prog.col_dtype[i]));
+    DFX_HIP(launch_reduce(prog, cols, plan, T, n, (uint64_t*)partial.get(), (uint32_t*)ctrl.get(), bytes, s));
+    DFX_HIP(launch_reduce_fold(T, (const uint8_t*)dev_arg_dtype.get(), (const uint8_t*)dev_func.get(),
+                               (uint64_t*)partial.get(), (uint64_t*)state.get(), s));
+    rows_seen += n;
+    return Status::OK();
+  }
+  // grouped: can this batch overflow the table in the worst case (every row a new group)?
+  const bool may_spill = occupied_known + (uint64_t)n > T.load_limit;
+  if (may_spill) DFX_RETURN_IF_ERROR(ensure_spill(n + 65536));
+  T.max_probe = may_spill ? 128 : (int)std::min<uint64_t>(T.mask + 1, 1u << 30);
+  int64_t row0 = 0;
+  const AggOptions& o = agg_options();
+  if (!lds_calibrated && o.strategy == 0 && n > (1 << 21)) {
+    // calibration slice: measure the LDS front-cache hit rate and the group count on the first
+    // 2^20 rows before committing the rest of the stream to a strategy
+    const int64_t n0 = 1 << 20;
+    DFX_RETURN_IF_ERROR(launch_rows(b, prog, cols, 0, n0));
+    uint32_t hc[CTRL_WORDS];
+    DFX_RETURN_IF_ERROR(read_ctrl(hc));
+    const double hit = hc[CTRL_LDS_HIT], miss = hc[CTRL_LDS_MISS];
+    lds_enabled = (hit + miss == 0) || (hit / (hit + miss) >= 0.5);
+    occupied_known = hc[CTRL_OCCUPIED];
+    lds_calibrated = true;
+    row0 = n0;
+  } else if (!lds_calibrated) {
+    if (o.strategy == 1) lds_enabled = false;
+  }
+  DFX_RETURN_IF_ERROR(launch_rows(b, prog, cols, row0, n - row0));
+  uint32_t hc[CTRL_WORDS];
+  DFX_RETURN_IF_ERROR(read_ctrl(hc));
+  if (hc[CTRL_ERROR]) return error_from_ctrl(hc[CTRL_ERROR]);
+  occupied_known = hc[CTRL_OCCUPIED];
+  const uint64_t spilled = ((uint64_t)hc[CTRL_SPILL_HI] << 32) | hc[CTRL_SPILL_LO];
+  if (!lds_calibrated) {
+    const double hit = hc[CTRL_LDS_HIT], miss = hc[CTRL_LDS_MISS];
+    if (o.strategy == 0 && hit + miss > 4096) lds_enabled = hit / (hit + miss) >= 0.5;
+    lds_calibrated = true;
+  }
+  if (spilled > 0 || hc[CTRL_SATURATED] || occupied_known > T.load_limit) {
+    DFX_RETURN_IF_ERROR(grow_and_replay(occupied_known, spilled));
+    DFX_RETURN_IF_ERROR(read_ctrl(hc));
+    occupied_known = hc[CTRL_OCCUPIED];
+  }
+  rows_seen += n;
+  return Status::OK();
+}
+
+Status AggregateRelation::Impl::drain() {
+  if (built) return Status::OK();
+  DFX_RETURN_IF_ERROR(ensure_init());
+  hipStream_t s = ctx().stream;
+  Status st;
+  if (kw == 0) {
+    memset(&T, 0, sizeof(T));
+    T.na = na;
+    for (int a = 0; a < na; ++a) {
+      T.acc_kind[a] = acc_kind[a];
+      T.val_xform[a] = val_xform[a];
+      T.acc_init[a] = acc_init[a];
+    }
+    partial = device_alloc(sizeof(uint64_t) * 4 * kMaxAggs, &st);
+    if (!partial) return st;
+    state = device_alloc(sizeof(uint64_t) * 2 * kMaxAggs, &st);
+    if (!state) return st;
+    ctrl = device_alloc(sizeof(uint32_t) * CTRL_WORDS, &st);
+    if (!ctrl) return st;
+    dev_arg_dtype = device_alloc(kMaxAggs, &st);
+    if (!dev_arg_dtype) return st;
+    dev_func = device_alloc(kMaxAggs, &st);
+    if (!dev_func) return st;
+    uint64_t hp[4 * kMaxAggs];
+    uint8_t hd[kMaxAggs], hf[kMaxAggs];
+    memset(hp, 0, sizeof(hp));
+    memset(hd, 0, sizeof(hd));
+    memset(hf, 0, sizeof(hf));
+    for (int a = 0; a < na; ++a) {
+      hp[4 * a] = acc_init[a];
+      hp[4 * a + 2] = ~0ull;
+      hd[a] = (uint8_t)arg_dtype[a];
+      hf[a] = (uint8_t)func[a];
+    }
+    DFX_HIP(hipMemcpyAsync(partial.get(), hp, sizeof(hp), hipMemcpyHostToDevice, s));
+    DFX_HIP(hipMemcpyAsync(dev_arg_dtype.get(), hd, sizeof(hd), hipMemcpyHostToDevice, s));
+    DFX_HIP(hipMemcpyAsync(dev_func.get(), hf, sizeof(hf), hipMemcpyHostToDevice, s));
+    DFX_HIP(hipMemsetAsync(state.get(), 0, sizeof(uint64_t) * 2 * kMaxAggs, s));
+    DFX_HIP(hipMemsetAsync(ctrl.get(), 0, sizeof(uint32_t) * CTRL_WORDS, s));
+    DFX_HIP(hipStreamSynchronize(s));
+  } else {
+    int cap_log2 = agg_options().capacity_log2 > 0 ? agg_options().capacity_log2 : 22;
+    cap_log2 = std::max(6, std::min(cap_log2, 34));
+    DFX_RETURN_IF_ERROR(alloc_table(cap_log2, &T, &table_owners, true));
+    spill.words = nullptr;
+    spill.capacity = 0;
+  }
+  for (;;) {
+    DeviceBatch b;
+    bool has = false;
+    DFX_RETURN_IF_ERROR(input->next(&b, &has));
+    if (!has) break;
+    DFX_RETURN_IF_ERROR(consume_batch(b));
+  }
+  if (kw == 0) {
+    uint32_t hc[CTRL_WORDS];
+    DFX_RETURN_IF_ERROR(read_ctrl(hc));
+    if (hc[CTRL_ERROR]) return error_from_ctrl(hc[CTRL_ERROR]);
+  }
+  built = true;
+  return Status::OK();
+}
+
+// ---- output ------------------------------------------------------------------------------------------
+static Status upload_small(const void* host, size_t bytes, std::shared_ptr<void>* dev) {
+  Status st;
+  *dev = device_alloc(bytes ? bytes : 8, &st);
+  if (!*dev) return st;
+  if (bytes) DFX_HIP(hipMemcpy(dev->get(), host, bytes, hipMemcpyHostToDevice));
+  return Status::OK();
+}
+
+Status AggregateRelation::Impl::emit_ungrouped(DeviceBatch* out) {  // aggregate.rs:745-784
+  uint64_t hs[2 * kMaxAggs];
+  DFX_HIP(hipMemcpy(hs, state.get(), sizeof(hs), hipMemcpyDeviceToHost));
+  out->num_rows = 1;
+  out->columns.clear();
+  out->columns.resize(na);
+  for (int a = 0; a < na; ++a) {
+    DeviceColumn& c = out->columns[a];
+    c.dtype = out_dtype[a];
+    c.length = 1;
+    uint64_t bits = hs[2 * a + 1];
+    uint8_t raw[8];
+    memcpy(raw, &bits, 8);  // little endian: the low bytes are the narrow value
+    std::shared_ptr<void> dv, dn;
+    DFX_RETURN_IF_ERROR(upload_small(raw, 8, &dv));
+    c.values = dv.get();
+    c.owners.push_back(dv);
+    const bool has = hs[2 * a] != 0;
+    uint8_t vb[8] = {(uint8_t)(has ? 1 : 0), 0, 0, 0, 0, 0, 0, 0};
+    DFX_RETURN_IF_ERROR(upload_small(vb, 8, &dn));
+    c.validity = (const uint8_t*)dn.get();
+    c.null_count = has ? 0 : 1;
+    if (!has) c.null_count = 1;
+    else c.validity = nullptr;
+    c.owners.push_back(dn);
+  }
+  return Status::OK();
+}
+
+Status AggregateRelation::Impl::emit_grouped(DeviceBatch* out) {  // aggregate.rs:877-951
+  hipStream_t s = ctx().stream;
+  const int64_t n_slots = (int64_t)T.mask + 2;
+  const int64_t n_words = (n_slots + 63) / 64;
+  const int64_t n_tiles = (n_slots + kTileRows - 1) / kTileRows;
+  Status st;
+  auto mask = device_alloc(sizeof(uint64_t) * (size_t)n_words, &st);
+  if (!mask) return st;
+  auto counts = device_alloc(sizeof(uint32_t) * (size_t)n_tiles, &st);
+  if (!counts) return st;
+  auto offsets = device_alloc(sizeof(uint64_t) * (size_t)(n_tiles + 1), &st);
+  if (!offsets) return st;
+  auto tmp = device_alloc(sizeof(uint64_t) * (size_t)(n_tiles / 4096 + 4), &st);
+  if (!tmp) return st;
+  DFX_HIP(launch_table_mask(T, (uint64_t*)mask.get(), (uint32_t*)counts.get(), s));
+  DFX_HIP(launch_scan_u32((const uint32_t*)counts.get(), (uint64_t*)offsets.get(), n_tiles, (uint64_t*)tmp.get(), s));
+  uint64_t total = 0;
+  DFX_HIP(hipMemcpyAsync(&total, (uint64_t*)offsets.get() + n_tiles, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+  DFX_HIP(hipStreamSynchronize(s));
+  const int64_t g = (int64_t)total;
+  out->num_rows = g;
+  out->columns.clear();
+  out->columns.resize(kw + na);
+  auto dense = device_alloc(sizeof(uint64_t) * (size_t)std::max<int64_t>(g, 1), &st);
+  if (!dense) return st;
+  // the sentinel group's key word is not stored in the table: patch slot `cap` before compaction
+  if (kw == 1) DFX_HIP(launch_fill_u64(T.keys + T.mask + 1, kEmptyKey, 1, s));
+  for (int k = 0; k < kw + na; ++k) {
+    const bool is_key = k < kw;
+    const uint64_t* plane = is_key ? T.keys + (size_t)k * T.stride : T.accs + (size_t)(k - kw) * T.stride;
+    const int dt = is_key ? key_dtype[k] : out_dtype[k - kw];
+    DeviceColumn& c = out->columns[k];
+    c.dtype = dt;
+    c.length = g;
+    auto vals = device_alloc((size_t)std::max<int64_t>(g, 1) * dtype_width(dt), &st);
+    if (!vals) return st;
+    DFX_HIP(launch_compact(plane, 8, (const uint64_t*)mask.get(), (const uint64_t*)offsets.get(), n_slots, dense.get(), 0, s));
+    DFX_HIP(launch_finalize((const uint64_t*)dense.get(), g, (uint8_t)dt, is_key ? (uint8_t)VT_RAW : val_xform[k - kw], vals.get(), s));
+    c.values = vals.get();
+    c.owners.push_back(vals);
+  }
+  DFX_HIP(hipStreamSynchronize(s));
+  return Status::OK();
+}
+
+// ---- public class -----------------------------------------------------------------------------------
+AggregateRelation::AggregateRelation(SchemaInfo schema, std::unique_ptr<Relation> input,
+                                     std::vector<dfx_runtime_expr> group, std::vector<dfx_runtime_expr> aggr)
+    : schema_(std::move(schema)), impl_(new Impl()) {
+  Impl& m = *impl_;
+  m.group = std::move(group);
+  m.aggr = std::move(aggr);
+  // Filter -> Aggregate fusion (K7)
+  if (input->kind() == REL_FILTER) {
+    FilterRelation* f = static_cast<FilterRelation*>(input.get());
+    if (!f->predicate().is_aggregate) {
+      m.has_pred = true;
+      m.pred = f->predicate();
+      std::unique_ptr<Relation> inner = f->release_input();
+      input = std::move(inner);
+    }
+  }
+  m.input = std::move(input);
+  m.deferred = m.setup(m.input->schema());
+  // output schema: group columns then aggregates (aggregate.rs:894-949); context.rs:185 passes
+  // Schema::empty(), so derive names/types from the expressions when none is given
+  SchemaInfo derived;
+  for (size_t k = 0; k < m.group.size(); ++k) {
+    Field f;
+    f.name = m.group[k].name;
+    f.dtype = k < m.key_dtype.size() && m.key_dtype[k] ? m.key_dtype[k] : m.group[k].dtype;
+    f.nullable = false;
+    derived.fields.push_back(f);
+  }
+  for (size_t a = 0; a < m.aggr.size(); ++a) {
+    Field f;
+    f.name = m.aggr[a].name;
+    f.dtype = a < m.out_dtype.size() && m.out_dtype[a] ? m.out_dtype[a] : m.aggr[a].dtype;
+    f.nullable = true;
+    derived.fields.push_back(f);
+  }
+  if (schema_.fields.size() == derived.fields.size()) {
+    for (size_t i = 0; i < derived.fields.size(); ++i) {
+      derived.fields[i].name = schema_.fields[i].name;
+    }
+  }
+  schema_ = derived;
+}
+
+AggregateRelation::~AggregateRelation() {}
+
+Status AggregateRelation::next(DeviceBatch* out, bool* has) {
+  *has = false;
+  Impl& m = *impl_;
+  if (m.done) return Status::OK();  // end_of_results (aggregate.rs:616-618)
+  m.done = true;
+  if (!m.deferred.ok()) return m.deferred;
+  if (m.group.empty() && m.aggr.empty())
+    return Status::Err(DFX_INTERNAL_ERROR, "assertion failed: record batch needs at least one column");
+  DFX_RETURN_IF_ERROR(m.drain());
+  if (m.kw == 0) DFX_RETURN_IF_ERROR(m.emit_ungrouped(out));
+  else DFX_RETURN_IF_ERROR(m.emit_grouped(out));
+  *has = true;
+  return Status::OK();
+}
+
+// ---- multi-GPU partial exchange ---------------------------------------------------------------------
+Status AggregateRelation::partial_build(int world, int* n_words, int64_t* counts) {
+  Impl& m = *impl_;
+  if (!m.deferred.ok()) return m.deferred;
+  if (m.kw == 0) return Status::Err(DFX_NOT_IMPLEMENTED, "partial exchange is for GROUP BY aggregates");
+  if (world < 1) return Status::Err(DFX_GENERAL, "world must be >= 1");
+  DFX_RETURN_IF_ERROR(m.drain());
+  hipStream_t s = ctx().stream;
+  Status st;
+  auto dc = device_alloc(sizeof(uint64_t) * (size_t)world, &st);
+  if (!dc) return st;
+  DFX_HIP(hipMemsetAsync(dc.get(), 0, sizeof(uint64_t) * (size_t)world, s));
+  DFX_HIP(launch_partial_count(m.T, world, (uint64_t*)dc.get(), s));
+  m.export_counts.assign((size_t)world, 0);
+  DFX_HIP(hipMemcpyAsync(m.export_counts.data(), dc.get(), sizeof(uint64_t) * (size_t)world, hipMemcpyDeviceToHost, s));
+  DFX_HIP(hipStreamSynchronize(s));
+  for (int r = 0; r < world; ++r) counts[r] = (int64_t)m.export_counts[r];
+  *n_words = m.kw + m.na;
+  return Status::OK();
+}
+
+Status AggregateRelation::partial_export(void* dst_device, int64_t dst_words) {
+  Impl& m = *impl_;
+  if (m.export_counts.empty()) return Status::Err(DFX_GENERAL, "partial_build must precede partial_export");
+  const int world = (int)m.export_counts.size();
+  std::vector<uint64_t> base((size_t)world, 0);
+  uint64_t total = 0;
+  for (int r = 0; r < world; ++r) {
+    base[r] = total;
+    total += m.export_counts[r];
+  }
+  if ((uint64_t)dst_words < total * (uint64_t)(m.kw + m.na))
+    return Status::Err(DFX_GENERAL, "partial export buffer too small");
+  hipStream_t s = ctx().stream;
+  Status st;
+  auto dbase = device_alloc(sizeof(uint64_t) * (size_t)world * 3, &st);
+  if (!dbase) return st;
+  uint64_t* d = (uint64_t*)dbase.get();
+  DFX_HIP(hipMemcpyAsync(d, base.data(), sizeof(uint64_t) * (size_t)world, hipMemcpyHostToDevice, s));
+  DFX_HIP(hipMemcpyAsync(d + world, m.export_counts.data(), sizeof(uint64_t) * (size_t)world, hipMemcpyHostToDevice, s));
+  DFX_HIP(hipMemsetAsync(d + 2 * world, 0, sizeof(uint64_t) * (size_t)world, s));
+  if (m.kw == 1) DFX_HIP(launch_fill_u64(m.T.keys + m.T.mask + 1, kEmptyKey, 1, s));
+  DFX_HIP(launch_partial_scatter(m.T, world, d, d + world, d + 2 * world, (uint64_t*)dst_device, s));
+  DFX_HIP(hipStreamSynchronize(s));
+  return Status::OK();
+}
+
+Status AggregateRelation::partial_import(const void* src_device, const int64_t* counts, int n_buckets) {
+  Impl& m = *impl_;
+  if (!m.built) return Status::Err(DFX_GENERAL, "partial_build must precede partial_import");
+  hipStream_t s = ctx().stream;
+  uint64_t total = 0;
+  for (int b = 0; b < n_buckets; ++b) total += (uint64_t)counts[b];
+  const int cap_log2 = std::max(10, ceil_log2(4 * (total + 1)));
+  DevTable Tn;
+  std::vector<std::shared_ptr<void>> owners;
+  DFX_RETURN_IF_ERROR(m.alloc_table(cap_log2, &Tn, &owners, true));
+  DevRows no_spill;
+  no_spill.words = nullptr;
+  no_spill.capacity = 0;
+  const int nw = m.kw + m.na;
+  uint64_t off = 0;
+  for (int b = 0; b < n_buckets; ++b) {
+    if (counts[b] > 0)
+      DFX_HIP(launch_merge_bucket((const uint64_t*)src_device + (size_t)nw * off, (uint64_t)counts[b], Tn, no_spill, s));
+    off += (uint64_t)counts[b];
+  }
+  DFX_HIP(hipStreamSynchronize(s));
+  m.T = Tn;
+  m.table_owners = owners;
+  m.export_counts.clear();
+  uint32_t hc[CTRL_WORDS];
+  DFX_RETURN_IF_ERROR(m.read_ctrl(hc));
+  m.occupied_known = hc[CTRL_OCCUPIED];
+  return Status::OK();
+}
+
+}  // namespace dfx
+
+using namespace dfx;
+
+extern "C" {
+
+int32_t dfx_aggregate_relation_new(const struct ArrowSchema* schema, struct ArrowArrayStream* input,
+                                   const dfx_runtime_expr* const* group_exprs, int32_t n_group,
+                                   const dfx_runtime_expr* const* aggr_exprs, int32_t n_aggr,
+                                   struct ArrowArrayStream* out, char* err, size_t errlen) {
+  try {
+    if (!out) return to_c(Status::Err(DFX_GENERAL, "null argument"), err, errlen);
+    std::unique_ptr<Relation> in;
+    Status st = adopt_input_stream(input, &in);
+    if (!st.ok()) return to_c(st, err, errlen);
+    SchemaInfo si;
+    st = schema_from_arrow(schema, &si);
+    if (!st.ok()) return to_c(st, err, errlen);
+    std::vector<dfx_runtime_expr> g, a;
+    for (int i = 0; i < n_group; ++i) g.push_back(*group_exprs[i]);
+    for (int i = 0; i < n_aggr; ++i) a.push_back(*aggr_exprs[i]);
+    std::unique_ptr<Relation> rel(new AggregateRelation(si, std::move(in), std::move(g), std::move(a)));
+    export_relation(std::move(rel), out);
+    return DFX_OK;
+  } catch (const std::exception& e) {
+    return to_c(Status::Err(DFX_INTERNAL_ERROR, e.what()), err, errlen);
+  }
+}
+
+static AggregateRelation* as_aggregate(struct ArrowArrayStream* s) {
+  Relation* r = peek_exported(s);
+  if (!r || r->kind() != REL_AGGREGATE) return nullptr;
+  return static_cast<AggregateRelation*>(r);
+}
+
+int32_t dfx_aggregate_partial_build(struct ArrowArrayStream* agg, int32_t world, int32_t* n_words, int64_t* counts,
+                                    char* err, size_t errlen) {
+  try {
+    AggregateRelation* a = as_aggregate(agg);
+    if (!a) return to_c(Status::Err(DFX_GENERAL, "not an aggregate stream of this library"), err, errlen);
+    int nw = 0;
+    Status st = a->partial_build(world, &nw, counts);
+    if (n_words) *n_words = nw;
+    return to_c(st, err, errlen);
+  } catch (const std::exception& e) {
+    return to_c(Status::Err(DFX_INTERNAL_ERROR, e.what()), err, errlen);
+  }
+}
+
+int32_t dfx_aggregate_partial_export(struct ArrowArrayStream* agg, void* dst_device, int64_t dst_words, char* err,
+                                     size_t errlen) {
+  try {
+    AggregateRelation* a = as_aggregate(agg);
+    if (!a) return to_c(Status::Err(DFX_GENERAL, "not an aggregate stream of this library"), err, errlen);
+    return to_c(a->partial_export(dst_device, dst_words), err, errlen);
+  } catch (const std::exception& e) {
+    return to_c(Status::Err(DFX_INTERNAL_ERROR, e.what()), err, errlen);
+  }
+}
+
+int32_t dfx_aggregate_partial_import(struct ArrowArrayStream* agg, const void* src_device, const int64_t* counts,
+                                     int32_t n_buckets, char* err, size_t errlen) {
+  try {
+    AggregateRelation* a = as_aggregate(agg);
+    if (!a) return to_c(Status::Err(DFX_GENERAL, "not an aggregate stream of this library"), err, errlen);
+    return to_c(a->partial_import(src_device, counts, n_buckets), err, errlen);
+  } catch (const std::exception& e) {
+    return to_c(Status::Err(DFX_INTERNAL_ERROR, e.what()), err, errlen);
+  }
+}
+
+}  // extern "C"

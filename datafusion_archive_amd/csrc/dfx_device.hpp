@@ -1,0 +1,144 @@
+// dfx_device.hpp -- structs shared by host code and gfx950 kernels.
+//
+// The RecordBatch expression evaluator of the reference (src/execution/expression.rs) composes
+// Rust closures, one full materialised array per node.  Here an expression forest (predicate +
+// group keys + aggregate arguments, or projection outputs) is compiled ONCE, at operator
+// creation, into a tiny SSA register program that one fused kernel interprets per row with all
+// intermediates in VGPRs (register files are ext_vector_type values indexed by wave-uniform
+// indices -> s_set_gpr_idx, no scratch).  Literals never become arrays: they live in the kernarg
+// segment and are read with scalar loads.
+#pragma once
+#include <stdint.h>
+
+namespace dfx {
+
+constexpr int kMaxRegs = 16;  // computed values per fused program
+constexpr int kMaxCols = 8;   // distinct input columns per fused program
+constexpr int kMaxImm = 16;   // distinct literals per fused program
+constexpr int kMaxKeys = 4;   // GROUP BY key words
+constexpr int kMaxAggs = 8;   // aggregates per AggregateRelation
+constexpr int kMaxOut = 8;    // projection outputs per launch
+
+// dtype codes == dfx_dtype (include/dfx.h)
+enum : uint8_t {
+  T_NONE = 0, T_BOOL = 1, T_I8 = 2, T_I16 = 3, T_I32 = 4, T_I64 = 5, T_U8 = 6, T_U16 = 7,
+  T_U32 = 8, T_U64 = 9, T_F32 = 10, T_F64 = 11, T_UTF8 = 12
+};
+
+// operand = (kind << 6) | index
+enum : uint8_t { OPK_REG = 0, OPK_COL = 1, OPK_IMM = 2, OPK_NONE = 3 };
+constexpr uint8_t kNoOperand = 0xFF;
+inline constexpr uint8_t make_operand(int kind, int idx) { return (uint8_t)((kind << 6) | (idx & 63)); }
+
+enum : uint8_t {
+  DOP_EQ = 0, DOP_NE = 1, DOP_LT = 2, DOP_LE = 3, DOP_GT = 4, DOP_GE = 5,  // == dfx_operator 0..5
+  DOP_AND = 6, DOP_OR = 7, DOP_ADD = 8, DOP_SUB = 9, DOP_MUL = 10, DOP_DIV = 11, DOP_CAST = 12
+};
+
+struct DevIns {
+  uint8_t op;  // DOP_*
+  uint8_t t;   // operand dtype (CAST: source dtype)
+  uint8_t a;   // operand
+  uint8_t b;   // operand (CAST: target dtype, raw)
+};
+
+struct DevProgram {
+  int32_t n_ins;
+  int32_t n_cols;
+  int32_t n_imm;
+  int32_t has_nulls;  // any referenced column carries a validity bitmap in this batch
+  DevIns ins[kMaxRegs];
+  uint64_t imm[kMaxImm];
+  uint8_t col_dtype[kMaxCols];
+};
+
+struct DevColumn {
+  const void* values;       // element 0 of the (offset-adjusted) values buffer; Boolean: bitmap base
+  const uint8_t* validity;  // bitmap base or nullptr
+  int64_t bit_offset;       // arrow `offset`: applies to validity bits and Boolean value bits
+};
+
+struct DevColumns {
+  DevColumn c[kMaxCols];
+};
+
+// ---- aggregation ----------------------------------------------------------------------------
+// Every accumulator is one 64-bit word updated with ONE hardware atomic per row.
+enum : uint8_t {
+  ACC_ADD_F64 = 0,  // SUM(f64): global_atomic_add_f64 / ds_add_f64
+  ACC_ADD_F32 = 1,  // SUM(f32): f32 add on the low dword
+  ACC_ADD_U64 = 2,  // SUM(int*) wrapping, COUNT
+  ACC_MIN_S64 = 3,
+  ACC_MAX_S64 = 4,
+  ACC_MIN_U64 = 5,  // also MIN(f32/f64) on the order-preserving integer image
+  ACC_MAX_U64 = 6   // also MAX(f32/f64)
+};
+// how the evaluated argument becomes the accumulator operand
+enum : uint8_t {
+  VT_RAW = 0,           // canonical 64-bit value as is
+  VT_F64_ORD_MIN = 1,   // f64 -> sortable u64, NaN canonicalised ABOVE +inf (f64::min ignores NaN)
+  VT_F64_ORD_MAX = 2,   // f64 -> sortable u64, NaN canonicalised BELOW -inf (f64::max ignores NaN)
+  VT_F32_ORD_MIN = 3,   // f32 widened to f64 (exact), then as above
+  VT_F32_ORD_MAX = 4,
+  VT_COUNT_VALID = 5    // 1 if the argument is valid else 0
+};
+
+constexpr uint64_t kEmptyKey = 0x8000000000000000ull;  // single-word key claim sentinel
+
+// control block words (uint32) of a group table / reduction
+enum : int {
+  CTRL_OCCUPIED = 0,    // groups in the table
+  CTRL_ERROR = 1,       // bit0 DivideByZero, bit1 signed-division overflow
+  CTRL_SPILL_LO = 2,    // spill cursor (64-bit, two words)
+  CTRL_SPILL_HI = 3,
+  CTRL_SENTINEL = 4,    // 1: the key equal to kEmptyKey has been seen (its slot is index cap)
+  CTRL_SATURATED = 5,   // table past its load limit: blocks spill instead of probing
+  CTRL_LDS_HIT = 6,     // rows absorbed by the LDS front cache (sampled statistic)
+  CTRL_LDS_MISS = 7,
+  CTRL_PASSED_LO = 8,   // rows that passed the predicate (64-bit)
+  CTRL_PASSED_HI = 9,
+  CTRL_WORDS = 16
+};
+
+struct DevTable {
+  uint64_t* keys;      // kw planes of `stride` words; plane 0 doubles as the claim word when kw == 1
+  uint64_t* accs;      // na planes of `stride` words, pre-filled with the identity
+  uint32_t* state;     // kw > 1: claim state per slot (0 empty, 1 busy, 2 ready); else nullptr
+  uint32_t* ctrl;      // CTRL_WORDS words
+  uint64_t stride;     // cap + 64 (slot `cap` is reserved for the kEmptyKey group)
+  uint64_t mask;       // cap - 1
+  int32_t shift;       // 64 - log2(cap): slot = hash >> shift
+  int32_t kw;
+  int32_t na;
+  int32_t max_probe;
+  uint64_t load_limit; // occupied above this => saturated
+  uint8_t acc_kind[kMaxAggs];
+  uint8_t val_xform[kMaxAggs];
+  uint64_t acc_init[kMaxAggs];
+};
+
+// spill / partial rows: word-major planes [kw + na][capacity]
+struct DevRows {
+  uint64_t* words;
+  uint64_t capacity;
+};
+
+struct DevAggPlan {
+  uint8_t pred;                // operand or kNoOperand
+  uint8_t key[kMaxKeys];       // operands
+  uint8_t key_dtype[kMaxKeys];
+  uint8_t arg[kMaxAggs];       // operands
+  uint8_t arg_dtype[kMaxAggs];
+  int32_t lds_slots;           // 0: no LDS front cache; else power of two
+  int32_t lds_copies;          // power of two: lane-replicated sub-tables (few-group inputs)
+};
+
+struct DevProjectPlan {
+  int32_t n_out;
+  uint8_t out[kMaxOut];        // operands
+  uint8_t out_dtype[kMaxOut];
+  void* out_values[kMaxOut];
+  uint64_t* out_validity[kMaxOut];  // nullptr: not wanted
+};
+
+}  // namespace dfx

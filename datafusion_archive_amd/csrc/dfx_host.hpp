@@ -1,0 +1,180 @@
+// dfx_host.hpp -- host-side runtime shared by the C-ABI translation units: status type, schema
+// model, device/pinned memory pools, device-resident batches and the internal operator interface.
+//
+// The internal operator tree mirrors the reference's: `struct Relation` below is
+// src/execution/relation.rs:27-32 with RecordBatch replaced by a device-resident batch.  The
+// Arrow C Stream adapters at the library edge (dfx_relation.cpp) convert to / from host Arrow.
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/dfx.h"
+#include "dfx_device.hpp"
+
+namespace dfx {
+
+// ---- status -----------------------------------------------------------------------------------
+struct Status {
+  int32_t code = DFX_OK;
+  std::string msg;
+  bool ok() const { return code == DFX_OK; }
+  static Status OK() { return Status(); }
+  static Status Err(int32_t code, std::string m) {
+    Status s;
+    s.code = code;
+    s.msg = std::move(m);
+    return s;
+  }
+};
+std::string strfmt(const char* fmt, ...);
+int32_t to_c(const Status& s, char* err, size_t errlen);
+
+#define DFX_RETURN_IF_ERROR(expr)   \
+  do {                              \
+    ::dfx::Status _st = (expr);     \
+    if (!_st.ok()) return _st;      \
+  } while (0)
+
+#define DFX_HIP(expr)                                                                          \
+  do {                                                                                         \
+    hipError_t _e = (expr);                                                                    \
+    if (_e != hipSuccess)                                                                      \
+      return ::dfx::Status::Err(DFX_EXECUTION_ERROR,                                           \
+                                ::dfx::strfmt("HIP error %s at %s:%d (%s)", hipGetErrorString(_e), \
+                                              __FILE__, __LINE__, #expr));                     \
+  } while (0)
+
+// ---- types / schema ---------------------------------------------------------------------------
+const char* dtype_name(int dt);  // Rust {:?} of the DataType
+int dtype_width(int dt);         // bytes of a fixed-width value (0: Boolean/Utf8)
+bool dtype_is_numeric(int dt);
+bool dtype_is_int(int dt);
+bool dtype_is_signed(int dt);
+const char* dtype_arrow_format(int dt);
+int dtype_from_arrow_format(const char* fmt);  // DFX_TYPE_NONE if unsupported
+
+struct Field {
+  std::string name;
+  int dtype = DFX_TYPE_NONE;
+  bool nullable = true;
+};
+struct SchemaInfo {
+  std::vector<Field> fields;
+};
+Status schema_from_arrow(const struct ArrowSchema* s, SchemaInfo* out);
+// exports a struct-typed ArrowSchema ("+s") owning all its memory
+void schema_to_arrow(const SchemaInfo& s, struct ArrowSchema* out);
+
+// ---- device context ---------------------------------------------------------------------------
+struct Context {
+  int device = 0;
+  bool initialised = false;
+  hipStream_t stream = nullptr;  // all kernels and copies of this process: one in-order stream
+};
+Context& ctx();
+Status ensure_init();
+
+// pooled device memory (hipMalloc is ~100 us; operators allocate per batch)
+std::shared_ptr<void> device_alloc(size_t bytes, Status* st);
+// pooled pinned host memory for H2D / D2H staging
+std::shared_ptr<void> pinned_alloc(size_t bytes, Status* st);
+void pool_trim();
+
+// ---- device-resident data ---------------------------------------------------------------------
+struct DeviceColumn {
+  int dtype = DFX_TYPE_NONE;
+  int64_t length = 0;
+  int64_t null_count = 0;       // 0: validity may be absent
+  const void* values = nullptr; // fixed width: element 0; Boolean: bitmap base (see bit_offset)
+  const uint8_t* validity = nullptr;
+  int64_t bit_offset = 0;       // for validity and Boolean values
+  const int32_t* offsets = nullptr;  // Utf8: length + 1 entries
+  const uint8_t* data = nullptr;     // Utf8: indexed by the raw offsets
+  int64_t data_bytes = 0;            // Utf8: bytes referenced (offsets[length] - offsets[0])
+  std::vector<std::shared_ptr<void>> owners;  // keeps the buffers alive
+};
+
+struct DeviceBatch {
+  int64_t num_rows = 0;
+  std::vector<DeviceColumn> columns;
+};
+
+enum RelationKind { REL_HOST_STREAM, REL_TABLE_SCAN, REL_FILTER, REL_PROJECT, REL_AGGREGATE };
+
+// trait Relation (src/execution/relation.rs:27-32)
+struct Relation {
+  virtual ~Relation() {}
+  virtual RelationKind kind() const = 0;
+  // Ok(Some(batch)) -> *has = true; Ok(None) -> *has = false
+  virtual Status next(DeviceBatch* out, bool* has) = 0;
+  virtual const SchemaInfo& schema() const = 0;
+};
+
+// ---- expressions (dfx_expr.cpp) ---------------------------------------------------------------
+enum AggregateType { AGG_MIN = 0, AGG_MAX = 1, AGG_SUM = 2, AGG_COUNT = 3 };
+
+}  // namespace dfx
+
+// RuntimeExpr (src/execution/expression.rs:42-54): a validated copy of the Expr tree + name + type.
+struct dfx_runtime_expr {
+  std::vector<dfx_expr_node> nodes;  // own copy (names point into `strings`)
+  std::vector<std::string> strings;
+  std::vector<char> has_name;
+  dfx_runtime_expr() = default;
+  dfx_runtime_expr(const dfx_runtime_expr& o) { *this = o; }
+  dfx_runtime_expr& operator=(const dfx_runtime_expr& o) {
+    if (this == &o) return *this;
+    nodes = o.nodes;
+    strings = o.strings;
+    has_name = o.has_name;
+    root = o.root;
+    name = o.name;
+    dtype = o.dtype;
+    is_aggregate = o.is_aggregate;
+    agg_func = o.agg_func;
+    agg_arg = o.agg_arg;
+    agg_type = o.agg_type;
+    rebind();
+    return *this;
+  }
+  void rebind() {  // node names must point into THIS object's strings
+    for (size_t i = 0; i < nodes.size(); ++i) nodes[i].name = has_name[i] ? strings[i].c_str() : nullptr;
+  }
+  int32_t root = -1;
+  std::string name;
+  int32_t dtype = DFX_TYPE_NONE;  // type of the evaluated array
+  bool is_aggregate = false;
+  int32_t agg_func = -1;   // dfx::AggregateType
+  int32_t agg_arg = -1;    // node index of args[0]
+  int32_t agg_type = DFX_TYPE_NONE;  // declared return_type `t`
+};
+
+namespace dfx {
+
+// Builds ONE fused device program for a set of expression roots over one input schema, with
+// common-subexpression elimination.  Type errors the reference raises at evaluation time
+// (comparison_ops / math_ops / boolean_ops downcasts) are returned by add() as a Status the
+// operator stores and raises on its first next().
+class ProgramBuilder {
+ public:
+  explicit ProgramBuilder(const SchemaInfo& schema);
+  // returns the operand naming the value of node `root` of `e`, and its dtype
+  Status add(const dfx_runtime_expr& e, int32_t root, uint8_t* operand, int* dtype);
+  const DevProgram& program() const { return prog_; }
+  // column slot -> schema column index
+  const std::vector<int>& columns() const { return cols_; }
+  // bind the batch's buffers; sets has_nulls
+  Status bind(const DeviceBatch& batch, DevProgram* prog, DevColumns* cols) const;
+
+ private:
+  Status emit(const dfx_runtime_expr& e, int32_t idx, uint8_t* operand, int* dtype);
+  const SchemaInfo& schema_;
+  DevProgram prog_;
+  std::vector<int> cols_;
+};
+
+}  // namespace dfx

@@ -1,0 +1,116 @@
+// dfx_kernels.hpp -- host-callable launchers of the gfx950 kernels (implemented in dfx_kernels.hip).
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+
+#include "dfx_device.hpp"
+
+namespace dfx {
+
+constexpr int kTileRows = 4096;  // one compaction tile = 64 bitmap words
+constexpr int kBlock = 256;
+
+// kernel ids for the built-in profiler
+enum KernelId : int {
+  KID_PREDICATE_MASK = 0,
+  KID_COMPACT,
+  KID_PROJECT,
+  KID_REDUCE,
+  KID_HASH_AGG,
+  KID_MERGE_ROWS,
+  KID_REHASH,
+  KID_EMIT_MASK,
+  KID_FINALIZE,
+  KID_SCAN,
+  KID_SYNTH,
+  KID_FILL,
+  KID_GATHER_UTF8,
+  KID_PARTIAL,
+  KID_PARTITION,
+  KID_COUNT_
+};
+const char* kernel_name(int kid);
+
+// ---- profiler (HIP events around tracked launches, on the launch stream) --------------------
+void profile_enable(bool on);
+void profile_reset();
+int profile_count();
+bool profile_get(int index, const char** name, int64_t* launches, double* total_ms, double* algo_bytes);
+
+int device_cu_count();
+
+// K1 predicate_mask: fused compare/AND/OR expression -> Arrow LSB bitmap (one __ballot per 64 rows)
+//   replaces comparison_ops!/boolean_ops!/literal_array! closures (expression.rs:171-243, :410-465)
+// tile_counts (may be null): popcount per 4096-row tile, for the compaction offsets.
+hipError_t launch_predicate_mask(const DevProgram& P, const DevColumns& C, uint8_t pred, int64_t n,
+                                 uint64_t* mask_words, uint32_t* tile_counts, uint32_t* ctrl,
+                                 double algo_bytes, hipStream_t s);
+
+// exclusive scan of uint32 counts into uint64 offsets (out[n] = total); tmp: >= (n/4096 + 2) u64
+hipError_t launch_scan_u32(const uint32_t* in, uint64_t* out, int64_t n, uint64_t* tmp, hipStream_t s);
+// exclusive scan of int32 lengths into int32 offsets (out[n] = total); tmp as above
+hipError_t launch_scan_i32(const int32_t* in, int32_t* out, int64_t n, uint64_t* tmp, hipStream_t s);
+
+// K4 compact: order-preserving stream compaction of one fixed-width column by bitmap
+//   replaces fn filter (filter.rs:79-110).  width in {1,2,4,8} bytes.
+hipError_t launch_compact(const void* in, int width, const uint64_t* mask_words,
+                          const uint64_t* tile_offsets, int64_t n, void* out, double algo_bytes,
+                          hipStream_t s);
+// Utf8 support for K4: lengths from offsets, byte gather
+hipError_t launch_utf8_lengths(const int32_t* offsets, int64_t n, int32_t* lengths, int32_t* starts, hipStream_t s);
+hipError_t launch_utf8_gather(const uint8_t* data, const int32_t* src_starts, const int32_t* dst_offsets,
+                              int64_t m, uint8_t* out, hipStream_t s);
+
+// K2/K3 project: fused arithmetic / cast expression outputs (typed values + validity bitmaps)
+//   replaces math_ops!/cast_column! closures (expression.rs:131-169, :246-280, :466-493)
+hipError_t launch_project(const DevProgram& P, const DevColumns& C, const DevProjectPlan& plan,
+                          int64_t n, uint32_t* ctrl, double algo_bytes, hipStream_t s);
+
+// K5 reduce_all: ungrouped aggregates of one batch into per-aggregate batch partials, then the
+// scalar fold (accumulate_scalar) into the running state.
+//   replaces array_min/max/sum + without_group_by (aggregate.rs:344-546, :703-785)
+// partial: na * 4 u64 words {acc, valid_count, first_valid_tag, unused}; state: na * 2 words {has, bits}
+hipError_t launch_reduce(const DevProgram& P, const DevColumns& C, const DevAggPlan& plan,
+                         const DevTable& T /* kinds / xforms / inits only */, int64_t n,
+                         uint64_t* partial, uint32_t* ctrl, double algo_bytes, hipStream_t s);
+hipError_t launch_reduce_fold(const DevTable& T, const uint8_t* arg_dtype, const uint8_t* func,
+                              uint64_t* partial, uint64_t* state, hipStream_t s);
+
+// K6/K7 hash_agg: (optional predicate) + group keys + aggregate arguments -> table updates, with
+// an LDS front cache per workgroup and a spill list for rows the table cannot take.
+//   replaces with_group_by + update_accumulators (aggregate.rs:787-875, :548-612)
+hipError_t launch_hash_agg(const DevProgram& P, const DevColumns& C, const DevAggPlan& plan,
+                           const DevTable& T, const DevRows& spill, int64_t n, double algo_bytes,
+                           hipStream_t s);
+// insert pre-evaluated rows (spill replays, LDS flushes of other ranks, all-to-all imports)
+hipError_t launch_merge_rows(const DevRows& rows, int64_t row_begin, int64_t n_rows, const DevTable& T,
+                             const DevRows& spill, hipStream_t s);
+hipError_t launch_rehash(const DevTable& from, const DevTable& to, const DevRows& spill, hipStream_t s);
+hipError_t launch_fill_u64(uint64_t* p, uint64_t v, int64_t n, hipStream_t s);
+hipError_t launch_fill_u32(uint32_t* p, uint32_t v, int64_t n, hipStream_t s);
+
+// K8 emit_groups: occupancy bitmap of the table (then launch_scan_u32 + launch_compact on each
+// plane), and the typed finalisation of one output column.
+//   replaces the result macros (aggregate.rs:633-699, :877-951)
+hipError_t launch_table_mask(const DevTable& T, uint64_t* mask_words, uint32_t* tile_counts, hipStream_t s);
+// in: dense u64 plane; out: typed column. is_key: narrow only. xform/kind/func describe the agg.
+hipError_t launch_finalize(const uint64_t* in, int64_t n, uint8_t out_dtype, uint8_t val_xform,
+                           void* out, hipStream_t s);
+
+// multi-GPU partial export: count per destination rank, then scatter into bucketed planes
+hipError_t launch_partial_count(const DevTable& T, int world, uint64_t* counts, hipStream_t s);
+hipError_t launch_partial_scatter(const DevTable& T, int world, const uint64_t* bucket_base,
+                                  const uint64_t* bucket_count, uint64_t* cursors, uint64_t* dst,
+                                  hipStream_t s);
+// merge bucketed planes (layout of dfx_aggregate_partial_export) into a table
+hipError_t launch_merge_bucket(const uint64_t* bucket, uint64_t count, const DevTable& T,
+                               const DevRows& spill, hipStream_t s);
+
+// synthetic columns (definition shared with oracle/dfx_oracle.c: orc_synth_fill)
+hipError_t launch_synth(int kind, int column_id, double p0, double p1, uint64_t seed, int64_t row_begin,
+                        int64_t n, void* out, hipStream_t s);
+
+// host mirror of the device hash (rank ownership in tests)
+uint64_t host_hash_keys(const uint64_t* key, int kw);
+
+}  // namespace dfx

@@ -1,0 +1,680 @@
+// dfx_relation.cpp -- Arrow C stream adapters at the library edge, FilterRelation, ProjectRelation
+// and their C-ABI constructors.
+#include "dfx_relation.hpp"
+
+#include <errno.h>
+#include <stdlib.h>
+#include <string.h>
+
+namespace dfx {
+
+Status error_from_ctrl(uint32_t bits) {
+  if (bits & 1u) return Status::Err(DFX_ARROW_ERROR, "DivideByZero");  // arrow 0.12 array_ops::divide
+  if (bits & 2u) return Status::Err(DFX_INTERNAL_ERROR, "attempt to divide with overflow");
+  return Status::OK();
+}
+
+// =================================================================================================
+// host Arrow stream -> device batches
+// =================================================================================================
+namespace {
+
+class HostStreamRelation : public Relation {
+ public:
+  explicit HostStreamRelation(struct ArrowArrayStream* s) {
+    stream_ = *s;  // move
+    memset(s, 0, sizeof(*s));
+  }
+  ~HostStreamRelation() override {
+    if (stream_.release) stream_.release(&stream_);
+  }
+  RelationKind kind() const override { return REL_HOST_STREAM; }
+
+  Status init() {
+    struct ArrowSchema as;
+    memset(&as, 0, sizeof(as));
+    const int rc = stream_.get_schema(&stream_, &as);
+    if (rc != 0) return stream_error(rc, "get_schema");
+    Status st = schema_from_arrow(&as, &schema_);
+    if (as.release) as.release(&as);
+    return st;
+  }
+
+  const SchemaInfo& schema() const override { return schema_; }
+
+  Status next(DeviceBatch* out, bool* has) override {
+    *has = false;
+    DFX_RETURN_IF_ERROR(ensure_init());
+    struct ArrowArray arr;
+    memset(&arr, 0, sizeof(arr));
+    const int rc = stream_.get_next(&stream_, &arr);
+    if (rc != 0) return stream_error(rc, "get_next");
+    if (arr.release == nullptr) return Status::OK();  // end of stream == Ok(None)
+    Status st = upload(arr, out);
+    if (st.ok()) {
+      hipError_t e = hipStreamSynchronize(ctx().stream);  // host buffers are borrowed until here
+      if (e != hipSuccess) st = Status::Err(DFX_EXECUTION_ERROR, strfmt("HIP error %s after H2D", hipGetErrorString(e)));
+    }
+    arr.release(&arr);
+    if (st.ok()) *has = true;
+    return st;
+  }
+
+ private:
+  Status stream_error(int rc, const char* what) {
+    const char* m = stream_.get_last_error ? stream_.get_last_error(&stream_) : nullptr;
+    // our own streams return a dfx_status; foreign producers an errno
+    const int code = (rc > 0 && rc <= DFX_EXECUTION_ERROR) ? rc : DFX_IO_ERROR;
+    return Status::Err(code, m ? std::string(m) : strfmt("input stream %s failed with code %d", what, rc));
+  }
+
+  Status h2d(const void* host, size_t bytes, std::shared_ptr<void>* dev) {
+    Status st;
+    *dev = device_alloc(bytes ? bytes : 8, &st);
+    if (!*dev) return st;
+    if (bytes) DFX_HIP(hipMemcpyAsync(dev->get(), host, bytes, hipMemcpyHostToDevice, ctx().stream));
+    return Status::OK();
+  }
+
+  Status upload(const struct ArrowArray& arr, DeviceBatch* out) {
+    if ((size_t)arr.n_children != schema_.fields.size())
+      return Status::Err(DFX_ARROW_ERROR, strfmt("batch has %lld columns, schema has %zu", (long long)arr.n_children, schema_.fields.size()));
+    out->num_rows = arr.length;
+    out->columns.clear();
+    out->columns.resize(schema_.fields.size());
+    for (size_t ci = 0; ci < schema_.fields.size(); ++ci) {
+      const struct ArrowArray* c = arr.children[ci];
+      const int dt = schema_.fields[ci].dtype;
+      DeviceColumn& d = out->columns[ci];
+      const int64_t off = arr.offset + c->offset;
+      const int64_t n = arr.length;
+      d.dtype = dt;
+      d.length = n;
+      d.bit_offset = off & 7;
+      const uint8_t* validity = (c->n_buffers > 0) ? (const uint8_t*)c->buffers[0] : nullptr;
+      if (validity && c->null_count != 0) {
+        std::shared_ptr<void> dv;
+        const int64_t b0 = off >> 3, b1 = (off + n + 7) >> 3;
+        DFX_RETURN_IF_ERROR(h2d(validity + b0, (size_t)(b1 - b0), &dv));
+        d.validity = (const uint8_t*)dv.get();
+        d.owners.push_back(dv);
+        d.null_count = c->null_count < 0 ? -1 : c->null_count;
+      }
+      if (dt == DFX_UTF8) {
+        if (c->n_buffers < 3) return Status::Err(DFX_ARROW_ERROR, "Utf8 array without 3 buffers");
+        const int32_t* offs = (const int32_t*)c->buffers[1] + off;
+        const uint8_t* data = (const uint8_t*)c->buffers[2];
+        std::shared_ptr<void> doff, ddata;
+        DFX_RETURN_IF_ERROR(h2d(offs, sizeof(int32_t) * (size_t)(n + 1), &doff));
+        const int32_t o0 = offs[0], o1 = offs[n];
+        DFX_RETURN_IF_ERROR(h2d(data ? data + o0 : nullptr, (size_t)(o1 - o0), &ddata));
+        d.offsets = (const int32_t*)doff.get();
+        d.data = (const uint8_t*)ddata.get() - o0;  // raw offsets index straight into it
+        d.data_bytes = o1 - o0;
+        d.owners.push_back(doff);
+        d.owners.push_back(ddata);
+      } else if (dt == DFX_BOOLEAN) {
+        if (c->n_buffers < 2) return Status::Err(DFX_ARROW_ERROR, "Boolean array without 2 buffers");
+        std::shared_ptr<void> dv;
+        const int64_t b0 = off >> 3, b1 = (off + n + 7) >> 3;
+        DFX_RETURN_IF_ERROR(h2d((const uint8_t*)c->buffers[1] + b0, (size_t)(b1 - b0), &dv));
+        d.values = dv.get();
+        d.owners.push_back(dv);
+      } else {
+        if (c->n_buffers < 2) return Status::Err(DFX_ARROW_ERROR, "primitive array without 2 buffers");
+        const int w = dtype_width(dt);
+        std::shared_ptr<void> dv;
+        DFX_RETURN_IF_ERROR(h2d((const uint8_t*)c->buffers[1] + (size_t)off * w, (size_t)n * w, &dv));
+        d.values = dv.get();
+        d.owners.push_back(dv);
+      }
+    }
+    return Status::OK();
+  }
+
+  struct ArrowArrayStream stream_;
+  SchemaInfo schema_;
+};
+
+// =================================================================================================
+// device relation -> host Arrow stream
+// =================================================================================================
+struct ExportedStream {
+  std::unique_ptr<Relation> rel;
+  std::string last_error;
+};
+
+struct ArrayPriv {
+  std::vector<std::shared_ptr<void>> pinned; // large result buffers: pooled pinned memory (fast D2H)
+  std::vector<void*> host_buffers;           // malloc'd, 64-byte aligned
+  std::vector<const void*> buffer_ptrs;      // this array's buffers
+  std::vector<struct ArrowArray> kids;
+  std::vector<struct ArrowArray*> kid_ptrs;
+};
+
+void release_array(struct ArrowArray* a) {
+  if (!a || !a->release) return;
+  ArrayPriv* p = (ArrayPriv*)a->private_data;
+  for (auto& k : p->kids)
+    if (k.release) k.release(&k);
+  for (void* b : p->host_buffers) free(b);
+  delete p;
+  a->release = nullptr;
+}
+
+void* host_alloc(size_t bytes) {
+  void* p = nullptr;
+  const size_t cap = ((bytes ? bytes : 1) + 63) / 64 * 64;  // padded to 64 bytes, tail zeroed
+  if (posix_memalign(&p, 64, cap) != 0) return nullptr;
+  memset((uint8_t*)p + (cap - 64), 0, 64);
+  return p;
+}
+
+// result buffer owned by the exported array: pinned (pooled) when large, so the D2H copy runs at
+// PCIe speed instead of through a pageable staging copy
+void* alloc_result(ArrayPriv* p, size_t bytes) {
+  if (bytes >= (1u << 16)) {
+    Status st;
+    std::shared_ptr<void> b = pinned_alloc(bytes + 64, &st);
+    if (b) {
+      p->pinned.push_back(b);
+      return b.get();
+    }
+  }
+  void* raw = host_alloc(bytes);
+  if (raw) p->host_buffers.push_back(raw);
+  return raw;
+}
+
+// move `n` bits starting at src bit `off` to bit 0 of dst (dst pre-zeroed)
+void realign_bits(const uint8_t* src, int64_t off, int64_t n, uint8_t* dst) {
+  for (int64_t i = 0; i < n; ++i)
+    if ((src[(off + i) >> 3] >> ((off + i) & 7)) & 1) dst[i >> 3] |= (uint8_t)(1u << (i & 7));
+}
+
+Status download_column(const DeviceColumn& c, struct ArrowArray* out, std::vector<std::function<void()>>* fixups) {
+  ArrayPriv* p = new ArrayPriv();
+  memset(out, 0, sizeof(*out));
+  out->private_data = p;
+  out->release = release_array;
+  out->length = c.length;
+  out->offset = 0;
+  const int64_t n = c.length;
+  hipStream_t s = ctx().stream;
+  // validity
+  void* vbuf = nullptr;
+  if (c.validity && c.null_count != 0) {
+    const size_t bytes = (size_t)((c.bit_offset + n + 7) >> 3);
+    void* raw = alloc_result(p, bytes);
+    if (!raw) return Status::Err(DFX_EXECUTION_ERROR, "host allocation failed");
+    DFX_HIP(hipMemcpyAsync(raw, c.validity, bytes, hipMemcpyDeviceToHost, s));
+    vbuf = raw;
+    if (c.bit_offset != 0) {
+      void* al = alloc_result(p, (size_t)((n + 7) >> 3));
+      memset(al, 0, (size_t)((n + 7) >> 3));
+      const int64_t bo = c.bit_offset;
+      fixups->push_back([raw, al, bo, n]() { realign_bits((const uint8_t*)raw, bo, n, (uint8_t*)al); });
+      vbuf = al;
+    }
+    ArrowArray* oo = out;
+    fixups->push_back([oo, vbuf, n]() {  // count nulls once the bits are on the host
+      int64_t set = 0;
+      const uint8_t* b = (const uint8_t*)vbuf;
+      for (int64_t i = 0; i < n; ++i) set += (b[i >> 3] >> (i & 7)) & 1;
+      oo->null_count = n - set;
+    });
+  }
+  p->buffer_ptrs.push_back(vbuf);
+  if (c.dtype == DFX_UTF8) {
+    void* obuf = alloc_result(p, sizeof(int32_t) * (size_t)(n + 1));
+    if (!obuf) return Status::Err(DFX_EXECUTION_ERROR, "host allocation failed");
+    if (c.offsets) DFX_HIP(hipMemcpyAsync(obuf, c.offsets, sizeof(int32_t) * (size_t)(n + 1), hipMemcpyDeviceToHost, s));
+    else memset(obuf, 0, sizeof(int32_t) * (size_t)(n + 1));
+    p->buffer_ptrs.push_back(obuf);
+    p->buffer_ptrs.push_back(nullptr);  // data: sized from the offsets once they are on the host
+    const uint8_t* dev_data = c.data;
+    fixups->push_back([obuf, p, dev_data, n]() {  // fetch the referenced bytes, rebase offsets to 0
+      int32_t* o = (int32_t*)obuf;
+      const int32_t o0 = o[0];
+      const int64_t nbytes = (int64_t)o[n] - o0;
+      void* dbuf = alloc_result(p, (size_t)(nbytes > 0 ? nbytes : 1));
+      if (nbytes > 0 && dev_data) (void)hipMemcpy(dbuf, dev_data + o0, (size_t)nbytes, hipMemcpyDeviceToHost);
+      if (o0 != 0)
+        for (int64_t i = 0; i <= n; ++i) o[i] -= o0;
+      p->buffer_ptrs[2] = dbuf;
+    });
+    out->n_buffers = 3;
+  } else if (c.dtype == DFX_BOOLEAN) {
+    const size_t bytes = (size_t)((c.bit_offset + n + 7) >> 3);
+    void* raw = alloc_result(p, bytes);
+    if (!raw) return Status::Err(DFX_EXECUTION_ERROR, "host allocation failed");
+    if (n) DFX_HIP(hipMemcpyAsync(raw, c.values, bytes, hipMemcpyDeviceToHost, s));
+    void* vals = raw;
+    if (c.bit_offset != 0) {
+      void* al = alloc_result(p, (size_t)((n + 7) >> 3));
+      memset(al, 0, (size_t)((n + 7) >> 3));
+      const int64_t bo = c.bit_offset;
+      fixups->push_back([raw, al, bo, n]() { realign_bits((const uint8_t*)raw, bo, n, (uint8_t*)al); });
+      vals = al;
+    }
+    p->buffer_ptrs.push_back(vals);
+    out->n_buffers = 2;
+  } else {
+    const size_t bytes = (size_t)n * dtype_width(c.dtype);
+    void* raw = alloc_result(p, bytes);
+    if (!raw) return Status::Err(DFX_EXECUTION_ERROR, "host allocation failed");
+    if (bytes) DFX_HIP(hipMemcpyAsync(raw, c.values, bytes, hipMemcpyDeviceToHost, s));
+    p->buffer_ptrs.push_back(raw);
+    out->n_buffers = 2;
+  }
+  out->buffers = p->buffer_ptrs.data();
+  out->null_count = 0;
+  return Status::OK();
+}
+
+Status download_batch(const DeviceBatch& b, struct ArrowArray* out) {
+  ArrayPriv* p = new ArrayPriv();
+  memset(out, 0, sizeof(*out));
+  out->private_data = p;
+  out->release = release_array;
+  out->length = b.num_rows;
+  p->kids.resize(b.columns.size());
+  p->kid_ptrs.resize(b.columns.size());
+  std::vector<std::function<void()>> fixups;
+  for (size_t i = 0; i < b.columns.size(); ++i) {
+    memset(&p->kids[i], 0, sizeof(struct ArrowArray));
+    p->kid_ptrs[i] = &p->kids[i];
+  }
+  Status st;
+  for (size_t i = 0; i < b.columns.size() && st.ok(); ++i) st = download_column(b.columns[i], &p->kids[i], &fixups);
+  if (st.ok()) {
+    hipError_t e = hipStreamSynchronize(ctx().stream);
+    if (e != hipSuccess) st = Status::Err(DFX_EXECUTION_ERROR, strfmt("HIP error %s after D2H", hipGetErrorString(e)));
+  }
+  if (!st.ok()) {
+    release_array(out);
+    return st;
+  }
+  for (auto& f : fixups) f();
+  p->buffer_ptrs.push_back(nullptr);  // struct validity
+  out->n_buffers = 1;
+  out->buffers = p->buffer_ptrs.data();
+  out->n_children = (int64_t)p->kids.size();
+  out->children = p->kid_ptrs.empty() ? nullptr : p->kid_ptrs.data();
+  return Status::OK();
+}
+
+int exported_get_schema(struct ArrowArrayStream* s, struct ArrowSchema* out) {
+  ExportedStream* es = (ExportedStream*)s->private_data;
+  schema_to_arrow(es->rel->schema(), out);
+  return 0;
+}
+
+int exported_get_next(struct ArrowArrayStream* s, struct ArrowArray* out) {
+  ExportedStream* es = (ExportedStream*)s->private_data;
+  memset(out, 0, sizeof(*out));
+  DeviceBatch b;
+  bool has = false;
+  Status st;
+  try {
+    st = es->rel->next(&b, &has);
+    if (st.ok() && has) st = download_batch(b, out);
+  } catch (const std::exception& e) {  // nothing unwinds across the C ABI
+    st = Status::Err(DFX_INTERNAL_ERROR, std::string("internal exception: ") + e.what());
+  } catch (...) {
+    st = Status::Err(DFX_INTERNAL_ERROR, "internal exception");
+  }
+  if (!st.ok()) {
+    es->last_error = st.msg;
+    if (out->release) out->release(out);
+    memset(out, 0, sizeof(*out));
+    return st.code;
+  }
+  return 0;  // released (zeroed) array == end of stream
+}
+
+const char* exported_get_last_error(struct ArrowArrayStream* s) {
+  ExportedStream* es = (ExportedStream*)s->private_data;
+  return es->last_error.empty() ? nullptr : es->last_error.c_str();
+}
+
+void exported_release(struct ArrowArrayStream* s) {
+  if (!s || !s->release) return;
+  delete (ExportedStream*)s->private_data;
+  s->release = nullptr;
+  s->private_data = nullptr;
+}
+
+}  // namespace
+
+void export_relation(std::unique_ptr<Relation> rel, struct ArrowArrayStream* out) {
+  ExportedStream* es = new ExportedStream();
+  es->rel = std::move(rel);
+  memset(out, 0, sizeof(*out));
+  out->get_schema = exported_get_schema;
+  out->get_next = exported_get_next;
+  out->get_last_error = exported_get_last_error;
+  out->release = exported_release;
+  out->private_data = es;
+}
+
+Relation* peek_exported(struct ArrowArrayStream* s) {
+  if (!s || s->release != exported_release) return nullptr;
+  return ((ExportedStream*)s->private_data)->rel.get();
+}
+
+Status adopt_input_stream(struct ArrowArrayStream* input, std::unique_ptr<Relation>* out) {
+  if (!input || !input->release) return Status::Err(DFX_GENERAL, "input stream is null or released");
+  if (input->release == exported_release) {  // one of ours: stay on the device
+    ExportedStream* es = (ExportedStream*)input->private_data;
+    *out = std::move(es->rel);
+    delete es;
+    memset(input, 0, sizeof(*input));
+    return Status::OK();
+  }
+  std::unique_ptr<HostStreamRelation> h(new HostStreamRelation(input));
+  DFX_RETURN_IF_ERROR(h->init());
+  *out = std::move(h);
+  return Status::OK();
+}
+
+// =================================================================================================
+// FilterRelation
+// =================================================================================================
+FilterRelation::FilterRelation(std::unique_ptr<Relation> input, const dfx_runtime_expr& expr, SchemaInfo schema)
+    : input_(std::move(input)), expr_(expr), schema_(std::move(schema)) {
+  builder_.reset(new ProgramBuilder(input_->schema()));
+  int dt = DFX_TYPE_NONE;
+  deferred_ = builder_->add(expr_, expr_.root, &pred_operand_, &dt);
+  if (deferred_.ok() && dt != DFX_BOOLEAN)  // filter.rs:64-66
+    deferred_ = Status::Err(DFX_EXECUTION_ERROR, "Filter expression did not evaluate to boolean");
+}
+
+static Status alloc_zeroed_ctrl(std::shared_ptr<void>* ctrl) {
+  Status st;
+  *ctrl = device_alloc(sizeof(uint32_t) * CTRL_WORDS, &st);
+  if (!*ctrl) return st;
+  DFX_HIP(hipMemsetAsync(ctrl->get(), 0, sizeof(uint32_t) * CTRL_WORDS, ctx().stream));
+  return Status::OK();
+}
+
+Status FilterRelation::next(DeviceBatch* out, bool* has) {
+  *has = false;
+  DeviceBatch in;
+  bool got = false;
+  DFX_RETURN_IF_ERROR(input_->next(&in, &got));
+  if (!got) return Status::OK();
+  if (!deferred_.ok()) return deferred_;
+  DFX_RETURN_IF_ERROR(ensure_init());
+  hipStream_t s = ctx().stream;
+  const int64_t n = in.num_rows;
+  out->columns.clear();
+  out->columns.resize(in.columns.size());
+  if (n == 0) {  // zero-row batches are still emitted (filter.rs:55-62)
+    for (size_t c = 0; c < in.columns.size(); ++c) {
+      out->columns[c].dtype = in.columns[c].dtype;
+      out->columns[c].length = 0;
+    }
+    out->num_rows = 0;
+    *has = true;
+    return Status::OK();
+  }
+  DevProgram prog;
+  DevColumns cols;
+  DFX_RETURN_IF_ERROR(builder_->bind(in, &prog, &cols));
+  if (!ctrl_) DFX_RETURN_IF_ERROR(alloc_zeroed_ctrl(&ctrl_));
+  const int64_t n_words = (n + 63) / 64;
+  const int64_t n_tiles = (n + kTileRows - 1) / kTileRows;
+  Status st;
+  auto mask = device_alloc(sizeof(uint64_t) * (size_t)n_words, &st);
+  if (!mask) return st;
+  auto counts = device_alloc(sizeof(uint32_t) * (size_t)n_tiles, &st);
+  if (!counts) return st;
+  auto offsets = device_alloc(sizeof(uint64_t) * (size_t)(n_tiles + 1), &st);
+  if (!offsets) return st;
+  auto tmp = device_alloc(sizeof(uint64_t) * (size_t)(n_tiles / 4096 + 4), &st);
+  if (!tmp) return st;
+  double in_bytes = (double)n / 8.0;
+  for (int ci : builder_->columns()) in_bytes += (double)n * (in.columns[ci].dtype == DFX_BOOLEAN ? 0.125 : dtype_width(in.columns[ci].dtype));
+  DFX_HIP(launch_predicate_mask(prog, cols, pred_operand_, n, (uint64_t*)mask.get(), (uint32_t*)counts.get(),
+                                (uint32_t*)ctrl_.get(), in_bytes, s));
+  DFX_HIP(launch_scan_u32((const uint32_t*)counts.get(), (uint64_t*)offsets.get(), n_tiles, (uint64_t*)tmp.get(), s));
+  uint64_t kept = 0;
+  uint32_t errbits = 0;
+  DFX_HIP(hipMemcpyAsync(&kept, (uint64_t*)offsets.get() + n_tiles, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+  DFX_HIP(hipMemcpyAsync(&errbits, (uint32_t*)ctrl_.get() + CTRL_ERROR, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  DFX_HIP(hipStreamSynchronize(s));
+  if (errbits) {
+    DFX_HIP(hipMemsetAsync(ctrl_.get(), 0, sizeof(uint32_t) * CTRL_WORDS, s));
+    return error_from_ctrl(errbits);
+  }
+  const int64_t m = (int64_t)kept;
+  for (size_t c = 0; c < in.columns.size(); ++c) {  // fn filter per column (filter.rs:55-57)
+    const DeviceColumn& ic = in.columns[c];
+    DeviceColumn& oc = out->columns[c];
+    oc.dtype = ic.dtype;
+    oc.length = m;
+    oc.null_count = 0;  // value nulls are ignored: the output is all-valid (filter.rs:83-92)
+    if (ic.dtype == DFX_UTF8) {
+      // lengths + starts -> compact both -> scan lengths -> gather bytes
+      auto lens = device_alloc(sizeof(int32_t) * (size_t)n, &st);
+      if (!lens) return st;
+      auto starts = device_alloc(sizeof(int32_t) * (size_t)n, &st);
+      if (!starts) return st;
+      auto lens_c = device_alloc(sizeof(int32_t) * (size_t)(m + 1), &st);
+      if (!lens_c) return st;
+      auto starts_c = device_alloc(sizeof(int32_t) * (size_t)(m + 1), &st);
+      if (!starts_c) return st;
+      auto offs = device_alloc(sizeof(int32_t) * (size_t)(m + 1), &st);
+      if (!offs) return st;
+      auto tmp2 = device_alloc(sizeof(uint64_t) * (size_t)(m / 4096 + 4), &st);
+      if (!tmp2) return st;
+      DFX_HIP(launch_utf8_lengths(ic.offsets, n, (int32_t*)lens.get(), (int32_t*)starts.get(), s));
+      DFX_HIP(launch_compact(lens.get(), 4, (const uint64_t*)mask.get(), (const uint64_t*)offsets.get(), n, lens_c.get(), 0, s));
+      DFX_HIP(launch_compact(starts.get(), 4, (const uint64_t*)mask.get(), (const uint64_t*)offsets.get(), n, starts_c.get(), 0, s));
+      DFX_HIP(launch_scan_i32((const int32_t*)lens_c.get(), (int32_t*)offs.get(), m, (uint64_t*)tmp2.get(), s));
+      int32_t total = 0;
+      DFX_HIP(hipMemcpyAsync(&total, (int32_t*)offs.get() + m, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+      DFX_HIP(hipStreamSynchronize(s));
+      auto bytes = device_alloc((size_t)total + 8, &st);
+      if (!bytes) return st;
+      DFX_HIP(launch_utf8_gather(ic.data, (const int32_t*)starts_c.get(), (const int32_t*)offs.get(), m, (uint8_t*)bytes.get(), s));
+      oc.offsets = (const int32_t*)offs.get();
+      oc.data = (const uint8_t*)bytes.get();
+      oc.data_bytes = total;
+      oc.owners = {offs, bytes};
+    } else if (ic.dtype == DFX_BOOLEAN) {
+      return Status::Err(DFX_EXECUTION_ERROR, "filter not supported for Boolean");  // filter.rs:105-108
+    } else {  // deviation D2: every fixed-width type, not just Float64
+      const int w = dtype_width(ic.dtype);
+      auto vals = device_alloc((size_t)(m > 0 ? m : 1) * w, &st);
+      if (!vals) return st;
+      DFX_HIP(launch_compact(ic.values, w, (const uint64_t*)mask.get(), (const uint64_t*)offsets.get(), n, vals.get(),
+                             (double)n * w + (double)m * w + (double)n / 8.0, s));
+      oc.values = vals.get();
+      oc.owners = {vals};
+    }
+  }
+  out->num_rows = m;
+  *has = true;
+  return Status::OK();
+}
+
+// =================================================================================================
+// ProjectRelation
+// =================================================================================================
+ProjectRelation::ProjectRelation(std::unique_ptr<Relation> input, std::vector<dfx_runtime_expr> exprs, SchemaInfo schema)
+    : input_(std::move(input)), exprs_(std::move(exprs)), schema_(std::move(schema)) {
+  builder_.reset(new ProgramBuilder(input_->schema()));
+  passthrough_.assign(exprs_.size(), -1);
+  operands_.assign(exprs_.size(), kNoOperand);
+  out_dtype_.assign(exprs_.size(), DFX_TYPE_NONE);
+  for (size_t i = 0; i < exprs_.size() && deferred_.ok(); ++i) {
+    const dfx_runtime_expr& e = exprs_[i];
+    if (e.is_aggregate) {  // RuntimeExpr::get_func() panics on an aggregate (expression.rs:60)
+      deferred_ = Status::Err(DFX_INTERNAL_ERROR, "explicit panic: get_func() on an aggregate expression");
+      break;
+    }
+    const dfx_expr_node& root = e.nodes[e.root];
+    if (root.kind == DFX_EXPR_COLUMN) {  // Arc clone, zero copy (expression.rs:311-315)
+      passthrough_[i] = root.column;
+      out_dtype_[i] = input_->schema().fields[root.column].dtype;
+      continue;
+    }
+    int dt = DFX_TYPE_NONE;
+    deferred_ = builder_->add(e, e.root, &operands_[i], &dt);
+    out_dtype_[i] = dt;
+  }
+  // the output schema is rebuilt from the expressions (projection.rs:52-57): names from
+  // RuntimeExpr::get_name, every field nullable.  Deviation D6: actual array types.
+  SchemaInfo derived;
+  for (size_t i = 0; i < exprs_.size(); ++i) {
+    Field f;
+    f.name = exprs_[i].name;
+    f.dtype = out_dtype_[i];
+    f.nullable = true;
+    derived.fields.push_back(f);
+  }
+  if (schema_.fields.size() != derived.fields.size()) {
+    schema_ = derived;
+  } else {
+    for (size_t i = 0; i < derived.fields.size(); ++i) {
+      schema_.fields[i].dtype = derived.fields[i].dtype;
+      schema_.fields[i].nullable = true;
+      if (schema_.fields[i].name.empty()) schema_.fields[i].name = derived.fields[i].name;
+    }
+  }
+}
+
+Status ProjectRelation::next(DeviceBatch* out, bool* has) {
+  *has = false;
+  DeviceBatch in;
+  bool got = false;
+  DFX_RETURN_IF_ERROR(input_->next(&in, &got));
+  if (!got) return Status::OK();
+  if (!deferred_.ok()) return deferred_;
+  DFX_RETURN_IF_ERROR(ensure_init());
+  hipStream_t s = ctx().stream;
+  const int64_t n = in.num_rows;
+  out->num_rows = n;
+  out->columns.clear();
+  out->columns.resize(exprs_.size());
+  std::vector<size_t> computed;
+  for (size_t i = 0; i < exprs_.size(); ++i) {
+    if (passthrough_[i] >= 0) out->columns[i] = in.columns[passthrough_[i]];
+    else computed.push_back(i);
+  }
+  if (computed.empty() || n == 0) {
+    for (size_t i : computed) {
+      out->columns[i].dtype = out_dtype_[i];
+      out->columns[i].length = 0;
+    }
+    *has = true;
+    return Status::OK();
+  }
+  DevProgram prog;
+  DevColumns cols;
+  DFX_RETURN_IF_ERROR(builder_->bind(in, &prog, &cols));
+  if (!ctrl_) DFX_RETURN_IF_ERROR(alloc_zeroed_ctrl(&ctrl_));
+  const int64_t n_words = (n + 63) / 64;
+  double in_bytes = 0;
+  for (int ci : builder_->columns()) in_bytes += (double)n * (in.columns[ci].dtype == DFX_BOOLEAN ? 0.125 : dtype_width(in.columns[ci].dtype));
+  Status st;
+  for (size_t base = 0; base < computed.size(); base += kMaxOut) {
+    DevProjectPlan plan;
+    memset(&plan, 0, sizeof(plan));
+    double out_bytes = 0;
+    const size_t cnt = std::min((size_t)kMaxOut, computed.size() - base);
+    plan.n_out = (int32_t)cnt;
+    for (size_t k = 0; k < cnt; ++k) {
+      const size_t i = computed[base + k];
+      DeviceColumn& oc = out->columns[i];
+      oc.dtype = out_dtype_[i];
+      oc.length = n;
+      const size_t vbytes = oc.dtype == DFX_BOOLEAN ? sizeof(uint64_t) * (size_t)n_words : (size_t)n * dtype_width(oc.dtype);
+      auto vals = device_alloc(vbytes, &st);
+      if (!vals) return st;
+      oc.values = vals.get();
+      oc.owners.push_back(vals);
+      plan.out[k] = operands_[i];
+      plan.out_dtype[k] = (uint8_t)oc.dtype;
+      plan.out_values[k] = vals.get();
+      out_bytes += (double)vbytes;
+      if (prog.has_nulls) {  // null in => null out (arrow 0.12 math_op / and / or)
+        auto vb = device_alloc(sizeof(uint64_t) * (size_t)n_words, &st);
+        if (!vb) return st;
+        oc.validity = (const uint8_t*)vb.get();
+        oc.null_count = -1;
+        oc.owners.push_back(vb);
+        plan.out_validity[k] = (uint64_t*)vb.get();
+        out_bytes += (double)n / 8.0;
+      }
+    }
+    DFX_HIP(launch_project(prog, cols, plan, n, (uint32_t*)ctrl_.get(), in_bytes + out_bytes, s));
+  }
+  uint32_t errbits = 0;
+  DFX_HIP(hipMemcpyAsync(&errbits, (uint32_t*)ctrl_.get() + CTRL_ERROR, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  DFX_HIP(hipStreamSynchronize(s));
+  if (errbits) {
+    DFX_HIP(hipMemsetAsync(ctrl_.get(), 0, sizeof(uint32_t) * CTRL_WORDS, s));
+    return error_from_ctrl(errbits);
+  }
+  *has = true;
+  return Status::OK();
+}
+
+}  // namespace dfx
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+using namespace dfx;
+
+extern "C" {
+
+int32_t dfx_filter_relation_new(struct ArrowArrayStream* input, const dfx_runtime_expr* expr,
+                                const struct ArrowSchema* schema, struct ArrowArrayStream* out, char* err,
+                                size_t errlen) {
+  try {
+    if (!expr || !out) return to_c(Status::Err(DFX_GENERAL, "null argument"), err, errlen);
+    std::unique_ptr<Relation> in;
+    Status st = adopt_input_stream(input, &in);
+    if (!st.ok()) return to_c(st, err, errlen);
+    SchemaInfo si;
+    st = schema_from_arrow(schema, &si);
+    if (!st.ok()) return to_c(st, err, errlen);
+    if (si.fields.empty()) si = in->schema();
+    if (expr->is_aggregate)
+      return to_c(Status::Err(DFX_INTERNAL_ERROR, "explicit panic: get_func() on an aggregate expression"), err, errlen);
+    std::unique_ptr<Relation> rel(new FilterRelation(std::move(in), *expr, si));
+    export_relation(std::move(rel), out);
+    return DFX_OK;
+  } catch (const std::exception& e) {
+    return to_c(Status::Err(DFX_INTERNAL_ERROR, e.what()), err, errlen);
+  }
+}
+
+int32_t dfx_project_relation_new(struct ArrowArrayStream* input, const dfx_runtime_expr* const* exprs,
+                                 int32_t n_exprs, const struct ArrowSchema* schema, struct ArrowArrayStream* out,
+                                 char* err, size_t errlen) {
+  try {
+    if (!out || (n_exprs > 0 && !exprs)) return to_c(Status::Err(DFX_GENERAL, "null argument"), err, errlen);
+    std::unique_ptr<Relation> in;
+    Status st = adopt_input_stream(input, &in);
+    if (!st.ok()) return to_c(st, err, errlen);
+    SchemaInfo si;
+    st = schema_from_arrow(schema, &si);
+    if (!st.ok()) return to_c(st, err, errlen);
+    if (n_exprs < 1)  // RecordBatch::new asserts at least one column
+      return to_c(Status::Err(DFX_INTERNAL_ERROR, "assertion failed: record batch needs at least one column"), err, errlen);
+    std::vector<dfx_runtime_expr> ev;
+    for (int i = 0; i < n_exprs; ++i) ev.push_back(*exprs[i]);
+    std::unique_ptr<Relation> rel(new ProjectRelation(std::move(in), std::move(ev), si));
+    export_relation(std::move(rel), out);
+    return DFX_OK;
+  } catch (const std::exception& e) {
+    return to_c(Status::Err(DFX_INTERNAL_ERROR, e.what()), err, errlen);
+  }
+}
+
+}  // extern "C"

@@ -1,0 +1,117 @@
+// dfx_relation.hpp -- internal operator classes (device-side mirror of the reference's operator tree).
+#pragma once
+#include <functional>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "dfx_host.hpp"
+#include "dfx_kernels.hpp"
+
+namespace dfx {
+
+// ---- stream adapters --------------------------------------------------------------------------
+// Takes ownership of *input (moves the struct). If the stream was produced by this library the
+// inner device relation is unwrapped, otherwise the host stream is wrapped in an uploader.
+Status adopt_input_stream(struct ArrowArrayStream* input, std::unique_ptr<Relation>* out);
+// Exposes a device relation as an Arrow C stream (downloads each batch to host Arrow memory).
+void export_relation(std::unique_ptr<Relation> rel, struct ArrowArrayStream* out);
+// The relation behind one of our exported streams (nullptr if foreign). Not owning.
+Relation* peek_exported(struct ArrowArrayStream* s);
+
+// ---- table scan (dfx_table.cpp) -----------------------------------------------------------------
+struct TableData {
+  SchemaInfo schema;
+  int64_t num_rows = 0;
+  std::vector<DeviceColumn> columns;  // whole-table columns
+};
+class TableScanRelation : public Relation {
+ public:
+  TableScanRelation(std::shared_ptr<const TableData> t, int64_t batch_rows);
+  RelationKind kind() const override { return REL_TABLE_SCAN; }
+  Status next(DeviceBatch* out, bool* has) override;
+  const SchemaInfo& schema() const override { return table_->schema; }
+
+ private:
+  std::shared_ptr<const TableData> table_;
+  int64_t batch_rows_;
+  int64_t pos_ = 0;
+  bool emitted_any_ = false;
+};
+
+// ---- FilterRelation (src/execution/filter.rs) ---------------------------------------------------
+class FilterRelation : public Relation {
+ public:
+  FilterRelation(std::unique_ptr<Relation> input, const dfx_runtime_expr& expr, SchemaInfo schema);
+  RelationKind kind() const override { return REL_FILTER; }
+  Status next(DeviceBatch* out, bool* has) override;
+  const SchemaInfo& schema() const override { return schema_; }
+  // for Filter -> Aggregate fusion
+  std::unique_ptr<Relation> release_input() { return std::move(input_); }
+  const dfx_runtime_expr& predicate() const { return expr_; }
+  Relation* input() { return input_.get(); }
+
+ private:
+  std::unique_ptr<Relation> input_;
+  dfx_runtime_expr expr_;
+  SchemaInfo schema_;
+  std::unique_ptr<ProgramBuilder> builder_;
+  uint8_t pred_operand_ = kNoOperand;
+  Status deferred_;  // evaluation-time type errors of the reference surface on next()
+  std::shared_ptr<void> ctrl_;
+};
+
+// ---- ProjectRelation (src/execution/projection.rs) ----------------------------------------------
+class ProjectRelation : public Relation {
+ public:
+  ProjectRelation(std::unique_ptr<Relation> input, std::vector<dfx_runtime_expr> exprs, SchemaInfo schema);
+  RelationKind kind() const override { return REL_PROJECT; }
+  Status next(DeviceBatch* out, bool* has) override;
+  const SchemaInfo& schema() const override { return schema_; }
+
+ private:
+  std::unique_ptr<Relation> input_;
+  std::vector<dfx_runtime_expr> exprs_;
+  SchemaInfo schema_;
+  std::unique_ptr<ProgramBuilder> builder_;
+  std::vector<int> passthrough_;      // >= 0: plain column reference (Arc clone in the reference)
+  std::vector<uint8_t> operands_;     // computed outputs
+  std::vector<int> out_dtype_;
+  Status deferred_;
+  std::shared_ptr<void> ctrl_;
+};
+
+// ---- AggregateRelation (src/execution/aggregate.rs) ---------------------------------------------
+struct AggOptions {
+  int strategy = 0;         // 0 auto, 1 global table only, 2 LDS front cache
+  int capacity_log2 = 0;    // 0: default
+  int lds_slots = -1;       // -1 auto
+  int lds_copies = -1;      // -1 auto
+};
+AggOptions& agg_options();
+
+class AggregateRelation : public Relation {
+ public:
+  AggregateRelation(SchemaInfo schema, std::unique_ptr<Relation> input, std::vector<dfx_runtime_expr> group,
+                    std::vector<dfx_runtime_expr> aggr);
+  ~AggregateRelation() override;
+  RelationKind kind() const override { return REL_AGGREGATE; }
+  Status next(DeviceBatch* out, bool* has) override;
+  const SchemaInfo& schema() const override { return schema_; }
+
+  // multi-GPU partial exchange (include/dfx.h: dfx_aggregate_partial_*)
+  Status partial_build(int world, int* n_words, int64_t* counts);
+  Status partial_export(void* dst_device, int64_t dst_words);
+  Status partial_import(const void* src_device, const int64_t* counts, int n_buckets);
+
+  struct Impl;
+
+ private:
+  SchemaInfo schema_;
+  std::unique_ptr<Impl> impl_;
+};
+
+// shared by filter / aggregate: CTRL_ERROR bits -> the reference's error
+Status error_from_ctrl(uint32_t bits);
+
+}  // namespace dfx

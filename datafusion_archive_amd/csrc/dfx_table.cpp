@@ -1,0 +1,244 @@
+// dfx_table.cpp -- HBM-resident tables (the in-memory DataSource: src/execution/datasource.rs:27-30,
+// relation.rs:34-54), synthetic generators, and the library-level C ABI (init, info, profiling,
+// options).
+#include <string.h>
+
+#include "dfx_relation.hpp"
+
+struct dfx_table {
+  std::shared_ptr<dfx::TableData> data;
+};
+
+namespace dfx {
+
+TableScanRelation::TableScanRelation(std::shared_ptr<const TableData> t, int64_t batch_rows)
+    : table_(std::move(t)), batch_rows_(batch_rows) {
+  if (batch_rows_ <= 0) batch_rows_ = table_->num_rows > 0 ? table_->num_rows : 1;
+  batch_rows_ = (batch_rows_ + 63) / 64 * 64;  // slices stay byte-aligned in every bitmap
+}
+
+Status TableScanRelation::next(DeviceBatch* out, bool* has) {
+  *has = false;
+  if (pos_ >= table_->num_rows) return Status::OK();  // Ok(None)
+  const int64_t n = std::min(batch_rows_, table_->num_rows - pos_);
+  out->num_rows = n > 0 ? n : 0;
+  out->columns.clear();
+  out->columns.reserve(table_->columns.size());
+  for (const DeviceColumn& c : table_->columns) {
+    DeviceColumn s = c;  // shares the owners: zero copy
+    s.length = out->num_rows;
+    if (c.dtype == DFX_UTF8) {
+      s.offsets = c.offsets + pos_;
+      s.data_bytes = 0;  // resolved lazily by the exporter from the offsets
+    } else if (c.dtype == DFX_BOOLEAN) {
+      s.values = (const uint8_t*)c.values + (pos_ >> 3);
+    } else {
+      s.values = (const uint8_t*)c.values + (size_t)pos_ * dtype_width(c.dtype);
+    }
+    if (c.validity) s.validity = c.validity + (pos_ >> 3);
+    if (c.null_count != 0) s.null_count = -1;
+    out->columns.push_back(std::move(s));
+  }
+  pos_ += batch_rows_;
+  emitted_any_ = true;
+  *has = true;
+  return Status::OK();
+}
+
+namespace {
+
+// concatenates device batches column-wise into one resident table
+Status build_table(Relation* rel, std::shared_ptr<TableData>* out) {
+  std::shared_ptr<TableData> t(new TableData());
+  t->schema = rel->schema();
+  std::vector<DeviceBatch> batches;
+  int64_t total = 0;
+  for (;;) {
+    DeviceBatch b;
+    bool has = false;
+    DFX_RETURN_IF_ERROR(rel->next(&b, &has));
+    if (!has) break;
+    total += b.num_rows;
+    batches.push_back(std::move(b));
+  }
+  t->num_rows = total;
+  const size_t nc = t->schema.fields.size();
+  t->columns.resize(nc);
+  hipStream_t s = ctx().stream;
+  for (size_t c = 0; c < nc; ++c) {
+    DeviceColumn& col = t->columns[c];
+    col.dtype = t->schema.fields[c].dtype;
+    col.length = total;
+    if (batches.size() == 1 && batches[0].columns[c].bit_offset == 0) {  // common case: adopt
+      col = batches[0].columns[c];
+      continue;
+    }
+    if (col.dtype == DFX_UTF8 || col.dtype == DFX_BOOLEAN)
+      return Status::Err(DFX_NOT_IMPLEMENTED, "multi-batch upload of Utf8/Boolean columns into a resident table");
+    const int w = dtype_width(col.dtype);
+    Status st;
+    auto vals = device_alloc((size_t)std::max<int64_t>(total, 1) * w, &st);
+    if (!vals) return st;
+    int64_t pos = 0;
+    bool any_nulls = false;
+    for (auto& b : batches) {
+      const DeviceColumn& bc = b.columns[c];
+      if (bc.length) DFX_HIP(hipMemcpyAsync((uint8_t*)vals.get() + (size_t)pos * w, bc.values, (size_t)bc.length * w, hipMemcpyDeviceToDevice, s));
+      if (bc.validity && bc.null_count != 0) any_nulls = true;
+      pos += bc.length;
+    }
+    if (any_nulls)
+      return Status::Err(DFX_NOT_IMPLEMENTED, "multi-batch upload of nullable columns into a resident table");
+    col.values = vals.get();
+    col.owners.push_back(vals);
+  }
+  DFX_HIP(hipStreamSynchronize(s));
+  *out = t;
+  return Status::OK();
+}
+
+}  // namespace
+}  // namespace dfx
+
+using namespace dfx;
+
+extern "C" {
+
+int32_t dfx_init(int32_t device_ordinal, char* err, size_t errlen) {
+  Context& c = ctx();
+  if (c.initialised && c.device != device_ordinal)
+    return to_c(Status::Err(DFX_GENERAL, "dfx_init: the library is already bound to another device"), err, errlen);
+  c.device = device_ordinal;
+  return to_c(ensure_init(), err, errlen);
+}
+
+int32_t dfx_device_info(char* name, size_t namelen, int32_t* n_cu, int64_t* hbm_bytes, int32_t* wavefront, char* err,
+                        size_t errlen) {
+  Status st = ensure_init();
+  if (!st.ok()) return to_c(st, err, errlen);
+  hipDeviceProp_t prop;
+  hipError_t e = hipGetDeviceProperties(&prop, ctx().device);
+  if (e != hipSuccess) return to_c(Status::Err(DFX_EXECUTION_ERROR, hipGetErrorString(e)), err, errlen);
+  if (name && namelen) snprintf(name, namelen, "%s (%s)", prop.name, prop.gcnArchName);
+  if (n_cu) *n_cu = prop.multiProcessorCount;
+  if (hbm_bytes) *hbm_bytes = (int64_t)prop.totalGlobalMem;
+  if (wavefront) *wavefront = prop.warpSize;
+  return DFX_OK;
+}
+
+int32_t dfx_synchronize(char* err, size_t errlen) {
+  Status st = ensure_init();
+  if (!st.ok()) return to_c(st, err, errlen);
+  hipError_t e = hipStreamSynchronize(ctx().stream);
+  if (e != hipSuccess) return to_c(Status::Err(DFX_EXECUTION_ERROR, hipGetErrorString(e)), err, errlen);
+  return DFX_OK;
+}
+
+int32_t dfx_table_from_stream(struct ArrowArrayStream* input, dfx_table** out, char* err, size_t errlen) {
+  try {
+    if (!out) return to_c(Status::Err(DFX_GENERAL, "null argument"), err, errlen);
+    *out = nullptr;
+    Status st = ensure_init();
+    if (!st.ok()) return to_c(st, err, errlen);
+    std::unique_ptr<Relation> in;
+    st = adopt_input_stream(input, &in);
+    if (!st.ok()) return to_c(st, err, errlen);
+    std::shared_ptr<TableData> t;
+    st = build_table(in.get(), &t);
+    if (!st.ok()) return to_c(st, err, errlen);
+    *out = new dfx_table{t};
+    return DFX_OK;
+  } catch (const std::exception& e) {
+    return to_c(Status::Err(DFX_INTERNAL_ERROR, e.what()), err, errlen);
+  }
+}
+
+int32_t dfx_table_synth(const dfx_synth_column* cols, int32_t n_cols, uint64_t seed, int64_t row_begin, int64_t n_rows,
+                        dfx_table** out, char* err, size_t errlen) {
+  try {
+    if (!out || !cols || n_cols < 1 || n_rows < 0) return to_c(Status::Err(DFX_GENERAL, "invalid argument"), err, errlen);
+    *out = nullptr;
+    Status st = ensure_init();
+    if (!st.ok()) return to_c(st, err, errlen);
+    std::shared_ptr<TableData> t(new TableData());
+    t->num_rows = n_rows;
+    hipStream_t s = ctx().stream;
+    for (int c = 0; c < n_cols; ++c) {
+      Field f;
+      f.name = cols[c].name ? cols[c].name : strfmt("c%d", c);
+      f.dtype = (cols[c].kind == DFX_SYNTH_I64_UNIFORM || cols[c].kind == DFX_SYNTH_I64_ZIPF) ? DFX_INT64 : DFX_FLOAT64;
+      f.nullable = false;
+      if (cols[c].kind < 0 || cols[c].kind > DFX_SYNTH_I64_ZIPF)
+        return to_c(Status::Err(DFX_NOT_IMPLEMENTED, "unknown synthetic column kind"), err, errlen);
+      t->schema.fields.push_back(f);
+      DeviceColumn col;
+      col.dtype = f.dtype;
+      col.length = n_rows;
+      auto vals = device_alloc((size_t)std::max<int64_t>(n_rows, 1) * 8, &st);
+      if (!vals) return to_c(st, err, errlen);
+      hipError_t e = launch_synth(cols[c].kind, cols[c].column_id, cols[c].p0, cols[c].p1, seed, row_begin, n_rows, vals.get(), s);
+      if (e != hipSuccess) return to_c(Status::Err(DFX_EXECUTION_ERROR, hipGetErrorString(e)), err, errlen);
+      col.values = vals.get();
+      col.owners.push_back(vals);
+      t->columns.push_back(std::move(col));
+    }
+    hipError_t e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return to_c(Status::Err(DFX_EXECUTION_ERROR, hipGetErrorString(e)), err, errlen);
+    *out = new dfx_table{t};
+    return DFX_OK;
+  } catch (const std::exception& e) {
+    return to_c(Status::Err(DFX_INTERNAL_ERROR, e.what()), err, errlen);
+  }
+}
+
+int64_t dfx_table_num_rows(const dfx_table* t) { return t ? t->data->num_rows : 0; }
+int32_t dfx_table_num_columns(const dfx_table* t) { return t ? (int32_t)t->data->columns.size() : 0; }
+const void* dfx_table_column_device_ptr(const dfx_table* t, int32_t column) {
+  if (!t || column < 0 || column >= (int32_t)t->data->columns.size()) return nullptr;
+  return t->data->columns[column].values;
+}
+
+int32_t dfx_table_scan_new(const dfx_table* t, int64_t batch_rows, struct ArrowArrayStream* out, char* err, size_t errlen) {
+  if (!t || !out) return to_c(Status::Err(DFX_GENERAL, "null argument"), err, errlen);
+  std::unique_ptr<Relation> rel(new TableScanRelation(t->data, batch_rows));
+  export_relation(std::move(rel), out);
+  return DFX_OK;
+}
+
+void dfx_table_free(dfx_table* t) { delete t; }
+
+// ---- measurement hooks ---------------------------------------------------------------------------
+int32_t dfx_profile_enable(int32_t on) {
+  profile_enable(on != 0);
+  return DFX_OK;
+}
+int32_t dfx_profile_reset(void) {
+  profile_reset();
+  return DFX_OK;
+}
+int32_t dfx_profile_count(void) { return profile_count(); }
+int32_t dfx_profile_get(int32_t index, char* name, size_t namelen, int64_t* launches, double* total_ms, double* algo_bytes) {
+  const char* nm = nullptr;
+  int64_t l = 0;
+  double ms = 0, b = 0;
+  if (!profile_get(index, &nm, &l, &ms, &b)) return DFX_GENERAL;
+  if (name && namelen) snprintf(name, namelen, "%s", nm);
+  if (launches) *launches = l;
+  if (total_ms) *total_ms = ms;
+  if (algo_bytes) *algo_bytes = b;
+  return DFX_OK;
+}
+
+int32_t dfx_set_option(const char* key, int64_t value) {
+  if (!key) return DFX_GENERAL;
+  AggOptions& o = agg_options();
+  if (!strcmp(key, "agg.strategy")) o.strategy = (int)value;
+  else if (!strcmp(key, "agg.capacity_log2")) o.capacity_log2 = (int)value;
+  else if (!strcmp(key, "agg.lds_slots")) o.lds_slots = (int)value;
+  else if (!strcmp(key, "agg.lds_copies")) o.lds_copies = (int)value;
+  else if (!strcmp(key, "pool.trim")) pool_trim();
+  else return DFX_GENERAL;
+  return DFX_OK;
+}
+
+}  // extern "C"

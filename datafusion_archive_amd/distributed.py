@@ -1,0 +1,45 @@
+"""Multi-GPU GROUP BY: one process per GPU, partial tables exchanged with ONE all-to-all.
+
+The reference is single-process (README.md:20); this is the MI355X-native addition.  GROUP BY shards
+on hash(key): every rank aggregates its own row range into a local table (K7), buckets the
+*groups* (not the rows) by hash(key) % world, one all-to-all of counts and one of payload move
+the buckets over xGMI (torch.distributed backend "nccl" == RCCL), each rank merges the buckets it
+received and emits the groups it owns.  Exchange volume is O(groups), never O(rows).
+
+torch / torch.distributed are plumbing here (buffers + the collective); the aggregate object only
+needs partial_build / partial_export / partial_import, so the CPU tests drive the same function over
+gloo with an oracle-backed stand-in.
+"""
+from __future__ import annotations
+
+from typing import Sequence
+
+
+def exchange_group_partials(agg, world: int, device, dist=None, torch=None) -> dict:
+    """Runs the exchange step for `agg` (an AggregateRelation-like object). Returns traffic stats."""
+    if torch is None:
+        import torch  # type: ignore
+    if dist is None:
+        import torch.distributed as dist  # type: ignore
+    n_words, counts = agg.partial_build(world)
+    send_counts = torch.tensor(list(counts), dtype=torch.int64, device=device)
+    recv_counts = torch.empty_like(send_counts)
+    if world > 1:
+        dist.all_to_all_single(recv_counts, send_counts)
+    else:
+        recv_counts.copy_(send_counts)
+    rc = [int(x) for x in recv_counts.tolist()]
+    send = torch.empty(max(1, n_words * sum(counts)), dtype=torch.int64, device=device)
+    agg.partial_export(send.data_ptr(), n_words * sum(counts))
+    recv = torch.empty(max(1, n_words * sum(rc)), dtype=torch.int64, device=device)
+    if world > 1:
+        dist.all_to_all_single(recv[: n_words * sum(rc)], send[: n_words * sum(counts)],
+                               output_split_sizes=[n_words * c for c in rc],
+                               input_split_sizes=[n_words * c for c in counts])
+    else:
+        recv.copy_(send)
+    if getattr(device, "type", str(device)) == "cuda" or str(device).startswith("cuda"):
+        torch.cuda.synchronize()
+    agg.partial_import(recv.data_ptr(), rc)
+    return {"n_words": n_words, "sent_groups": int(sum(counts)), "received_groups": int(sum(rc)),
+            "sent_bytes": int(8 * n_words * sum(counts))}

@@ -1,0 +1,116 @@
+"""CPU tests of the host side of the product: the C-ABI library loads and exports every symbol
+include/dfx.h declares, the expression compiler mirrors the reference's names / types / errors, and
+the execution path fails loudly (no CPU fallback) when there is no GPU.  No compute calls here."""
+import ctypes
+import os
+import re
+
+import pyarrow as pa
+import pytest
+
+from datafusion_archive_amd import _ffi
+from datafusion_archive_amd import execution as ex
+from datafusion_archive_amd.logicalplan import (AggregateFunction, BinaryExpr, Cast, Column, DataType, IsNull,
+                                                Literal, Operator, ScalarFunction, ScalarValue, Sort, serialize)
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SCHEMA = pa.schema([pa.field("city", pa.string(), False), pa.field("lat", pa.float64(), False),
+                    pa.field("lng", pa.float64(), False), pa.field("n", pa.int32(), False)])
+
+
+def test_library_exports_every_declared_symbol():
+    L = _ffi.lib()
+    header = open(os.path.join(ROOT, "include", "dfx.h")).read()
+    declared = sorted(set(re.findall(r"^(?:int32_t|int64_t|void|const char\*|const void\*)\s+(dfx_[a-z0-9_]+)\(", header, re.M)))
+    assert declared, "no declarations parsed from include/dfx.h"
+    for name in declared:
+        assert hasattr(L, name), f"libdfx_hip.so does not export {name}"
+    assert sorted(_ffi.EXPORTED_SYMBOLS) == declared
+    assert L.dfx_abi_version() == 1
+
+
+def test_expr_node_layout_matches_header():
+    # include/dfx.h: 8 x int32, an 8-byte union, a pointer
+    assert ctypes.sizeof(_ffi.ExprNode) == 8 * 4 + 8 + ctypes.sizeof(ctypes.c_void_p)
+
+
+def test_compile_scalar_expr_names_and_types():
+    """expression.rs: literal -> format!("{}", n); column -> field name; binary -> Debug of the Expr."""
+    c = lambda e: ex.compile_scalar_expr(None, e, SCHEMA)
+    assert c(Column(1)).get_name() == "lat" and c(Column(1)).get_type() == DataType.Float64
+    assert c(Literal(ScalarValue.Float64(51.0))).get_name() == "51"
+    assert c(Literal(ScalarValue.Int64(53))).get_name() == "53"
+    gt = BinaryExpr(Column(1), Operator.Gt, Literal(ScalarValue.Float64(51.0)))
+    lt = BinaryExpr(Column(1), Operator.Lt, Cast(Literal(ScalarValue.Int64(53)), DataType.Float64))
+    e = c(BinaryExpr(gt, Operator.And, lt))
+    assert e.get_name() == "#1 Gt Float64(51.0) And #1 Lt CAST(Int64(53) AS Float64)"  # sqlplanner.rs:576-584 style
+    assert e.get_type() == DataType.Boolean
+    assert c(BinaryExpr(Column(1), Operator.Plus, Column(2))).get_name() == "#1 Plus #2"
+    assert c(BinaryExpr(Column(1), Operator.Plus, Column(2))).get_type() == DataType.Float64  # op_type = left type
+    assert c(Cast(Column(1), DataType.Int32)).get_name() == "lat"  # expression.rs:323
+    assert c(Cast(Literal(ScalarValue.Int64(53)), DataType.Float64)).get_name() == "lit"  # :353
+
+
+@pytest.mark.parametrize("expr,kind,needle", [
+    (Literal(ScalarValue.Utf8("x")), "ExecutionError", "No support for literal type"),      # :306-309
+    (Literal(ScalarValue.Boolean(True)), "ExecutionError", "No support for literal type"),
+    (BinaryExpr(Column(1), Operator.Modulus, Column(2)), "ExecutionError", "operator: Modulus"),  # :494-497
+    (BinaryExpr(Column(1), Operator.Like, Column(2)), "ExecutionError", "operator: Like"),
+    (IsNull(Column(1)), "ExecutionError", "expression #1 IS NULL"),                           # :500-503
+    (Sort(Column(1), True), "ExecutionError", "expression #1 ASC"),
+    (ScalarFunction("sqrt", (Column(1),), DataType.Float64), "ExecutionError", "expression sqrt(#1)"),
+    (AggregateFunction("min", [Column(1)], DataType.Float64), "ExecutionError", "expression min(#1)"),
+    (Cast(Column(0), DataType.Int32), "InternalError", "unsupported CAST operation"),         # :336 panic
+    (Cast(Column(1), DataType.Utf8), "NotImplemented", "CAST from Float64 to Utf8"),
+    (Column(9), "InternalError", "index out of bounds"),
+])
+def test_compile_scalar_expr_errors_mirror_reference(expr, kind, needle):
+    with pytest.raises(ex.ExecutionError) as ei:
+        ex.compile_scalar_expr(None, expr, SCHEMA)
+    assert ei.value.kind == kind and needle in ei.value.message
+
+
+def test_compile_expr_aggregates():
+    """expression.rs:80-121."""
+    a = ex.compile_expr(None, AggregateFunction("MIN", [Column(1)], DataType.Float64), SCHEMA)
+    assert a.is_aggregate() and a.get_name() == "MIN" and a.get_type() == DataType.Float64
+    assert ex.compile_expr(None, AggregateFunction("Count", [Column(0)], DataType.UInt64), SCHEMA).is_aggregate()
+    with pytest.raises(ex.ExecutionError) as ei:  # :103-106 ("avg" passes the planner, not the executor)
+        ex.compile_expr(None, AggregateFunction("avg", [Column(1)], DataType.Float64), SCHEMA)
+    assert ei.value.kind == "General" and "Unsupported aggregate function 'avg'" in ei.value.message
+    with pytest.raises(ex.ExecutionError) as ei:  # assert_eq!(1, args.len()) :91
+        ex.compile_expr(None, AggregateFunction("min", [Column(1), Column(2)], DataType.Float64), SCHEMA)
+    assert ei.value.kind == "InternalError"
+    # a scalar expression falls through to compile_scalar_expr (:119)
+    assert not ex.compile_expr(None, Column(1), SCHEMA).is_aggregate()
+
+
+def test_serialization_is_children_before_parents():
+    s = serialize([BinaryExpr(Column(1), Operator.Plus, Cast(Column(2), DataType.Float64))])
+    assert s.roots == [3] and s.nodes[3].left == 0 and s.nodes[3].right == 2 and s.nodes[2].left == 1
+
+
+def test_no_cpu_fallback_without_gpu():
+    """Operators can be built without a device; pulling a batch must fail loudly, never compute on CPU."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            pytest.skip("a GPU is present")
+    except ImportError:
+        pass
+    b = pa.RecordBatch.from_pydict({"city": ["a"], "lat": [52.0], "lng": [1.0], "n": pa.array([1], pa.int32())}, schema=SCHEMA)
+    src = ex.DataSourceRelation(SCHEMA, [b])
+    f = ex.FilterRelation(src, ex.compile_scalar_expr(None, BinaryExpr(Column(1), Operator.Gt, Column(2)), SCHEMA), SCHEMA)
+    with pytest.raises(ex.ExecutionError) as ei:
+        f.next()
+    assert "no CPU fallback" in ei.value.message
+    with pytest.raises(ex.ExecutionError):
+        ex.DeviceTable.synth([("v", ex.SYNTH_F64_EXACT, 0, 0.0, 0.0)], 1, 0, 10)
+
+
+def test_consumed_relation_cannot_be_pulled():
+    b = pa.RecordBatch.from_pydict({"city": ["a"], "lat": [52.0], "lng": [1.0], "n": pa.array([1], pa.int32())}, schema=SCHEMA)
+    src = ex.DataSourceRelation(SCHEMA, [b])
+    ex.ProjectRelation(src, [ex.compile_scalar_expr(None, Column(1), SCHEMA)], None)
+    with pytest.raises(ex.ExecutionError):
+        src.next()
