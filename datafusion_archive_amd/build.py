@@ -18,9 +18,12 @@ LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(HERE, "build")
 LIB = os.path.join(LIBDIR, "libdfx_hip.so")
 
-SOURCES = ["dfx_kernels.hip", "dfx_host.cpp", "dfx_expr.cpp", "dfx_relation.cpp", "dfx_aggregate.cpp",
+# kernel translation units first (slowest): they compile in parallel
+SOURCES = ["dfx_k_table1.hip", "dfx_k_table2.hip", "dfx_k_table3.hip", "dfx_k_table4.hip", "dfx_k_core.hip",
+           "dfx_k_reduce.hip", "dfx_host.cpp", "dfx_expr.cpp", "dfx_relation.cpp", "dfx_aggregate.cpp",
            "dfx_table.cpp"]
-HEADERS = ["dfx_device.hpp", "dfx_kernels.hpp", "dfx_host.hpp", "dfx_relation.hpp", "../../include/dfx.h"]
+HEADERS = ["dfx_device.hpp", "dfx_kernels.hpp", "dfx_kernels_inl.hpp", "dfx_k_table_inl.hpp", "dfx_launch.hpp",
+           "dfx_host.hpp", "dfx_relation.hpp", "../../include/dfx.h"]
 
 # -ffp-contract=off : the reference never fuses a*b+c; projections must be bit-exact
 # -munsafe-fp-atomics: hardware global_atomic_add_f64 / ds_add_f64 instead of CAS loops
@@ -66,7 +69,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         return r
 
     if jobs:
-        with ThreadPoolExecutor(max_workers=min(6, len(jobs))) as ex:
+        with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
             list(ex.map(run, jobs))
     if jobs or force or _stale(LIB, objs):
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)

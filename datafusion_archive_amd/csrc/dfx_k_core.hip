@@ -1,0 +1,675 @@
+// dfx_k_core.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the filter / projection /
+// aggregate path.  Memory-bound integer/f64 work: no MFMA.  Design rules used throughout:
+//   * one wave owns 64 consecutive rows at a time, so every global access is a fully coalesced
+//     512-byte (8 B/lane) request and `__ballot` of a per-row predicate IS the Arrow LSB-first
+//     bitmap word of those rows;
+//   * expression intermediates live in VGPR register files indexed by wave-uniform indices
+//     (s_set_gpr_idx), never in memory; literals come from the kernarg segment by scalar load;
+//   * all inter-workgroup state (group table, counters) is touched only with agent-scope atomics:
+//     per-XCD L2s are not coherent, atomics are (MI355X_MICROARCH.md, inter-workgroup visibility);
+//   * grids are sized to a few resident workgroups per CU on 256 CUs and stride over tiles.
+// Compile with -ffp-contract=off (the reference never fuses a*b+c) and -munsafe-fp-atomics
+// (hardware global_atomic_add_f64 / ds_add_f64 instead of CAS loops).
+#include "dfx_kernels.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "dfx_kernels_inl.hpp"
+#include "dfx_launch.hpp"
+
+namespace dfx {
+
+uint64_t host_hash_keys(const uint64_t* key, int kw) {
+  switch (kw) {
+    case 1: return hash_keys<1>(key);
+    case 2: return hash_keys<2>(key);
+    case 3: return hash_keys<3>(key);
+    default: return hash_keys<4>(key);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1 predicate_mask
+// ---------------------------------------------------------------------------------------------
+template <int BANK, int U>
+__global__ __launch_bounds__(kBlock) void k_predicate_mask(const DevProgram P, const DevColumns C,
+                                                           const uint8_t pred, const int64_t n,
+                                                           uint64_t* __restrict__ mask_words,
+                                                           uint32_t* __restrict__ tile_counts,
+                                                           uint32_t* __restrict__ ctrl) {
+  typedef typename Bank<BANK>::type COLV;
+  __shared__ uint32_t wave_cnt[kBlock / 64];
+  const int lane = lane_id();
+  const int wave = threadIdx.x >> 6;
+  const int64_t n_words = (n + 63) >> 6;
+  const int64_t n_tiles = (n + kTileRows - 1) / kTileRows;
+  uint32_t err = 0;
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    uint32_t cnt = 0;
+    for (int i0 = 0; i0 < 16; i0 += U) {
+      COLV col[U];
+      uint32_t cv[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t row = (tile * 64 + wave * 16 + i0 + u) * 64 + lane;
+        load_columns(P, C, row, row < n, col[u], cv[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t w = tile * 64 + wave * 16 + i0 + u;
+        const bool inb = w * 64 + lane < n;
+        u64x16 reg;
+        uint32_t rv;
+        run_program(P, col[u], reg, cv[u], rv, inb, err);
+        const bool pass = inb && eval_predicate(P, col[u], reg, cv[u], rv, pred);
+        const uint64_t word = __ballot(pass);
+        if (lane == 0 && w < n_words) mask_words[w] = word;
+        cnt += (uint32_t)__popcll(word);
+      }
+    }
+    if (tile_counts != nullptr) {
+      if (lane == 0) wave_cnt[wave] = cnt;
+      __syncthreads();
+      if (threadIdx.x == 0) tile_counts[tile] = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+      __syncthreads();
+    }
+  }
+  if (err) atomicOr(&ctrl[CTRL_ERROR], err);
+}
+
+// ---------------------------------------------------------------------------------------------
+// exclusive scans (tile counts -> offsets; string lengths -> offsets)
+// ---------------------------------------------------------------------------------------------
+constexpr int kScanChunk = 4096;  // elements per block (256 threads x 16)
+
+DEV uint64_t wave_inclusive_scan(uint64_t v) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint64_t o = __shfl_up(v, d, 64);
+    if (lane_id() >= d) v += o;
+  }
+  return v;
+}
+
+// block-wide exclusive scan of one value per thread; returns the exclusive prefix, *total = block sum
+DEV uint64_t block_exclusive_scan(uint64_t v, uint64_t* total, uint64_t* lds4) {
+  const uint64_t inc = wave_inclusive_scan(v);
+  const int wave = threadIdx.x >> 6;
+  if (lane_id() == 63) lds4[wave] = inc;
+  __syncthreads();
+  uint64_t base = 0;
+  for (int w = 0; w < wave; ++w) base += lds4[w];
+  *total = lds4[0] + lds4[1] + lds4[2] + lds4[3];
+  __syncthreads();
+  return base + inc - v;
+}
+
+template <typename TIN>
+__global__ __launch_bounds__(kBlock) void k_scan_local(const TIN* __restrict__ in, int64_t n,
+                                                       uint64_t* __restrict__ block_sums) {
+  __shared__ uint64_t lds4[4];
+  const int64_t base = (int64_t)blockIdx.x * kScanChunk + (int64_t)threadIdx.x * 16;
+  uint64_t sum = 0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+    if (base + i < n) sum += (uint64_t)in[base + i];
+  uint64_t total;
+  block_exclusive_scan(sum, &total, lds4);
+  if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(kBlock) void k_scan_sums(uint64_t* __restrict__ block_sums, int64_t nb) {
+  // single block: exclusive scan of block_sums in place; block_sums[nb] = grand total
+  __shared__ uint64_t lds4[4];
+  uint64_t carry = 0;
+  for (int64_t b0 = 0; b0 < nb; b0 += kBlock) {
+    const int64_t i = b0 + threadIdx.x;
+    const uint64_t v = i < nb ? block_sums[i] : 0;
+    uint64_t total;
+    const uint64_t ex = block_exclusive_scan(v, &total, lds4);
+    if (i < nb) block_sums[i] = carry + ex;
+    carry += total;
+  }
+  if (threadIdx.x == 0) block_sums[nb] = carry;
+}
+
+template <typename TIN, typename TOUT>
+__global__ __launch_bounds__(kBlock) void k_scan_apply(const TIN* __restrict__ in, int64_t n,
+                                                       const uint64_t* __restrict__ block_sums,
+                                                       int64_t nb, TOUT* __restrict__ out) {
+  __shared__ uint64_t lds4[4];
+  const int64_t base = (int64_t)blockIdx.x * kScanChunk + (int64_t)threadIdx.x * 16;
+  uint64_t v[16];
+  uint64_t sum = 0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    v[i] = (base + i < n) ? (uint64_t)in[base + i] : 0;
+    sum += v[i];
+  }
+  uint64_t total;
+  uint64_t run = block_sums[blockIdx.x] + block_exclusive_scan(sum, &total, lds4);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    if (base + i < n) out[base + i] = (TOUT)run;
+    run += v[i];
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = (TOUT)block_sums[nb];
+}
+
+// ---------------------------------------------------------------------------------------------
+// K4 compact
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_compact(const T* __restrict__ in,
+                                                    const uint64_t* __restrict__ mask_words,
+                                                    const uint64_t* __restrict__ tile_offsets,
+                                                    const int64_t n, T* __restrict__ out) {
+  __shared__ uint32_t word_off[64];
+  const int lane = lane_id();
+  const int wave = threadIdx.x >> 6;
+  const int64_t n_words = (n + 63) >> 6;
+  const int64_t n_tiles = (n + kTileRows - 1) / kTileRows;
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    if (wave == 0) {  // popcount of each of the tile's 64 words, exclusive-scanned by one wave
+      const int64_t w = tile * 64 + lane;
+      const uint32_t c = w < n_words ? (uint32_t)__popcll(mask_words[w]) : 0u;
+      const uint64_t inc = wave_inclusive_scan((uint64_t)c);
+      word_off[lane] = (uint32_t)(inc - c);
+    }
+    __syncthreads();
+    const uint64_t tile_base = tile_offsets[tile];
+#pragma unroll 4
+    for (int i = 0; i < 16; ++i) {
+      const int wi = wave * 16 + i;
+      const int64_t w = tile * 64 + wi;
+      if (w < n_words) {
+        const uint64_t word = mask_words[w];  // wave-uniform address: one request
+        const int64_t row = w * 64 + lane;
+        if ((word >> lane) & 1) {
+          const uint32_t rank = (uint32_t)__popcll(word & ((1ull << lane) - 1ull));
+          out[tile_base + word_off[wi] + rank] = in[row];
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_utf8_lengths(const int32_t* __restrict__ offsets, int64_t n,
+                                                         int32_t* __restrict__ lengths,
+                                                         int32_t* __restrict__ starts) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+    const int32_t a = offsets[i], b = offsets[i + 1];
+    lengths[i] = b - a;
+    starts[i] = a;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_utf8_gather(const uint8_t* __restrict__ data,
+                                                        const int32_t* __restrict__ src_starts,
+                                                        const int32_t* __restrict__ dst_offsets,
+                                                        int64_t m, uint8_t* __restrict__ out) {
+  // one 16-lane group per output string: lanes stride over the bytes
+  const int64_t gid = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 4;
+  const int sub = threadIdx.x & 15;
+  const int64_t stride = ((int64_t)gridDim.x * kBlock) >> 4;
+  for (int64_t i = gid; i < m; i += stride) {
+    const int32_t s = src_starts[i], d = dst_offsets[i], len = dst_offsets[i + 1] - d;
+    for (int32_t b = sub; b < len; b += 16) out[d + b] = data[s + b];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2/K3 project
+// ---------------------------------------------------------------------------------------------
+template <int BANK, int U>
+__global__ __launch_bounds__(kBlock) void k_project(const DevProgram P, const DevColumns C,
+                                                    const DevProjectPlan plan, const int64_t n,
+                                                    uint32_t* __restrict__ ctrl) {
+  typedef typename Bank<BANK>::type COLV;
+  const int lane = lane_id();
+  const int64_t n_words = (n + 63) >> 6;
+  const int64_t wave_global = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+  const int64_t n_waves = ((int64_t)gridDim.x * kBlock) >> 6;
+  uint32_t err = 0;
+  for (int64_t w0 = wave_global * U; w0 < n_words; w0 += n_waves * U) {
+    COLV col[U];
+    uint32_t cv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t row = (w0 + u) * 64 + lane;
+      load_columns(P, C, row, row < n, col[u], cv[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t w = w0 + u;
+      const int64_t row = w * 64 + lane;
+      const bool inb = row < n;
+      if (w < n_words) {  // wave-uniform
+        u64x16 reg;
+        uint32_t rv;
+        run_program(P, col[u], reg, cv[u], rv, inb, err);
+#pragma unroll
+        for (int o = 0; o < kMaxOut; ++o) {
+          if (o < plan.n_out) {
+            uint64_t v;
+            bool valid;
+            fetch(P, col[u], reg, cv[u], rv, plan.out[o], v, valid);
+            const uint8_t t = plan.out_dtype[o];
+            if (t == T_BOOL) {
+              const uint64_t bits = __ballot(inb && (v & 1));
+              if (lane == 0) ((uint64_t*)plan.out_values[o])[w] = bits;
+            } else if (inb) {
+              store_typed(t, plan.out_values[o], row, v);
+            }
+            if (plan.out_validity[o] != nullptr) {
+              const uint64_t vb = __ballot(inb && valid);
+              if (lane == 0) plan.out_validity[o][w] = vb;
+            }
+          }
+        }
+      }
+    }
+  }
+  if (err) atomicOr(&ctrl[CTRL_ERROR], err);
+}
+
+// AccumulatorSet::accumulate_scalar for the batch scalars (aggregate.rs:107-145/:176-214/:245-283),
+// executed by one thread; then re-arms the batch partials with their identities.
+// func: 0 min, 1 max, 2 sum, 3 count.  state[2a] = has, state[2a+1] = value bits (canonical).
+__global__ void k_reduce_fold(const DevTable T, const uint8_t* __restrict__ arg_dtype,
+                              const uint8_t* __restrict__ func, uint64_t* __restrict__ partial,
+                              uint64_t* __restrict__ state) {
+  const int a = threadIdx.x;
+  if (a >= T.na) return;
+  const uint64_t accw = partial[4 * a + 0], cnt = partial[4 * a + 1], first = partial[4 * a + 2];
+  partial[4 * a + 0] = T.acc_init[a];
+  partial[4 * a + 1] = 0;
+  partial[4 * a + 2] = ~0ull;
+  const uint8_t t = arg_dtype[a], f = func[a];
+  bool has = cnt != 0;
+  uint64_t val = accw;
+  if (f == 3) {
+    has = true;  // deviation D3: COUNT of a batch is always Some(n)
+  } else if (has && (t == T_F64 || t == T_F32) && f != 2) {
+    double d = (first & 1) ? __longlong_as_double(0x7FF8000000000000ll) : f64_from_ordered(accw);
+    val = (t == T_F64) ? f64_bits(d) : f32_bits((float)d);
+  } else if (has && f == 2 && is_int(t)) {
+    val = wrap_to(t, accw);
+  }
+  if (!has) return;  // Option::None: accumulator unchanged (or stays None)
+  if (!state[2 * a]) {
+    state[2 * a] = 1;
+    state[2 * a + 1] = val;
+    return;
+  }
+  const uint64_t cur = state[2 * a + 1];
+  uint64_t out;
+  if (f == 3) {
+    out = cur + val;
+  } else if (t == T_F64) {
+    const double x = as_f64(cur), y = as_f64(val);
+    out = f64_bits(f == 0 ? fmin(x, y) : f == 1 ? fmax(x, y) : x + y);
+  } else if (t == T_F32) {
+    const float x = as_f32(cur), y = as_f32(val);
+    out = f32_bits(f == 0 ? fminf(x, y) : f == 1 ? fmaxf(x, y) : x + y);
+  } else if (is_signed_int(t)) {
+    const int64_t x = (int64_t)cur, y = (int64_t)val;
+    out = f == 0 ? (uint64_t)(x < y ? x : y) : f == 1 ? (uint64_t)(x > y ? x : y) : wrap_to(t, cur + val);
+  } else {
+    out = f == 0 ? (cur < val ? cur : val) : f == 1 ? (cur > val ? cur : val) : wrap_to(t, cur + val);
+  }
+  state[2 * a + 1] = out;
+}
+
+__global__ __launch_bounds__(kBlock) void k_fill_u64(uint64_t* __restrict__ p, uint64_t v, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) p[i] = v;
+}
+__global__ __launch_bounds__(kBlock) void k_fill_u32(uint32_t* __restrict__ p, uint32_t v, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) p[i] = v;
+}
+
+// dense u64 plane -> typed output column (keys: narrow; aggregates: undo the accumulator image)
+__global__ __launch_bounds__(kBlock) void k_finalize(const uint64_t* __restrict__ in, int64_t n,
+                                                     uint8_t out_dtype, uint8_t val_xform,
+                                                     void* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+    uint64_t v = in[i];
+    if (val_xform == VT_F64_ORD_MIN || val_xform == VT_F64_ORD_MAX) {
+      v = f64_bits(f64_from_ordered(v));
+    } else if (val_xform == VT_F32_ORD_MIN || val_xform == VT_F32_ORD_MAX) {
+      v = f32_bits((float)f64_from_ordered(v));
+    }
+    store_typed(out_dtype, out, i, v);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// synthetic columns -- same definition as orc_synth_fill (oracle/dfx_oracle.c)
+// ---------------------------------------------------------------------------------------------
+DEV uint64_t synth_u64(uint64_t seed, int column_id, int64_t row) {
+  const uint64_t s = seed ^ ((uint64_t)(uint32_t)column_id * 0xA0761D6478BD642Full);
+  return mix64(s + ((uint64_t)row + 1ull) * 0x9E3779B97F4A7C15ull);
+}
+
+__global__ __launch_bounds__(kBlock) void k_synth(int kind, int column_id, double p0, double p1, uint64_t seed,
+                                                  int64_t row_begin, int64_t n, void* __restrict__ out) {
+  int zipf_bits = 0;
+  const uint64_t G = (uint64_t)(int64_t)p0;
+  if (kind == 3) {
+    while ((1ull << zipf_bits) < G && zipf_bits < 62) ++zipf_bits;
+  }
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+    const uint64_t r = synth_u64(seed, column_id, row_begin + i);
+    if (kind == 0) {
+      const double u = (double)(r >> 11) * 0x1.0p-53;
+      const double t = p1 * u;
+      ((double*)out)[i] = p0 + t;
+    } else if (kind == 1) {
+      ((double*)out)[i] = (double)(r >> 44) * 0x1.0p-10;
+    } else if (kind == 2) {
+      ((int64_t*)out)[i] = (int64_t)__umul64hi(r, G);
+    } else {
+      const uint64_t b = __umul64hi(r, (uint64_t)zipf_bits + 1ull);
+      const uint64_t r2 = mix64(r ^ 0xD6E8FEB86659FD93ull);
+      uint64_t k = (b == 0) ? 0 : ((1ull << (b - 1)) + __umul64hi(r2, 1ull << (b - 1)));
+      if (k >= G) k = G - 1;
+      ((int64_t*)out)[i] = (int64_t)k;
+    }
+  }
+}
+
+// =============================================================================================
+// host side: launch helpers + profiler
+// =============================================================================================
+static const char* kKernelNames[KID_COUNT_] = {
+    "predicate_mask", "compact", "project", "reduce_all", "hash_agg", "merge_rows", "rehash",
+    "emit_mask", "finalize", "scan", "synth", "fill", "gather_utf8", "partial", "partition"};
+const char* kernel_name(int kid) { return (kid >= 0 && kid < KID_COUNT_) ? kKernelNames[kid] : "?"; }
+
+namespace {
+struct ProfEntry {
+  int64_t launches = 0;
+  double total_ms = 0.0;
+  double algo_bytes = 0.0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+std::mutex g_prof_mu;
+bool g_prof_on = false;
+ProfEntry g_prof[KID_COUNT_];
+std::vector<hipEvent_t> g_event_pool;
+
+hipEvent_t get_event() {
+  if (!g_event_pool.empty()) {
+    hipEvent_t e = g_event_pool.back();
+    g_event_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  if (hipEventCreate(&e) != hipSuccess) return nullptr;
+  return e;
+}
+
+void drain(ProfEntry& p) {
+  for (auto& pr : p.pending) {
+    float ms = 0.f;
+    if (hipEventSynchronize(pr.second) == hipSuccess && hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess)
+      p.total_ms += (double)ms;
+    g_event_pool.push_back(pr.first);
+    g_event_pool.push_back(pr.second);
+  }
+  p.pending.clear();
+}
+
+int g_cu_count = 0;
+}  // namespace
+
+Scope::Scope(int kid_, hipStream_t s_, double bytes) : kid(kid_), s(s_) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  if (!g_prof_on) return;
+  a = get_event();
+  b = get_event();
+  g_prof[kid].launches += 1;
+  g_prof[kid].algo_bytes += bytes;
+  if (a) (void)hipEventRecord(a, s);
+}
+Scope::~Scope() {
+  if (!a || !b) return;
+  (void)hipEventRecord(b, s);
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  g_prof[kid].pending.emplace_back(a, b);
+}
+
+int device_cu_count() {
+  if (g_cu_count == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+      g_cu_count = prop.multiProcessorCount;
+    if (g_cu_count <= 0) g_cu_count = 256;
+  }
+  return g_cu_count;
+}
+
+void profile_enable(bool on) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  g_prof_on = on;
+}
+void profile_reset() {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  for (auto& p : g_prof) {
+    drain(p);
+    p.launches = 0;
+    p.total_ms = 0;
+    p.algo_bytes = 0;
+  }
+}
+int profile_count() { return KID_COUNT_; }
+bool profile_get(int index, const char** name, int64_t* launches, double* total_ms, double* algo_bytes) {
+  if (index < 0 || index >= KID_COUNT_) return false;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  drain(g_prof[index]);
+  *name = kKernelNames[index];
+  *launches = g_prof[index].launches;
+  *total_ms = g_prof[index].total_ms;
+  *algo_bytes = g_prof[index].algo_bytes;
+  return true;
+}
+
+// grid for a streaming kernel over `units` block-sized units: enough workgroups to fill 256 CUs
+// several times over (>> 256 WGs; blocks land round-robin on the 8 XCDs), capped so the
+// grid-stride loop amortises launch and tail effects.
+int stream_grid(int64_t units, int per_cu) {
+  int64_t cap = (int64_t)device_cu_count() * per_cu;
+  if (units < 1) units = 1;
+  return (int)(units < cap ? units : cap);
+}
+
+hipError_t launch_predicate_mask(const DevProgram& P, const DevColumns& C, uint8_t pred, int64_t n,
+                                 uint64_t* mask_words, uint32_t* tile_counts, uint32_t* ctrl,
+                                 double algo_bytes, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  Scope sc(KID_PREDICATE_MASK, s, algo_bytes);
+  const int64_t tiles = (n + kTileRows - 1) / kTileRows;
+  const int grid = stream_grid(tiles, 8);
+  if (P.n_cols <= 2)
+    hipLaunchKernelGGL((k_predicate_mask<2, 8>), dim3(grid), dim3(kBlock), 0, s, P, C, pred, n, mask_words, tile_counts, ctrl);
+  else if (P.n_cols <= 4)
+    hipLaunchKernelGGL((k_predicate_mask<4, 4>), dim3(grid), dim3(kBlock), 0, s, P, C, pred, n, mask_words, tile_counts, ctrl);
+  else
+    hipLaunchKernelGGL((k_predicate_mask<8, 2>), dim3(grid), dim3(kBlock), 0, s, P, C, pred, n, mask_words, tile_counts, ctrl);
+  return hipGetLastError();
+}
+
+template <typename TIN, typename TOUT>
+static hipError_t scan_impl(const TIN* in, TOUT* out, int64_t n, uint64_t* tmp, hipStream_t s) {
+  Scope sc(KID_SCAN, s, 0);
+  const int64_t nb = n > 0 ? (n + kScanChunk - 1) / kScanChunk : 1;
+  hipLaunchKernelGGL((k_scan_local<TIN>), dim3((unsigned)nb), dim3(kBlock), 0, s, in, n, tmp);
+  hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kBlock), 0, s, tmp, nb);
+  hipLaunchKernelGGL((k_scan_apply<TIN, TOUT>), dim3((unsigned)nb), dim3(kBlock), 0, s, in, n, tmp, nb, out);
+  return hipGetLastError();
+}
+hipError_t launch_scan_u32(const uint32_t* in, uint64_t* out, int64_t n, uint64_t* tmp, hipStream_t s) {
+  return scan_impl<uint32_t, uint64_t>(in, out, n, tmp, s);
+}
+hipError_t launch_scan_i32(const int32_t* in, int32_t* out, int64_t n, uint64_t* tmp, hipStream_t s) {
+  return scan_impl<int32_t, int32_t>(in, out, n, tmp, s);
+}
+
+hipError_t launch_compact(const void* in, int width, const uint64_t* mask_words, const uint64_t* tile_offsets,
+                          int64_t n, void* out, double algo_bytes, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  Scope sc(KID_COMPACT, s, algo_bytes);
+  const int64_t tiles = (n + kTileRows - 1) / kTileRows;
+  const int grid = stream_grid(tiles, 8);
+  switch (width) {
+    case 8: hipLaunchKernelGGL(k_compact<uint64_t>, dim3(grid), dim3(kBlock), 0, s, (const uint64_t*)in, mask_words, tile_offsets, n, (uint64_t*)out); break;
+    case 4: hipLaunchKernelGGL(k_compact<uint32_t>, dim3(grid), dim3(kBlock), 0, s, (const uint32_t*)in, mask_words, tile_offsets, n, (uint32_t*)out); break;
+    case 2: hipLaunchKernelGGL(k_compact<uint16_t>, dim3(grid), dim3(kBlock), 0, s, (const uint16_t*)in, mask_words, tile_offsets, n, (uint16_t*)out); break;
+    case 1: hipLaunchKernelGGL(k_compact<uint8_t>, dim3(grid), dim3(kBlock), 0, s, (const uint8_t*)in, mask_words, tile_offsets, n, (uint8_t*)out); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_utf8_lengths(const int32_t* offsets, int64_t n, int32_t* lengths, int32_t* starts, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  Scope sc(KID_GATHER_UTF8, s, 0);
+  const int grid = stream_grid((n + kBlock - 1) / kBlock, 8);
+  hipLaunchKernelGGL(k_utf8_lengths, dim3(grid), dim3(kBlock), 0, s, offsets, n, lengths, starts);
+  return hipGetLastError();
+}
+hipError_t launch_utf8_gather(const uint8_t* data, const int32_t* src_starts, const int32_t* dst_offsets,
+                              int64_t m, uint8_t* out, hipStream_t s) {
+  if (m <= 0) return hipSuccess;
+  Scope sc(KID_GATHER_UTF8, s, 0);
+  const int grid = stream_grid((m * 16 + kBlock - 1) / kBlock, 8);
+  hipLaunchKernelGGL(k_utf8_gather, dim3(grid), dim3(kBlock), 0, s, data, src_starts, dst_offsets, m, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_project(const DevProgram& P, const DevColumns& C, const DevProjectPlan& plan, int64_t n,
+                          uint32_t* ctrl, double algo_bytes, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  Scope sc(KID_PROJECT, s, algo_bytes);
+  const int grid = stream_grid((n + kBlock - 1) / kBlock, 8);
+  if (P.n_cols <= 2)
+    hipLaunchKernelGGL((k_project<2, 8>), dim3(grid), dim3(kBlock), 0, s, P, C, plan, n, ctrl);
+  else if (P.n_cols <= 4)
+    hipLaunchKernelGGL((k_project<4, 4>), dim3(grid), dim3(kBlock), 0, s, P, C, plan, n, ctrl);
+  else
+    hipLaunchKernelGGL((k_project<8, 2>), dim3(grid), dim3(kBlock), 0, s, P, C, plan, n, ctrl);
+  return hipGetLastError();
+}
+
+hipError_t launch_reduce_fold(const DevTable& T, const uint8_t* arg_dtype, const uint8_t* func,
+                              uint64_t* partial, uint64_t* state, hipStream_t s) {
+  hipLaunchKernelGGL(k_reduce_fold, dim3(1), dim3(64), 0, s, T, arg_dtype, func, partial, state);
+  return hipGetLastError();
+}
+
+
+DFX_DECLARE_TABLE_KW(1)
+DFX_DECLARE_TABLE_KW(2)
+DFX_DECLARE_TABLE_KW(3)
+DFX_DECLARE_TABLE_KW(4)
+
+#define DFX_KW_DISPATCH(kw, CALL)            \
+  switch (kw) {                              \
+    case 1: return CALL(1);                  \
+    case 2: return CALL(2);                  \
+    case 3: return CALL(3);                  \
+    case 4: return CALL(4);                  \
+    default: return hipErrorInvalidValue;    \
+  }
+
+hipError_t launch_hash_agg(const DevProgram& P, const DevColumns& C, const DevAggPlan& plan, const DevTable& T,
+                           const DevRows& spill, int64_t n, double algo_bytes, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  Scope sc(KID_HASH_AGG, s, algo_bytes);
+#define CALL(K) table_hash_agg<K>(P, C, plan, T, spill, n, s)
+  DFX_KW_DISPATCH(T.kw, CALL)
+#undef CALL
+}
+
+hipError_t launch_merge_rows(const DevRows& rows, int64_t row_begin, int64_t n_rows, const DevTable& T,
+                             const DevRows& spill, hipStream_t s) {
+  if (n_rows <= 0) return hipSuccess;
+  Scope sc(KID_MERGE_ROWS, s, 0);
+#define CALL(K) table_merge_rows<K>(rows, row_begin, n_rows, T, spill, s)
+  DFX_KW_DISPATCH(T.kw, CALL)
+#undef CALL
+}
+
+hipError_t launch_merge_bucket(const uint64_t* bucket, uint64_t count, const DevTable& T, const DevRows& spill,
+                               hipStream_t s) {
+  DevRows rows;
+  rows.words = const_cast<uint64_t*>(bucket);
+  rows.capacity = count;
+  return launch_merge_rows(rows, 0, (int64_t)count, T, spill, s);
+}
+
+hipError_t launch_rehash(const DevTable& from, const DevTable& to, const DevRows& spill, hipStream_t s) {
+  Scope sc(KID_REHASH, s, 0);
+#define CALL(K) table_rehash<K>(from, to, spill, s)
+  DFX_KW_DISPATCH(from.kw, CALL)
+#undef CALL
+}
+
+hipError_t launch_table_mask(const DevTable& T, uint64_t* mask_words, uint32_t* tile_counts, hipStream_t s) {
+  Scope sc(KID_EMIT_MASK, s, 0);
+#define CALL(K) table_mask<K>(T, mask_words, tile_counts, s)
+  DFX_KW_DISPATCH(T.kw, CALL)
+#undef CALL
+}
+
+hipError_t launch_partial_count(const DevTable& T, int world, uint64_t* counts, hipStream_t s) {
+  Scope sc(KID_PARTIAL, s, 0);
+#define CALL(K) table_partial_count<K>(T, world, counts, s)
+  DFX_KW_DISPATCH(T.kw, CALL)
+#undef CALL
+}
+
+hipError_t launch_partial_scatter(const DevTable& T, int world, const uint64_t* bucket_base,
+                                  const uint64_t* bucket_count, uint64_t* cursors, uint64_t* dst, hipStream_t s) {
+  Scope sc(KID_PARTIAL, s, 0);
+#define CALL(K) table_partial_scatter<K>(T, world, bucket_base, bucket_count, cursors, dst, s)
+  DFX_KW_DISPATCH(T.kw, CALL)
+#undef CALL
+}
+
+hipError_t launch_fill_u64(uint64_t* p, uint64_t v, int64_t n, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  Scope sc(KID_FILL, s, 0);
+  hipLaunchKernelGGL(k_fill_u64, dim3(stream_grid((n + kBlock - 1) / kBlock, 8)), dim3(kBlock), 0, s, p, v, n);
+  return hipGetLastError();
+}
+hipError_t launch_fill_u32(uint32_t* p, uint32_t v, int64_t n, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  Scope sc(KID_FILL, s, 0);
+  hipLaunchKernelGGL(k_fill_u32, dim3(stream_grid((n + kBlock - 1) / kBlock, 8)), dim3(kBlock), 0, s, p, v, n);
+  return hipGetLastError();
+}
+
+hipError_t launch_finalize(const uint64_t* in, int64_t n, uint8_t out_dtype, uint8_t val_xform, void* out,
+                           hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  Scope sc(KID_FINALIZE, s, 0);
+  hipLaunchKernelGGL(k_finalize, dim3(stream_grid((n + kBlock - 1) / kBlock, 8)), dim3(kBlock), 0, s, in, n, out_dtype, val_xform, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_synth(int kind, int column_id, double p0, double p1, uint64_t seed, int64_t row_begin, int64_t n,
+                        void* out, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  Scope sc(KID_SYNTH, s, 0);
+  hipLaunchKernelGGL(k_synth, dim3(stream_grid((n + kBlock - 1) / kBlock, 16)), dim3(kBlock), 0, s, kind, column_id, p0, p1, seed, row_begin, n, out);
+  return hipGetLastError();
+}
+
+}  // namespace dfx

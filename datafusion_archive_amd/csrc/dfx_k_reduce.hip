@@ -1,0 +1,145 @@
+// dfx_k_reduce.hip -- K5 reduce_all (ungrouped aggregates), its own translation unit.
+#include "dfx_kernels_inl.hpp"
+#include "dfx_launch.hpp"
+
+namespace dfx {
+// ---------------------------------------------------------------------------------------------
+// K5 reduce_all (ungrouped aggregates of one batch)
+// ---------------------------------------------------------------------------------------------
+// partial layout per aggregate a: partial[4a+0] accumulator word (pre-filled with the identity),
+// [4a+1] number of valid arguments, [4a+2] min over (row << 1 | is_nan) of valid rows (u64::MAX
+// when none): arrow 0.12 min/max scan with `<` / `>`, so a NaN in the first valid slot sticks.
+template <int BANK, int U, int NAMAX>
+__global__ __launch_bounds__(kBlock) void k_reduce(const DevProgram P, const DevColumns C,
+                                                   const DevAggPlan plan, const DevTable T,
+                                                   const int64_t n, uint64_t* __restrict__ partial,
+                                                   uint32_t* __restrict__ ctrl) {
+  typedef typename Bank<BANK>::type COLV;
+  __shared__ uint64_t lds[kBlock / 64][kMaxAggs * 3];
+  const int lane = lane_id();
+  const int wave = threadIdx.x >> 6;
+  const int64_t n_words = (n + 63) >> 6;
+  const int64_t wave_global = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+  const int64_t n_waves = ((int64_t)gridDim.x * kBlock) >> 6;
+  uint64_t acc[NAMAX], cnt[NAMAX], first[NAMAX];
+#pragma unroll
+  for (int a = 0; a < NAMAX; ++a) {
+    acc[a] = T.acc_init[a];
+    cnt[a] = 0;
+    first[a] = ~0ull;
+  }
+  uint32_t err = 0;
+  uint64_t passed = 0;
+  for (int64_t w0 = wave_global * U; w0 < n_words; w0 += n_waves * U) {
+    COLV col[U];
+    uint32_t cv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t row = (w0 + u) * 64 + lane;
+      load_columns(P, C, row, row < n, col[u], cv[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t row = (w0 + u) * 64 + lane;
+      const bool inb = row < n;
+      u64x16 reg;
+      uint32_t rv;
+      run_program(P, col[u], reg, cv[u], rv, inb, err);
+      const bool pass = inb && eval_predicate(P, col[u], reg, cv[u], rv, plan.pred);
+      if (pass) {
+        ++passed;
+#pragma unroll
+        for (int a = 0; a < NAMAX; ++a) {
+          if (a < T.na) {
+            uint64_t v;
+            bool valid;
+            fetch(P, col[u], reg, cv[u], rv, plan.arg[a], v, valid);
+            const uint8_t xf = T.val_xform[a];
+            if (xf == VT_COUNT_VALID) {
+              acc[a] += valid ? 1ull : 0ull;
+              cnt[a] += 1;
+            } else if (valid) {  // array_ops::{min,max,sum} skip nulls
+              if (xf != VT_RAW) {
+                const double d = (xf == VT_F32_ORD_MIN || xf == VT_F32_ORD_MAX) ? (double)as_f32(v) : as_f64(v);
+                const uint64_t tag = ((uint64_t)row << 1) | (d != d ? 1ull : 0ull);
+                first[a] = tag < first[a] ? tag : first[a];
+              }
+              acc[a] = acc_combine(T.acc_kind[a], acc[a], transform_value(xf, v, valid));
+              cnt[a] += 1;
+            }
+          }
+        }
+      }
+    }
+  }
+  // wave tree (xor butterfly), then one atomic per workgroup per word
+#pragma unroll
+  for (int a = 0; a < NAMAX; ++a) {
+    if (a < T.na) {
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) {
+        acc[a] = acc_combine(T.acc_kind[a], acc[a], shfl_xor_u64(acc[a], m));
+        cnt[a] += shfl_xor_u64(cnt[a], m);
+        const uint64_t of = shfl_xor_u64(first[a], m);
+        first[a] = of < first[a] ? of : first[a];
+      }
+      if (lane == 0) {
+        lds[wave][a * 3 + 0] = acc[a];
+        lds[wave][a * 3 + 1] = cnt[a];
+        lds[wave][a * 3 + 2] = first[a];
+      }
+    }
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) passed += shfl_xor_u64(passed, m);
+  __syncthreads();
+  if (threadIdx.x < T.na) {
+    const int a = threadIdx.x;
+    uint64_t x = lds[0][a * 3], c = lds[0][a * 3 + 1], f = lds[0][a * 3 + 2];
+    for (int w = 1; w < kBlock / 64; ++w) {
+      x = acc_combine(T.acc_kind[a], x, lds[w][a * 3]);
+      c += lds[w][a * 3 + 1];
+      f = lds[w][a * 3 + 2] < f ? lds[w][a * 3 + 2] : f;
+    }
+    if (c) {
+      acc_atomic(T.acc_kind[a], &partial[4 * a + 0], x);
+      atomicAdd((unsigned long long*)&partial[4 * a + 1], (unsigned long long)c);
+      atomicMin((unsigned long long*)&partial[4 * a + 2], (unsigned long long)f);
+    }
+  }
+  if (lane == 0 && passed) atomicAdd((unsigned long long*)&ctrl[CTRL_PASSED_LO], (unsigned long long)passed);
+  if (err) atomicOr(&ctrl[CTRL_ERROR], err);
+}
+
+hipError_t launch_reduce(const DevProgram& P, const DevColumns& C, const DevAggPlan& plan, const DevTable& T,
+                         int64_t n, uint64_t* partial, uint32_t* ctrl, double algo_bytes, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  Scope sc(KID_REDUCE, s, algo_bytes);
+  const int grid = stream_grid((n + kBlock - 1) / kBlock, 8);
+#define DFX_REDUCE(B, UU, NM) hipLaunchKernelGGL((k_reduce<B, UU, NM>), dim3(grid), dim3(kBlock), 0, s, P, C, plan, T, n, partial, ctrl)
+  const bool small = T.na <= 2;
+  if (P.n_cols <= 2) { if (small) DFX_REDUCE(2, 8, 2); else DFX_REDUCE(2, 8, 8); }
+  else if (P.n_cols <= 4) { if (small) DFX_REDUCE(4, 4, 2); else DFX_REDUCE(4, 4, 8); }
+  else { if (small) DFX_REDUCE(8, 2, 2); else DFX_REDUCE(8, 2, 8); }
+#undef DFX_REDUCE
+  return hipGetLastError();
+}
+
+
+}  // namespace dfx
+hipError_t launch_reduce(const DevProgram& P, const DevColumns& C, const DevAggPlan& plan, const DevTable& T,
+                         int64_t n, uint64_t* partial, uint32_t* ctrl, double algo_bytes, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  Scope sc(KID_REDUCE, s, algo_bytes);
+  const int grid = stream_grid((n + kBlock - 1) / kBlock, 8);
+#define DFX_REDUCE(B, UU, NM) hipLaunchKernelGGL((k_reduce<B, UU, NM>), dim3(grid), dim3(kBlock), 0, s, P, C, plan, T, n, partial, ctrl)
+  const bool small = T.na <= 2;
+  if (P.n_cols <= 2) { if (small) DFX_REDUCE(2, 8, 2); else DFX_REDUCE(2, 8, 8); }
+  else if (P.n_cols <= 4) { if (small) DFX_REDUCE(4, 4, 2); else DFX_REDUCE(4, 4, 8); }
+  else { if (small) DFX_REDUCE(8, 2, 2); else DFX_REDUCE(8, 2, 8); }
+#undef DFX_REDUCE
+  return hipGetLastError();
+}
+
+
+}  // namespace dfx

@@ -1,0 +1,379 @@
+// dfx_k_table_inl.hpp -- the group-table kernels, templated on the number of key words KW.
+// Instantiated once per KW in dfx_k_table{1,2,3,4}.hip so the four variants build in parallel.
+#pragma once
+#include "dfx_kernels_inl.hpp"
+#include "dfx_launch.hpp"
+
+namespace dfx {
+// ---------------------------------------------------------------------------------------------
+// K6/K7 hash_agg with an LDS front cache
+// ---------------------------------------------------------------------------------------------
+// Dynamic LDS layout (all 8-byte words, base 16-byte aligned): keys[KW][S], accs[na][S].
+// For KW > 1 an extra state[S] (uint32) follows.  S = plan.lds_slots (power of two), split into
+// plan.lds_copies lane-replicated sub-tables so that few-group inputs (TPC-H Q1: <= 6 groups) do not
+// serialise 64 lanes on one LDS address.
+template <int KW, int BANK, int U>
+__global__ __launch_bounds__(kBlock) void k_hash_agg(const DevProgram P, const DevColumns C,
+                                                     const DevAggPlan plan, const DevTable T,
+                                                     const DevRows spill, const int64_t n) {
+  typedef typename Bank<BANK>::type COLV;
+  extern __shared__ __attribute__((aligned(16))) uint64_t lds[];
+  const int S = plan.lds_slots;
+  uint64_t* lkeys = lds;
+  uint64_t* laccs = lds + (size_t)KW * S;
+  uint32_t* lstate = (uint32_t*)(lds + (size_t)(KW + T.na) * S);
+  const int lane = lane_id();
+  if (S > 0) {
+    for (int i = threadIdx.x; i < S; i += kBlock) {
+      lkeys[i] = kEmptyKey;
+      if (KW > 1) lstate[i] = 0u;
+      for (int a = 0; a < T.na; ++a) laccs[a * S + i] = T.acc_init[a];
+    }
+    __syncthreads();
+  }
+  const int sub_slots = S > 0 ? S / plan.lds_copies : 0;
+  const int sub_base = S > 0 ? (lane & (plan.lds_copies - 1)) * sub_slots : 0;
+
+  const int64_t n_words = (n + 63) >> 6;
+  const int64_t wave_global = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+  const int64_t n_waves = ((int64_t)gridDim.x * kBlock) >> 6;
+  uint32_t err = 0;
+  uint32_t lds_hit = 0, lds_miss = 0;
+  uint64_t passed = 0;
+  int iter = 0;
+  bool saturated = false;
+  for (int64_t w0 = wave_global * U; w0 < n_words; w0 += n_waves * U, ++iter) {
+    if ((iter & 7) == 0) {  // wave-uniform, one request: has the table passed its load limit?
+      saturated = __hip_atomic_load(&T.ctrl[CTRL_SATURATED], RLX_AGENT) != 0u;
+      if (!saturated && (uint64_t)__hip_atomic_load(&T.ctrl[CTRL_OCCUPIED], RLX_AGENT) > T.load_limit) {
+        saturated = true;
+        if (lane == 0) __hip_atomic_store(&T.ctrl[CTRL_SATURATED], 1u, RLX_AGENT);
+      }
+    }
+    COLV col[U];
+    uint32_t cv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t row = (w0 + u) * 64 + lane;
+      load_columns(P, C, row, row < n, col[u], cv[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t row = (w0 + u) * 64 + lane;
+      const bool inb = row < n;
+      u64x16 reg;
+      uint32_t rv;
+      run_program(P, col[u], reg, cv[u], rv, inb, err);
+      const bool pass = inb && eval_predicate(P, col[u], reg, cv[u], rv, plan.pred);
+      uint64_t key[KW];
+      uint64_t val[kMaxAggs];
+  #pragma unroll
+      for (int k = 0; k < KW; ++k) {
+        bool kvalid;
+        fetch(P, col[u], reg, cv[u], rv, plan.key[k], key[k], kvalid);  // key nulls are not checked (aggregate.rs:807-852)
+      }
+  #pragma unroll
+      for (int a = 0; a < kMaxAggs; ++a) {
+        val[a] = 0;
+        if (a < T.na) {
+          uint64_t v;
+          bool valid;
+          fetch(P, col[u], reg, cv[u], rv, plan.arg[a], v, valid);  // value(row) read blindly (aggregate.rs:561-603)
+          val[a] = transform_value(T.val_xform[a], v, valid);
+        }
+      }
+      passed += pass ? 1 : 0;
+      bool todo = pass;
+      // ---- LDS front cache ----
+      if (S > 0 && todo && !(KW == 1 && key[0] == kEmptyKey)) {
+        const uint64_t h = hash_keys<KW>(key);
+        int slot = sub_base + (int)(h & (uint64_t)(sub_slots - 1));
+        int found = -1;
+        if (KW == 1) {
+          for (int p = 0; p < 4 && found < 0; ++p) {
+            const uint64_t k = lkeys[slot];
+            if (k == key[0]) {
+              found = slot;
+            } else if (k == kEmptyKey) {
+              const uint64_t old = atomicCAS((unsigned long long*)&lkeys[slot], (unsigned long long)kEmptyKey,
+                                             (unsigned long long)key[0]);
+              if (old == kEmptyKey || old == key[0]) found = slot;
+            }
+            if (found < 0) slot = sub_base + ((slot - sub_base + 1) & (sub_slots - 1));
+          }
+        } else {
+          int spins = 0;
+          for (int p = 0; p < 4 && found < 0;) {
+            uint32_t st = __hip_atomic_load(&lstate[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (st == 0u) {
+              const uint32_t old = atomicCAS(&lstate[slot], 0u, 1u);
+              if (old == 0u) {
+  #pragma unroll
+                for (int k = 0; k < KW; ++k) lkeys[k * S + slot] = key[k];
+                __threadfence_block();
+                __hip_atomic_store(&lstate[slot], 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                found = slot;
+                break;
+              }
+              st = old;
+            }
+            if (st == 1u) {
+              if (++spins > 4096) break;
+              continue;
+            }
+            __threadfence_block();
+            bool same = true;
+  #pragma unroll
+            for (int k = 0; k < KW; ++k) same = same && (((volatile uint64_t*)lkeys)[k * S + slot] == key[k]);
+            if (same) found = slot;
+            else slot = sub_base + ((slot - sub_base + 1) & (sub_slots - 1));
+            ++p;
+          }
+        }
+        if (found >= 0) {
+  #pragma unroll
+          for (int a = 0; a < kMaxAggs; ++a)
+            if (a < T.na) acc_atomic(T.acc_kind[a], &laccs[a * S + found], val[a]);
+          todo = false;
+          ++lds_hit;
+        } else {
+          ++lds_miss;
+        }
+      }
+      // ---- global table ----
+      if (todo && !saturated) {
+        if (table_apply<KW>(T, key, val)) todo = false;
+      }
+      // ---- spill (table saturated or probe sequence exhausted) ----
+      spill_row<KW>(T, spill, todo, key, val);
+    }
+  }
+  // flush the LDS cache: every occupied slot becomes one merge into the global table
+  if (S > 0) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < S; i += kBlock) {
+      bool occ;
+      uint64_t key[KW];
+      if (KW == 1) {
+        key[0] = lkeys[i];
+        occ = key[0] != kEmptyKey;
+      } else {
+        occ = lstate[i] == 2u;
+#pragma unroll
+        for (int k = 0; k < KW; ++k) key[k] = lkeys[k * S + i];
+      }
+      uint64_t val[kMaxAggs];
+#pragma unroll
+      for (int a = 0; a < kMaxAggs; ++a) val[a] = (a < T.na) ? laccs[a * S + i] : 0;
+      bool todo = occ;
+      const bool sat = __hip_atomic_load(&T.ctrl[CTRL_SATURATED], RLX_AGENT) != 0u;
+      if (todo && !sat) {
+        if (table_apply<KW>(T, key, val)) todo = false;
+      }
+      spill_row<KW>(T, spill, todo, key, val);
+    }
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    passed += shfl_xor_u64(passed, m);
+    lds_hit += __shfl_xor(lds_hit, m, 64);
+    lds_miss += __shfl_xor(lds_miss, m, 64);
+  }
+  if (lane == 0) {
+    if (passed) atomicAdd((unsigned long long*)&T.ctrl[CTRL_PASSED_LO], (unsigned long long)passed);
+    if (lds_hit) atomicAdd(&T.ctrl[CTRL_LDS_HIT], lds_hit);
+    if (lds_miss) atomicAdd(&T.ctrl[CTRL_LDS_MISS], lds_miss);
+  }
+  if (err) atomicOr(&T.ctrl[CTRL_ERROR], err);
+}
+
+// pre-evaluated rows -> table (spill replay, rehash, partial import).  The source is `rows` planes
+// of capacity rows.capacity; rows [row_begin, row_begin + n_rows).
+template <int KW>
+__global__ __launch_bounds__(kBlock) void k_merge_rows(const DevRows rows, const int64_t row_begin,
+                                                       const int64_t n_rows, const DevTable T,
+                                                       const DevRows spill) {
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  const int64_t n_pad = (n_rows + 63) & ~63ll;  // whole waves stay in the loop for the ballots
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n_pad; i += stride) {
+    const bool inb = i < n_rows;
+    uint64_t key[KW];
+    uint64_t val[kMaxAggs];
+#pragma unroll
+    for (int k = 0; k < KW; ++k) key[k] = inb ? rows.words[(uint64_t)k * rows.capacity + row_begin + i] : 0;
+#pragma unroll
+    for (int a = 0; a < kMaxAggs; ++a)
+      val[a] = (inb && a < T.na) ? rows.words[(uint64_t)(KW + a) * rows.capacity + row_begin + i] : 0;
+    bool todo = inb;
+    if (todo && table_apply<KW>(T, key, val)) todo = false;
+    spill_row<KW>(T, spill, todo, key, val);
+  }
+}
+
+template <int KW>
+DEV bool slot_occupied(const DevTable& T, uint64_t slot) {
+  if (slot == T.mask + 1) return KW == 1 && T.ctrl[CTRL_SENTINEL] != 0u;
+  if (KW == 1) return T.keys[slot] != kEmptyKey;
+  return T.state[slot] == 2u;
+}
+
+template <int KW>
+__global__ __launch_bounds__(kBlock) void k_rehash(const DevTable from, const DevTable to, const DevRows spill) {
+  const int64_t n_slots = (int64_t)from.mask + 2;  // + the sentinel slot
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  const int64_t n_pad = (n_slots + 63) & ~63ll;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n_pad; i += stride) {
+    const bool occ = i < n_slots && slot_occupied<KW>(from, (uint64_t)i);
+    uint64_t key[KW];
+    uint64_t val[kMaxAggs];
+#pragma unroll
+    for (int k = 0; k < KW; ++k) key[k] = occ ? from.keys[(uint64_t)k * from.stride + i] : 0;
+    if (KW == 1 && occ && (uint64_t)i == from.mask + 1) key[0] = kEmptyKey;
+#pragma unroll
+    for (int a = 0; a < kMaxAggs; ++a) val[a] = (occ && a < from.na) ? from.accs[(uint64_t)a * from.stride + i] : 0;
+    bool todo = occ;
+    if (todo && table_apply<KW>(to, key, val)) todo = false;
+    spill_row<KW>(to, spill, todo, key, val);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K8 emit_groups
+// ---------------------------------------------------------------------------------------------
+template <int KW>
+__global__ __launch_bounds__(kBlock) void k_table_mask(const DevTable T, uint64_t* __restrict__ mask_words,
+                                                       uint32_t* __restrict__ tile_counts) {
+  __shared__ uint32_t wave_cnt[kBlock / 64];
+  const int lane = lane_id();
+  const int wave = threadIdx.x >> 6;
+  const int64_t n = (int64_t)T.mask + 2;
+  const int64_t n_words = (n + 63) >> 6;
+  const int64_t n_tiles = (n + kTileRows - 1) / kTileRows;
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    uint32_t cnt = 0;
+    for (int i = 0; i < 16; ++i) {
+      const int64_t w = tile * 64 + wave * 16 + i;
+      const int64_t slot = w * 64 + lane;
+      const bool occ = slot < n && slot_occupied<KW>(T, (uint64_t)slot);
+      const uint64_t word = __ballot(occ);
+      if (lane == 0 && w < n_words) mask_words[w] = word;
+      cnt += (uint32_t)__popcll(word);
+    }
+    if (lane == 0) wave_cnt[wave] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) tile_counts[tile] = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// multi-GPU partial export
+// ---------------------------------------------------------------------------------------------
+template <int KW>
+DEV uint64_t slot_key_hash(const DevTable& T, uint64_t slot, uint64_t (&key)[KW]) {
+#pragma unroll
+  for (int k = 0; k < KW; ++k) key[k] = T.keys[(uint64_t)k * T.stride + slot];
+  if (KW == 1 && slot == T.mask + 1) key[0] = kEmptyKey;
+  return hash_keys<KW>(key);
+}
+
+template <int KW>
+__global__ __launch_bounds__(kBlock) void k_partial_count(const DevTable T, int world, uint64_t* counts) {
+  const int64_t n = (int64_t)T.mask + 2;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+    if (slot_occupied<KW>(T, (uint64_t)i)) {
+      uint64_t key[KW];
+      const uint64_t h = slot_key_hash<KW>(T, (uint64_t)i, key);
+      atomicAdd((unsigned long long*)&counts[(h >> 7) % (uint64_t)world], 1ull);
+    }
+  }
+}
+
+template <int KW>
+__global__ __launch_bounds__(kBlock) void k_partial_scatter(const DevTable T, int world,
+                                                            const uint64_t* __restrict__ bucket_base,
+                                                            const uint64_t* __restrict__ bucket_count,
+                                                            uint64_t* cursors, uint64_t* __restrict__ dst) {
+  const int64_t n = (int64_t)T.mask + 2;
+  const int nw = KW + T.na;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+    if (slot_occupied<KW>(T, (uint64_t)i)) {
+      uint64_t key[KW];
+      const uint64_t h = slot_key_hash<KW>(T, (uint64_t)i, key);
+      const uint64_t r = (h >> 7) % (uint64_t)world;
+      const uint64_t g = atomicAdd((unsigned long long*)&cursors[r], 1ull);
+      uint64_t* b = dst + (uint64_t)nw * bucket_base[r];
+      const uint64_t cnt = bucket_count[r];
+#pragma unroll
+      for (int k = 0; k < KW; ++k) b[(uint64_t)k * cnt + g] = key[k];
+      for (int a = 0; a < T.na; ++a) b[(uint64_t)(KW + a) * cnt + g] = T.accs[(uint64_t)a * T.stride + i];
+    }
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// host launchers (one instantiation per KW)
+// ---------------------------------------------------------------------------------------------
+template <int KW>
+hipError_t table_hash_agg(const DevProgram& P, const DevColumns& C, const DevAggPlan& plan, const DevTable& T,
+                          const DevRows& spill, int64_t n, hipStream_t s) {
+  const int64_t n_blocks = (n + kBlock - 1) / kBlock;
+  const size_t lds_bytes = plan.lds_slots > 0
+                               ? (size_t)plan.lds_slots * ((size_t)(KW + T.na) * 8 + (KW > 1 ? 4 : 0))
+                               : 0;
+  // LDS-heavy blocks: fewer, longer-lived workgroups amortise the cache init + flush
+  const int per_cu = lds_bytes > 0 ? (lds_bytes > 40 * 1024 ? 2 : 4) : 8;
+  const int grid = stream_grid(n_blocks, per_cu);
+  if (P.n_cols <= 2)
+    hipLaunchKernelGGL((k_hash_agg<KW, 2, 4>), dim3(grid), dim3(kBlock), lds_bytes, s, P, C, plan, T, spill, n);
+  else if (P.n_cols <= 4)
+    hipLaunchKernelGGL((k_hash_agg<KW, 4, 2>), dim3(grid), dim3(kBlock), lds_bytes, s, P, C, plan, T, spill, n);
+  else
+    hipLaunchKernelGGL((k_hash_agg<KW, 8, 2>), dim3(grid), dim3(kBlock), lds_bytes, s, P, C, plan, T, spill, n);
+  return hipGetLastError();
+}
+
+template <int KW>
+hipError_t table_merge_rows(const DevRows& rows, int64_t row_begin, int64_t n_rows, const DevTable& T,
+                            const DevRows& spill, hipStream_t s) {
+  const int grid = stream_grid((n_rows + kBlock - 1) / kBlock, 8);
+  hipLaunchKernelGGL(k_merge_rows<KW>, dim3(grid), dim3(kBlock), 0, s, rows, row_begin, n_rows, T, spill);
+  return hipGetLastError();
+}
+
+template <int KW>
+hipError_t table_rehash(const DevTable& from, const DevTable& to, const DevRows& spill, hipStream_t s) {
+  const int64_t n = (int64_t)from.mask + 2;
+  const int grid = stream_grid((n + kBlock - 1) / kBlock, 8);
+  hipLaunchKernelGGL(k_rehash<KW>, dim3(grid), dim3(kBlock), 0, s, from, to, spill);
+  return hipGetLastError();
+}
+
+template <int KW>
+hipError_t table_mask(const DevTable& T, uint64_t* mask_words, uint32_t* tile_counts, hipStream_t s) {
+  const int64_t n = (int64_t)T.mask + 2;
+  const int64_t tiles = (n + kTileRows - 1) / kTileRows;
+  const int grid = stream_grid(tiles, 8);
+  hipLaunchKernelGGL(k_table_mask<KW>, dim3(grid), dim3(kBlock), 0, s, T, mask_words, tile_counts);
+  return hipGetLastError();
+}
+
+template <int KW>
+hipError_t table_partial_count(const DevTable& T, int world, uint64_t* counts, hipStream_t s) {
+  const int64_t n = (int64_t)T.mask + 2;
+  const int grid = stream_grid((n + kBlock - 1) / kBlock, 8);
+  hipLaunchKernelGGL(k_partial_count<KW>, dim3(grid), dim3(kBlock), 0, s, T, world, counts);
+  return hipGetLastError();
+}
+
+template <int KW>
+hipError_t table_partial_scatter(const DevTable& T, int world, const uint64_t* bucket_base,
+                                 const uint64_t* bucket_count, uint64_t* cursors, uint64_t* dst, hipStream_t s) {
+  const int64_t n = (int64_t)T.mask + 2;
+  const int grid = stream_grid((n + kBlock - 1) / kBlock, 8);
+  hipLaunchKernelGGL(k_partial_scatter<KW>, dim3(grid), dim3(kBlock), 0, s, T, world, bucket_base, bucket_count, cursors, dst);
+  return hipGetLastError();
+}
+
+}  // namespace dfx

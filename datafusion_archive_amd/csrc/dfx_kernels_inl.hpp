@@ -1,0 +1,472 @@
+// dfx_kernels_inl.hpp -- device-side building blocks shared by the kernel translation units:
+// scalar helpers, the per-row expression interpreter, the accumulator algebra and the group-table
+// find-or-insert.  Everything here is __device__ __forceinline__ (or a template), so each .hip
+// translation unit gets its own copy and they compile in parallel.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "dfx_kernels.hpp"
+
+namespace dfx {
+
+typedef uint64_t u64x16 __attribute__((ext_vector_type(16)));
+typedef uint64_t u64x8 __attribute__((ext_vector_type(8)));
+
+#define DEV __device__ __forceinline__
+
+// ---------------------------------------------------------------------------------------------
+// scalar helpers
+// ---------------------------------------------------------------------------------------------
+DEV double as_f64(uint64_t x) { return __longlong_as_double((long long)x); }
+DEV uint64_t f64_bits(double x) { return (uint64_t)__double_as_longlong(x); }
+DEV float as_f32(uint64_t x) { return __uint_as_float((uint32_t)x); }
+DEV uint64_t f32_bits(float x) { return (uint64_t)__float_as_uint(x); }
+DEV bool get_bit(const uint8_t* bm, int64_t i) { return (bm[i >> 3] >> (i & 7)) & 1; }
+DEV int lane_id() { return (int)(threadIdx.x & 63); }
+
+__host__ __device__ inline uint64_t mix64(uint64_t z) {  // splitmix64 finaliser
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+template <int KW>
+__host__ __device__ inline uint64_t hash_keys(const uint64_t* key) {
+  uint64_t h = mix64(key[0] + 0x9E3779B97F4A7C15ull);
+#pragma unroll
+  for (int w = 1; w < KW; ++w) h = mix64(h ^ (key[w] + 0x9E3779B97F4A7C15ull * (uint64_t)(w + 1)));
+  return h;
+}
+
+DEV bool is_signed_int(uint8_t t) { return t >= T_I8 && t <= T_I64; }
+DEV bool is_int(uint8_t t) { return t >= T_I8 && t <= T_U64; }
+
+// canonical 64-bit image of a value of dtype t: signed ints sign-extended, unsigned zero-extended,
+// f32 as its bit pattern in the low dword, f64 as its bit pattern, Boolean 0/1
+DEV uint64_t wrap_to(uint8_t t, uint64_t x) {
+  switch (t) {
+    case T_I8: return (uint64_t)(int64_t)(int8_t)x;
+    case T_I16: return (uint64_t)(int64_t)(int16_t)x;
+    case T_I32: return (uint64_t)(int64_t)(int32_t)x;
+    case T_U8: return (uint64_t)(uint8_t)x;
+    case T_U16: return (uint64_t)(uint16_t)x;
+    case T_U32: return (uint64_t)(uint32_t)x;
+    default: return x;
+  }
+}
+
+DEV uint64_t load_canonical(uint8_t t, const void* base, int64_t row, int64_t bit_offset) {
+  switch (t) {
+    case T_F64: case T_I64: case T_U64: return ((const uint64_t*)base)[row];
+    case T_I32: return (uint64_t)(int64_t)((const int32_t*)base)[row];
+    case T_U32: case T_F32: return (uint64_t)((const uint32_t*)base)[row];
+    case T_I16: return (uint64_t)(int64_t)((const int16_t*)base)[row];
+    case T_U16: return (uint64_t)((const uint16_t*)base)[row];
+    case T_I8: return (uint64_t)(int64_t)((const int8_t*)base)[row];
+    case T_U8: return (uint64_t)((const uint8_t*)base)[row];
+    case T_BOOL: return (uint64_t)get_bit((const uint8_t*)base, bit_offset + row);
+    default: return 0;
+  }
+}
+
+DEV void store_typed(uint8_t t, void* base, int64_t row, uint64_t v) {
+  switch (t) {
+    case T_F64: case T_I64: case T_U64: ((uint64_t*)base)[row] = v; break;
+    case T_I32: case T_U32: case T_F32: ((uint32_t*)base)[row] = (uint32_t)v; break;
+    case T_I16: case T_U16: ((uint16_t*)base)[row] = (uint16_t)v; break;
+    case T_I8: case T_U8: ((uint8_t*)base)[row] = (uint8_t)v; break;
+    default: break;
+  }
+}
+
+// Rust `as` numeric casts (float -> int saturating, NaN -> 0); same table as oracle cast_val
+DEV int64_t sat_to_i64(double x, int64_t lo, int64_t hi) {
+  if (x != x) return 0;
+  if (x <= (double)lo) return lo;
+  if (x >= (double)hi) return hi;
+  return (int64_t)x;
+}
+DEV uint64_t sat_to_u64(double x, uint64_t hi) {
+  if (x != x) return 0;
+  if (x <= 0.0) return 0;
+  if (x >= (double)hi) return hi;
+  return (uint64_t)x;
+}
+
+DEV uint64_t cast_value(uint8_t from, uint8_t to, uint64_t v) {
+  if (from == to) return v;
+  if (is_int(from)) {
+    if (is_int(to)) return wrap_to(to, v);
+    if (to == T_F64) return f64_bits(is_signed_int(from) ? (double)(int64_t)v : (double)v);
+    return f32_bits(is_signed_int(from) ? (float)(int64_t)v : (float)v);
+  }
+  const double x = (from == T_F32) ? (double)as_f32(v) : as_f64(v);
+  switch (to) {
+    case T_F32: return (from == T_F32) ? v : f32_bits((float)as_f64(v));
+    case T_F64: return f64_bits(x);
+    case T_I8: return (uint64_t)sat_to_i64(x, -128, 127);
+    case T_I16: return (uint64_t)sat_to_i64(x, -32768, 32767);
+    case T_I32: return (uint64_t)sat_to_i64(x, -2147483648ll, 2147483647ll);
+    case T_I64: return (uint64_t)sat_to_i64(x, (int64_t)0x8000000000000000ull, 0x7FFFFFFFFFFFFFFFll);
+    case T_U8: return sat_to_u64(x, 255ull);
+    case T_U16: return sat_to_u64(x, 65535ull);
+    case T_U32: return sat_to_u64(x, 4294967295ull);
+    case T_U64: return sat_to_u64(x, 0xFFFFFFFFFFFFFFFFull);
+    default: return 0;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// the per-row expression interpreter
+// ---------------------------------------------------------------------------------------------
+// NOTE: the register files are separate local vector VALUES (never members of a struct that is
+// passed by reference): that is what lets SROA keep them in VGPRs and lower the wave-uniform
+// dynamic indices to s_set_gpr_idx instead of scratch memory.
+//
+// Memory-level parallelism: a wave owns U consecutive 64-row groups per trip.  It first issues the
+// column loads of ALL U groups (U x n_cols independent 512-byte requests in flight), then
+// interprets the groups one after the other.  The column bank (values loaded per row) is sized to
+// the program: BANK in {2,4,8} columns, U chosen so that BANK * U <= 16 values (32 VGPRs).
+typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
+typedef uint64_t u64x4 __attribute__((ext_vector_type(4)));
+template <int BANK> struct Bank;
+template <> struct Bank<2> { typedef u64x2 type; };
+template <> struct Bank<4> { typedef u64x4 type; };
+template <> struct Bank<8> { typedef u64x8 type; };
+
+#define ROWSTATE_ARGS(s) s##_col, s##_reg, s##_colvalid, s##_regvalid
+#define ROWSTATE_PARAMS COLV& s_col, u64x16& s_reg, uint32_t& s_colvalid, uint32_t& s_regvalid
+#define ROWSTATE_CPARAMS const COLV& s_col, const u64x16& s_reg, const uint32_t& s_colvalid, const uint32_t& s_regvalid
+
+// issue every column load of this row back to back (independent loads, all in flight together)
+template <typename COLV>
+DEV void load_columns(const DevProgram& P, const DevColumns& C, int64_t row, bool inb, COLV& s_col,
+                      uint32_t& s_colvalid) {
+  constexpr int BANK = (int)(sizeof(COLV) / 8);
+  s_colvalid = 0xFFFFFFFFu;
+#pragma unroll
+  for (int c = 0; c < BANK; ++c) {
+    if (c < P.n_cols) {
+      uint64_t v = 0;
+      if (inb) v = load_canonical(P.col_dtype[c], C.c[c].values, row, C.c[c].bit_offset);
+      s_col[c] = v;
+      if (P.has_nulls) {  // wave-uniform branch
+        if (C.c[c].validity != nullptr) {
+          const bool ok = inb ? get_bit(C.c[c].validity, C.c[c].bit_offset + row) : false;
+          if (!ok) s_colvalid &= ~(1u << c);
+        }
+      }
+    }
+  }
+}
+
+template <typename COLV>
+DEV void fetch(const DevProgram& P, ROWSTATE_CPARAMS, uint8_t opnd, uint64_t& v, bool& valid) {
+  const int idx = opnd & 63;
+  const int kind = opnd >> 6;
+  if (kind == OPK_REG) {
+    v = s_reg[idx];
+    valid = (s_regvalid >> idx) & 1;
+  } else if (kind == OPK_COL) {
+    v = s_col[idx & (int)(sizeof(COLV) / 8 - 1)];
+    valid = (s_colvalid >> idx) & 1;
+  } else {
+    v = P.imm[idx & (kMaxImm - 1)];
+    valid = true;
+  }
+}
+
+// Executes the SSA program for one row.  Semantics per op are arrow 0.12 array_ops, the same
+// table the oracle restates (oracle/dfx_oracle.c: compare_arrays / boolean_arrays / math_arrays).
+template <typename COLV>
+DEV void run_program(const DevProgram& P, ROWSTATE_PARAMS, bool active, uint32_t& err) {
+  s_regvalid = 0;
+  for (int pc = 0; pc < P.n_ins; ++pc) {
+    const DevIns in = P.ins[pc];
+    const uint8_t t = in.t;
+    uint64_t x, y = 0;
+    bool vx, vy = true;
+    fetch(P, ROWSTATE_ARGS(s), in.a, x, vx);
+    if (in.op != DOP_CAST) fetch(P, ROWSTATE_ARGS(s), in.b, y, vy);
+    uint64_t res = 0;
+    bool v = vx && vy;
+    if (in.op <= DOP_GE) {
+      bool lt, eq, gt;
+      if (t == T_F64) {
+        const double a = as_f64(x), b = as_f64(y);
+        lt = a < b; eq = a == b; gt = a > b;
+      } else if (t == T_F32) {
+        const float a = as_f32(x), b = as_f32(y);
+        lt = a < b; eq = a == b; gt = a > b;
+      } else if (t == T_U64) {
+        lt = x < y; eq = x == y; gt = x > y;
+      } else {
+        const int64_t a = (int64_t)x, b = (int64_t)y;
+        lt = a < b; eq = a == b; gt = a > b;
+      }
+      bool r;
+      if (vx && vy) {
+        switch (in.op) {
+          case DOP_EQ: r = eq; break;
+          case DOP_NE: r = !eq; break;
+          case DOP_LT: r = lt; break;
+          case DOP_LE: r = lt || eq; break;
+          case DOP_GT: r = gt; break;
+          default: r = gt || eq; break;
+        }
+      } else {  // arrow 0.12 bool_op over Option<T>: never null; None sorts below every value
+        switch (in.op) {
+          case DOP_EQ: r = (!vx && !vy); break;
+          case DOP_NE: r = (vx != vy); break;
+          case DOP_LT: r = (!vx && vy); break;
+          case DOP_LE: r = !vx; break;
+          case DOP_GT: r = (vx && !vy); break;
+          default: r = !vy; break;
+        }
+      }
+      res = r ? 1 : 0;
+      v = true;
+    } else if (in.op == DOP_AND) {
+      res = x & y & 1;
+    } else if (in.op == DOP_OR) {
+      res = (x | y) & 1;
+    } else if (in.op == DOP_CAST) {
+      res = cast_value(t, in.b, x);
+      v = vx;
+    } else if (t == T_F64) {
+      const double a = as_f64(x), b = as_f64(y);
+      double o;
+      switch (in.op) {
+        case DOP_ADD: o = a + b; break;
+        case DOP_SUB: o = a - b; break;
+        case DOP_MUL: o = a * b; break;
+        default:
+          if (v && active && b == 0.0) err |= 1u;
+          o = a / b;
+          break;
+      }
+      res = f64_bits(o);
+    } else if (t == T_F32) {
+      const float a = as_f32(x), b = as_f32(y);
+      float o;
+      switch (in.op) {
+        case DOP_ADD: o = a + b; break;
+        case DOP_SUB: o = a - b; break;
+        case DOP_MUL: o = a * b; break;
+        default:
+          if (v && active && b == 0.0f) err |= 1u;
+          o = a / b;
+          break;
+      }
+      res = f32_bits(o);
+    } else {
+      uint64_t o;
+      switch (in.op) {
+        case DOP_ADD: o = x + y; break;
+        case DOP_SUB: o = x - y; break;
+        case DOP_MUL: o = x * y; break;
+        default:
+          if (y == 0) {
+            if (v && active) err |= 1u;
+            o = 0;
+          } else if (is_signed_int(t)) {
+            const uint64_t mn = wrap_to(t, 1ull << (t == T_I8 ? 7 : t == T_I16 ? 15 : t == T_I32 ? 31 : 63));
+            if ((int64_t)y == -1 && x == mn) {
+              if (v && active) err |= 2u;
+              o = x;
+            } else {
+              o = (uint64_t)((int64_t)x / (int64_t)y);
+            }
+          } else {
+            o = x / y;
+          }
+          break;
+      }
+      res = wrap_to(t, o);
+    }
+    s_reg[pc] = res;
+    s_regvalid |= (v ? 1u : 0u) << pc;
+  }
+}
+
+template <typename COLV>
+DEV bool eval_predicate(const DevProgram& P, ROWSTATE_CPARAMS, uint8_t pred) {
+  if (pred == kNoOperand) return true;
+  uint64_t v;
+  bool valid;
+  fetch(P, ROWSTATE_ARGS(s), pred, v, valid);
+  // FilterRelation reads filter.value(i): the raw value bit; a null slot holds false (filter.rs:86)
+  return valid && (v & 1);
+}
+
+// ---------------------------------------------------------------------------------------------
+// accumulator algebra (one 64-bit word per (group, aggregate))
+// ---------------------------------------------------------------------------------------------
+// order-preserving u64 image of an f64; NaN is canonicalised so that MIN and MAX ignore it unless
+// every value is NaN (f64::min / f64::max, aggregate.rs:136-141 / :205-210)
+DEV uint64_t f64_ordered(double d, bool for_min) {
+  uint64_t b = f64_bits(d);
+  if (d != d) b = for_min ? 0x7FF8000000000000ull : 0xFFF8000000000000ull;
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__host__ __device__ inline double f64_from_ordered(uint64_t u) {
+  const uint64_t b = (u >> 63) ? (u & 0x7FFFFFFFFFFFFFFFull) : ~u;
+  union { uint64_t u; double d; } c;
+  c.u = b;
+  return c.d;
+}
+
+DEV uint64_t transform_value(uint8_t xf, uint64_t v, bool valid) {
+  switch (xf) {
+    case VT_F64_ORD_MIN: return f64_ordered(as_f64(v), true);
+    case VT_F64_ORD_MAX: return f64_ordered(as_f64(v), false);
+    case VT_F32_ORD_MIN: return f64_ordered((double)as_f32(v), true);
+    case VT_F32_ORD_MAX: return f64_ordered((double)as_f32(v), false);
+    case VT_COUNT_VALID: return valid ? 1ull : 0ull;
+    default: return v;
+  }
+}
+
+// non-atomic combine (thread-private / shuffle reductions)
+DEV uint64_t acc_combine(uint8_t kind, uint64_t a, uint64_t b) {
+  switch (kind) {
+    case ACC_ADD_F64: return f64_bits(as_f64(a) + as_f64(b));
+    case ACC_ADD_F32: return f32_bits(as_f32(a) + as_f32(b));
+    case ACC_ADD_U64: return a + b;
+    case ACC_MIN_S64: return (uint64_t)(((int64_t)a < (int64_t)b) ? (int64_t)a : (int64_t)b);
+    case ACC_MAX_S64: return (uint64_t)(((int64_t)a > (int64_t)b) ? (int64_t)a : (int64_t)b);
+    case ACC_MIN_U64: return a < b ? a : b;
+    default: return a > b ? a : b;
+  }
+}
+
+// one hardware atomic, result unused (no-return form); works on global and LDS addresses
+DEV void acc_atomic(uint8_t kind, uint64_t* p, uint64_t v) {
+  switch (kind) {
+    case ACC_ADD_F64: unsafeAtomicAdd((double*)p, as_f64(v)); break;
+    case ACC_ADD_F32: unsafeAtomicAdd((float*)p, as_f32(v)); break;
+    case ACC_ADD_U64: atomicAdd((unsigned long long*)p, (unsigned long long)v); break;
+    case ACC_MIN_S64: atomicMin((long long*)p, (long long)v); break;
+    case ACC_MAX_S64: atomicMax((long long*)p, (long long)v); break;
+    case ACC_MIN_U64: atomicMin((unsigned long long*)p, (unsigned long long)v); break;
+    default: atomicMax((unsigned long long*)p, (unsigned long long)v); break;
+  }
+}
+
+DEV uint64_t shfl_xor_u64(uint64_t v, int m) { return (uint64_t)__shfl_xor((unsigned long long)v, m, 64); }
+
+// ---------------------------------------------------------------------------------------------
+// group table: find-or-insert + atomic update
+// ---------------------------------------------------------------------------------------------
+#define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+
+// returns false when the bounded probe sequence found neither the key nor a free slot
+template <int KW>
+DEV bool table_upsert_slot(const DevTable& T, const uint64_t (&key)[KW], uint64_t h, uint64_t& slot_out,
+                           bool& inserted) {
+  inserted = false;
+  uint64_t slot = (h >> T.shift) & T.mask;
+  if (KW == 1) {
+    if (key[0] == kEmptyKey) {  // the one key that collides with the claim sentinel owns slot `cap`
+      slot_out = T.mask + 1;
+      if (__hip_atomic_load(&T.ctrl[CTRL_SENTINEL], RLX_AGENT) == 0u) {
+        if (atomicExch(&T.ctrl[CTRL_SENTINEL], 1u) == 0u) inserted = true;
+      }
+      return true;
+    }
+    for (int p = 0; p < T.max_probe; ++p) {
+      const uint64_t k = __hip_atomic_load(&T.keys[slot], RLX_AGENT);
+      if (k == key[0]) {
+        slot_out = slot;
+        return true;
+      }
+      if (k == kEmptyKey) {
+        const uint64_t old = atomicCAS((unsigned long long*)&T.keys[slot], (unsigned long long)kEmptyKey,
+                                       (unsigned long long)key[0]);
+        if (old == kEmptyKey) {
+          inserted = true;
+          slot_out = slot;
+          return true;
+        }
+        if (old == key[0]) {
+          slot_out = slot;
+          return true;
+        }
+      }
+      slot = (slot + 1) & T.mask;
+    }
+    return false;
+  } else {
+    // multi-word keys: claim the slot's state word (0 empty -> 1 busy), publish the key words
+    // write-through, drain, then state = 2.  A lane that meets a busy slot re-reads it on its next
+    // loop trip (structured loop: the claimer never waits on anybody, so no SIMT deadlock).
+    int spins = 0;
+    for (int p = 0; p < T.max_probe;) {
+      uint32_t st = __hip_atomic_load(&T.state[slot], RLX_AGENT);
+      if (st == 0u) {
+        const uint32_t old = atomicCAS(&T.state[slot], 0u, 1u);
+        if (old == 0u) {
+#pragma unroll
+          for (int w = 0; w < KW; ++w) __hip_atomic_store(&T.keys[(uint64_t)w * T.stride + slot], key[w], RLX_AGENT);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __hip_atomic_store(&T.state[slot], 2u, RLX_AGENT);
+          inserted = true;
+          slot_out = slot;
+          return true;
+        }
+        st = old;
+      }
+      if (st == 1u) {
+        if (++spins > (1 << 20)) return false;
+        continue;
+      }
+      bool same = true;
+#pragma unroll
+      for (int w = 0; w < KW; ++w)
+        same = same && (__hip_atomic_load(&T.keys[(uint64_t)w * T.stride + slot], RLX_AGENT) == key[w]);
+      if (same) {
+        slot_out = slot;
+        return true;
+      }
+      slot = (slot + 1) & T.mask;
+      ++p;
+    }
+    return false;
+  }
+}
+
+// append one row (keys + accumulator operands) to the spill list; wave-aggregated cursor bump
+template <int KW>
+DEV void spill_row(const DevTable& T, const DevRows& spill, bool do_spill, const uint64_t (&key)[KW],
+                   const uint64_t (&val)[kMaxAggs]) {
+  const uint64_t m = __ballot(do_spill);
+  if (m == 0) return;
+  const int lane = lane_id();
+  const int leader = __ffsll((unsigned long long)m) - 1;
+  uint64_t base = 0;
+  if (lane == leader)
+    base = atomicAdd((unsigned long long*)&T.ctrl[CTRL_SPILL_LO], (unsigned long long)__popcll(m));
+  base = __shfl(base, leader, 64);
+  if (do_spill) {
+    const uint64_t pos = base + (uint64_t)__popcll(m & ((1ull << lane) - 1ull));
+    if (pos < spill.capacity) {
+#pragma unroll
+      for (int w = 0; w < KW; ++w) spill.words[(uint64_t)w * spill.capacity + pos] = key[w];
+      for (int a = 0; a < T.na; ++a) spill.words[(uint64_t)(KW + a) * spill.capacity + pos] = val[a];
+    }
+  }
+}
+
+template <int KW>
+DEV bool table_apply(const DevTable& T, const uint64_t (&key)[KW], const uint64_t (&val)[kMaxAggs]) {
+  uint64_t slot;
+  bool inserted;
+  if (!table_upsert_slot<KW>(T, key, hash_keys<KW>(key), slot, inserted)) return false;
+  if (inserted) atomicAdd(&T.ctrl[CTRL_OCCUPIED], 1u);
+#pragma unroll
+  for (int a = 0; a < kMaxAggs; ++a)
+    if (a < T.na) acc_atomic(T.acc_kind[a], &T.accs[(uint64_t)a * T.stride + slot], val[a]);
+  return true;
+}
+
+}  // namespace dfx

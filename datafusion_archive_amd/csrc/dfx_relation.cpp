@@ -505,7 +505,6 @@ Status FilterRelation::next(DeviceBatch* out, bool* has) {
 // =================================================================================================
 ProjectRelation::ProjectRelation(std::unique_ptr<Relation> input, std::vector<dfx_runtime_expr> exprs, SchemaInfo schema)
     : input_(std::move(input)), exprs_(std::move(exprs)), schema_(std::move(schema)) {
-  builder_.reset(new ProgramBuilder(input_->schema()));
   passthrough_.assign(exprs_.size(), -1);
   operands_.assign(exprs_.size(), kNoOperand);
   out_dtype_.assign(exprs_.size(), DFX_TYPE_NONE);
@@ -522,7 +521,24 @@ ProjectRelation::ProjectRelation(std::unique_ptr<Relation> input, std::vector<df
       continue;
     }
     int dt = DFX_TYPE_NONE;
-    deferred_ = builder_->add(e, e.root, &operands_[i], &dt);
+    Status st = Status::Err(DFX_NOT_IMPLEMENTED, "");
+    if (!groups_.empty() && groups_.back().outputs.size() < (size_t)kMaxOut) {
+      // try to extend the current fused program; roll back if it would exceed the device limits
+      std::unique_ptr<ProgramBuilder> trial(new ProgramBuilder(*groups_.back().builder));
+      st = trial->add(e, e.root, &operands_[i], &dt);
+      if (st.ok()) groups_.back().builder = std::move(trial);
+    }
+    if (!st.ok() && st.code == DFX_NOT_IMPLEMENTED) {
+      Group g;
+      g.builder.reset(new ProgramBuilder(input_->schema()));
+      st = g.builder->add(e, e.root, &operands_[i], &dt);
+      if (st.ok()) groups_.push_back(std::move(g));
+    }
+    if (!st.ok()) {
+      deferred_ = st;
+      break;
+    }
+    groups_.back().outputs.push_back(i);
     out_dtype_[i] = dt;
   }
   // the output schema is rebuilt from the expressions (projection.rs:52-57): names from
@@ -559,35 +575,35 @@ Status ProjectRelation::next(DeviceBatch* out, bool* has) {
   out->num_rows = n;
   out->columns.clear();
   out->columns.resize(exprs_.size());
-  std::vector<size_t> computed;
+  bool any_computed = false;
   for (size_t i = 0; i < exprs_.size(); ++i) {
     if (passthrough_[i] >= 0) out->columns[i] = in.columns[passthrough_[i]];
-    else computed.push_back(i);
+    else any_computed = true;
   }
-  if (computed.empty() || n == 0) {
-    for (size_t i : computed) {
+  if (!any_computed || n == 0) {
+    for (size_t i = 0; i < exprs_.size(); ++i) {
+      if (passthrough_[i] >= 0) continue;
       out->columns[i].dtype = out_dtype_[i];
       out->columns[i].length = 0;
     }
     *has = true;
     return Status::OK();
   }
-  DevProgram prog;
-  DevColumns cols;
-  DFX_RETURN_IF_ERROR(builder_->bind(in, &prog, &cols));
   if (!ctrl_) DFX_RETURN_IF_ERROR(alloc_zeroed_ctrl(&ctrl_));
   const int64_t n_words = (n + 63) / 64;
-  double in_bytes = 0;
-  for (int ci : builder_->columns()) in_bytes += (double)n * (in.columns[ci].dtype == DFX_BOOLEAN ? 0.125 : dtype_width(in.columns[ci].dtype));
   Status st;
-  for (size_t base = 0; base < computed.size(); base += kMaxOut) {
+  for (const Group& g : groups_) {
+    DevProgram prog;
+    DevColumns cols;
+    DFX_RETURN_IF_ERROR(g.builder->bind(in, &prog, &cols));
+    double in_bytes = 0;
+    for (int ci : g.builder->columns()) in_bytes += (double)n * (in.columns[ci].dtype == DFX_BOOLEAN ? 0.125 : dtype_width(in.columns[ci].dtype));
     DevProjectPlan plan;
     memset(&plan, 0, sizeof(plan));
     double out_bytes = 0;
-    const size_t cnt = std::min((size_t)kMaxOut, computed.size() - base);
-    plan.n_out = (int32_t)cnt;
-    for (size_t k = 0; k < cnt; ++k) {
-      const size_t i = computed[base + k];
+    plan.n_out = (int32_t)g.outputs.size();
+    for (size_t k = 0; k < g.outputs.size(); ++k) {
+      const size_t i = g.outputs[k];
       DeviceColumn& oc = out->columns[i];
       oc.dtype = out_dtype_[i];
       oc.length = n;

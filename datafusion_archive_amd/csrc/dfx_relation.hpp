@@ -73,7 +73,13 @@ class ProjectRelation : public Relation {
   std::unique_ptr<Relation> input_;
   std::vector<dfx_runtime_expr> exprs_;
   SchemaInfo schema_;
-  std::unique_ptr<ProgramBuilder> builder_;
+  // computed outputs are packed greedily into fused programs (each within the device program
+  // limits: kMaxRegs computed values, kMaxCols columns, kMaxOut outputs)
+  struct Group {
+    std::unique_ptr<ProgramBuilder> builder;
+    std::vector<size_t> outputs;  // indices into exprs_
+  };
+  std::vector<Group> groups_;
   std::vector<int> passthrough_;      // >= 0: plain column reference (Arc clone in the reference)
   std::vector<uint8_t> operands_;     // computed outputs
   std::vector<int> out_dtype_;

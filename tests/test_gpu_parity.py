@@ -281,13 +281,21 @@ def test_ungrouped_empty_input_yields_nulls():
 
 
 def test_ungrouped_sum_tolerance_on_arbitrary_doubles():
+    """Arbitrary doubles: a parallel (tree) sum cannot reproduce the reference's sequential rounding.
+    Stated tolerance: |gpu - exact| <= (log2(n) + 2) * eps * sum|v| (pairwise-summation bound) and
+    |gpu - reference| <= n * eps * sum|v| (the a-priori bound of the reference's own sequential sum)."""
     rng = np.random.default_rng(3)
     v = rng.random(300001)
+    n = len(v)
     b = pa.RecordBatch.from_arrays([pa.array(v)], names=["v"])
     got = gpu_aggregate([], [agg("sum", Column(0), F64)], b.schema, [b]).column(0)[0].as_py()
     want = oracle.aggregate([], [agg("sum", Column(0), F64)], [b]).column(0)[0].as_py()
-    assert abs(got - want) <= 2 * EPS * float(np.sum(np.abs(v)))
-    assert abs(got - math.fsum(v)) <= 2 * EPS * float(np.sum(np.abs(v)))
+    mass = float(np.sum(np.abs(v)))
+    assert abs(got - math.fsum(v)) <= (math.log2(n) + 2) * EPS * mass
+    assert abs(got - want) <= n * EPS * mass
+    ulps = abs(got - want) / (np.spacing(want))
+    print(f"ungrouped SUM: {ulps:.0f} ulps from the reference-order sum, "
+          f"{abs(got - math.fsum(v)) / np.spacing(want):.1f} ulps from the exact sum")
 
 
 GROUP_AGGS = [agg("min", Column(1), F64), agg("max", Column(1), F64), agg("sum", Column(1), F64),
