@@ -127,19 +127,3 @@ hipError_t launch_reduce(const DevProgram& P, const DevColumns& C, const DevAggP
 
 
 }  // namespace dfx
-hipError_t launch_reduce(const DevProgram& P, const DevColumns& C, const DevAggPlan& plan, const DevTable& T,
-                         int64_t n, uint64_t* partial, uint32_t* ctrl, double algo_bytes, hipStream_t s) {
-  if (n <= 0) return hipSuccess;
-  Scope sc(KID_REDUCE, s, algo_bytes);
-  const int grid = stream_grid((n + kBlock - 1) / kBlock, 8);
-#define DFX_REDUCE(B, UU, NM) hipLaunchKernelGGL((k_reduce<B, UU, NM>), dim3(grid), dim3(kBlock), 0, s, P, C, plan, T, n, partial, ctrl)
-  const bool small = T.na <= 2;
-  if (P.n_cols <= 2) { if (small) DFX_REDUCE(2, 8, 2); else DFX_REDUCE(2, 8, 8); }
-  else if (P.n_cols <= 4) { if (small) DFX_REDUCE(4, 4, 2); else DFX_REDUCE(4, 4, 8); }
-  else { if (small) DFX_REDUCE(8, 2, 2); else DFX_REDUCE(8, 2, 8); }
-#undef DFX_REDUCE
-  return hipGetLastError();
-}
-
-
-}  // namespace dfx
