@@ -37,6 +37,7 @@ struct AggregateRelation::Impl {
   std::vector<dfx_runtime_expr> group, aggr;
   std::unique_ptr<ProgramBuilder> builder;
   DevAggPlan plan;
+  DevFastPlan fast;
   Status deferred;
   bool done = false;
   bool built = false;
@@ -75,6 +76,7 @@ struct AggregateRelation::Impl {
 Status AggregateRelation::Impl::setup(const SchemaInfo& input_schema) {
   builder.reset(new ProgramBuilder(input_schema));
   memset(&plan, 0, sizeof(plan));
+  memset(&fast, 0, sizeof(fast));
   plan.pred = kNoOperand;
   kw = (int)group.size();
   na = (int)aggr.size();
@@ -161,6 +163,7 @@ Status AggregateRelation::Impl::setup(const SchemaInfo& input_schema) {
       }
     }
   }
+  builder->build_fast(plan.pred, plan.key, kw, plan.arg, na, &fast);
   return Status::OK();
 }
 
@@ -307,7 +310,9 @@ Status AggregateRelation::Impl::launch_rows(const DeviceBatch& b, const DevProgr
     p.lds_slots = 0;
     p.lds_copies = 1;
   }
-  DFX_HIP(launch_hash_agg(prog, cols, p, T, spill, n, bytes, s));
+  DevFastPlan fp = fast;
+  if (!agg_options().fast) fp.valid = 0;
+  DFX_HIP(launch_hash_agg(prog, fp, cols, p, T, spill, n, bytes, s));
   (void)b;
   return Status::OK();
 }
@@ -322,7 +327,9 @@ Status AggregateRelation::Impl::consume_batch(const DeviceBatch& b) {
   if (kw == 0) {
     double bytes = 0;
     for (int i = 0; i < prog.n_cols; ++i) bytes += (double)n * (prog.col_dtype[i] == T_BOOL ? 0.125 : dtype_width(prog.col_dtype[i]));
-    DFX_HIP(launch_reduce(prog, cols, plan, T, n, (uint64_t*)partial.get(), (uint32_t*)ctrl.get(), bytes, s));
+    DevFastPlan fp = fast;
+    if (!agg_options().fast) fp.valid = 0;
+    DFX_HIP(launch_reduce(prog, fp, cols, plan, T, n, (uint64_t*)partial.get(), (uint32_t*)ctrl.get(), bytes, s));
     DFX_HIP(launch_reduce_fold(T, (const uint8_t*)dev_arg_dtype.get(), (const uint8_t*)dev_func.get(),
                                (uint64_t*)partial.get(), (uint64_t*)state.get(), s));
     rows_seen += n;

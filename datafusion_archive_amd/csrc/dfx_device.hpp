@@ -62,6 +62,41 @@ struct DevColumns {
   DevColumn c[kMaxCols];
 };
 
+// ---- shape-specialised fast plan ------------------------------------------------------------
+// Most scans have a fixed shape: a conjunction of `column <op> literal` comparisons, plain-column
+// GROUP BY keys, and aggregate arguments that are a column or a short product of
+// (column | literal +- column) factors (TPC-H Q1: price * (1 - disc) * (1 + tax)).  For these the
+// host derives a DevFastPlan from the SSA program; the kernels then evaluate it with straight-line
+// code (no bytecode loop, almost no scalar work).  Anything else, and any batch with nulls, runs
+// the generic interpreter.  Both produce identical results (tests compare them).
+enum : uint8_t {
+  FF_NONE = 0, FF_COL = 1, FF_IMM_MINUS_COL = 2, FF_COL_PLUS_IMM = 3, FF_COL_MINUS_IMM = 4, FF_COL_TIMES_IMM = 5
+};
+struct DevFastTerm {
+  uint8_t col;    // column slot
+  uint8_t dtype;  // column dtype (compare class)
+  uint8_t m;      // three-way mask: 1 less, 2 equal, 4 greater
+  uint8_t inv;    // 1: NotEq
+};
+struct DevFastFactor {
+  uint8_t kind;  // FF_*
+  uint8_t col;
+};
+struct DevFastArg {
+  uint8_t nf;  // 1..3 factors multiplied left to right; nf == 1 && FF_COL: the plain column
+  uint8_t pad;
+  DevFastFactor f[3];
+};
+struct DevFastPlan {
+  int32_t valid;  // 0: shape not covered
+  int32_t np;     // predicate terms (0: no predicate)
+  DevFastTerm term[4];
+  uint64_t term_imm[4];
+  uint8_t keycol[kMaxKeys];
+  DevFastArg arg[kMaxAggs];
+  uint64_t arg_imm[kMaxAggs][3];
+};
+
 // ---- aggregation ----------------------------------------------------------------------------
 // Every accumulator is one 64-bit word updated with ONE hardware atomic per row.
 enum : uint8_t {

@@ -140,6 +140,58 @@ Status validate_scalar(const std::vector<dfx_expr_node>& nodes, int32_t idx, con
   }
 }
 
+// Rust `as` on the canonical 64-bit image (same table as the device cast_value / oracle cast_val):
+// used to fold CAST(literal) at compile time
+int64_t sat_i64(double x, int64_t lo, int64_t hi) {
+  if (x != x) return 0;
+  if (x <= (double)lo) return lo;
+  if (x >= (double)hi) return hi;
+  return (int64_t)x;
+}
+uint64_t sat_u64(double x, uint64_t hi) {
+  if (x != x) return 0;
+  if (x <= 0.0) return 0;
+  if (x >= (double)hi) return hi;
+  return (uint64_t)x;
+}
+uint64_t wrap_int(int t, uint64_t x) {
+  switch (t) {
+    case DFX_INT8: return (uint64_t)(int64_t)(int8_t)x;
+    case DFX_INT16: return (uint64_t)(int64_t)(int16_t)x;
+    case DFX_INT32: return (uint64_t)(int64_t)(int32_t)x;
+    case DFX_UINT8: return (uint64_t)(uint8_t)x;
+    case DFX_UINT16: return (uint64_t)(uint16_t)x;
+    case DFX_UINT32: return (uint64_t)(uint32_t)x;
+    default: return x;
+  }
+}
+uint64_t host_cast_value(int from, int to, uint64_t v) {
+  if (from == to) return v;
+  auto f64b = [](double d) { uint64_t b; memcpy(&b, &d, 8); return b; };
+  auto f32b = [](float f) { uint32_t b; memcpy(&b, &f, 4); return (uint64_t)b; };
+  if (dtype_is_int(from)) {
+    if (dtype_is_int(to)) return wrap_int(to, v);
+    if (to == DFX_FLOAT64) return f64b(dtype_is_signed(from) ? (double)(int64_t)v : (double)v);
+    return f32b(dtype_is_signed(from) ? (float)(int64_t)v : (float)v);
+  }
+  double x;
+  if (from == DFX_FLOAT32) { uint32_t b = (uint32_t)v; float f; memcpy(&f, &b, 4); x = (double)f; }
+  else memcpy(&x, &v, 8);
+  switch (to) {
+    case DFX_FLOAT32: return from == DFX_FLOAT32 ? v : f32b((float)x);
+    case DFX_FLOAT64: return f64b(x);
+    case DFX_INT8: return (uint64_t)sat_i64(x, -128, 127);
+    case DFX_INT16: return (uint64_t)sat_i64(x, -32768, 32767);
+    case DFX_INT32: return (uint64_t)sat_i64(x, -2147483648ll, 2147483647ll);
+    case DFX_INT64: return (uint64_t)sat_i64(x, INT64_MIN, INT64_MAX);
+    case DFX_UINT8: return sat_u64(x, 255ull);
+    case DFX_UINT16: return sat_u64(x, 65535ull);
+    case DFX_UINT32: return sat_u64(x, 4294967295ull);
+    case DFX_UINT64: return sat_u64(x, UINT64_MAX);
+    default: return 0;
+  }
+}
+
 Status copy_tree(const dfx_expr_node* nodes, int32_t n_nodes, int32_t root, dfx_runtime_expr* e) {
   if (!nodes || n_nodes <= 0 || root < 0 || root >= n_nodes)
     return Status::Err(DFX_INTERNAL_ERROR, "invalid expression tree");
@@ -226,6 +278,21 @@ Status ProgramBuilder::emit(const dfx_runtime_expr& e, int32_t idx, uint8_t* ope
           *dtype = ta;
           return Status::OK();
         }
+        if ((a >> 6) == OPK_IMM) {  // CAST(literal): folded at compile time (no per-row work at all)
+          const uint64_t bits = host_cast_value(ta, n.dtype, prog_.imm[a & 63]);
+          int slot = -1;
+          for (int i = 0; i < prog_.n_imm; ++i)
+            if (prog_.imm[i] == bits) slot = i;
+          if (slot < 0) {
+            if (prog_.n_imm >= kMaxImm)
+              return Status::Err(DFX_NOT_IMPLEMENTED, strfmt("fused expression uses more than %d literals", kMaxImm));
+            slot = prog_.n_imm++;
+            prog_.imm[slot] = bits;
+          }
+          *operand = make_operand(OPK_IMM, slot);
+          *dtype = n.dtype;
+          return Status::OK();
+        }
         ins.op = DOP_CAST;
         ins.t = (uint8_t)ta;
         ins.a = a;
@@ -270,6 +337,95 @@ Status ProgramBuilder::emit(const dfx_runtime_expr& e, int32_t idx, uint8_t* ope
     default:
       return Status::Err(DFX_EXECUTION_ERROR, "expression " + expr_debug(e.nodes, idx));
   }
+}
+
+namespace {
+bool fast_factor(const DevProgram& P, uint8_t opnd, DevFastFactor* f, uint64_t* imm) {
+  const int kind = opnd >> 6, idx = opnd & 63;
+  *imm = 0;
+  if (kind == OPK_COL) {
+    if (P.col_dtype[idx] != DFX_FLOAT64) return false;
+    f->kind = FF_COL;
+    f->col = (uint8_t)idx;
+    return true;
+  }
+  if (kind != OPK_REG) return false;
+  const DevIns& in = P.ins[idx];
+  if (in.t != DFX_FLOAT64 || in.op < DOP_ADD || in.op > DOP_MUL) return false;
+  const int ka = in.a >> 6, kb = in.b >> 6;
+  const bool col_imm = ka == OPK_COL && kb == OPK_IMM, imm_col = ka == OPK_IMM && kb == OPK_COL;
+  if (!col_imm && !imm_col) return false;
+  f->col = (uint8_t)((col_imm ? in.a : in.b) & 63);
+  *imm = P.imm[(col_imm ? in.b : in.a) & 63];
+  if (in.op == DOP_ADD) f->kind = FF_COL_PLUS_IMM;        // f64 addition commutes bit for bit
+  else if (in.op == DOP_MUL) f->kind = FF_COL_TIMES_IMM;  // so does multiplication
+  else f->kind = col_imm ? FF_COL_MINUS_IMM : FF_IMM_MINUS_COL;
+  return true;
+}
+
+// left-nested product ((f0 * f1) * f2) of factors, evaluated in the tree's own association
+bool fast_product(const DevProgram& P, uint8_t opnd, DevFastArg* A, uint64_t* imms) {
+  DevFastFactor f;
+  uint64_t imm;
+  if (fast_factor(P, opnd, &f, &imm)) {
+    A->nf = 1;
+    A->f[0] = f;
+    imms[0] = imm;
+    return true;
+  }
+  if ((opnd >> 6) != OPK_REG) return false;
+  const DevIns& in = P.ins[opnd & 63];
+  if (in.op != DOP_MUL || in.t != DFX_FLOAT64) return false;
+  if (!fast_product(P, in.a, A, imms)) return false;
+  if (A->nf >= 3) return false;
+  if (!fast_factor(P, in.b, &f, &imm)) return false;
+  A->f[A->nf] = f;
+  imms[A->nf] = imm;
+  A->nf++;
+  return true;
+}
+
+bool fast_terms(const DevProgram& P, uint8_t opnd, DevFastPlan* F) {
+  if ((opnd >> 6) != OPK_REG) return false;
+  const DevIns& in = P.ins[opnd & 63];
+  if (in.op == DOP_AND) return fast_terms(P, in.a, F) && fast_terms(P, in.b, F);
+  if (in.op > DOP_GE) return false;
+  const int ka = in.a >> 6, kb = in.b >> 6;
+  const bool col_imm = ka == OPK_COL && kb == OPK_IMM, imm_col = ka == OPK_IMM && kb == OPK_COL;
+  if ((!col_imm && !imm_col) || F->np >= 4) return false;
+  int op = in.op;
+  if (imm_col) {  // literal on the left: mirror the operator
+    op = op == DOP_LT ? DOP_GT : op == DOP_LE ? DOP_GE : op == DOP_GT ? DOP_LT : op == DOP_GE ? DOP_LE : op;
+  }
+  DevFastTerm& t = F->term[F->np];
+  t.col = (uint8_t)((col_imm ? in.a : in.b) & 63);
+  t.dtype = in.t;
+  t.m = op == DOP_EQ || op == DOP_NE ? 2 : op == DOP_LT ? 1 : op == DOP_LE ? 3 : op == DOP_GT ? 4 : 6;
+  t.inv = op == DOP_NE ? 1 : 0;
+  F->term_imm[F->np] = P.imm[(col_imm ? in.b : in.a) & 63];
+  F->np++;
+  return true;
+}
+}  // namespace
+
+void ProgramBuilder::build_fast(uint8_t pred, const uint8_t* keys, int kw, const uint8_t* args, int na,
+                                DevFastPlan* F) const {
+  memset(F, 0, sizeof(*F));
+  if (pred != kNoOperand && !fast_terms(prog_, pred, F)) return;
+  for (int k = 0; k < kw; ++k) {
+    if ((keys[k] >> 6) != OPK_COL) return;
+    F->keycol[k] = (uint8_t)(keys[k] & 63);
+  }
+  for (int a = 0; a < na; ++a) {
+    if ((args[a] >> 6) == OPK_COL) {  // plain column of any type
+      F->arg[a].nf = 1;
+      F->arg[a].f[0].kind = FF_COL;
+      F->arg[a].f[0].col = (uint8_t)(args[a] & 63);
+      continue;
+    }
+    if (!fast_product(prog_, args[a], &F->arg[a], F->arg_imm[a])) return;
+  }
+  F->valid = 1;
 }
 
 Status ProgramBuilder::bind(const DeviceBatch& batch, DevProgram* prog, DevColumns* cols) const {

@@ -169,6 +169,10 @@ class ProgramBuilder {
   const std::vector<int>& columns() const { return cols_; }
   // bind the batch's buffers; sets has_nulls
   Status bind(const DeviceBatch& batch, DevProgram* prog, DevColumns* cols) const;
+  // Derive the shape-specialised plan (dfx_device.hpp: DevFastPlan) from the SSA program: pred is a
+  // conjunction of `column <op> literal`, keys are plain columns, arguments are a column or a product
+  // of up to three (column | literal +- column | column * literal) factors.  F->valid = 0 otherwise.
+  void build_fast(uint8_t pred, const uint8_t* keys, int kw, const uint8_t* args, int na, DevFastPlan* F) const;
 
  private:
   Status emit(const dfx_runtime_expr& e, int32_t idx, uint8_t* operand, int* dtype);

@@ -35,13 +35,14 @@ uint64_t host_hash_keys(const uint64_t* key, int kw) {
 // ---------------------------------------------------------------------------------------------
 // K1 predicate_mask
 // ---------------------------------------------------------------------------------------------
-template <int BANK, int U>
-__global__ __launch_bounds__(kBlock) void k_predicate_mask(const DevProgram P, const DevColumns C,
+template <typename POL>
+__global__ __launch_bounds__(kBlock) void k_predicate_mask(const DevProgram P, const DevFastPlan F, const DevColumns C,
                                                            const uint8_t pred, const int64_t n,
                                                            uint64_t* __restrict__ mask_words,
                                                            uint32_t* __restrict__ tile_counts,
                                                            uint32_t* __restrict__ ctrl) {
-  typedef typename Bank<BANK>::type COLV;
+  typedef typename POL::COLV COLV;
+  constexpr int U = POL::U;
   __shared__ uint32_t wave_cnt[kBlock / 64];
   const int lane = lane_id();
   const int wave = threadIdx.x >> 6;
@@ -51,21 +52,24 @@ __global__ __launch_bounds__(kBlock) void k_predicate_mask(const DevProgram P, c
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     uint32_t cnt = 0;
     for (int i0 = 0; i0 < 16; i0 += U) {
+      const int64_t w0 = tile * 64 + wave * 16 + i0;
       COLV col[U];
       uint32_t cv[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int64_t row = (tile * 64 + wave * 16 + i0 + u) * 64 + lane;
+      FOR_U {
+        const int64_t row = (w0 + u) * 64 + lane;
         load_columns(P, C, row, row < n, col[u], cv[u]);
       }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int64_t w = tile * 64 + wave * 16 + i0 + u;
+#pragma nounroll
+      for (int uu = 0; uu < U; ++uu) {
+        COLV cur;
+        uint32_t curv;
+        DFX_SELECT_BANK(uu, col, cv, cur, curv)
+        const int64_t w = w0 + uu;
         const bool inb = w * 64 + lane < n;
         u64x16 reg;
-        uint32_t rv;
-        run_program(P, col[u], reg, cv[u], rv, inb, err);
-        const bool pass = inb && eval_predicate(P, col[u], reg, cv[u], rv, pred);
+        uint32_t rv = 0;
+        POL::eval(P, F, cur, curv, reg, rv, inb, err);
+        const bool pass = inb && POL::pass(P, F, pred, cur, curv, reg, rv);
         const uint64_t word = __ballot(pass);
         if (lane == 0 && w < n_words) mask_words[w] = word;
         cnt += (uint32_t)__popcll(word);
@@ -226,50 +230,54 @@ __global__ __launch_bounds__(kBlock) void k_utf8_gather(const uint8_t* __restric
 // ---------------------------------------------------------------------------------------------
 // K2/K3 project
 // ---------------------------------------------------------------------------------------------
-template <int BANK, int U>
+template <typename POL>
 __global__ __launch_bounds__(kBlock) void k_project(const DevProgram P, const DevColumns C,
                                                     const DevProjectPlan plan, const int64_t n,
                                                     uint32_t* __restrict__ ctrl) {
-  typedef typename Bank<BANK>::type COLV;
+  typedef typename POL::COLV COLV;
+  constexpr int U = POL::U;
   const int lane = lane_id();
   const int64_t n_words = (n + 63) >> 6;
   const int64_t wave_global = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
   const int64_t n_waves = ((int64_t)gridDim.x * kBlock) >> 6;
+  DevFastPlan F_unused;
+  F_unused.valid = 0;
   uint32_t err = 0;
   for (int64_t w0 = wave_global * U; w0 < n_words; w0 += n_waves * U) {
     COLV col[U];
     uint32_t cv[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
+    FOR_U {
       const int64_t row = (w0 + u) * 64 + lane;
       load_columns(P, C, row, row < n, col[u], cv[u]);
     }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int64_t w = w0 + u;
+#pragma nounroll
+    for (int uu = 0; uu < U; ++uu) {
+      const int64_t w = w0 + uu;
+      if (w >= n_words) break;  // wave-uniform
+      COLV cur;
+      uint32_t curv;
+      DFX_SELECT_BANK(uu, col, cv, cur, curv)
       const int64_t row = w * 64 + lane;
       const bool inb = row < n;
-      if (w < n_words) {  // wave-uniform
-        u64x16 reg;
-        uint32_t rv;
-        run_program(P, col[u], reg, cv[u], rv, inb, err);
+      u64x16 reg;
+      uint32_t rv = 0;
+      POL::eval(P, F_unused, cur, curv, reg, rv, inb, err);
 #pragma unroll
-        for (int o = 0; o < kMaxOut; ++o) {
-          if (o < plan.n_out) {
-            uint64_t v;
-            bool valid;
-            fetch(P, col[u], reg, cv[u], rv, plan.out[o], v, valid);
-            const uint8_t t = plan.out_dtype[o];
-            if (t == T_BOOL) {
-              const uint64_t bits = __ballot(inb && (v & 1));
-              if (lane == 0) ((uint64_t*)plan.out_values[o])[w] = bits;
-            } else if (inb) {
-              store_typed(t, plan.out_values[o], row, v);
-            }
-            if (plan.out_validity[o] != nullptr) {
-              const uint64_t vb = __ballot(inb && valid);
-              if (lane == 0) plan.out_validity[o][w] = vb;
-            }
+      for (int o = 0; o < kMaxOut; ++o) {
+        if (o < plan.n_out) {
+          uint64_t v;
+          bool valid;
+          fetch(P, cur, reg, curv, rv, plan.out[o], v, valid);
+          const uint8_t t = plan.out_dtype[o];
+          if (t == T_BOOL) {
+            const uint64_t bits = __ballot(inb && (v & 1));
+            if (lane == 0) ((uint64_t*)plan.out_values[o])[w] = bits;
+          } else if (inb) {
+            store_typed(t, plan.out_values[o], row, v);
+          }
+          if (plan.out_validity[o] != nullptr) {
+            const uint64_t vb = __ballot(inb && valid);
+            if (lane == 0) plan.out_validity[o][w] = vb;
           }
         }
       }
@@ -489,19 +497,19 @@ int stream_grid(int64_t units, int per_cu) {
   return (int)(units < cap ? units : cap);
 }
 
-hipError_t launch_predicate_mask(const DevProgram& P, const DevColumns& C, uint8_t pred, int64_t n,
-                                 uint64_t* mask_words, uint32_t* tile_counts, uint32_t* ctrl,
+hipError_t launch_predicate_mask(const DevProgram& P, const DevFastPlan& fast, const DevColumns& C, uint8_t pred,
+                                 int64_t n, uint64_t* mask_words, uint32_t* tile_counts, uint32_t* ctrl,
                                  double algo_bytes, hipStream_t s) {
   if (n <= 0) return hipSuccess;
   Scope sc(KID_PREDICATE_MASK, s, algo_bytes);
   const int64_t tiles = (n + kTileRows - 1) / kTileRows;
   const int grid = stream_grid(tiles, 8);
-  if (P.n_cols <= 2)
-    hipLaunchKernelGGL((k_predicate_mask<2, 8>), dim3(grid), dim3(kBlock), 0, s, P, C, pred, n, mask_words, tile_counts, ctrl);
-  else if (P.n_cols <= 4)
-    hipLaunchKernelGGL((k_predicate_mask<4, 4>), dim3(grid), dim3(kBlock), 0, s, P, C, pred, n, mask_words, tile_counts, ctrl);
-  else
-    hipLaunchKernelGGL((k_predicate_mask<8, 2>), dim3(grid), dim3(kBlock), 0, s, P, C, pred, n, mask_words, tile_counts, ctrl);
+#define DFX_MASK(POL) hipLaunchKernelGGL((k_predicate_mask<POL>), dim3(grid), dim3(kBlock), 0, s, P, fast, C, pred, n, mask_words, tile_counts, ctrl)
+  const bool use_fast = fast.valid && !P.has_nulls;
+  if (P.n_cols <= 2) { if (use_fast) DFX_MASK(DFX_ARG(FastPolicy<2, 8>)); else DFX_MASK(DFX_ARG(InterpPolicy<2, 8>)); }
+  else if (P.n_cols <= 4) { if (use_fast) DFX_MASK(DFX_ARG(FastPolicy<4, 4>)); else DFX_MASK(DFX_ARG(InterpPolicy<4, 4>)); }
+  else { if (use_fast) DFX_MASK(DFX_ARG(FastPolicy<8, 2>)); else DFX_MASK(DFX_ARG(InterpPolicy<8, 2>)); }
+#undef DFX_MASK
   return hipGetLastError();
 }
 
@@ -559,11 +567,11 @@ hipError_t launch_project(const DevProgram& P, const DevColumns& C, const DevPro
   Scope sc(KID_PROJECT, s, algo_bytes);
   const int grid = stream_grid((n + kBlock - 1) / kBlock, 8);
   if (P.n_cols <= 2)
-    hipLaunchKernelGGL((k_project<2, 8>), dim3(grid), dim3(kBlock), 0, s, P, C, plan, n, ctrl);
+    hipLaunchKernelGGL((k_project<InterpPolicy<2, 8>>), dim3(grid), dim3(kBlock), 0, s, P, C, plan, n, ctrl);
   else if (P.n_cols <= 4)
-    hipLaunchKernelGGL((k_project<4, 4>), dim3(grid), dim3(kBlock), 0, s, P, C, plan, n, ctrl);
+    hipLaunchKernelGGL((k_project<InterpPolicy<4, 4>>), dim3(grid), dim3(kBlock), 0, s, P, C, plan, n, ctrl);
   else
-    hipLaunchKernelGGL((k_project<8, 2>), dim3(grid), dim3(kBlock), 0, s, P, C, plan, n, ctrl);
+    hipLaunchKernelGGL((k_project<InterpPolicy<8, 2>>), dim3(grid), dim3(kBlock), 0, s, P, C, plan, n, ctrl);
   return hipGetLastError();
 }
 
@@ -588,11 +596,11 @@ DFX_DECLARE_TABLE_KW(4)
     default: return hipErrorInvalidValue;    \
   }
 
-hipError_t launch_hash_agg(const DevProgram& P, const DevColumns& C, const DevAggPlan& plan, const DevTable& T,
-                           const DevRows& spill, int64_t n, double algo_bytes, hipStream_t s) {
+hipError_t launch_hash_agg(const DevProgram& P, const DevFastPlan& fast, const DevColumns& C, const DevAggPlan& plan,
+                           const DevTable& T, const DevRows& spill, int64_t n, double algo_bytes, hipStream_t s) {
   if (n <= 0) return hipSuccess;
   Scope sc(KID_HASH_AGG, s, algo_bytes);
-#define CALL(K) table_hash_agg<K>(P, C, plan, T, spill, n, s)
+#define CALL(K) table_hash_agg<K>(P, fast, C, plan, T, spill, n, s)
   DFX_KW_DISPATCH(T.kw, CALL)
 #undef CALL
 }

@@ -9,12 +9,13 @@ namespace dfx {
 // partial layout per aggregate a: partial[4a+0] accumulator word (pre-filled with the identity),
 // [4a+1] number of valid arguments, [4a+2] min over (row << 1 | is_nan) of valid rows (u64::MAX
 // when none): arrow 0.12 min/max scan with `<` / `>`, so a NaN in the first valid slot sticks.
-template <int BANK, int U, int NAMAX>
-__global__ __launch_bounds__(kBlock) void k_reduce(const DevProgram P, const DevColumns C,
+template <typename POL, int NAMAX>
+__global__ __launch_bounds__(kBlock) void k_reduce(const DevProgram P, const DevFastPlan F, const DevColumns C,
                                                    const DevAggPlan plan, const DevTable T,
                                                    const int64_t n, uint64_t* __restrict__ partial,
                                                    uint32_t* __restrict__ ctrl) {
-  typedef typename Bank<BANK>::type COLV;
+  typedef typename POL::COLV COLV;
+  constexpr int U = POL::U;
   __shared__ uint64_t lds[kBlock / 64][kMaxAggs * 3];
   const int lane = lane_id();
   const int wave = threadIdx.x >> 6;
@@ -33,19 +34,21 @@ __global__ __launch_bounds__(kBlock) void k_reduce(const DevProgram P, const Dev
   for (int64_t w0 = wave_global * U; w0 < n_words; w0 += n_waves * U) {
     COLV col[U];
     uint32_t cv[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
+    FOR_U {
       const int64_t row = (w0 + u) * 64 + lane;
       load_columns(P, C, row, row < n, col[u], cv[u]);
     }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int64_t row = (w0 + u) * 64 + lane;
+#pragma nounroll
+    for (int uu = 0; uu < U; ++uu) {
+      COLV cur;
+      uint32_t curv;
+      DFX_SELECT_BANK(uu, col, cv, cur, curv)
+      const int64_t row = (w0 + uu) * 64 + lane;
       const bool inb = row < n;
       u64x16 reg;
-      uint32_t rv;
-      run_program(P, col[u], reg, cv[u], rv, inb, err);
-      const bool pass = inb && eval_predicate(P, col[u], reg, cv[u], rv, plan.pred);
+      uint32_t rv = 0;
+      POL::eval(P, F, cur, curv, reg, rv, inb, err);
+      const bool pass = inb && POL::pass(P, F, plan.pred, cur, curv, reg, rv);
       if (pass) {
         ++passed;
 #pragma unroll
@@ -53,7 +56,7 @@ __global__ __launch_bounds__(kBlock) void k_reduce(const DevProgram P, const Dev
           if (a < T.na) {
             uint64_t v;
             bool valid;
-            fetch(P, col[u], reg, cv[u], rv, plan.arg[a], v, valid);
+            POL::arg(P, F, plan.arg[a], a, cur, curv, reg, rv, v, valid);
             const uint8_t xf = T.val_xform[a];
             if (xf == VT_COUNT_VALID) {
               acc[a] += valid ? 1ull : 0ull;
@@ -111,19 +114,21 @@ __global__ __launch_bounds__(kBlock) void k_reduce(const DevProgram P, const Dev
   if (err) atomicOr(&ctrl[CTRL_ERROR], err);
 }
 
-hipError_t launch_reduce(const DevProgram& P, const DevColumns& C, const DevAggPlan& plan, const DevTable& T,
-                         int64_t n, uint64_t* partial, uint32_t* ctrl, double algo_bytes, hipStream_t s) {
+hipError_t launch_reduce(const DevProgram& P, const DevFastPlan& fast, const DevColumns& C, const DevAggPlan& plan,
+                         const DevTable& T, int64_t n, uint64_t* partial, uint32_t* ctrl, double algo_bytes,
+                         hipStream_t s) {
   if (n <= 0) return hipSuccess;
   Scope sc(KID_REDUCE, s, algo_bytes);
   const int grid = stream_grid((n + kBlock - 1) / kBlock, 8);
-#define DFX_REDUCE(B, UU, NM) hipLaunchKernelGGL((k_reduce<B, UU, NM>), dim3(grid), dim3(kBlock), 0, s, P, C, plan, T, n, partial, ctrl)
-  const bool small = T.na <= 2;
-  if (P.n_cols <= 2) { if (small) DFX_REDUCE(2, 8, 2); else DFX_REDUCE(2, 8, 8); }
-  else if (P.n_cols <= 4) { if (small) DFX_REDUCE(4, 4, 2); else DFX_REDUCE(4, 4, 8); }
-  else { if (small) DFX_REDUCE(8, 2, 2); else DFX_REDUCE(8, 2, 8); }
+#define DFX_REDUCE(POL, NM) hipLaunchKernelGGL((k_reduce<POL, NM>), dim3(grid), dim3(kBlock), 0, s, P, fast, C, plan, T, n, partial, ctrl)
+#define DFX_REDUCE_NA(POL) do { if (T.na <= 2) DFX_REDUCE(DFX_ARG(POL), 2); else DFX_REDUCE(DFX_ARG(POL), 8); } while (0)
+  const bool use_fast = fast.valid && !P.has_nulls;
+  if (P.n_cols <= 2) { if (use_fast) DFX_REDUCE_NA(DFX_ARG(FastPolicy<2, 8>)); else DFX_REDUCE_NA(DFX_ARG(InterpPolicy<2, 8>)); }
+  else if (P.n_cols <= 4) { if (use_fast) DFX_REDUCE_NA(DFX_ARG(FastPolicy<4, 4>)); else DFX_REDUCE_NA(DFX_ARG(InterpPolicy<4, 4>)); }
+  else { if (use_fast) DFX_REDUCE_NA(DFX_ARG(FastPolicy<8, 2>)); else DFX_REDUCE_NA(DFX_ARG(InterpPolicy<8, 2>)); }
+#undef DFX_REDUCE_NA
 #undef DFX_REDUCE
   return hipGetLastError();
 }
-
 
 }  // namespace dfx

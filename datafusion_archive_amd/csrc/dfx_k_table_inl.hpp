@@ -12,11 +12,12 @@ namespace dfx {
 // For KW > 1 an extra state[S] (uint32) follows.  S = plan.lds_slots (power of two), split into
 // plan.lds_copies lane-replicated sub-tables so that few-group inputs (TPC-H Q1: <= 6 groups) do not
 // serialise 64 lanes on one LDS address.
-template <int KW, int BANK, int U>
-__global__ __launch_bounds__(kBlock) void k_hash_agg(const DevProgram P, const DevColumns C,
+template <int KW, typename POL>
+__global__ __launch_bounds__(kBlock) void k_hash_agg(const DevProgram P, const DevFastPlan F, const DevColumns C,
                                                      const DevAggPlan plan, const DevTable T,
                                                      const DevRows spill, const int64_t n) {
-  typedef typename Bank<BANK>::type COLV;
+  typedef typename POL::COLV COLV;
+  constexpr int U = POL::U;
   extern __shared__ __attribute__((aligned(16))) uint64_t lds[];
   const int S = plan.lds_slots;
   uint64_t* lkeys = lds;
@@ -52,33 +53,34 @@ __global__ __launch_bounds__(kBlock) void k_hash_agg(const DevProgram P, const D
     }
     COLV col[U];
     uint32_t cv[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
+    FOR_U {
       const int64_t row = (w0 + u) * 64 + lane;
       load_columns(P, C, row, row < n, col[u], cv[u]);
     }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int64_t row = (w0 + u) * 64 + lane;
+    // ONE copy of the evaluation + table code: a run-time loop over the U prefetched row-groups
+#pragma nounroll
+    for (int uu = 0; uu < U; ++uu) {
+      COLV cur;
+      uint32_t curv;
+      DFX_SELECT_BANK(uu, col, cv, cur, curv)
+      const int64_t row = (w0 + uu) * 64 + lane;
       const bool inb = row < n;
       u64x16 reg;
-      uint32_t rv;
-      run_program(P, col[u], reg, cv[u], rv, inb, err);
-      const bool pass = inb && eval_predicate(P, col[u], reg, cv[u], rv, plan.pred);
+      uint32_t rv = 0;
+      POL::eval(P, F, cur, curv, reg, rv, inb, err);
+      const bool pass = inb && POL::pass(P, F, plan.pred, cur, curv, reg, rv);
       uint64_t key[KW];
       uint64_t val[kMaxAggs];
-  #pragma unroll
-      for (int k = 0; k < KW; ++k) {
-        bool kvalid;
-        fetch(P, col[u], reg, cv[u], rv, plan.key[k], key[k], kvalid);  // key nulls are not checked (aggregate.rs:807-852)
-      }
-  #pragma unroll
+#pragma unroll
+      for (int k = 0; k < KW; ++k)  // key nulls are not checked (aggregate.rs:807-852)
+        key[k] = POL::key(P, F, plan.key[k], k, cur, curv, reg, rv);
+#pragma unroll
       for (int a = 0; a < kMaxAggs; ++a) {
         val[a] = 0;
         if (a < T.na) {
           uint64_t v;
-          bool valid;
-          fetch(P, col[u], reg, cv[u], rv, plan.arg[a], v, valid);  // value(row) read blindly (aggregate.rs:561-603)
+          bool valid;  // value(row) read blindly (aggregate.rs:561-603)
+          POL::arg(P, F, plan.arg[a], a, cur, curv, reg, rv, v, valid);
           val[a] = transform_value(T.val_xform[a], v, valid);
         }
       }
@@ -316,8 +318,8 @@ __global__ __launch_bounds__(kBlock) void k_partial_scatter(const DevTable T, in
 // host launchers (one instantiation per KW)
 // ---------------------------------------------------------------------------------------------
 template <int KW>
-hipError_t table_hash_agg(const DevProgram& P, const DevColumns& C, const DevAggPlan& plan, const DevTable& T,
-                          const DevRows& spill, int64_t n, hipStream_t s) {
+hipError_t table_hash_agg(const DevProgram& P, const DevFastPlan& fast, const DevColumns& C, const DevAggPlan& plan,
+                          const DevTable& T, const DevRows& spill, int64_t n, hipStream_t s) {
   const int64_t n_blocks = (n + kBlock - 1) / kBlock;
   const size_t lds_bytes = plan.lds_slots > 0
                                ? (size_t)plan.lds_slots * ((size_t)(KW + T.na) * 8 + (KW > 1 ? 4 : 0))
@@ -325,12 +327,12 @@ hipError_t table_hash_agg(const DevProgram& P, const DevColumns& C, const DevAgg
   // LDS-heavy blocks: fewer, longer-lived workgroups amortise the cache init + flush
   const int per_cu = lds_bytes > 0 ? (lds_bytes > 40 * 1024 ? 2 : 4) : 8;
   const int grid = stream_grid(n_blocks, per_cu);
-  if (P.n_cols <= 2)
-    hipLaunchKernelGGL((k_hash_agg<KW, 2, 4>), dim3(grid), dim3(kBlock), lds_bytes, s, P, C, plan, T, spill, n);
-  else if (P.n_cols <= 4)
-    hipLaunchKernelGGL((k_hash_agg<KW, 4, 2>), dim3(grid), dim3(kBlock), lds_bytes, s, P, C, plan, T, spill, n);
-  else
-    hipLaunchKernelGGL((k_hash_agg<KW, 8, 2>), dim3(grid), dim3(kBlock), lds_bytes, s, P, C, plan, T, spill, n);
+#define DFX_HA(POL) hipLaunchKernelGGL((k_hash_agg<KW, POL>), dim3(grid), dim3(kBlock), lds_bytes, s, P, fast, C, plan, T, spill, n)
+  const bool use_fast = fast.valid && !P.has_nulls;
+  if (P.n_cols <= 2) { if (use_fast) DFX_HA(DFX_ARG(FastPolicy<2, 4>)); else DFX_HA(DFX_ARG(InterpPolicy<2, 4>)); }
+  else if (P.n_cols <= 4) { if (use_fast) DFX_HA(DFX_ARG(FastPolicy<4, 4>)); else DFX_HA(DFX_ARG(InterpPolicy<4, 4>)); }
+  else { if (use_fast) DFX_HA(DFX_ARG(FastPolicy<8, 2>)); else DFX_HA(DFX_ARG(InterpPolicy<8, 2>)); }
+#undef DFX_HA
   return hipGetLastError();
 }
 

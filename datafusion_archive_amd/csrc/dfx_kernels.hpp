@@ -42,8 +42,9 @@ int device_cu_count();
 // K1 predicate_mask: fused compare/AND/OR expression -> Arrow LSB bitmap (one __ballot per 64 rows)
 //   replaces comparison_ops!/boolean_ops!/literal_array! closures (expression.rs:171-243, :410-465)
 // tile_counts (may be null): popcount per 4096-row tile, for the compaction offsets.
-hipError_t launch_predicate_mask(const DevProgram& P, const DevColumns& C, uint8_t pred, int64_t n,
-                                 uint64_t* mask_words, uint32_t* tile_counts, uint32_t* ctrl,
+// fast: shape-specialised plan (valid == 0 or nulls present: the generic interpreter runs)
+hipError_t launch_predicate_mask(const DevProgram& P, const DevFastPlan& fast, const DevColumns& C, uint8_t pred,
+                                 int64_t n, uint64_t* mask_words, uint32_t* tile_counts, uint32_t* ctrl,
                                  double algo_bytes, hipStream_t s);
 
 // exclusive scan of uint32 counts into uint64 offsets (out[n] = total); tmp: >= (n/4096 + 2) u64
@@ -70,7 +71,7 @@ hipError_t launch_project(const DevProgram& P, const DevColumns& C, const DevPro
 // scalar fold (accumulate_scalar) into the running state.
 //   replaces array_min/max/sum + without_group_by (aggregate.rs:344-546, :703-785)
 // partial: na * 4 u64 words {acc, valid_count, first_valid_tag, unused}; state: na * 2 words {has, bits}
-hipError_t launch_reduce(const DevProgram& P, const DevColumns& C, const DevAggPlan& plan,
+hipError_t launch_reduce(const DevProgram& P, const DevFastPlan& fast, const DevColumns& C, const DevAggPlan& plan,
                          const DevTable& T /* kinds / xforms / inits only */, int64_t n,
                          uint64_t* partial, uint32_t* ctrl, double algo_bytes, hipStream_t s);
 hipError_t launch_reduce_fold(const DevTable& T, const uint8_t* arg_dtype, const uint8_t* func,
@@ -79,9 +80,9 @@ hipError_t launch_reduce_fold(const DevTable& T, const uint8_t* arg_dtype, const
 // K6/K7 hash_agg: (optional predicate) + group keys + aggregate arguments -> table updates, with
 // an LDS front cache per workgroup and a spill list for rows the table cannot take.
 //   replaces with_group_by + update_accumulators (aggregate.rs:787-875, :548-612)
-hipError_t launch_hash_agg(const DevProgram& P, const DevColumns& C, const DevAggPlan& plan,
-                           const DevTable& T, const DevRows& spill, int64_t n, double algo_bytes,
-                           hipStream_t s);
+hipError_t launch_hash_agg(const DevProgram& P, const DevFastPlan& fast, const DevColumns& C,
+                           const DevAggPlan& plan, const DevTable& T, const DevRows& spill, int64_t n,
+                           double algo_bytes, hipStream_t s);
 // insert pre-evaluated rows (spill replays, LDS flushes of other ranks, all-to-all imports)
 hipError_t launch_merge_rows(const DevRows& rows, int64_t row_begin, int64_t n_rows, const DevTable& T,
                              const DevRows& spill, hipStream_t s);

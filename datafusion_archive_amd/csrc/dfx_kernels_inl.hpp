@@ -300,6 +300,121 @@ DEV bool eval_predicate(const DevProgram& P, ROWSTATE_CPARAMS, uint8_t pred) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// row-source policies: how one 64-row group turns into (pass, keys, aggregate arguments)
+// ---------------------------------------------------------------------------------------------
+// Kernels are templated on a policy.  All state lives in kernel-local variables (vector VALUES,
+// see the note above); a policy is a bag of static inline functions.  Each kernel contains ONE
+// copy of the evaluation code: the U prefetched row-groups are visited by a run-time loop that
+// re-selects the group's column bank through a wave-uniform switch.
+#define FOR_U _Pragma("unroll") for (int u = 0; u < U; ++u)
+#define DFX_SELECT_BANK(uu, col, cv, cur, curv)                     \
+  switch (uu) {                                                      \
+    case 0: cur = col[0]; curv = cv[0]; break;                       \
+    case 1: cur = col[U > 1 ? 1 : 0]; curv = cv[U > 1 ? 1 : 0]; break; \
+    case 2: cur = col[U > 2 ? 2 : 0]; curv = cv[U > 2 ? 2 : 0]; break; \
+    case 3: cur = col[U > 3 ? 3 : 0]; curv = cv[U > 3 ? 3 : 0]; break; \
+    case 4: cur = col[U > 4 ? 4 : 0]; curv = cv[U > 4 ? 4 : 0]; break; \
+    case 5: cur = col[U > 5 ? 5 : 0]; curv = cv[U > 5 ? 5 : 0]; break; \
+    case 6: cur = col[U > 6 ? 6 : 0]; curv = cv[U > 6 ? 6 : 0]; break; \
+    default: cur = col[U > 7 ? 7 : 0]; curv = cv[U > 7 ? 7 : 0]; break; \
+  }
+
+// generic: the SSA register program (any expression the compiler accepts, nulls included)
+template <int BANK, int U_>
+struct InterpPolicy {
+  static constexpr int U = U_;
+  typedef typename Bank<BANK>::type COLV;
+  static DEV void eval(const DevProgram& P, const DevFastPlan&, const COLV& cur, uint32_t curv, u64x16& reg,
+                       uint32_t& rv, bool inb, uint32_t& err) {
+    COLV c = cur;
+    uint32_t cvv = curv;
+    run_program(P, c, reg, cvv, rv, inb, err);
+  }
+  static DEV bool pass(const DevProgram& P, const DevFastPlan&, uint8_t pred, const COLV& cur, uint32_t curv,
+                       const u64x16& reg, uint32_t rv) {
+    return eval_predicate(P, cur, reg, curv, rv, pred);
+  }
+  static DEV uint64_t key(const DevProgram& P, const DevFastPlan&, uint8_t opnd, int, const COLV& cur, uint32_t curv,
+                          const u64x16& reg, uint32_t rv) {
+    uint64_t v;
+    bool valid;
+    fetch(P, cur, reg, curv, rv, opnd, v, valid);
+    return v;
+  }
+  static DEV void arg(const DevProgram& P, const DevFastPlan&, uint8_t opnd, int, const COLV& cur, uint32_t curv,
+                      const u64x16& reg, uint32_t rv, uint64_t& v, bool& valid) {
+    fetch(P, cur, reg, curv, rv, opnd, v, valid);
+  }
+};
+
+// three-way compare code of two canonical values of dtype t: 1 less, 2 equal, 4 greater, 0 unordered
+DEV uint32_t cmp3(uint8_t t, uint64_t x, uint64_t y) {
+  if (t == T_F64) {
+    const double a = as_f64(x), b = as_f64(y);
+    return (a < b ? 1u : 0u) | (a == b ? 2u : 0u) | (a > b ? 4u : 0u);
+  }
+  if (t == T_F32) {
+    const float a = as_f32(x), b = as_f32(y);
+    return (a < b ? 1u : 0u) | (a == b ? 2u : 0u) | (a > b ? 4u : 0u);
+  }
+  if (t == T_U64) return (x < y ? 1u : 0u) | (x == y ? 2u : 0u) | (x > y ? 4u : 0u);
+  const int64_t a = (int64_t)x, b = (int64_t)y;
+  return (a < b ? 1u : 0u) | (a == b ? 2u : 0u) | (a > b ? 4u : 0u);
+}
+
+// shape-specialised (DevFastPlan): conjunction of `column <op> literal`, plain-column keys, column /
+// short-product arguments; no nulls.  Straight-line code, the only scalar work is reading the plan.
+template <int BANK, int U_>
+struct FastPolicy {
+  static constexpr int U = U_;
+  typedef typename Bank<BANK>::type COLV;
+  static DEV void eval(const DevProgram&, const DevFastPlan&, const COLV&, uint32_t, u64x16&, uint32_t&, bool,
+                       uint32_t&) {}
+  static DEV bool pass(const DevProgram&, const DevFastPlan& F, uint8_t, const COLV& cur, uint32_t, const u64x16&,
+                       uint32_t) {
+    uint32_t ok = 1u;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (i < F.np) {
+        const DevFastTerm t = F.term[i];
+        const uint32_t c = cmp3(t.dtype, cur[t.col & (BANK - 1)], F.term_imm[i]);
+        ok &= (((c & t.m) != 0u) ? 1u : 0u) ^ (uint32_t)t.inv;
+      }
+    }
+    return ok != 0u;
+  }
+  static DEV uint64_t key(const DevProgram&, const DevFastPlan& F, uint8_t, int k, const COLV& cur, uint32_t,
+                          const u64x16&, uint32_t) {
+    return cur[F.keycol[k] & (BANK - 1)];
+  }
+  static DEV double factor(const DevFastPlan& F, int a, int j, const COLV& cur) {
+    const DevFastFactor f = F.arg[a].f[j];
+    const double x = as_f64(cur[f.col & (BANK - 1)]);
+    const double imm = as_f64(F.arg_imm[a][j]);
+    switch (f.kind) {
+      case FF_IMM_MINUS_COL: return imm - x;
+      case FF_COL_PLUS_IMM: return x + imm;
+      case FF_COL_MINUS_IMM: return x - imm;
+      case FF_COL_TIMES_IMM: return x * imm;
+      default: return x;
+    }
+  }
+  static DEV void arg(const DevProgram&, const DevFastPlan& F, uint8_t, int a, const COLV& cur, uint32_t,
+                      const u64x16&, uint32_t, uint64_t& v, bool& valid) {
+    valid = true;
+    const DevFastArg A = F.arg[a];
+    if (A.nf == 1 && A.f[0].kind == FF_COL) {
+      v = cur[A.f[0].col & (BANK - 1)];
+      return;
+    }
+    double acc = factor(F, a, 0, cur);
+    if (A.nf > 1) acc = acc * factor(F, a, 1, cur);
+    if (A.nf > 2) acc = acc * factor(F, a, 2, cur);
+    v = f64_bits(acc);
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
 // accumulator algebra (one 64-bit word per (group, aggregate))
 // ---------------------------------------------------------------------------------------------
 // order-preserving u64 image of an f64; NaN is canonicalised so that MIN and MAX ignore it unless

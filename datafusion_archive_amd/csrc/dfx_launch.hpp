@@ -22,11 +22,12 @@ struct Scope {
 // several times over (>> 256 WGs; blocks land round-robin on the 8 XCDs), capped so the
 // grid-stride loop amortises launch and tail effects.
 int stream_grid(int64_t units, int per_cu);
+#define DFX_ARG(...) __VA_ARGS__  // protects template commas inside macro arguments
 
 // group-table kernels, one explicit instantiation per key width (dfx_k_table{1,2,3,4}.hip)
 template <int KW>
-hipError_t table_hash_agg(const DevProgram& P, const DevColumns& C, const DevAggPlan& plan, const DevTable& T,
-                          const DevRows& spill, int64_t n, hipStream_t s);
+hipError_t table_hash_agg(const DevProgram& P, const DevFastPlan& fast, const DevColumns& C, const DevAggPlan& plan,
+                          const DevTable& T, const DevRows& spill, int64_t n, hipStream_t s);
 template <int KW>
 hipError_t table_merge_rows(const DevRows& rows, int64_t row_begin, int64_t n_rows, const DevTable& T,
                             const DevRows& spill, hipStream_t s);
@@ -41,8 +42,9 @@ hipError_t table_partial_scatter(const DevTable& T, int world, const uint64_t* b
                                  const uint64_t* bucket_count, uint64_t* cursors, uint64_t* dst, hipStream_t s);
 
 #define DFX_DECLARE_TABLE_KW(KW)                                                                                   \
-  extern template hipError_t table_hash_agg<KW>(const DevProgram&, const DevColumns&, const DevAggPlan&,          \
-                                                const DevTable&, const DevRows&, int64_t, hipStream_t);           \
+  extern template hipError_t table_hash_agg<KW>(const DevProgram&, const DevFastPlan&, const DevColumns&,         \
+                                                const DevAggPlan&, const DevTable&, const DevRows&, int64_t,      \
+                                                hipStream_t);                                                     \
   extern template hipError_t table_merge_rows<KW>(const DevRows&, int64_t, int64_t, const DevTable&,              \
                                                   const DevRows&, hipStream_t);                                   \
   extern template hipError_t table_rehash<KW>(const DevTable&, const DevTable&, const DevRows&, hipStream_t);      \
@@ -52,8 +54,9 @@ hipError_t table_partial_scatter(const DevTable& T, int world, const uint64_t* b
                                                        uint64_t*, uint64_t*, hipStream_t);
 
 #define DFX_INSTANTIATE_TABLE_KW(KW)                                                                               \
-  template hipError_t table_hash_agg<KW>(const DevProgram&, const DevColumns&, const DevAggPlan&,                 \
-                                         const DevTable&, const DevRows&, int64_t, hipStream_t);                  \
+  template hipError_t table_hash_agg<KW>(const DevProgram&, const DevFastPlan&, const DevColumns&,                \
+                                         const DevAggPlan&, const DevTable&, const DevRows&, int64_t,             \
+                                         hipStream_t);                                                            \
   template hipError_t table_merge_rows<KW>(const DevRows&, int64_t, int64_t, const DevTable&, const DevRows&,     \
                                            hipStream_t);                                                          \
   template hipError_t table_rehash<KW>(const DevTable&, const DevTable&, const DevRows&, hipStream_t);             \

@@ -388,6 +388,8 @@ FilterRelation::FilterRelation(std::unique_ptr<Relation> input, const dfx_runtim
   deferred_ = builder_->add(expr_, expr_.root, &pred_operand_, &dt);
   if (deferred_.ok() && dt != DFX_BOOLEAN)  // filter.rs:64-66
     deferred_ = Status::Err(DFX_EXECUTION_ERROR, "Filter expression did not evaluate to boolean");
+  memset(&fast_, 0, sizeof(fast_));
+  if (deferred_.ok()) builder_->build_fast(pred_operand_, nullptr, 0, nullptr, 0, &fast_);
 }
 
 static Status alloc_zeroed_ctrl(std::shared_ptr<void>* ctrl) {
@@ -436,7 +438,9 @@ Status FilterRelation::next(DeviceBatch* out, bool* has) {
   if (!tmp) return st;
   double in_bytes = (double)n / 8.0;
   for (int ci : builder_->columns()) in_bytes += (double)n * (in.columns[ci].dtype == DFX_BOOLEAN ? 0.125 : dtype_width(in.columns[ci].dtype));
-  DFX_HIP(launch_predicate_mask(prog, cols, pred_operand_, n, (uint64_t*)mask.get(), (uint32_t*)counts.get(),
+  DevFastPlan fp = fast_;
+  if (!agg_options().fast) fp.valid = 0;
+  DFX_HIP(launch_predicate_mask(prog, fp, cols, pred_operand_, n, (uint64_t*)mask.get(), (uint32_t*)counts.get(),
                                 (uint32_t*)ctrl_.get(), in_bytes, s));
   DFX_HIP(launch_scan_u32((const uint32_t*)counts.get(), (uint64_t*)offsets.get(), n_tiles, (uint64_t*)tmp.get(), s));
   uint64_t kept = 0;

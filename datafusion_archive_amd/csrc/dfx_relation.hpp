@@ -57,6 +57,7 @@ class FilterRelation : public Relation {
   SchemaInfo schema_;
   std::unique_ptr<ProgramBuilder> builder_;
   uint8_t pred_operand_ = kNoOperand;
+  DevFastPlan fast_;
   Status deferred_;  // evaluation-time type errors of the reference surface on next()
   std::shared_ptr<void> ctrl_;
 };
@@ -93,6 +94,7 @@ struct AggOptions {
   int capacity_log2 = 0;    // 0: default
   int lds_slots = -1;       // -1 auto
   int lds_copies = -1;      // -1 auto
+  int fast = 1;             // 0: always run the generic interpreter (tests compare both paths)
 };
 AggOptions& agg_options();
 

@@ -43,6 +43,7 @@ def agg(name, e, t):
 def _reset_options():
     for k in ("agg.strategy", "agg.capacity_log2"):
         ex.set_option(k, 0)
+    ex.set_option("scan.fast", 1)
     ex.set_option("agg.lds_slots", -1)
     ex.set_option("agg.lds_copies", -1)
     yield
@@ -152,7 +153,9 @@ def _random_batch(rng, n, with_nulls=False):
 
 @pytest.mark.parametrize("n", [0, 1, 63, 64, 65, 4095, 4096, 4097, 100003])
 @pytest.mark.parametrize("with_nulls", [False, True])
-def test_filter_matches_oracle(n, with_nulls):
+@pytest.mark.parametrize("fast", [1, 0])
+def test_filter_matches_oracle(n, with_nulls, fast):
+    ex.set_option("scan.fast", fast)  # shape-specialised kernel vs generic interpreter
     rng = np.random.default_rng(1000 + n)
     b = _random_batch(rng, n, with_nulls)
     pred = BinaryExpr(BinaryExpr(Column(0), Operator.Gt, lit(51.0)), Operator.And,
@@ -305,7 +308,9 @@ GROUP_AGGS = [agg("min", Column(1), F64), agg("max", Column(1), F64), agg("sum",
 
 @pytest.mark.parametrize("n_groups", [1, 6, 1000, 50000])
 @pytest.mark.parametrize("strategy", [0, 1, 2])
-def test_grouped_aggregates(n_groups, strategy):
+@pytest.mark.parametrize("fast", [1, 0])
+def test_grouped_aggregates(n_groups, strategy, fast):
+    ex.set_option("scan.fast", fast)
     ex.set_option("agg.strategy", strategy)
     rng = np.random.default_rng(n_groups)
     whole = _exact_batch(rng, 150001, n_groups)
@@ -369,7 +374,9 @@ def test_grouped_multi_column_keys(strategy):
         assert_groups_identical(got, oracle.aggregate(keys, aggs, [b]), len(keys), f"{len(keys)} keys")
 
 
-def test_fused_filter_aggregate_matches_filter_then_aggregate():
+@pytest.mark.parametrize("fast", [1, 0])
+def test_fused_filter_aggregate_matches_filter_then_aggregate(fast):
+    ex.set_option("scan.fast", fast)
     rng = np.random.default_rng(12)
     whole = _exact_batch(rng, 100000, 700)
     pred = BinaryExpr(BinaryExpr(Column(1), Operator.Gt, lit(204.8)), Operator.And,
@@ -381,8 +388,10 @@ def test_fused_filter_aggregate_matches_filter_then_aggregate():
     assert_batches_identical(got, oracle.aggregate([], ALL_AGGS, [oracle.filter_next(pred, whole)]), "fused ungrouped")
 
 
-def test_aggregate_computed_arguments_q1_shape():
+@pytest.mark.parametrize("fast", [1, 0])
+def test_aggregate_computed_arguments_q1_shape(fast):
     """SUM(price*(1-disc)*(1+tax)) etc. with two predicates and two group keys (config 5 shape)."""
+    ex.set_option("scan.fast", fast)
     rng = np.random.default_rng(21)
     n = 60000
     cols = {"rf": rng.integers(0, 3, n).astype(np.int64), "ls": rng.integers(0, 2, n).astype(np.int64),

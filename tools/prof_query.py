@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""Runs one workload a few times (no CPU baseline): the target of rocprofv3 runs.
+usage: prof_query.py <headline|cfg3|cfg2|q1> [rows] [iters]"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import pyarrow as pa  # noqa: E402
+from datafusion_archive_amd import execution as ex  # noqa: E402
+from datafusion_archive_amd.logicalplan import (AggregateFunction, BinaryExpr, Column, DataType, Literal, Operator,  # noqa: E402
+                                                ScalarValue)
+
+wl = sys.argv[1] if len(sys.argv) > 1 else "headline"
+rows = int(float(sys.argv[2])) if len(sys.argv) > 2 else 1 << 28
+iters = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+for kv in sys.argv[4:]:
+    k, v = kv.split("=")
+    ex.set_option(k, int(v))
+ex.init(0)
+f64 = DataType.Float64
+
+
+def lit(v):
+    return Literal(ScalarValue.Float64(v))
+
+
+if wl == "q1":
+    syn = [("rf", ex.SYNTH_I64_UNIFORM, 0, 3.0, 0.0), ("ls", ex.SYNTH_I64_UNIFORM, 1, 2.0, 0.0),
+           ("qty", ex.SYNTH_F64_UNIFORM, 2, 1.0, 49.0), ("price", ex.SYNTH_F64_UNIFORM, 3, 900.0, 104100.0),
+           ("disc", ex.SYNTH_F64_UNIFORM, 4, 0.0, 0.10), ("tax", ex.SYNTH_F64_UNIFORM, 5, 0.0, 0.08),
+           ("ship", ex.SYNTH_F64_UNIFORM, 6, 0.0, 2526.0)]
+    schema = pa.schema([(n, pa.int64() if i < 2 else pa.float64()) for i, (n, *_r) in enumerate(syn)])
+    one_minus = BinaryExpr(lit(1.0), Operator.Minus, Column(4))
+    one_plus = BinaryExpr(lit(1.0), Operator.Plus, Column(5))
+    dp = BinaryExpr(Column(3), Operator.Multiply, one_minus)
+    aggs = [AggregateFunction("sum", [Column(2)], f64), AggregateFunction("sum", [Column(3)], f64),
+            AggregateFunction("sum", [dp], f64), AggregateFunction("sum", [BinaryExpr(dp, Operator.Multiply, one_plus)], f64)]
+    pred = BinaryExpr(BinaryExpr(Column(6), Operator.LtEq, lit(2436.0)), Operator.And,
+                      BinaryExpr(Column(4), Operator.GtEq, lit(0.0)))
+    group = [Column(0), Column(1)]
+    bytes_per_row = 56
+else:
+    syn = [("k", ex.SYNTH_I64_UNIFORM, 0, 1e6, 0.0), ("v", ex.SYNTH_F64_EXACT, 1, 0.0, 0.0)]
+    schema = pa.schema([("k", pa.int64()), ("v", pa.float64())])
+    pred = BinaryExpr(BinaryExpr(Column(1), Operator.Gt, lit(204.8)), Operator.And,
+                      BinaryExpr(Column(1), Operator.Lt, lit(409.6)))
+    aggs = [AggregateFunction("SUM", [Column(1)], f64)]
+    group = [Column(0)]
+    bytes_per_row = 16
+    if wl == "cfg3":
+        pred = None
+    if wl == "cfg2":
+        group = []
+        aggs = [AggregateFunction("COUNT", [Column(1)], DataType.UInt64)]
+        bytes_per_row = 8
+
+table = ex.DeviceTable.synth(syn, 0xDF02, 0, rows)
+
+
+def run():
+    rel = table.scan(1 << 26)
+    if pred is not None:
+        rel = ex.FilterRelation(rel, ex.compile_scalar_expr(None, pred, schema), schema)
+    rel = ex.AggregateRelation(None, rel, [ex.compile_scalar_expr(None, g, schema) for g in group],
+                               [ex.compile_expr(None, a, schema) for a in aggs])
+    return rel.next()
+
+
+run()
+ex.synchronize()
+t0 = time.perf_counter()
+for _ in range(iters):
+    out = run()
+ex.synchronize()
+dt = (time.perf_counter() - t0) / iters
+print(f"{wl}: rows={rows} {dt*1e3:.3f} ms/iter  {rows/dt/1e9:.2f} Grows/s  {rows*bytes_per_row/dt/1e9:.1f} GB/s  groups={out.num_rows}")
