@@ -9,6 +9,8 @@
 //     not fit are spilled and replayed); K8 emits dense arrays at end of input.
 //   A FilterRelation feeding the aggregate (context.rs:126-139,162-192) is absorbed: its predicate
 //   becomes part of the fused program and no filtered batch is ever materialised.
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -53,6 +55,9 @@ struct AggregateRelation::Impl {
   std::shared_ptr<void> spill_owner;
   bool lds_enabled = true;
   bool lds_calibrated = false;
+  bool use_partition = false;   // strategy 3: route rows to table blocks, aggregate blocks in LDS
+  DevPartition PT;
+  std::shared_ptr<void> pt_rows, pt_counts;
   int64_t rows_seen = 0;
   uint64_t occupied_known = 0;
   // ungrouped state
@@ -63,6 +68,7 @@ struct AggregateRelation::Impl {
   Status setup(const SchemaInfo& input_schema);
   Status alloc_table(int cap_log2, DevTable* T, std::vector<std::shared_ptr<void>>* owners, bool new_ctrl);
   Status ensure_spill(int64_t rows);
+  Status ensure_partition(int64_t rows);
   Status grow_and_replay(uint64_t occupied, uint64_t spilled);
   Status consume_batch(const DeviceBatch& b);
   Status launch_rows(const DeviceBatch& b, const DevProgram& prog, const DevColumns& cols, int64_t row0, int64_t n);
@@ -180,6 +186,13 @@ Status AggregateRelation::Impl::alloc_table(int cap_log2, DevTable* Tn, std::vec
   Tn->na = na;
   Tn->load_limit = cap / 2;
   Tn->max_probe = (int)std::min<uint64_t>(cap, 1u << 30);
+  {  // probing block = what one workgroup can hold in 64 KB of LDS (keys + accumulators)
+    uint64_t blk = 8192 / (uint64_t)(std::max(kw, 1) + std::max(na, 1));
+    uint64_t p2 = 64;
+    while (p2 * 2 <= blk) p2 *= 2;
+    if (p2 > cap) p2 = cap;
+    Tn->block_mask = (uint32_t)(p2 - 1);
+  }
   for (int a = 0; a < na; ++a) {
     Tn->acc_kind[a] = acc_kind[a];
     Tn->val_xform[a] = val_xform[a];
@@ -224,6 +237,40 @@ Status AggregateRelation::Impl::ensure_spill(int64_t rows) {
   if (!spill_owner) return st;
   spill.words = (uint64_t*)spill_owner.get();
   spill.capacity = (uint64_t)rows;
+  return Status::OK();
+}
+
+// scratch for the partitioned strategy, sized for a batch of `rows` rows (worst case: all pass)
+Status AggregateRelation::Impl::ensure_partition(int64_t rows) {
+  memset(&PT, 0, sizeof(PT));
+  const uint64_t S = (uint64_t)T.block_mask + 1;
+  PT.n_parts = (uint32_t)((T.mask + 1) / S);
+  PT.n_producers = (uint32_t)(2 * device_cu_count());
+  PT.n_words = (uint32_t)(kw + na);
+  int ps = 0;
+  while ((1ull << ps) < S) ++ps;
+  PT.part_shift = (uint32_t)ps;
+  // LDS budget of a producer: 64 KB = staging planes + one u32 fill counter per partition.  A
+  // workgroup round (4 waves x U x 64 rows) must fit the staging area: U = 4 (1024 rows) when the
+  // rows are narrow, U = 2 (512 rows) otherwise.
+  if (PT.n_parts > 4096) return Status::Err(DFX_NOT_IMPLEMENTED, "partitioned strategy: too many table blocks");
+  const uint32_t budget = 65536 - PT.n_parts * 4 - 16;
+  uint32_t stage = budget / (PT.n_words * 8);
+  if (stage >= 1024) stage = stage / 1024 * 1024;
+  else if (stage >= 512) stage = 512;
+  else return Status::Err(DFX_NOT_IMPLEMENTED, "partitioned strategy: rows too wide for the LDS staging area");
+  PT.stage_rows = stage;
+  const uint64_t avg = (uint64_t)rows / ((uint64_t)PT.n_producers * PT.n_parts) + 1;
+  PT.cap_rows = (uint32_t)((2 * avg + 64 + 63) / 64 * 64);
+  const size_t row_bytes = sizeof(uint64_t) * (size_t)PT.n_parts * PT.n_producers * PT.n_words * PT.cap_rows;
+  const size_t cnt_bytes = sizeof(uint32_t) * (size_t)PT.n_parts * PT.n_producers;
+  Status st;
+  pt_rows = device_alloc(row_bytes, &st);
+  if (!pt_rows) return st;
+  pt_counts = device_alloc(cnt_bytes, &st);
+  if (!pt_counts) return st;
+  PT.rows = (uint64_t*)pt_rows.get();
+  PT.counts = (uint32_t*)pt_counts.get();
   return Status::OK();
 }
 
@@ -294,10 +341,23 @@ Status AggregateRelation::Impl::launch_rows(const DeviceBatch& b, const DevProgr
     bytes += (double)n * (w ? w : 0.125);
   }
   DevAggPlan p = plan;
+  bool partition_now = use_partition;
+  if (partition_now) {
+    Status pst = ensure_partition(n);
+    if (!pst.ok() && pst.code == DFX_NOT_IMPLEMENTED) partition_now = false;  // global-atomic path instead
+    else if (!pst.ok()) return pst;
+  }
+  if (partition_now) {
+    DevFastPlan fpp = fast;
+    if (!agg_options().fast) fpp.valid = 0;
+    DFX_HIP(launch_partition(prog, fpp, cols, p, T, PT, spill, n, bytes, s));
+    DFX_HIP(launch_partition_agg(T, PT, spill, 0, s));
+    return Status::OK();
+  }
   if (lds_enabled && agg_options().strategy != 1) {
     const AggOptions& o = agg_options();
     int slots = o.lds_slots >= 0 ? o.lds_slots : 4096;
-    while (slots > 64 && (size_t)slots * (size_t)(kw + na) * 8 > 64 * 1024) slots >>= 1;
+    while (slots > 64 && (size_t)slots * ((size_t)(kw + na) * 8 + (kw > 1 ? 4 : 0)) > 64 * 1024) slots >>= 1;
     int copies = o.lds_copies > 0 ? o.lds_copies : 1;
     if (o.lds_copies <= 0 && lds_calibrated) {  // few groups: lane-replicated sub-tables
       if (occupied_known <= 16) copies = 16;
@@ -336,7 +396,9 @@ Status AggregateRelation::Impl::consume_batch(const DeviceBatch& b) {
     return Status::OK();
   }
   // grouped: can this batch overflow the table in the worst case (every row a new group)?
-  const bool may_spill = occupied_known + (uint64_t)n > T.load_limit;
+  const AggOptions& oo = agg_options();
+  if (oo.strategy == 3 && kw == 1) use_partition = true;
+  const bool may_spill = use_partition || occupied_known + (uint64_t)n > T.load_limit;
   if (may_spill) DFX_RETURN_IF_ERROR(ensure_spill(n + 65536));
   T.max_probe = may_spill ? 128 : (int)std::min<uint64_t>(T.mask + 1, 1u << 30);
   int64_t row0 = 0;
@@ -352,6 +414,12 @@ Status AggregateRelation::Impl::consume_batch(const DeviceBatch& b) {
     lds_enabled = (hit + miss == 0) || (hit / (hit + miss) >= 0.5);
     occupied_known = hc[CTRL_OCCUPIED];
     lds_calibrated = true;
+    // many groups and a useless front cache: per-row global atomics would cap the whole query at
+    // ~24 G rows/s, so route the rows to their table blocks instead (dfx_k_partition.hip)
+    if (!lds_enabled && kw == 1 && occupied_known >= 16384 && o.strategy == 0) {
+      use_partition = true;
+      DFX_RETURN_IF_ERROR(ensure_spill(n + 65536));
+    }
     row0 = n0;
   } else if (!lds_calibrated) {
     if (o.strategy == 1) lds_enabled = false;
@@ -362,6 +430,12 @@ Status AggregateRelation::Impl::consume_batch(const DeviceBatch& b) {
   if (hc[CTRL_ERROR]) return error_from_ctrl(hc[CTRL_ERROR]);
   occupied_known = hc[CTRL_OCCUPIED];
   const uint64_t spilled = ((uint64_t)hc[CTRL_SPILL_HI] << 32) | hc[CTRL_SPILL_LO];
+  if (getenv("DFX_DEBUG"))
+    fprintf(stderr, "[dfx] batch n=%lld partition=%d lds=%d occupied=%u spilled=%llu saturated=%u passed=%llu cap=%llu "
+            "parts=%u cap_rows=%u stage=%u spillcap=%llu\n", (long long)n, (int)use_partition, (int)lds_enabled,
+            hc[CTRL_OCCUPIED], (unsigned long long)spilled, hc[CTRL_SATURATED],
+            (unsigned long long)(((uint64_t)hc[CTRL_PASSED_HI] << 32) | hc[CTRL_PASSED_LO]),
+            (unsigned long long)(T.mask + 1), PT.n_parts, PT.cap_rows, PT.stage_rows, (unsigned long long)spill.capacity);
   if (!lds_calibrated) {
     const double hit = hc[CTRL_LDS_HIT], miss = hc[CTRL_LDS_MISS];
     if (o.strategy == 0 && hit + miss > 4096) lds_enabled = hit / (hit + miss) >= 0.5;

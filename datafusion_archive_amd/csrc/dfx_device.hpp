@@ -146,6 +146,9 @@ struct DevTable {
   int32_t kw;
   int32_t na;
   int32_t max_probe;
+  uint32_t block_mask; // probing is confined to aligned blocks of block_mask + 1 slots (a block is
+                       // also the LDS sub-table of one partition in the partitioned strategy)
+  uint32_t pad0;
   uint64_t load_limit; // occupied above this => saturated
   uint8_t acc_kind[kMaxAggs];
   uint8_t val_xform[kMaxAggs];
@@ -166,6 +169,22 @@ struct DevAggPlan {
   uint8_t arg_dtype[kMaxAggs];
   int32_t lds_slots;           // 0: no LDS front cache; else power of two
   int32_t lds_copies;          // power of two: lane-replicated sub-tables (few-group inputs)
+};
+
+// ---- partitioned strategy (high-cardinality GROUP BY) -------------------------------------------
+// Global atomics top out at ~24 G/s on MI355X whatever the table size; LDS atomics run at > 1 T/s.
+// So for many groups the passing rows are first routed (pass 1) into per-(workgroup, partition)
+// private regions -- partition = the table block the key hashes to -- and then (pass 2) each
+// partition is aggregated by one workgroup inside an LDS copy of its table block.
+struct DevPartition {
+  uint64_t* rows;      // [partition][producer][word][cap_rows]
+  uint32_t* counts;    // [partition][producer]
+  uint32_t n_parts;    // table blocks
+  uint32_t n_producers;// pass-1 workgroups
+  uint32_t cap_rows;   // rows per (producer, partition) region
+  uint32_t n_words;    // kw + na
+  uint32_t part_shift; // partition = slot >> part_shift
+  uint32_t stage_rows; // LDS staging capacity per pass-1 workgroup
 };
 
 struct DevProjectPlan {

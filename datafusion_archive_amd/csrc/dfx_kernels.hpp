@@ -27,6 +27,7 @@ enum KernelId : int {
   KID_GATHER_UTF8,
   KID_PARTIAL,
   KID_PARTITION,
+  KID_PARTITION_AGG,
   KID_COUNT_
 };
 const char* kernel_name(int kid);
@@ -106,6 +107,15 @@ hipError_t launch_partial_scatter(const DevTable& T, int world, const uint64_t* 
 // merge bucketed planes (layout of dfx_aggregate_partial_export) into a table
 hipError_t launch_merge_bucket(const uint64_t* bucket, uint64_t count, const DevTable& T,
                                const DevRows& spill, hipStream_t s);
+
+// partitioned GROUP BY (dfx_k_partition.hip): pass 1 routes passing rows to per-(producer, partition)
+// regions, pass 2 aggregates every partition in an LDS copy of its table block.  Single-word keys.
+size_t partition_stage_bytes(const DevPartition& PT);
+hipError_t launch_partition(const DevProgram& P, const DevFastPlan& fast, const DevColumns& C, const DevAggPlan& plan,
+                            const DevTable& T, const DevPartition& PT, const DevRows& spill, int64_t n,
+                            double algo_bytes, hipStream_t s);
+hipError_t launch_partition_agg(const DevTable& T, const DevPartition& PT, const DevRows& spill, double algo_bytes,
+                                hipStream_t s);
 
 // synthetic columns (definition shared with oracle/dfx_oracle.c: orc_synth_fill)
 hipError_t launch_synth(int kind, int column_id, double p0, double p1, uint64_t seed, int64_t row_begin,

@@ -508,7 +508,7 @@ DEV bool table_upsert_slot(const DevTable& T, const uint64_t (&key)[KW], uint64_
           return true;
         }
       }
-      slot = (slot + 1) & T.mask;
+      slot = (slot & ~(uint64_t)T.block_mask) | ((slot + 1) & (uint64_t)T.block_mask);
     }
     return false;
   } else {
@@ -543,7 +543,7 @@ DEV bool table_upsert_slot(const DevTable& T, const uint64_t (&key)[KW], uint64_
         slot_out = slot;
         return true;
       }
-      slot = (slot + 1) & T.mask;
+      slot = (slot & ~(uint64_t)T.block_mask) | ((slot + 1) & (uint64_t)T.block_mask);
       ++p;
     }
     return false;

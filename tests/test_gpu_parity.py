@@ -307,7 +307,7 @@ GROUP_AGGS = [agg("min", Column(1), F64), agg("max", Column(1), F64), agg("sum",
 
 
 @pytest.mark.parametrize("n_groups", [1, 6, 1000, 50000])
-@pytest.mark.parametrize("strategy", [0, 1, 2])
+@pytest.mark.parametrize("strategy", [0, 1, 2, 3])
 @pytest.mark.parametrize("fast", [1, 0])
 def test_grouped_aggregates(n_groups, strategy, fast):
     ex.set_option("scan.fast", fast)
@@ -330,7 +330,7 @@ def test_grouped_lds_replicated_subtables(copies):
     assert_groups_identical(got, oracle.aggregate([Column(0)], GROUP_AGGS, [whole]), 1, f"copies={copies}")
 
 
-@pytest.mark.parametrize("strategy", [1, 2])
+@pytest.mark.parametrize("strategy", [1, 2, 3])
 def test_grouped_table_growth_from_tiny_capacity(strategy):
     """capacity 2^6 with 30000 groups: the table saturates, rows spill, the table is rebuilt."""
     ex.set_option("agg.strategy", strategy)
@@ -353,7 +353,7 @@ def test_grouped_keys_int32_and_sentinel_key():
     b = pa.RecordBatch.from_arrays([pa.array(k), pa.array(np.arange(7, dtype=np.float64)),
                                     pa.array(np.arange(7, dtype=np.int64)),
                                     pa.array(np.arange(7, dtype=np.float32))], names=["k", "v", "i", "f"])
-    for strategy in (1, 2):
+    for strategy in (1, 2, 3):
         ex.set_option("agg.strategy", strategy)
         got = gpu_aggregate([Column(0)], GROUP_AGGS, b.schema, [b])
         assert_groups_identical(got, oracle.aggregate([Column(0)], GROUP_AGGS, [b]), 1, "sentinel key")
@@ -377,6 +377,7 @@ def test_grouped_multi_column_keys(strategy):
 @pytest.mark.parametrize("fast", [1, 0])
 def test_fused_filter_aggregate_matches_filter_then_aggregate(fast):
     ex.set_option("scan.fast", fast)
+    _check_partitioned_filter_aggregate()
     rng = np.random.default_rng(12)
     whole = _exact_batch(rng, 100000, 700)
     pred = BinaryExpr(BinaryExpr(Column(1), Operator.Gt, lit(204.8)), Operator.And,
@@ -419,6 +420,31 @@ def test_aggregate_computed_arguments_q1_shape(fast):
             assert abs(a - bb) <= 2 * EPS * abs(bb) * 4 + 1e-300, (k, a, bb)
 
 
+def _check_partitioned_filter_aggregate():
+    ex.set_option("agg.strategy", 3)
+    rng = np.random.default_rng(13)
+    whole = _exact_batch(rng, 300000, 90000)
+    pred = BinaryExpr(Column(1), Operator.Gt, lit(300.0))
+    got = gpu_aggregate([Column(0)], GROUP_AGGS, whole.schema, [whole.slice(0, 100000), whole.slice(100000, 200000)],
+                        filter_expr=pred)
+    want = oracle.aggregate([Column(0)], GROUP_AGGS, [oracle.filter_next(pred, whole)])
+    assert_groups_identical(got, want, 1, "partitioned filter+aggregate")
+    ex.set_option("agg.strategy", 0)
+
+
+def test_skewed_keys_partitioned_strategy_spills_correctly():
+    """Zipf-like keys overflow the per-(producer, partition) regions: the spill path must take them."""
+    ex.set_option("agg.strategy", 3)
+    syn = [("k", ex.SYNTH_I64_ZIPF, 0, 1000000.0, 0.0), ("v", ex.SYNTH_F64_EXACT, 1, 0.0, 0.0)]
+    n, seed = 1 << 21, 0xDF05
+    t = ex.DeviceTable.synth(syn, seed, 0, n)
+    aggs = [agg("sum", Column(1), F64), agg("count", Column(1), DataType.UInt64), agg("min", Column(1), F64)]
+    schema = pa.schema([("k", pa.int64()), ("v", pa.float64())])
+    got = gpu_aggregate([Column(0)], aggs, schema, [], source=t.scan(1 << 20))
+    want = oracle.aggregate([Column(0)], aggs, [oracle.synth_batch(syn, seed, 0, n)])
+    assert_groups_identical(got, want, 1, "skewed keys")
+
+
 def test_aggregate_errors_mirror_reference():
     b = _exact_batch(np.random.default_rng(1), 100, 5)
     fb = pa.RecordBatch.from_arrays([pa.array([1.5, 2.5]), pa.array([1.0, 2.0])], names=["k", "v"])
@@ -436,8 +462,11 @@ def test_aggregate_errors_mirror_reference():
 SYN = [("k", ex.SYNTH_I64_UNIFORM, 0, 1000000.0, 0.0), ("v", ex.SYNTH_F64_EXACT, 1, 0.0, 0.0)]
 
 
-def test_resident_table_group_by_1m_keys_vs_oracle():
-    """4M rows, 1M Int64 keys, device-resident scan -> fused aggregate; oracle on the same generator."""
+@pytest.mark.parametrize("strategy", [0, 1, 3])
+def test_resident_table_group_by_1m_keys_vs_oracle(strategy):
+    """4M rows, 1M Int64 keys, device-resident scan -> fused aggregate; oracle on the same generator.
+    strategy 3 = partitioned (rows routed to table blocks, blocks aggregated in LDS)."""
+    ex.set_option("agg.strategy", strategy)
     n, seed = 1 << 22, 0xDF02
     t = ex.DeviceTable.synth(SYN, seed, 0, n)
     aggs = [agg("sum", Column(1), F64), agg("count", Column(1), DataType.UInt64), agg("max", Column(1), F64)]
@@ -448,7 +477,9 @@ def test_resident_table_group_by_1m_keys_vs_oracle():
     assert_groups_identical(got, want, 1, "1M-key group by")
 
 
-def test_resident_table_growth_under_spill_at_scale():
+@pytest.mark.parametrize("strategy", [0, 3])
+def test_resident_table_growth_under_spill_at_scale(strategy):
+    ex.set_option("agg.strategy", strategy)
     ex.set_option("agg.capacity_log2", 16)
     n, seed = 1 << 22, 0xDF03
     t = ex.DeviceTable.synth(SYN, seed, 0, n)
