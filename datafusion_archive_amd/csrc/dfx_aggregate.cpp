@@ -187,7 +187,7 @@ Status AggregateRelation::Impl::alloc_table(int cap_log2, DevTable* Tn, std::vec
   Tn->load_limit = cap / 2;
   Tn->max_probe = (int)std::min<uint64_t>(cap, 1u << 30);
   {  // probing block = what one workgroup can hold in 64 KB of LDS (keys + accumulators)
-    uint64_t blk = 8192 / (uint64_t)(std::max(kw, 1) + std::max(na, 1));
+    uint64_t blk = 4096 / (uint64_t)(std::max(kw, 1) + std::max(na, 1));  // 32 KB of LDS per block
     uint64_t p2 = 64;
     while (p2 * 2 <= blk) p2 *= 2;
     if (p2 > cap) p2 = cap;
@@ -250,15 +250,14 @@ Status AggregateRelation::Impl::ensure_partition(int64_t rows) {
   int ps = 0;
   while ((1ull << ps) < S) ++ps;
   PT.part_shift = (uint32_t)ps;
-  // LDS budget of a producer: 64 KB = staging planes + one u32 fill counter per partition.  A
-  // workgroup round (4 waves x U x 64 rows) must fit the staging area: U = 4 (1024 rows) when the
-  // rows are narrow, U = 2 (512 rows) otherwise.
+  // LDS budget of a producer workgroup: 64 KB = 4 wave-private staging areas + one u32 fill counter
+  // per partition.  A wave trip (U x 64 rows) must fit its staging area: U = 4 when the rows are
+  // narrow, U = 2 otherwise.
   if (PT.n_parts > 4096) return Status::Err(DFX_NOT_IMPLEMENTED, "partitioned strategy: too many table blocks");
   const uint32_t budget = 65536 - PT.n_parts * 4 - 16;
-  uint32_t stage = budget / (PT.n_words * 8);
-  if (stage >= 1024) stage = stage / 1024 * 1024;
-  else if (stage >= 512) stage = 512;
-  else return Status::Err(DFX_NOT_IMPLEMENTED, "partitioned strategy: rows too wide for the LDS staging area");
+  uint32_t stage = budget / (4 * PT.n_words * 8) / 64 * 64;
+  if (stage < 128) return Status::Err(DFX_NOT_IMPLEMENTED, "partitioned strategy: rows too wide for the LDS staging area");
+  if (stage < 256) stage = 128;
   PT.stage_rows = stage;
   const uint64_t avg = (uint64_t)rows / ((uint64_t)PT.n_producers * PT.n_parts) + 1;
   PT.cap_rows = (uint32_t)((2 * avg + 64 + 63) / 64 * 64);
@@ -410,13 +409,14 @@ Status AggregateRelation::Impl::consume_batch(const DeviceBatch& b) {
     DFX_RETURN_IF_ERROR(launch_rows(b, prog, cols, 0, n0));
     uint32_t hc[CTRL_WORDS];
     DFX_RETURN_IF_ERROR(read_ctrl(hc));
-    const double hit = hc[CTRL_LDS_HIT], miss = hc[CTRL_LDS_MISS];
-    lds_enabled = (hit + miss == 0) || (hit / (hit + miss) >= 0.5);
+    // strategy from the number of groups the calibration slice produced: the LDS front cache pays
+    // when the groups fit it (every later row is an LDS atomic); for many groups per-row global
+    // atomics would cap the query near 24 G rows/s, so rows are routed to their table blocks
+    // instead (dfx_k_partition.hip); in between, the global table alone.
     occupied_known = hc[CTRL_OCCUPIED];
     lds_calibrated = true;
-    // many groups and a useless front cache: per-row global atomics would cap the whole query at
-    // ~24 G rows/s, so route the rows to their table blocks instead (dfx_k_partition.hip)
-    if (!lds_enabled && kw == 1 && occupied_known >= 16384 && o.strategy == 0) {
+    lds_enabled = occupied_known <= 8192;
+    if (!lds_enabled && kw == 1 && occupied_known >= 16384) {
       use_partition = true;
       DFX_RETURN_IF_ERROR(ensure_spill(n + 65536));
     }
@@ -437,8 +437,7 @@ Status AggregateRelation::Impl::consume_batch(const DeviceBatch& b) {
             (unsigned long long)(((uint64_t)hc[CTRL_PASSED_HI] << 32) | hc[CTRL_PASSED_LO]),
             (unsigned long long)(T.mask + 1), PT.n_parts, PT.cap_rows, PT.stage_rows, (unsigned long long)spill.capacity);
   if (!lds_calibrated) {
-    const double hit = hc[CTRL_LDS_HIT], miss = hc[CTRL_LDS_MISS];
-    if (o.strategy == 0 && hit + miss > 4096) lds_enabled = hit / (hit + miss) >= 0.5;
+    if (o.strategy == 0) lds_enabled = occupied_known <= 8192;
     lds_calibrated = true;
   }
   if (spilled > 0 || hc[CTRL_SATURATED] || occupied_known > T.load_limit) {

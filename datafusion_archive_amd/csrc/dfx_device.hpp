@@ -177,14 +177,14 @@ struct DevAggPlan {
 // private regions -- partition = the table block the key hashes to -- and then (pass 2) each
 // partition is aggregated by one workgroup inside an LDS copy of its table block.
 struct DevPartition {
-  uint64_t* rows;      // [partition][producer][word][cap_rows]
+  uint64_t* rows;      // [partition][producer][cap_rows][n_words]  (row-major regions)
   uint32_t* counts;    // [partition][producer]
   uint32_t n_parts;    // table blocks
   uint32_t n_producers;// pass-1 workgroups
   uint32_t cap_rows;   // rows per (producer, partition) region
   uint32_t n_words;    // kw + na
   uint32_t part_shift; // partition = slot >> part_shift
-  uint32_t stage_rows; // LDS staging capacity per pass-1 workgroup
+  uint32_t stage_rows; // LDS staging capacity per pass-1 WAVE (waves stage and flush independently)
 };
 
 struct DevProjectPlan {

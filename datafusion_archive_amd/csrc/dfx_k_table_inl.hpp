@@ -96,10 +96,12 @@ __global__ __launch_bounds__(kBlock) void k_hash_agg(const DevProgram P, const D
             const uint64_t k = lkeys[slot];
             if (k == key[0]) {
               found = slot;
+              ++lds_hit;  // a REUSED cache entry: the only case in which the cache saves a global atomic
             } else if (k == kEmptyKey) {
               const uint64_t old = atomicCAS((unsigned long long*)&lkeys[slot], (unsigned long long)kEmptyKey,
                                              (unsigned long long)key[0]);
               if (old == kEmptyKey || old == key[0]) found = slot;
+              if (old == key[0]) ++lds_hit;
             }
             if (found < 0) slot = sub_base + ((slot - sub_base + 1) & (sub_slots - 1));
           }
@@ -127,7 +129,10 @@ __global__ __launch_bounds__(kBlock) void k_hash_agg(const DevProgram P, const D
             bool same = true;
   #pragma unroll
             for (int k = 0; k < KW; ++k) same = same && (((volatile uint64_t*)lkeys)[k * S + slot] == key[k]);
-            if (same) found = slot;
+            if (same) {
+              found = slot;
+              ++lds_hit;
+            }
             else slot = sub_base + ((slot - sub_base + 1) & (sub_slots - 1));
             ++p;
           }
@@ -137,10 +142,8 @@ __global__ __launch_bounds__(kBlock) void k_hash_agg(const DevProgram P, const D
           for (int a = 0; a < kMaxAggs; ++a)
             if (a < T.na) acc_atomic(T.acc_kind[a], &laccs[a * S + found], val[a]);
           todo = false;
-          ++lds_hit;
-        } else {
-          ++lds_miss;
         }
+        ++lds_miss;  // rows that went through the cache (hit / rows = reuse rate)
       }
       // ---- global table ----
       if (todo && !saturated) {

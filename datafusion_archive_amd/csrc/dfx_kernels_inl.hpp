@@ -574,10 +574,14 @@ DEV void spill_row(const DevTable& T, const DevRows& spill, bool do_spill, const
 
 template <int KW>
 DEV bool table_apply(const DevTable& T, const uint64_t (&key)[KW], const uint64_t (&val)[kMaxAggs]) {
-  uint64_t slot;
-  bool inserted;
-  if (!table_upsert_slot<KW>(T, key, hash_keys<KW>(key), slot, inserted)) return false;
-  if (inserted) atomicAdd(&T.ctrl[CTRL_OCCUPIED], 1u);
+  uint64_t slot = 0;
+  bool inserted = false;
+  const bool ok = table_upsert_slot<KW>(T, key, hash_keys<KW>(key), slot, inserted);
+  // new groups are counted ONCE PER WAVE: thousands of lanes bumping the same word serialise at
+  // ~11 ns per atomic (MI355X_MICROARCH.md, fanin) -- 1 M inserts would cost 11 ms
+  const uint64_t mi = __ballot(ok && inserted);
+  if (mi != 0 && lane_id() == __ffsll((unsigned long long)mi) - 1) atomicAdd(&T.ctrl[CTRL_OCCUPIED], (uint32_t)__popcll(mi));
+  if (!ok) return false;
 #pragma unroll
   for (int a = 0; a < kMaxAggs; ++a)
     if (a < T.na) acc_atomic(T.acc_kind[a], &T.accs[(uint64_t)a * T.stride + slot], val[a]);
