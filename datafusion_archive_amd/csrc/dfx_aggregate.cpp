@@ -250,12 +250,12 @@ Status AggregateRelation::Impl::ensure_partition(int64_t rows) {
   int ps = 0;
   while ((1ull << ps) < S) ++ps;
   PT.part_shift = (uint32_t)ps;
-  // LDS budget of a producer workgroup: 64 KB = 4 wave-private staging areas + one u32 fill counter
+  // LDS budget of a producer workgroup: 64 KB = 8 wave-private staging areas + one u32 fill counter
   // per partition.  A wave trip (U x 64 rows) must fit its staging area: U = 4 when the rows are
   // narrow, U = 2 otherwise.
   if (PT.n_parts > 4096) return Status::Err(DFX_NOT_IMPLEMENTED, "partitioned strategy: too many table blocks");
   const uint32_t budget = 65536 - PT.n_parts * 4 - 16;
-  uint32_t stage = budget / (4 * PT.n_words * 8) / 64 * 64;
+  uint32_t stage = budget / (8 * PT.n_words * 8) / 64 * 64;  // 8 waves per producer workgroup
   if (stage < 128) return Status::Err(DFX_NOT_IMPLEMENTED, "partitioned strategy: rows too wide for the LDS staging area");
   if (stage < 256) stage = 128;
   PT.stage_rows = stage;

@@ -57,7 +57,7 @@ __global__ __launch_bounds__(kBlock) void k_predicate_mask(const DevProgram P, c
       uint32_t cv[U];
       FOR_U {
         const int64_t row = (w0 + u) * 64 + lane;
-        load_columns(P, C, row, row < n, col[u], cv[u]);
+        POL::load(P, C, row, row < n, col[u], cv[u]);
       }
 #pragma nounroll
       for (int uu = 0; uu < U; ++uu) {
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(kBlock) void k_project(const DevProgram P, const De
     uint32_t cv[U];
     FOR_U {
       const int64_t row = (w0 + u) * 64 + lane;
-      load_columns(P, C, row, row < n, col[u], cv[u]);
+      POL::load(P, C, row, row < n, col[u], cv[u]);
     }
 #pragma nounroll
     for (int uu = 0; uu < U; ++uu) {
@@ -505,6 +505,13 @@ hipError_t launch_predicate_mask(const DevProgram& P, const DevFastPlan& fast, c
   const int64_t tiles = (n + kTileRows - 1) / kTileRows;
   const int grid = stream_grid(tiles, 8);
 #define DFX_MASK(POL) hipLaunchKernelGGL((k_predicate_mask<POL>), dim3(grid), dim3(kBlock), 0, s, P, fast, C, pred, n, mask_words, tile_counts, ctrl)
+  {
+    const uint8_t none[kMaxAggs] = {0};
+    if (sig_matches<SigPred2F64>(P, fast, 0, 0, none, none)) {
+      DFX_MASK(DFX_ARG(StaticPolicy<2, 8, SigPred2F64>));
+      return hipGetLastError();
+    }
+  }
   const bool use_fast = fast.valid && !P.has_nulls;
   if (P.n_cols <= 2) { if (use_fast) DFX_MASK(DFX_ARG(FastPolicy<2, 8>)); else DFX_MASK(DFX_ARG(InterpPolicy<2, 8>)); }
   else if (P.n_cols <= 4) { if (use_fast) DFX_MASK(DFX_ARG(FastPolicy<4, 4>)); else DFX_MASK(DFX_ARG(InterpPolicy<4, 4>)); }

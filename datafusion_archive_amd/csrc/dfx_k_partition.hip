@@ -21,6 +21,8 @@
 
 namespace dfx {
 
+constexpr int kPBlock = 512;  // pass-1 workgroup: 8 waves share one set of fill counters and 64 KB of LDS
+
 DEV uint32_t partition_of(const DevTable& T, const DevPartition& PT, uint64_t h) {
   return (uint32_t)(((h >> T.shift) & T.mask) >> PT.part_shift);
 }
@@ -28,6 +30,7 @@ DEV uint32_t partition_of(const DevTable& T, const DevPartition& PT, uint64_t h)
 // One WAVE flushes its own staging area: every staged row is appended to its (producer,
 // partition) region; the per-partition fill counters are shared by the workgroup's four waves
 // (LDS atomics), the regions have no other writer, so no global atomic and no barrier is needed.
+template <typename POL>
 DEV void partition_flush_wave(const DevTable& T, const DevPartition& PT, const DevRows& spill,
                               const uint64_t* stage, uint32_t* fill, uint32_t cnt, uint32_t producer) {
   const int NW = (int)PT.n_words;
@@ -39,7 +42,7 @@ DEV void partition_flush_wave(const DevTable& T, const DevPartition& PT, const D
     uint64_t val[kMaxAggs];
     key[0] = inb ? stage[(size_t)i * NW] : 0;
 #pragma unroll
-    for (int a = 0; a < kMaxAggs; ++a) val[a] = (inb && a < T.na) ? stage[(size_t)i * NW + 1 + a] : 0;
+    for (int a = 0; a < kMaxAggs; ++a) val[a] = (inb && a < POL::na(T)) ? stage[(size_t)i * NW + 1 + a] : 0;
     bool todo = inb;
     if (inb) {
       const uint32_t p = partition_of(T, PT, hash_keys<1>(key));
@@ -47,7 +50,7 @@ DEV void partition_flush_wave(const DevTable& T, const DevPartition& PT, const D
       if (pos < PT.cap_rows) {
         uint64_t* dst = PT.rows + (((uint64_t)p * PT.n_producers + producer) * PT.cap_rows + pos) * NW;
         dst[0] = key[0];
-        for (int a = 0; a < T.na; ++a) dst[1 + a] = val[a];
+        for (int a = 0; a < POL::na(T); ++a) dst[1 + a] = val[a];
         todo = false;
       }
     }
@@ -56,7 +59,7 @@ DEV void partition_flush_wave(const DevTable& T, const DevPartition& PT, const D
 }
 
 template <typename POL>
-__global__ __launch_bounds__(kBlock) void k_partition(const DevProgram P, const DevFastPlan F, const DevColumns C,
+__global__ __launch_bounds__(kPBlock) void k_partition(const DevProgram P, const DevFastPlan F, const DevColumns C,
                                                       const DevAggPlan plan, const DevTable T,
                                                       const DevPartition PT, const DevRows spill, const int64_t n) {
   typedef typename POL::COLV COLV;
@@ -67,13 +70,13 @@ __global__ __launch_bounds__(kBlock) void k_partition(const DevProgram P, const 
   const int NW = (int)PT.n_words;
   const uint32_t RSW = PT.stage_rows;
   uint64_t* stage = lds + (size_t)wave * RSW * NW;                          // this wave's rows [RSW][NW]
-  uint32_t* fill = (uint32_t*)(lds + (size_t)(kBlock / 64) * RSW * NW);     // [n_parts], shared
-  for (uint32_t p = threadIdx.x; p < PT.n_parts; p += kBlock) fill[p] = 0;
+  uint32_t* fill = (uint32_t*)(lds + (size_t)(kPBlock / 64) * RSW * NW);     // [n_parts], shared
+  for (uint32_t p = threadIdx.x; p < PT.n_parts; p += kPBlock) fill[p] = 0;
   __syncthreads();
   const uint32_t producer = blockIdx.x;
   const int64_t n_groups = (n + 63) >> 6;
-  const int64_t wave_global = (int64_t)blockIdx.x * (kBlock / 64) + wave;
-  const int64_t n_waves = (int64_t)gridDim.x * (kBlock / 64);
+  const int64_t wave_global = (int64_t)blockIdx.x * (kPBlock / 64) + wave;
+  const int64_t n_waves = (int64_t)gridDim.x * (kPBlock / 64);
   uint32_t err = 0;
   uint64_t passed = 0;
   uint32_t scnt = 0;  // rows staged by this wave (wave-uniform)
@@ -82,7 +85,7 @@ __global__ __launch_bounds__(kBlock) void k_partition(const DevProgram P, const 
     uint32_t cv[U];
     FOR_U {
       const int64_t row = (w0 + u) * 64 + lane;
-      load_columns(P, C, row, row < n, col[u], cv[u]);
+      POL::load(P, C, row, row < n, col[u], cv[u]);
     }
 #pragma nounroll
     for (int uu = 0; uu < U; ++uu) {
@@ -101,11 +104,11 @@ __global__ __launch_bounds__(kBlock) void k_partition(const DevProgram P, const 
 #pragma unroll
       for (int a = 0; a < kMaxAggs; ++a) {
         val[a] = 0;
-        if (a < T.na) {
+        if (a < POL::na(T)) {
           uint64_t v;
           bool valid;
           POL::arg(P, F, plan.arg[a], a, cur, curv, reg, rv, v, valid);
-          val[a] = transform_value(T.val_xform[a], v, valid);
+          val[a] = transform_value(POL::xform(T, a), v, valid);
         }
       }
       passed += pass ? 1 : 0;
@@ -122,18 +125,18 @@ __global__ __launch_bounds__(kBlock) void k_partition(const DevProgram P, const 
         stage[(size_t)pos * NW] = key[0];
 #pragma unroll
         for (int a = 0; a < kMaxAggs; ++a)
-          if (a < T.na) stage[(size_t)pos * NW + 1 + a] = val[a];
+          if (a < POL::na(T)) stage[(size_t)pos * NW + 1 + a] = val[a];
       }
       scnt += (uint32_t)__popcll(m);
     }
     if (scnt + (uint32_t)(U * 64) > RSW) {  // the next trip might not fit (wave-uniform)
-      partition_flush_wave(T, PT, spill, stage, fill, scnt, producer);
+      partition_flush_wave<POL>(T, PT, spill, stage, fill, scnt, producer);
       scnt = 0;
     }
   }
-  if (scnt > 0) partition_flush_wave(T, PT, spill, stage, fill, scnt, producer);
+  if (scnt > 0) partition_flush_wave<POL>(T, PT, spill, stage, fill, scnt, producer);
   __syncthreads();
-  for (uint32_t p = threadIdx.x; p < PT.n_parts; p += kBlock) {
+  for (uint32_t p = threadIdx.x; p < PT.n_parts; p += kPBlock) {
     const uint32_t f = fill[p];
     PT.counts[(uint64_t)p * PT.n_producers + producer] = f < PT.cap_rows ? f : PT.cap_rows;
   }
@@ -250,7 +253,7 @@ __global__ __launch_bounds__(kBlock) void k_partition_agg(const DevTable T, cons
 }
 
 size_t partition_stage_bytes(const DevPartition& PT) {
-  return (size_t)(kBlock / 64) * PT.n_words * PT.stage_rows * 8 + (size_t)PT.n_parts * 4 + 16;
+  return (size_t)(kPBlock / 64) * PT.n_words * PT.stage_rows * 8 + (size_t)PT.n_parts * 4 + 16;
 }
 
 hipError_t launch_partition(const DevProgram& P, const DevFastPlan& fast, const DevColumns& C, const DevAggPlan& plan,
@@ -261,7 +264,15 @@ hipError_t launch_partition(const DevProgram& P, const DevFastPlan& fast, const 
   const size_t lds_bytes = partition_stage_bytes(PT);
   const int grid = (int)PT.n_producers;  // every producer writes its counts, even with no rows
   if (lds_bytes > 65536) return hipErrorInvalidValue;  // the host sizes the plan to fit (ensure_partition)
-#define DFX_PT(POL) hipLaunchKernelGGL((k_partition<POL>), dim3(grid), dim3(kBlock), lds_bytes, s, P, fast, C, plan, T, PT, spill, n)
+#define DFX_PT(POL) hipLaunchKernelGGL((k_partition<POL>), dim3(grid), dim3(kPBlock), lds_bytes, s, P, fast, C, plan, T, PT, spill, n)
+  if (PT.stage_rows >= 256 && sig_matches<SigKeySumPred2F64>(P, fast, 1, T.na, T.acc_kind, T.val_xform)) {
+    DFX_PT(DFX_ARG(StaticPolicy<2, 4, SigKeySumPred2F64>));
+    return hipGetLastError();
+  }
+  if (PT.stage_rows >= 256 && sig_matches<SigKeySum>(P, fast, 1, T.na, T.acc_kind, T.val_xform)) {
+    DFX_PT(DFX_ARG(StaticPolicy<2, 4, SigKeySum>));
+    return hipGetLastError();
+  }
   const bool use_fast = fast.valid && !P.has_nulls;
   // a wave trip is U x 64 rows and must fit the wave's staging area: wide rows use U = 2
   if (PT.stage_rows >= 256) {

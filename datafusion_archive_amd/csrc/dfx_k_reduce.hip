@@ -36,7 +36,7 @@ __global__ __launch_bounds__(kBlock) void k_reduce(const DevProgram P, const Dev
     uint32_t cv[U];
     FOR_U {
       const int64_t row = (w0 + u) * 64 + lane;
-      load_columns(P, C, row, row < n, col[u], cv[u]);
+      POL::load(P, C, row, row < n, col[u], cv[u]);
     }
 #pragma nounroll
     for (int uu = 0; uu < U; ++uu) {
@@ -53,11 +53,11 @@ __global__ __launch_bounds__(kBlock) void k_reduce(const DevProgram P, const Dev
         ++passed;
 #pragma unroll
         for (int a = 0; a < NAMAX; ++a) {
-          if (a < T.na) {
+          if (a < POL::na(T)) {
             uint64_t v;
             bool valid;
             POL::arg(P, F, plan.arg[a], a, cur, curv, reg, rv, v, valid);
-            const uint8_t xf = T.val_xform[a];
+            const uint8_t xf = POL::xform(T, a);
             if (xf == VT_COUNT_VALID) {
               acc[a] += valid ? 1ull : 0ull;
               cnt[a] += 1;
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(kBlock) void k_reduce(const DevProgram P, const Dev
                 const uint64_t tag = ((uint64_t)row << 1) | (d != d ? 1ull : 0ull);
                 first[a] = tag < first[a] ? tag : first[a];
               }
-              acc[a] = acc_combine(T.acc_kind[a], acc[a], transform_value(xf, v, valid));
+              acc[a] = acc_combine(POL::acc_kind(T, a), acc[a], transform_value(xf, v, valid));
               cnt[a] += 1;
             }
           }
@@ -78,10 +78,10 @@ __global__ __launch_bounds__(kBlock) void k_reduce(const DevProgram P, const Dev
   // wave tree (xor butterfly), then one atomic per workgroup per word
 #pragma unroll
   for (int a = 0; a < NAMAX; ++a) {
-    if (a < T.na) {
+    if (a < POL::na(T)) {
 #pragma unroll
       for (int m = 32; m >= 1; m >>= 1) {
-        acc[a] = acc_combine(T.acc_kind[a], acc[a], shfl_xor_u64(acc[a], m));
+        acc[a] = acc_combine(POL::acc_kind(T, a), acc[a], shfl_xor_u64(acc[a], m));
         cnt[a] += shfl_xor_u64(cnt[a], m);
         const uint64_t of = shfl_xor_u64(first[a], m);
         first[a] = of < first[a] ? of : first[a];
@@ -122,6 +122,16 @@ hipError_t launch_reduce(const DevProgram& P, const DevFastPlan& fast, const Dev
   const int grid = stream_grid((n + kBlock - 1) / kBlock, 8);
 #define DFX_REDUCE(POL, NM) hipLaunchKernelGGL((k_reduce<POL, NM>), dim3(grid), dim3(kBlock), 0, s, P, fast, C, plan, T, n, partial, ctrl)
 #define DFX_REDUCE_NA(POL) do { if (T.na <= 2) DFX_REDUCE(DFX_ARG(POL), 2); else DFX_REDUCE(DFX_ARG(POL), 8); } while (0)
+  // compile-time shape signatures first (dfx_sigs.hpp), then the run-time decoded fast plan, then
+  // the generic interpreter
+  if (sig_matches<SigCountPred2F64>(P, fast, 0, T.na, T.acc_kind, T.val_xform)) {
+    DFX_REDUCE(DFX_ARG(StaticPolicy<2, 8, SigCountPred2F64>), 2);
+    return hipGetLastError();
+  }
+  if (sig_matches<SigSumCountPred2F64>(P, fast, 0, T.na, T.acc_kind, T.val_xform)) {
+    DFX_REDUCE(DFX_ARG(StaticPolicy<2, 8, SigSumCountPred2F64>), 2);
+    return hipGetLastError();
+  }
   const bool use_fast = fast.valid && !P.has_nulls;
   if (P.n_cols <= 2) { if (use_fast) DFX_REDUCE_NA(DFX_ARG(FastPolicy<2, 8>)); else DFX_REDUCE_NA(DFX_ARG(InterpPolicy<2, 8>)); }
   else if (P.n_cols <= 4) { if (use_fast) DFX_REDUCE_NA(DFX_ARG(FastPolicy<4, 4>)); else DFX_REDUCE_NA(DFX_ARG(InterpPolicy<4, 4>)); }

@@ -22,13 +22,13 @@ __global__ __launch_bounds__(kBlock) void k_hash_agg(const DevProgram P, const D
   const int S = plan.lds_slots;
   uint64_t* lkeys = lds;
   uint64_t* laccs = lds + (size_t)KW * S;
-  uint32_t* lstate = (uint32_t*)(lds + (size_t)(KW + T.na) * S);
+  uint32_t* lstate = (uint32_t*)(lds + (size_t)(KW + POL::na(T)) * S);
   const int lane = lane_id();
   if (S > 0) {
     for (int i = threadIdx.x; i < S; i += kBlock) {
       lkeys[i] = kEmptyKey;
       if (KW > 1) lstate[i] = 0u;
-      for (int a = 0; a < T.na; ++a) laccs[a * S + i] = T.acc_init[a];
+      for (int a = 0; a < POL::na(T); ++a) laccs[a * S + i] = T.acc_init[a];
     }
     __syncthreads();
   }
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(kBlock) void k_hash_agg(const DevProgram P, const D
     uint32_t cv[U];
     FOR_U {
       const int64_t row = (w0 + u) * 64 + lane;
-      load_columns(P, C, row, row < n, col[u], cv[u]);
+      POL::load(P, C, row, row < n, col[u], cv[u]);
     }
     // ONE copy of the evaluation + table code: a run-time loop over the U prefetched row-groups
 #pragma nounroll
@@ -77,11 +77,11 @@ __global__ __launch_bounds__(kBlock) void k_hash_agg(const DevProgram P, const D
 #pragma unroll
       for (int a = 0; a < kMaxAggs; ++a) {
         val[a] = 0;
-        if (a < T.na) {
+        if (a < POL::na(T)) {
           uint64_t v;
           bool valid;  // value(row) read blindly (aggregate.rs:561-603)
           POL::arg(P, F, plan.arg[a], a, cur, curv, reg, rv, v, valid);
-          val[a] = transform_value(T.val_xform[a], v, valid);
+          val[a] = transform_value(POL::xform(T, a), v, valid);
         }
       }
       passed += pass ? 1 : 0;
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(kBlock) void k_hash_agg(const DevProgram P, const D
         if (found >= 0) {
   #pragma unroll
           for (int a = 0; a < kMaxAggs; ++a)
-            if (a < T.na) acc_atomic(T.acc_kind[a], &laccs[a * S + found], val[a]);
+            if (a < POL::na(T)) acc_atomic(POL::acc_kind(T, a), &laccs[a * S + found], val[a]);
           todo = false;
         }
         ++lds_miss;  // rows that went through the cache (hit / rows = reuse rate)
@@ -156,6 +156,9 @@ __global__ __launch_bounds__(kBlock) void k_hash_agg(const DevProgram P, const D
   // flush the LDS cache: every occupied slot becomes one merge into the global table
   if (S > 0) {
     __syncthreads();
+    // ONE poll per thread: an agent-scope load of the same word from every lane of every slot
+    // iteration serialises on one L2 channel (measured: 2 M loads ~ 1 ms)
+    const bool sat = __hip_atomic_load(&T.ctrl[CTRL_SATURATED], RLX_AGENT) != 0u;
     for (int i = threadIdx.x; i < S; i += kBlock) {
       bool occ;
       uint64_t key[KW];
@@ -169,9 +172,8 @@ __global__ __launch_bounds__(kBlock) void k_hash_agg(const DevProgram P, const D
       }
       uint64_t val[kMaxAggs];
 #pragma unroll
-      for (int a = 0; a < kMaxAggs; ++a) val[a] = (a < T.na) ? laccs[a * S + i] : 0;
+      for (int a = 0; a < kMaxAggs; ++a) val[a] = (a < POL::na(T)) ? laccs[a * S + i] : 0;
       bool todo = occ;
-      const bool sat = __hip_atomic_load(&T.ctrl[CTRL_SATURATED], RLX_AGENT) != 0u;
       if (todo && !sat) {
         if (table_apply<KW>(T, key, val)) todo = false;
       }
@@ -331,6 +333,18 @@ hipError_t table_hash_agg(const DevProgram& P, const DevFastPlan& fast, const De
   const int per_cu = lds_bytes > 0 ? (lds_bytes > 40 * 1024 ? 2 : 4) : 8;
   const int grid = stream_grid(n_blocks, per_cu);
 #define DFX_HA(POL) hipLaunchKernelGGL((k_hash_agg<KW, POL>), dim3(grid), dim3(kBlock), lds_bytes, s, P, fast, C, plan, T, spill, n)
+  if (KW == 1 && sig_matches<SigKeySumPred2F64>(P, fast, KW, T.na, T.acc_kind, T.val_xform)) {
+    DFX_HA(DFX_ARG(StaticPolicy<2, 4, SigKeySumPred2F64>));
+    return hipGetLastError();
+  }
+  if (KW == 1 && sig_matches<SigKeySum>(P, fast, KW, T.na, T.acc_kind, T.val_xform)) {
+    DFX_HA(DFX_ARG(StaticPolicy<2, 4, SigKeySum>));
+    return hipGetLastError();
+  }
+  if (KW == 2 && sig_matches<SigQ1>(P, fast, KW, T.na, T.acc_kind, T.val_xform)) {
+    DFX_HA(DFX_ARG(StaticPolicy<8, 2, SigQ1>));
+    return hipGetLastError();
+  }
   const bool use_fast = fast.valid && !P.has_nulls;
   if (P.n_cols <= 2) { if (use_fast) DFX_HA(DFX_ARG(FastPolicy<2, 4>)); else DFX_HA(DFX_ARG(InterpPolicy<2, 4>)); }
   else if (P.n_cols <= 4) { if (use_fast) DFX_HA(DFX_ARG(FastPolicy<4, 4>)); else DFX_HA(DFX_ARG(InterpPolicy<4, 4>)); }

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include "dfx_kernels.hpp"
+#include "dfx_sigs.hpp"
 
 namespace dfx {
 
@@ -324,6 +325,12 @@ template <int BANK, int U_>
 struct InterpPolicy {
   static constexpr int U = U_;
   typedef typename Bank<BANK>::type COLV;
+  static DEV void load(const DevProgram& P, const DevColumns& C, int64_t row, bool inb, COLV& col, uint32_t& cv) {
+    load_columns(P, C, row, inb, col, cv);
+  }
+  static DEV int na(const DevTable& T) { return T.na; }
+  static DEV uint8_t acc_kind(const DevTable& T, int a) { return T.acc_kind[a]; }
+  static DEV uint8_t xform(const DevTable& T, int a) { return T.val_xform[a]; }
   static DEV void eval(const DevProgram& P, const DevFastPlan&, const COLV& cur, uint32_t curv, u64x16& reg,
                        uint32_t& rv, bool inb, uint32_t& err) {
     COLV c = cur;
@@ -368,6 +375,12 @@ template <int BANK, int U_>
 struct FastPolicy {
   static constexpr int U = U_;
   typedef typename Bank<BANK>::type COLV;
+  static DEV void load(const DevProgram& P, const DevColumns& C, int64_t row, bool inb, COLV& col, uint32_t& cv) {
+    load_columns(P, C, row, inb, col, cv);
+  }
+  static DEV int na(const DevTable& T) { return T.na; }
+  static DEV uint8_t acc_kind(const DevTable& T, int a) { return T.acc_kind[a]; }
+  static DEV uint8_t xform(const DevTable& T, int a) { return T.val_xform[a]; }
   static DEV void eval(const DevProgram&, const DevFastPlan&, const COLV&, uint32_t, u64x16&, uint32_t&, bool,
                        uint32_t&) {}
   static DEV bool pass(const DevProgram&, const DevFastPlan& F, uint8_t, const COLV& cur, uint32_t, const u64x16&,
@@ -413,6 +426,61 @@ struct FastPolicy {
     v = f64_bits(acc);
   }
 };
+
+// compile-time shape signature (dfx_sigs.hpp): column slots, term types, accumulator kinds and
+// operand transforms are constants, every referenced column is 8 bytes wide, no nulls.  The only
+// run-time inputs are the comparison masks and the literals.
+template <int BANK, int U_, typename SIG>
+struct StaticPolicy {
+  static constexpr int U = U_;
+  typedef typename Bank<BANK>::type COLV;
+  static DEV void load(const DevProgram&, const DevColumns& C, int64_t row, bool inb, COLV& col, uint32_t& cv) {
+    cv = 0xFFFFFFFFu;
+#pragma unroll
+    for (int c = 0; c < BANK; ++c)
+      if (c < SIG::NCOL) col[c] = inb ? ((const uint64_t*)C.c[c].values)[row] : 0ull;
+  }
+  static DEV int na(const DevTable&) { return SIG::NA; }
+  static DEV uint8_t acc_kind(const DevTable&, int a) { return SIG::acc(a); }
+  static DEV uint8_t xform(const DevTable&, int a) { return SIG::xf(a); }
+  static DEV void eval(const DevProgram&, const DevFastPlan&, const COLV&, uint32_t, u64x16&, uint32_t&, bool,
+                       uint32_t&) {}
+  static DEV bool pass(const DevProgram&, const DevFastPlan& F, uint8_t, const COLV& cur, uint32_t, const u64x16&,
+                       uint32_t) {
+    uint32_t ok = 1u;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (i < SIG::NP) {
+        const uint32_t c = cmp3(SIG::term_cls(i), cur[SIG::term_col(i)], F.term_imm[i]);
+        ok &= (((c & (uint32_t)F.term[i].m) != 0u) ? 1u : 0u) ^ (uint32_t)F.term[i].inv;
+      }
+    }
+    return ok != 0u;
+  }
+  static DEV uint64_t key(const DevProgram&, const DevFastPlan&, uint8_t, int k, const COLV& cur, uint32_t,
+                          const u64x16&, uint32_t) {
+    uint64_t v = 0;
+#pragma unroll
+    for (int j = 0; j < kMaxKeys; ++j)  // k is a compile-time constant after unrolling at the call site
+      if (j < SIG::KW && j == k) v = cur[SIG::key_col(j)];
+    return v;
+  }
+  static DEV void arg(const DevProgram& P, const DevFastPlan& F, uint8_t opnd, int a, const COLV& cur, uint32_t curv,
+                      const u64x16& reg, uint32_t rv, uint64_t& v, bool& valid) {
+    valid = true;
+    v = 0;
+#pragma unroll
+    for (int j = 0; j < kMaxAggs; ++j) {
+      if (j < SIG::NA && j == a) {
+        if (SIG::arg_dyn(j)) FastPolicy<BANK, U_>::arg(P, F, opnd, j, cur, curv, reg, rv, v, valid);
+        else v = cur[SIG::arg_col(j)];
+      }
+    }
+  }
+};
+
+// signature list: index == sig id handed to the launchers; -1: none
+template <int BANK, int U> using PolPred2F64 = StaticPolicy<BANK, U, SigPred2F64>;
 
 // ---------------------------------------------------------------------------------------------
 // accumulator algebra (one 64-bit word per (group, aggregate))

@@ -1,0 +1,26 @@
+"""Kernel-time probe: runs one query a few times and prints the built-in profiler's per-kernel averages."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import pyarrow as pa
+from datafusion_archive_amd import execution as ex
+from datafusion_archive_amd.logicalplan import *
+rows = int(float(sys.argv[1])); groups = float(sys.argv[2]); filt = int(sys.argv[3])
+for kv in sys.argv[4:]:
+    k, v = kv.split("="); ex.set_option(k, int(v))
+ex.init(0)
+syn = [("k", ex.SYNTH_I64_UNIFORM, 0, groups, 0.0), ("v", ex.SYNTH_F64_EXACT, 1, 0.0, 0.0)]
+schema = pa.schema([("k", pa.int64()), ("v", pa.float64())])
+t = ex.DeviceTable.synth(syn, 0xDF02, 0, rows)
+lit = lambda v: Literal(ScalarValue.Float64(v))
+pred = BinaryExpr(BinaryExpr(Column(1), Operator.Gt, lit(204.8)), Operator.And, BinaryExpr(Column(1), Operator.Lt, lit(409.6)))
+def run():
+    rel = t.scan(1 << 26)
+    if filt: rel = ex.FilterRelation(rel, ex.compile_scalar_expr(None, pred, schema), schema)
+    rel = ex.AggregateRelation(None, rel, [ex.compile_scalar_expr(None, Column(0), schema)], [ex.compile_expr(None, AggregateFunction("SUM", [Column(1)], DataType.Float64), schema)])
+    return rel.next()
+run(); ex.profile_reset(); ex.profile_enable(True)
+for _ in range(3): out = run()
+ex.profile_enable(False)
+print(f"rows={rows} groups={groups} filt={filt} opts={sys.argv[4:]} -> groups_out={out.num_rows}")
+for p in ex.profile_snapshot():
+    print(f"   {p['kernel']:14s} launches={p['launches']:3d} avg_us={p['total_ms']/p['launches']*1e3:9.1f}")
