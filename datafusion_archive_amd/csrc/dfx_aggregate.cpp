@@ -404,8 +404,8 @@ Status AggregateRelation::Impl::consume_batch(const DeviceBatch& b) {
   const AggOptions& o = agg_options();
   if (!lds_calibrated && o.strategy == 0 && n > (1 << 21)) {
     // calibration slice: measure the LDS front-cache hit rate and the group count on the first
-    // 2^20 rows before committing the rest of the stream to a strategy
-    const int64_t n0 = 1 << 20;
+    // 2^18 rows before committing the rest of the stream to a strategy
+    const int64_t n0 = 1 << 18;
     DFX_RETURN_IF_ERROR(launch_rows(b, prog, cols, 0, n0));
     uint32_t hc[CTRL_WORDS];
     DFX_RETURN_IF_ERROR(read_ctrl(hc));
