@@ -187,7 +187,7 @@ Status AggregateRelation::Impl::alloc_table(int cap_log2, DevTable* Tn, std::vec
   Tn->load_limit = cap / 2;
   Tn->max_probe = (int)std::min<uint64_t>(cap, 1u << 30);
   {  // probing block = what one workgroup can hold in 64 KB of LDS (keys + accumulators)
-    uint64_t blk = 4096 / (uint64_t)(std::max(kw, 1) + std::max(na, 1));  // 32 KB of LDS per block
+    uint64_t blk = 16384 / (uint64_t)(std::max(kw, 1) + std::max(na, 1));  // 128 KB of LDS per block (pass 2: one workgroup per CU)
     uint64_t p2 = 64;
     while (p2 * 2 <= blk) p2 *= 2;
     if (p2 > cap) p2 = cap;
@@ -250,15 +250,12 @@ Status AggregateRelation::Impl::ensure_partition(int64_t rows) {
   int ps = 0;
   while ((1ull << ps) < S) ++ps;
   PT.part_shift = (uint32_t)ps;
-  // LDS budget of a producer workgroup: 64 KB = 8 wave-private staging areas + one u32 fill counter
-  // per partition.  A wave trip (U x 64 rows) must fit its staging area: U = 4 when the rows are
-  // narrow, U = 2 otherwise.
+  // producers keep one u32 fill counter per partition in LDS (<= 16 KB): 4 workgroups of 512 lanes per CU
   if (PT.n_parts > 4096) return Status::Err(DFX_NOT_IMPLEMENTED, "partitioned strategy: too many table blocks");
-  const uint32_t budget = 65536 - PT.n_parts * 4 - 16;
-  uint32_t stage = budget / (8 * PT.n_words * 8) / 64 * 64;  // 8 waves per producer workgroup
-  if (stage < 128) return Status::Err(DFX_NOT_IMPLEMENTED, "partitioned strategy: rows too wide for the LDS staging area");
-  if (stage < 256) stage = 128;
-  PT.stage_rows = stage;
+  // one producer workgroup (1024 lanes) per CU: producers x partitions x 128 B of open region lines
+  // (8 MB at 256 x 256) stay L2-resident, so the 16-byte row stores merge into full lines in L2
+  PT.n_producers = (uint32_t)std::min(1024, device_cu_count());
+  PT.stage_rows = 0;
   const uint64_t avg = (uint64_t)rows / ((uint64_t)PT.n_producers * PT.n_parts) + 1;
   PT.cap_rows = (uint32_t)((2 * avg + 64 + 63) / 64 * 64);
   const size_t row_bytes = sizeof(uint64_t) * (size_t)PT.n_parts * PT.n_producers * PT.n_words * PT.cap_rows;
@@ -490,7 +487,7 @@ Status AggregateRelation::Impl::drain() {
     DFX_HIP(hipMemsetAsync(ctrl.get(), 0, sizeof(uint32_t) * CTRL_WORDS, s));
     DFX_HIP(hipStreamSynchronize(s));
   } else {
-    int cap_log2 = agg_options().capacity_log2 > 0 ? agg_options().capacity_log2 : 22;
+    int cap_log2 = agg_options().capacity_log2 > 0 ? agg_options().capacity_log2 : 21;
     cap_log2 = std::max(6, std::min(cap_log2, 34));
     DFX_RETURN_IF_ERROR(alloc_table(cap_log2, &T, &table_owners, true));
     spill.words = nullptr;

@@ -438,7 +438,8 @@ struct StaticPolicy {
     cv = 0xFFFFFFFFu;
 #pragma unroll
     for (int c = 0; c < BANK; ++c)
-      if (c < SIG::NCOL) col[c] = inb ? ((const uint64_t*)C.c[c].values)[row] : 0ull;
+      if (c < SIG::NCOL)  // streamed once: non-temporal, so the table blocks / open region lines keep the L2
+        col[c] = inb ? __builtin_nontemporal_load((const uint64_t*)C.c[c].values + row) : 0ull;
   }
   static DEV int na(const DevTable&) { return SIG::NA; }
   static DEV uint8_t acc_kind(const DevTable&, int a) { return SIG::acc(a); }
@@ -635,7 +636,9 @@ DEV void spill_row(const DevTable& T, const DevRows& spill, bool do_spill, const
     if (pos < spill.capacity) {
 #pragma unroll
       for (int w = 0; w < KW; ++w) spill.words[(uint64_t)w * spill.capacity + pos] = key[w];
-      for (int a = 0; a < T.na; ++a) spill.words[(uint64_t)(KW + a) * spill.capacity + pos] = val[a];
+#pragma unroll
+      for (int a = 0; a < kMaxAggs; ++a)  // static indices: val[] must stay in registers
+        if (a < T.na) spill.words[(uint64_t)(KW + a) * spill.capacity + pos] = val[a];
     }
   }
 }

@@ -5,14 +5,17 @@ import pyarrow as pa
 from datafusion_archive_amd import execution as ex
 from datafusion_archive_amd.logicalplan import *
 rows = int(float(sys.argv[1])); groups = float(sys.argv[2]); filt = int(sys.argv[3])
+LO, HI = 204.8, 409.6
 for kv in sys.argv[4:]:
+    if kv.startswith("lo="): LO = float(kv[3:]); continue
+    if kv.startswith("hi="): HI = float(kv[3:]); continue
     k, v = kv.split("="); ex.set_option(k, int(v))
 ex.init(0)
 syn = [("k", ex.SYNTH_I64_UNIFORM, 0, groups, 0.0), ("v", ex.SYNTH_F64_EXACT, 1, 0.0, 0.0)]
 schema = pa.schema([("k", pa.int64()), ("v", pa.float64())])
 t = ex.DeviceTable.synth(syn, 0xDF02, 0, rows)
 lit = lambda v: Literal(ScalarValue.Float64(v))
-pred = BinaryExpr(BinaryExpr(Column(1), Operator.Gt, lit(204.8)), Operator.And, BinaryExpr(Column(1), Operator.Lt, lit(409.6)))
+pred = BinaryExpr(BinaryExpr(Column(1), Operator.Gt, lit(LO)), Operator.And, BinaryExpr(Column(1), Operator.Lt, lit(HI)))
 def run():
     rel = t.scan(1 << 26)
     if filt: rel = ex.FilterRelation(rel, ex.compile_scalar_expr(None, pred, schema), schema)
