@@ -156,6 +156,22 @@ def main():
                     "all_aggregation_kernels_GBps": round(n_rows * args.steps * 16 / pipeline_ms * 1e-6, 1)
                     if pipeline_ms > 0 else None}
 
+    # HBM traffic of the dominant kernel from the rocprofv3 PMC passes of this same command
+    # (tools/gpu_profile_bench.sh -> profiles/r01_bench_hbm_counters.json; FETCH_SIZE and WRITE_SIZE
+    # collected in separate passes; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950 --
+    # with the doubling it equals the table bytes read, our calibration point).  null if absent.
+    if roofline is not None:
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_bench_hbm_counters.json")) as f:
+                ctr = json.load(f)
+            key = [k for k in ctr if ("k_partition<" in k if dom == "partition" else dom in k)]
+            if key:
+                c = ctr[key[0]]
+                roofline["traffic"] = (2.0 * c["FETCH_SIZE_KB_per_dispatch"] + c["WRITE_SIZE_KB_per_dispatch"]) * 1024.0
+                roofline["traffic_source"] = "profiles/r01_bench_hbm_counters.json (rocprofv3 --pmc, 2*FETCH_SIZE + WRITE_SIZE per dispatch)"
+        except Exception:
+            pass
+
     # ---- correctness of the timed result (not timed) --------------------------------------------
     verified = None
     if rank == 0 or world > 1:
