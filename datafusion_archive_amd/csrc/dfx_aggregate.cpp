@@ -245,17 +245,37 @@ Status AggregateRelation::Impl::ensure_partition(int64_t rows) {
   memset(&PT, 0, sizeof(PT));
   const uint64_t S = (uint64_t)T.block_mask + 1;
   PT.n_parts = (uint32_t)((T.mask + 1) / S);
-  PT.n_producers = (uint32_t)(2 * device_cu_count());
   PT.n_words = (uint32_t)(kw + na);
   int ps = 0;
   while ((1ull << ps) < S) ++ps;
   PT.part_shift = (uint32_t)ps;
-  // producers keep one u32 fill counter per partition in LDS (<= 16 KB): 4 workgroups of 512 lanes per CU
   if (PT.n_parts > 4096) return Status::Err(DFX_NOT_IMPLEMENTED, "partitioned strategy: too many table blocks");
-  // one producer workgroup (1024 lanes) per CU: producers x partitions x 128 B of open region lines
-  // (8 MB at 256 x 256) stay L2-resident, so the 16-byte row stores merge into full lines in L2
-  PT.n_producers = (uint32_t)std::min(1024, device_cu_count());
-  PT.stage_rows = 0;
+  // pass-1 flavour.  mode 1 (default): the workgroup collects passing rows in LDS, counting-sorts them by
+  // partition and writes them out in runs (scattered 16-byte stores are transaction-bound at ~87 G/s,
+  // tools/ubench2.hip); it needs runs of several rows per partition per flush, i.e. few enough partitions.
+  // mode 0: one 16-byte store per row straight from registers (many partitions, or by option).
+  const AggOptions& o = agg_options();
+  const uint32_t block = o.partition_block == 512 ? 512u : 1024u;
+  const size_t budget = block == 512 ? (size_t)79 * 1024 : (size_t)156 * 1024;
+  const uint32_t sort_cap = partition_sort_capacity(PT.n_words, PT.n_parts, block, budget);
+  const int want = o.partition_mode & 15;
+  if (want == 2 && partition_ring_bytes(PT.n_words, PT.n_parts) <= (size_t)158 * 1024) {
+    PT.mode = 2u | ((uint32_t)o.partition_mode & ~15u);
+    PT.block = 1024;
+    PT.stage_rows = 0;
+    PT.n_producers = (uint32_t)std::min(1024, device_cu_count());
+  } else if (want != 0 && PT.n_parts <= 1024 && sort_cap >= 4 * PT.n_parts) {
+    PT.mode = 1u | ((uint32_t)o.partition_mode & ~15u);
+    PT.block = block;
+    PT.stage_rows = sort_cap;
+    PT.n_producers = (uint32_t)std::min(1024, device_cu_count() * (int)(1024 / block));
+  } else {
+    // one producer workgroup (1024 lanes) per CU: producers x partitions x 128 B of open region lines
+    PT.mode = 0;
+    PT.block = 1024;
+    PT.stage_rows = 0;
+    PT.n_producers = (uint32_t)std::min(1024, device_cu_count());
+  }
   const uint64_t avg = (uint64_t)rows / ((uint64_t)PT.n_producers * PT.n_parts) + 1;
   PT.cap_rows = (uint32_t)((2 * avg + 64 + 63) / 64 * 64);
   const size_t row_bytes = sizeof(uint64_t) * (size_t)PT.n_parts * PT.n_producers * PT.n_words * PT.cap_rows;

@@ -184,7 +184,9 @@ struct DevPartition {
   uint32_t cap_rows;   // rows per (producer, partition) region
   uint32_t n_words;    // kw + na
   uint32_t part_shift; // partition = slot >> part_shift
-  uint32_t stage_rows; // LDS staging capacity per pass-1 WAVE (waves stage and flush independently)
+  uint32_t stage_rows; // mode 1: rows of the pass-1 workgroup's LDS write-combining buffer
+  uint32_t mode;       // pass 1: 0 direct routing (one 16-byte store per row), 1 LDS counting sort + coalesced copy-out
+  uint32_t block;      // pass-1 workgroup size (mode 1: 512 or 1024)
 };
 
 struct DevProjectPlan {

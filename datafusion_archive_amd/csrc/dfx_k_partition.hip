@@ -120,12 +120,484 @@ __global__ __launch_bounds__(kPBlock) void k_partition(const DevProgram P, const
   if (err) atomicOr(&T.ctrl[CTRL_ERROR], err);
 }
 
+
+// ---- pass 1, write-combining variant --------------------------------------------------------------
+// Measured on MI355X (tools/ubench2.hip, profiles/r01_ubench_mi355x.jsonl): scattered 16-byte stores
+// run at ~87 G/s chip-wide however L2-resident their lines are (transaction-bound), while runs of
+// >= 64 contiguous bytes written by adjacent lanes run at > 400 G rows/s.  So the workgroup first
+// COLLECTS passing rows in an LDS buffer (one wave-aggregated LDS atomic per trip), and when the
+// buffer is full the whole workgroup counting-sorts it by partition (LDS histogram -> scan ->
+// permutation) and copies it out in sorted order: adjacent lanes then write adjacent rows of the
+// same region.  The hash is computed once per PASSING row at full lane utilisation, not once per
+// scanned row.  A flush round is six barriers; all waves take part in every round (a wave that has
+// finished its input keeps joining rounds until every wave has finished).
+constexpr int kSortMaxCap = 8192;  // LDS buffer rows (upper bound: 13-bit row index in the permutation word)
+
+DEV uint32_t mbcnt64(uint64_t m) {
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+struct SortLds {
+  uint64_t* buf;    // [n_words][cap] word-major row buffer
+  uint32_t* perm;   // [cap] sorted position -> (partition << 16 | buffer row)
+  uint32_t* hist;   // [n_parts] rows of this round per partition; after the scan: exclusive offsets
+  uint32_t* fill;   // [n_parts] rows already written to this producer's region
+  uint32_t* delta;  // [n_parts] region row = sorted position + delta (mod 2^32)
+  uint32_t* misc;   // [0] claimed rows, [1] finished waves, [2..] wave totals of the scan
+  uint32_t cap;     // rows of the buffer (plane stride)
+  uint32_t limit;   // rows accepted before the next flush (<= cap)
+};
+
+template <int BLOCK>
+DEV bool partition_flush(const DevTable& T, const DevPartition& PT, const DevRows& spill, const SortLds& L,
+                         uint32_t producer, int na) {
+  constexpr int NWAVES = BLOCK / 64;
+  constexpr int ITEMS = kSortMaxCap / BLOCK;
+  const uint32_t tid = threadIdx.x;
+  const int lane = lane_id();
+  const uint32_t items = L.cap / BLOCK;
+  __syncthreads();  // B0: every append of this round is in the buffer
+  uint32_t R = L.misc[0];
+  if (R > L.limit) R = L.limit;
+  const bool last = L.misc[1] == (uint32_t)NWAVES;
+  if (PT.mode & 0x20u) { __syncthreads(); if (tid == 0) L.misc[0] = 0; __syncthreads(); return last; }
+  uint32_t packed[ITEMS];
+#pragma unroll
+  for (int it = 0; it < ITEMS; ++it) {
+    packed[it] = 0xFFFFFFFFu;
+    const uint32_t i = tid + (uint32_t)it * BLOCK;
+    if ((uint32_t)it < items && i < R) {
+      uint64_t key[1] = {L.buf[i]};
+      const uint32_t part = partition_of(T, PT, hash_keys<1>(key));
+      const uint32_t rank = atomicAdd(&L.hist[part], 1u);
+      packed[it] = (part << 16) | rank;
+    }
+  }
+  __syncthreads();  // B1: histogram complete
+  // exclusive scan over partitions; PP consecutive partitions per thread
+  const uint32_t NPT = PT.n_parts;
+  const uint32_t PP = (NPT + BLOCK - 1) / BLOCK;
+  const uint32_t p0 = tid * PP;
+  uint32_t sum = 0;
+  for (uint32_t q = 0; q < PP; ++q)
+    if (p0 + q < NPT) sum += L.hist[p0 + q];
+  uint32_t inc = sum;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t o = __shfl_up(inc, d, 64);
+    if (lane >= d) inc += o;
+  }
+  if (lane == 63) L.misc[2 + (tid >> 6)] = inc;
+  __syncthreads();  // B2
+  uint32_t excl = inc - sum;
+#pragma unroll
+  for (int w = 0; w < NWAVES; ++w)
+    if (w < (int)(tid >> 6)) excl += L.misc[2 + w];
+  for (uint32_t q = 0; q < PP; ++q) {
+    const uint32_t p = p0 + q;
+    if (p < NPT) {
+      const uint32_t h = L.hist[p];
+      const uint32_t f = L.fill[p];
+      L.hist[p] = excl;
+      L.delta[p] = f - excl;
+      L.fill[p] = f + h;
+      excl += h;
+    }
+  }
+  __syncthreads();  // B3: offsets ready
+#pragma unroll
+  for (int it = 0; it < ITEMS; ++it) {
+    if (packed[it] != 0xFFFFFFFFu) {
+      const uint32_t part = packed[it] >> 16, rank = packed[it] & 0xFFFFu;
+      L.perm[L.hist[part] + rank] = (part << 16) | (tid + (uint32_t)it * BLOCK);
+    }
+  }
+  __syncthreads();  // B4: permutation complete
+  for (uint32_t p = tid; p < NPT; p += BLOCK) L.hist[p] = 0;
+  if (tid == 0) L.misc[0] = 0;
+#pragma unroll
+  for (int it = 0; it < ITEMS; ++it) {
+    if ((uint32_t)it < items && (uint32_t)it * BLOCK < R) {  // wave-uniform
+      const uint32_t j = tid + (uint32_t)it * BLOCK;
+      const bool inb = j < R;
+      uint64_t key[1] = {0};
+      uint64_t val[kMaxAggs];
+#pragma unroll
+      for (int a = 0; a < kMaxAggs; ++a) val[a] = 0;
+      bool todo = false;
+      if (inb) {
+        const uint32_t e = L.perm[j];
+        const uint32_t part = e >> 16, i = e & 0xFFFFu;
+        const uint32_t row = j + L.delta[part];
+        key[0] = L.buf[i];
+#pragma unroll
+        for (int a = 0; a < kMaxAggs; ++a)
+          if (a < na) val[a] = L.buf[(size_t)(1 + a) * L.cap + i];
+        if (PT.mode & 0x10u) { if (key[0] == 77 && val[0] == 78) todo = true; } else
+        if (row < PT.cap_rows) {
+          uint64_t* dst = PT.rows + (((uint64_t)part * PT.n_producers + producer) * PT.cap_rows + row) * PT.n_words;
+          if (na == 1) {
+            *(ulonglong2*)dst = make_ulonglong2(key[0], val[0]);
+          } else {
+            dst[0] = key[0];
+#pragma unroll
+            for (int a = 0; a < kMaxAggs; ++a)
+              if (a < na) dst[1 + a] = val[a];
+          }
+        } else {
+          todo = true;  // region overflow (skewed keys): the general path takes the row
+        }
+      }
+      spill_row<1>(T, spill, todo, key, val);
+    }
+  }
+  __syncthreads();  // B5: the buffer may be overwritten
+  return last;
+}
+
+template <typename POL, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_partition_sorted(const DevProgram P, const DevFastPlan F, const DevColumns C,
+                                                           const DevAggPlan plan, const DevTable T,
+                                                           const DevPartition PT, const DevRows spill, const int64_t n) {
+  typedef typename POL::COLV COLV;
+  constexpr int U = POL::U;
+  constexpr int NWAVES = BLOCK / 64;
+  extern __shared__ __attribute__((aligned(16))) uint64_t lds[];
+  SortLds L;
+  L.cap = PT.stage_rows;
+  // co-resident workgroups must not flush in lockstep (a flush leaves the CU's memory pipe idle unless the
+  // other workgroup is scanning): odd producers take a short first round
+  L.limit = (blockIdx.x & 1u) ? L.cap / 2 : L.cap;
+  L.buf = lds;
+  L.perm = (uint32_t*)(lds + (size_t)PT.n_words * L.cap);
+  L.hist = L.perm + L.cap;
+  L.fill = L.hist + PT.n_parts;
+  L.delta = L.fill + PT.n_parts;
+  L.misc = L.delta + PT.n_parts;
+  const int lane = lane_id();
+  const int wave = threadIdx.x >> 6;
+  const int na = POL::na(T);
+  for (uint32_t p = threadIdx.x; p < PT.n_parts; p += BLOCK) {
+    L.hist[p] = 0;
+    L.fill[p] = 0;
+  }
+  if (threadIdx.x < 2 + NWAVES) L.misc[threadIdx.x] = 0;
+  __syncthreads();
+  const uint32_t producer = blockIdx.x;
+  const int64_t n_groups = (n + 63) >> 6;
+  const int64_t wave_global = (int64_t)blockIdx.x * NWAVES + wave;
+  const int64_t n_waves = (int64_t)gridDim.x * NWAVES;
+  uint32_t err = 0;
+  uint64_t passed = 0;
+  for (int64_t w0 = wave_global * U; w0 < n_groups; w0 += n_waves * U) {
+    COLV col[U];
+    uint32_t cv[U];
+    FOR_U {
+      const int64_t row = (w0 + u) * 64 + lane;
+      POL::load(P, C, row, row < n, col[u], cv[u]);
+    }
+    uint64_t key[U][1];
+    uint64_t val[U][kMaxAggs];
+    uint32_t pend = 0;
+    FOR_U {
+      const int64_t row = (w0 + u) * 64 + lane;
+      const bool inb = row < n;
+      u64x16 reg;
+      uint32_t rv = 0;
+      POL::eval(P, F, col[u], cv[u], reg, rv, inb, err);
+      bool pass = inb && POL::pass(P, F, plan.pred, col[u], cv[u], reg, rv);
+      key[u][0] = POL::key(P, F, plan.key[0], 0, col[u], cv[u], reg, rv);
+#pragma unroll
+      for (int a = 0; a < kMaxAggs; ++a) {
+        val[u][a] = 0;
+        if (a < POL::na(T)) {
+          uint64_t v;
+          bool valid;
+          POL::arg(P, F, plan.arg[a], a, col[u], cv[u], reg, rv, v, valid);
+          val[u][a] = transform_value(POL::xform(T, a), v, valid);
+        }
+      }
+      passed += pass ? 1 : 0;
+      if (pass && key[u][0] == kEmptyKey) {  // the claim-sentinel key lives outside the blocks
+        const bool ok = table_apply<1>(T, key[u], val[u]);
+        (void)ok;
+        pass = false;
+      }
+      pend |= (pass ? 1u : 0u) << u;
+    }
+    while (true) {
+      uint64_t m[U];
+      uint32_t tot = 0;
+      FOR_U {
+        m[u] = __ballot((pend >> u) & 1u);
+        tot += (uint32_t)__popcll(m[u]);
+      }
+      if (tot == 0) break;
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(&L.misc[0], tot);
+      base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+      uint32_t b = base;
+      FOR_U {
+        const uint32_t pos = b + mbcnt64(m[u]);
+        if (((pend >> u) & 1u) && pos < L.limit) {
+          if (!(PT.mode & 0x40u))
+          L.buf[pos] = key[u][0];
+#pragma unroll
+          for (int a = 0; a < kMaxAggs; ++a)
+            if (a < POL::na(T)) L.buf[(size_t)(1 + a) * L.cap + pos] = val[u][a];
+          pend &= ~(1u << u);
+        }
+        b += (uint32_t)__popcll(m[u]);
+      }
+      if (base + tot <= L.limit) break;
+      partition_flush<BLOCK>(T, PT, spill, L, producer, na);
+      L.limit = L.cap;
+    }
+  }
+  if (lane == 0) atomicAdd(&L.misc[1], 1u);
+  while (!partition_flush<BLOCK>(T, PT, spill, L, producer, na)) {
+  }
+  for (uint32_t p = threadIdx.x; p < PT.n_parts; p += BLOCK) {
+    const uint32_t f = L.fill[p];
+    PT.counts[(uint64_t)p * PT.n_producers + producer] = f < PT.cap_rows ? f : PT.cap_rows;
+  }
+#pragma unroll
+  for (int mm = 32; mm >= 1; mm >>= 1) passed += shfl_xor_u64(passed, mm);
+  if (lane == 0 && passed) atomicAdd((unsigned long long*)&T.ctrl[CTRL_PASSED_LO], (unsigned long long)passed);
+  if (err) atomicOr(&T.ctrl[CTRL_ERROR], err);
+}
+
+// ---- pass 1, lock-free write-combining variant ("ring") ----------------------------------------------
+// The counting-sort variant above pays for its barriers: while a workgroup sorts, its CU issues no
+// loads.  Here no wave ever waits for another one in the common case:
+//   * each wave compacts its passing rows into a wave-private LDS queue (ballot + mbcnt); whenever 64
+//     rows are queued it pops them and routes them at full lane utilisation;
+//   * routing a row: hash -> partition; pos = LDS atomic on the workgroup's fill[partition] = the row's
+//     final index in this producer's region; the row is parked in the partition's LDS ring
+//     (kRingNCH chunks of kRingCH rows); the lane that parks the last row of a chunk (per-chunk commit
+//     counter) owns the flush;
+//   * flush jobs of a wave are executed cooperatively: kRingCH adjacent lanes store one chunk, i.e. one
+//     64-byte run (>= 64-byte runs reach the coalesced store rate, tools/ubench2.hip);
+//   * a chunk slot is reused only after its previous generation was flushed (per-slot generation word).
+//     A lane whose slot is still busy keeps its row, helps with this wave's flush jobs and retries; the
+//     lowest incomplete chunk of a partition never depends on anything, so every retry loop terminates.
+// Leftover partial chunks are written row by row at the end.
+constexpr int kRingCH = 4;
+constexpr int kRingNCH = 4;
+constexpr int kRingRP = kRingCH * kRingNCH;  // ring rows per partition
+constexpr int kRingQ = 192;                  // wave queue rows: < 64 left over + 2 row-groups appended
+constexpr int kRingBlock = 1024;
+
+struct RingLds {
+  uint64_t* ring;    // [n_parts][kRingRP][n_words]
+  uint64_t* queue;   // [waves][n_words][kRingQ]
+  uint2* jobs;       // [waves][64] (partition, chunk)
+  uint32_t* fill;    // [n_parts]
+  uint32_t* commit;  // [n_parts][kRingNCH]
+  uint32_t* gen;     // [n_parts][kRingNCH]
+};
+
+size_t partition_ring_bytes(uint32_t n_words, uint32_t n_parts) {
+  return (size_t)n_parts * kRingRP * n_words * 8 + (size_t)(kRingBlock / 64) * kRingQ * n_words * 8 +
+         (size_t)(kRingBlock / 64) * 64 * 8 + (size_t)n_parts * 4 * (1 + 2 * kRingNCH) + 64;
+}
+
+#define WG_SCOPE __HIP_MEMORY_SCOPE_WORKGROUP
+
+// route up to 64 rows (one per lane with have == true)
+template <int NV>
+DEV void ring_route(const DevTable& T, const DevPartition& PT, const DevRows& spill, const RingLds& L, uint32_t producer,
+                    int na, bool have, const uint64_t (&key)[1], const uint64_t (&val)[kMaxAggs], uint32_t& err) {
+  const int lane = lane_id();
+  const int wave = threadIdx.x >> 6;
+  const int NW = (int)PT.n_words;
+  uint32_t part = 0, pos = 0;
+  bool pending = false, todo = false;
+  if (have) {
+    part = partition_of(T, PT, hash_keys<1>(key));
+    pos = atomicAdd(&L.fill[part], 1u);
+    pending = pos < PT.cap_rows;
+    todo = !pending;  // region overflow (skewed keys): the general path takes the row
+  }
+  spill_row<1>(T, spill, todo, key, val);
+  const uint32_t c = pos / kRingCH, sl = c % kRingNCH, g = c / kRingNCH, r = pos % kRingCH;
+  const uint32_t cs = part * kRingNCH + sl;
+  uint2* jobs = L.jobs + wave * 64;
+  uint32_t spins = 0;
+  while (true) {
+    bool job = false;
+    if (pending && __hip_atomic_load(&L.gen[cs], __ATOMIC_ACQUIRE, WG_SCOPE) == g) {
+      uint64_t* dst = L.ring + ((size_t)part * kRingRP + sl * kRingCH + r) * NW;
+      if (NV == 1) {
+        *(ulonglong2*)dst = make_ulonglong2(key[0], val[0]);
+      } else {
+        dst[0] = key[0];
+#pragma unroll
+        for (int a = 0; a < NV; ++a)
+          if (a < na) dst[1 + a] = val[a];
+      }
+      const uint32_t old = __hip_atomic_fetch_add(&L.commit[cs], 1u, __ATOMIC_ACQ_REL, WG_SCOPE);
+      job = old == (uint32_t)kRingCH - 1u;
+      pending = false;
+    }
+    const uint64_t jm = __ballot(job);
+    if (jm != 0) {
+      const uint32_t njobs = (uint32_t)__popcll(jm);
+      if (job) jobs[mbcnt64(jm)] = make_uint2(part, c);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      for (uint32_t j0 = 0; j0 < njobs; j0 += 64 / kRingCH) {
+        const uint32_t j = j0 + (uint32_t)lane / kRingCH;
+        if (j < njobs) {
+          const uint2 jb = jobs[j];
+          const uint32_t rr = (uint32_t)lane % kRingCH;
+          const uint64_t* src = L.ring + ((size_t)jb.x * kRingRP + (jb.y % kRingNCH) * kRingCH + rr) * NW;
+          uint64_t* out = PT.rows + (((uint64_t)jb.x * PT.n_producers + producer) * PT.cap_rows + (uint64_t)jb.y * kRingCH + rr) * NW;
+          if (NV == 1) {
+            *(ulonglong2*)out = *(const ulonglong2*)src;
+          } else {
+            for (int w = 0; w < NW; ++w) out[w] = src[w];
+          }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      if (job) {  // the slot belongs to the next generation
+        __hip_atomic_store(&L.commit[cs], 0u, __ATOMIC_RELAXED, WG_SCOPE);
+        __hip_atomic_fetch_add(&L.gen[cs], 1u, __ATOMIC_RELEASE, WG_SCOPE);
+      }
+    }
+    if (__ballot(pending) == 0) break;
+    if (++spins > (1u << 22)) {  // cannot happen (see above); never hang the device
+      err |= 4u;
+      break;
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
+
+template <typename POL>
+__global__ __launch_bounds__(kRingBlock) void k_partition_ring(const DevProgram P, const DevFastPlan F, const DevColumns C,
+                                                              const DevAggPlan plan, const DevTable T,
+                                                              const DevPartition PT, const DevRows spill, const int64_t n) {
+  typedef typename POL::COLV COLV;
+  constexpr int U = POL::U;
+  static_assert(U == 1 || U == 2 || U == 4, "row-groups per trip");
+  constexpr int NWAVES = kRingBlock / 64;
+  constexpr int NV = POL::kStaticNa == 1 ? 1 : kMaxAggs;
+  extern __shared__ __attribute__((aligned(16))) uint64_t lds[];
+  const int NW = (int)PT.n_words;
+  RingLds L;
+  L.ring = lds;
+  L.queue = L.ring + (size_t)PT.n_parts * kRingRP * NW;
+  L.jobs = (uint2*)(L.queue + (size_t)NWAVES * kRingQ * NW);
+  L.fill = (uint32_t*)(L.jobs + NWAVES * 64);
+  L.commit = L.fill + PT.n_parts;
+  L.gen = L.commit + (size_t)PT.n_parts * kRingNCH;
+  const int lane = lane_id();
+  const int wave = threadIdx.x >> 6;
+  const int na = POL::na(T);
+  for (uint32_t p = threadIdx.x; p < PT.n_parts * (1 + 2 * kRingNCH); p += kRingBlock) L.fill[p] = 0;  // fill, commit, gen
+  __syncthreads();
+  const uint32_t producer = blockIdx.x;
+  uint64_t* q = L.queue + (size_t)wave * kRingQ * NW;  // word-major planes [NW][kRingQ]
+  uint32_t qn = 0;                                     // queued rows (wave-uniform)
+  const int64_t n_groups = (n + 63) >> 6;
+  const int64_t wave_global = (int64_t)blockIdx.x * NWAVES + wave;
+  const int64_t n_waves = (int64_t)gridDim.x * NWAVES;
+  uint32_t err = 0;
+  uint64_t passed = 0;
+  for (int64_t w0 = wave_global * U; w0 < n_groups; w0 += n_waves * U) {
+    COLV col[U];
+    uint32_t cv[U];
+    FOR_U {
+      const int64_t row = (w0 + u) * 64 + lane;
+      POL::load(P, C, row, row < n, col[u], cv[u]);
+    }
+    FOR_U {
+      const int64_t row = (w0 + u) * 64 + lane;
+      const bool inb = row < n;
+      u64x16 reg;
+      uint32_t rv = 0;
+      POL::eval(P, F, col[u], cv[u], reg, rv, inb, err);
+      bool pass = inb && POL::pass(P, F, plan.pred, col[u], cv[u], reg, rv);
+      uint64_t key[1];
+      uint64_t val[kMaxAggs];
+      key[0] = POL::key(P, F, plan.key[0], 0, col[u], cv[u], reg, rv);
+#pragma unroll
+      for (int a = 0; a < kMaxAggs; ++a) {
+        val[a] = 0;
+        if (a < POL::na(T)) {
+          uint64_t v;
+          bool valid;
+          POL::arg(P, F, plan.arg[a], a, col[u], cv[u], reg, rv, v, valid);
+          val[a] = transform_value(POL::xform(T, a), v, valid);
+        }
+      }
+      passed += pass ? 1 : 0;
+      if (pass && key[0] == kEmptyKey) {  // the claim-sentinel key lives outside the blocks
+        const bool ok = table_apply<1>(T, key, val);
+        (void)ok;
+        pass = false;
+      }
+      const uint64_t m = __ballot(pass);
+      if (pass) {
+        const uint32_t at = qn + mbcnt64(m);
+        q[at] = key[0];
+#pragma unroll
+        for (int a = 0; a < NV; ++a)
+          if (a < na) q[(size_t)(1 + a) * kRingQ + at] = val[a];
+      }
+      qn += (uint32_t)__popcll(m);
+      if ((u & 1) == 1 || u == U - 1) {  // after every second row-group: the queue holds < 64 + 128 rows
+        while (qn >= 64) {
+          qn -= 64;
+          uint64_t k2[1];
+          uint64_t v2[kMaxAggs];
+          k2[0] = q[qn + lane];
+#pragma unroll
+          for (int a = 0; a < kMaxAggs; ++a) v2[a] = (a < NV && a < na) ? q[(size_t)(1 + a) * kRingQ + qn + lane] : 0;
+          ring_route<NV>(T, PT, spill, L, producer, na, true, k2, v2, err);
+        }
+      }
+    }
+  }
+  {  // the wave's last < 64 rows
+    uint64_t k2[1];
+    uint64_t v2[kMaxAggs];
+    const bool have = (uint32_t)lane < qn;
+    k2[0] = have ? q[lane] : 0;
+#pragma unroll
+    for (int a = 0; a < kMaxAggs; ++a) v2[a] = (have && a < NV && a < na) ? q[(size_t)(1 + a) * kRingQ + lane] : 0;
+    if (qn != 0) ring_route<NV>(T, PT, spill, L, producer, na, have, k2, v2, err);
+  }
+  __syncthreads();
+  // partial chunks + region counts
+  for (uint32_t p = threadIdx.x; p < PT.n_parts; p += kRingBlock) {
+    uint32_t f = L.fill[p];
+    if (f > PT.cap_rows) f = PT.cap_rows;
+    const uint32_t c = f / kRingCH;
+    for (uint32_t r = 0; r < f % kRingCH; ++r) {
+      const uint64_t* src = L.ring + ((size_t)p * kRingRP + (c % kRingNCH) * kRingCH + r) * NW;
+      uint64_t* out = PT.rows + (((uint64_t)p * PT.n_producers + producer) * PT.cap_rows + (uint64_t)c * kRingCH + r) * NW;
+      for (int w = 0; w < NW; ++w) out[w] = src[w];
+    }
+    PT.counts[(uint64_t)p * PT.n_producers + producer] = f;
+  }
+#pragma unroll
+  for (int mm = 32; mm >= 1; mm >>= 1) passed += shfl_xor_u64(passed, mm);
+  if (lane == 0 && passed) atomicAdd((unsigned long long*)&T.ctrl[CTRL_PASSED_LO], (unsigned long long)passed);
+  if (err) atomicOr(&T.ctrl[CTRL_ERROR], err);
+}
+
 // pass 2: one workgroup per partition (= table block).  The rows of all producers are visited as
-// ONE flattened index space (prefix sums of the per-producer counts live in LDS), so all 256
-// lanes stay busy however small the individual regions are.
+// ONE flattened index space (prefix sums of the per-producer counts live in LDS), so all lanes stay
+// busy however small the individual regions are.  Global loads are issued RU rows ahead of the LDS
+// probing (the kernel is latency-bound otherwise: 16 waves, one dependent load each).
+template <int NA1>  // NA1 == 1: one aggregate (16-byte rows); 0: any
 __global__ __launch_bounds__(kABlock) void k_partition_agg(const DevTable T, const DevPartition PT, const DevRows spill) {
   extern __shared__ __attribute__((aligned(16))) uint64_t lds[];
   __shared__ uint32_t wave_tot[kABlock / 64];
+  constexpr int RU = NA1 ? 4 : 2;
+  constexpr int NV = NA1 ? 1 : kMaxAggs;
   const uint32_t S = T.block_mask + 1;
   const int NW = (int)PT.n_words;
   uint64_t* lkeys = lds;
@@ -134,9 +606,21 @@ __global__ __launch_bounds__(kABlock) void k_partition_agg(const DevTable T, con
   const uint32_t p = blockIdx.x;
   const uint64_t slot0 = (uint64_t)p * S;
   const int lane = lane_id();
-  for (uint32_t i = threadIdx.x; i < S; i += kABlock) {
-    lkeys[i] = T.keys[slot0 + i];
-    for (int a = 0; a < T.na; ++a) laccs[(size_t)a * S + i] = T.accs[(uint64_t)a * T.stride + slot0 + i];
+  // block -> LDS, 16-byte loads, all loads of a plane in flight before the LDS writes (S is a power of two >= 2)
+  for (int w = 0; w < NW; ++w) {
+    const uint64_t* src = (w == 0 ? T.keys : T.accs + (uint64_t)(w - 1) * T.stride) + slot0;
+    uint64_t* dst = lds + (size_t)w * S;
+    for (uint32_t i0 = threadIdx.x * 2; i0 < S; i0 += kABlock * 2 * 4) {
+      const uint32_t ia = i0, ib = i0 + kABlock * 2, ic = i0 + kABlock * 4, id = i0 + kABlock * 6;
+      const ulonglong2 ta = *(const ulonglong2*)(src + (ia < S ? ia : 0));  // clamped: all four loads in flight together
+      const ulonglong2 tb = *(const ulonglong2*)(src + (ib < S ? ib : 0));
+      const ulonglong2 tc = *(const ulonglong2*)(src + (ic < S ? ic : 0));
+      const ulonglong2 td = *(const ulonglong2*)(src + (id < S ? id : 0));
+      if (ia < S) *(ulonglong2*)(dst + ia) = ta;
+      if (ib < S) *(ulonglong2*)(dst + ib) = tb;
+      if (ic < S) *(ulonglong2*)(dst + ic) = tc;
+      if (id < S) *(ulonglong2*)(dst + id) = td;
+    }
   }
   // exclusive scan of the producer counts (n_producers <= 1024: one per thread)
   const uint32_t NP = PT.n_producers;
@@ -159,58 +643,79 @@ __global__ __launch_bounds__(kABlock) void k_partition_agg(const DevTable T, con
   if (threadIdx.x == 0) pre[NP] = total;
   __syncthreads();
   uint32_t new_keys = 0;
-  const uint32_t total_pad = (total + 63u) & ~63u;
-  for (uint32_t i = threadIdx.x; i < total_pad; i += kABlock) {
-    const bool inb = i < total;
-    uint64_t key[1];
-    uint64_t val[kMaxAggs];
-    key[0] = 0;
+  for (uint32_t i0 = 0; i0 < total; i0 += kABlock * RU) {  // wave-uniform trip count
+    uint64_t key[RU][1];
+    uint64_t val[RU][NV];
+    bool inb[RU];
 #pragma unroll
-    for (int a = 0; a < kMaxAggs; ++a) val[a] = 0;
-    bool todo = inb;
-    if (inb) {
-      // producer of flattened row i: the counts are near-uniform, so interpolate and correct
-      uint32_t lo = (uint32_t)(((uint64_t)i * NP) / total);
-      if (lo >= NP) lo = NP - 1;
-      while (pre[lo] > i) --lo;
-      while (pre[lo + 1] <= i) ++lo;
-      const uint64_t* src = PT.rows + (((uint64_t)p * NP + lo) * PT.cap_rows + (i - pre[lo])) * NW;
-      key[0] = src[0];
+    for (int r = 0; r < RU; ++r) {
+      const uint32_t i = i0 + (uint32_t)r * kABlock + threadIdx.x;
+      inb[r] = i < total;
+      key[r][0] = 0;
 #pragma unroll
-      for (int a = 0; a < kMaxAggs; ++a)
-        if (a < T.na) val[a] = src[1 + a];
-      const uint64_t h = hash_keys<1>(key);
-      uint32_t slot = (uint32_t)((h >> T.shift) & T.mask) & T.block_mask;
-      int found = -1;
-      for (uint32_t pr = 0; pr < S && found < 0; ++pr) {
-        const uint64_t k = lkeys[slot];
-        if (k == key[0]) {
-          found = (int)slot;
-        } else if (k == kEmptyKey) {
-          const uint64_t old = atomicCAS((unsigned long long*)&lkeys[slot], (unsigned long long)kEmptyKey,
-                                         (unsigned long long)key[0]);
-          if (old == kEmptyKey) {
-            found = (int)slot;
-            ++new_keys;
-          } else if (old == key[0]) {
-            found = (int)slot;
-          }
+      for (int a = 0; a < NV; ++a) val[r][a] = 0;
+      if (inb[r]) {
+        // producer of flattened row i: the counts are near-uniform, so interpolate and correct
+        uint32_t lo = (uint32_t)(((uint64_t)i * NP) / total);
+        if (lo >= NP) lo = NP - 1;
+        while (pre[lo] > i) --lo;
+        while (pre[lo + 1] <= i) ++lo;
+        const uint64_t* src = PT.rows + (((uint64_t)p * NP + lo) * PT.cap_rows + (i - pre[lo])) * NW;
+        if (NA1) {
+          const ulonglong2 kv = *(const ulonglong2*)src;
+          key[r][0] = kv.x;
+          val[r][0] = kv.y;
+        } else {
+          key[r][0] = src[0];
+#pragma unroll
+          for (int a = 0; a < NV; ++a)
+            if (a < T.na) val[r][a] = src[1 + a];
         }
-        if (found < 0) slot = (slot + 1) & T.block_mask;
-      }
-      if (found >= 0) {
-#pragma unroll
-        for (int a = 0; a < kMaxAggs; ++a)
-          if (a < T.na) acc_atomic(T.acc_kind[a], &laccs[(size_t)a * S + found], val[a]);
-        todo = false;
       }
     }
-    spill_row<1>(T, spill, todo, key, val);  // block full: grow-and-replay takes it
+#pragma unroll
+    for (int r = 0; r < RU; ++r) {
+      bool todo = inb[r];
+      if (inb[r]) {
+        const uint64_t h = hash_keys<1>(key[r]);
+        uint32_t slot = (uint32_t)((h >> T.shift) & T.mask) & T.block_mask;
+        int found = -1;
+        for (uint32_t pr = 0; pr < S && found < 0; ++pr) {
+          const uint64_t k = lkeys[slot];
+          if (k == key[r][0]) {
+            found = (int)slot;
+          } else if (k == kEmptyKey) {
+            const uint64_t old = atomicCAS((unsigned long long*)&lkeys[slot], (unsigned long long)kEmptyKey,
+                                           (unsigned long long)key[r][0]);
+            if (old == kEmptyKey) {
+              found = (int)slot;
+              ++new_keys;
+            } else if (old == key[r][0]) {
+              found = (int)slot;
+            }
+          }
+          if (found < 0) slot = (slot + 1) & T.block_mask;
+        }
+        if (found >= 0) {
+#pragma unroll
+          for (int a = 0; a < NV; ++a)
+            if (a < T.na) acc_atomic(T.acc_kind[a], &laccs[(size_t)a * S + found], val[r][a]);
+          todo = false;
+        }
+      }
+      if (__ballot(todo) != 0) {  // block full: grow-and-replay takes the row
+        uint64_t sv[kMaxAggs];
+#pragma unroll
+        for (int a = 0; a < kMaxAggs; ++a) sv[a] = a < NV ? val[r][a < NV ? a : 0] : 0;
+        spill_row<1>(T, spill, todo, key[r], sv);
+      }
+    }
   }
   __syncthreads();
-  for (uint32_t i = threadIdx.x; i < S; i += kABlock) {
-    T.keys[slot0 + i] = lkeys[i];
-    for (int a = 0; a < T.na; ++a) T.accs[(uint64_t)a * T.stride + slot0 + i] = laccs[(size_t)a * S + i];
+  for (int w = 0; w < NW; ++w) {
+    uint64_t* dst = (w == 0 ? T.keys : T.accs + (uint64_t)(w - 1) * T.stride) + slot0;
+    const uint64_t* src = lds + (size_t)w * S;
+    for (uint32_t i = threadIdx.x * 2; i < S; i += kABlock * 2) *(ulonglong2*)(dst + i) = *(const ulonglong2*)(src + i);
   }
 #pragma unroll
   for (int mm = 32; mm >= 1; mm >>= 1) new_keys += __shfl_xor(new_keys, mm, 64);
@@ -218,7 +723,34 @@ __global__ __launch_bounds__(kABlock) void k_partition_agg(const DevTable T, con
 }
 
 size_t partition_stage_bytes(const DevPartition& PT) {
-  return (size_t)PT.n_parts * 4 + 16;
+  if ((PT.mode & 15u) == 0) return (size_t)PT.n_parts * 4 + 16;
+  if ((PT.mode & 15u) == 2) return partition_ring_bytes(PT.n_words, PT.n_parts);
+  return (size_t)PT.stage_rows * ((size_t)PT.n_words * 8 + 4) + (size_t)PT.n_parts * 12 + (2 + 16) * 4 + 16;
+}
+
+// LDS rows of the write-combining buffer for a workgroup of `block` lanes and an LDS budget
+uint32_t partition_sort_capacity(uint32_t n_words, uint32_t n_parts, uint32_t block, size_t lds_budget) {
+  const size_t fixed = (size_t)n_parts * 12 + (2 + 16) * 4 + 16;
+  if (lds_budget <= fixed) return 0;
+  size_t cap = (lds_budget - fixed) / ((size_t)n_words * 8 + 4);
+  cap = cap / block * block;
+  if (cap > (size_t)kSortMaxCap) cap = kSortMaxCap;
+  return (uint32_t)cap;
+}
+
+template <typename POL, typename POLS>  // POLS: the policy flavour used by the write-combining kernel
+static void launch_partition_pol(const DevProgram& P, const DevFastPlan& fast, const DevColumns& C, const DevAggPlan& plan,
+                                 const DevTable& T, const DevPartition& PT, const DevRows& spill, int64_t n,
+                                 size_t lds_bytes, hipStream_t s) {
+  const int grid = (int)PT.n_producers;  // every producer writes its counts, even with no rows
+  if ((PT.mode & 15u) == 0)
+    hipLaunchKernelGGL((k_partition<POL>), dim3(grid), dim3(kPBlock), lds_bytes, s, P, fast, C, plan, T, PT, spill, n);
+  else if ((PT.mode & 15u) == 2)
+    hipLaunchKernelGGL((k_partition_ring<POLS>), dim3(grid), dim3(kRingBlock), lds_bytes, s, P, fast, C, plan, T, PT, spill, n);
+  else if (PT.block == 512)
+    hipLaunchKernelGGL((k_partition_sorted<POLS, 512>), dim3(grid), dim3(512), lds_bytes, s, P, fast, C, plan, T, PT, spill, n);
+  else
+    hipLaunchKernelGGL((k_partition_sorted<POLS, 1024>), dim3(grid), dim3(1024), lds_bytes, s, P, fast, C, plan, T, PT, spill, n);
 }
 
 hipError_t launch_partition(const DevProgram& P, const DevFastPlan& fast, const DevColumns& C, const DevAggPlan& plan,
@@ -227,21 +759,24 @@ hipError_t launch_partition(const DevProgram& P, const DevFastPlan& fast, const 
   if (n <= 0) return hipSuccess;
   Scope sc(KID_PARTITION, s, algo_bytes);
   const size_t lds_bytes = partition_stage_bytes(PT);
-  const int grid = (int)PT.n_producers;  // every producer writes its counts, even with no rows
-  if (lds_bytes > 65536) return hipErrorInvalidValue;
-#define DFX_PT(POL) hipLaunchKernelGGL((k_partition<POL>), dim3(grid), dim3(kPBlock), lds_bytes, s, P, fast, C, plan, T, PT, spill, n)
+  if ((PT.mode & 15u) == 0 && lds_bytes > 65536) return hipErrorInvalidValue;
+  if ((PT.mode & 15u) == 2 && lds_bytes > 160 * 1024) return hipErrorInvalidValue;
+  if ((PT.mode & 15u) == 1 && (lds_bytes > 160 * 1024 || PT.stage_rows == 0 || PT.stage_rows > (uint32_t)kSortMaxCap ||
+                       PT.n_parts > 4096 || (PT.block != 512 && PT.block != 1024)))
+    return hipErrorInvalidValue;
+#define DFX_PT(POL, POLS) launch_partition_pol<POL, POLS>(P, fast, C, plan, T, PT, spill, n, lds_bytes, s)
   if (sig_matches<SigKeySumPred2F64>(P, fast, 1, T.na, T.acc_kind, T.val_xform)) {
-    DFX_PT(DFX_ARG(StaticPolicy<2, 4, SigKeySumPred2F64>));
+    DFX_PT(DFX_ARG(StaticPolicy<2, 4, SigKeySumPred2F64>), DFX_ARG(StaticPolicy<2, 4, SigKeySumPred2F64>));
     return hipGetLastError();
   }
   if (sig_matches<SigKeySum>(P, fast, 1, T.na, T.acc_kind, T.val_xform)) {
-    DFX_PT(DFX_ARG(StaticPolicy<2, 4, SigKeySum>));
+    DFX_PT(DFX_ARG(StaticPolicy<2, 4, SigKeySum>), DFX_ARG(StaticPolicy<2, 4, SigKeySum>));
     return hipGetLastError();
   }
   const bool use_fast = fast.valid && !P.has_nulls;
-  if (P.n_cols <= 2) { if (use_fast) DFX_PT(DFX_ARG(FastPolicy<2, 4>)); else DFX_PT(DFX_ARG(InterpPolicy<2, 2>)); }
-  else if (P.n_cols <= 4) { if (use_fast) DFX_PT(DFX_ARG(FastPolicy<4, 2>)); else DFX_PT(DFX_ARG(InterpPolicy<4, 2>)); }
-  else { if (use_fast) DFX_PT(DFX_ARG(FastPolicy<8, 2>)); else DFX_PT(DFX_ARG(InterpPolicy<8, 1>)); }
+  if (P.n_cols <= 2) { if (use_fast) DFX_PT(DFX_ARG(FastPolicy<2, 4>), DFX_ARG(FastPolicy<2, 2>)); else DFX_PT(DFX_ARG(InterpPolicy<2, 2>), DFX_ARG(InterpPolicy<2, 1>)); }
+  else if (P.n_cols <= 4) { if (use_fast) DFX_PT(DFX_ARG(FastPolicy<4, 2>), DFX_ARG(FastPolicy<4, 2>)); else DFX_PT(DFX_ARG(InterpPolicy<4, 2>), DFX_ARG(InterpPolicy<4, 1>)); }
+  else { if (use_fast) DFX_PT(DFX_ARG(FastPolicy<8, 2>), DFX_ARG(FastPolicy<8, 1>)); else DFX_PT(DFX_ARG(InterpPolicy<8, 1>), DFX_ARG(InterpPolicy<8, 1>)); }
 #undef DFX_PT
   return hipGetLastError();
 }
@@ -251,7 +786,8 @@ hipError_t launch_partition_agg(const DevTable& T, const DevPartition& PT, const
   Scope sc(KID_PARTITION_AGG, s, algo_bytes);
   const size_t lds_bytes = (size_t)(T.block_mask + 1) * (size_t)(1 + T.na) * 8 + (size_t)(PT.n_producers + 1) * 4 + 16;
   if (lds_bytes > 160 * 1024 - 256 || PT.n_producers > 1024) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(k_partition_agg, dim3(PT.n_parts), dim3(kABlock), lds_bytes, s, T, PT, spill);
+  if (T.na == 1) hipLaunchKernelGGL(k_partition_agg<1>, dim3(PT.n_parts), dim3(kABlock), lds_bytes, s, T, PT, spill);
+  else hipLaunchKernelGGL(k_partition_agg<0>, dim3(PT.n_parts), dim3(kABlock), lds_bytes, s, T, PT, spill);
   return hipGetLastError();
 }
 

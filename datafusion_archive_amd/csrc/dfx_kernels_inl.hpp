@@ -324,6 +324,7 @@ DEV bool eval_predicate(const DevProgram& P, ROWSTATE_CPARAMS, uint8_t pred) {
 template <int BANK, int U_>
 struct InterpPolicy {
   static constexpr int U = U_;
+  static constexpr int kStaticNa = 0;  // aggregates known at compile time (0: run-time)
   typedef typename Bank<BANK>::type COLV;
   static DEV void load(const DevProgram& P, const DevColumns& C, int64_t row, bool inb, COLV& col, uint32_t& cv) {
     load_columns(P, C, row, inb, col, cv);
@@ -374,6 +375,7 @@ DEV uint32_t cmp3(uint8_t t, uint64_t x, uint64_t y) {
 template <int BANK, int U_>
 struct FastPolicy {
   static constexpr int U = U_;
+  static constexpr int kStaticNa = 0;  // aggregates known at compile time (0: run-time)
   typedef typename Bank<BANK>::type COLV;
   static DEV void load(const DevProgram& P, const DevColumns& C, int64_t row, bool inb, COLV& col, uint32_t& cv) {
     load_columns(P, C, row, inb, col, cv);
@@ -433,6 +435,7 @@ struct FastPolicy {
 template <int BANK, int U_, typename SIG>
 struct StaticPolicy {
   static constexpr int U = U_;
+  static constexpr int kStaticNa = SIG::NA;
   typedef typename Bank<BANK>::type COLV;
   static DEV void load(const DevProgram&, const DevColumns& C, int64_t row, bool inb, COLV& col, uint32_t& cv) {
     cv = 0xFFFFFFFFu;

@@ -11,6 +11,7 @@ namespace dfx {
 Status error_from_ctrl(uint32_t bits) {
   if (bits & 1u) return Status::Err(DFX_ARROW_ERROR, "DivideByZero");  // arrow 0.12 array_ops::divide
   if (bits & 2u) return Status::Err(DFX_INTERNAL_ERROR, "attempt to divide with overflow");
+  if (bits & 4u) return Status::Err(DFX_INTERNAL_ERROR, "partitioned aggregation: LDS ring stalled");
   return Status::OK();
 }
 
