@@ -307,7 +307,7 @@ Status AggregateRelation::Impl::grow_and_replay(uint64_t occupied, uint64_t spil
   const int cur_log2 = 64 - T.shift;
   const int need_log2 = ceil_log2(4 * (occupied + spilled + 1));
   const int new_log2 = std::max(cur_log2 + 2, need_log2);
-  if (new_log2 > 34) return Status::Err(DFX_EXECUTION_ERROR, "GROUP BY table would exceed 2^34 slots");
+  if (new_log2 > 31) return Status::Err(DFX_EXECUTION_ERROR, "GROUP BY table would exceed 2^31 slots");
   DevTable Tn;
   std::vector<std::shared_ptr<void>> owners;
   DFX_RETURN_IF_ERROR(alloc_table(new_log2, &Tn, &owners, false));
@@ -508,7 +508,7 @@ Status AggregateRelation::Impl::drain() {
     DFX_HIP(hipStreamSynchronize(s));
   } else {
     int cap_log2 = agg_options().capacity_log2 > 0 ? agg_options().capacity_log2 : 21;
-    cap_log2 = std::max(6, std::min(cap_log2, 34));
+    cap_log2 = std::max(6, std::min(cap_log2, 31));
     DFX_RETURN_IF_ERROR(alloc_table(cap_log2, &T, &table_owners, true));
     spill.words = nullptr;
     spill.capacity = 0;
@@ -727,6 +727,7 @@ Status AggregateRelation::partial_import(const void* src_device, const int64_t* 
   uint64_t total = 0;
   for (int b = 0; b < n_buckets; ++b) total += (uint64_t)counts[b];
   const int cap_log2 = std::max(10, ceil_log2(4 * (total + 1)));
+  if (cap_log2 > 31) return Status::Err(DFX_EXECUTION_ERROR, "GROUP BY table would exceed 2^31 slots");
   DevTable Tn;
   std::vector<std::shared_ptr<void>> owners;
   DFX_RETURN_IF_ERROR(m.alloc_table(cap_log2, &Tn, &owners, true));

@@ -382,9 +382,7 @@ __global__ __launch_bounds__(BLOCK) void k_partition_sorted(const DevProgram P, 
 //     A lane whose slot is still busy keeps its row, helps with this wave's flush jobs and retries; the
 //     lowest incomplete chunk of a partition never depends on anything, so every retry loop terminates.
 // Leftover partial chunks are written row by row at the end.
-constexpr int kRingCH = 4;
-constexpr int kRingNCH = 4;
-constexpr int kRingRP = kRingCH * kRingNCH;  // ring rows per partition
+constexpr int kRingRP = 16;  // ring rows per partition = rows per chunk (CH: 4 or 8) x chunks (NCH)
 constexpr int kRingQ = 192;                  // wave queue rows: < 64 left over + 2 row-groups appended
 constexpr int kRingBlock = 1024;
 
@@ -399,26 +397,29 @@ struct RingLds {
 
 size_t partition_ring_bytes(uint32_t n_words, uint32_t n_parts) {
   return (size_t)n_parts * kRingRP * n_words * 8 + (size_t)(kRingBlock / 64) * kRingQ * n_words * 8 +
-         (size_t)(kRingBlock / 64) * 64 * 8 + (size_t)n_parts * 4 * (1 + 2 * kRingNCH) + 64;
+         (size_t)(kRingBlock / 64) * 64 * 8 + (size_t)n_parts * 4 * (1 + 2 * 4) + 64;
 }
 
 #define WG_SCOPE __HIP_MEMORY_SCOPE_WORKGROUP
 
 // route up to 64 rows (one per lane with have == true)
-template <int NV>
+template <int NV, int kRingCH>
 DEV void ring_route(const DevTable& T, const DevPartition& PT, const DevRows& spill, const RingLds& L, uint32_t producer,
                     int na, bool have, const uint64_t (&key)[1], const uint64_t (&val)[kMaxAggs], uint32_t& err) {
+  constexpr int kRingNCH = kRingRP / kRingCH;
   const int lane = lane_id();
   const int wave = threadIdx.x >> 6;
   const int NW = (int)PT.n_words;
   uint32_t part = 0, pos = 0;
   bool pending = false, todo = false;
+  if (PT.mode & 0x20u) return;
   if (have) {
     part = partition_of(T, PT, hash_keys<1>(key));
     pos = atomicAdd(&L.fill[part], 1u);
     pending = pos < PT.cap_rows;
     todo = !pending;  // region overflow (skewed keys): the general path takes the row
   }
+  if (PT.mode & 0x40u) { if (pos == 0xFFFFFFF0u) err |= 8u; return; }
   spill_row<1>(T, spill, todo, key, val);
   const uint32_t c = pos / kRingCH, sl = c % kRingNCH, g = c / kRingNCH, r = pos % kRingCH;
   const uint32_t cs = part * kRingNCH + sl;
@@ -452,7 +453,9 @@ DEV void ring_route(const DevTable& T, const DevPartition& PT, const DevRows& sp
           const uint32_t rr = (uint32_t)lane % kRingCH;
           const uint64_t* src = L.ring + ((size_t)jb.x * kRingRP + (jb.y % kRingNCH) * kRingCH + rr) * NW;
           uint64_t* out = PT.rows + (((uint64_t)jb.x * PT.n_producers + producer) * PT.cap_rows + (uint64_t)jb.y * kRingCH + rr) * NW;
-          if (NV == 1) {
+          if (PT.mode & 0x10u) {
+            if (src[0] == 77) err |= 8u;
+          } else if (NV == 1) {
             *(ulonglong2*)out = *(const ulonglong2*)src;
           } else {
             for (int w = 0; w < NW; ++w) out[w] = src[w];
@@ -474,7 +477,7 @@ DEV void ring_route(const DevTable& T, const DevPartition& PT, const DevRows& sp
   }
 }
 
-template <typename POL>
+template <typename POL, int kRingCH>
 __global__ __launch_bounds__(kRingBlock) void k_partition_ring(const DevProgram P, const DevFastPlan F, const DevColumns C,
                                                               const DevAggPlan plan, const DevTable T,
                                                               const DevPartition PT, const DevRows spill, const int64_t n) {
@@ -483,6 +486,7 @@ __global__ __launch_bounds__(kRingBlock) void k_partition_ring(const DevProgram 
   static_assert(U == 1 || U == 2 || U == 4, "row-groups per trip");
   constexpr int NWAVES = kRingBlock / 64;
   constexpr int NV = POL::kStaticNa == 1 ? 1 : kMaxAggs;
+  constexpr int kRingNCH = kRingRP / kRingCH;
   extern __shared__ __attribute__((aligned(16))) uint64_t lds[];
   const int NW = (int)PT.n_words;
   RingLds L;
@@ -491,11 +495,11 @@ __global__ __launch_bounds__(kRingBlock) void k_partition_ring(const DevProgram 
   L.jobs = (uint2*)(L.queue + (size_t)NWAVES * kRingQ * NW);
   L.fill = (uint32_t*)(L.jobs + NWAVES * 64);
   L.commit = L.fill + PT.n_parts;
-  L.gen = L.commit + (size_t)PT.n_parts * kRingNCH;
+  L.gen = L.commit + (size_t)PT.n_parts * 4;
   const int lane = lane_id();
   const int wave = threadIdx.x >> 6;
   const int na = POL::na(T);
-  for (uint32_t p = threadIdx.x; p < PT.n_parts * (1 + 2 * kRingNCH); p += kRingBlock) L.fill[p] = 0;  // fill, commit, gen
+  for (uint32_t p = threadIdx.x; p < PT.n_parts * (1 + 2 * 4); p += kRingBlock) L.fill[p] = 0;  // fill, commit, gen
   __syncthreads();
   const uint32_t producer = blockIdx.x;
   uint64_t* q = L.queue + (size_t)wave * kRingQ * NW;  // word-major planes [NW][kRingQ]
@@ -505,13 +509,34 @@ __global__ __launch_bounds__(kRingBlock) void k_partition_ring(const DevProgram 
   const int64_t n_waves = (int64_t)gridDim.x * NWAVES;
   uint32_t err = 0;
   uint64_t passed = 0;
+  // software pipeline: the columns of trip t + 1 are requested before trip t is evaluated and routed, so
+  // every wave keeps loads in flight while it works on LDS
+  COLV ncol[U];
+  uint32_t ncv[U];
+  {
+    const int64_t w0 = wave_global * U;
+    FOR_U {
+      const int64_t row = (w0 + u) * 64 + lane;
+      POL::load(P, C, row, row < n && w0 < n_groups, ncol[u], ncv[u]);
+    }
+  }
   for (int64_t w0 = wave_global * U; w0 < n_groups; w0 += n_waves * U) {
     COLV col[U];
     uint32_t cv[U];
     FOR_U {
-      const int64_t row = (w0 + u) * 64 + lane;
-      POL::load(P, C, row, row < n, col[u], cv[u]);
+      col[u] = ncol[u];
+      cv[u] = ncv[u];
     }
+    {
+      const int64_t w1 = w0 + n_waves * U;
+      FOR_U {
+        const int64_t row = (w1 + u) * 64 + lane;
+        POL::load(P, C, row, row < n, ncol[u], ncv[u]);
+      }
+    }
+#ifdef DFX_RING_WAIT_ALL
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
     FOR_U {
       const int64_t row = (w0 + u) * 64 + lane;
       const bool inb = row < n;
@@ -533,10 +558,12 @@ __global__ __launch_bounds__(kRingBlock) void k_partition_ring(const DevProgram 
         }
       }
       passed += pass ? 1 : 0;
-      if (pass && key[0] == kEmptyKey) {  // the claim-sentinel key lives outside the blocks
-        const bool ok = table_apply<1>(T, key, val);
-        (void)ok;
-        pass = false;
+      if (__ballot(pass && key[0] == kEmptyKey) != 0) {  // the claim-sentinel key lives outside the blocks
+        if (pass && key[0] == kEmptyKey) {
+          const bool ok = table_apply<1>(T, key, val);
+          (void)ok;
+          pass = false;
+        }
       }
       const uint64_t m = __ballot(pass);
       if (pass) {
@@ -555,7 +582,7 @@ __global__ __launch_bounds__(kRingBlock) void k_partition_ring(const DevProgram 
           k2[0] = q[qn + lane];
 #pragma unroll
           for (int a = 0; a < kMaxAggs; ++a) v2[a] = (a < NV && a < na) ? q[(size_t)(1 + a) * kRingQ + qn + lane] : 0;
-          ring_route<NV>(T, PT, spill, L, producer, na, true, k2, v2, err);
+          ring_route<NV, kRingCH>(T, PT, spill, L, producer, na, true, k2, v2, err);
         }
       }
     }
@@ -567,7 +594,7 @@ __global__ __launch_bounds__(kRingBlock) void k_partition_ring(const DevProgram 
     k2[0] = have ? q[lane] : 0;
 #pragma unroll
     for (int a = 0; a < kMaxAggs; ++a) v2[a] = (have && a < NV && a < na) ? q[(size_t)(1 + a) * kRingQ + lane] : 0;
-    if (qn != 0) ring_route<NV>(T, PT, spill, L, producer, na, have, k2, v2, err);
+    if (qn != 0) ring_route<NV, kRingCH>(T, PT, spill, L, producer, na, have, k2, v2, err);
   }
   __syncthreads();
   // partial chunks + region counts
@@ -643,36 +670,50 @@ __global__ __launch_bounds__(kABlock) void k_partition_agg(const DevTable T, con
   if (threadIdx.x == 0) pre[NP] = total;
   __syncthreads();
   uint32_t new_keys = 0;
-  for (uint32_t i0 = 0; i0 < total; i0 += kABlock * RU) {  // wave-uniform trip count
-    uint64_t key[RU][1];
-    uint64_t val[RU][NV];
-    bool inb[RU];
+  // software pipeline: the rows of trip t + 1 are loaded while trip t probes the LDS block
+  const float inv = total ? (float)NP / (float)total : 0.f;
+  uint64_t key[RU][1], nkey[RU][1];
+  uint64_t val[RU][NV], nval[RU][NV];
+  bool inb[RU], ninb[RU];
+  auto fetch = [&](uint32_t i0, uint64_t (&k)[RU][1], uint64_t (&v)[RU][NV], bool (&ib)[RU]) {
 #pragma unroll
     for (int r = 0; r < RU; ++r) {
       const uint32_t i = i0 + (uint32_t)r * kABlock + threadIdx.x;
-      inb[r] = i < total;
-      key[r][0] = 0;
+      ib[r] = i < total;
+      k[r][0] = 0;
 #pragma unroll
-      for (int a = 0; a < NV; ++a) val[r][a] = 0;
-      if (inb[r]) {
+      for (int a = 0; a < NV; ++a) v[r][a] = 0;
+      if (ib[r]) {
         // producer of flattened row i: the counts are near-uniform, so interpolate and correct
-        uint32_t lo = (uint32_t)(((uint64_t)i * NP) / total);
+        uint32_t lo = (uint32_t)((float)i * inv);
         if (lo >= NP) lo = NP - 1;
         while (pre[lo] > i) --lo;
         while (pre[lo + 1] <= i) ++lo;
         const uint64_t* src = PT.rows + (((uint64_t)p * NP + lo) * PT.cap_rows + (i - pre[lo])) * NW;
         if (NA1) {
-          const ulonglong2 kv = *(const ulonglong2*)src;
-          key[r][0] = kv.x;
-          val[r][0] = kv.y;
+          typedef uint64_t u64x2_t __attribute__((ext_vector_type(2)));
+          const u64x2_t kv = __builtin_nontemporal_load((const u64x2_t*)src);
+          k[r][0] = kv.x;
+          v[r][0] = kv.y;
         } else {
-          key[r][0] = src[0];
+          k[r][0] = src[0];
 #pragma unroll
           for (int a = 0; a < NV; ++a)
-            if (a < T.na) val[r][a] = src[1 + a];
+            if (a < T.na) v[r][a] = src[1 + a];
         }
       }
     }
+  };
+  fetch(0, nkey, nval, ninb);
+  for (uint32_t i0 = 0; i0 < total; i0 += kABlock * RU) {  // wave-uniform trip count
+#pragma unroll
+    for (int r = 0; r < RU; ++r) {
+      key[r][0] = nkey[r][0];
+      inb[r] = ninb[r];
+#pragma unroll
+      for (int a = 0; a < NV; ++a) val[r][a] = nval[r][a];
+    }
+    if (i0 + kABlock * RU < total) fetch(i0 + kABlock * RU, nkey, nval, ninb);
 #pragma unroll
     for (int r = 0; r < RU; ++r) {
       bool todo = inb[r];
@@ -745,8 +786,10 @@ static void launch_partition_pol(const DevProgram& P, const DevFastPlan& fast, c
   const int grid = (int)PT.n_producers;  // every producer writes its counts, even with no rows
   if ((PT.mode & 15u) == 0)
     hipLaunchKernelGGL((k_partition<POL>), dim3(grid), dim3(kPBlock), lds_bytes, s, P, fast, C, plan, T, PT, spill, n);
+  else if ((PT.mode & 15u) == 2 && (PT.mode & 0x80u))
+    hipLaunchKernelGGL((k_partition_ring<POLS, 8>), dim3(grid), dim3(kRingBlock), lds_bytes, s, P, fast, C, plan, T, PT, spill, n);
   else if ((PT.mode & 15u) == 2)
-    hipLaunchKernelGGL((k_partition_ring<POLS>), dim3(grid), dim3(kRingBlock), lds_bytes, s, P, fast, C, plan, T, PT, spill, n);
+    hipLaunchKernelGGL((k_partition_ring<POLS, 4>), dim3(grid), dim3(kRingBlock), lds_bytes, s, P, fast, C, plan, T, PT, spill, n);
   else if (PT.block == 512)
     hipLaunchKernelGGL((k_partition_sorted<POLS, 512>), dim3(grid), dim3(512), lds_bytes, s, P, fast, C, plan, T, PT, spill, n);
   else

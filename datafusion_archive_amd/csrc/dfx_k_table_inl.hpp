@@ -291,7 +291,7 @@ __global__ __launch_bounds__(kBlock) void k_partial_count(const DevTable T, int 
     if (slot_occupied<KW>(T, (uint64_t)i)) {
       uint64_t key[KW];
       const uint64_t h = slot_key_hash<KW>(T, (uint64_t)i, key);
-      atomicAdd((unsigned long long*)&counts[(h >> 7) % (uint64_t)world], 1ull);
+      atomicAdd((unsigned long long*)&counts[hash_rank(h, (uint32_t)world)], 1ull);
     }
   }
 }
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(kBlock) void k_partial_scatter(const DevTable T, in
     if (slot_occupied<KW>(T, (uint64_t)i)) {
       uint64_t key[KW];
       const uint64_t h = slot_key_hash<KW>(T, (uint64_t)i, key);
-      const uint64_t r = (h >> 7) % (uint64_t)world;
+      const uint64_t r = hash_rank(h, (uint32_t)world);
       const uint64_t g = atomicAdd((unsigned long long*)&cursors[r], 1ull);
       uint64_t* b = dst + (uint64_t)nw * bucket_base[r];
       const uint64_t cnt = bucket_count[r];

@@ -31,12 +31,34 @@ __host__ __device__ inline uint64_t mix64(uint64_t z) {  // splitmix64 finaliser
   return z ^ (z >> 31);
 }
 
+// Group-key hash.  Every scanned (or routed) row pays for it, and 64-bit multiplies are ~8 quarter-rate
+// VALU ops each on CDNA, so the hash is built from three 32-bit multiplies per key word (murmur3-style
+// two-block mix + fmix32 finaliser; ~2.5x cheaper than a splitmix64 finaliser).  The 32 hash bits are
+// returned in the HIGH half: table slot = h >> (64 - log2 capacity), capacity <= 2^31.
+__host__ __device__ inline uint32_t hash_word(uint64_t k, uint32_t seed) {
+  uint32_t x = ((uint32_t)k ^ seed) * 0xCC9E2D51u;
+  x ^= x >> 15;
+  x ^= (uint32_t)(k >> 32);
+  x *= 0x85EBCA6Bu;
+  x ^= x >> 13;
+  x *= 0xC2B2AE35u;
+  return x ^ (x >> 16);
+}
 template <int KW>
 __host__ __device__ inline uint64_t hash_keys(const uint64_t* key) {
-  uint64_t h = mix64(key[0] + 0x9E3779B97F4A7C15ull);
+  uint32_t h = hash_word(key[0], 0x9E3779B9u);
 #pragma unroll
-  for (int w = 1; w < KW; ++w) h = mix64(h ^ (key[w] + 0x9E3779B97F4A7C15ull * (uint64_t)(w + 1)));
-  return h;
+  for (int w = 1; w < KW; ++w) h = hash_word(key[w], h);
+  return (uint64_t)h << 32;
+}
+// owner rank of a group in the multi-GPU exchange: bits independent of the slot index
+__host__ __device__ inline uint32_t hash_rank(uint64_t h, uint32_t world) {
+  uint32_t x = (uint32_t)(h >> 32) ^ 0x5BD1E995u;
+  x *= 0x2C1B3C6Du;
+  x ^= x >> 15;
+  x *= 0x297A2D39u;
+  x ^= x >> 16;
+  return x % world;
 }
 
 DEV bool is_signed_int(uint8_t t) { return t >= T_I8 && t <= T_I64; }
@@ -370,6 +392,21 @@ DEV uint32_t cmp3(uint8_t t, uint64_t x, uint64_t y) {
   return (a < b ? 1u : 0u) | (a == b ? 2u : 0u) | (a > b ? 4u : 0u);
 }
 
+// `(cmp3(t, x, y) & m) != 0` for a wave-uniform m (it comes from the kernarg segment)
+template <typename TT>
+DEV bool cmp_by_mask(TT a, TT b, uint32_t m) {
+  // m is wave-uniform: the three selectors are scalar lane masks, the result is three v_cmp writing SGPR
+  // pairs combined on the scalar unit (no per-lane select / or, no branch)
+  const bool ml = (m & 1u) != 0, me = (m & 2u) != 0, mg = (m & 4u) != 0;
+  return (ml & (a < b)) | (me & (a == b)) | (mg & (a > b));
+}
+DEV bool cmp_masked(uint8_t t, uint64_t x, uint64_t y, uint32_t m) {
+  if (t == T_F64) return cmp_by_mask<double>(as_f64(x), as_f64(y), m);
+  if (t == T_F32) return cmp_by_mask<float>(as_f32(x), as_f32(y), m);
+  if (t == T_U64) return cmp_by_mask<uint64_t>(x, y, m);
+  return cmp_by_mask<int64_t>((int64_t)x, (int64_t)y, m);
+}
+
 // shape-specialised (DevFastPlan): conjunction of `column <op> literal`, plain-column keys, column /
 // short-product arguments; no nulls.  Straight-line code, the only scalar work is reading the plan.
 template <int BANK, int U_>
@@ -392,8 +429,8 @@ struct FastPolicy {
     for (int i = 0; i < 4; ++i) {
       if (i < F.np) {
         const DevFastTerm t = F.term[i];
-        const uint32_t c = cmp3(t.dtype, cur[t.col & (BANK - 1)], F.term_imm[i]);
-        ok &= (((c & t.m) != 0u) ? 1u : 0u) ^ (uint32_t)t.inv;
+        const bool c = cmp_masked(t.dtype, cur[t.col & (BANK - 1)], F.term_imm[i], (uint32_t)t.m);
+        ok &= (c ? 1u : 0u) ^ (uint32_t)t.inv;
       }
     }
     return ok != 0u;
@@ -441,8 +478,14 @@ struct StaticPolicy {
     cv = 0xFFFFFFFFu;
 #pragma unroll
     for (int c = 0; c < BANK; ++c)
-      if (c < SIG::NCOL)  // streamed once: non-temporal, so the table blocks / open region lines keep the L2
+      if (c < SIG::NCOL)  // streamed once: non-temporal, so the table blocks / open region lines keep the L2.
+        // Out-of-range lanes re-read row 0 (no branch around the load: the compiler can then count the
+        // loads in flight and software-pipelined kernels wait with vmcnt(N) instead of vmcnt(0)).
+#ifdef DFX_COND_LOAD
         col[c] = inb ? __builtin_nontemporal_load((const uint64_t*)C.c[c].values + row) : 0ull;
+#else
+        col[c] = __builtin_nontemporal_load((const uint64_t*)C.c[c].values + (inb ? row : 0));
+#endif
   }
   static DEV int na(const DevTable&) { return SIG::NA; }
   static DEV uint8_t acc_kind(const DevTable&, int a) { return SIG::acc(a); }
@@ -455,8 +498,8 @@ struct StaticPolicy {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       if (i < SIG::NP) {
-        const uint32_t c = cmp3(SIG::term_cls(i), cur[SIG::term_col(i)], F.term_imm[i]);
-        ok &= (((c & (uint32_t)F.term[i].m) != 0u) ? 1u : 0u) ^ (uint32_t)F.term[i].inv;
+        const bool c = cmp_masked(SIG::term_cls(i), cur[SIG::term_col(i)], F.term_imm[i], (uint32_t)F.term[i].m);
+        ok &= (c ? 1u : 0u) ^ (uint32_t)F.term[i].inv;
       }
     }
     return ok != 0u;
