@@ -58,8 +58,18 @@ struct AggregateRelation::Impl {
   bool use_partition = false;   // strategy 3: route rows to table blocks, aggregate blocks in LDS
   DevPartition PT;
   std::shared_ptr<void> pt_rows, pt_counts;
+  size_t pt_rows_bytes = 0, pt_cnt_bytes = 0;
   int64_t rows_seen = 0;
   uint64_t occupied_known = 0;
+  // control block checks run ONE BATCH BEHIND the launches: after batch i its control block is copied to
+  // pinned memory asynchronously, batch i + 1 is launched, and only then is batch i's copy examined, so
+  // the device never idles on a host round trip between batches
+  std::shared_ptr<void> ctrl_host;          // pinned, 2 x CTRL_WORDS
+  hipEvent_t ctrl_ev[2] = {nullptr, nullptr};
+  bool ctrl_pending[2] = {false, false};
+  int64_t ctrl_rows[2] = {0, 0};
+  int64_t batch_seq = 0;
+  uint64_t unconfirmed_rows = 0;            // rows of launched batches whose control block is not examined yet
   // ungrouped state
   std::shared_ptr<void> partial, state, dev_arg_dtype, dev_func;
   // export
@@ -76,6 +86,14 @@ struct AggregateRelation::Impl {
   Status emit_grouped(DeviceBatch* out);
   Status emit_ungrouped(DeviceBatch* out);
   Status read_ctrl(uint32_t* host_ctrl);
+  Status post_ctrl(int64_t rows);
+  Status examine_ctrl(int slot);
+  Status settle_ctrl();
+  Status handle_ctrl(const uint32_t* hc, int64_t n);
+  ~Impl() {
+    for (int i = 0; i < 2; ++i)
+      if (ctrl_ev[i]) (void)hipEventDestroy(ctrl_ev[i]);
+  }
 };
 
 // ---- setup ---------------------------------------------------------------------------------------
@@ -232,6 +250,7 @@ Status AggregateRelation::Impl::ensure_spill(int64_t rows) {
     return Status::OK();
   }
   if (spill.words && spill.capacity >= (uint64_t)rows) return Status::OK();
+  DFX_RETURN_IF_ERROR(settle_ctrl());  // rows spilled by batches still in flight live in the old list
   Status st;
   spill_owner = device_alloc(sizeof(uint64_t) * (size_t)rows * (size_t)(kw + na), &st);
   if (!spill_owner) return st;
@@ -278,13 +297,23 @@ Status AggregateRelation::Impl::ensure_partition(int64_t rows) {
   }
   const uint64_t avg = (uint64_t)rows / ((uint64_t)PT.n_producers * PT.n_parts) + 1;
   PT.cap_rows = (uint32_t)((2 * avg + 64 + 63) / 64 * 64);
-  const size_t row_bytes = sizeof(uint64_t) * (size_t)PT.n_parts * PT.n_producers * PT.n_words * PT.cap_rows;
+  if (o.partition_cap_rows > 0) PT.cap_rows = (uint32_t)((o.partition_cap_rows + 63) / 64 * 64);
+  PT.part_stride = (uint64_t)PT.n_producers * PT.cap_rows * PT.n_words + (uint64_t)(o.partition_pad >= 0 ? o.partition_pad : 0) / 8;
+  const size_t row_bytes = sizeof(uint64_t) * (size_t)PT.n_parts * PT.part_stride;
   const size_t cnt_bytes = sizeof(uint32_t) * (size_t)PT.n_parts * PT.n_producers;
   Status st;
-  pt_rows = device_alloc(row_bytes, &st);
-  if (!pt_rows) return st;
-  pt_counts = device_alloc(cnt_bytes, &st);
-  if (!pt_counts) return st;
+  if (!pt_rows || pt_rows_bytes < row_bytes) {
+    pt_rows.reset();
+    pt_rows = device_alloc(row_bytes, &st);
+    if (!pt_rows) return st;
+    pt_rows_bytes = row_bytes;
+  }
+  if (!pt_counts || pt_cnt_bytes < cnt_bytes) {
+    pt_counts.reset();
+    pt_counts = device_alloc(cnt_bytes, &st);
+    if (!pt_counts) return st;
+    pt_cnt_bytes = cnt_bytes;
+  }
   PT.rows = (uint64_t*)pt_rows.get();
   PT.counts = (uint32_t*)pt_counts.get();
   return Status::OK();
@@ -294,6 +323,72 @@ Status AggregateRelation::Impl::read_ctrl(uint32_t* host_ctrl) {
   hipStream_t s = ctx().stream;
   DFX_HIP(hipMemcpyAsync(host_ctrl, ctrl.get(), sizeof(uint32_t) * CTRL_WORDS, hipMemcpyDeviceToHost, s));
   DFX_HIP(hipStreamSynchronize(s));
+  return Status::OK();
+}
+
+// queue an asynchronous snapshot of the control block after the batch just launched
+Status AggregateRelation::Impl::post_ctrl(int64_t rows) {
+  hipStream_t s = ctx().stream;
+  if (!ctrl_host) {
+    Status st;
+    ctrl_host = pinned_alloc(sizeof(uint32_t) * CTRL_WORDS * 2, &st);
+    if (!ctrl_host) return st;
+    for (int i = 0; i < 2; ++i) DFX_HIP(hipEventCreateWithFlags(&ctrl_ev[i], hipEventDisableTiming));
+  }
+  const int slot = (int)(batch_seq & 1);
+  if (ctrl_pending[slot]) DFX_RETURN_IF_ERROR(examine_ctrl(slot));
+  DFX_HIP(hipMemcpyAsync((uint32_t*)ctrl_host.get() + slot * CTRL_WORDS, ctrl.get(), sizeof(uint32_t) * CTRL_WORDS,
+                         hipMemcpyDeviceToHost, s));
+  DFX_HIP(hipEventRecord(ctrl_ev[slot], s));
+  ctrl_pending[slot] = true;
+  ctrl_rows[slot] = rows;
+  unconfirmed_rows += (uint64_t)rows;
+  ++batch_seq;
+  return Status::OK();
+}
+
+// errors, growth: what the per-batch check has always done, on a (possibly one batch old) snapshot
+Status AggregateRelation::Impl::handle_ctrl(const uint32_t* hc, int64_t n) {
+  if (hc[CTRL_ERROR]) return error_from_ctrl(hc[CTRL_ERROR]);
+  occupied_known = hc[CTRL_OCCUPIED];
+  const uint64_t spilled = ((uint64_t)hc[CTRL_SPILL_HI] << 32) | hc[CTRL_SPILL_LO];
+  if (getenv("DFX_DEBUG"))
+    fprintf(stderr, "[dfx] batch n=%lld partition=%d lds=%d occupied=%u spilled=%llu saturated=%u passed=%llu cap=%llu "
+            "parts=%u cap_rows=%u stage=%u spillcap=%llu\n", (long long)n, (int)use_partition, (int)lds_enabled,
+            hc[CTRL_OCCUPIED], (unsigned long long)spilled, hc[CTRL_SATURATED],
+            (unsigned long long)(((uint64_t)hc[CTRL_PASSED_HI] << 32) | hc[CTRL_PASSED_LO]),
+            (unsigned long long)(T.mask + 1), PT.n_parts, PT.cap_rows, PT.stage_rows, (unsigned long long)spill.capacity);
+  if (spilled > 0 || hc[CTRL_SATURATED] || occupied_known > T.load_limit) {
+    // later batches may already be running against the saturated table: let them finish, then rebuild
+    uint32_t now[CTRL_WORDS];
+    DFX_RETURN_IF_ERROR(read_ctrl(now));
+    ctrl_pending[0] = ctrl_pending[1] = false;
+    unconfirmed_rows = 0;
+    if (now[CTRL_ERROR]) return error_from_ctrl(now[CTRL_ERROR]);
+    const uint64_t spilled_now = ((uint64_t)now[CTRL_SPILL_HI] << 32) | now[CTRL_SPILL_LO];
+    DFX_RETURN_IF_ERROR(grow_and_replay(now[CTRL_OCCUPIED], spilled_now));
+    DFX_RETURN_IF_ERROR(read_ctrl(now));
+    occupied_known = now[CTRL_OCCUPIED];
+  }
+  return Status::OK();
+}
+
+Status AggregateRelation::Impl::examine_ctrl(int slot) {
+  if (!ctrl_pending[slot]) return Status::OK();
+  DFX_HIP(hipEventSynchronize(ctrl_ev[slot]));
+  ctrl_pending[slot] = false;
+  unconfirmed_rows -= std::min<uint64_t>(unconfirmed_rows, (uint64_t)ctrl_rows[slot]);
+  uint32_t hc[CTRL_WORDS];
+  memcpy(hc, (const uint32_t*)ctrl_host.get() + slot * CTRL_WORDS, sizeof(hc));
+  return handle_ctrl(hc, ctrl_rows[slot]);
+}
+
+// everything launched so far has been checked (end of input, or before the spill list is replaced)
+Status AggregateRelation::Impl::settle_ctrl() {
+  if (!ctrl_pending[0] && !ctrl_pending[1]) return Status::OK();
+  const int older = (int)(batch_seq & 1);  // the slot the NEXT batch would use holds the older snapshot
+  DFX_RETURN_IF_ERROR(examine_ctrl(older));
+  DFX_RETURN_IF_ERROR(examine_ctrl(older ^ 1));
   return Status::OK();
 }
 
@@ -414,8 +509,8 @@ Status AggregateRelation::Impl::consume_batch(const DeviceBatch& b) {
   // grouped: can this batch overflow the table in the worst case (every row a new group)?
   const AggOptions& oo = agg_options();
   if (oo.strategy == 3 && kw == 1) use_partition = true;
-  const bool may_spill = use_partition || occupied_known + (uint64_t)n > T.load_limit;
-  if (may_spill) DFX_RETURN_IF_ERROR(ensure_spill(n + 65536));
+  const bool may_spill = use_partition || occupied_known + unconfirmed_rows + (uint64_t)n > T.load_limit;
+  if (may_spill) DFX_RETURN_IF_ERROR(ensure_spill(2 * n + 65536));  // two batches can be in flight unchecked
   T.max_probe = may_spill ? 128 : (int)std::min<uint64_t>(T.mask + 1, 1u << 30);
   int64_t row0 = 0;
   const AggOptions& o = agg_options();
@@ -435,32 +530,23 @@ Status AggregateRelation::Impl::consume_batch(const DeviceBatch& b) {
     lds_enabled = occupied_known <= 8192;
     if (!lds_enabled && kw == 1 && occupied_known >= 16384) {
       use_partition = true;
-      DFX_RETURN_IF_ERROR(ensure_spill(n + 65536));
+      DFX_RETURN_IF_ERROR(ensure_spill(2 * n + 65536));
     }
     row0 = n0;
   } else if (!lds_calibrated) {
     if (o.strategy == 1) lds_enabled = false;
   }
   DFX_RETURN_IF_ERROR(launch_rows(b, prog, cols, row0, n - row0));
-  uint32_t hc[CTRL_WORDS];
-  DFX_RETURN_IF_ERROR(read_ctrl(hc));
-  if (hc[CTRL_ERROR]) return error_from_ctrl(hc[CTRL_ERROR]);
-  occupied_known = hc[CTRL_OCCUPIED];
-  const uint64_t spilled = ((uint64_t)hc[CTRL_SPILL_HI] << 32) | hc[CTRL_SPILL_LO];
-  if (getenv("DFX_DEBUG"))
-    fprintf(stderr, "[dfx] batch n=%lld partition=%d lds=%d occupied=%u spilled=%llu saturated=%u passed=%llu cap=%llu "
-            "parts=%u cap_rows=%u stage=%u spillcap=%llu\n", (long long)n, (int)use_partition, (int)lds_enabled,
-            hc[CTRL_OCCUPIED], (unsigned long long)spilled, hc[CTRL_SATURATED],
-            (unsigned long long)(((uint64_t)hc[CTRL_PASSED_HI] << 32) | hc[CTRL_PASSED_LO]),
-            (unsigned long long)(T.mask + 1), PT.n_parts, PT.cap_rows, PT.stage_rows, (unsigned long long)spill.capacity);
-  if (!lds_calibrated) {
+  if (!lds_calibrated) {  // first batch of a stream that skipped the calibration slice: decide now
+    uint32_t hc[CTRL_WORDS];
+    DFX_RETURN_IF_ERROR(read_ctrl(hc));
+    DFX_RETURN_IF_ERROR(handle_ctrl(hc, n));
     if (o.strategy == 0) lds_enabled = occupied_known <= 8192;
     lds_calibrated = true;
-  }
-  if (spilled > 0 || hc[CTRL_SATURATED] || occupied_known > T.load_limit) {
-    DFX_RETURN_IF_ERROR(grow_and_replay(occupied_known, spilled));
-    DFX_RETURN_IF_ERROR(read_ctrl(hc));
-    occupied_known = hc[CTRL_OCCUPIED];
+  } else {
+    const int prev = (int)((batch_seq & 1) ^ 1);
+    DFX_RETURN_IF_ERROR(post_ctrl(n));       // snapshot of THIS batch, examined after the next launch
+    DFX_RETURN_IF_ERROR(examine_ctrl(prev)); // the previous batch's snapshot (normally complete by now)
   }
   rows_seen += n;
   return Status::OK();
@@ -524,6 +610,8 @@ Status AggregateRelation::Impl::drain() {
     uint32_t hc[CTRL_WORDS];
     DFX_RETURN_IF_ERROR(read_ctrl(hc));
     if (hc[CTRL_ERROR]) return error_from_ctrl(hc[CTRL_ERROR]);
+  } else {
+    DFX_RETURN_IF_ERROR(settle_ctrl());
   }
   built = true;
   return Status::OK();

@@ -178,6 +178,8 @@ struct DevAggPlan {
 // partition is aggregated by one workgroup inside an LDS copy of its table block.
 struct DevPartition {
   uint64_t* rows;      // [partition][producer][cap_rows][n_words]  (row-major regions)
+  uint64_t part_stride;// words between the regions of consecutive partitions (>= n_producers * cap_rows * n_words;
+                       // padded so that the 256 streams a producer writes do not share an HBM channel)
   uint32_t* counts;    // [partition][producer]
   uint32_t n_parts;    // table blocks
   uint32_t n_producers;// pass-1 workgroups

@@ -24,6 +24,11 @@ namespace dfx {
 constexpr int kPBlock = 1024;  // pass-1 workgroup (one per CU): 16 waves share one set of fill counters
 constexpr int kABlock = 1024;  // pass-2 workgroup (one per CU): 16 waves share a 128 KB LDS copy of a table block
 
+// address of row `row` of the region that producer `producer` fills for partition `part`
+DEV uint64_t* region_row(const DevPartition& PT, uint32_t part, uint32_t producer, uint32_t row) {
+  return PT.rows + (uint64_t)part * PT.part_stride + ((uint64_t)producer * PT.cap_rows + row) * PT.n_words;
+}
+
 DEV uint32_t partition_of(const DevTable& T, const DevPartition& PT, uint64_t h) {
   return (uint32_t)(((h >> T.shift) & T.mask) >> PT.part_shift);
 }
@@ -95,7 +100,7 @@ __global__ __launch_bounds__(kPBlock) void k_partition(const DevProgram P, const
       const bool pass = (passbits >> u) & 1u;
       bool todo = pass;
       if (pass && pos[u] < PT.cap_rows) {
-        uint64_t* dst = PT.rows + (((uint64_t)part[u] * PT.n_producers + producer) * PT.cap_rows + pos[u]) * NW;
+        uint64_t* dst = region_row(PT, part[u], producer, pos[u]);
         if (POL::na(T) == 1) {  // 16-byte row: one store
           *(ulonglong2*)dst = make_ulonglong2(key[u][0], val[u][0]);
         } else {
@@ -235,7 +240,7 @@ DEV bool partition_flush(const DevTable& T, const DevPartition& PT, const DevRow
           if (a < na) val[a] = L.buf[(size_t)(1 + a) * L.cap + i];
         if (PT.mode & 0x10u) { if (key[0] == 77 && val[0] == 78) todo = true; } else
         if (row < PT.cap_rows) {
-          uint64_t* dst = PT.rows + (((uint64_t)part * PT.n_producers + producer) * PT.cap_rows + row) * PT.n_words;
+          uint64_t* dst = region_row(PT, part, producer, row);
           if (na == 1) {
             *(ulonglong2*)dst = make_ulonglong2(key[0], val[0]);
           } else {
@@ -452,7 +457,7 @@ DEV void ring_route(const DevTable& T, const DevPartition& PT, const DevRows& sp
           const uint2 jb = jobs[j];
           const uint32_t rr = (uint32_t)lane % kRingCH;
           const uint64_t* src = L.ring + ((size_t)jb.x * kRingRP + (jb.y % kRingNCH) * kRingCH + rr) * NW;
-          uint64_t* out = PT.rows + (((uint64_t)jb.x * PT.n_producers + producer) * PT.cap_rows + (uint64_t)jb.y * kRingCH + rr) * NW;
+          uint64_t* out = region_row(PT, jb.x, producer, jb.y * kRingCH + rr);
           if (PT.mode & 0x10u) {
             if (src[0] == 77) err |= 8u;
           } else if (NV == 1) {
@@ -604,7 +609,7 @@ __global__ __launch_bounds__(kRingBlock) void k_partition_ring(const DevProgram 
     const uint32_t c = f / kRingCH;
     for (uint32_t r = 0; r < f % kRingCH; ++r) {
       const uint64_t* src = L.ring + ((size_t)p * kRingRP + (c % kRingNCH) * kRingCH + r) * NW;
-      uint64_t* out = PT.rows + (((uint64_t)p * PT.n_producers + producer) * PT.cap_rows + (uint64_t)c * kRingCH + r) * NW;
+      uint64_t* out = region_row(PT, p, producer, c * kRingCH + r);
       for (int w = 0; w < NW; ++w) out[w] = src[w];
     }
     PT.counts[(uint64_t)p * PT.n_producers + producer] = f;
@@ -689,7 +694,7 @@ __global__ __launch_bounds__(kABlock) void k_partition_agg(const DevTable T, con
         if (lo >= NP) lo = NP - 1;
         while (pre[lo] > i) --lo;
         while (pre[lo + 1] <= i) ++lo;
-        const uint64_t* src = PT.rows + (((uint64_t)p * NP + lo) * PT.cap_rows + (i - pre[lo])) * NW;
+        const uint64_t* src = region_row(PT, p, lo, i - pre[lo]);
         if (NA1) {
           typedef uint64_t u64x2_t __attribute__((ext_vector_type(2)));
           const u64x2_t kv = __builtin_nontemporal_load((const u64x2_t*)src);
