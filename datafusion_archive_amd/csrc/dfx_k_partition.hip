@@ -724,23 +724,37 @@ __global__ __launch_bounds__(kABlock) void k_partition_agg(const DevTable T, con
       bool todo = inb[r];
       if (inb[r]) {
         const uint64_t h = hash_keys<1>(key[r]);
-        uint32_t slot = (uint32_t)((h >> T.shift) & T.mask) & T.block_mask;
+        const uint32_t slot = (uint32_t)((h >> T.shift) & T.mask) & T.block_mask;
         int found = -1;
-        for (uint32_t pr = 0; pr < S && found < 0; ++pr) {
-          const uint64_t k = lkeys[slot];
-          if (k == key[r][0]) {
-            found = (int)slot;
-          } else if (k == kEmptyKey) {
-            const uint64_t old = atomicCAS((unsigned long long*)&lkeys[slot], (unsigned long long)kEmptyKey,
-                                           (unsigned long long)key[r][0]);
+        // Linear probing, FOUR slots per step (two 16-byte LDS reads of the aligned group): a wave pays for
+        // the longest probe sequence among its 64 lanes, and with the table half full that tail is ~12
+        // single-slot steps.  The probe ORDER is exactly slot, slot + 1, ... (positions before `slot` in the
+        // first group are masked), so the block stays a valid linear-probing table for the global kernels.
+        uint32_t g = slot >> 2;
+        uint32_t vm = (0xFu << (slot & 3u)) & 0xFu;
+        for (uint32_t it = 0; it <= (S >> 2) && found < 0;) {
+          const ulonglong2 ka = *(const ulonglong2*)&lkeys[g * 4];
+          const ulonglong2 kb = *(const ulonglong2*)&lkeys[g * 4 + 2];
+          const uint64_t kk = key[r][0];
+          const uint32_t mm = ((ka.x == kk ? 1u : 0u) | (ka.y == kk ? 2u : 0u) | (kb.x == kk ? 4u : 0u) | (kb.y == kk ? 8u : 0u)) & vm;
+          const uint32_t em = ((ka.x == kEmptyKey ? 1u : 0u) | (ka.y == kEmptyKey ? 2u : 0u) | (kb.x == kEmptyKey ? 4u : 0u) |
+                               (kb.y == kEmptyKey ? 8u : 0u)) & vm;
+          if (mm) {
+            found = (int)(g * 4 + (uint32_t)__ffs((int)mm) - 1u);
+          } else if (em) {
+            const uint32_t at = g * 4 + (uint32_t)__ffs((int)em) - 1u;
+            const uint64_t old = atomicCAS((unsigned long long*)&lkeys[at], (unsigned long long)kEmptyKey, (unsigned long long)kk);
             if (old == kEmptyKey) {
-              found = (int)slot;
+              found = (int)at;
               ++new_keys;
-            } else if (old == key[r][0]) {
-              found = (int)slot;
-            }
+            } else if (old == kk) {
+              found = (int)at;
+            }  // else: another key claimed it meanwhile -- look at the same group again
+          } else {
+            g = (g + 1) & ((S >> 2) - 1);
+            vm = 0xFu;
+            ++it;
           }
-          if (found < 0) slot = (slot + 1) & T.block_mask;
         }
         if (found >= 0) {
 #pragma unroll
