@@ -164,7 +164,8 @@ def main():
         try:
             with open(os.path.join(ROOT, "profiles", "r01_bench_hbm_counters.json")) as f:
                 ctr = json.load(f)
-            key = [k for k in ctr if ("k_partition<" in k if dom == "partition" else dom in k)]
+            key = [k for k in ctr if (("k_partition_ring<" in k or "k_partition<" in k or "k_partition_sorted<" in k)
+                                    if dom == "partition" else dom in k)]
             if key:
                 c = ctr[key[0]]
                 roofline["traffic"] = (2.0 * c["FETCH_SIZE_KB_per_dispatch"] + c["WRITE_SIZE_KB_per_dispatch"]) * 1024.0

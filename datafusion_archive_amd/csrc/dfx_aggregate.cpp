@@ -269,16 +269,18 @@ Status AggregateRelation::Impl::ensure_partition(int64_t rows) {
   while ((1ull << ps) < S) ++ps;
   PT.part_shift = (uint32_t)ps;
   if (PT.n_parts > 4096) return Status::Err(DFX_NOT_IMPLEMENTED, "partitioned strategy: too many table blocks");
-  // pass-1 flavour.  mode 1 (default): the workgroup collects passing rows in LDS, counting-sorts them by
-  // partition and writes them out in runs (scattered 16-byte stores are transaction-bound at ~87 G/s,
-  // tools/ubench2.hip); it needs runs of several rows per partition per flush, i.e. few enough partitions.
-  // mode 0: one 16-byte store per row straight from registers (many partitions, or by option).
+  // pass-1 flavour (agg.partition_mode).  Scattered 16-byte stores are transaction-bound at ~87 G rows/s on
+  // MI355X while runs of >= 64 bytes reach > 400 G rows/s (tools/ubench2.hip), so routed rows are write-combined
+  // in LDS whenever the partition count allows it:
+  //   2 (default)  lock-free per-partition LDS rings, 128-byte chunks, no barrier in the scan loop
+  //   1            workgroup-wide LDS counting sort (also for partition counts whose rings do not fit LDS)
+  //   0            one 16-byte store per row straight from registers (very many partitions)
   const AggOptions& o = agg_options();
   const uint32_t block = o.partition_block == 512 ? 512u : 1024u;
   const size_t budget = block == 512 ? (size_t)79 * 1024 : (size_t)156 * 1024;
   const uint32_t sort_cap = partition_sort_capacity(PT.n_words, PT.n_parts, block, budget);
   const int want = o.partition_mode & 15;
-  if (want == 2 && partition_ring_bytes(PT.n_words, PT.n_parts) <= (size_t)158 * 1024) {
+  if (want == 2 && partition_ring_bytes(PT.n_words, PT.n_parts, 16) <= (size_t)158 * 1024) {
     PT.mode = 2u | ((uint32_t)o.partition_mode & ~15u);
     PT.block = 1024;
     PT.stage_rows = 0;

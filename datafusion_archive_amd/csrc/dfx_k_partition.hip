@@ -165,7 +165,6 @@ DEV bool partition_flush(const DevTable& T, const DevPartition& PT, const DevRow
   uint32_t R = L.misc[0];
   if (R > L.limit) R = L.limit;
   const bool last = L.misc[1] == (uint32_t)NWAVES;
-  if (PT.mode & 0x20u) { __syncthreads(); if (tid == 0) L.misc[0] = 0; __syncthreads(); return last; }
   uint32_t packed[ITEMS];
 #pragma unroll
   for (int it = 0; it < ITEMS; ++it) {
@@ -238,7 +237,6 @@ DEV bool partition_flush(const DevTable& T, const DevPartition& PT, const DevRow
 #pragma unroll
         for (int a = 0; a < kMaxAggs; ++a)
           if (a < na) val[a] = L.buf[(size_t)(1 + a) * L.cap + i];
-        if (PT.mode & 0x10u) { if (key[0] == 77 && val[0] == 78) todo = true; } else
         if (row < PT.cap_rows) {
           uint64_t* dst = region_row(PT, part, producer, row);
           if (na == 1) {
@@ -345,7 +343,6 @@ __global__ __launch_bounds__(BLOCK) void k_partition_sorted(const DevProgram P, 
       FOR_U {
         const uint32_t pos = b + mbcnt64(m[u]);
         if (((pend >> u) & 1u) && pos < L.limit) {
-          if (!(PT.mode & 0x40u))
           L.buf[pos] = key[u][0];
 #pragma unroll
           for (int a = 0; a < kMaxAggs; ++a)
@@ -387,28 +384,30 @@ __global__ __launch_bounds__(BLOCK) void k_partition_sorted(const DevProgram P, 
 //     A lane whose slot is still busy keeps its row, helps with this wave's flush jobs and retries; the
 //     lowest incomplete chunk of a partition never depends on anything, so every retry loop terminates.
 // Leftover partial chunks are written row by row at the end.
-constexpr int kRingRP = 16;  // ring rows per partition = rows per chunk (CH: 4 or 8) x chunks (NCH)
-constexpr int kRingQ = 192;                  // wave queue rows: < 64 left over + 2 row-groups appended
+// ring rows per partition kRingRP = rows per chunk (CH: 4 or 8) x chunks (NCH).  (An 8-row ring with two
+// workgroups per CU -- 32 waves -- was measured ~20 % slower than 16 rows and one workgroup.)
+constexpr int ring_queue_rows(int rp) { return rp >= 16 ? 192 : 128; }
 constexpr int kRingBlock = 1024;
 
 struct RingLds {
   uint64_t* ring;    // [n_parts][kRingRP][n_words]
   uint64_t* queue;   // [waves][n_words][kRingQ]
-  uint2* jobs;       // [waves][64] (partition, chunk)
+  uint32_t* jobs;    // [waves][64] partition << 20 | chunk
   uint32_t* fill;    // [n_parts]
   uint32_t* commit;  // [n_parts][kRingNCH]
   uint32_t* gen;     // [n_parts][kRingNCH]
 };
 
-size_t partition_ring_bytes(uint32_t n_words, uint32_t n_parts) {
+size_t partition_ring_bytes(uint32_t n_words, uint32_t n_parts, int kRingRP) {
+  const int kRingQ = ring_queue_rows(kRingRP);
   return (size_t)n_parts * kRingRP * n_words * 8 + (size_t)(kRingBlock / 64) * kRingQ * n_words * 8 +
-         (size_t)(kRingBlock / 64) * 64 * 8 + (size_t)n_parts * 4 * (1 + 2 * 4) + 64;
+         (size_t)(kRingBlock / 64) * 64 * (kRingRP >= 16 ? 8 : 4) + (size_t)n_parts * 4 * (1 + 2 * 4) + 64;
 }
 
 #define WG_SCOPE __HIP_MEMORY_SCOPE_WORKGROUP
 
 // route up to 64 rows (one per lane with have == true)
-template <int NV, int kRingCH>
+template <int NV, int kRingCH, int kRingRP>
 DEV void ring_route(const DevTable& T, const DevPartition& PT, const DevRows& spill, const RingLds& L, uint32_t producer,
                     int na, bool have, const uint64_t (&key)[1], const uint64_t (&val)[kMaxAggs], uint32_t& err) {
   constexpr int kRingNCH = kRingRP / kRingCH;
@@ -417,18 +416,16 @@ DEV void ring_route(const DevTable& T, const DevPartition& PT, const DevRows& sp
   const int NW = (int)PT.n_words;
   uint32_t part = 0, pos = 0;
   bool pending = false, todo = false;
-  if (PT.mode & 0x20u) return;
   if (have) {
     part = partition_of(T, PT, hash_keys<1>(key));
     pos = atomicAdd(&L.fill[part], 1u);
     pending = pos < PT.cap_rows;
     todo = !pending;  // region overflow (skewed keys): the general path takes the row
   }
-  if (PT.mode & 0x40u) { if (pos == 0xFFFFFFF0u) err |= 8u; return; }
   spill_row<1>(T, spill, todo, key, val);
   const uint32_t c = pos / kRingCH, sl = c % kRingNCH, g = c / kRingNCH, r = pos % kRingCH;
   const uint32_t cs = part * kRingNCH + sl;
-  uint2* jobs = L.jobs + wave * 64;
+  uint32_t* jobs = L.jobs + wave * 64;
   uint32_t spins = 0;
   while (true) {
     bool job = false;
@@ -449,18 +446,17 @@ DEV void ring_route(const DevTable& T, const DevPartition& PT, const DevRows& sp
     const uint64_t jm = __ballot(job);
     if (jm != 0) {
       const uint32_t njobs = (uint32_t)__popcll(jm);
-      if (job) jobs[mbcnt64(jm)] = make_uint2(part, c);
+      if (job) jobs[mbcnt64(jm)] = (part << 20) | c;
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       for (uint32_t j0 = 0; j0 < njobs; j0 += 64 / kRingCH) {
         const uint32_t j = j0 + (uint32_t)lane / kRingCH;
         if (j < njobs) {
-          const uint2 jb = jobs[j];
+          const uint32_t jw = jobs[j];
+          const uint2 jb = make_uint2(jw >> 20, jw & 0xFFFFFu);
           const uint32_t rr = (uint32_t)lane % kRingCH;
           const uint64_t* src = L.ring + ((size_t)jb.x * kRingRP + (jb.y % kRingNCH) * kRingCH + rr) * NW;
           uint64_t* out = region_row(PT, jb.x, producer, jb.y * kRingCH + rr);
-          if (PT.mode & 0x10u) {
-            if (src[0] == 77) err |= 8u;
-          } else if (NV == 1) {
+          if (NV == 1) {
             *(ulonglong2*)out = *(const ulonglong2*)src;
           } else {
             for (int w = 0; w < NW; ++w) out[w] = src[w];
@@ -482,7 +478,7 @@ DEV void ring_route(const DevTable& T, const DevPartition& PT, const DevRows& sp
   }
 }
 
-template <typename POL, int kRingCH>
+template <typename POL, int kRingCH, int kRingRP>
 __global__ __launch_bounds__(kRingBlock) void k_partition_ring(const DevProgram P, const DevFastPlan F, const DevColumns C,
                                                               const DevAggPlan plan, const DevTable T,
                                                               const DevPartition PT, const DevRows spill, const int64_t n) {
@@ -492,13 +488,14 @@ __global__ __launch_bounds__(kRingBlock) void k_partition_ring(const DevProgram 
   constexpr int NWAVES = kRingBlock / 64;
   constexpr int NV = POL::kStaticNa == 1 ? 1 : kMaxAggs;
   constexpr int kRingNCH = kRingRP / kRingCH;
+  constexpr int kRingQ = ring_queue_rows(kRingRP);
   extern __shared__ __attribute__((aligned(16))) uint64_t lds[];
   const int NW = (int)PT.n_words;
   RingLds L;
   L.ring = lds;
   L.queue = L.ring + (size_t)PT.n_parts * kRingRP * NW;
-  L.jobs = (uint2*)(L.queue + (size_t)NWAVES * kRingQ * NW);
-  L.fill = (uint32_t*)(L.jobs + NWAVES * 64);
+  L.jobs = (uint32_t*)(L.queue + (size_t)NWAVES * kRingQ * NW);
+  L.fill = (uint32_t*)(L.jobs + NWAVES * 64 * (kRingRP >= 16 ? 2 : 1));
   L.commit = L.fill + PT.n_parts;
   L.gen = L.commit + (size_t)PT.n_parts * 4;
   const int lane = lane_id();
@@ -565,8 +562,7 @@ __global__ __launch_bounds__(kRingBlock) void k_partition_ring(const DevProgram 
       passed += pass ? 1 : 0;
       if (__ballot(pass && key[0] == kEmptyKey) != 0) {  // the claim-sentinel key lives outside the blocks
         if (pass && key[0] == kEmptyKey) {
-          const bool ok = table_apply<1>(T, key, val);
-          (void)ok;
+          sentinel_apply(T, val);
           pass = false;
         }
       }
@@ -579,7 +575,7 @@ __global__ __launch_bounds__(kRingBlock) void k_partition_ring(const DevProgram 
           if (a < na) q[(size_t)(1 + a) * kRingQ + at] = val[a];
       }
       qn += (uint32_t)__popcll(m);
-      if ((u & 1) == 1 || u == U - 1) {  // after every second row-group: the queue holds < 64 + 128 rows
+      if (kRingQ < 192 || (u & 1) == 1 || u == U - 1) {  // the queue holds < 64 + (kRingQ - 64) rows
         while (qn >= 64) {
           qn -= 64;
           uint64_t k2[1];
@@ -587,7 +583,7 @@ __global__ __launch_bounds__(kRingBlock) void k_partition_ring(const DevProgram 
           k2[0] = q[qn + lane];
 #pragma unroll
           for (int a = 0; a < kMaxAggs; ++a) v2[a] = (a < NV && a < na) ? q[(size_t)(1 + a) * kRingQ + qn + lane] : 0;
-          ring_route<NV, kRingCH>(T, PT, spill, L, producer, na, true, k2, v2, err);
+          ring_route<NV, kRingCH, kRingRP>(T, PT, spill, L, producer, na, true, k2, v2, err);
         }
       }
     }
@@ -599,7 +595,7 @@ __global__ __launch_bounds__(kRingBlock) void k_partition_ring(const DevProgram 
     k2[0] = have ? q[lane] : 0;
 #pragma unroll
     for (int a = 0; a < kMaxAggs; ++a) v2[a] = (have && a < NV && a < na) ? q[(size_t)(1 + a) * kRingQ + lane] : 0;
-    if (qn != 0) ring_route<NV, kRingCH>(T, PT, spill, L, producer, na, have, k2, v2, err);
+    if (qn != 0) ring_route<NV, kRingCH, kRingRP>(T, PT, spill, L, producer, na, have, k2, v2, err);
   }
   __syncthreads();
   // partial chunks + region counts
@@ -784,7 +780,7 @@ __global__ __launch_bounds__(kABlock) void k_partition_agg(const DevTable T, con
 
 size_t partition_stage_bytes(const DevPartition& PT) {
   if ((PT.mode & 15u) == 0) return (size_t)PT.n_parts * 4 + 16;
-  if ((PT.mode & 15u) == 2) return partition_ring_bytes(PT.n_words, PT.n_parts);
+  if ((PT.mode & 15u) == 2) return partition_ring_bytes(PT.n_words, PT.n_parts, 16);
   return (size_t)PT.stage_rows * ((size_t)PT.n_words * 8 + 4) + (size_t)PT.n_parts * 12 + (2 + 16) * 4 + 16;
 }
 
@@ -805,10 +801,10 @@ static void launch_partition_pol(const DevProgram& P, const DevFastPlan& fast, c
   const int grid = (int)PT.n_producers;  // every producer writes its counts, even with no rows
   if ((PT.mode & 15u) == 0)
     hipLaunchKernelGGL((k_partition<POL>), dim3(grid), dim3(kPBlock), lds_bytes, s, P, fast, C, plan, T, PT, spill, n);
-  else if ((PT.mode & 15u) == 2 && (PT.mode & 0x80u))
-    hipLaunchKernelGGL((k_partition_ring<POLS, 8>), dim3(grid), dim3(kRingBlock), lds_bytes, s, P, fast, C, plan, T, PT, spill, n);
-  else if ((PT.mode & 15u) == 2)
-    hipLaunchKernelGGL((k_partition_ring<POLS, 4>), dim3(grid), dim3(kRingBlock), lds_bytes, s, P, fast, C, plan, T, PT, spill, n);
+  else if ((PT.mode & 15u) == 2 && (PT.mode & 0x80u))  // 4-row chunks (64-byte runs)
+    hipLaunchKernelGGL((k_partition_ring<POLS, 4, 16>), dim3(grid), dim3(kRingBlock), lds_bytes, s, P, fast, C, plan, T, PT, spill, n);
+  else if ((PT.mode & 15u) == 2)  // 8-row chunks (full 128-byte lines): ~4 % faster on MI355X
+    hipLaunchKernelGGL((k_partition_ring<POLS, 8, 16>), dim3(grid), dim3(kRingBlock), lds_bytes, s, P, fast, C, plan, T, PT, spill, n);
   else if (PT.block == 512)
     hipLaunchKernelGGL((k_partition_sorted<POLS, 512>), dim3(grid), dim3(512), lds_bytes, s, P, fast, C, plan, T, PT, spill, n);
   else

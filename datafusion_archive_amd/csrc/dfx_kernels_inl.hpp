@@ -689,6 +689,20 @@ DEV void spill_row(const DevTable& T, const DevRows& spill, bool do_spill, const
   }
 }
 
+// the group whose (single-word) key equals the claim sentinel lives in slot `cap`: the slice of table_apply<1>
+// that such a row takes, as a small function of its own (the partition kernels call it from unrolled loops)
+DEV void sentinel_apply(const DevTable& T, const uint64_t (&val)[kMaxAggs]) {
+  bool inserted = false;
+  if (__hip_atomic_load(&T.ctrl[CTRL_SENTINEL], RLX_AGENT) == 0u)
+    inserted = atomicExch(&T.ctrl[CTRL_SENTINEL], 1u) == 0u;
+  const uint64_t mi = __ballot(inserted);
+  if (mi != 0 && lane_id() == __ffsll((unsigned long long)mi) - 1) atomicAdd(&T.ctrl[CTRL_OCCUPIED], (uint32_t)__popcll(mi));
+  const uint64_t slot = T.mask + 1;
+#pragma unroll
+  for (int a = 0; a < kMaxAggs; ++a)
+    if (a < T.na) acc_atomic(T.acc_kind[a], &T.accs[(uint64_t)a * T.stride + slot], val[a]);
+}
+
 template <int KW>
 DEV bool table_apply(const DevTable& T, const uint64_t (&key)[KW], const uint64_t (&val)[kMaxAggs]) {
   uint64_t slot = 0;

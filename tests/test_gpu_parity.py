@@ -46,6 +46,8 @@ def _reset_options():
     ex.set_option("scan.fast", 1)
     ex.set_option("agg.lds_slots", -1)
     ex.set_option("agg.lds_copies", -1)
+    ex.set_option("agg.partition_mode", 2)
+    ex.set_option("agg.partition_block", 1024)
     yield
 
 
@@ -443,6 +445,38 @@ def test_skewed_keys_partitioned_strategy_spills_correctly():
     got = gpu_aggregate([Column(0)], aggs, schema, [], source=t.scan(1 << 20))
     want = oracle.aggregate([Column(0)], aggs, [oracle.synth_batch(syn, seed, 0, n)])
     assert_groups_identical(got, want, 1, "skewed keys")
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2, 2 | 0x80])
+@pytest.mark.parametrize("skew", [False, True])
+def test_partitioned_pass1_flavours(mode, skew):
+    """Every pass-1 flavour of the partitioned strategy (direct routing, LDS counting sort, lock-free LDS
+    rings with 8- and 4-row chunks) gives the oracle's groups: uniform keys, Zipf keys (region overflow ->
+    spill), three aggregates (generic row width), a predicate, and the claim-sentinel key i64::MIN."""
+    ex.set_option("agg.strategy", 3)
+    ex.set_option("agg.partition_mode", mode)
+    kind = ex.SYNTH_I64_ZIPF if skew else ex.SYNTH_I64_UNIFORM
+    syn = [("k", kind, 0, 300000.0, 0.0), ("v", ex.SYNTH_F64_EXACT, 1, 0.0, 0.0)]
+    n, seed = (1 << 21) + 12345, 0xDF07
+    t = ex.DeviceTable.synth(syn, seed, 0, n)
+    schema = pa.schema([("k", pa.int64()), ("v", pa.float64())])
+    pred = BinaryExpr(Column(1), Operator.Gt, lit(100.0))
+    ob = oracle.synth_batch(syn, seed, 0, n)
+    for aggs in ([agg("sum", Column(1), F64)],
+                 [agg("sum", Column(1), F64), agg("count", Column(1), DataType.UInt64), agg("min", Column(1), F64)]):
+        got = gpu_aggregate([Column(0)], aggs, schema, [], source=t.scan(1 << 20), filter_expr=pred)
+        want = oracle.aggregate([Column(0)], aggs, [oracle.filter_next(pred, ob)])
+        assert_groups_identical(got, want, 1, f"partition_mode={mode} skew={skew} aggs={len(aggs)}")
+    # sentinel key + host batches of ragged sizes
+    rng = np.random.default_rng(5)
+    k = rng.integers(0, 50000, 200001).astype(np.int64)
+    k[::97] = np.iinfo(np.int64).min
+    v = rng.integers(0, 1 << 20, 200001).astype(np.float64) / 1024.0
+    whole = pa.RecordBatch.from_arrays([pa.array(k), pa.array(v)], names=["k", "v"])
+    aggs = [agg("sum", Column(1), F64), agg("max", Column(1), F64)]
+    got = gpu_aggregate([Column(0)], aggs, whole.schema, [whole.slice(0, 70001), whole.slice(70001, 130000)])
+    want = oracle.aggregate([Column(0)], aggs, [whole])
+    assert_groups_identical(got, want, 1, f"partition_mode={mode} sentinel key")
 
 
 def test_aggregate_errors_mirror_reference():

@@ -1,4 +1,4 @@
 #!/bin/bash
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -x --timeout 300 -k "strateg or partition or skew or keys or growth or sentinel or property" 2>&1 | tail -3
-for f in 1 0; do timeout 120 python tools/kprobe.py 268435456 1e6 $f agg.strategy=3 2>&1 | grep -E "partition|groups_out"; done
+timeout 1500 python -m pytest tests -m gpu -q -x --timeout 600 > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -n 5 gpurun_out/pytest_gpu.log
+bash tools/gpu_profile_bench.sh 2>&1 | tail -12
