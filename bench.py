@@ -144,8 +144,8 @@ def main():
         avg_ms = p["total_ms"] / p["launches"]
         achieved = p["algo_bytes"] / p["total_ms"] * 1e-6  # GB/s
         pipeline_ms = sum(prof[k]["total_ms"] for k in ("partition", "partition_agg", "hash_agg") if k in prof)
-        roofline = {"bound": "hbm", "kernel": {"partition": "k_partition (K7 pass 1: fused predicate + key/arg "
-                                               "evaluation + routing to table blocks)",
+        roofline = {"bound": "hbm", "kernel": {"partition": "k_partition_ring (K7 pass 1: fused predicate + key/arg "
+                                               "evaluation + LDS write-combined routing to table blocks)",
                                                "hash_agg": "k_hash_agg (fused predicate + group-by, K7)",
                                                "reduce_all": "k_reduce (K5)"}[dom],
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
