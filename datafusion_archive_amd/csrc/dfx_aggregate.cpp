@@ -37,6 +37,21 @@ struct AggregateRelation::Impl {
   bool has_pred = false;
   dfx_runtime_expr pred;
   std::vector<dfx_runtime_expr> group, aggr;
+  // Utf8 GROUP BY keys are dictionary-encoded on the device into UInt64 ids that live in extra ("virtual")
+  // columns appended to every input batch; the fused program sees an ordinary integer key (dfx_k_dict.hip)
+  struct DictKey {
+    int key = 0;       // index among the GROUP BY expressions
+    int src_col = 0;   // the Utf8 column of the input schema
+    int virt_col = 0;  // its UInt64 id column in `bind_schema`
+    DevDict D;
+    std::shared_ptr<void> state, hash, sid, str_off, str_len, pool, cursors;
+    uint64_t ids_used = 0, pool_used = 0;  // as of the last completed batch
+    bool allocated = false;
+  };
+  std::vector<DictKey> dicts;
+  SchemaInfo bind_schema;                  // input schema + the virtual id columns (what the program binds to)
+  std::vector<dfx_runtime_expr> group_rw;  // GROUP BY expressions with Utf8 columns redirected to their id columns
+  std::vector<int> key_out_dtype;          // result type of each key column (DFX_UTF8 for dictionary keys)
   std::unique_ptr<ProgramBuilder> builder;
   DevAggPlan plan;
   DevFastPlan fast;
@@ -90,6 +105,9 @@ struct AggregateRelation::Impl {
   Status examine_ctrl(int slot);
   Status settle_ctrl();
   Status handle_ctrl(const uint32_t* hc, int64_t n);
+  Status dict_alloc(DictKey& d, int slots_log2, uint64_t pool_cap, bool keep);
+  Status dict_encode(DictKey& d, const DeviceColumn& src, int64_t n, DeviceColumn* ids_col);
+  Status dict_emit(const DictKey& d, const uint64_t* ids, int64_t g, DeviceColumn* out);
   ~Impl() {
     for (int i = 0; i < 2; ++i)
       if (ctrl_ev[i]) (void)hipEventDestroy(ctrl_ev[i]);
@@ -98,7 +116,30 @@ struct AggregateRelation::Impl {
 
 // ---- setup ---------------------------------------------------------------------------------------
 Status AggregateRelation::Impl::setup(const SchemaInfo& input_schema) {
-  builder.reset(new ProgramBuilder(input_schema));
+  bind_schema = input_schema;
+  group_rw = group;
+  key_out_dtype.assign(group.size(), 0);
+  for (size_t k = 0; k < group.size(); ++k) {  // GroupByScalar::Utf8 (aggregate.rs:838-846)
+    if (group[k].is_aggregate || group[k].root < 0) continue;
+    const dfx_expr_node& r = group[k].nodes[group[k].root];
+    if (r.kind != DFX_EXPR_COLUMN || r.column < 0 || r.column >= (int)input_schema.fields.size()) continue;
+    if (input_schema.fields[r.column].dtype != DFX_UTF8) continue;
+    DictKey d;
+    d.key = (int)k;
+    d.src_col = r.column;
+    d.virt_col = (int)bind_schema.fields.size();
+    memset(&d.D, 0, sizeof(d.D));
+    Field f;
+    f.name = "__dict_ids_" + std::to_string(k);
+    f.dtype = DFX_UINT64;
+    f.nullable = false;
+    bind_schema.fields.push_back(f);
+    group_rw[k].nodes[group_rw[k].root].column = d.virt_col;
+    group_rw[k].dtype = DFX_UINT64;
+    key_out_dtype[k] = DFX_UTF8;
+    dicts.push_back(std::move(d));
+  }
+  builder.reset(new ProgramBuilder(bind_schema));
   memset(&plan, 0, sizeof(plan));
   memset(&fast, 0, sizeof(fast));
   plan.pred = kNoOperand;
@@ -115,16 +156,11 @@ Status AggregateRelation::Impl::setup(const SchemaInfo& input_schema) {
   for (int k = 0; k < kw; ++k) {
     if (group[k].is_aggregate) return Status::Err(DFX_INTERNAL_ERROR, "explicit panic: get_func() on an aggregate expression");
     int dt = 0;
-    Status st = builder->add(group[k], group[k].root, &plan.key[k], &dt);
-    if (!st.ok()) {
-      const dfx_expr_node& r = group[k].nodes[group[k].root];
-      if (r.kind == DFX_EXPR_COLUMN && input_schema.fields[r.column].dtype == DFX_UTF8)
-        return Status::Err(DFX_NOT_IMPLEMENTED, "GROUP BY on a Utf8 column is not implemented on the device yet");
-      return st;
-    }
+    DFX_RETURN_IF_ERROR(builder->add(group_rw[k], group_rw[k].root, &plan.key[k], &dt));
     if (!dtype_is_int(dt))  // aggregate.rs:848-850 (floats and booleans are rejected)
       return Status::Err(DFX_EXECUTION_ERROR, "Unsupported GROUP BY data type");
     key_dtype[k] = dt;
+    if (!key_out_dtype[k]) key_out_dtype[k] = dt;
     plan.key_dtype[k] = (uint8_t)dt;
   }
   arg_dtype.assign(na, 0);
@@ -496,7 +532,18 @@ Status AggregateRelation::Impl::consume_batch(const DeviceBatch& b) {
   hipStream_t s = ctx().stream;
   DevProgram prog;
   DevColumns cols;
-  DFX_RETURN_IF_ERROR(builder->bind(b, &prog, &cols));
+  if (dicts.empty()) {
+    DFX_RETURN_IF_ERROR(builder->bind(b, &prog, &cols));
+  } else {  // append the id column of every Utf8 key
+    DeviceBatch ab = b;
+    ab.columns.resize(bind_schema.fields.size());
+    for (DictKey& d : dicts) {
+      if (d.src_col >= (int)b.columns.size() || b.columns[d.src_col].dtype != DFX_UTF8)
+        return Status::Err(DFX_INTERNAL_ERROR, "GROUP BY key column is not Utf8 in this batch");
+      DFX_RETURN_IF_ERROR(dict_encode(d, b.columns[d.src_col], n, &ab.columns[d.virt_col]));
+    }
+    DFX_RETURN_IF_ERROR(builder->bind(ab, &prog, &cols));
+  }
   if (kw == 0) {
     double bytes = 0;
     for (int i = 0; i < prog.n_cols; ++i) bytes += (double)n * (prog.col_dtype[i] == T_BOOL ? 0.125 : dtype_width(prog.col_dtype[i]));
@@ -551,6 +598,137 @@ Status AggregateRelation::Impl::consume_batch(const DeviceBatch& b) {
     DFX_RETURN_IF_ERROR(examine_ctrl(prev)); // the previous batch's snapshot (normally complete by now)
   }
   rows_seen += n;
+  return Status::OK();
+}
+
+// ---- Utf8 key dictionary (host side of dfx_k_dict.hip) ------------------------------------------------
+// (re)allocate a dictionary with 2^slots_log2 slots (ids capacity = half of that) and `pool_cap` pool bytes;
+// keep == true carries the strings of completed batches over and rebuilds the slot table from them
+Status AggregateRelation::Impl::dict_alloc(DictKey& d, int slots_log2, uint64_t pool_cap, bool keep) {
+  hipStream_t s = ctx().stream;
+  const uint64_t slots = 1ull << slots_log2, id_cap = slots / 2;
+  Status st;
+  auto state = device_alloc(sizeof(uint32_t) * slots, &st);
+  if (!state) return st;
+  auto hash = device_alloc(sizeof(uint64_t) * slots, &st);
+  if (!hash) return st;
+  auto sid = device_alloc(sizeof(uint64_t) * slots, &st);
+  if (!sid) return st;
+  auto str_off = device_alloc(sizeof(uint64_t) * id_cap, &st);
+  if (!str_off) return st;
+  auto str_len = device_alloc(sizeof(uint32_t) * id_cap, &st);
+  if (!str_len) return st;
+  auto pool = device_alloc(std::max<uint64_t>(pool_cap, 64), &st);
+  if (!pool) return st;
+  auto cursors = device_alloc(sizeof(uint64_t) * DICT_WORDS, &st);
+  if (!cursors) return st;
+  DFX_HIP(hipMemsetAsync(state.get(), 0, sizeof(uint32_t) * slots, s));
+  if (keep && d.allocated) {
+    if (d.pool_used) DFX_HIP(hipMemcpyAsync(pool.get(), d.pool.get(), d.pool_used, hipMemcpyDeviceToDevice, s));
+    if (d.ids_used) {
+      DFX_HIP(hipMemcpyAsync(str_off.get(), d.str_off.get(), sizeof(uint64_t) * d.ids_used, hipMemcpyDeviceToDevice, s));
+      DFX_HIP(hipMemcpyAsync(str_len.get(), d.str_len.get(), sizeof(uint32_t) * d.ids_used, hipMemcpyDeviceToDevice, s));
+    }
+  } else {
+    d.ids_used = d.pool_used = 0;
+  }
+  const uint64_t hc[DICT_WORDS] = {d.pool_used, d.ids_used, 0, 0};
+  DFX_HIP(hipMemcpyAsync(cursors.get(), hc, sizeof(hc), hipMemcpyHostToDevice, s));
+  DFX_HIP(hipStreamSynchronize(s));  // hc is a stack buffer; the old arrays are released below
+  d.state = state; d.hash = hash; d.sid = sid; d.str_off = str_off; d.str_len = str_len; d.pool = pool; d.cursors = cursors;
+  d.D.state = (uint32_t*)state.get();
+  d.D.hash = (uint64_t*)hash.get();
+  d.D.sid = (uint64_t*)sid.get();
+  d.D.str_off = (uint64_t*)str_off.get();
+  d.D.str_len = (uint32_t*)str_len.get();
+  d.D.pool = (uint8_t*)pool.get();
+  d.D.cursors = (uint64_t*)cursors.get();
+  d.D.mask = slots - 1;
+  d.D.shift = 64 - slots_log2;
+  d.D.id_cap = id_cap;
+  d.D.pool_cap = std::max<uint64_t>(pool_cap, 64);
+  d.allocated = true;
+  if (d.ids_used) DFX_HIP(launch_dict_rebuild(d.D, d.ids_used, s));
+  return Status::OK();
+}
+
+// ids of one batch's strings; grows the dictionary (ids stay stable) and re-encodes when it overflows
+Status AggregateRelation::Impl::dict_encode(DictKey& d, const DeviceColumn& src, int64_t n, DeviceColumn* ids_col) {
+  hipStream_t s = ctx().stream;
+  Status st;
+  auto ids = device_alloc(sizeof(uint64_t) * (size_t)std::max<int64_t>(n, 1), &st);
+  if (!ids) return st;
+  if (!d.allocated) {
+    int lg = agg_options().dict_capacity_log2 > 0 ? agg_options().dict_capacity_log2 : 16;
+    lg = std::max(4, std::min(lg, 30));
+    DFX_RETURN_IF_ERROR(dict_alloc(d, lg, std::max<uint64_t>((uint64_t)src.data_bytes * 2, 1u << 16), false));
+  }
+  for (int attempt = 0; n > 0; ++attempt) {
+    if (attempt > 16) return Status::Err(DFX_INTERNAL_ERROR, "Utf8 key dictionary does not converge");
+    DFX_HIP(launch_dict_encode(src.offsets, src.data, n, d.D, (uint64_t*)ids.get(), s));
+    uint64_t hc[DICT_WORDS];
+    DFX_HIP(hipMemcpyAsync(hc, d.D.cursors, sizeof(hc), hipMemcpyDeviceToHost, s));
+    DFX_HIP(hipStreamSynchronize(s));
+    if (hc[DICT_OVERFLOW] == 2) return Status::Err(DFX_INTERNAL_ERROR, "Utf8 key dictionary: slot claim timed out");
+    if (hc[DICT_OVERFLOW] == 0) {
+      d.ids_used = hc[DICT_IDS];
+      d.pool_used = hc[DICT_POOL];
+      break;
+    }
+    // overflow: forget this attempt (its ids were not used yet), grow x4 (slots / ids) and to fit the batch (pool)
+    int lg = 64 - d.D.shift;
+    const uint64_t want_ids = std::max<uint64_t>(hc[DICT_IDS], d.ids_used + 1);
+    while ((1ull << lg) / 2 < want_ids * 2 && lg < 31) ++lg;
+    lg = std::min(31, std::max(lg, 64 - d.D.shift + 2));
+    const uint64_t want_pool = std::max<uint64_t>(hc[DICT_POOL], d.pool_used + (uint64_t)src.data_bytes) * 2;
+    DFX_RETURN_IF_ERROR(dict_alloc(d, lg, std::max<uint64_t>(want_pool, d.D.pool_cap), true));
+  }
+  ids_col->dtype = DFX_UINT64;
+  ids_col->length = n;
+  ids_col->null_count = 0;
+  ids_col->values = ids.get();
+  ids_col->validity = nullptr;
+  ids_col->bit_offset = 0;
+  ids_col->owners.clear();
+  ids_col->owners.push_back(ids);
+  return Status::OK();
+}
+
+// group ids -> Arrow Utf8 column (offsets + data) on the device
+Status AggregateRelation::Impl::dict_emit(const DictKey& d, const uint64_t* ids, int64_t g, DeviceColumn* out) {
+  hipStream_t s = ctx().stream;
+  Status st;
+  auto lens = device_alloc(sizeof(uint32_t) * (size_t)std::max<int64_t>(g, 1), &st);
+  if (!lens) return st;
+  auto starts = device_alloc(sizeof(uint64_t) * (size_t)(g + 1), &st);
+  if (!starts) return st;
+  auto tmp = device_alloc(sizeof(uint64_t) * (size_t)(g / 4096 + 4), &st);
+  if (!tmp) return st;
+  auto offs = device_alloc(sizeof(int32_t) * (size_t)(g + 1), &st);
+  if (!offs) return st;
+  uint64_t total = 0;
+  if (g > 0) {
+    DFX_HIP(launch_dict_lengths(ids, g, d.D, (uint32_t*)lens.get(), s));
+    DFX_HIP(launch_scan_u32((const uint32_t*)lens.get(), (uint64_t*)starts.get(), g, (uint64_t*)tmp.get(), s));
+    DFX_HIP(hipMemcpyAsync(&total, (uint64_t*)starts.get() + g, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    DFX_HIP(hipStreamSynchronize(s));
+  } else {
+    DFX_HIP(hipMemsetAsync(starts.get(), 0, sizeof(uint64_t), s));
+  }
+  if (total > 0x7FFFFFFFull) return Status::Err(DFX_EXECUTION_ERROR, "Utf8 group keys exceed 2 GB (Arrow Utf8 offsets are 32-bit)");
+  auto data = device_alloc((size_t)std::max<uint64_t>(total, 8), &st);
+  if (!data) return st;
+  DFX_HIP(launch_dict_gather(ids, g, d.D, (const uint64_t*)starts.get(), (int32_t*)offs.get(), (uint8_t*)data.get(), s));
+  out->dtype = DFX_UTF8;
+  out->length = g;
+  out->null_count = 0;
+  out->values = nullptr;
+  out->offsets = (const int32_t*)offs.get();
+  out->data = (const uint8_t*)data.get();
+  out->data_bytes = (int64_t)total;
+  out->owners.clear();
+  out->owners.push_back(offs);
+  out->owners.push_back(data);
   return Status::OK();
 }
 
@@ -694,6 +872,13 @@ Status AggregateRelation::Impl::emit_grouped(DeviceBatch* out) {  // aggregate.r
     auto vals = device_alloc((size_t)std::max<int64_t>(g, 1) * dtype_width(dt), &st);
     if (!vals) return st;
     DFX_HIP(launch_compact(plane, 8, (const uint64_t*)mask.get(), (const uint64_t*)offsets.get(), n_slots, dense.get(), 0, s));
+    const DictKey* dk = nullptr;
+    for (const DictKey& d : dicts)
+      if (is_key && d.key == k) dk = &d;
+    if (dk) {  // ids -> Arrow Utf8
+      DFX_RETURN_IF_ERROR(dict_emit(*dk, (const uint64_t*)dense.get(), g, &c));
+      continue;
+    }
     DFX_HIP(launch_finalize((const uint64_t*)dense.get(), g, (uint8_t)dt, is_key ? (uint8_t)VT_RAW : val_xform[k - kw], vals.get(), s));
     c.values = vals.get();
     c.owners.push_back(vals);
@@ -727,7 +912,7 @@ AggregateRelation::AggregateRelation(SchemaInfo schema, std::unique_ptr<Relation
   for (size_t k = 0; k < m.group.size(); ++k) {
     Field f;
     f.name = m.group[k].name;
-    f.dtype = k < m.key_dtype.size() && m.key_dtype[k] ? m.key_dtype[k] : m.group[k].dtype;
+    f.dtype = k < m.key_out_dtype.size() && m.key_out_dtype[k] ? m.key_out_dtype[k] : m.group[k].dtype;
     f.nullable = false;
     derived.fields.push_back(f);
   }
@@ -765,6 +950,8 @@ Status AggregateRelation::next(DeviceBatch* out, bool* has) {
 
 // ---- multi-GPU partial exchange ---------------------------------------------------------------------
 Status AggregateRelation::partial_build(int world, int* n_words, int64_t* counts) {
+  if (!impl_->dicts.empty())
+    return Status::Err(DFX_NOT_IMPLEMENTED, "multi-GPU exchange of Utf8 GROUP BY keys (dictionary ids are rank-local)");
   Impl& m = *impl_;
   if (!m.deferred.ok()) return m.deferred;
   if (m.kw == 0) return Status::Err(DFX_NOT_IMPLEMENTED, "partial exchange is for GROUP BY aggregates");

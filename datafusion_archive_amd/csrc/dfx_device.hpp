@@ -191,6 +191,23 @@ struct DevPartition {
   uint32_t block;      // pass-1 workgroup size (mode 1: 512 or 1024)
 };
 
+// ---- Utf8 GROUP BY keys: device string dictionary (dfx_k_dict.hip) ---------------------------------
+enum : int { DICT_POOL = 0, DICT_IDS = 1, DICT_OVERFLOW = 2, DICT_WORDS = 4 };
+struct DevDict {
+  uint32_t* state;    // per slot: 0 empty, 1 being filled, 2 ready, 3 abandoned (overflow; cleared by the rebuild)
+  uint64_t* hash;     // per slot
+  uint64_t* sid;      // per slot: string id
+  uint64_t* str_off;  // per id: offset of the bytes in `pool`
+  uint32_t* str_len;  // per id
+  uint8_t* pool;
+  uint64_t* cursors;  // DICT_WORDS words: pool bytes used, ids used, overflow flag
+  uint64_t mask;      // slots - 1
+  int32_t shift;      // 64 - log2(slots)
+  int32_t pad;
+  uint64_t id_cap;
+  uint64_t pool_cap;
+};
+
 struct DevProjectPlan {
   int32_t n_out;
   uint8_t out[kMaxOut];        // operands

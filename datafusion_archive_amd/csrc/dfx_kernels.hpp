@@ -108,6 +108,14 @@ hipError_t launch_partial_scatter(const DevTable& T, int world, const uint64_t* 
 hipError_t launch_merge_bucket(const uint64_t* bucket, uint64_t count, const DevTable& T,
                                const DevRows& spill, hipStream_t s);
 
+// Utf8 GROUP BY keys (dfx_k_dict.hip): strings -> stable 64-bit ids and back
+hipError_t launch_dict_encode(const int32_t* offsets, const uint8_t* data, int64_t n, const DevDict& D, uint64_t* ids,
+                              hipStream_t s);
+hipError_t launch_dict_rebuild(const DevDict& D, uint64_t n_ids, hipStream_t s);
+hipError_t launch_dict_lengths(const uint64_t* ids, int64_t g, const DevDict& D, uint32_t* lens, hipStream_t s);
+hipError_t launch_dict_gather(const uint64_t* ids, int64_t g, const DevDict& D, const uint64_t* starts, int32_t* offsets,
+                              uint8_t* out, hipStream_t s);
+
 // partitioned GROUP BY (dfx_k_partition.hip): pass 1 routes passing rows to per-(producer, partition)
 // regions, pass 2 aggregates every partition in an LDS copy of its table block.  Single-word keys.
 size_t partition_stage_bytes(const DevPartition& PT);

@@ -96,6 +96,7 @@ struct AggOptions {
   int lds_copies = -1;      // -1 auto
   int fast = 1;             // 0: always run the generic interpreter (tests compare both paths)
   int partition_mode = 2;   // pass 1 of the partitioned strategy: 2 lock-free LDS rings, 1 LDS counting sort, 0 direct routing
+  int dict_capacity_log2 = 0;  // initial slots of a Utf8 key dictionary (0: 2^16); tests use tiny values to force growth
   int partition_cap_rows = 0;  // rows per (producer, partition) region; 0: sized from the batch
   int partition_pad = 0;       // bytes of padding between partitions in the routing scratch
   int partition_block = 1024;  // pass-1 workgroup size in mode 1 (512: two workgroups per CU)

@@ -130,12 +130,48 @@ def test_golden_min_max_sum_group_by():
     assert abs(vals[1] - 3.3000000000000003) <= 2 * EPS * 3.3
 
 
-def test_group_by_utf8_is_reported_not_faked():
-    """tests/sql.rs:54-67 needs Utf8 group keys: not on the device yet -> a loud NotImplemented."""
+def test_golden_csv_query_group_by_string_min_max():
+    """tests/sql.rs:54-67: GROUP BY a Utf8 column (GroupByScalar::Utf8, aggregate.rs:838-846).  The strings are
+    dictionary-encoded on the device; the result must be the reference's golden string (as a set: no ORDER BY)."""
     schema = aggr_test_schema(pa.string())
-    with pytest.raises(ex.ExecutionError) as ei:
-        gpu_aggregate([Column(0)], [agg("MIN", Column(1), F64)], schema, load_csv("aggregate_test_2.csv", schema))
-    assert ei.value.kind == "NotImplemented"
+    res = gpu_aggregate([Column(0)], [agg("MIN", Column(1), F64), agg("MAX", Column(1), F64)], schema,
+                        load_csv("aggregate_test_2.csv", schema))
+    expected = "\"three\"\t1.0\t2.0\n\"two\"\t3.3\t5.5\n\"one\"\t1.1\t2.2\n"
+    assert res.schema.field(0).type == pa.string()
+    assert sorted(result_str([res]).splitlines()) == sorted(expected.splitlines())
+
+
+@pytest.mark.parametrize("dict_log2", [0, 4])
+@pytest.mark.parametrize("strategy", [0, 1, 3])
+def test_group_by_utf8_keys_vs_oracle(strategy, dict_log2):
+    """Random strings (empty, 1 byte ... 40 bytes, shared prefixes, UTF-8 multibyte), many distinct values,
+    several ragged batches, a second Int32 key; dict_log2=4 starts with a 16-slot dictionary so that it has to
+    grow (ids must stay stable across growth).  Compared with the oracle as a set of groups."""
+    ex.set_option("agg.strategy", strategy)
+    ex.set_option("agg.dict_capacity_log2", dict_log2)
+    rng = np.random.default_rng(77)
+    words = ["", "a", "b", "ab", "ba", "München", "東京", "x" * 40] + \
+            ["city_%d" % i for i in range(3000)] + ["city_%d_suffix" % i for i in range(0, 3000, 7)]
+    n = 60000
+    ks = rng.integers(0, len(words), n)
+    keys = pa.array([words[i] for i in ks], type=pa.string())
+    k2 = pa.array(rng.integers(0, 3, n).astype(np.int32))
+    v = pa.array(rng.integers(0, 1 << 20, n).astype(np.float64) / 1024.0)
+    whole = pa.RecordBatch.from_arrays([keys, k2, v], names=["s", "k", "v"])
+    batches = [whole.slice(0, 1), whole.slice(1, 20000), whole.slice(20001, 39999)]
+    aggs = [agg("sum", Column(2), F64), agg("min", Column(2), F64), agg("count", Column(2), DataType.UInt64)]
+    for group, nk in (([Column(0)], 1), ([Column(0), Column(1)], 2), ([Column(1), Column(0)], 2)):
+        if strategy == 3 and nk > 1:
+            continue  # the partitioned strategy is single-key
+        got = gpu_aggregate(group, aggs, whole.schema, batches)
+        want = oracle.aggregate(group, aggs, batches)
+        assert_groups_identical(got, want, nk, f"utf8 keys strategy={strategy} nk={nk}")
+    # Filter under the aggregate (fused): the predicate sees the original columns
+    pred = BinaryExpr(Column(2), Operator.Gt, lit(300.0))
+    got = gpu_aggregate([Column(0)], aggs, whole.schema, batches, filter_expr=pred)
+    want = oracle.aggregate([Column(0)], aggs, [oracle.filter_next(pred, b) for b in batches])
+    assert_groups_identical(got, want, 1, "utf8 keys under a filter")
+    ex.set_option("agg.dict_capacity_log2", 0)
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -1,4 +1,3 @@
 #!/bin/bash
 mkdir -p gpurun_out
-timeout 1500 python -m pytest tests -m gpu -q -x --timeout 600 > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -n 5 gpurun_out/pytest_gpu.log
-bash tools/gpu_profile_bench.sh 2>&1 | tail -12
+timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -x --timeout 300 -k "utf8 or string or golden" 2>&1 | tail -15
