@@ -560,6 +560,64 @@ def test_resident_table_growth_under_spill_at_scale(strategy):
     assert_groups_identical(got, want, 1, "growth at scale")
 
 
+@pytest.mark.parametrize("world", [1, 2, 3])
+@pytest.mark.parametrize("strategy", [0, 3])
+def test_device_partial_exchange_emulated_ranks(world, strategy):
+    """The multi-GPU exchange entry points on the real device, with the all-to-all emulated in ONE process:
+    `world` aggregates over disjoint row shards -> partial_build (bucket counts by owner rank) ->
+    partial_export (bucketed key/accumulator words) -> every "rank" imports its bucket of every export ->
+    the union of the emitted groups equals the oracle over all rows, and every group has exactly one owner."""
+    import torch
+    ex.set_option("agg.strategy", strategy)
+    syn = [("k", ex.SYNTH_I64_UNIFORM, 0, 200000.0, 0.0), ("v", ex.SYNTH_F64_EXACT, 1, 0.0, 0.0)]
+    n, seed = 3 * (1 << 19), 0xDF09
+    schema = pa.schema([("k", pa.int64()), ("v", pa.float64())])
+    aggs = [agg("sum", Column(1), F64), agg("count", Column(1), DataType.UInt64), agg("max", Column(1), F64)]
+    pred = BinaryExpr(Column(1), Operator.Lt, lit(700.0))
+    per = n // world
+    rels, tables = [], []
+    for r in range(world):
+        t = ex.DeviceTable.synth(syn, seed, r * per, per if r < world - 1 else n - r * per)
+        tables.append(t)
+        rel = ex.FilterRelation(t.scan(1 << 18), ex.compile_scalar_expr(None, pred, schema), schema)
+        rels.append(ex.AggregateRelation(None, rel, [ex.compile_scalar_expr(None, Column(0), schema)],
+                                         [ex.compile_expr(None, a, schema) for a in aggs]))
+    built = [rel.partial_build(world) for rel in rels]
+    n_words = built[0][0]
+    assert all(b[0] == n_words for b in built) and n_words == 1 + len(aggs)
+    dev = torch.device("cuda:0")
+    sends = []
+    for rel, (_, counts) in zip(rels, built):
+        buf = torch.empty(max(1, n_words * sum(counts)), dtype=torch.int64, device=dev)
+        rel.partial_export(buf.data_ptr(), n_words * sum(counts))
+        sends.append(buf)
+    torch.cuda.synchronize()
+    outs = []
+    for r, rel in enumerate(rels):
+        parts, rc = [], []
+        for s_rank, (_, counts) in enumerate(built):
+            lo = n_words * sum(counts[:r])
+            parts.append(sends[s_rank][lo: lo + n_words * counts[r]])
+            rc.append(counts[r])
+        recv = torch.cat(parts) if sum(rc) else torch.empty(1, dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()
+        rel.partial_import(recv.data_ptr(), rc)
+        out = rel.next()
+        assert out is not None and rel.next() is None
+        outs.append(out)
+    keys = [set(o.column(0).to_pylist()) for o in outs]
+    for a in range(world):
+        for b in range(a + 1, world):
+            assert not (keys[a] & keys[b]), "a group was emitted by two ranks"
+    got = pa.Table.from_batches(outs).combine_chunks().to_batches()[0]
+    ob = oracle.synth_batch(syn, seed, 0, n)
+    want = oracle.aggregate([Column(0)], aggs, [oracle.filter_next(pred, ob)])
+    assert_groups_identical(got, want, 1, f"emulated exchange world={world}")
+    if world > 1:
+        sizes = [o.num_rows for o in outs]
+        assert min(sizes) > 0.5 * max(sizes), f"owner hash is badly balanced: {sizes}"
+
+
 def test_large_properties_filter_groupby_sum():
     """2^28 rows (4 GB): sum over groups of SUM(v) == ungrouped SUM(v) bit for bit (exact data),
     sum of COUNTs == rows passing the predicate == ungrouped COUNT."""

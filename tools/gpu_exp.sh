@@ -1,3 +1,3 @@
 #!/bin/bash
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -x --timeout 300 -k "utf8 or string or golden" 2>&1 | tail -15
+timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -x --timeout 300 -k "emulated" 2>&1 | tail -25
