@@ -57,11 +57,18 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU path")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # DFX_BENCH_SHARED_GPU=1: dry run of the N-rank code path on a ONE-GPU box (every rank on cuda:0, gloo with
+    # host staging instead of RCCL).  Its numbers mean nothing; it exists to test the plumbing.
+    shared_gpu = os.environ.get("DFX_BENCH_SHARED_GPU") == "1"
+    dev_index = 0 if shared_gpu else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=device)
+        if shared_gpu:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=device)
 
     import pyarrow as pa
     from datafusion_archive_amd import execution as ex
@@ -69,7 +76,8 @@ def main():
     from datafusion_archive_amd.logicalplan import (AggregateFunction, BinaryExpr, Column, DataType, Literal,
                                                     Operator, ScalarValue)
 
-    ex.init(local_rank)
+    ex.init(dev_index)
+    coll_device = torch.device("cpu") if shared_gpu else device  # where the tiny bookkeeping collectives run
     info = ex.device_info()
     n_rows = int(args.rows)
     seed = 0xDF02
@@ -115,7 +123,7 @@ def main():
         sync()
         dt = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=device)
+            t = torch.tensor([dt], dtype=torch.float64, device=coll_device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         return dt, last
@@ -180,14 +188,14 @@ def main():
         local_sum = float(np.sum(result.column(1).to_numpy())) if result.num_rows else 0.0
         local_groups = result.num_rows
         if world > 1:
-            t = torch.tensor([local_sum, float(local_groups)], dtype=torch.float64, device=device)
+            t = torch.tensor([local_sum, float(local_groups)], dtype=torch.float64, device=coll_device)
             dist.all_reduce(t)
             local_sum, local_groups = float(t[0].item()), int(t[1].item())
         # ungrouped fused SUM over the same rows: exact data => must agree bit for bit
         tot = build(pred, [], [sum_v, count_v]).next()
         ts, tc = tot.column(0)[0].as_py() or 0.0, tot.column(1)[0].as_py() or 0
         if world > 1:
-            t = torch.tensor([ts, float(tc)], dtype=torch.float64, device=device)
+            t = torch.tensor([ts, float(tc)], dtype=torch.float64, device=coll_device)
             dist.all_reduce(t)
             ts, tc = float(t[0].item()), int(t[1].item())
         verified = bool(local_sum == ts and local_groups == GROUPS and abs(tc / total_rows - 0.2) < 1e-3)

@@ -22,7 +22,12 @@ def exchange_group_partials(agg, world: int, device, dist=None, torch=None) -> d
     if dist is None:
         import torch.distributed as dist  # type: ignore
     n_words, counts = agg.partial_build(world)
-    send_counts = torch.tensor(list(counts), dtype=torch.int64, device=device)
+    # the collective runs on `cdev`: the GPU itself (RCCL), or the host when the process group is gloo
+    # (CPU tests; shared-GPU dry runs of bench.py) -- the library's entry points always take DEVICE pointers
+    is_cuda = getattr(device, "type", str(device)) == "cuda" or str(device).startswith("cuda")
+    staged = is_cuda and world > 1 and dist.get_backend() == "gloo"
+    cdev = torch.device("cpu") if staged else device
+    send_counts = torch.tensor(list(counts), dtype=torch.int64, device=cdev)
     recv_counts = torch.empty_like(send_counts)
     if world > 1:
         dist.all_to_all_single(recv_counts, send_counts)
@@ -30,15 +35,19 @@ def exchange_group_partials(agg, world: int, device, dist=None, torch=None) -> d
         recv_counts.copy_(send_counts)
     rc = [int(x) for x in recv_counts.tolist()]
     send = torch.empty(max(1, n_words * sum(counts)), dtype=torch.int64, device=device)
-    agg.partial_export(send.data_ptr(), n_words * sum(counts))
+    agg.partial_export(send.data_ptr(), n_words * sum(counts))  # synchronises the library's stream
     recv = torch.empty(max(1, n_words * sum(rc)), dtype=torch.int64, device=device)
     if world > 1:
-        dist.all_to_all_single(recv[: n_words * sum(rc)], send[: n_words * sum(counts)],
+        src = send.cpu() if staged else send
+        dst = torch.empty(max(1, n_words * sum(rc)), dtype=torch.int64, device=cdev) if staged else recv
+        dist.all_to_all_single(dst[: n_words * sum(rc)], src[: n_words * sum(counts)],
                                output_split_sizes=[n_words * c for c in rc],
                                input_split_sizes=[n_words * c for c in counts])
+        if staged:
+            recv.copy_(dst)
     else:
         recv.copy_(send)
-    if getattr(device, "type", str(device)) == "cuda" or str(device).startswith("cuda"):
+    if is_cuda:
         torch.cuda.synchronize()
     agg.partial_import(recv.data_ptr(), rc)
     return {"n_words": n_words, "sent_groups": int(sum(counts)), "received_groups": int(sum(rc)),
