@@ -955,7 +955,7 @@ Status AggregateRelation::partial_build(int world, int* n_words, int64_t* counts
   Impl& m = *impl_;
   if (!m.deferred.ok()) return m.deferred;
   if (m.kw == 0) return Status::Err(DFX_NOT_IMPLEMENTED, "partial exchange is for GROUP BY aggregates");
-  if (world < 1) return Status::Err(DFX_GENERAL, "world must be >= 1");
+  if (world < 1 || world > 1024) return Status::Err(DFX_GENERAL, "world must be in 1..1024");
   DFX_RETURN_IF_ERROR(m.drain());
   hipStream_t s = ctx().stream;
   Status st;

@@ -284,16 +284,28 @@ DEV uint64_t slot_key_hash(const DevTable& T, uint64_t slot, uint64_t (&key)[KW]
   return hash_keys<KW>(key);
 }
 
+// Both kernels aggregate per WORKGROUP in LDS and touch the `world` global counters once per workgroup (tile):
+// agent-scope atomics on one address serialise at ~11 ns each on MI355X, so one atomic per group would cost
+// ~11 ms per million groups -- more than the whole scan of 1e9 rows.
+constexpr int kMaxWorld = 1024;
+constexpr int kPartialItems = 8;  // table slots per thread and tile
+
 template <int KW>
 __global__ __launch_bounds__(kBlock) void k_partial_count(const DevTable T, int world, uint64_t* counts) {
+  __shared__ uint32_t hist[kMaxWorld];
+  for (int r = threadIdx.x; r < world; r += kBlock) hist[r] = 0;
+  __syncthreads();
   const int64_t n = (int64_t)T.mask + 2;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
     if (slot_occupied<KW>(T, (uint64_t)i)) {
       uint64_t key[KW];
       const uint64_t h = slot_key_hash<KW>(T, (uint64_t)i, key);
-      atomicAdd((unsigned long long*)&counts[hash_rank(h, (uint32_t)world)], 1ull);
+      atomicAdd(&hist[hash_rank(h, (uint32_t)world)], 1u);
     }
   }
+  __syncthreads();
+  for (int r = threadIdx.x; r < world; r += kBlock)
+    if (hist[r]) atomicAdd((unsigned long long*)&counts[r], (unsigned long long)hist[r]);
 }
 
 template <int KW>
@@ -301,20 +313,47 @@ __global__ __launch_bounds__(kBlock) void k_partial_scatter(const DevTable T, in
                                                             const uint64_t* __restrict__ bucket_base,
                                                             const uint64_t* __restrict__ bucket_count,
                                                             uint64_t* cursors, uint64_t* __restrict__ dst) {
+  __shared__ uint32_t hist[kMaxWorld];   // groups of this tile per destination rank
+  __shared__ uint64_t tbase[kMaxWorld];  // where this tile's groups start inside each bucket
   const int64_t n = (int64_t)T.mask + 2;
   const int nw = KW + T.na;
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
-    if (slot_occupied<KW>(T, (uint64_t)i)) {
-      uint64_t key[KW];
-      const uint64_t h = slot_key_hash<KW>(T, (uint64_t)i, key);
-      const uint64_t r = hash_rank(h, (uint32_t)world);
-      const uint64_t g = atomicAdd((unsigned long long*)&cursors[r], 1ull);
-      uint64_t* b = dst + (uint64_t)nw * bucket_base[r];
-      const uint64_t cnt = bucket_count[r];
+  const int64_t tile_slots = (int64_t)kBlock * kPartialItems;
+  for (int64_t t0 = (int64_t)blockIdx.x * tile_slots; t0 < n; t0 += (int64_t)gridDim.x * tile_slots) {
+    for (int r = threadIdx.x; r < world; r += kBlock) hist[r] = 0;
+    __syncthreads();
+    uint32_t rank[kPartialItems], lpos[kPartialItems];
 #pragma unroll
-      for (int k = 0; k < KW; ++k) b[(uint64_t)k * cnt + g] = key[k];
-      for (int a = 0; a < T.na; ++a) b[(uint64_t)(KW + a) * cnt + g] = T.accs[(uint64_t)a * T.stride + i];
+    for (int it = 0; it < kPartialItems; ++it) {
+      const int64_t i = t0 + (int64_t)it * kBlock + threadIdx.x;
+      rank[it] = 0xFFFFFFFFu;
+      lpos[it] = 0;
+      if (i < n && slot_occupied<KW>(T, (uint64_t)i)) {
+        uint64_t key[KW];
+        const uint64_t h = slot_key_hash<KW>(T, (uint64_t)i, key);
+        rank[it] = hash_rank(h, (uint32_t)world);
+        lpos[it] = atomicAdd(&hist[rank[it]], 1u);
+      }
     }
+    __syncthreads();
+    for (int r = threadIdx.x; r < world; r += kBlock)
+      tbase[r] = hist[r] ? atomicAdd((unsigned long long*)&cursors[r], (unsigned long long)hist[r]) : 0ull;
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < kPartialItems; ++it) {
+      if (rank[it] != 0xFFFFFFFFu) {
+        const int64_t i = t0 + (int64_t)it * kBlock + threadIdx.x;
+        const uint32_t r = rank[it];
+        const uint64_t g = tbase[r] + lpos[it];
+        uint64_t* b = dst + (uint64_t)nw * bucket_base[r];
+        const uint64_t cnt = bucket_count[r];
+        uint64_t key[KW];
+        (void)slot_key_hash<KW>(T, (uint64_t)i, key);
+#pragma unroll
+        for (int k = 0; k < KW; ++k) b[(uint64_t)k * cnt + g] = key[k];
+        for (int a = 0; a < T.na; ++a) b[(uint64_t)(KW + a) * cnt + g] = T.accs[(uint64_t)a * T.stride + i];
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -381,6 +420,7 @@ hipError_t table_mask(const DevTable& T, uint64_t* mask_words, uint32_t* tile_co
 template <int KW>
 hipError_t table_partial_count(const DevTable& T, int world, uint64_t* counts, hipStream_t s) {
   const int64_t n = (int64_t)T.mask + 2;
+  if (world > kMaxWorld) return hipErrorInvalidValue;
   const int grid = stream_grid((n + kBlock - 1) / kBlock, 8);
   hipLaunchKernelGGL(k_partial_count<KW>, dim3(grid), dim3(kBlock), 0, s, T, world, counts);
   return hipGetLastError();
@@ -390,7 +430,8 @@ template <int KW>
 hipError_t table_partial_scatter(const DevTable& T, int world, const uint64_t* bucket_base,
                                  const uint64_t* bucket_count, uint64_t* cursors, uint64_t* dst, hipStream_t s) {
   const int64_t n = (int64_t)T.mask + 2;
-  const int grid = stream_grid((n + kBlock - 1) / kBlock, 8);
+  if (world > kMaxWorld) return hipErrorInvalidValue;
+  const int grid = stream_grid((n + (int64_t)kBlock * kPartialItems - 1) / ((int64_t)kBlock * kPartialItems), 8);
   hipLaunchKernelGGL(k_partial_scatter<KW>, dim3(grid), dim3(kBlock), 0, s, T, world, bucket_base, bucket_count, cursors, dst);
   return hipGetLastError();
 }
