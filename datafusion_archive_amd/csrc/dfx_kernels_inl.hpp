@@ -392,20 +392,22 @@ DEV uint32_t cmp3(uint8_t t, uint64_t x, uint64_t y) {
   return (a < b ? 1u : 0u) | (a == b ? 2u : 0u) | (a > b ? 4u : 0u);
 }
 
-// `(cmp3(t, x, y) & m) != 0` for a wave-uniform m (it comes from the kernarg segment)
+// Wave-level comparison: the lane mask of `(cmp3(t, x, y) & m) != 0` for a wave-uniform m (it comes from the
+// kernarg segment).  The three v_cmp write SGPR pairs and the selection by m runs on the scalar unit -- no
+// per-lane select / or, no branch; the caller turns the final mask back into a per-lane predicate with
+// inverse_ballot (a copy into VCC).  Bits of inactive lanes are meaningless.
 template <typename TT>
-DEV bool cmp_by_mask(TT a, TT b, uint32_t m) {
-  // m is wave-uniform: the three selectors are scalar lane masks, the result is three v_cmp writing SGPR
-  // pairs combined on the scalar unit (no per-lane select / or, no branch)
-  const bool ml = (m & 1u) != 0, me = (m & 2u) != 0, mg = (m & 4u) != 0;
-  return (ml & (a < b)) | (me & (a == b)) | (mg & (a > b));
+DEV uint64_t cmp_mask_by(TT a, TT b, uint32_t m) {
+  const uint64_t lt = __ballot(a < b), eq = __ballot(a == b), gt = __ballot(a > b);
+  return ((m & 1u) ? lt : 0ull) | ((m & 2u) ? eq : 0ull) | ((m & 4u) ? gt : 0ull);
 }
-DEV bool cmp_masked(uint8_t t, uint64_t x, uint64_t y, uint32_t m) {
-  if (t == T_F64) return cmp_by_mask<double>(as_f64(x), as_f64(y), m);
-  if (t == T_F32) return cmp_by_mask<float>(as_f32(x), as_f32(y), m);
-  if (t == T_U64) return cmp_by_mask<uint64_t>(x, y, m);
-  return cmp_by_mask<int64_t>((int64_t)x, (int64_t)y, m);
+DEV uint64_t cmp_mask(uint8_t t, uint64_t x, uint64_t y, uint32_t m) {
+  if (t == T_F64) return cmp_mask_by<double>(as_f64(x), as_f64(y), m);
+  if (t == T_F32) return cmp_mask_by<float>(as_f32(x), as_f32(y), m);
+  if (t == T_U64) return cmp_mask_by<uint64_t>(x, y, m);
+  return cmp_mask_by<int64_t>((int64_t)x, (int64_t)y, m);
 }
+DEV bool lane_of_mask(uint64_t mask) { return __builtin_amdgcn_inverse_ballot_w64(mask); }
 
 // shape-specialised (DevFastPlan): conjunction of `column <op> literal`, plain-column keys, column /
 // short-product arguments; no nulls.  Straight-line code, the only scalar work is reading the plan.
@@ -424,16 +426,15 @@ struct FastPolicy {
                        uint32_t&) {}
   static DEV bool pass(const DevProgram&, const DevFastPlan& F, uint8_t, const COLV& cur, uint32_t, const u64x16&,
                        uint32_t) {
-    uint32_t ok = 1u;
+    uint64_t ok = ~0ull;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       if (i < F.np) {
         const DevFastTerm t = F.term[i];
-        const bool c = cmp_masked(t.dtype, cur[t.col & (BANK - 1)], F.term_imm[i], (uint32_t)t.m);
-        ok &= (c ? 1u : 0u) ^ (uint32_t)t.inv;
+        ok &= cmp_mask(t.dtype, cur[t.col & (BANK - 1)], F.term_imm[i], (uint32_t)t.m) ^ (t.inv ? ~0ull : 0ull);
       }
     }
-    return ok != 0u;
+    return lane_of_mask(ok);
   }
   static DEV uint64_t key(const DevProgram&, const DevFastPlan& F, uint8_t, int k, const COLV& cur, uint32_t,
                           const u64x16&, uint32_t) {
@@ -494,15 +495,14 @@ struct StaticPolicy {
                        uint32_t&) {}
   static DEV bool pass(const DevProgram&, const DevFastPlan& F, uint8_t, const COLV& cur, uint32_t, const u64x16&,
                        uint32_t) {
-    uint32_t ok = 1u;
+    uint64_t ok = ~0ull;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      if (i < SIG::NP) {
-        const bool c = cmp_masked(SIG::term_cls(i), cur[SIG::term_col(i)], F.term_imm[i], (uint32_t)F.term[i].m);
-        ok &= (c ? 1u : 0u) ^ (uint32_t)F.term[i].inv;
-      }
+      if (i < SIG::NP)
+        ok &= cmp_mask(SIG::term_cls(i), cur[SIG::term_col(i)], F.term_imm[i], (uint32_t)F.term[i].m) ^
+              (F.term[i].inv ? ~0ull : 0ull);
     }
-    return ok != 0u;
+    return lane_of_mask(ok);
   }
   static DEV uint64_t key(const DevProgram&, const DevFastPlan&, uint8_t, int k, const COLV& cur, uint32_t,
                           const u64x16&, uint32_t) {
