@@ -66,6 +66,7 @@ struct AggregateRelation::Impl {
   DevTable T;
   std::vector<std::shared_ptr<void>> table_owners;
   std::shared_ptr<void> ctrl;
+  std::shared_ptr<void> stats;  // DevTable::stats
   DevRows spill;
   std::shared_ptr<void> spill_owner;
   bool lds_enabled = true;
@@ -276,8 +277,12 @@ Status AggregateRelation::Impl::alloc_table(int cap_log2, DevTable* Tn, std::vec
     ctrl = device_alloc(sizeof(uint32_t) * CTRL_WORDS, &st);
     if (!ctrl) return st;
     DFX_HIP(hipMemsetAsync(ctrl.get(), 0, sizeof(uint32_t) * CTRL_WORDS, s));
+    stats = device_alloc(sizeof(uint64_t) * kStatStripes * STAT_WORDS, &st);
+    if (!stats) return st;
+    DFX_HIP(hipMemsetAsync(stats.get(), 0, sizeof(uint64_t) * kStatStripes * STAT_WORDS, s));
   }
   Tn->ctrl = (uint32_t*)ctrl.get();
+  Tn->stats = (uint64_t*)stats.get();
   return Status::OK();
 }
 
@@ -390,11 +395,17 @@ Status AggregateRelation::Impl::handle_ctrl(const uint32_t* hc, int64_t n) {
   if (hc[CTRL_ERROR]) return error_from_ctrl(hc[CTRL_ERROR]);
   occupied_known = hc[CTRL_OCCUPIED];
   const uint64_t spilled = ((uint64_t)hc[CTRL_SPILL_HI] << 32) | hc[CTRL_SPILL_LO];
+  uint64_t passed_total = 0;
+  if (getenv("DFX_DEBUG") && stats) {  // statistics stripes (debug only: one more synchronous copy)
+    std::vector<uint64_t> hs((size_t)kStatStripes * STAT_WORDS);
+    (void)hipMemcpy(hs.data(), stats.get(), sizeof(uint64_t) * hs.size(), hipMemcpyDeviceToHost);
+    for (int i = 0; i < kStatStripes; ++i) passed_total += hs[(size_t)i * STAT_WORDS + STAT_PASSED];
+  }
   if (getenv("DFX_DEBUG"))
     fprintf(stderr, "[dfx] batch n=%lld partition=%d lds=%d occupied=%u spilled=%llu saturated=%u passed=%llu cap=%llu "
             "parts=%u cap_rows=%u stage=%u spillcap=%llu\n", (long long)n, (int)use_partition, (int)lds_enabled,
             hc[CTRL_OCCUPIED], (unsigned long long)spilled, hc[CTRL_SATURATED],
-            (unsigned long long)(((uint64_t)hc[CTRL_PASSED_HI] << 32) | hc[CTRL_PASSED_LO]),
+            (unsigned long long)passed_total,
             (unsigned long long)(T.mask + 1), PT.n_parts, PT.cap_rows, PT.stage_rows, (unsigned long long)spill.capacity);
   if (spilled > 0 || hc[CTRL_SATURATED] || occupied_known > T.load_limit) {
     // later batches may already be running against the saturated table: let them finish, then rebuild
@@ -551,7 +562,7 @@ Status AggregateRelation::Impl::consume_batch(const DeviceBatch& b) {
     if (!agg_options().fast) fp.valid = 0;
     DFX_HIP(launch_reduce(prog, fp, cols, plan, T, n, (uint64_t*)partial.get(), (uint32_t*)ctrl.get(), bytes, s));
     DFX_HIP(launch_reduce_fold(T, (const uint8_t*)dev_arg_dtype.get(), (const uint8_t*)dev_func.get(),
-                               (uint64_t*)partial.get(), (uint64_t*)state.get(), s));
+                               (uint64_t*)partial.get(), (uint64_t*)state.get(), (uint32_t*)ctrl.get(), s));
     rows_seen += n;
     return Status::OK();
   }
@@ -745,7 +756,7 @@ Status AggregateRelation::Impl::drain() {
       T.val_xform[a] = val_xform[a];
       T.acc_init[a] = acc_init[a];
     }
-    partial = device_alloc(sizeof(uint64_t) * 4 * kMaxAggs, &st);
+    partial = device_alloc(sizeof(uint64_t) * kReduceSlots * kReduceSlotWords, &st);
     if (!partial) return st;
     state = device_alloc(sizeof(uint64_t) * 2 * kMaxAggs, &st);
     if (!state) return st;
@@ -755,18 +766,20 @@ Status AggregateRelation::Impl::drain() {
     if (!dev_arg_dtype) return st;
     dev_func = device_alloc(kMaxAggs, &st);
     if (!dev_func) return st;
-    uint64_t hp[4 * kMaxAggs];
+    std::vector<uint64_t> hpv((size_t)kReduceSlots * kReduceSlotWords, 0);
+    uint64_t* hp = hpv.data();
     uint8_t hd[kMaxAggs], hf[kMaxAggs];
-    memset(hp, 0, sizeof(hp));
     memset(hd, 0, sizeof(hd));
     memset(hf, 0, sizeof(hf));
     for (int a = 0; a < na; ++a) {
-      hp[4 * a] = acc_init[a];
-      hp[4 * a + 2] = ~0ull;
+      for (int sl = 0; sl < kReduceSlots; ++sl) {
+        hp[(size_t)sl * kReduceSlotWords + 4 * a] = acc_init[a];
+        hp[(size_t)sl * kReduceSlotWords + 4 * a + 2] = ~0ull;
+      }
       hd[a] = (uint8_t)arg_dtype[a];
       hf[a] = (uint8_t)func[a];
     }
-    DFX_HIP(hipMemcpyAsync(partial.get(), hp, sizeof(hp), hipMemcpyHostToDevice, s));
+    DFX_HIP(hipMemcpyAsync(partial.get(), hp, sizeof(uint64_t) * hpv.size(), hipMemcpyHostToDevice, s));
     DFX_HIP(hipMemcpyAsync(dev_arg_dtype.get(), hd, sizeof(hd), hipMemcpyHostToDevice, s));
     DFX_HIP(hipMemcpyAsync(dev_func.get(), hf, sizeof(hf), hipMemcpyHostToDevice, s));
     DFX_HIP(hipMemsetAsync(state.get(), 0, sizeof(uint64_t) * 2 * kMaxAggs, s));

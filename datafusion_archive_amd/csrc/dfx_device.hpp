@@ -120,6 +120,12 @@ enum : uint8_t {
 
 constexpr uint64_t kEmptyKey = 0x8000000000000000ull;  // single-word key claim sentinel
 
+// ungrouped aggregates: every workgroup of K5 adds its result to one of kReduceSlots copies of the batch
+// partial (slot = workgroup index mod kReduceSlots) -- thousands of agent-scope atomics on ONE address
+// serialise at ~11 ns each; the fold kernel combines the copies
+constexpr int kReduceSlots = 64;
+constexpr int kReduceSlotWords = 4 * kMaxAggs;  // per aggregate: accumulator, valid count, first-valid tag, (a == 0: rows passed)
+
 // control block words (uint32) of a group table / reduction
 enum : int {
   CTRL_OCCUPIED = 0,    // groups in the table
@@ -135,11 +141,16 @@ enum : int {
   CTRL_WORDS = 16
 };
 
+constexpr int kStatStripes = 64;
+enum : int { STAT_PASSED = 0, STAT_LDS_HIT = 1, STAT_LDS_MISS = 2, STAT_WORDS = 8 };
+
 struct DevTable {
   uint64_t* keys;      // kw planes of `stride` words; plane 0 doubles as the claim word when kw == 1
   uint64_t* accs;      // na planes of `stride` words, pre-filled with the identity
   uint32_t* state;     // kw > 1: claim state per slot (0 empty, 1 busy, 2 ready); else nullptr
   uint32_t* ctrl;      // CTRL_WORDS words
+  uint64_t* stats;     // [kStatStripes][STAT_WORDS] statistics counters (may be null), striped by workgroup:
+                       // thousands of atomics on ONE address serialise at ~11 ns each on MI355X
   uint64_t stride;     // cap + 64 (slot `cap` is reserved for the kEmptyKey group)
   uint64_t mask;       // cap - 1
   int32_t shift;       // 64 - log2(cap): slot = hash >> shift

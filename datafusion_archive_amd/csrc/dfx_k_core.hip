@@ -291,13 +291,30 @@ __global__ __launch_bounds__(kBlock) void k_project(const DevProgram P, const De
 // func: 0 min, 1 max, 2 sum, 3 count.  state[2a] = has, state[2a+1] = value bits (canonical).
 __global__ void k_reduce_fold(const DevTable T, const uint8_t* __restrict__ arg_dtype,
                               const uint8_t* __restrict__ func, uint64_t* __restrict__ partial,
-                              uint64_t* __restrict__ state) {
+                              uint64_t* __restrict__ state, uint32_t* __restrict__ ctrl) {
   const int a = threadIdx.x;
+  if (a == 0) {  // rows that passed the predicate (statistic)
+    uint64_t passed = 0;
+    for (int sl = 0; sl < kReduceSlots; ++sl) {
+      passed += partial[(size_t)sl * kReduceSlotWords + 3];
+      partial[(size_t)sl * kReduceSlotWords + 3] = 0;
+    }
+    if (passed && T.stats) atomicAdd((unsigned long long*)&T.stats[STAT_PASSED], (unsigned long long)passed);
+  }
   if (a >= T.na) return;
-  const uint64_t accw = partial[4 * a + 0], cnt = partial[4 * a + 1], first = partial[4 * a + 2];
-  partial[4 * a + 0] = T.acc_init[a];
-  partial[4 * a + 1] = 0;
-  partial[4 * a + 2] = ~0ull;
+  // combine the kReduceSlots copies (all three words are associative and commutative), re-arm them
+  uint64_t accw = T.acc_init[a], cnt = 0, first = ~0ull;
+  for (int sl = 0; sl < kReduceSlots; ++sl) {
+    uint64_t* p = partial + (size_t)sl * kReduceSlotWords;
+    if (p[4 * a + 1]) {
+      accw = cnt ? acc_combine(T.acc_kind[a], accw, p[4 * a + 0]) : p[4 * a + 0];
+      cnt += p[4 * a + 1];
+      first = p[4 * a + 2] < first ? p[4 * a + 2] : first;
+    }
+    p[4 * a + 0] = T.acc_init[a];
+    p[4 * a + 1] = 0;
+    p[4 * a + 2] = ~0ull;
+  }
   const uint8_t t = arg_dtype[a], f = func[a];
   bool has = cnt != 0;
   uint64_t val = accw;
@@ -583,8 +600,8 @@ hipError_t launch_project(const DevProgram& P, const DevColumns& C, const DevPro
 }
 
 hipError_t launch_reduce_fold(const DevTable& T, const uint8_t* arg_dtype, const uint8_t* func,
-                              uint64_t* partial, uint64_t* state, hipStream_t s) {
-  hipLaunchKernelGGL(k_reduce_fold, dim3(1), dim3(64), 0, s, T, arg_dtype, func, partial, state);
+                              uint64_t* partial, uint64_t* state, uint32_t* ctrl, hipStream_t s) {
+  hipLaunchKernelGGL(k_reduce_fold, dim3(1), dim3(64), 0, s, T, arg_dtype, func, partial, state, ctrl);
   return hipGetLastError();
 }
 

@@ -121,7 +121,7 @@ __global__ __launch_bounds__(kPBlock) void k_partition(const DevProgram P, const
   }
 #pragma unroll
   for (int mm = 32; mm >= 1; mm >>= 1) passed += shfl_xor_u64(passed, mm);
-  if (lane == 0 && passed) atomicAdd((unsigned long long*)&T.ctrl[CTRL_PASSED_LO], (unsigned long long)passed);
+  if (lane == 0) stat_add(T, STAT_PASSED, passed);
   if (err) atomicOr(&T.ctrl[CTRL_ERROR], err);
 }
 
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(BLOCK) void k_partition_sorted(const DevProgram P, 
   }
 #pragma unroll
   for (int mm = 32; mm >= 1; mm >>= 1) passed += shfl_xor_u64(passed, mm);
-  if (lane == 0 && passed) atomicAdd((unsigned long long*)&T.ctrl[CTRL_PASSED_LO], (unsigned long long)passed);
+  if (lane == 0) stat_add(T, STAT_PASSED, passed);
   if (err) atomicOr(&T.ctrl[CTRL_ERROR], err);
 }
 
@@ -612,7 +612,7 @@ __global__ __launch_bounds__(kRingBlock) void k_partition_ring(const DevProgram 
   }
 #pragma unroll
   for (int mm = 32; mm >= 1; mm >>= 1) passed += shfl_xor_u64(passed, mm);
-  if (lane == 0 && passed) atomicAdd((unsigned long long*)&T.ctrl[CTRL_PASSED_LO], (unsigned long long)passed);
+  if (lane == 0) stat_add(T, STAT_PASSED, passed);
   if (err) atomicOr(&T.ctrl[CTRL_ERROR], err);
 }
 

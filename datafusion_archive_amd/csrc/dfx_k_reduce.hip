@@ -6,9 +6,10 @@ namespace dfx {
 // ---------------------------------------------------------------------------------------------
 // K5 reduce_all (ungrouped aggregates of one batch)
 // ---------------------------------------------------------------------------------------------
-// partial layout per aggregate a: partial[4a+0] accumulator word (pre-filled with the identity),
-// [4a+1] number of valid arguments, [4a+2] min over (row << 1 | is_nan) of valid rows (u64::MAX
-// when none): arrow 0.12 min/max scan with `<` / `>`, so a NaN in the first valid slot sticks.
+// partial layout (kReduceSlots copies, see dfx_device.hpp) per aggregate a: [4a+0] accumulator word (pre-filled
+// with the identity), [4a+1] number of valid arguments, [4a+2] min over (row << 1 | is_nan) of valid rows
+// (u64::MAX when none): arrow 0.12 min/max scan with `<` / `>`, so a NaN in the first valid slot sticks;
+// word [3] of a copy counts the rows that passed the predicate.
 template <typename POL, int NAMAX>
 __global__ __launch_bounds__(kBlock) void k_reduce(const DevProgram P, const DevFastPlan F, const DevColumns C,
                                                    const DevAggPlan plan, const DevTable T,
@@ -38,12 +39,7 @@ __global__ __launch_bounds__(kBlock) void k_reduce(const DevProgram P, const Dev
       const int64_t row = (w0 + u) * 64 + lane;
       POL::load(P, C, row, row < n, col[u], cv[u]);
     }
-#pragma nounroll
-    for (int uu = 0; uu < U; ++uu) {
-      COLV cur;
-      uint32_t curv;
-      DFX_SELECT_BANK(uu, col, cv, cur, curv)
-      const int64_t row = (w0 + uu) * 64 + lane;
+    auto body = [&](const COLV& cur, const uint32_t curv, const int64_t row) {
       const bool inb = row < n;
       u64x16 reg;
       uint32_t rv = 0;
@@ -72,6 +68,20 @@ __global__ __launch_bounds__(kBlock) void k_reduce(const DevProgram P, const Dev
             }
           }
         }
+      }
+    };
+    if constexpr (POL::kStaticNa > 0) {
+      // compile-time shapes: the per-group code is a handful of instructions -- unroll it (the run-time
+      // bank select below costs more scalar branches than the work itself)
+      FOR_U body(col[u], cv[u], (w0 + u) * 64 + lane);
+    } else {
+      // ONE copy of the (large) generic evaluation code: a run-time loop over the U prefetched row-groups
+#pragma nounroll
+      for (int uu = 0; uu < U; ++uu) {
+        COLV cur;
+        uint32_t curv;
+        DFX_SELECT_BANK(uu, col, cv, cur, curv)
+        body(cur, curv, (w0 + uu) * 64 + lane);
       }
     }
   }
@@ -104,13 +114,15 @@ __global__ __launch_bounds__(kBlock) void k_reduce(const DevProgram P, const Dev
       c += lds[w][a * 3 + 1];
       f = lds[w][a * 3 + 2] < f ? lds[w][a * 3 + 2] : f;
     }
+    uint64_t* mine = partial + (size_t)(blockIdx.x % kReduceSlots) * kReduceSlotWords;
     if (c) {
-      acc_atomic(T.acc_kind[a], &partial[4 * a + 0], x);
-      atomicAdd((unsigned long long*)&partial[4 * a + 1], (unsigned long long)c);
-      atomicMin((unsigned long long*)&partial[4 * a + 2], (unsigned long long)f);
+      acc_atomic(T.acc_kind[a], &mine[4 * a + 0], x);
+      atomicAdd((unsigned long long*)&mine[4 * a + 1], (unsigned long long)c);
+      atomicMin((unsigned long long*)&mine[4 * a + 2], (unsigned long long)f);
     }
   }
-  if (lane == 0 && passed) atomicAdd((unsigned long long*)&ctrl[CTRL_PASSED_LO], (unsigned long long)passed);
+  if (lane == 0 && passed)
+    atomicAdd((unsigned long long*)&partial[(size_t)(blockIdx.x % kReduceSlots) * kReduceSlotWords + 3], (unsigned long long)passed);
   if (err) atomicOr(&ctrl[CTRL_ERROR], err);
 }
 

@@ -89,7 +89,8 @@ __global__ __launch_bounds__(kBlock) void k_hash_agg(const DevProgram P, const D
       // ---- LDS front cache ----
       if (S > 0 && todo && !(KW == 1 && key[0] == kEmptyKey)) {
         const uint64_t h = hash_keys<KW>(key);
-        int slot = sub_base + (int)(h & (uint64_t)(sub_slots - 1));
+        // the 32 hash bits live in the HIGH half of h; the table slot takes its top bits, the cache its low ones
+        int slot = sub_base + (int)((h >> 32) & (uint64_t)(sub_slots - 1));
         int found = -1;
         if (KW == 1) {
           for (int p = 0; p < 4 && found < 0; ++p) {
@@ -187,9 +188,9 @@ __global__ __launch_bounds__(kBlock) void k_hash_agg(const DevProgram P, const D
     lds_miss += __shfl_xor(lds_miss, m, 64);
   }
   if (lane == 0) {
-    if (passed) atomicAdd((unsigned long long*)&T.ctrl[CTRL_PASSED_LO], (unsigned long long)passed);
-    if (lds_hit) atomicAdd(&T.ctrl[CTRL_LDS_HIT], lds_hit);
-    if (lds_miss) atomicAdd(&T.ctrl[CTRL_LDS_MISS], lds_miss);
+    stat_add(T, STAT_PASSED, passed);
+    stat_add(T, STAT_LDS_HIT, lds_hit);
+    stat_add(T, STAT_LDS_MISS, lds_miss);
   }
   if (err) atomicOr(&T.ctrl[CTRL_ERROR], err);
 }

@@ -76,7 +76,7 @@ hipError_t launch_reduce(const DevProgram& P, const DevFastPlan& fast, const Dev
                          const DevTable& T /* kinds / xforms / inits only */, int64_t n,
                          uint64_t* partial, uint32_t* ctrl, double algo_bytes, hipStream_t s);
 hipError_t launch_reduce_fold(const DevTable& T, const uint8_t* arg_dtype, const uint8_t* func,
-                              uint64_t* partial, uint64_t* state, hipStream_t s);
+                              uint64_t* partial, uint64_t* state, uint32_t* ctrl, hipStream_t s);
 
 // K6/K7 hash_agg: (optional predicate) + group keys + aggregate arguments -> table updates, with
 // an LDS front cache per workgroup and a spill list for rows the table cannot take.

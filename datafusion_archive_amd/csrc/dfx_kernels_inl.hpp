@@ -689,6 +689,11 @@ DEV void spill_row(const DevTable& T, const DevRows& spill, bool do_spill, const
   }
 }
 
+// statistics counter of this workgroup's stripe (see DevTable::stats)
+DEV void stat_add(const DevTable& T, int which, uint64_t v) {
+  if (T.stats && v) atomicAdd((unsigned long long*)&T.stats[(size_t)(blockIdx.x % kStatStripes) * STAT_WORDS + which], (unsigned long long)v);
+}
+
 // the group whose (single-word) key equals the claim sentinel lives in slot `cap`: the slice of table_apply<1>
 // that such a row takes, as a small function of its own (the partition kernels call it from unrolled loops)
 DEV void sentinel_apply(const DevTable& T, const uint64_t (&val)[kMaxAggs]) {
