@@ -71,6 +71,7 @@ struct AggregateRelation::Impl {
   std::shared_ptr<void> spill_owner;
   bool lds_enabled = true;
   bool lds_calibrated = false;
+  bool calibrating = false;     // the launch in progress is the calibration slice
   bool use_partition = false;   // strategy 3: route rows to table blocks, aggregate blocks in LDS
   DevPartition PT;
   std::shared_ptr<void> pt_rows, pt_counts;
@@ -517,6 +518,7 @@ Status AggregateRelation::Impl::launch_rows(const DeviceBatch& b, const DevProgr
   if (lds_enabled && agg_options().strategy != 1) {
     const AggOptions& o = agg_options();
     int slots = o.lds_slots >= 0 ? o.lds_slots : 4096;
+    if (calibrating && o.lds_slots < 0) slots = 512;  // calibration slice: the cache only has to tell few groups from many
     while (slots > 64 && (size_t)slots * ((size_t)(kw + na) * 8 + (kw > 1 ? 4 : 0)) > 64 * 1024) slots >>= 1;
     int copies = o.lds_copies > 0 ? o.lds_copies : 1;
     if (o.lds_copies <= 0 && lds_calibrated) {  // few groups: lane-replicated sub-tables
@@ -578,7 +580,10 @@ Status AggregateRelation::Impl::consume_batch(const DeviceBatch& b) {
     // calibration slice: measure the LDS front-cache hit rate and the group count on the first
     // 2^18 rows before committing the rest of the stream to a strategy
     const int64_t n0 = 1 << 18;
-    DFX_RETURN_IF_ERROR(launch_rows(b, prog, cols, 0, n0));
+    calibrating = true;
+    Status cst = launch_rows(b, prog, cols, 0, n0);
+    calibrating = false;
+    DFX_RETURN_IF_ERROR(cst);
     uint32_t hc[CTRL_WORDS];
     DFX_RETURN_IF_ERROR(read_ctrl(hc));
     // strategy from the number of groups the calibration slice produced: the LDS front cache pays

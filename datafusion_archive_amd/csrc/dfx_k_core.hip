@@ -292,29 +292,38 @@ __global__ __launch_bounds__(kBlock) void k_project(const DevProgram P, const De
 __global__ void k_reduce_fold(const DevTable T, const uint8_t* __restrict__ arg_dtype,
                               const uint8_t* __restrict__ func, uint64_t* __restrict__ partial,
                               uint64_t* __restrict__ state, uint32_t* __restrict__ ctrl) {
-  const int a = threadIdx.x;
-  if (a == 0) {  // rows that passed the predicate (statistic)
-    uint64_t passed = 0;
-    for (int sl = 0; sl < kReduceSlots; ++sl) {
-      passed += partial[(size_t)sl * kReduceSlotWords + 3];
-      partial[(size_t)sl * kReduceSlotWords + 3] = 0;
+  // one wave: lane = copy of the batch partial (kReduceSlots == 64).  Combine the copies per aggregate with a
+  // shuffle tree (all three words are associative and commutative), re-arm them; lane a then folds aggregate a.
+  static_assert(kReduceSlots == 64, "one lane per partial copy");
+  const int lane = threadIdx.x;
+  uint64_t* mine = partial + (size_t)lane * kReduceSlotWords;
+  uint64_t passed = mine[3];
+  mine[3] = 0;
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) passed += shfl_xor_u64(passed, m);
+  if (lane == 0 && passed && T.stats) atomicAdd((unsigned long long*)&T.stats[STAT_PASSED], (unsigned long long)passed);
+  (void)ctrl;
+  uint64_t accw = 0, cnt = 0, first = ~0ull;
+  for (int a = 0; a < T.na; ++a) {
+    uint64_t x = mine[4 * a + 0], c = mine[4 * a + 1], f1 = mine[4 * a + 2];
+    mine[4 * a + 0] = T.acc_init[a];
+    mine[4 * a + 1] = 0;
+    mine[4 * a + 2] = ~0ull;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+      const uint64_t ox = shfl_xor_u64(x, m), oc = shfl_xor_u64(c, m), of = shfl_xor_u64(f1, m);
+      if (oc) x = c ? acc_combine(T.acc_kind[a], x, ox) : ox;  // copies without valid rows hold the identity
+      c += oc;
+      f1 = of < f1 ? of : f1;
     }
-    if (passed && T.stats) atomicAdd((unsigned long long*)&T.stats[STAT_PASSED], (unsigned long long)passed);
+    if (lane == a) {
+      accw = x;
+      cnt = c;
+      first = f1;
+    }
   }
+  const int a = lane;
   if (a >= T.na) return;
-  // combine the kReduceSlots copies (all three words are associative and commutative), re-arm them
-  uint64_t accw = T.acc_init[a], cnt = 0, first = ~0ull;
-  for (int sl = 0; sl < kReduceSlots; ++sl) {
-    uint64_t* p = partial + (size_t)sl * kReduceSlotWords;
-    if (p[4 * a + 1]) {
-      accw = cnt ? acc_combine(T.acc_kind[a], accw, p[4 * a + 0]) : p[4 * a + 0];
-      cnt += p[4 * a + 1];
-      first = p[4 * a + 2] < first ? p[4 * a + 2] : first;
-    }
-    p[4 * a + 0] = T.acc_init[a];
-    p[4 * a + 1] = 0;
-    p[4 * a + 2] = ~0ull;
-  }
   const uint8_t t = arg_dtype[a], f = func[a];
   bool has = cnt != 0;
   uint64_t val = accw;

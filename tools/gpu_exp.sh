@@ -1,4 +1,4 @@
 #!/bin/bash
-for wl in q1 cfg3 cfg2 headline; do python tools/prof_query.py $wl 268435456 3 2>&1 | tail -1; done
-python tools/prof_query.py headline 268435456 3 agg.strategy=1 2>&1 | tail -1; python tools/prof_query.py headline 268435456 3 agg.strategy=2 2>&1 | tail -1
-timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -x --timeout 300 -k "grouped" 2>&1 | tail -3
+mkdir -p gpurun_out
+timeout 1500 python -m pytest tests -m gpu -q -x --timeout 600 > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -n 4 gpurun_out/pytest_gpu.log
+bash tools/gpu_profile_bench.sh 2>&1 | tail -9 | cut -c1-250
