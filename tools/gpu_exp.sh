@@ -1,4 +1,3 @@
 #!/bin/bash
-mkdir -p gpurun_out
-timeout 1500 python -m pytest tests -m gpu -q -x --timeout 600 > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -n 4 gpurun_out/pytest_gpu.log
-bash tools/gpu_profile_bench.sh 2>&1 | tail -9 | cut -c1-250
+for rep in 1 2; do for b in 67108864 134217728; do python bench.py --no-cpu-baseline --no-extras --batch-rows $b --steps 8 2>&1 | tail -1 | python -c "
+import sys,json; d=json.loads(sys.stdin.read()); k=d['extra']['kernels']; print(d['config']['batch_rows'], round(d['value']/1e9,1), round(d['ms_per_step'],3), d['roofline']['frac'], 'kernel_ms_per_step', round(sum(v['total_ms'] for v in k.values())/d['steps'],3))"; done; done
