@@ -618,6 +618,27 @@ def test_device_partial_exchange_emulated_ranks(world, strategy):
         assert min(sizes) > 0.5 * max(sizes), f"owner hash is badly balanced: {sizes}"
 
 
+def test_c_abi_consumer_in_plain_c(tmp_path):
+    """tests/c_abi/smoke.c: a gcc-built C program drives the whole query through include/dfx.h (what the
+    Rust shim of INTEGRATION.md does); its result equals the oracle's."""
+    import subprocess
+    from test_host_logic import _build_c_abi_smoke
+    exe = _build_c_abi_smoke(tmp_path)
+    n, groups = 1000000, 5000.0
+    r = subprocess.run([exe, str(n), str(groups)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.startswith("OK"), r.stdout + r.stderr
+    got = dict(kv.split("=") for kv in r.stdout.split()[1:])
+    syn = [("k", ex.SYNTH_I64_UNIFORM, 0, groups, 0.0), ("v", ex.SYNTH_F64_EXACT, 1, 0.0, 0.0)]
+    ob = oracle.synth_batch(syn, 0xDF02, 0, n)
+    pred = BinaryExpr(BinaryExpr(Column(1), Operator.Gt, lit(204.8)), Operator.And,
+                      BinaryExpr(Column(1), Operator.Lt, lit(409.6)))
+    want = oracle.aggregate([Column(0)], [agg("sum", Column(1), F64), agg("count", Column(1), DataType.UInt64)],
+                            [oracle.filter_next(pred, ob)])
+    assert int(got["groups"]) == want.num_rows
+    assert float(got["sum"]) == float(np.sum(want.column(1).to_numpy()))
+    assert int(got["rows_passing"]) == int(np.sum(want.column(2).to_numpy()))
+
+
 def test_large_properties_filter_groupby_sum():
     """2^28 rows (4 GB): sum over groups of SUM(v) == ungrouped SUM(v) bit for bit (exact data),
     sum of COUNTs == rows passing the predicate == ungrouped COUNT."""

@@ -114,3 +114,28 @@ def test_consumed_relation_cannot_be_pulled():
     ex.ProjectRelation(src, [ex.compile_scalar_expr(None, Column(1), SCHEMA)], None)
     with pytest.raises(ex.ExecutionError):
         src.next()
+
+
+def _build_c_abi_smoke(tmp_path):
+    """gcc-compile the plain-C consumer of include/dfx.h against the built library (no Python, no torch)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "datafusion_archive_amd", "lib")
+    exe = os.path.join(str(tmp_path), "smoke")
+    subprocess.run(["gcc", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(root, "include"),
+                    os.path.join(root, "tests", "c_abi", "smoke.c"), "-L", libdir, "-ldfx_hip",
+                    "-Wl,-rpath," + libdir, "-o", exe], check=True)
+    return exe
+
+
+def test_c_abi_header_compiles_as_c_and_fails_loudly_without_gpu(tmp_path):
+    """include/dfx.h is valid C11, a C program links against the library, and on a machine without a GPU the
+    very first call reports an error instead of falling back to a CPU path."""
+    import subprocess
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("needs a machine without a GPU")
+    exe = _build_c_abi_smoke(tmp_path)
+    r = subprocess.run([exe, "1000", "10"], capture_output=True, text=True)
+    assert r.returncode != 0 and r.stdout.startswith("ERR"), r.stdout + r.stderr
+    assert "no CPU" in r.stdout or "HIP" in r.stdout, r.stdout
