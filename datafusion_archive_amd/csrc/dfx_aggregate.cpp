@@ -52,6 +52,15 @@ struct AggregateRelation::Impl {
   SchemaInfo bind_schema;                  // input schema + the virtual id columns (what the program binds to)
   std::vector<dfx_runtime_expr> group_rw;  // GROUP BY expressions with Utf8 columns redirected to their id columns
   std::vector<int> key_out_dtype;          // result type of each key column (DFX_UTF8 for dictionary keys)
+  // result aggregates -> accumulators: AVG(x) is the pair SUM(x), COUNT(x) of consecutive accumulators, divided at
+  // emit time (deviation D7).  `aggr` holds the ACCUMULATOR expressions (AVG already expanded), `outs` the results.
+  struct OutAgg {
+    int acc = 0;
+    bool avg = false;
+    int dtype = 0;
+    std::string name;
+  };
+  std::vector<OutAgg> outs;
   std::unique_ptr<ProgramBuilder> builder;
   DevAggPlan plan;
   DevFastPlan fast;
@@ -829,19 +838,26 @@ Status AggregateRelation::Impl::emit_ungrouped(DeviceBatch* out) {  // aggregate
   DFX_HIP(hipMemcpy(hs, state.get(), sizeof(hs), hipMemcpyDeviceToHost));
   out->num_rows = 1;
   out->columns.clear();
-  out->columns.resize(na);
-  for (int a = 0; a < na; ++a) {
-    DeviceColumn& c = out->columns[a];
-    c.dtype = out_dtype[a];
+  out->columns.resize(outs.size());
+  for (size_t j = 0; j < outs.size(); ++j) {
+    const int a = outs[j].acc;
+    DeviceColumn& c = out->columns[j];
+    c.dtype = outs[j].avg ? outs[j].dtype : out_dtype[a];
     c.length = 1;
     uint64_t bits = hs[2 * a + 1];
+    bool has_value = hs[2 * a] != 0;
+    if (outs[j].avg) {  // SUM / COUNT (deviation D7); None when nothing was counted
+      const uint64_t cntv = hs[2 * (a + 1)] ? hs[2 * (a + 1) + 1] : 0;
+      has_value = has_value && cntv != 0;
+      bits = has_value ? host_avg_value((uint8_t)outs[j].dtype, bits, cntv) : 0;
+    }
     uint8_t raw[8];
     memcpy(raw, &bits, 8);  // little endian: the low bytes are the narrow value
     std::shared_ptr<void> dv, dn;
     DFX_RETURN_IF_ERROR(upload_small(raw, 8, &dv));
     c.values = dv.get();
     c.owners.push_back(dv);
-    const bool has = hs[2 * a] != 0;
+    const bool has = has_value;
     uint8_t vb[8] = {(uint8_t)(has ? 1 : 0), 0, 0, 0, 0, 0, 0, 0};
     DFX_RETURN_IF_ERROR(upload_small(vb, 8, &dn));
     c.validity = (const uint8_t*)dn.get();
@@ -875,29 +891,64 @@ Status AggregateRelation::Impl::emit_grouped(DeviceBatch* out) {  // aggregate.r
   const int64_t g = (int64_t)total;
   out->num_rows = g;
   out->columns.clear();
-  out->columns.resize(kw + na);
+  out->columns.resize((size_t)kw + outs.size());
   auto dense = device_alloc(sizeof(uint64_t) * (size_t)std::max<int64_t>(g, 1), &st);
   if (!dense) return st;
   // the sentinel group's key word is not stored in the table: patch slot `cap` before compaction
   if (kw == 1) DFX_HIP(launch_fill_u64(T.keys + T.mask + 1, kEmptyKey, 1, s));
-  for (int k = 0; k < kw + na; ++k) {
-    const bool is_key = k < kw;
-    const uint64_t* plane = is_key ? T.keys + (size_t)k * T.stride : T.accs + (size_t)(k - kw) * T.stride;
-    const int dt = is_key ? key_dtype[k] : out_dtype[k - kw];
+  for (int k = 0; k < kw; ++k) {
+    const uint64_t* plane = T.keys + (size_t)k * T.stride;
+    const int dt = key_dtype[k];
     DeviceColumn& c = out->columns[k];
     c.dtype = dt;
     c.length = g;
-    auto vals = device_alloc((size_t)std::max<int64_t>(g, 1) * dtype_width(dt), &st);
-    if (!vals) return st;
     DFX_HIP(launch_compact(plane, 8, (const uint64_t*)mask.get(), (const uint64_t*)offsets.get(), n_slots, dense.get(), 0, s));
     const DictKey* dk = nullptr;
     for (const DictKey& d : dicts)
-      if (is_key && d.key == k) dk = &d;
+      if (d.key == k) dk = &d;
     if (dk) {  // ids -> Arrow Utf8
       DFX_RETURN_IF_ERROR(dict_emit(*dk, (const uint64_t*)dense.get(), g, &c));
       continue;
     }
-    DFX_HIP(launch_finalize((const uint64_t*)dense.get(), g, (uint8_t)dt, is_key ? (uint8_t)VT_RAW : val_xform[k - kw], vals.get(), s));
+    auto vals = device_alloc((size_t)std::max<int64_t>(g, 1) * dtype_width(dt), &st);
+    if (!vals) return st;
+    DFX_HIP(launch_finalize((const uint64_t*)dense.get(), g, (uint8_t)dt, (uint8_t)VT_RAW, vals.get(), s));
+    c.values = vals.get();
+    c.owners.push_back(vals);
+  }
+  for (size_t j = 0; j < outs.size(); ++j) {
+    const int a = outs[j].acc;
+    const int dt = outs[j].avg ? outs[j].dtype : out_dtype[a];
+    DeviceColumn& c = out->columns[(size_t)kw + j];
+    c.dtype = dt;
+    c.length = g;
+    auto vals = device_alloc((size_t)std::max<int64_t>(g, 1) * dtype_width(dt), &st);
+    if (!vals) return st;
+    DFX_HIP(launch_compact(T.accs + (size_t)a * T.stride, 8, (const uint64_t*)mask.get(), (const uint64_t*)offsets.get(), n_slots,
+                           dense.get(), 0, s));
+    if (!outs[j].avg) {
+      DFX_HIP(launch_finalize((const uint64_t*)dense.get(), g, (uint8_t)dt, val_xform[a], vals.get(), s));
+    } else {  // SUM plane / COUNT plane (deviation D7); groups that counted nothing are null
+      auto dense_cnt = device_alloc(sizeof(uint64_t) * (size_t)std::max<int64_t>(g, 1), &st);
+      if (!dense_cnt) return st;
+      auto valid = device_alloc(sizeof(uint64_t) * (size_t)((g + 63) / 64 + 1), &st);
+      if (!valid) return st;
+      auto nulls = device_alloc(sizeof(uint64_t), &st);
+      if (!nulls) return st;
+      DFX_HIP(hipMemsetAsync(nulls.get(), 0, sizeof(uint64_t), s));
+      DFX_HIP(launch_compact(T.accs + (size_t)(a + 1) * T.stride, 8, (const uint64_t*)mask.get(), (const uint64_t*)offsets.get(),
+                             n_slots, dense_cnt.get(), 0, s));
+      DFX_HIP(launch_finalize_avg((const uint64_t*)dense.get(), (const uint64_t*)dense_cnt.get(), g, (uint8_t)dt, vals.get(),
+                                  (uint64_t*)valid.get(), (uint64_t*)nulls.get(), s));
+      uint64_t n_null = 0;
+      DFX_HIP(hipMemcpyAsync(&n_null, nulls.get(), sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+      DFX_HIP(hipStreamSynchronize(s));
+      if (n_null) {
+        c.validity = (const uint8_t*)valid.get();
+        c.null_count = (int64_t)n_null;
+        c.owners.push_back(valid);
+      }
+    }
     c.values = vals.get();
     c.owners.push_back(vals);
   }
@@ -911,7 +962,24 @@ AggregateRelation::AggregateRelation(SchemaInfo schema, std::unique_ptr<Relation
     : schema_(std::move(schema)), impl_(new Impl()) {
   Impl& m = *impl_;
   m.group = std::move(group);
-  m.aggr = std::move(aggr);
+  for (const dfx_runtime_expr& e : aggr) {  // AVG(x) -> SUM(x), COUNT(x)
+    Impl::OutAgg o;
+    o.acc = (int)m.aggr.size();
+    o.avg = e.is_aggregate && e.agg_func == AGG_AVG;
+    o.dtype = e.agg_func == AGG_COUNT ? (int)DFX_UINT64 : e.agg_type;
+    o.name = e.name;
+    m.outs.push_back(o);
+    if (o.avg) {
+      dfx_runtime_expr sum = e, cnt = e;
+      sum.agg_func = AGG_SUM;
+      cnt.agg_func = AGG_COUNT;
+      cnt.agg_type = DFX_UINT64;
+      m.aggr.push_back(sum);
+      m.aggr.push_back(cnt);
+    } else {
+      m.aggr.push_back(e);
+    }
+  }
   // Filter -> Aggregate fusion (K7)
   if (input->kind() == REL_FILTER) {
     FilterRelation* f = static_cast<FilterRelation*>(input.get());
@@ -934,10 +1002,10 @@ AggregateRelation::AggregateRelation(SchemaInfo schema, std::unique_ptr<Relation
     f.nullable = false;
     derived.fields.push_back(f);
   }
-  for (size_t a = 0; a < m.aggr.size(); ++a) {
+  for (const Impl::OutAgg& o : m.outs) {
     Field f;
-    f.name = m.aggr[a].name;
-    f.dtype = a < m.out_dtype.size() && m.out_dtype[a] ? m.out_dtype[a] : m.aggr[a].dtype;
+    f.name = o.name;
+    f.dtype = o.dtype;
     f.nullable = true;
     derived.fields.push_back(f);
   }

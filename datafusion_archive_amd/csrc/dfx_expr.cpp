@@ -503,6 +503,7 @@ int32_t dfx_compile_expr(const dfx_expr_node* nodes, int32_t n_nodes, int32_t ro
   else if (!strcasecmp(nm, "max")) f = AGG_MAX;
   else if (!strcasecmp(nm, "count")) f = AGG_COUNT;
   else if (!strcasecmp(nm, "sum")) f = AGG_SUM;
+  else if (!strcasecmp(nm, "avg")) f = AGG_AVG;  // deviation D7: typed by the planner (sqlplanner.rs:309-322), no executor in the reference
   if (f < 0)  // expression.rs:103-106
     return to_c(Status::Err(DFX_GENERAL, std::string("Unsupported aggregate function '") + nm + "'"), err, errlen);
   e->is_aggregate = true;

@@ -115,7 +115,7 @@ struct Relation {
 };
 
 // ---- expressions (dfx_expr.cpp) ---------------------------------------------------------------
-enum AggregateType { AGG_MIN = 0, AGG_MAX = 1, AGG_SUM = 2, AGG_COUNT = 3 };
+enum AggregateType { AGG_MIN = 0, AGG_MAX = 1, AGG_SUM = 2, AGG_COUNT = 3, AGG_AVG = 4 };
 
 }  // namespace dfx
 

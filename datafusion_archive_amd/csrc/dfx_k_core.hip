@@ -382,6 +382,62 @@ __global__ __launch_bounds__(kBlock) void k_finalize(const uint64_t* __restrict_
   }
 }
 
+// AVG = SUM / COUNT of the same argument (deviation D7: the reference's planner types AVG, its executor has none).
+// sum: the SUM accumulator word, cnt: the COUNT word; result in the argument's type: IEEE division for floats,
+// truncating division of the wrapped sum for integers; null when cnt == 0.  validity: Arrow bitmap words.
+__host__ __device__ inline uint64_t avg_value(uint8_t t, uint64_t sum, uint64_t cnt) {
+  union { uint64_t u; double d; } c64;
+  union { uint32_t u; float f; } c32;
+  if (t == T_F64) {
+    c64.u = sum;
+    c64.d = c64.d / (double)cnt;
+    return c64.u;
+  }
+  if (t == T_F32) {
+    c32.u = (uint32_t)sum;
+    c32.f = c32.f / (float)cnt;
+    return (uint64_t)c32.u;
+  }
+  // integers: the wrapped sum in the argument's width, truncating division
+  int bits = 64;
+  bool is_signed = false;
+  switch (t) {
+    case T_I8: bits = 8; is_signed = true; break;
+    case T_I16: bits = 16; is_signed = true; break;
+    case T_I32: bits = 32; is_signed = true; break;
+    case T_I64: bits = 64; is_signed = true; break;
+    case T_U8: bits = 8; break;
+    case T_U16: bits = 16; break;
+    case T_U32: bits = 32; break;
+    default: break;
+  }
+  if (is_signed) {
+    const int64_t x = bits == 64 ? (int64_t)sum : (int64_t)(sum << (64 - bits)) >> (64 - bits);
+    return (uint64_t)(x / (int64_t)cnt);
+  }
+  const uint64_t x = bits == 64 ? sum : sum & ((1ull << bits) - 1ull);
+  return x / cnt;
+}
+uint64_t host_avg_value(uint8_t t, uint64_t sum, uint64_t cnt) { return avg_value(t, sum, cnt); }
+
+__global__ __launch_bounds__(kBlock) void k_finalize_avg(const uint64_t* __restrict__ sum, const uint64_t* __restrict__ cnt,
+                                                         int64_t n, uint8_t out_dtype, void* __restrict__ out,
+                                                         uint64_t* __restrict__ validity, uint64_t* __restrict__ null_count) {
+  const int64_t n_pad = (n + 63) & ~63ll;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n_pad; i += (int64_t)gridDim.x * kBlock) {
+    const bool inb = i < n;
+    const uint64_t c = inb ? cnt[i] : 0;
+    const bool valid = inb && c != 0;
+    if (inb) store_typed(out_dtype, out, i, valid ? avg_value(out_dtype, sum[i], c) : 0ull);
+    const uint64_t vm = __ballot(valid), im = __ballot(inb);
+    if (lane_id() == 0) {
+      validity[i >> 6] = vm;
+      const int nulls = __popcll(im & ~vm);
+      if (nulls) atomicAdd((unsigned long long*)null_count, (unsigned long long)nulls);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // synthetic columns -- same definition as orc_synth_fill (oracle/dfx_oracle.c)
 // ---------------------------------------------------------------------------------------------
@@ -702,6 +758,15 @@ hipError_t launch_finalize(const uint64_t* in, int64_t n, uint8_t out_dtype, uin
   if (n <= 0) return hipSuccess;
   Scope sc(KID_FINALIZE, s, 0);
   hipLaunchKernelGGL(k_finalize, dim3(stream_grid((n + kBlock - 1) / kBlock, 8)), dim3(kBlock), 0, s, in, n, out_dtype, val_xform, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_finalize_avg(const uint64_t* sum, const uint64_t* cnt, int64_t n, uint8_t out_dtype, void* out,
+                               uint64_t* validity, uint64_t* null_count, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  Scope sc(KID_FINALIZE, s, 0);
+  hipLaunchKernelGGL(k_finalize_avg, dim3(stream_grid((n + kBlock - 1) / kBlock, 8)), dim3(kBlock), 0, s, sum, cnt, n, out_dtype, out,
+                     validity, null_count);
   return hipGetLastError();
 }
 

@@ -98,6 +98,10 @@ hipError_t launch_table_mask(const DevTable& T, uint64_t* mask_words, uint32_t* 
 // in: dense u64 plane; out: typed column. is_key: narrow only. xform/kind/func describe the agg.
 hipError_t launch_finalize(const uint64_t* in, int64_t n, uint8_t out_dtype, uint8_t val_xform,
                            void* out, hipStream_t s);
+// AVG columns: sum / count in the argument's type, validity bitmap (count == 0 -> null), null count
+hipError_t launch_finalize_avg(const uint64_t* sum, const uint64_t* cnt, int64_t n, uint8_t out_dtype, void* out,
+                               uint64_t* validity, uint64_t* null_count, hipStream_t s);
+uint64_t host_avg_value(uint8_t t, uint64_t sum, uint64_t cnt);
 
 // multi-GPU partial export: count per destination rank, then scatter into bucketed planes
 hipError_t launch_partial_count(const DevTable& T, int world, uint64_t* counts, hipStream_t s);

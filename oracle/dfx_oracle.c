@@ -22,6 +22,10 @@
  *   D3 COUNT is implemented (number of rows whose argument is valid, UInt64); the reference
  *      rejects it at run time (aggregate.rs:331-333, :723-727).  Parity unpinned.
  *   D4 the Int8 aggregate output bug (aggregate.rs:934 uses the *group* macro) is not replicated.
+ *   D7 AVG is implemented as SUM(x) / COUNT(x) of the same argument, result in the argument's type (the planner's
+ *      contract, sqlplanner.rs:309-322): IEEE division for floats, truncating division of the wrapped integer sum,
+ *      NULL when nothing was counted.  The reference's compile_expr rejects "avg" (expression.rs:98-107) although
+ *      its planner accepts it; north_star names AVG.  Parity unpinned.
  *   D5 group output order is first-appearance order; the reference's is FnvHashMap iteration order
  *      (unspecified; its own tests flag it, tests/sql.rs:47,:62).  Compare as a set.
  */
@@ -559,7 +563,7 @@ int32_t orc_project_next(const dfx_expr_node* nodes, int32_t n_nodes, const int3
 /* ------------------------------------------------------------------------------------------ */
 /* aggregate (aggregate.rs)                                                                    */
 /* ------------------------------------------------------------------------------------------ */
-enum { AGG_MIN = 0, AGG_MAX = 1, AGG_SUM = 2, AGG_COUNT = 3 };
+enum { AGG_MIN = 0, AGG_MAX = 1, AGG_SUM = 2, AGG_COUNT = 3, AGG_AVG = 4 };
 
 typedef struct { int has; val_t v; } scalar_t; /* Option<ScalarValue> of a known dtype */
 
@@ -653,6 +657,7 @@ static int agg_func_from_name(const char* name) {
   if (!strcasecmp(name, "max")) return AGG_MAX;
   if (!strcasecmp(name, "sum")) return AGG_SUM;
   if (!strcasecmp(name, "count")) return AGG_COUNT;
+  if (!strcasecmp(name, "avg")) return AGG_AVG; /* deviation D7 */
   return -1;
 }
 
@@ -671,7 +676,7 @@ int32_t orc_agg_new(const dfx_expr_node* nodes, int32_t n_nodes, const int32_t* 
   g->aggr_args = (int32_t*)calloc((size_t)n_aggr + 1, sizeof(int32_t));
   g->aggr_func = (int32_t*)calloc((size_t)n_aggr + 1, sizeof(int32_t));
   g->aggr_type = (int32_t*)calloc((size_t)n_aggr + 1, sizeof(int32_t));
-  g->acc = (scalar_t*)calloc((size_t)n_aggr + 1, sizeof(scalar_t));
+  g->acc = (scalar_t*)calloc(2 * (size_t)n_aggr + 1, sizeof(scalar_t)); /* [n_aggr + i]: AVG's count */
   for (int i = 0; i < n_aggr; ++i) {
     const dfx_expr_node* nd = &nodes[aggr_roots[i]];
     if (nd->kind != DFX_EXPR_AGGREGATE_FUNCTION) { /* create_accumulators :335-337 */
@@ -752,7 +757,7 @@ static group_entry* map_get_or_insert(orc_agg* g, uint8_t* key, size_t key_len, 
   e->key = key; /* map.insert(key.clone(), ..): takes the heap key */
   e->key_len = key_len;
   e->hash = h;
-  e->acc = (scalar_t*)calloc((size_t)g->n_aggr + 1, sizeof(scalar_t)); /* create_accumulators */
+  e->acc = (scalar_t*)calloc(2 * (size_t)g->n_aggr + 1, sizeof(scalar_t)); /* create_accumulators; [n_aggr + i]: AVG's count */
   g->slots[p] = g->n_entries++;
   *inserted = 1;
   if (g->n_entries * 2 > g->n_slots) map_grow(g);
@@ -779,8 +784,14 @@ int32_t orc_agg_push(orc_agg* g, const orc_batch* batch, char* err, size_t errle
       if (st) return fail(err, errlen, DFX_EXECUTION_ERROR, "Failed to evaluate argument to aggregate function");
       st = check_agg_type(g, i, arr, err, errlen);
       if (st) { orc_array_free(arr); return st; }
-      scalar_t s = array_reduce(g->aggr_func[i], arr);
-      accumulate_scalar(g->aggr_func[i], g->aggr_type[i], &g->acc[i], s);
+      if (g->aggr_func[i] == AGG_AVG) { /* D7: the SUM and the COUNT of the same argument */
+        scalar_t s = array_reduce(AGG_SUM, arr), c = array_reduce(AGG_COUNT, arr);
+        accumulate_scalar(AGG_SUM, g->aggr_type[i], &g->acc[i], s);
+        accumulate_scalar(AGG_COUNT, DFX_UINT64, &g->acc[g->n_aggr + i], c);
+      } else {
+        scalar_t s = array_reduce(g->aggr_func[i], arr);
+        accumulate_scalar(g->aggr_func[i], g->aggr_type[i], &g->acc[i], s);
+      }
       orc_array_free(arr);
     }
     return DFX_OK;
@@ -834,7 +845,15 @@ int32_t orc_agg_push(orc_agg* g, const orc_batch* batch, char* err, size_t errle
         s.has = 1;
         if (g->aggr_func[j] == AGG_COUNT) { s.v.u = (uint64_t)is_valid(args[j], row); }
         else s.v = load_val(args[j], row);
-        accumulate_scalar(g->aggr_func[j], g->aggr_type[j], &e->acc[j], s);
+        if (g->aggr_func[j] == AGG_AVG) { /* D7 */
+          scalar_t c;
+          c.has = 1;
+          c.v.u = (uint64_t)is_valid(args[j], row);
+          accumulate_scalar(AGG_SUM, g->aggr_type[j], &e->acc[j], s);
+          accumulate_scalar(AGG_COUNT, DFX_UINT64, &e->acc[g->n_aggr + j], c);
+        } else {
+          accumulate_scalar(g->aggr_func[j], g->aggr_type[j], &e->acc[j], s);
+        }
       }
     }
   }
@@ -847,6 +866,21 @@ int32_t orc_agg_push(orc_agg* g, const orc_batch* batch, char* err, size_t errle
 
 static int agg_out_type(const orc_agg* g, int i) { return g->aggr_func[i] == AGG_COUNT ? DFX_UINT64 : g->aggr_type[i]; }
 
+/* D7: AVG = SUM / COUNT in the argument's type: IEEE division for floats, truncating division of the (wrapped)
+ * integer sum; None when nothing was counted. */
+static scalar_t avg_finish(int dt, scalar_t sum, scalar_t cnt) {
+  scalar_t r;
+  r.has = 0;
+  r.v.u = 0;
+  if (!sum.has || !cnt.has || cnt.v.u == 0) return r;
+  r.has = 1;
+  if (dt == DFX_FLOAT64) r.v.d = sum.v.d / (double)cnt.v.u;
+  else if (dt == DFX_FLOAT32) r.v.f = sum.v.f / (float)cnt.v.u;
+  else if (dt_is_signed_int(dt)) r.v.i = wrap_int(dt, sum.v).i / (int64_t)cnt.v.u;
+  else r.v.u = wrap_int(dt, sum.v).u / cnt.v.u;
+  return r;
+}
+
 int32_t orc_agg_finish(orc_agg* g, orc_batch** out, char* err, size_t errlen) {
   orc_batch* ob = (orc_batch*)calloc(1, sizeof(orc_batch));
   ob->owned = 1;
@@ -858,7 +892,8 @@ int32_t orc_agg_finish(orc_agg* g, orc_batch** out, char* err, size_t errlen) {
       int dt = agg_out_type(g, i);
       if (!dt_is_numeric(dt)) { orc_batch_free(ob); return fail(err, errlen, DFX_NOT_IMPLEMENTED, "tbd"); }
       orc_array* a = arr_new(dt, 1, 1);
-      if (g->acc[i].has) { bit_set(a->validity, 0); store_val(a, 0, g->acc[i].v); }
+      scalar_t r = g->aggr_func[i] == AGG_AVG ? avg_finish(dt, g->acc[i], g->acc[g->n_aggr + i]) : g->acc[i];
+      if (r.has) { bit_set(a->validity, 0); store_val(a, 0, r.v); }
       ob->columns[i] = a;
     }
     *out = ob;
@@ -903,8 +938,11 @@ int32_t orc_agg_finish(orc_agg* g, orc_batch** out, char* err, size_t errlen) {
     int dt = agg_out_type(g, i);
     if (!dt_is_numeric(dt)) { orc_batch_free(ob); return fail(err, errlen, DFX_EXECUTION_ERROR, "Unsupported aggregate expr"); }
     orc_array* a = arr_new(dt, n, 1);
-    for (int64_t e = 0; e < n; ++e)
-      if (g->entries[e].acc[i].has) { bit_set(a->validity, e); store_val(a, e, g->entries[e].acc[i].v); }
+    for (int64_t e = 0; e < n; ++e) {
+      scalar_t r = g->aggr_func[i] == AGG_AVG ? avg_finish(dt, g->entries[e].acc[i], g->entries[e].acc[g->n_aggr + i])
+                                              : g->entries[e].acc[i];
+      if (r.has) { bit_set(a->validity, e); store_val(a, e, r.v); }
+    }
     ob->columns[g->n_group + i] = a;
   }
   *out = ob;

@@ -618,6 +618,48 @@ def test_device_partial_exchange_emulated_ranks(world, strategy):
         assert min(sizes) > 0.5 * max(sizes), f"owner hash is badly balanced: {sizes}"
 
 
+@pytest.mark.parametrize("strategy", [0, 1, 3])
+def test_avg_matches_oracle(strategy):
+    """AVG (deviation D7) = SUM / COUNT in the argument's type: Float64, Float32, Int64 and Int32 arguments,
+    next to other aggregates (so that accumulator indices and result columns differ), ungrouped (multi-batch,
+    nulls skipped, all-null -> NULL) and grouped under every table strategy; exact data => bit-exact."""
+    ex.set_option("agg.strategy", strategy)
+    rng = np.random.default_rng(21)
+    n = 150001
+    k = rng.integers(0, 40000 if strategy == 3 else 900, n).astype(np.int64)
+    f = rng.integers(0, 1 << 16, n).astype(np.float64) / 64.0
+    g32 = (rng.integers(0, 16, n) / 4.0).astype(np.float32)  # f32 sums stay exact (< 2^24 quarter-units)
+    i64 = rng.integers(-(1 << 30), 1 << 30, n).astype(np.int64)
+    i32 = rng.integers(-5000, 5000, n).astype(np.int32)
+    whole = pa.RecordBatch.from_arrays([pa.array(k), pa.array(f), pa.array(g32), pa.array(i64), pa.array(i32)],
+                                       names=["k", "f", "g", "i", "j"])
+    batches = [whole.slice(0, 50000), whole.slice(50000, 1), whole.slice(50001)]
+    # 8 accumulators (the limit): AVG takes two
+    aggs = [agg("max", Column(1), F64), agg("AVG", Column(1), F64), agg("avg", Column(2), DataType.Float32),
+            agg("avg", Column(3), DataType.Int64), agg("count", Column(1), DataType.UInt64)]
+    aggs2 = [agg("Avg", Column(4), DataType.Int32), agg("sum", Column(4), DataType.Int32)]
+    for ag in (aggs, aggs2):
+        got = gpu_aggregate([], ag, whole.schema, batches)
+        want = oracle.aggregate([], ag, batches)
+        assert got.schema.types == want.schema.types
+        # this data is exact in f64 and f32 (sums of quarters below 2^24), so any summation order gives the same bits
+        assert [bits(c) for c in got.columns] == [bits(c) for c in want.columns]
+        got = gpu_aggregate([Column(0)], ag, whole.schema, batches)
+        want = oracle.aggregate([Column(0)], ag, batches)
+        assert_groups_identical(got, want, 1, f"avg grouped strategy={strategy}")
+    # nulls: skipped by the ungrouped reductions; nothing counted -> NULL
+    nb = pa.RecordBatch.from_arrays([pa.array([1, 2, 3], type=pa.int64()), pa.array([None, None, None], type=pa.float64()),
+                                     pa.array([None, 2.5, 3.5], type=pa.float32()), pa.array([7, None, 8], type=pa.int64()),
+                                     pa.array([None, None, None], type=pa.int32())], names=["k", "f", "g", "i", "j"])
+    got = gpu_aggregate([], aggs, nb.schema, [nb])
+    want = oracle.aggregate([], aggs, [nb])
+    assert [bits(c) for c in got.columns] == [bits(c) for c in want.columns]
+    assert got.column(1)[0].as_py() is None and got.column(2)[0].as_py() == 3.0 and got.column(3)[0].as_py() == 7
+    with pytest.raises(ex.ExecutionError) as ei:  # 5 AVGs = 10 accumulators > 8
+        gpu_aggregate([], [agg("avg", Column(1), F64)] * 5, whole.schema, batches)
+    assert ei.value.kind == "NotImplemented"
+
+
 def test_c_abi_consumer_in_plain_c(tmp_path):
     """tests/c_abi/smoke.c: a gcc-built C program drives the whole query through include/dfx.h (what the
     Rust shim of INTEGRATION.md does); its result equals the oracle's."""

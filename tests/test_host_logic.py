@@ -75,9 +75,12 @@ def test_compile_expr_aggregates():
     a = ex.compile_expr(None, AggregateFunction("MIN", [Column(1)], DataType.Float64), SCHEMA)
     assert a.is_aggregate() and a.get_name() == "MIN" and a.get_type() == DataType.Float64
     assert ex.compile_expr(None, AggregateFunction("Count", [Column(0)], DataType.UInt64), SCHEMA).is_aggregate()
-    with pytest.raises(ex.ExecutionError) as ei:  # :103-106 ("avg" passes the planner, not the executor)
-        ex.compile_expr(None, AggregateFunction("avg", [Column(1)], DataType.Float64), SCHEMA)
-    assert ei.value.kind == "General" and "Unsupported aggregate function 'avg'" in ei.value.message
+    # deviation D7: "avg" passes the reference's planner but not its executor (:103-106); here it compiles
+    e = ex.compile_expr(None, AggregateFunction("avg", [Column(1)], DataType.Float64), SCHEMA)
+    assert e.get_name() == "avg" and e.get_type() == DataType.Float64
+    with pytest.raises(ex.ExecutionError) as ei:  # :103-106
+        ex.compile_expr(None, AggregateFunction("median", [Column(1)], DataType.Float64), SCHEMA)
+    assert ei.value.kind == "General" and "Unsupported aggregate function 'median'" in ei.value.message
     with pytest.raises(ex.ExecutionError) as ei:  # assert_eq!(1, args.len()) :91
         ex.compile_expr(None, AggregateFunction("min", [Column(1), Column(2)], DataType.Float64), SCHEMA)
     assert ei.value.kind == "InternalError"

@@ -103,3 +103,30 @@ def test_project_all_columns():
     out = oracle.project_next([Column(0)], batches[0])
     assert out.num_columns == 1
     assert out.column(0).to_pylist() == list(range(1, 11))
+
+
+def test_avg_is_sum_over_count_in_the_argument_type():
+    """Deviation D7 (unpinned: the reference has no AVG executor): AVG(x) = SUM(x) / COUNT(x), result in x's type;
+    checked against numpy on exactly representable data, floats and ints, grouped and ungrouped, nulls -> skipped
+    (ungrouped) and an all-null input -> NULL."""
+    import numpy as np
+    rng = np.random.default_rng(3)
+    n = 5000
+    k = rng.integers(0, 7, n).astype(np.int32)
+    f = rng.integers(0, 1 << 12, n).astype(np.float64) / 16.0
+    i = rng.integers(-1000, 1000, n).astype(np.int64)
+    b = pa.RecordBatch.from_arrays([pa.array(k), pa.array(f), pa.array(i)], names=["k", "f", "i"])
+    aggs = [AggregateFunction("AVG", [Column(1)], DataType.Float64), AggregateFunction("avg", [Column(2)], DataType.Int64)]
+    res = oracle.aggregate([], aggs, [b.slice(0, 1234), b.slice(1234)])
+    assert res.column(0)[0].as_py() == float(np.sum(f)) / n
+    assert res.column(1)[0].as_py() == int(int(np.sum(i)) / n)  # truncation toward zero
+    res = oracle.aggregate([Column(0)], aggs, [b])
+    got = {kk: (a, c) for kk, a, c in zip(*[res.column(j).to_pylist() for j in range(3)])}
+    for kk in range(7):
+        m = k == kk
+        assert got[kk][0] == float(np.sum(f[m])) / int(m.sum())
+        assert got[kk][1] == int(int(np.sum(i[m])) / int(m.sum()))
+    nulls = pa.RecordBatch.from_arrays([pa.array([1, 2], type=pa.int32()), pa.array([None, None], type=pa.float64()),
+                                        pa.array([None, 4], type=pa.int64())], names=["k", "f", "i"])
+    res = oracle.aggregate([], aggs, [nulls])
+    assert res.column(0)[0].as_py() is None and res.column(1)[0].as_py() == 4
