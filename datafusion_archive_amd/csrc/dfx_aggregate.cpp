@@ -524,6 +524,15 @@ Status AggregateRelation::Impl::launch_rows(const DeviceBatch& b, const DevProgr
     DFX_HIP(launch_partition_agg(T, PT, spill, 0, s));
     return Status::OK();
   }
+  DevFastPlan fp = fast;
+  if (!agg_options().fast) fp.valid = 0;
+  // a handful of groups (the calibration slice / earlier batches saw <= 8): register accumulators.  Should more
+  // groups turn up later the kernel still handles them (through the table), and the next batch goes back to K7.
+  if (lds_enabled && lds_calibrated && !calibrating && agg_options().strategy != 1 && agg_options().fewgroup &&
+      occupied_known > 0 && occupied_known <= 8 && fewgroup_supported(prog, fp, T)) {
+    DFX_HIP(launch_fewgroup_agg(prog, fp, cols, p, T, spill, n, bytes, s));
+    return Status::OK();
+  }
   if (lds_enabled && agg_options().strategy != 1) {
     const AggOptions& o = agg_options();
     int slots = o.lds_slots >= 0 ? o.lds_slots : 4096;
@@ -541,8 +550,6 @@ Status AggregateRelation::Impl::launch_rows(const DeviceBatch& b, const DevProgr
     p.lds_slots = 0;
     p.lds_copies = 1;
   }
-  DevFastPlan fp = fast;
-  if (!agg_options().fast) fp.valid = 0;
   DFX_HIP(launch_hash_agg(prog, fp, cols, p, T, spill, n, bytes, s));
   (void)b;
   return Status::OK();

@@ -84,6 +84,13 @@ hipError_t launch_reduce_fold(const DevTable& T, const uint8_t* arg_dtype, const
 hipError_t launch_hash_agg(const DevProgram& P, const DevFastPlan& fast, const DevColumns& C,
                            const DevAggPlan& plan, const DevTable& T, const DevRows& spill, int64_t n,
                            double algo_bytes, hipStream_t s);
+// K7 for a handful of groups (dfx_k_fewgroup.hip): per-lane register accumulators against a wave-uniform key
+// dictionary; same table / spill contract as launch_hash_agg.  fewgroup_supported: fast plan, no nulls,
+// <= 2 key words, <= 4 aggregates.
+bool fewgroup_supported(const DevProgram& P, const DevFastPlan& fast, const DevTable& T);
+hipError_t launch_fewgroup_agg(const DevProgram& P, const DevFastPlan& fast, const DevColumns& C,
+                               const DevAggPlan& plan, const DevTable& T, const DevRows& spill, int64_t n,
+                               double algo_bytes, hipStream_t s);
 // insert pre-evaluated rows (spill replays, LDS flushes of other ranks, all-to-all imports)
 hipError_t launch_merge_rows(const DevRows& rows, int64_t row_begin, int64_t n_rows, const DevTable& T,
                              const DevRows& spill, hipStream_t s);

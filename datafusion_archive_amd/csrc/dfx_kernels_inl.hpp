@@ -512,15 +512,33 @@ struct StaticPolicy {
       if (j < SIG::KW && j == k) v = cur[SIG::key_col(j)];
     return v;
   }
-  static DEV void arg(const DevProgram& P, const DevFastPlan& F, uint8_t opnd, int a, const COLV& cur, uint32_t curv,
-                      const u64x16& reg, uint32_t rv, uint64_t& v, bool& valid) {
+  // factor j of aggregate argument a: kind and column are compile-time constants after unrolling
+  static DEV double sfactor(const DevFastPlan& F, int a, int j, const COLV& cur) {
+    const double x = as_f64(cur[SIG::fc(a, j) & (BANK - 1)]);
+    const double imm = as_f64(F.arg_imm[a][j]);
+    switch (SIG::fk(a, j)) {
+      case FF_IMM_MINUS_COL: return imm - x;
+      case FF_COL_PLUS_IMM: return x + imm;
+      case FF_COL_MINUS_IMM: return x - imm;
+      case FF_COL_TIMES_IMM: return x * imm;
+      default: return x;
+    }
+  }
+  static DEV void arg(const DevProgram&, const DevFastPlan& F, uint8_t, int a, const COLV& cur, uint32_t,
+                      const u64x16&, uint32_t, uint64_t& v, bool& valid) {
     valid = true;
     v = 0;
 #pragma unroll
     for (int j = 0; j < kMaxAggs; ++j) {
       if (j < SIG::NA && j == a) {
-        if (SIG::arg_dyn(j)) FastPolicy<BANK, U_>::arg(P, F, opnd, j, cur, curv, reg, rv, v, valid);
-        else v = cur[SIG::arg_col(j)];
+        if (SIG::arg_dyn(j)) {  // product of signature-defined factors, multiplied left to right
+          double acc = sfactor(F, j, 0, cur);
+          if (SIG::nf(j) > 1) acc = acc * sfactor(F, j, 1, cur);
+          if (SIG::nf(j) > 2) acc = acc * sfactor(F, j, 2, cur);
+          v = f64_bits(acc);
+        } else {
+          v = cur[SIG::arg_col(j)];
+        }
       }
     }
   }

@@ -100,6 +100,7 @@ struct AggOptions {
   int partition_cap_rows = 0;  // rows per (producer, partition) region; 0: sized from the batch
   int partition_pad = 0;       // bytes of padding between partitions in the routing scratch
   int partition_block = 1024;  // pass-1 workgroup size in mode 1 (512: two workgroups per CU)
+  int fewgroup = 1;            // <= 8 groups after calibration: register accumulators (dfx_k_fewgroup.hip); 0: LDS front cache
 };
 AggOptions& agg_options();
 

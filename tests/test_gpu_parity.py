@@ -48,6 +48,7 @@ def _reset_options():
     ex.set_option("agg.lds_copies", -1)
     ex.set_option("agg.partition_mode", 2)
     ex.set_option("agg.partition_block", 1024)
+    ex.set_option("agg.fewgroup", 1)
     yield
 
 
@@ -456,6 +457,83 @@ def test_aggregate_computed_arguments_q1_shape(fast):
     for k in wv:
         for a, bb in zip(gv[k], wv[k]):
             assert abs(a - bb) <= 2 * EPS * abs(bb) * 4 + 1e-300, (k, a, bb)
+
+
+FEW_AGGS = [agg("sum", Column(1), F64), agg("min", Column(1), F64), agg("count", Column(1), DataType.UInt64),
+            agg("max", Column(2), DataType.Int64)]
+
+
+@pytest.mark.parametrize("fewgroup", [1, 0])
+@pytest.mark.parametrize("n_groups", [1, 6, 8, 9, 20])
+def test_fewgroup_register_accumulators(n_groups, fewgroup):
+    """<= 8 groups seen so far: the batches after the first run k_fewgroup_agg (per-lane register accumulators
+    against a wave-uniform key dictionary).  The first batch only holds keys < 6; with n_groups 9 / 20 the later
+    batches bring more keys than a wave's dictionary holds (overflow -> table path).  agg.fewgroup=0: K7."""
+    ex.set_option("agg.fewgroup", fewgroup)
+    rng = np.random.default_rng(100 + n_groups)
+    first = _exact_batch(rng, 50000, min(n_groups, 6))
+    rest = [_exact_batch(rng, 70001, n_groups) for _ in range(3)]
+    batches = [first] + rest
+    pred = BinaryExpr(Column(1), Operator.Gt, lit(100.0))
+    for filt in (None, pred):
+        got = gpu_aggregate([Column(0)], FEW_AGGS, first.schema, batches, filter_expr=filt)
+        src = batches if filt is None else [oracle.filter_next(filt, b) for b in batches]
+        assert_groups_identical(got, oracle.aggregate([Column(0)], FEW_AGGS, src), 1, f"few groups={n_groups}")
+
+
+def test_fewgroup_two_key_words_and_sentinel_key():
+    rng = np.random.default_rng(77)
+    n = 40000
+
+    def mk():
+        return pa.RecordBatch.from_arrays(
+            [pa.array(rng.integers(0, 3, n).astype(np.int64)), pa.array(rng.integers(0, 2, n).astype(np.int32)),
+             pa.array(rng.integers(0, 2**20, n).astype(np.float64) * 2.0 ** -10),
+             pa.array(rng.integers(-50, 50, n).astype(np.int64))], names=["rf", "ls", "v", "i"])
+    batches = [mk() for _ in range(3)]
+    aggs = [agg("sum", Column(2), F64), agg("count", Column(2), DataType.UInt64), agg("min", Column(3), DataType.Int64),
+            agg("max", Column(2), F64)]
+    got = gpu_aggregate([Column(0), Column(1)], aggs, batches[0].schema, batches)
+    assert_groups_identical(got, oracle.aggregate([Column(0), Column(1)], aggs, batches), 2, "few groups, 2 key words")
+    # one-word keys including i64::MIN (the table's claim sentinel): lives in the wave dictionaries like any key
+    keys = np.array([-2**63, 5, 2**63 - 1], dtype=np.int64)
+
+    def mk1():
+        return pa.RecordBatch.from_arrays(
+            [pa.array(keys[rng.integers(0, 3, n)]), pa.array(rng.integers(0, 2**20, n).astype(np.float64) * 2.0 ** -10),
+             pa.array(rng.integers(-50, 50, n).astype(np.int64)), pa.array(rng.standard_normal(n).astype(np.float32))],
+            names=["k", "v", "i", "f"])
+    batches = [mk1() for _ in range(3)]
+    got = gpu_aggregate([Column(0)], FEW_AGGS, batches[0].schema, batches)
+    assert_groups_identical(got, oracle.aggregate([Column(0)], FEW_AGGS, batches), 1, "few groups, sentinel key")
+
+
+@pytest.mark.parametrize("fewgroup", [1, 0])
+def test_fewgroup_q1_shape_bit_exact(fewgroup):
+    """Config 5's shape over several batches (the later ones run the SigQ1 instance of k_fewgroup_agg).  Prices are
+    integers and disc / tax multiples of 1/128, so every product and every partial sum is exactly representable:
+    the SUMs are order-independent and must equal the oracle's bit for bit."""
+    ex.set_option("agg.fewgroup", fewgroup)
+    rng = np.random.default_rng(22)
+    n = 90000
+
+    def mk():
+        cols = {"rf": rng.integers(0, 3, n).astype(np.int64), "ls": rng.integers(0, 2, n).astype(np.int64),
+                "qty": rng.integers(1, 51, n).astype(np.float64), "price": rng.integers(900, 105000, n).astype(np.float64),
+                "disc": rng.integers(0, 11, n).astype(np.float64) / 128.0, "tax": rng.integers(0, 9, n).astype(np.float64) / 128.0,
+                "ship": rng.integers(0, 2526, n).astype(np.float64)}
+        return pa.RecordBatch.from_arrays([pa.array(v) for v in cols.values()], names=list(cols))
+    batches = [mk() for _ in range(3)]
+    one_minus = BinaryExpr(lit(1.0), Operator.Minus, Column(4))
+    one_plus = BinaryExpr(lit(1.0), Operator.Plus, Column(5))
+    disc_price = BinaryExpr(Column(3), Operator.Multiply, one_minus)
+    aggs = [agg("sum", Column(2), F64), agg("sum", Column(3), F64), agg("sum", disc_price, F64),
+            agg("sum", BinaryExpr(disc_price, Operator.Multiply, one_plus), F64)]
+    pred = BinaryExpr(BinaryExpr(Column(6), Operator.LtEq, lit(2436.0)), Operator.And,
+                      BinaryExpr(Column(4), Operator.GtEq, lit(0.0)))
+    got = gpu_aggregate([Column(0), Column(1)], aggs, batches[0].schema, batches, filter_expr=pred)
+    want = oracle.aggregate([Column(0), Column(1)], aggs, [oracle.filter_next(pred, b) for b in batches])
+    assert_groups_identical(got, want, 2, "Q1 shape")
 
 
 def _check_partitioned_filter_aggregate():

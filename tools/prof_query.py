@@ -15,9 +15,13 @@ from datafusion_archive_amd.logicalplan import (AggregateFunction, BinaryExpr, C
 wl = sys.argv[1] if len(sys.argv) > 1 else "headline"
 rows = int(float(sys.argv[2])) if len(sys.argv) > 2 else 1 << 28
 iters = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+batch_rows = 1 << 26
 for kv in sys.argv[4:]:
     k, v = kv.split("=")
-    ex.set_option(k, int(v))
+    if k == "batch":
+        batch_rows = int(v)
+    else:
+        ex.set_option(k, int(v))
 ex.init(0)
 f64 = DataType.Float64
 
@@ -60,7 +64,7 @@ table = ex.DeviceTable.synth(syn, 0xDF02, 0, rows)
 
 
 def run():
-    rel = table.scan(1 << 26)
+    rel = table.scan(batch_rows)
     if pred is not None:
         rel = ex.FilterRelation(rel, ex.compile_scalar_expr(None, pred, schema), schema)
     rel = ex.AggregateRelation(None, rel, [ex.compile_scalar_expr(None, g, schema) for g in group],
@@ -70,9 +74,15 @@ def run():
 
 run()
 ex.synchronize()
+ex.profile_reset()
+ex.profile_enable(True)
 t0 = time.perf_counter()
 for _ in range(iters):
     out = run()
 ex.synchronize()
 dt = (time.perf_counter() - t0) / iters
+ex.profile_enable(False)
+prof = " ".join(f"{p['kernel']}:{p['launches'] // iters}x{p['total_ms'] / iters:.3f}ms" for p in ex.profile_snapshot()
+                if p["total_ms"] / iters > 0.02)
+print(f"   kernels/iter: {prof}")
 print(f"{wl}: rows={rows} {dt*1e3:.3f} ms/iter  {rows/dt/1e9:.2f} Grows/s  {rows*bytes_per_row/dt/1e9:.1f} GB/s  groups={out.num_rows}")
