@@ -177,6 +177,7 @@ Status ensure_init() {
   if (c.device >= n) return Status::Err(DFX_EXECUTION_ERROR, strfmt("device %d out of range (%d devices)", c.device, n));
   DFX_HIP(hipSetDevice(c.device));
   DFX_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+  DFX_HIP(hipStreamCreateWithFlags(&c.aux, hipStreamNonBlocking));
   c.initialised = true;
   return Status::OK();
 }

@@ -74,6 +74,7 @@ struct Context {
   int device = 0;
   bool initialised = false;
   hipStream_t stream = nullptr;  // all kernels and copies of this process: one in-order stream
+  hipStream_t aux = nullptr;     // side stream for control-block snapshots (keeps D2H copies out of the kernel chain)
 };
 Context& ctx();
 Status ensure_init();

@@ -75,7 +75,7 @@ def run():
 run()
 ex.synchronize()
 ex.profile_reset()
-ex.profile_enable(True)
+ex.profile_enable(os.environ.get('NOPROF') != '1')
 t0 = time.perf_counter()
 for _ in range(iters):
     out = run()
