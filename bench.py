@@ -44,8 +44,9 @@ def main():
     ap.add_argument("--cpu-sample-rows", type=float, default=3e8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
-    ap.add_argument("--prewarm-seconds", type=float, default=1.0,
-                    help="untimed steps before the W warmup steps (a fresh box runs its first ~second slower)")
+    ap.add_argument("--prewarm-steps", type=int, default=150,
+                    help="untimed steps before the W warmup steps (~1 s: a fresh box runs its first moments slower); "
+                         "a fixed count so that every rank runs the same number of exchanges")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -137,8 +138,7 @@ def main():
     #      -> the per-kernel durations the roofline is computed from.  The events serialise the kernel chain
     #      (~10 us of idle device per launch, rocprofv3 timeline), so region 2 is ~8 % slower; its time is
     #      reported as extra.instrumented_ms_per_step.
-    t_pre = time.perf_counter()
-    while time.perf_counter() - t_pre < args.prewarm_seconds:
+    for _ in range(args.prewarm_steps):
         step()
     for _ in range(args.warmup):
         step()
