@@ -1,0 +1,157 @@
+// dfx_csv_walk.hpp -- the record / field automaton of the reference's CSV source, shared by the device kernels
+// (dfx_k_csv.hip) and the host (dfx_csv.cpp: error messages quote the offending cell).
+//
+// CsvDataSource (src/execution/datasource.rs:33-58) is arrow 0.12's csv::Reader over the `csv` crate with its
+// defaults: delimiter ',', quote '"', doubled quotes inside a quoted field are one literal quote, a quote is
+// special only as the FIRST byte of a field (inside an unquoted field it is a literal), bytes after a closing
+// quote continue the field unquoted, records end at \n, \r or \r\n, empty lines are skipped.  The states:
+//   0 StartRecord  1 StartField  2 InField  3 InQuotedField  4 QuoteInQuoted (closing quote or first of a pair)
+// and the byte classes Q(uote) D(elimiter) T(erminator) O(ther).
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define DFX_HD __host__ __device__ inline
+#else
+#define DFX_HD inline
+#endif
+
+namespace dfx {
+
+enum : uint32_t { CSV_Q = 0, CSV_D = 1, CSV_T = 2, CSV_O = 3 };
+DFX_HD uint32_t csv_class(uint8_t c) { return c == '"' ? CSV_Q : c == ',' ? CSV_D : (c == '\n' || c == '\r') ? CSV_T : CSV_O; }
+
+// transition vectors: next state for each start state s in bits [3s, 3s + 3)
+constexpr uint32_t csv_pack5(uint32_t s0, uint32_t s1, uint32_t s2, uint32_t s3, uint32_t s4) {
+  return s0 | (s1 << 3) | (s2 << 6) | (s3 << 9) | (s4 << 12);
+}
+constexpr uint32_t kCsvTvQ = csv_pack5(3, 3, 2, 4, 3);
+constexpr uint32_t kCsvTvD = csv_pack5(1, 1, 1, 3, 1);
+constexpr uint32_t kCsvTvT = csv_pack5(0, 0, 0, 3, 0);
+constexpr uint32_t kCsvTvO = csv_pack5(2, 2, 2, 3, 2);
+constexpr uint32_t kCsvTvId = csv_pack5(0, 1, 2, 3, 4);
+DFX_HD uint32_t csv_tv_of(uint32_t cls) { return cls == CSV_Q ? kCsvTvQ : cls == CSV_D ? kCsvTvD : cls == CSV_T ? kCsvTvT : kCsvTvO; }
+DFX_HD uint32_t csv_tv_apply(uint32_t v, uint32_t s) { return (v >> (3 * s)) & 7u; }
+DFX_HD uint32_t csv_tv_compose(uint32_t f, uint32_t g) {  // f first, then g
+  uint32_t h = 0;
+  for (uint32_t s = 0; s < 5; ++s) h |= csv_tv_apply(g, csv_tv_apply(f, s)) << (3 * s);
+  return h;
+}
+
+// One field of a record as the walker reports it.
+struct CsvField {
+  uint64_t begin;   // first raw byte (the opening quote of a quoted field)
+  uint64_t end;     // one past the last raw byte (the delimiter / terminator / end of input)
+  uint64_t close;   // quoted: position of the closing quote (or `end` when the input ends inside the quotes)
+  uint32_t ulen;    // length of the unescaped content
+  bool quoted;      // started with a quote
+  bool complex;     // doubled quotes, or bytes after the closing quote: content is not one contiguous span
+};
+
+// Walks the record that starts at `begin` (a non-terminator byte in state StartRecord) and calls
+// field(index, CsvField) for every field; stops at the record terminator or at `limit`.  Returns the field count.
+template <typename F>
+DFX_HD int csv_walk_record(const uint8_t* buf, uint64_t begin, uint64_t limit, F&& field) {
+  enum { START = 0, INF = 1, INQ = 2, QQ = 3 };
+  int st = START;
+  int nf = 0;
+  CsvField f;
+  f.begin = begin;
+  f.end = begin;
+  f.close = 0;
+  f.ulen = 0;
+  f.quoted = false;
+  f.complex = false;
+  uint64_t pos = begin;
+  for (; pos < limit; ++pos) {
+    const uint8_t c = buf[pos];
+    const bool is_t = c == '\n' || c == '\r';
+    bool end_field = false;
+    if (st == START) {
+      if (c == '"') {
+        st = INQ;
+        f.quoted = true;
+      } else if (c == ',') {
+        end_field = true;
+      } else if (is_t) {
+        break;
+      } else {
+        st = INF;
+        f.ulen = 1;
+      }
+    } else if (st == INF) {
+      if (c == ',') end_field = true;
+      else if (is_t) break;
+      else ++f.ulen;
+    } else if (st == INQ) {
+      if (c == '"') {
+        st = QQ;
+        f.close = pos;
+      } else {
+        ++f.ulen;
+      }
+    } else {  // QQ
+      if (c == '"') {
+        ++f.ulen;
+        f.complex = true;
+        st = INQ;
+      } else if (c == ',') {
+        end_field = true;
+      } else if (is_t) {
+        break;
+      } else {
+        st = INF;
+        ++f.ulen;
+        f.complex = true;
+      }
+    }
+    if (end_field) {
+      f.end = pos;
+      field(nf++, f);
+      f.begin = pos + 1;
+      f.close = 0;
+      f.ulen = 0;
+      f.quoted = false;
+      f.complex = false;
+      st = START;
+    }
+  }
+  f.end = pos;
+  if (st == INQ) f.close = pos;  // input ended inside the quotes
+  field(nf++, f);
+  return nf;
+}
+
+// contiguous content span of a field (valid when !f.complex)
+DFX_HD void csv_field_span(const CsvField& f, uint64_t* b, uint64_t* e) {
+  if (f.quoted) {
+    *b = f.begin + 1;
+    *e = f.close;
+  } else {
+    *b = f.begin;
+    *e = f.end;
+  }
+}
+
+// unescaped content of a field -> out (f.ulen bytes)
+DFX_HD void csv_copy_field(const uint8_t* buf, const CsvField& f, uint8_t* out) {
+  if (!f.quoted) {
+    for (uint64_t p = f.begin; p < f.end; ++p) *out++ = buf[p];
+    return;
+  }
+  int st = 0;  // 0 in quotes, 1 just saw a quote, 2 unquoted tail
+  for (uint64_t p = f.begin + 1; p < f.end; ++p) {
+    const uint8_t c = buf[p];
+    if (st == 0) {
+      if (c == '"') st = 1;
+      else *out++ = c;
+    } else if (st == 1) {
+      *out++ = c;  // a second quote is the literal quote; anything else starts the unquoted tail
+      st = c == '"' ? 0 : 2;
+    } else {
+      *out++ = c;
+    }
+  }
+}
+
+}  // namespace dfx

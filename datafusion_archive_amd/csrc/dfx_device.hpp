@@ -219,6 +219,22 @@ struct DevDict {
   uint64_t pool_cap;
 };
 
+// ---- CSV source (dfx_k_csv.hip) -------------------------------------------------------------------------
+constexpr int kCsvMaxCols = 32;
+struct DevCsvCol {
+  void* values;        // fixed width: nb values; Boolean: (nb + 63) / 64 bitmap words
+  uint64_t* validity;  // (nb + 63) / 64 words (not used for Utf8: csv cells of a Utf8 column are never null)
+  int32_t* lens;       // Utf8: unescaped length per record
+  uint8_t dtype;
+};
+struct DevCsvPlan {
+  int32_t n_cols;            // schema columns (cells beyond are ignored)
+  uint32_t expected_fields;  // fields of the first record: every record must have as many (csv crate, flexible = false)
+  uint64_t* null_counts;     // [n_cols]
+  uint64_t* err;             // min over failing cells of (record << 16 | column << 8 | code); ~0: none
+  DevCsvCol col[kCsvMaxCols];
+};
+
 struct DevProjectPlan {
   int32_t n_out;
   uint8_t out[kMaxOut];        // operands

@@ -28,6 +28,7 @@ enum KernelId : int {
   KID_PARTIAL,
   KID_PARTITION,
   KID_PARTITION_AGG,
+  KID_CSV,
   KID_COUNT_
 };
 const char* kernel_name(int kid);
@@ -137,6 +138,22 @@ hipError_t launch_partition(const DevProgram& P, const DevFastPlan& fast, const 
                             double algo_bytes, hipStream_t s);
 hipError_t launch_partition_agg(const DevTable& T, const DevPartition& PT, const DevRows& spill, double algo_bytes,
                                 hipStream_t s);
+
+// CSV text -> Arrow columns (dfx_k_csv.hip): record boundaries by parallel simulation of the csv automaton, then one
+// thread per record converts the cells.  buf must be readable up to the next multiple of 32 bytes past n.
+//   boundaries_count: tile_trans / tile_state / tile_counts have one entry per csv_tile_bytes() of text;
+//   (scan tile_counts into tile_offsets, total = number of records) then boundaries_write fills row_start[0..total).
+int64_t csv_tile_bytes();
+hipError_t launch_csv_boundaries_count(const uint8_t* buf, uint64_t n, uint32_t* tile_trans, uint8_t* tile_state,
+                                       uint32_t* tile_counts, hipStream_t s);
+hipError_t launch_csv_boundaries_write(const uint8_t* buf, uint64_t n, const uint8_t* tile_state,
+                                       const uint64_t* tile_offsets, uint64_t* row_start, hipStream_t s);
+hipError_t launch_csv_count_fields(const uint8_t* buf, const uint64_t* row_start, int64_t row, uint32_t* out,
+                                   hipStream_t s);
+hipError_t launch_csv_parse(const uint8_t* buf, const uint64_t* row_start, int64_t r0, int64_t nb,
+                            const DevCsvPlan& plan, double algo_bytes, hipStream_t s);
+hipError_t launch_csv_utf8_gather(const uint8_t* buf, const uint64_t* row_start, int64_t r0, int64_t nb, int field,
+                                  const int32_t* offsets, uint8_t* out, hipStream_t s);
 
 // synthetic columns (definition shared with oracle/dfx_oracle.c: orc_synth_fill)
 hipError_t launch_synth(int kind, int column_id, double p0, double p1, uint64_t seed, int64_t row_begin,

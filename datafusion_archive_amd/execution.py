@@ -15,6 +15,7 @@ This module is plumbing: all computing happens in ``libdfx_hip.so`` on the GPU.
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Iterable, List, Optional, Sequence
 
 import pyarrow as pa
@@ -178,6 +179,24 @@ class DataSourceRelation(Relation):
         super().__init__()
         reader = pa.RecordBatchReader.from_batches(schema, iter(batches))
         reader._export_to_c(ctypes.addressof(self._stream))
+        self._schema = schema
+
+
+class CsvDataSource(Relation):
+    """datasource::CsvDataSource::new(filename, schema, batch_size) (datasource.rs:39-43) wrapped in its
+    DataSourceRelation (relation.rs:34-54).  The first record is always consumed as a header, as in the reference.
+    Parsing runs on the device; stacked operators consume the batches without a host round trip."""
+
+    def __init__(self, filename: str, schema: pa.Schema, batch_size: int = 1024):
+        super().__init__()
+        cs = _export_schema(schema)
+        err = _errbuf()
+        try:
+            code = _ffi.lib().dfx_csv_datasource_new(os.fsencode(filename), ctypes.byref(cs), batch_size,
+                                                     ctypes.byref(self._stream), err, 1024)
+        finally:
+            _release_schema(cs)
+        _check(code, err)
         self._schema = schema
 
 

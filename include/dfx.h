@@ -271,6 +271,20 @@ int32_t dfx_table_scan_new(const dfx_table* t, int64_t batch_rows, struct ArrowA
 void dfx_table_free(dfx_table* t);
 
 /* ------------------------------------------------------------------------------------------
+ * CSV data source.  replaces CsvDataSource::new(filename, schema, batch_size) + impl DataSource
+ * (src/execution/datasource.rs:33-58; wrapped by DataSourceRelation, relation.rs:34-54).  As in the
+ * reference the arrow csv reader is created with has_headers = true: the FIRST RECORD IS ALWAYS
+ * CONSUMED AS A HEADER.  The text is copied to HBM once; record boundaries, cell conversion
+ * (Rust `str::parse` semantics, correctly rounded floats) and Utf8 extraction run on the device,
+ * batch_size records per get_next().  Errors: a missing file is the reference's unwrap() panic
+ * (DFX_INTERNAL_ERROR); a cell that does not parse is DFX_ARROW_ERROR "Error while parsing value
+ * {cell} at line {n}"; a record with a different field count than the first is DFX_ARROW_ERROR.
+ * The stream is a library stream: operators stacked on it never leave the device.
+ * ---------------------------------------------------------------------------------------- */
+int32_t dfx_csv_datasource_new(const char* filename, const struct ArrowSchema* schema, int64_t batch_size,
+                               struct ArrowArrayStream* out, char* err, size_t errlen);
+
+/* ------------------------------------------------------------------------------------------
  * Multi-GPU GROUP BY exchange (no reference equivalent: the reference is single-process).
  * One process per GPU.  After draining its local input, an aggregate stream exports its partial
  * groups bucketed by hash(key) % world into one contiguous device buffer per payload word; the

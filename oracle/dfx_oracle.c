@@ -1074,3 +1074,273 @@ int32_t orc_run_synth_query(const dfx_synth_column* cols, int32_t n_cols, uint64
   if (rows_out) *rows_out = kept;
   return st;
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* CsvDataSource (src/execution/datasource.rs:33-58) = arrow 0.12 csv::Reader over the `csv`    */
+/* crate (req "1", Cargo.toml:30 via arrow) with has_headers = true, batch_size, no projection. */
+/*                                                                                            */
+/* Restated from the published sources (neither crate is vendored under the reference tree):   */
+/*   csv-core reader NFA with default settings: delimiter ',', quote '"', double_quote = true, */
+/*     quoting on, no escape, no comment, terminator CRLF (= \r, \n or \r\n), flexible = false; */
+/*     a quote opens a quoted field only as the first byte of a field, bytes after the closing */
+/*     quote continue the field unquoted, empty lines are skipped, the last record needs no    */
+/*     terminator;                                                                             */
+/*   arrow 0.12 csv::Reader::next: reads up to batch_size records; primitive cell: "" -> null,  */
+/*     else s.parse::<T>() or ParseError("Error while parsing value {s} at line {n}"); Utf8    */
+/*     cell: the string (never null; a record shorter than the schema gives "");              */
+/*   Rust 2019 str::parse: ints [+-]?digits (unsigned rejects '-'), floats dec2flt grammar +    */
+/*     "inf"/"NaN", correctly rounded (glibc strtod is, too: used here after a grammar check); */
+/*     bool "true"/"false".                                                                    */
+/* Pinned by: the row counts / values every reference test reads from test/data (the .csv files)   */
+/* (tests/sql.rs:29-77, aggregate.rs:965-1127, projection.rs:83-103) -- e.g. uk_cities.csv has   */
+/* 37 lines and the tests see 36 rows.  Unpinned: quoting corner cases, errors, nulls.          */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct { char* p; size_t n, cap; } sbuf;
+static void sb_put(sbuf* b, char c) {
+  if (b->n + 1 > b->cap) { b->cap = b->cap ? b->cap * 2 : 64; b->p = (char*)realloc(b->p, b->cap); }
+  b->p[b->n++] = c;
+}
+typedef struct { sbuf text; size_t* ends; int nf, cap; } csv_record; /* fields back to back, ends[i] = end of field i */
+static void rec_end_field(csv_record* r) {
+  if (r->nf + 1 > r->cap) { r->cap = r->cap ? r->cap * 2 : 16; r->ends = (size_t*)realloc(r->ends, sizeof(size_t) * (size_t)r->cap); }
+  r->ends[r->nf++] = r->text.n;
+}
+
+/* reads the next record starting at *pos; returns 0 at end of input */
+static int csv_next_record(const uint8_t* buf, size_t n, size_t* pos, csv_record* r) {
+  enum { START_RECORD, START_FIELD, IN_FIELD, IN_QUOTED, QUOTE_IN_QUOTED } st = START_RECORD;
+  size_t i = *pos;
+  r->text.n = 0;
+  r->nf = 0;
+  for (; i < n; ++i) {
+    const uint8_t c = buf[i];
+    const int is_t = c == '\n' || c == '\r';
+    switch (st) {
+      case START_RECORD:
+        if (is_t) continue; /* empty line */
+        __attribute__((fallthrough)); /* the first byte of the record is the first byte of a field */
+      case START_FIELD:
+        if (c == '"') st = IN_QUOTED;
+        else if (c == ',') { rec_end_field(r); st = START_FIELD; }
+        else if (is_t) { rec_end_field(r); *pos = i + 1; return 1; }
+        else { sb_put(&r->text, (char)c); st = IN_FIELD; }
+        break;
+      case IN_FIELD:
+        if (c == ',') { rec_end_field(r); st = START_FIELD; }
+        else if (is_t) { rec_end_field(r); *pos = i + 1; return 1; }
+        else sb_put(&r->text, (char)c); /* a quote here is a literal */
+        break;
+      case IN_QUOTED:
+        if (c == '"') st = QUOTE_IN_QUOTED;
+        else sb_put(&r->text, (char)c);
+        break;
+      case QUOTE_IN_QUOTED:
+        if (c == '"') { sb_put(&r->text, '"'); st = IN_QUOTED; }
+        else if (c == ',') { rec_end_field(r); st = START_FIELD; }
+        else if (is_t) { rec_end_field(r); *pos = i + 1; return 1; }
+        else { sb_put(&r->text, (char)c); st = IN_FIELD; }
+        break;
+    }
+  }
+  *pos = n;
+  if (st == START_RECORD) return 0;
+  rec_end_field(r); /* last record without a terminator */
+  return 1;
+}
+
+static int rust_float_grammar(const char* s, size_t n, int* special) {
+  size_t i = 0, nd = 0;
+  *special = 0;
+  if (n == 0) return 0;
+  if (s[0] == '+' || s[0] == '-') i = 1;
+  if (n - i == 3 && !memcmp(s + i, "inf", 3)) { *special = 1; return 1; }
+  if (n - i == 3 && !memcmp(s + i, "NaN", 3)) { *special = 2; return 1; }
+  while (i < n && s[i] >= '0' && s[i] <= '9') { ++i; ++nd; }
+  if (i < n && s[i] == '.') { ++i; while (i < n && s[i] >= '0' && s[i] <= '9') { ++i; ++nd; } }
+  if (nd == 0) return 0;
+  if (i < n && (s[i] == 'e' || s[i] == 'E')) {
+    size_t ne = 0;
+    ++i;
+    if (i < n && (s[i] == '+' || s[i] == '-')) ++i;
+    while (i < n && s[i] >= '0' && s[i] <= '9') { ++i; ++ne; }
+    if (ne == 0) return 0;
+  }
+  return i == n;
+}
+
+/* s.parse::<T>() for one cell; returns 0 on failure */
+static int csv_parse_cell(int dt, const char* s, size_t n, orc_array* a, int64_t row) {
+  char tmp[512];
+  if (n >= sizeof(tmp)) return 0;
+  memcpy(tmp, s, n);
+  tmp[n] = 0;
+  if (dt == DFX_FLOAT64 || dt == DFX_FLOAT32) {
+    int special;
+    if (!rust_float_grammar(tmp, n, &special)) return 0;
+    const int neg = tmp[0] == '-';
+    if (dt == DFX_FLOAT64) {
+      double d = special == 1 ? INFINITY : special == 2 ? NAN : strtod(tmp, NULL);
+      if (special && neg) d = -d;
+      ((double*)a->values)[row] = d;
+    } else {
+      float f = special == 1 ? INFINITY : special == 2 ? NAN : strtof(tmp, NULL);
+      if (special && neg) f = -f;
+      ((float*)a->values)[row] = f;
+    }
+    return 1;
+  }
+  if (dt == DFX_BOOLEAN) {
+    if (!strcmp(tmp, "true")) { bit_set((uint8_t*)a->values, row); return 1; }
+    return !strcmp(tmp, "false");
+  }
+  { /* integers */
+    const int is_signed = dt >= DFX_INT8 && dt <= DFX_INT64;
+    const int bits = (int)dt_size(dt) * 8;
+    size_t i = 0;
+    int neg = 0;
+    unsigned __int128 v = 0;
+    if (tmp[0] == '+' || tmp[0] == '-') { neg = tmp[0] == '-'; i = 1; }
+    if (neg && !is_signed) return 0;
+    if (i == n) return 0;
+    for (; i < n; ++i) {
+      if (tmp[i] < '0' || tmp[i] > '9') return 0;
+      v = v * 10 + (unsigned)(tmp[i] - '0');
+      if (v > ((unsigned __int128)1 << 64)) return 0;
+    }
+    const unsigned __int128 maxpos = is_signed ? (((unsigned __int128)1 << (bits - 1)) - 1) : (((unsigned __int128)1 << bits) - 1);
+    if (v > (neg ? maxpos + 1 : maxpos)) return 0;
+    const int64_t sv = neg ? (int64_t)(0 - (uint64_t)v) : (int64_t)(uint64_t)v;
+    switch (dt) {
+      case DFX_INT8: ((int8_t*)a->values)[row] = (int8_t)sv; break;
+      case DFX_INT16: ((int16_t*)a->values)[row] = (int16_t)sv; break;
+      case DFX_INT32: ((int32_t*)a->values)[row] = (int32_t)sv; break;
+      case DFX_INT64: ((int64_t*)a->values)[row] = sv; break;
+      case DFX_UINT8: ((uint8_t*)a->values)[row] = (uint8_t)v; break;
+      case DFX_UINT16: ((uint16_t*)a->values)[row] = (uint16_t)v; break;
+      case DFX_UINT32: ((uint32_t*)a->values)[row] = (uint32_t)v; break;
+      default: ((uint64_t*)a->values)[row] = (uint64_t)v; break;
+    }
+    return 1;
+  }
+}
+
+struct orc_csv {
+  uint8_t* buf;
+  size_t n, pos;
+  int32_t n_cols;
+  int32_t* dtypes;
+  int64_t batch_size;
+  int64_t line_number; /* arrow: 1 after the header */
+  int expected_fields;
+  int started;
+};
+
+int32_t orc_csv_open(const char* filename, const int32_t* dtypes, int32_t n_cols, int64_t batch_size, orc_csv** out,
+                     char* err, size_t errlen) {
+  FILE* fp = fopen(filename, "rb");
+  if (!fp) return fail(err, errlen, DFX_INTERNAL_ERROR, "called `Result::unwrap()` on an `Err` value: could not open %s", filename);
+  orc_csv* c = (orc_csv*)calloc(1, sizeof(orc_csv));
+  fseek(fp, 0, SEEK_END);
+  c->n = (size_t)ftell(fp);
+  fseek(fp, 0, SEEK_SET);
+  c->buf = (uint8_t*)malloc(c->n + 1);
+  if (fread(c->buf, 1, c->n, fp) != c->n) { fclose(fp); free(c->buf); free(c); return fail(err, errlen, DFX_IO_ERROR, "short read"); }
+  fclose(fp);
+  c->n_cols = n_cols;
+  c->dtypes = (int32_t*)malloc(sizeof(int32_t) * (size_t)n_cols);
+  memcpy(c->dtypes, dtypes, sizeof(int32_t) * (size_t)n_cols);
+  c->batch_size = batch_size;
+  c->line_number = 1;
+  c->expected_fields = -1;
+  *out = c;
+  return DFX_OK;
+}
+
+void orc_csv_close(orc_csv* c) {
+  if (!c) return;
+  free(c->buf);
+  free(c->dtypes);
+  free(c);
+}
+
+/* csv::Reader::next: Ok(None) -> *out = NULL */
+int32_t orc_csv_next(orc_csv* c, orc_batch** out, char* err, size_t errlen) {
+  *out = NULL;
+  csv_record rec;
+  memset(&rec, 0, sizeof(rec));
+  if (!c->started) { /* has_headers = true: the first record is consumed whatever it holds */
+    c->started = 1;
+    if (csv_next_record(c->buf, c->n, &c->pos, &rec)) c->expected_fields = rec.nf;
+  }
+  /* collect up to batch_size records (copies: the record buffer is reused) */
+  const int64_t cap = c->batch_size > 0 ? c->batch_size : 1024;
+  char** texts = (char**)calloc((size_t)cap, sizeof(char*));
+  size_t** ends = (size_t**)calloc((size_t)cap, sizeof(size_t*));
+  int* nfs = (int*)calloc((size_t)cap, sizeof(int));
+  int64_t rows = 0;
+  int32_t st = DFX_OK;
+  while (rows < cap && csv_next_record(c->buf, c->n, &c->pos, &rec)) {
+    if (c->expected_fields >= 0 && rec.nf != c->expected_fields) {
+      st = fail(err, errlen, DFX_ARROW_ERROR, "Error parsing line %lld: UnequalLengths { expected_len: %d, len: %d }",
+                (long long)(c->line_number + rows), c->expected_fields, rec.nf);
+      break;
+    }
+    if (c->expected_fields < 0) c->expected_fields = rec.nf;
+    texts[rows] = (char*)malloc(rec.text.n + 1);
+    memcpy(texts[rows], rec.text.p, rec.text.n);
+    ends[rows] = (size_t*)malloc(sizeof(size_t) * (size_t)(rec.nf > 0 ? rec.nf : 1));
+    memcpy(ends[rows], rec.ends, sizeof(size_t) * (size_t)rec.nf);
+    nfs[rows] = rec.nf;
+    ++rows;
+  }
+  orc_batch* b = NULL;
+  if (!st && rows > 0) {
+    b = (orc_batch*)calloc(1, sizeof(orc_batch));
+    b->owned = 1;
+    b->num_rows = rows;
+    b->num_columns = c->n_cols;
+    b->columns = (orc_array**)calloc((size_t)c->n_cols, sizeof(orc_array*));
+    for (int col = 0; col < c->n_cols && !st; ++col) {
+      const int dt = c->dtypes[col];
+      orc_array* a = arr_new(dt, rows, dt != DFX_UTF8);
+      b->columns[col] = a;
+      if (dt == DFX_UTF8) {
+        size_t total = 0;
+        for (int64_t r = 0; r < rows; ++r) {
+          const size_t fb = col < nfs[r] ? (col ? ends[r][col - 1] : 0) : 0, fe = col < nfs[r] ? ends[r][col] : 0;
+          total += fe - fb;
+        }
+        a->data = (uint8_t*)malloc(total + 1);
+        size_t at = 0;
+        for (int64_t r = 0; r < rows; ++r) {
+          const size_t fb = col < nfs[r] ? (col ? ends[r][col - 1] : 0) : 0, fe = col < nfs[r] ? ends[r][col] : 0;
+          a->offsets[r] = (int32_t)at;
+          memcpy(a->data + at, texts[r] + fb, fe - fb);
+          at += fe - fb;
+        }
+        a->offsets[rows] = (int32_t)at;
+        continue;
+      }
+      int any_null = 0;
+      for (int64_t r = 0; r < rows; ++r) {
+        if (col >= nfs[r]) { any_null = 1; continue; } /* rows[i].get(col) == None */
+        const size_t fb = col ? ends[r][col - 1] : 0, fe = ends[r][col];
+        if (fe == fb) { any_null = 1; continue; }        /* "" -> append_null */
+        if (!csv_parse_cell(dt, texts[r] + fb, fe - fb, a, r)) {
+          st = fail(err, errlen, DFX_ARROW_ERROR, "Error while parsing value %.*s at line %lld", (int)(fe - fb), texts[r] + fb,
+                    (long long)(c->line_number + r));
+          break;
+        }
+        bit_set(a->validity, r);
+      }
+      if (!any_null && !st) { free(a->validity); a->validity = NULL; }
+    }
+  }
+  c->line_number += rows;
+  for (int64_t r = 0; r < rows; ++r) { free(texts[r]); free(ends[r]); }
+  free(texts); free(ends); free(nfs);
+  free(rec.text.p); free(rec.ends);
+  if (st) { orc_batch_free(b); return st; }
+  *out = b;
+  return DFX_OK;
+}

@@ -86,6 +86,14 @@ int32_t orc_run_synth_query(const dfx_synth_column* cols, int32_t n_cols, uint64
                             int32_t n_aggr, int32_t mask_only, double* seconds, orc_batch** out,
                             int64_t* rows_out, char* err, size_t errlen);
 
+/* CsvDataSource::new(filename, schema, batch_size) + next() (datasource.rs:33-58): arrow 0.12 csv::Reader with
+ * has_headers = true over the csv crate's defaults.  *out == NULL at end of input (Ok(None)). */
+typedef struct orc_csv orc_csv;
+int32_t orc_csv_open(const char* filename, const int32_t* dtypes, int32_t n_cols, int64_t batch_size, orc_csv** out,
+                     char* err, size_t errlen);
+int32_t orc_csv_next(orc_csv* c, orc_batch** out, char* err, size_t errlen);
+void orc_csv_close(orc_csv* c);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,152 @@
+// Host build of csrc/dfx_numparse.hpp checked against glibc strtod / strtof (correctly rounded, like Rust's dec2flt).
+// usage: numparse_fuzz <iterations> <seed>   -> prints "ok ..." or the first mismatch and exits 1
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <random>
+#include <string>
+
+#include "../../datafusion_archive_amd/csrc/dfx_numparse.hpp"
+
+static long long n_ok = 0, n_unsupported = 0;
+
+static bool check64(const std::string& s) {
+  double got = 0;
+  const int rc = dfx::np_parse_f64((const uint8_t*)s.data(), (int64_t)s.size(), &got);
+  if (rc == dfx::NP_UNSUPPORTED) {
+    ++n_unsupported;
+    return true;
+  }
+  if (rc != dfx::NP_OK) {
+    printf("MISMATCH f64: '%s' rejected\n", s.c_str());
+    return false;
+  }
+  const double want = strtod(s.c_str(), nullptr);
+  if (memcmp(&got, &want, 8) != 0 && !(got != got && want != want)) {
+    printf("MISMATCH f64: '%s' got %.17g want %.17g\n", s.c_str(), got, want);
+    return false;
+  }
+  ++n_ok;
+  return true;
+}
+
+static bool check32(const std::string& s) {
+  float got = 0;
+  const int rc = dfx::np_parse_f32((const uint8_t*)s.data(), (int64_t)s.size(), &got);
+  if (rc == dfx::NP_UNSUPPORTED) {
+    ++n_unsupported;
+    return true;
+  }
+  if (rc != dfx::NP_OK) {
+    printf("MISMATCH f32: '%s' rejected\n", s.c_str());
+    return false;
+  }
+  const float want = strtof(s.c_str(), nullptr);
+  if (memcmp(&got, &want, 4) != 0 && !(got != got && want != want)) {
+    printf("MISMATCH f32: '%s' got %.9g want %.9g\n", s.c_str(), got, want);
+    return false;
+  }
+  ++n_ok;
+  return true;
+}
+
+static bool expect_invalid(const char* s) {
+  double d;
+  float f;
+  if (dfx::np_parse_f64((const uint8_t*)s, (int64_t)strlen(s), &d) != dfx::NP_INVALID ||
+      dfx::np_parse_f32((const uint8_t*)s, (int64_t)strlen(s), &f) != dfx::NP_INVALID) {
+    printf("MISMATCH: '%s' should be invalid\n", s);
+    return false;
+  }
+  return true;
+}
+
+static bool check_int(const char* s, int bits, bool sg, bool ok, long long want) {
+  uint64_t v = 0;
+  const int rc = dfx::np_parse_int((const uint8_t*)s, (int64_t)strlen(s), bits, sg, &v);
+  if ((rc == dfx::NP_OK) != ok || (ok && (long long)v != want)) {
+    printf("MISMATCH int: '%s' bits=%d signed=%d rc=%d v=%lld\n", s, bits, (int)sg, rc, (long long)v);
+    return false;
+  }
+  return true;
+}
+
+int main(int argc, char** argv) {
+  const long long iters = argc > 1 ? atoll(argv[1]) : 1000000;
+  std::mt19937_64 rng(argc > 2 ? strtoull(argv[2], nullptr, 10) : 1);
+  const char* fixed[] = {"0", "-0", "0.0", "-0.0", "1", "1.", ".5", "+.5e1", "1e0", "1E+2", "1e-2", "123456789012345678901234567890",
+                         "0.000000000000000000000000000001", "1.7976931348623157e308", "1.7976931348623158e308",
+                         "1.7976931348623159e308", "1e309", "2.2250738585072014e-308", "2.2250738585072011e-308",
+                         "4.9406564584124654e-324", "2.4703282292062327e-324", "2.4703282292062328e-324", "1e-400",
+                         "9007199254740993", "9007199254740992", "9007199254740991", "0.1", "0.2", "0.3", "57.653484",
+                         "-3.335724", "50.494344999999996", "51.67569700000001", "3.3000000000000003", "1e23", "8.5e22",
+                         "9.5e22", "1.00000000000000011102230246251565404236316680908203125",
+                         "1.00000000000000011102230246251565404236316680908203124",
+                         "1.00000000000000011102230246251565404236316680908203126", "inf", "-inf", "+inf", "NaN", "-NaN",
+                         "3.4028235e38", "3.4028236e38", "1.1754944e-38", "1e-46", "16777217", "7e-46"};
+  for (const char* f : fixed)
+    if (!check64(f) || !check32(f)) return 1;
+  const char* bad[] = {"", "+", "-", ".", "e5", "1e", "1e+", " 1", "1 ", "0x10", "infinity", "nan", "Inf", "1.2.3", "1,2", "--1", "1e5.0", "\"1\""};
+  for (const char* b : bad)
+    if (!expect_invalid(b)) return 1;
+  if (!check_int("127", 8, true, true, 127) || !check_int("128", 8, true, false, 0) || !check_int("-128", 8, true, true, -128) ||
+      !check_int("-129", 8, true, false, 0) || !check_int("255", 8, false, true, 255) || !check_int("256", 8, false, false, 0) ||
+      !check_int("-0", 8, false, false, 0) || !check_int("+5", 32, true, true, 5) || !check_int("", 32, true, false, 0) ||
+      !check_int("-", 32, true, false, 0) || !check_int("9223372036854775807", 64, true, true, 9223372036854775807ll) ||
+      !check_int("9223372036854775808", 64, true, false, 0) ||
+      !check_int("-9223372036854775808", 64, true, true, (long long)0x8000000000000000ull) ||
+      !check_int("18446744073709551615", 64, false, true, -1) || !check_int("18446744073709551616", 64, false, false, 0) ||
+      !check_int("1.0", 32, true, false, 0) || !check_int("12a", 32, true, false, 0) || !check_int("-2147483648", 32, true, true, -2147483648ll) ||
+      !check_int("2147483648", 32, true, false, 0) || !check_int("65535", 16, false, true, 65535) || !check_int("-32769", 16, true, false, 0))
+    return 1;
+  char buf[128];
+  for (long long it = 0; it < iters; ++it) {
+    const int kind = (int)(rng() % 8);
+    std::string s;
+    if (kind == 0) {  // random bit patterns, shortest round-trip-ish formats
+      uint64_t b = rng();
+      double d;
+      memcpy(&d, &b, 8);
+      if (!(d == d) || isinf(d)) continue;
+      snprintf(buf, sizeof buf, "%.17g", d);
+      s = buf;
+    } else if (kind == 1) {
+      uint64_t b = rng();
+      double d;
+      memcpy(&d, &b, 8);
+      if (!(d == d) || isinf(d)) continue;
+      snprintf(buf, sizeof buf, "%.*e", (int)(rng() % 20), d);
+      s = buf;
+    } else if (kind == 2) {  // CSV-like fixed point
+      const double d = (double)(int64_t)(rng() % 2000000000000ull) / 1e6 - 1e6;
+      snprintf(buf, sizeof buf, "%.6f", d);
+      s = buf;
+    } else if (kind == 3) {  // float32 bit patterns
+      uint32_t b = (uint32_t)rng();
+      float f;
+      memcpy(&f, &b, 4);
+      if (!(f == f) || isinf(f)) continue;
+      snprintf(buf, sizeof buf, "%.9g", (double)f);
+      s = buf;
+    } else {  // random digit strings: 1..30 digits, optional point, optional exponent
+      const int nd = 1 + (int)(rng() % (kind == 4 ? 19 : 30));
+      if (rng() & 1) s += (rng() & 1) ? '-' : '+';
+      const int point = (int)(rng() % (nd + 2)) - 1;  // -1: none
+      for (int i = 0; i < nd; ++i) {
+        if (i == point) s += '.';
+        s += (char)('0' + rng() % 10);
+      }
+      if (point == nd) s += '.';
+      if (rng() % 3) {
+        snprintf(buf, sizeof buf, "%c%s%d", (rng() & 1) ? 'e' : 'E', (rng() & 1) ? "-" : ((rng() & 1) ? "+" : ""),
+                 (int)(rng() % (kind == 5 ? 340 : 40)));
+        s += buf;
+      }
+    }
+    if (!check64(s) || !check32(s)) return 1;
+  }
+  printf("ok: %lld conversions agree with strtod/strtof, %lld declined (NP_UNSUPPORTED)\n", n_ok, n_unsupported);
+  return 0;
+}

@@ -80,6 +80,8 @@ def lib():
         _lib.orc_array_free.argtypes = [ctypes.POINTER(OrcArray)]
         _lib.orc_batch_free.argtypes = [ctypes.POINTER(OrcBatch)]
         _lib.orc_agg_free.argtypes = [ctypes.c_void_p]
+        _lib.orc_csv_close.argtypes = [ctypes.c_void_p]
+        _lib.orc_csv_next.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.POINTER(OrcBatch)), ctypes.c_char_p, ctypes.c_size_t]
     return _lib
 
 
@@ -298,3 +300,26 @@ def run_synth_query(cols: Sequence[tuple], seed: int, row_begin: int, n_rows: in
         finally:
             lib().orc_batch_free(out)
     return secs.value, kept.value, res
+
+
+def read_csv(filename: str, schema: pa.Schema, batch_size: int = 1024) -> List[pa.RecordBatch]:
+    """CsvDataSource::new(filename, schema, batch_size) drained (datasource.rs:33-58): every batch next() yields."""
+    dts = (ctypes.c_int32 * len(schema))(*[int(_PA_TO_DT[f.type]) for f in schema])
+    h = ctypes.c_void_p()
+    err = ctypes.create_string_buffer(512)
+    L = lib()
+    _check(L.orc_csv_open(os.fsencode(filename), dts, len(schema), ctypes.c_int64(batch_size), ctypes.byref(h), err, 512), err)
+    out: List[pa.RecordBatch] = []
+    try:
+        while True:
+            bp = ctypes.POINTER(OrcBatch)()
+            _check(L.orc_csv_next(h, ctypes.byref(bp), err, 512), err)
+            if not bp:
+                break
+            try:
+                out.append(_batch_to_arrow(bp, schema.names))
+            finally:
+                L.orc_batch_free(bp)
+    finally:
+        L.orc_csv_close(h)
+    return out
