@@ -24,23 +24,79 @@ constexpr int kCsvChunk = 32;                      // bytes per thread
 constexpr int kCsvBlock = 256;                     // threads per tile
 constexpr int kCsvTile = kCsvChunk * kCsvBlock;    // 8192 bytes
 
-// transition vector of the chunk [pos, pos + 32) clipped to n
-DEV uint32_t csv_chunk_vector(const uint8_t* __restrict__ buf, uint64_t pos, uint64_t n) {
-  uint32_t v = kCsvTvId;
-  if (pos >= n) return v;
+// one thread's 32 bytes
+struct CsvChunk {
   uint32_t w[8];
-  const uint4 a = *(const uint4*)(buf + pos);  // the buffer is padded to a multiple of 32 bytes
-  const uint4 b = *(const uint4*)(buf + pos + 16);
-  w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
-  const int m = (int)((n - pos) < (uint64_t)kCsvChunk ? (n - pos) : (uint64_t)kCsvChunk);
+  int m;           // valid bytes (0..32)
+  bool has_quote;  // any '"' among the valid bytes (false also when m < 32: those chunks take the general path)
+};
+
+// exact per-byte "== c" flags of a 32-bit word, gathered into 4 bits (bit k: byte k)
+DEV uint32_t csv_eq_nibble(uint32_t w, uint32_t c4) {
+  const uint32_t x = w ^ c4;
+  const uint32_t t = ((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x;  // bit 7 of every byte: byte != 0
+  const uint32_t z = ~(t | 0x7F7F7F7Fu) >> 7;                // bits 0, 8, 16, 24: byte == 0
+  return ((z * 0x00204081u) >> 21) & 0xFu;
+}
+
+DEV CsvChunk csv_load_chunk(const uint8_t* __restrict__ buf, uint64_t pos, uint64_t n) {
+  CsvChunk c;
+  c.m = pos >= n ? 0 : (int)((n - pos) < (uint64_t)kCsvChunk ? (n - pos) : (uint64_t)kCsvChunk);
+  c.has_quote = false;
+  if (c.m == 0) {
 #pragma unroll
-  for (int i = 0; i < kCsvChunk; ++i) {
-    if (i < m) {
-      const uint8_t c = (uint8_t)(w[i >> 2] >> ((i & 3) * 8));
-      v = csv_tv_compose(v, csv_tv_of(csv_class(c)));
-    }
+    for (int i = 0; i < 8; ++i) c.w[i] = 0;
+    return c;
   }
+  const uint4 a = *(const uint4*)(buf + pos);  // the buffer is padded to a multiple of 64 bytes
+  const uint4 b = *(const uint4*)(buf + pos + 16);
+  c.w[0] = a.x; c.w[1] = a.y; c.w[2] = a.z; c.w[3] = a.w; c.w[4] = b.x; c.w[5] = b.y; c.w[6] = b.z; c.w[7] = b.w;
+  uint32_t q = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) q |= csv_eq_nibble(c.w[i], 0x22222222u);
+  c.has_quote = q != 0;
+  return c;
+}
+
+DEV uint8_t csv_chunk_byte(const CsvChunk& c, int i) { return (uint8_t)(c.w[i >> 2] >> ((i & 3) * 8)); }
+
+// bit i: byte i is a record terminator (\n or \r) -- only meaningful for the general bytes of a full chunk
+DEV uint32_t csv_chunk_tmask(const CsvChunk& c) {
+  uint32_t t = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) t |= (csv_eq_nibble(c.w[i], 0x0A0A0A0Au) | csv_eq_nibble(c.w[i], 0x0D0D0D0Du)) << (4 * i);
+  return t;
+}
+
+// transition vector of the chunk
+DEV uint32_t csv_chunk_vector(const CsvChunk& c) {
+  if (c.m == kCsvChunk && !c.has_quote) {
+    // no quote in the chunk: every start state but InQuoted ends in the state the LAST byte dictates
+    // (D -> StartField, T -> StartRecord, other -> InField); InQuoted stays InQuoted
+    const uint32_t e = csv_tv_apply(csv_tv_of(csv_class(csv_chunk_byte(c, kCsvChunk - 1))), 2u);
+    return csv_pack5(e, e, e, 3u, e);
+  }
+  uint32_t v = kCsvTvId;
+#pragma unroll
+  for (int i = 0; i < kCsvChunk; ++i)
+    if (i < c.m) v = csv_tv_compose(v, csv_tv_of(csv_class(csv_chunk_byte(c, i))));
   return v;
+}
+
+// bit i: byte i starts a record, given the state before the chunk
+DEV uint32_t csv_chunk_starts(const CsvChunk& c, uint32_t s) {
+  if (c.m == kCsvChunk && !c.has_quote) {
+    if (s == 3u) return 0u;  // the whole chunk is inside a quoted field
+    const uint32_t t = csv_chunk_tmask(c);
+    return ~t & ((t << 1) | (s == 0u ? 1u : 0u));  // a non-terminator right after a terminator / in StartRecord
+  }
+  uint32_t starts = 0;
+  for (int i = 0; i < c.m; ++i) {
+    const uint32_t cls = csv_class(csv_chunk_byte(c, i));
+    if (s == 0u && cls != CSV_T) starts |= 1u << i;
+    s = csv_tv_apply(csv_tv_of(cls), s);
+  }
+  return starts;
 }
 
 // exclusive scan of the transition vectors of a 256-thread block; returns the prefix of this thread and the total
@@ -72,7 +128,7 @@ __global__ __launch_bounds__(kCsvBlock) void k_csv_tile_trans(const uint8_t* __r
                                                              uint32_t* __restrict__ tile_trans) {
   __shared__ uint32_t wave_tot[kCsvBlock / 64];
   const uint64_t pos = (uint64_t)blockIdx.x * kCsvTile + (uint64_t)threadIdx.x * kCsvChunk;
-  const uint32_t v = csv_chunk_vector(buf, pos, n);
+  const uint32_t v = csv_chunk_vector(csv_load_chunk(buf, pos, n));
   uint32_t total;
   (void)csv_block_scan(v, wave_tot, &total);
   if (threadIdx.x == 0) tile_trans[blockIdx.x] = total;
@@ -117,20 +173,12 @@ __global__ __launch_bounds__(kCsvBlock) void k_csv_mark(const uint8_t* __restric
   const int lane = lane_id();
   const int wave = threadIdx.x >> 6;
   const uint64_t pos = (uint64_t)blockIdx.x * kCsvTile + (uint64_t)threadIdx.x * kCsvChunk;
-  const uint32_t v = csv_chunk_vector(buf, pos, n);
+  const CsvChunk chunk = csv_load_chunk(buf, pos, n);
+  const uint32_t v = csv_chunk_vector(chunk);
   uint32_t total;
   const uint32_t pre = csv_block_scan(v, wave_tot, &total);
-  uint32_t s = csv_tv_apply(pre, (uint32_t)tile_state[blockIdx.x]);
-  // replay: a record starts at a non-terminator byte met in state StartRecord
-  uint32_t starts = 0;  // bit i: byte i of the chunk starts a record
-  if (pos < n) {
-    const int m = (int)((n - pos) < (uint64_t)kCsvChunk ? (n - pos) : (uint64_t)kCsvChunk);
-    for (int i = 0; i < m; ++i) {
-      const uint32_t cls = csv_class(buf[pos + i]);
-      if (s == 0u && cls != CSV_T) starts |= 1u << i;
-      s = csv_tv_apply(csv_tv_of(cls), s);
-    }
-  }
+  // replay with the true start state: a record starts at a non-terminator byte met in state StartRecord
+  const uint32_t starts = csv_chunk_starts(chunk, csv_tv_apply(pre, (uint32_t)tile_state[blockIdx.x]));
   const uint32_t cnt = (uint32_t)__popc(starts);
   uint32_t inc = cnt;
 #pragma unroll
@@ -174,31 +222,57 @@ __global__ void k_csv_count_fields(const uint8_t* __restrict__ buf, const uint64
   out[0] = (uint32_t)csv_walk_record(buf, row_start[row], row_start[row + 1], [](int, const CsvField&) {});
 }
 
+// Two phases, so that the expensive part runs convergently:
+//   A  every lane walks its record once and only RECORDS where its cells are (LDS: content offset + length/flags per
+//      column) -- lanes reach their cell ends at different bytes, but the walk itself is a few instructions per byte;
+//   B  a wave-uniform loop over the columns: all 64 lanes convert the cell of the SAME column together (one dtype,
+//      one code path).  Converting inside the walk ran the conversions one lane at a time (measured 6.7x slower).
 __global__ __launch_bounds__(kBlock) void k_csv_parse(const uint8_t* __restrict__ buf,
                                                      const uint64_t* __restrict__ row_start, int64_t r0, int64_t nb,
                                                      const DevCsvPlan plan) {
+  extern __shared__ uint32_t cell_lds[];  // [n_cols][kBlock] content offset, then [n_cols][kBlock] ulen | quoted << 30 | complex << 31
+  uint32_t* cell_off = cell_lds;
+  uint32_t* cell_len = cell_lds + (size_t)plan.n_cols * kBlock;
   const int64_t tid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   const bool inb = tid < nb;
   const int lane = lane_id();
-  uint32_t valid_bits = 0;  // bit c: column c holds a value in this record
-  uint32_t bool_bits = 0;   // bit c: value of a Boolean column
   uint64_t err = ~0ull;
+  uint64_t begin = 0;
+  int nf = 0;
   if (inb) {
-    const uint64_t begin = row_start[r0 + tid], limit = row_start[r0 + tid + 1];
-    const int nf = csv_walk_record(buf, begin, limit, [&](int fi, const CsvField& f) {
-      if (fi >= plan.n_cols) return;
-      const DevCsvCol col = plan.col[fi];
-      if (col.dtype == T_UTF8) {  // Some(s) => append_string(s): never null
-        col.lens[tid] = (int32_t)f.ulen;
-        valid_bits |= 1u << fi;
-        return;
-      }
-      if (f.ulen == 0) return;  // `Some(s) if s.len() > 0` else append_null
+    begin = row_start[r0 + tid];
+    const uint64_t limit = row_start[r0 + tid + 1];
+    const int n_cols = plan.n_cols;
+    nf = csv_walk_record(buf, begin, limit, [&](int fi, const CsvField& f) {
+      if (fi >= n_cols) return;
       uint64_t cb, ce;
       csv_field_span(f, &cb, &ce);
-      int rc = f.complex ? NP_INVALID : NP_OK;  // a number cannot contain a quote; "12"3 (-> 123 in the csv crate) is rejected here
-      const uint8_t* s = buf + cb;
-      const int64_t sl = (int64_t)(ce - cb);
+      (void)ce;
+      cell_off[fi * kBlock + threadIdx.x] = (uint32_t)(cb - begin);
+      cell_len[fi * kBlock + threadIdx.x] = (f.ulen & 0x3FFFFFFFu) | (f.quoted ? 0x40000000u : 0u) | (f.complex ? 0x80000000u : 0u);
+    });
+    if ((uint32_t)nf != plan.expected_fields) {  // csv crate, flexible == false: UnequalLengths
+      const uint64_t e = ((uint64_t)(r0 + tid) << 16) | ((uint64_t)(nf & 0xFF) << 8) | 3ull;
+      err = e < err ? e : err;
+    }
+  }
+  for (int c = 0; c < plan.n_cols; ++c) {  // wave-uniform: one column, one dtype for all lanes
+    const DevCsvCol col = plan.col[c];
+    const bool have = inb && c < nf;  // a record shorter than the schema: `rows[i].get(col)` is None
+    const uint32_t off = have ? cell_off[c * kBlock + threadIdx.x] : 0u;
+    const uint32_t lw = have ? cell_len[c * kBlock + threadIdx.x] : 0u;
+    const uint32_t ulen = lw & 0x3FFFFFFFu;
+    if (col.dtype == T_UTF8) {  // Some(s) => append_string(s): never null ("" when the record is short)
+      if (inb) col.lens[tid] = (int32_t)ulen;
+      continue;
+    }
+    bool valid = false;
+    bool bval = false;
+    if (have && ulen != 0) {  // `Some(s) if s.len() > 0` else append_null
+      // a number cannot contain a quote: "12"3 (-> 123 in the csv crate) is rejected here
+      int rc = (lw & 0x80000000u) ? NP_INVALID : NP_OK;
+      const uint8_t* s = buf + begin + off;
+      const int64_t sl = (int64_t)ulen;  // contiguous content: its length is the unescaped length
       if (rc == NP_OK) {
         switch (col.dtype) {
           case T_F64: {
@@ -214,7 +288,7 @@ __global__ __launch_bounds__(kBlock) void k_csv_parse(const uint8_t* __restrict_
             break;
           }
           case T_BOOL: {
-            if (csv_bytes_equal(s, (uint64_t)sl, "true", 4)) bool_bits |= 1u << fi;
+            if (csv_bytes_equal(s, (uint64_t)sl, "true", 4)) bval = true;
             else if (!csv_bytes_equal(s, (uint64_t)sl, "false", 5)) rc = NP_INVALID;
             break;
           }
@@ -228,24 +302,11 @@ __global__ __launch_bounds__(kBlock) void k_csv_parse(const uint8_t* __restrict_
           }
         }
       }
-      if (rc == NP_OK) valid_bits |= 1u << fi;
+      if (rc == NP_OK) valid = true;
       else {
-        const uint64_t e = ((uint64_t)(r0 + tid) << 16) | ((uint64_t)fi << 8) | (uint64_t)(rc == NP_INVALID ? 1 : 2);
+        const uint64_t e = ((uint64_t)(r0 + tid) << 16) | ((uint64_t)c << 8) | (uint64_t)(rc == NP_INVALID ? 1 : 2);
         err = e < err ? e : err;
       }
-    });
-    if ((uint32_t)nf != plan.expected_fields) {  // csv crate, flexible == false: UnequalLengths
-      const uint64_t e = ((uint64_t)(r0 + tid) << 16) | ((uint64_t)(nf & 0xFF) << 8) | 3ull;
-      err = e < err ? e : err;
-    }
-  }
-  // a record shorter than the schema: `rows[i].get(col)` is None -> null (primitive) / "" (Utf8)
-  for (int c = 0; c < plan.n_cols; ++c) {  // wave-uniform loop
-    const DevCsvCol col = plan.col[c];
-    const bool valid = inb && ((valid_bits >> c) & 1u);
-    if (col.dtype == T_UTF8) {
-      if (inb && !valid) col.lens[tid] = 0;
-      continue;
     }
     if (inb && !valid && col.dtype != T_BOOL) store_typed(col.dtype, col.values, tid, 0ull);
     const uint64_t vm = __ballot(valid);
@@ -256,7 +317,7 @@ __global__ __launch_bounds__(kBlock) void k_csv_parse(const uint8_t* __restrict_
       if (nulls > 0) atomicAdd((unsigned long long*)&plan.null_counts[c], (unsigned long long)nulls);
     }
     if (col.dtype == T_BOOL) {
-      const uint64_t bm = __ballot(valid && ((bool_bits >> c) & 1u));
+      const uint64_t bm = __ballot(valid && bval);
       if (lane == 0) ((uint64_t*)col.values)[tid >> 6] = bm;
     }
   }
@@ -312,7 +373,8 @@ hipError_t launch_csv_parse(const uint8_t* buf, const uint64_t* row_start, int64
   if (nb <= 0) return hipSuccess;
   Scope sc(KID_CSV, s, algo_bytes);
   const int64_t blocks = (nb + kBlock - 1) / kBlock;
-  hipLaunchKernelGGL(k_csv_parse, dim3((unsigned)blocks), dim3(kBlock), 0, s, buf, row_start, r0, nb, plan);
+  const size_t lds = (size_t)plan.n_cols * kBlock * 2 * sizeof(uint32_t);  // <= 32 columns: 64 KB
+  hipLaunchKernelGGL(k_csv_parse, dim3((unsigned)blocks), dim3(kBlock), lds, s, buf, row_start, r0, nb, plan);
   return hipGetLastError();
 }
 
