@@ -68,6 +68,7 @@ EXPORTED_SYMBOLS = [
     "dfx_table_column_device_ptr", "dfx_table_scan_new", "dfx_table_free", "dfx_csv_datasource_new",
     "dfx_aggregate_partial_build", "dfx_aggregate_partial_export", "dfx_aggregate_partial_import",
     "dfx_profile_enable", "dfx_profile_reset", "dfx_profile_count", "dfx_profile_get", "dfx_set_option",
+    "dfx_counter_get", "dfx_counter_reset",
 ]
 
 _lib = None
@@ -143,5 +144,8 @@ def lib() -> ctypes.CDLL:
     L.dfx_profile_get.argtypes = [ctypes.c_int32, ctypes.c_char_p, ctypes.c_size_t, P(ctypes.c_int64),
                                   P(ctypes.c_double), P(ctypes.c_double)]
     L.dfx_set_option.argtypes = [ctypes.c_char_p, ctypes.c_int64]
+    L.dfx_counter_get.argtypes = [ctypes.c_char_p]
+    L.dfx_counter_get.restype = ctypes.c_int64
+    L.dfx_counter_reset.restype = None
     _lib = L
     return L

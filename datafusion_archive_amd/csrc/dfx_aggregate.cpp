@@ -1012,6 +1012,14 @@ AggregateRelation::AggregateRelation(SchemaInfo schema, std::unique_ptr<Relation
   }
   m.input = std::move(input);
   m.deferred = m.setup(m.input->schema());
+  if (m.deferred.ok()) {  // projection push-down: predicate, key and argument columns only (incl. the Utf8 key sources)
+    std::vector<char> needed(m.input->schema().fields.size(), 0);
+    for (int ci : m.builder->columns())
+      if (ci >= 0 && ci < (int)needed.size()) needed[ci] = 1;
+    for (const Impl::DictKey& d : m.dicts)
+      if (d.src_col >= 0 && d.src_col < (int)needed.size()) needed[d.src_col] = 1;
+    m.input->require_columns(needed);
+  }
   // output schema: group columns then aggregates (aggregate.rs:894-949); context.rs:185 passes
   // Schema::empty(), so derive names/types from the expressions when none is given
   SchemaInfo derived;

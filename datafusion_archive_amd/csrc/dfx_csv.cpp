@@ -27,6 +27,7 @@ class CsvRelation : public Relation {
   RelationKind kind() const override { return REL_CSV; }
   const SchemaInfo& schema() const override { return schema_; }
   Status next(DeviceBatch* out, bool* has) override;
+  void require_columns(const std::vector<char>& needed) override { needed_ = needed; }
   Status open();  // File::open(filename).unwrap() happens in the constructor of the reference: so does this
 
  private:
@@ -42,6 +43,7 @@ class CsvRelation : public Relation {
   uint32_t expected_fields_ = 0;
   int64_t next_record_ = 1;          // record 0 is the header
   bool indexed_ = false;
+  std::vector<char> needed_;  // projection push-down: cells of other columns are located but not converted
 };
 
 Status CsvRelation::open() {
@@ -214,7 +216,13 @@ Status CsvRelation::next(DeviceBatch* out, bool* has) {
     DeviceColumn& col = out->columns[c];
     col.dtype = schema_.fields[c].dtype;
     col.length = nb;
+    if ((size_t)c < needed_.size() && !needed_[c]) {
+      col.absent = true;
+      plan.col[c].dtype = T_NONE;
+      continue;
+    }
     plan.col[c].dtype = (uint8_t)col.dtype;
+    counters().csv_cells += nb;
     if (col.dtype == DFX_UTF8) {
       lens[c] = device_alloc(sizeof(int32_t) * (size_t)(nb + 1), &st);
       if (!lens[c]) return st;
@@ -242,6 +250,7 @@ Status CsvRelation::next(DeviceBatch* out, bool* has) {
   if (hc[(size_t)nc] != ~0ull) return cell_error(hc[(size_t)nc]);
   for (int c = 0; c < nc; ++c) {
     DeviceColumn& col = out->columns[c];
+    if (col.absent) continue;
     if (col.dtype != DFX_UTF8) {
       col.null_count = (int64_t)hc[(size_t)c];
       if (col.null_count == 0) col.validity = nullptr;

@@ -259,6 +259,11 @@ std::shared_ptr<void> pool_alloc(Pool& pool, size_t bytes, Status* st) {
 }
 }  // namespace
 
+Counters& counters() {
+  static Counters c;
+  return c;
+}
+
 std::shared_ptr<void> device_alloc(size_t bytes, Status* st) { return pool_alloc(dev_pool(), bytes, st); }
 std::shared_ptr<void> pinned_alloc(size_t bytes, Status* st) { return pool_alloc(pin_pool(), bytes, st); }
 void pool_trim() {

@@ -78,6 +78,12 @@ struct Context {
 };
 Context& ctx();
 Status ensure_init();
+// measurement: bytes of column data copied host -> device by the uploaders (dfx_counter_get("h2d_bytes"))
+struct Counters {
+  long long h2d_bytes = 0;
+  long long csv_cells = 0;  // cells converted by the CSV source
+};
+Counters& counters();
 
 // pooled device memory (hipMalloc is ~100 us; operators allocate per batch)
 std::shared_ptr<void> device_alloc(size_t bytes, Status* st);
@@ -97,6 +103,7 @@ struct DeviceColumn {
   const uint8_t* data = nullptr;     // Utf8: indexed by the raw offsets
   int64_t data_bytes = 0;            // Utf8: bytes referenced (offsets[length] - offsets[0])
   std::vector<std::shared_ptr<void>> owners;  // keeps the buffers alive
+  bool absent = false;  // projection push-down: the consumer declared it never reads this column (no buffers)
 };
 
 struct DeviceBatch {
@@ -113,6 +120,11 @@ struct Relation {
   // Ok(Some(batch)) -> *has = true; Ok(None) -> *has = false
   virtual Status next(DeviceBatch* out, bool* has) = 0;
   virtual const SchemaInfo& schema() const = 0;
+  // Projection push-down (the rule the reference has written but switched off: sqlplanner.rs:433-539, context.rs:89;
+  // TableScan.projection logicalplan.rs:340-345).  A consumer tells its input which of the input's columns it will
+  // ever read; the producer may then leave the others `absent` (not uploaded / not parsed / not compacted).  Without
+  // a call every column is produced.  needed.size() == schema().fields.size().
+  virtual void require_columns(const std::vector<char>& needed) { (void)needed; }
 };
 
 // ---- expressions (dfx_expr.cpp) ---------------------------------------------------------------

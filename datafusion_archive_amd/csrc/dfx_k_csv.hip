@@ -258,6 +258,7 @@ __global__ __launch_bounds__(kBlock) void k_csv_parse(const uint8_t* __restrict_
   }
   for (int c = 0; c < plan.n_cols; ++c) {  // wave-uniform: one column, one dtype for all lanes
     const DevCsvCol col = plan.col[c];
+    if (col.dtype == T_NONE) continue;  // projection push-down: nobody reads this column
     const bool have = inb && c < nf;  // a record shorter than the schema: `rows[i].get(col)` is None
     const uint32_t off = have ? cell_off[c * kBlock + threadIdx.x] : 0u;
     const uint32_t lw = have ? cell_len[c * kBlock + threadIdx.x] : 0u;

@@ -42,6 +42,7 @@ class HostStreamRelation : public Relation {
   }
 
   const SchemaInfo& schema() const override { return schema_; }
+  void require_columns(const std::vector<char>& needed) override { needed_ = needed; }
 
   Status next(DeviceBatch* out, bool* has) override {
     *has = false;
@@ -74,6 +75,7 @@ class HostStreamRelation : public Relation {
     *dev = device_alloc(bytes ? bytes : 8, &st);
     if (!*dev) return st;
     if (bytes) DFX_HIP(hipMemcpyAsync(dev->get(), host, bytes, hipMemcpyHostToDevice, ctx().stream));
+    counters().h2d_bytes += (long long)bytes;
     return Status::OK();
   }
 
@@ -91,6 +93,10 @@ class HostStreamRelation : public Relation {
       const int64_t n = arr.length;
       d.dtype = dt;
       d.length = n;
+      if (ci < needed_.size() && !needed_[ci]) {  // projection push-down: never read downstream, so never crosses PCIe
+        d.absent = true;
+        continue;
+      }
       d.bit_offset = off & 7;
       const uint8_t* validity = (c->n_buffers > 0) ? (const uint8_t*)c->buffers[0] : nullptr;
       if (validity && c->null_count != 0) {
@@ -135,6 +141,7 @@ class HostStreamRelation : public Relation {
 
   struct ArrowArrayStream stream_;
   SchemaInfo schema_;
+  std::vector<char> needed_;
 };
 
 // =================================================================================================
@@ -393,6 +400,17 @@ FilterRelation::FilterRelation(std::unique_ptr<Relation> input, const dfx_runtim
   if (deferred_.ok()) builder_->build_fast(pred_operand_, nullptr, 0, nullptr, 0, &fast_);
 }
 
+// the consumer reads only `needed` of the filter's output columns: the input must still deliver the predicate's
+// columns, and only the needed ones are compacted
+void FilterRelation::require_columns(const std::vector<char>& needed) {
+  out_needed_ = needed;
+  std::vector<char> in_needed = needed;
+  in_needed.resize(input_->schema().fields.size(), 1);
+  for (int ci : builder_->columns())
+    if (ci >= 0 && ci < (int)in_needed.size()) in_needed[ci] = 1;
+  input_->require_columns(in_needed);
+}
+
 static Status alloc_zeroed_ctrl(std::shared_ptr<void>* ctrl) {
   Status st;
   *ctrl = device_alloc(sizeof(uint32_t) * CTRL_WORDS, &st);
@@ -454,12 +472,18 @@ Status FilterRelation::next(DeviceBatch* out, bool* has) {
     return error_from_ctrl(errbits);
   }
   const int64_t m = (int64_t)kept;
+  for (size_t c = 0; c < in.columns.size(); ++c)  // fn filter errs for the batch whatever is projected later
+    if (in.columns[c].dtype == DFX_BOOLEAN) return Status::Err(DFX_EXECUTION_ERROR, "filter not supported for Boolean");  // filter.rs:105-108
   for (size_t c = 0; c < in.columns.size(); ++c) {  // fn filter per column (filter.rs:55-57)
     const DeviceColumn& ic = in.columns[c];
     DeviceColumn& oc = out->columns[c];
     oc.dtype = ic.dtype;
     oc.length = m;
     oc.null_count = 0;  // value nulls are ignored: the output is all-valid (filter.rs:83-92)
+    if (ic.absent || (c < out_needed_.size() && !out_needed_[c])) {  // projection push-down: nobody reads it
+      oc.absent = true;
+      continue;
+    }
     if (ic.dtype == DFX_UTF8) {
       // lengths + starts -> compact both -> scan lengths -> gather bytes
       auto lens = device_alloc(sizeof(int32_t) * (size_t)n, &st);
@@ -564,6 +588,15 @@ ProjectRelation::ProjectRelation(std::unique_ptr<Relation> input, std::vector<df
       schema_.fields[i].nullable = true;
       if (schema_.fields[i].name.empty()) schema_.fields[i].name = derived.fields[i].name;
     }
+  }
+  if (deferred_.ok()) {  // projection push-down: the input only has to produce what the expressions read
+    std::vector<char> needed(input_->schema().fields.size(), 0);
+    for (int pcol : passthrough_)
+      if (pcol >= 0 && pcol < (int)needed.size()) needed[pcol] = 1;
+    for (const Group& g : groups_)
+      for (int ci : g.builder->columns())
+        if (ci >= 0 && ci < (int)needed.size()) needed[ci] = 1;
+    input_->require_columns(needed);
   }
 }
 

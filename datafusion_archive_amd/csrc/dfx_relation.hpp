@@ -46,6 +46,7 @@ class FilterRelation : public Relation {
   RelationKind kind() const override { return REL_FILTER; }
   Status next(DeviceBatch* out, bool* has) override;
   const SchemaInfo& schema() const override { return schema_; }
+  void require_columns(const std::vector<char>& needed) override;
   // for Filter -> Aggregate fusion
   std::unique_ptr<Relation> release_input() { return std::move(input_); }
   const dfx_runtime_expr& predicate() const { return expr_; }
@@ -60,6 +61,7 @@ class FilterRelation : public Relation {
   DevFastPlan fast_;
   Status deferred_;  // evaluation-time type errors of the reference surface on next()
   std::shared_ptr<void> ctrl_;
+  std::vector<char> out_needed_;  // empty: every column is compacted
 };
 
 // ---- ProjectRelation (src/execution/projection.rs) ----------------------------------------------

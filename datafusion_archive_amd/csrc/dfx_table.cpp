@@ -229,6 +229,14 @@ int32_t dfx_profile_get(int32_t index, char* name, size_t namelen, int64_t* laun
   return DFX_OK;
 }
 
+int64_t dfx_counter_get(const char* name) {
+  if (!name) return -1;
+  if (!strcmp(name, "h2d_bytes")) return counters().h2d_bytes;
+  if (!strcmp(name, "csv_cells")) return counters().csv_cells;
+  return -1;
+}
+void dfx_counter_reset(void) { counters() = Counters(); }
+
 int32_t dfx_set_option(const char* key, int64_t value) {
   if (!key) return DFX_GENERAL;
   AggOptions& o = agg_options();

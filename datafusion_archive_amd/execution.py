@@ -369,6 +369,14 @@ def set_option(key: str, value: int) -> None:
         raise ExecutionError(3, f"unknown option {key}")
 
 
+def counter_get(name: str) -> int:
+    return int(_ffi.lib().dfx_counter_get(name.encode()))
+
+
+def counter_reset() -> None:
+    _ffi.lib().dfx_counter_reset()
+
+
 def profile_enable(on: bool) -> None:
     _ffi.lib().dfx_profile_enable(1 if on else 0)
 

@@ -321,6 +321,10 @@ int32_t dfx_profile_get(int32_t index, char* name, size_t namelen, int64_t* laun
 /* Tunables (bench/test only).  Known keys: "agg.strategy" (0 auto, 1 global-atomic table,
  * 2 LDS partial tables, 3 partitioned), "agg.capacity_log2", "batch.rows". */
 int32_t dfx_set_option(const char* key, int64_t value);
+/* Measurement counters: "h2d_bytes" (column bytes the uploaders copied host -> device), "csv_cells" (cells the CSV
+ * source converted) -- what projection push-down saves.  -1: unknown name. */
+int64_t dfx_counter_get(const char* name);
+void dfx_counter_reset(void);
 
 #ifdef __cplusplus
 }

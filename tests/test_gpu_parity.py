@@ -779,3 +779,53 @@ def test_large_properties_filter_groupby_sum():
     assert abs(total.column(1)[0].as_py() / n - 0.2) < 1e-3
     # spot-check 64 groups against the oracle restricted to the first 2^22 rows' keys is not
     # meaningful at this size; the per-key check lives in test_resident_table_group_by_1m_keys_vs_oracle
+
+
+# ---------------------------------------------------------------------------------------------------
+# projection push-down (the reference's rule is written but switched off:
+# sqlplanner.rs:433-539, context.rs:89): consumers tell their input which columns they read
+# ---------------------------------------------------------------------------------------------------
+def _wide_batch(rng, n):
+    base = _exact_batch(rng, n, 50)
+    extra = [pa.array([f"city {i % 97}" for i in range(n)]), pa.array(rng.random(n)), pa.array(rng.integers(0, 9, n).astype(np.int64))]
+    return pa.RecordBatch.from_arrays(list(base.columns) + extra, names=list(base.schema.names) + ["name", "x", "y"])
+
+
+def test_projection_pushdown_aggregate_uploads_only_referenced_columns():
+    rng = np.random.default_rng(31)
+    batches = [_wide_batch(rng, 30000) for _ in range(2)]
+    schema = batches[0].schema
+    aggs = [agg("sum", Column(1), F64), agg("count", Column(1), DataType.UInt64)]
+    pred = BinaryExpr(Column(1), Operator.Gt, lit(300.0))
+    ex.counter_reset()
+    got = gpu_aggregate([Column(0)], aggs, schema, batches, filter_expr=pred)
+    moved = ex.counter_get("h2d_bytes")
+    want = oracle.aggregate([Column(0)], aggs, [oracle.filter_next(pred, b) for b in batches])
+    assert_groups_identical(got, want, 1, "push-down aggregate")
+    # only k (8 B) and v (8 B) cross PCIe: 16 B/row of the 52+ B/row the batches hold (i, f, name, x, y stay on the host)
+    assert moved == 2 * 30000 * 16, moved
+
+
+def test_projection_pushdown_filter_project_compacts_only_projected_columns():
+    rng = np.random.default_rng(32)
+    batches = [_wide_batch(rng, 20000)]
+    schema = batches[0].schema
+    pred = BinaryExpr(Column(5), Operator.Lt, lit(0.25))  # predicate on x, output name and v + 1
+    exprs = [Column(4), BinaryExpr(Column(1), Operator.Plus, lit(1.0))]
+    ex.counter_reset()
+    got = gpu_project(exprs, schema, batches, filter_expr=pred)
+    moved = ex.counter_get("h2d_bytes")
+    want = [oracle.project_next(exprs, oracle.filter_next(pred, b)) for b in batches]
+    assert len(got) == len(want)
+    for g, w in zip(got, want):
+        assert_batches_identical(g, w, "push-down filter+project")
+    name_bytes = sum(len(s) for s in batches[0].column(4).to_pylist()) + 4 * (20000 + 1)
+    assert moved == 20000 * 16 + name_bytes, (moved, name_bytes)  # v, x and the Utf8 column; not k, i, f, y
+
+
+def test_projection_pushdown_keeps_filter_errors():
+    # fn filter errs for a Boolean column of the batch whatever is projected afterwards (filter.rs:105-108)
+    b = pa.RecordBatch.from_arrays([pa.array([1.0, 2.0]), pa.array([True, False])], names=["v", "flag"])
+    with pytest.raises(ex.ExecutionError) as ei:
+        gpu_project([Column(0)], b.schema, [b], filter_expr=BinaryExpr(Column(0), Operator.Gt, lit(0.0)))
+    assert "filter not supported" in ei.value.message
