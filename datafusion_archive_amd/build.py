@@ -29,6 +29,7 @@ HEADERS = ["dfx_device.hpp", "dfx_sigs.hpp", "dfx_numparse.hpp", "dfx_pow5_table
 # -munsafe-fp-atomics: hardware global_atomic_add_f64 / ds_add_f64 instead of CAS loops
 CXXFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
             "-munsafe-fp-atomics", "-Wall", "-Wno-unused-result", "-fno-gpu-rdc"]
+CXXFLAGS += os.environ.get("DFX_EXTRA_CXXFLAGS", "").split()  # debug builds (e.g. -DDFX_PA_TIMING)
 
 
 def _hipcc() -> str:

@@ -634,6 +634,9 @@ __global__ __launch_bounds__(kABlock) void k_partition_agg(const DevTable T, con
   const uint32_t p = blockIdx.x;
   const uint64_t slot0 = (uint64_t)p * S;
   const int lane = lane_id();
+#ifdef DFX_PA_TIMING
+  const long long tt0 = wall_clock64();
+#endif
   // block -> LDS, 16-byte loads, all loads of a plane in flight before the LDS writes (S is a power of two >= 2)
   for (int w = 0; w < NW; ++w) {
     const uint64_t* src = (w == 0 ? T.keys : T.accs + (uint64_t)(w - 1) * T.stride) + slot0;
@@ -661,6 +664,9 @@ __global__ __launch_bounds__(kABlock) void k_partition_agg(const DevTable T, con
   }
   if (lane == 63) wave_tot[threadIdx.x >> 6] = inc;
   __syncthreads();
+#ifdef DFX_PA_TIMING
+  const long long tt1 = wall_clock64();
+#endif
   uint32_t base = 0, total = 0;
 #pragma unroll
   for (int w = 0; w < kABlock / 64; ++w) {
@@ -684,19 +690,30 @@ __global__ __launch_bounds__(kABlock) void k_partition_agg(const DevTable T, con
       k[r][0] = 0;
 #pragma unroll
       for (int a = 0; a < NV; ++a) v[r][a] = 0;
-      if (ib[r]) {
+      if (NA1) {
+        // unconditional load (idle lanes re-read the partition's first row): a branch around it makes the compiler
+        // wait with vmcnt(0) -- a full memory round trip per trip -- instead of counting the loads in flight
+        const uint64_t* src = PT.rows + (uint64_t)p * PT.part_stride;
+        if (ib[r]) {
+          // producer of flattened row i: the counts are near-uniform, so interpolate and correct
+          uint32_t lo = (uint32_t)((float)i * inv);
+          if (lo >= NP) lo = NP - 1;
+          while (pre[lo] > i) --lo;
+          while (pre[lo + 1] <= i) ++lo;
+          src = region_row(PT, p, lo, i - pre[lo]);
+        }
+        typedef uint64_t u64x2_t __attribute__((ext_vector_type(2)));
+        const u64x2_t kv = __builtin_nontemporal_load((const u64x2_t*)src);
+        k[r][0] = ib[r] ? kv.x : 0ull;
+        v[r][0] = ib[r] ? kv.y : 0ull;
+      } else if (ib[r]) {
         // producer of flattened row i: the counts are near-uniform, so interpolate and correct
         uint32_t lo = (uint32_t)((float)i * inv);
         if (lo >= NP) lo = NP - 1;
         while (pre[lo] > i) --lo;
         while (pre[lo + 1] <= i) ++lo;
         const uint64_t* src = region_row(PT, p, lo, i - pre[lo]);
-        if (NA1) {
-          typedef uint64_t u64x2_t __attribute__((ext_vector_type(2)));
-          const u64x2_t kv = __builtin_nontemporal_load((const u64x2_t*)src);
-          k[r][0] = kv.x;
-          v[r][0] = kv.y;
-        } else {
+        {
           k[r][0] = src[0];
 #pragma unroll
           for (int a = 0; a < NV; ++a)
@@ -705,6 +722,9 @@ __global__ __launch_bounds__(kABlock) void k_partition_agg(const DevTable T, con
       }
     }
   };
+#ifdef DFX_PA_TIMING
+  const long long tt2 = wall_clock64();
+#endif
   fetch(0, nkey, nval, ninb);
   for (uint32_t i0 = 0; i0 < total; i0 += kABlock * RU) {  // wave-uniform trip count
 #pragma unroll
@@ -767,7 +787,13 @@ __global__ __launch_bounds__(kABlock) void k_partition_agg(const DevTable T, con
       }
     }
   }
+#ifdef DFX_PA_TIMING
+  const long long tt3 = wall_clock64();
+#endif
   __syncthreads();
+#ifdef DFX_PA_TIMING
+  const long long tt4 = wall_clock64();
+#endif
   for (int w = 0; w < NW; ++w) {
     uint64_t* dst = (w == 0 ? T.keys : T.accs + (uint64_t)(w - 1) * T.stride) + slot0;
     const uint64_t* src = lds + (size_t)w * S;
@@ -776,6 +802,11 @@ __global__ __launch_bounds__(kABlock) void k_partition_agg(const DevTable T, con
 #pragma unroll
   for (int mm = 32; mm >= 1; mm >>= 1) new_keys += __shfl_xor(new_keys, mm, 64);
   if (lane == 0 && new_keys) atomicAdd(&T.ctrl[CTRL_OCCUPIED], new_keys);
+#ifdef DFX_PA_TIMING
+  if ((threadIdx.x == 0 || threadIdx.x == 1023) && (p == 0 || p == 100 || p == 255))
+    printf("PA p=%u t=%u total=%u: load %lld prefix %lld loop %lld barrier %lld store %lld (100MHz ticks)\n", p, threadIdx.x, total,
+           tt1 - tt0, tt2 - tt1, tt3 - tt2, tt4 - tt3, wall_clock64() - tt4);
+#endif
 }
 
 size_t partition_stage_bytes(const DevPartition& PT) {
