@@ -66,6 +66,7 @@ EXPORTED_SYMBOLS = [
     "dfx_filter_relation_new", "dfx_project_relation_new", "dfx_aggregate_relation_new",
     "dfx_table_from_stream", "dfx_table_synth", "dfx_table_num_rows", "dfx_table_num_columns",
     "dfx_table_column_device_ptr", "dfx_table_scan_new", "dfx_table_free", "dfx_csv_datasource_new",
+    "dfx_sort_relation_new", "dfx_limit_relation_new",
     "dfx_aggregate_partial_build", "dfx_aggregate_partial_export", "dfx_aggregate_partial_import",
     "dfx_profile_enable", "dfx_profile_reset", "dfx_profile_count", "dfx_profile_get", "dfx_set_option",
     "dfx_counter_get", "dfx_counter_reset",
@@ -134,6 +135,9 @@ def lib() -> ctypes.CDLL:
     L.dfx_table_scan_new.argtypes = [ctypes.c_void_p, ctypes.c_int64, P(ArrowArrayStream)] + c_err
     L.dfx_table_free.argtypes = [ctypes.c_void_p]
     L.dfx_table_free.restype = None
+    L.dfx_sort_relation_new.argtypes = [P(ArrowArrayStream), P(ctypes.c_void_p), P(ctypes.c_int32), ctypes.c_int32,
+                                        P(ArrowSchema), P(ArrowArrayStream)] + c_err
+    L.dfx_limit_relation_new.argtypes = [P(ArrowArrayStream), ctypes.c_int64, P(ArrowSchema), P(ArrowArrayStream)] + c_err
     L.dfx_csv_datasource_new.argtypes = [ctypes.c_char_p, P(ArrowSchema), ctypes.c_int64, P(ArrowArrayStream)] + c_err
     L.dfx_aggregate_partial_build.argtypes = [P(ArrowArrayStream), ctypes.c_int32, P(ctypes.c_int32),
                                               P(ctypes.c_int64)] + c_err

@@ -111,7 +111,7 @@ struct DeviceBatch {
   std::vector<DeviceColumn> columns;
 };
 
-enum RelationKind { REL_HOST_STREAM, REL_TABLE_SCAN, REL_FILTER, REL_PROJECT, REL_AGGREGATE, REL_CSV };
+enum RelationKind { REL_HOST_STREAM, REL_TABLE_SCAN, REL_FILTER, REL_PROJECT, REL_AGGREGATE, REL_CSV, REL_SORT, REL_LIMIT };
 
 // trait Relation (src/execution/relation.rs:27-32)
 struct Relation {

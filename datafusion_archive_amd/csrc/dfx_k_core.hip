@@ -478,7 +478,7 @@ __global__ __launch_bounds__(kBlock) void k_synth(int kind, int column_id, doubl
 // =============================================================================================
 static const char* kKernelNames[KID_COUNT_] = {
     "predicate_mask", "compact", "project", "reduce_all", "hash_agg", "merge_rows", "rehash",
-    "emit_mask", "finalize", "scan", "synth", "fill", "gather_utf8", "partial", "partition", "partition_agg", "csv"};
+    "emit_mask", "finalize", "scan", "synth", "fill", "gather_utf8", "partial", "partition", "partition_agg", "csv", "sort"};
 const char* kernel_name(int kid) { return (kid >= 0 && kid < KID_COUNT_) ? kKernelNames[kid] : "?"; }
 
 namespace {

@@ -29,6 +29,7 @@ enum KernelId : int {
   KID_PARTITION,
   KID_PARTITION_AGG,
   KID_CSV,
+  KID_SORT,
   KID_COUNT_
 };
 const char* kernel_name(int kid);
@@ -154,6 +155,24 @@ hipError_t launch_csv_parse(const uint8_t* buf, const uint64_t* row_start, int64
                             const DevCsvPlan& plan, double algo_bytes, hipStream_t s);
 hipError_t launch_csv_utf8_gather(const uint8_t* buf, const uint64_t* row_start, int64_t r0, int64_t nb, int field,
                                   const int32_t* offsets, uint8_t* out, hipStream_t s);
+
+// ORDER BY (dfx_k_sort.hip): order-preserving key images, stable LSD radix sort of (image, row) pairs, gathers
+hipError_t launch_sort_image(const void* values, const uint8_t* validity, int64_t bit_offset, uint8_t dtype, int asc, int64_t n,
+                             uint64_t* image, uint64_t* null_image, hipStream_t s);
+hipError_t launch_sort_iota(uint32_t* idx, int64_t n, hipStream_t s);
+hipError_t launch_sort_gather_u64(const uint64_t* src, const uint32_t* idx, int64_t n, uint64_t* dst, hipStream_t s);
+hipError_t launch_radix_hist8(const uint64_t* img, int64_t n, uint64_t* hist /* [8][256], zeroed */, hipStream_t s);
+int64_t radix_tiles(int64_t n);  // counts / offsets hold 256 * radix_tiles(n) entries, digit-major
+hipError_t launch_radix_count(const uint64_t* img, int64_t n, int shift, uint32_t* counts, hipStream_t s);
+hipError_t launch_radix_scatter(const uint64_t* img_in, const uint32_t* idx_in, int64_t n, int shift, const uint64_t* offsets,
+                                uint64_t* img_out, uint32_t* idx_out, hipStream_t s);
+hipError_t launch_sort_locate(const uint32_t* idx, int64_t n, const uint64_t* starts, int nb, uint64_t* loc, hipStream_t s);
+hipError_t launch_gather_fixed(const void* const* bases, const uint64_t* loc, int64_t n, int width, void* out, hipStream_t s);
+hipError_t launch_gather_bits(const uint8_t* const* bases, const int64_t* bit_offsets, const uint64_t* loc, int64_t n,
+                              uint64_t* out, uint64_t* zero_count, hipStream_t s);
+hipError_t launch_gather_utf8_lens(const int32_t* const* offsets, const uint64_t* loc, int64_t n, int32_t* lens, hipStream_t s);
+hipError_t launch_gather_utf8_copy(const int32_t* const* offsets, const uint8_t* const* data, const uint64_t* loc, int64_t n,
+                                   const int32_t* dst_offsets, uint8_t* out, hipStream_t s);
 
 // synthetic columns (definition shared with oracle/dfx_oracle.c: orc_synth_fill)
 hipError_t launch_synth(int kind, int column_id, double p0, double p1, uint64_t seed, int64_t row_begin,

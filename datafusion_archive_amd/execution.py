@@ -235,6 +235,41 @@ class ProjectRelation(Relation):
         self._keep = [input, list(expr)]
 
 
+class SortRelation(Relation):
+    """The operator behind LogicalPlan::Sort (logicalplan.rs:327-332; the reference's executor has none, context.rs:113).
+    `sort_expr`: [(RuntimeExpr of the inner expression of Expr::Sort, asc)]."""
+
+    def __init__(self, input: Relation, sort_expr: Sequence[tuple], schema: Optional[pa.Schema] = None):
+        super().__init__()
+        cs = _export_schema(schema)
+        hs = (ctypes.c_void_p * max(1, len(sort_expr)))(*[e._h for e, _ in sort_expr])
+        asc = (ctypes.c_int32 * max(1, len(sort_expr)))(*[1 if a else 0 for _, a in sort_expr])
+        err = _errbuf()
+        try:
+            code = _ffi.lib().dfx_sort_relation_new(ctypes.byref(input._take_stream()), hs, asc, len(sort_expr),
+                                                    ctypes.byref(cs), ctypes.byref(self._stream), err, 1024)
+        finally:
+            _release_schema(cs)
+        _check(code, err)
+        self._keep = [input] + [e for e, _ in sort_expr]
+
+
+class LimitRelation(Relation):
+    """The operator behind LogicalPlan::Limit { limit, input, schema } (logicalplan.rs:313-318)."""
+
+    def __init__(self, input: Relation, limit: int, schema: Optional[pa.Schema] = None):
+        super().__init__()
+        cs = _export_schema(schema)
+        err = _errbuf()
+        try:
+            code = _ffi.lib().dfx_limit_relation_new(ctypes.byref(input._take_stream()), limit, ctypes.byref(cs),
+                                                     ctypes.byref(self._stream), err, 1024)
+        finally:
+            _release_schema(cs)
+        _check(code, err)
+        self._keep = [input]
+
+
 class AggregateRelation(Relation):
     """aggregate::AggregateRelation::new(schema, input, group_expr, aggr_expr) (aggregate.rs:47-52)."""
 

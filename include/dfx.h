@@ -285,6 +285,22 @@ int32_t dfx_csv_datasource_new(const char* filename, const struct ArrowSchema* s
                                struct ArrowArrayStream* out, char* err, size_t errlen);
 
 /* ------------------------------------------------------------------------------------------
+ * ORDER BY / LIMIT.  The operators behind LogicalPlan::Sort { expr: [Expr::Sort { expr, asc }], input, schema } and
+ * LogicalPlan::Limit { limit, input, schema } (src/logicalplan.rs:313-338), which the reference's planner emits
+ * (sqlplanner.rs:142-183) and its executor leaves at unimplemented!() (context.rs:113,194): there is no reference
+ * behaviour, the semantics are this library's (parity unpinned): stable sort, NULL larger than every value (last
+ * when ascending, first when descending), NaN larger than every number, ONE result batch.  `exprs` are the sort
+ * expressions compiled with dfx_compile_scalar_expr (the inner `expr` of Expr::Sort; compile_scalar_expr itself
+ * rejects Expr::Sort like the reference, expression.rs:380-399), `ascending[i]` their direction.  Keys of a
+ * fixed-width type; Utf8 keys are DFX_NOT_IMPLEMENTED.  LIMIT keeps the first `limit` rows of the stream.
+ * ---------------------------------------------------------------------------------------- */
+int32_t dfx_sort_relation_new(struct ArrowArrayStream* input, const dfx_runtime_expr* const* exprs,
+                              const int32_t* ascending, int32_t n_exprs, const struct ArrowSchema* schema,
+                              struct ArrowArrayStream* out, char* err, size_t errlen);
+int32_t dfx_limit_relation_new(struct ArrowArrayStream* input, int64_t limit, const struct ArrowSchema* schema,
+                               struct ArrowArrayStream* out, char* err, size_t errlen);
+
+/* ------------------------------------------------------------------------------------------
  * Multi-GPU GROUP BY exchange (no reference equivalent: the reference is single-process).
  * One process per GPU.  After draining its local input, an aggregate stream exports its partial
  * groups bucketed by hash(key) % world into one contiguous device buffer per payload word; the

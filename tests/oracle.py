@@ -323,3 +323,41 @@ def read_csv(filename: str, schema: pa.Schema, batch_size: int = 1024) -> List[p
     finally:
         L.orc_csv_close(h)
     return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# ORDER BY / LIMIT (LogicalPlan::Sort / Limit, logicalplan.rs:313-338).  The reference's executor has neither
+# (context.rs:113,194: unimplemented!()), so this restates the SEMANTICS THE LIBRARY DEFINES, independently and
+# naively (pure Python, small inputs only) -- PARITY UNPINNED: stable; NULL larger than every value; NaN larger than
+# every number; one result batch.
+# ---------------------------------------------------------------------------------------------------
+def sort_batches(batches: Sequence[pa.RecordBatch], keys: Sequence[tuple]) -> Optional[pa.RecordBatch]:
+    """keys: [(Expr, asc)] -- the inner expressions of Expr::Sort, evaluated with the oracle's own evaluator."""
+    batches = [b for b in batches if b.num_rows]
+    if not batches:
+        return None
+    table = pa.Table.from_batches(batches).combine_chunks()
+    key_cols = []
+    for e, _asc in keys:
+        key_cols.append(pa.concat_arrays([eval_expr(e, b) for b in batches]).to_pylist())
+    order = list(range(table.num_rows))
+    for (_e, asc), col in reversed(list(zip(keys, key_cols))):  # least significant key first, stable sorts
+        def rank(i, col=col):
+            v = col[i]
+            if v is None:
+                return (1, 0, 0)
+            if isinstance(v, float) and v != v:
+                return (0, 1, 0)
+            return (0, 0, v)
+        order = sorted(order, key=rank, reverse=not asc)  # reverse=True keeps the input order of equal elements
+    return table.take(pa.array(order, pa.int64())).to_batches()[0] if table.num_rows else None
+
+
+def limit_batches(batches: Sequence[pa.RecordBatch], limit: int) -> List[pa.RecordBatch]:
+    out, left = [], limit
+    for b in batches:
+        if left <= 0:
+            break
+        out.append(b.slice(0, min(left, b.num_rows)))
+        left -= out[-1].num_rows
+    return out

@@ -1,0 +1,119 @@
+"""GPU tests of ORDER BY / LIMIT.  The reference plans them (sqlplanner.rs:142-183) but
+cannot execute them (context.rs:113,194), so parity is against the semantics the library defines, restated naively in
+tests/oracle.py (sort_batches / limit_batches) -- unpinned -- plus order properties at sizes the oracle cannot do."""
+import os
+import sys
+
+import numpy as np
+import pyarrow as pa
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import fixtures  # noqa: E402
+import oracle  # noqa: E402
+from gpu_util import assert_batches_identical  # noqa: E402
+
+from datafusion_archive_amd import execution as ex  # noqa: E402
+from datafusion_archive_amd.logicalplan import BinaryExpr, Column, Literal, Operator, ScalarValue  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def lit(v):
+    return Literal(ScalarValue.Float64(float(v)))
+
+
+def gpu_sort(batches, schema, keys, limit=None):
+    rel = ex.DataSourceRelation(schema, batches)
+    rel = ex.SortRelation(rel, [(ex.compile_scalar_expr(None, e, schema), asc) for e, asc in keys], schema)
+    if limit is not None:
+        rel = ex.LimitRelation(rel, limit, schema)
+    return list(rel)
+
+
+def _mixed_batch(rng, n, with_nulls):
+    a = rng.integers(-5, 5, n).astype(np.int64)
+    f = rng.standard_normal(n)
+    f[rng.random(n) < 0.05] = np.nan
+    f[rng.random(n) < 0.05] = np.inf
+    f[rng.random(n) < 0.05] = -0.0
+    u = rng.integers(0, 200, n).astype(np.uint8)
+    s = [f"s{int(x) % 13}" * (int(x) % 3) for x in rng.integers(0, 1000, n)]
+    g = rng.standard_normal(n).astype(np.float32)
+    t = rng.random(n) < 0.5
+    arrays = [pa.array(a), pa.array(f), pa.array(u), pa.array(s), pa.array(g), pa.array(t)]
+    if with_nulls:
+        arrays[0] = pa.array(a, mask=rng.random(n) < 0.15)
+        arrays[1] = pa.array(f, mask=rng.random(n) < 0.15)
+        arrays[4] = pa.array(g, mask=rng.random(n) < 0.15)
+    return pa.RecordBatch.from_arrays(arrays, names=["a", "f", "u", "s", "g", "t"])
+
+
+@pytest.mark.parametrize("with_nulls", [False, True])
+@pytest.mark.parametrize("keys", [[(Column(1), True)], [(Column(1), False)], [(Column(0), True), (Column(4), False)],
+                                  [(Column(2), False), (Column(0), True), (Column(1), True)], [(Column(5), True), (Column(2), True)],
+                                  [(BinaryExpr(Column(1), Operator.Multiply, lit(-2.0)), True)]])
+def test_sort_matches_oracle(keys, with_nulls):
+    rng = np.random.default_rng(7)
+    batches = [_mixed_batch(rng, n, with_nulls) for n in (700, 1, 1300)]
+    schema = batches[0].schema
+    got = gpu_sort(batches, schema, keys)
+    want = oracle.sort_batches(batches, keys)
+    assert len(got) == 1
+    assert_batches_identical(got[0], want, f"sort {len(keys)} keys nulls={with_nulls}")
+
+
+def test_sort_empty_and_limit():
+    rng = np.random.default_rng(9)
+    b = _mixed_batch(rng, 500, True)
+    assert gpu_sort([], b.schema, [(Column(0), True)]) == []
+    got = gpu_sort([b, b], b.schema, [(Column(2), False)], limit=17)
+    want = oracle.limit_batches([oracle.sort_batches([b, b], [(Column(2), False)])], 17)
+    assert len(got) == 1 and got[0].num_rows == 17
+    assert_batches_identical(got[0], want[0], "sort + limit")
+    # LIMIT alone keeps batch boundaries: 500 + 500 rows, LIMIT 620 -> 500 + 120
+    rel = ex.LimitRelation(ex.DataSourceRelation(b.schema, [b, b]), 620, b.schema)
+    out = list(rel)
+    assert [x.num_rows for x in out] == [500, 120]
+    for g, w in zip(out, oracle.limit_batches([b, b], 620)):
+        assert_batches_identical(g, w, "limit")
+    assert list(ex.LimitRelation(ex.DataSourceRelation(b.schema, [b]), 0, b.schema)) == []
+
+
+def test_sort_csv_top_cities():
+    """SELECT city, lat, lng FROM cities ORDER BY lat DESC LIMIT 3 -- text file in, three rows out."""
+    schema = fixtures.uk_cities_schema()
+    src = ex.CsvDataSource(os.path.join(fixtures.DATA, "uk_cities.csv"), schema, 1024)
+    rel = ex.LimitRelation(ex.SortRelation(src, [(ex.compile_scalar_expr(None, Column(1), schema), False)], schema), 3, schema)
+    got = list(rel)[0]
+    rows = fixtures.load_csv("uk_cities.csv", schema)[0].to_pylist()
+    want = sorted(rows, key=lambda r: -r["lat"])[:3]
+    assert got.to_pylist() == want
+    assert got.column(0)[0].as_py() == "Inverness, the UK" and got.column(1)[0].as_py() == 57.477772  # aggregate.rs:999-1031: max lat
+
+
+def test_sort_utf8_key_not_implemented():
+    b = pa.RecordBatch.from_arrays([pa.array(["b", "a"])], names=["s"])
+    with pytest.raises(ex.ExecutionError) as ei:
+        gpu_sort([b], b.schema, [(Column(0), True)])
+    assert ei.value.kind == "NotImplemented"
+
+
+def test_sort_large_properties():
+    """2^24 rows resident in HBM: the output is ordered, is a permutation (payload sums agree bit for bit on exact data)
+    and equal keys keep their input order (stability, checked through a row-number payload)."""
+    n = 1 << 24
+    syn = [("k", ex.SYNTH_I64_UNIFORM, 0, 1000.0, 0.0), ("v", ex.SYNTH_F64_EXACT, 1, 0.0, 0.0), ("r", ex.SYNTH_I64_UNIFORM, 2, float(2**40), 0.0)]
+    schema = pa.schema([("k", pa.int64()), ("v", pa.float64()), ("r", pa.int64())])
+    table = ex.DeviceTable.synth(syn, 0xDF05, 0, n)
+    rel = ex.SortRelation(table.scan(1 << 22), [(ex.compile_scalar_expr(None, Column(0), schema), True),
+                                                (ex.compile_scalar_expr(None, Column(1), schema), False)], schema)
+    out = rel.next()
+    assert rel.next() is None and out.num_rows == n
+    k, v = out.column(0).to_numpy(), out.column(1).to_numpy()
+    assert np.all(np.diff(k) >= 0)
+    same = np.diff(k) == 0
+    assert np.all(np.diff(v)[same] <= 0)
+    src = pa.Table.from_batches(list(table.scan(1 << 22)))
+    assert float(np.sum(v)) == float(np.sum(src.column(1).to_numpy()))
+    assert int(np.sum(out.column(2).to_numpy())) == int(np.sum(src.column(2).to_numpy()))
