@@ -743,11 +743,11 @@ __global__ __launch_bounds__(kABlock) void k_partition_agg(const DevTable T, con
         const uint32_t slot = (uint32_t)((h >> T.shift) & T.mask) & T.block_mask;
         int found = -1;
         // Linear probing, FOUR slots per step (two 16-byte LDS reads of the aligned group): a wave pays for
-        // the longest probe sequence among its 64 lanes, and with the table half full that tail is ~12
-        // single-slot steps.  The probe ORDER is exactly slot, slot + 1, ... (positions before `slot` in the
-        // first group are masked), so the block stays a valid linear-probing table for the global kernels.
+        // the longest probe sequence among its 64 lanes.  The home slot is the group base (table_upsert_slot),
+        // so the probe ORDER is exactly home, home + 1, ... and the block stays a valid linear-probing table for
+        // the global kernels; ~98 % of the lookups end in the first group.
         uint32_t g = slot >> 2;
-        uint32_t vm = (0xFu << (slot & 3u)) & 0xFu;
+        uint32_t vm = 0xFu;
         for (uint32_t it = 0; it <= (S >> 2) && found < 0;) {
           const ulonglong2 ka = *(const ulonglong2*)&lkeys[g * 4];
           const ulonglong2 kb = *(const ulonglong2*)&lkeys[g * 4 + 2];
