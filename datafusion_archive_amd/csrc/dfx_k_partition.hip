@@ -806,6 +806,13 @@ __global__ __launch_bounds__(kABlock) void k_partition_agg(const DevTable T, con
   if ((threadIdx.x == 0 || threadIdx.x == 1023) && (p == 0 || p == 100 || p == 255))
     printf("PA p=%u t=%u total=%u: load %lld prefix %lld loop %lld barrier %lld store %lld (100MHz ticks)\n", p, threadIdx.x, total,
            tt1 - tt0, tt2 - tt1, tt3 - tt2, tt4 - tt3, wall_clock64() - tt4);
+  if (threadIdx.x == 0 && (p % 16) == 0) {  // are the 256 workgroups resident together?
+    unsigned xcc = 0, hwid = 0;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    printf("PAWG p=%u start %lld end %lld xcc %u cu %u se %u\n", p, tt0 % 100000000ll, wall_clock64() % 100000000ll, xcc & 15u,
+           (hwid >> 8) & 15u, (hwid >> 13) & 7u);
+  }
 #endif
 }
 

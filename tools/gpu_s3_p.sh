@@ -1,3 +1,3 @@
 #!/bin/bash
 export TMPDIR=/tmp
-for wl in cfg3 headline; do timeout 300 python tools/prof_query.py $wl 134217728 1 agg.partition_mode=258 2>&1 | grep "PA p=" | tail -12; done
+timeout 300 python tools/prof_query.py cfg3 67108864 0 2>&1 | grep "PAWG" | sort -k4 -n | head -40
