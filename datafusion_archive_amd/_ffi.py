@@ -94,7 +94,8 @@ def lib() -> ctypes.CDLL:
         except Exception:  # torch is optional plumbing; the library itself does not need it
             pass
     try:
-        path = build_library()
+        # DFX_LIB: load this (already built) variant of the library instead -- A/B runs of kernel build options
+        path = os.environ.get("DFX_LIB") or build_library()
     except Exception as e:  # stale/missing library and no compiler: fail loudly, no fallback
         if not os.path.exists(LIB_PATH):
             raise ImportError(f"datafusion_archive_amd: the HIP extension {LIB_PATH} is missing and could "

@@ -388,6 +388,9 @@ __global__ __launch_bounds__(BLOCK) void k_partition_sorted(const DevProgram P, 
 // workgroups per CU -- 32 waves -- was measured ~20 % slower than 16 rows and one workgroup.)
 constexpr int ring_queue_rows(int rp) { return rp >= 16 ? 192 : 128; }
 constexpr int kRingBlock = 1024;
+#ifndef DFX_RING_DEPTH
+#define DFX_RING_DEPTH 1
+#endif
 
 struct RingLds {
   uint64_t* ring;    // [n_parts][kRingRP][n_words]
@@ -511,29 +514,40 @@ __global__ __launch_bounds__(kRingBlock) void k_partition_ring(const DevProgram 
   const int64_t n_waves = (int64_t)gridDim.x * NWAVES;
   uint32_t err = 0;
   uint64_t passed = 0;
-  // software pipeline: the columns of trip t + 1 are requested before trip t is evaluated and routed, so
-  // every wave keeps loads in flight while it works on LDS
-  COLV ncol[U];
-  uint32_t ncv[U];
-  {
-    const int64_t w0 = wave_global * U;
+  // software pipeline, kRingDepth trips deep: the columns of trips t + 1 .. t + kRingDepth are in flight while trip t
+  // is evaluated and routed.  Depth 1 = 16 waves per CU x 4 KB = 16 MB in flight chip-wide.  Depths 2 and 3 (92 / 104
+  // VGPRs, -DDFX_RING_DEPTH) were measured: 3.46-3.66 ms per 1e9 rows against 3.24-3.62 ms at depth 1 -- no gain, the
+  // kernel is not short of bytes in flight; the run-to-run spread (+-6 % on one box) is larger than any difference.
+  constexpr int kRingDepth = DFX_RING_DEPTH;
+  COLV ncol[kRingDepth][U];
+  uint32_t ncv[kRingDepth][U];
+#pragma unroll
+  for (int d = 0; d < kRingDepth; ++d) {
+    const int64_t w0 = wave_global * U + (int64_t)d * n_waves * U;
     FOR_U {
       const int64_t row = (w0 + u) * 64 + lane;
-      POL::load(P, C, row, row < n && w0 < n_groups, ncol[u], ncv[u]);
+      POL::load(P, C, row, row < n && w0 < n_groups, ncol[d][u], ncv[d][u]);
     }
   }
   for (int64_t w0 = wave_global * U; w0 < n_groups; w0 += n_waves * U) {
     COLV col[U];
     uint32_t cv[U];
     FOR_U {
-      col[u] = ncol[u];
-      cv[u] = ncv[u];
+      col[u] = ncol[0][u];
+      cv[u] = ncv[0][u];
+    }
+#pragma unroll
+    for (int d = 0; d + 1 < kRingDepth; ++d) {
+      FOR_U {
+        ncol[d][u] = ncol[d + 1][u];
+        ncv[d][u] = ncv[d + 1][u];
+      }
     }
     {
-      const int64_t w1 = w0 + n_waves * U;
+      const int64_t w1 = w0 + (int64_t)kRingDepth * n_waves * U;
       FOR_U {
         const int64_t row = (w1 + u) * 64 + lane;
-        POL::load(P, C, row, row < n, ncol[u], ncv[u]);
+        POL::load(P, C, row, row < n, ncol[kRingDepth - 1][u], ncv[kRingDepth - 1][u]);
       }
     }
 #ifdef DFX_RING_WAIT_ALL
