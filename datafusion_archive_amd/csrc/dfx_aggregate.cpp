@@ -64,6 +64,15 @@ struct AggregateRelation::Impl {
   std::unique_ptr<ProgramBuilder> builder;
   DevAggPlan plan;
   DevFastPlan fast;
+  // The same program WITHOUT the absorbed predicate, for batches whose referenced columns carry nulls: the reference's
+  // FilterRelation emits all-valid arrays (fn filter ignores value nulls, filter.rs:83-92), so an aggregate over a Filter
+  // sees every surviving slot as valid -- COUNT counts them, SUM adds whatever the slot holds.  A fused evaluation would
+  // apply the ORIGINAL validity to the aggregate arguments; such batches are therefore filtered for real
+  // (FilterRelation's kernels) and then aggregated without a predicate.  Null-free batches stay fused.
+  std::unique_ptr<ProgramBuilder> builder_np;
+  DevAggPlan plan_np;
+  DevFastPlan fast_np;
+  bool unfused_now = false;
   Status deferred;
   bool done = false;
   bool built = false;
@@ -239,6 +248,15 @@ Status AggregateRelation::Impl::setup(const SchemaInfo& input_schema) {
     }
   }
   builder->build_fast(plan.pred, plan.key, kw, plan.arg, na, &fast);
+  if (has_pred) {  // predicate-free twin (operands are numbered differently: its own plan)
+    builder_np.reset(new ProgramBuilder(bind_schema));
+    plan_np = plan;
+    plan_np.pred = kNoOperand;
+    int dt = 0;
+    for (int k = 0; k < kw; ++k) DFX_RETURN_IF_ERROR(builder_np->add(group_rw[k], group_rw[k].root, &plan_np.key[k], &dt));
+    for (int a = 0; a < na; ++a) DFX_RETURN_IF_ERROR(builder_np->add(aggr[a], aggr[a].agg_arg, &plan_np.arg[a], &dt));
+    builder_np->build_fast(plan_np.pred, plan_np.key, kw, plan_np.arg, na, &fast_np);
+  }
   return Status::OK();
 }
 
@@ -568,7 +586,55 @@ Status AggregateRelation::Impl::launch_rows(const DeviceBatch& b, const DevProgr
   return Status::OK();
 }
 
+namespace {
+// one batch as a relation (input of the per-batch FilterRelation of the unfused path)
+struct OneBatchRelation : Relation {
+  DeviceBatch batch;
+  SchemaInfo schema_;
+  bool done = false;
+  RelationKind kind() const override { return REL_TABLE_SCAN; }
+  const SchemaInfo& schema() const override { return schema_; }
+  Status next(DeviceBatch* out, bool* has) override {
+    *has = !done;
+    if (!done) *out = batch;
+    done = true;
+    return Status::OK();
+  }
+};
+}  // namespace
+
 Status AggregateRelation::Impl::consume_batch(const DeviceBatch& b) {
+  if (has_pred && !unfused_now && b.num_rows > 0) {
+    bool nulls = false;
+    for (int ci : builder->columns())
+      if (ci >= 0 && ci < (int)b.columns.size() && b.columns[(size_t)ci].validity && b.columns[(size_t)ci].null_count != 0) nulls = true;
+    if (nulls) {  // FilterRelation for real (its output is all-valid), then the predicate-free program
+      std::unique_ptr<OneBatchRelation> one(new OneBatchRelation());
+      one->batch = b;
+      one->schema_ = input->schema();
+      FilterRelation filter(std::move(one), pred, input->schema());
+      std::vector<char> needed(input->schema().fields.size(), 0);
+      for (int ci : builder_np->columns())
+        if (ci >= 0 && ci < (int)needed.size()) needed[(size_t)ci] = 1;
+      for (const DictKey& d : dicts)
+        if (d.src_col >= 0 && d.src_col < (int)needed.size()) needed[(size_t)d.src_col] = 1;
+      filter.require_columns(needed);
+      DeviceBatch fb;
+      bool got = false;
+      DFX_RETURN_IF_ERROR(filter.next(&fb, &got));
+      if (!got) return Status::OK();
+      std::swap(builder, builder_np);
+      std::swap(plan, plan_np);
+      std::swap(fast, fast_np);
+      unfused_now = true;
+      Status st = consume_batch(fb);
+      unfused_now = false;
+      std::swap(builder, builder_np);
+      std::swap(plan, plan_np);
+      std::swap(fast, fast_np);
+      return st;
+    }
+  }
   const int64_t n = b.num_rows;
   if (n == 0 && kw > 0) return Status::OK();  // (ungrouped: an empty batch still folds Some(0) into COUNT)
   hipStream_t s = ctx().stream;

@@ -307,7 +307,10 @@ DEV void run_program(const DevProgram& P, ROWSTATE_PARAMS, bool active, uint32_t
       }
       res = wrap_to(t, o);
     }
-    s_reg[pc] = res;
+    // a null result slot holds zero: arrow 0.12's builders append_null() over zero-initialised buffers, and the grouped
+    // aggregates read value(row) of their argument WITHOUT a null check (aggregate.rs:561-603), so the slot's content
+    // is observable (MAX(x + x) over a null x sees 0, not raw + raw)
+    s_reg[pc] = v ? res : 0ull;
     s_regvalid |= (v ? 1u : 0u) << pc;
   }
 }

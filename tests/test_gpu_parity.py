@@ -829,3 +829,36 @@ def test_projection_pushdown_keeps_filter_errors():
     with pytest.raises(ex.ExecutionError) as ei:
         gpu_project([Column(0)], b.schema, [b], filter_expr=BinaryExpr(Column(0), Operator.Gt, lit(0.0)))
     assert "filter not supported" in ei.value.message
+
+
+# ---------------------------------------------------------------------------------------------------
+# two rules the randomised differential test (tests/test_gpu_fuzz.py) found the fused paths breaking
+# ---------------------------------------------------------------------------------------------------
+def test_aggregate_over_filter_sees_all_valid_slots():
+    """FilterRelation's output is all-valid (fn filter ignores value nulls, filter.rs:83-92), so COUNT(x) over a Filter
+    counts the surviving NULL slots of x and SUM adds what they hold.  Batches with nulls are therefore filtered for
+    real and not fused."""
+    rng = np.random.default_rng(77)
+    b = _exact_batch(rng, 50000, 9, with_nulls=True)
+    pred = BinaryExpr(Column(2), Operator.Gt, ilit(0))  # i has nulls too: `null > 0` is false (None sorts below)
+    aggs = [agg("count", Column(1), DataType.UInt64), agg("sum", Column(2), DataType.Int64), agg("min", Column(1), F64)]
+    got = gpu_aggregate([Column(0)], aggs, b.schema, [b.slice(0, 20000), b.slice(20000, 30000)], filter_expr=pred)
+    want = oracle.aggregate([Column(0)], aggs, [oracle.filter_next(pred, b.slice(0, 20000)), oracle.filter_next(pred, b.slice(20000, 30000))])
+    assert_groups_identical(got, want, 1, "aggregate over filter with nulls")
+    nonnull = oracle.aggregate([Column(0)], aggs, [b])  # without the filter COUNT skips... no: grouped reads blindly too
+    assert nonnull.num_rows == 9
+    got_u = gpu_aggregate([], aggs, b.schema, [b], filter_expr=pred)
+    assert_batches_identical(got_u, oracle.aggregate([], aggs, [oracle.filter_next(pred, b)]), "ungrouped over filter with nulls")
+
+
+def test_grouped_aggregate_of_computed_argument_reads_zero_in_null_slots():
+    """update_accumulators reads value(row) without a null check (aggregate.rs:561-603); the slot of a null result of
+    x + x holds 0 (arrow builders append_null over zeroed buffers), not raw + raw."""
+    k = pa.array(np.zeros(6, dtype=np.int64))
+    x = pa.array(np.array([5, 50, 7, 60, 1, 2], dtype=np.uint64), mask=np.array([False, True, False, True, False, False]))
+    b = pa.RecordBatch.from_arrays([k, x], names=["k", "x"])
+    aggs = [agg("max", BinaryExpr(Column(1), Operator.Plus, Column(1)), DataType.UInt64), agg("max", Column(1), DataType.UInt64)]
+    got = gpu_aggregate([Column(0)], aggs, b.schema, [b])
+    want = oracle.aggregate([Column(0)], aggs, [b])
+    assert_groups_identical(got, want, 1, "null slots of computed arguments")
+    assert got.column(1)[0].as_py() == 14 and got.column(2)[0].as_py() == 60  # computed: 0 in null slots; plain column: raw 60
