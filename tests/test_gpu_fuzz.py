@@ -53,7 +53,13 @@ def random_batch(rng, n, with_nulls):
         arr = pa.array(a, mask=(rng.random(n) < 0.15)) if with_nulls else pa.array(a)
         arrays.append(arr)
         names.append(dt.name.lower())
-    return pa.RecordBatch.from_arrays(arrays, names=names)
+    arrays.append(pa.array([("g%d" % int(x)) * int(x % 3) for x in rng.integers(0, 12, n)]))  # column 10: Utf8 (never an operand)
+    names.append("txt")
+    b = pa.RecordBatch.from_arrays(arrays, names=names)
+    if n > 8 and rng.random() < 0.5:  # a slice: non-zero Arrow offsets (values, validity bit offsets, Utf8 offsets)
+        lo = int(rng.integers(1, min(n - 1, 70)))
+        b = b.slice(lo, n - lo - int(rng.integers(0, 3)))
+    return b
 
 
 class Gen:
@@ -137,12 +143,14 @@ def test_fuzz_project(with_nulls, fast):
     ex.set_option("scan.fast", fast)
     rng = np.random.default_rng(4000 + with_nulls)
     stats = {"ok": 0, "error": 0, "skipped": 0}
-    for case in range(60):
+    for case in range(120):
         b = random_batch(rng, int(rng.integers(1, 3000)), with_nulls)
         g = Gen(rng, allow_divide=True)
         exprs = [g.numeric(int(rng.integers(0, len(NP_TYPES))), int(rng.integers(1, 4))) for _ in range(int(rng.integers(1, 4)))]
         if rng.random() < 0.5:
             exprs.append(g.boolean(1))
+        if rng.random() < 0.3:
+            exprs.append(Column(10))
         r = run_both(lambda: gpu_project(exprs, b.schema, [b])[0], lambda: oracle.project_next(exprs, b), f"project case {case}: {exprs}")
         if isinstance(r, tuple):
             same_batches(r[0], r[1], f"project case {case}: {exprs}")
@@ -150,7 +158,7 @@ def test_fuzz_project(with_nulls, fast):
         else:
             stats[r] += 1
     print(f"fuzz project nulls={with_nulls} fast={fast}: {stats}")
-    assert stats["ok"] >= 30
+    assert stats["ok"] >= 60
 
 
 @pytest.mark.parametrize("with_nulls", [False, True])
@@ -159,7 +167,7 @@ def test_fuzz_filter(with_nulls, fast):
     ex.set_option("scan.fast", fast)
     rng = np.random.default_rng(5000 + with_nulls)
     stats = {"ok": 0, "error": 0, "skipped": 0}
-    for case in range(60):
+    for case in range(120):
         b = random_batch(rng, int(rng.integers(1, 5000)), with_nulls)
         pred = Gen(rng, allow_divide=False).boolean(int(rng.integers(0, 3)))
         r = run_both(lambda: gpu_filter(pred, b.schema, [b])[0], lambda: oracle.filter_next(pred, b), f"filter case {case}: {pred}")
@@ -169,7 +177,7 @@ def test_fuzz_filter(with_nulls, fast):
         else:
             stats[r] += 1
     print(f"fuzz filter nulls={with_nulls} fast={fast}: {stats}")
-    assert stats["ok"] >= 40
+    assert stats["ok"] >= 80
 
 
 @pytest.mark.parametrize("strategy", [0, 1, 3])
@@ -181,17 +189,19 @@ def test_fuzz_aggregate(with_nulls, strategy):
     rng = np.random.default_rng(6000 + with_nulls + 10 * strategy)
     stats = {"ok": 0, "error": 0, "skipped": 0}
     int_types = [i for i, (_dt, npt) in enumerate(NP_TYPES) if not np.issubdtype(npt, np.floating)]
-    for case in range(40):
+    for case in range(80):
         batches = [random_batch(rng, int(rng.integers(1, 4000)), with_nulls) for _ in range(int(rng.integers(1, 4)))]
         schema = batches[0].schema
         g = Gen(rng, allow_divide=False)
         n_keys = int(rng.integers(0, 3)) if strategy != 3 else int(rng.integers(0, 2))
         keys = [Column(int(rng.choice(int_types))) for _ in range(n_keys)]
+        if keys and strategy != 3 and rng.random() < 0.25:
+            keys[0] = Column(10)  # a Utf8 key (device dictionary)
         aggs = []
         for _ in range(int(rng.integers(1, 5))):
             t = int(rng.integers(0, len(NP_TYPES)))
-            fn = str(rng.choice(["min", "max", "count", "sum"]))
-            if fn == "sum":
+            fn = str(rng.choice(["min", "max", "count", "sum", "avg"]))
+            if fn in ("sum", "avg"):
                 t = int(rng.choice(int_types))
             rt = DataType.UInt64 if fn == "count" else NP_TYPES[t][0]
             aggs.append(AggregateFunction(fn, [g.numeric(t, int(rng.integers(0, 3)))], rt))
@@ -228,4 +238,4 @@ def test_fuzz_aggregate(with_nulls, strategy):
             stats[r] += 1
         del src
     print(f"fuzz aggregate nulls={with_nulls} strategy={strategy}: {stats}")
-    assert stats["ok"] >= 20
+    assert stats["ok"] >= 40
