@@ -85,3 +85,15 @@ def test_number_parser_agrees_with_strtod(tmp_path):
     out = subprocess.run([exe, "400000", "11"], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.startswith("ok:")
+
+
+def test_device_csv_automaton_agrees_with_oracle_on_cpu(tmp_path):
+    """csrc/dfx_csv_walk.hpp -- the automaton the device kernels run, host build -- against the oracle's reader on random
+    text, and the parallel (transition-vector) boundary detection against the sequential one."""
+    exe = str(tmp_path / "csv_walk_fuzz")
+    obj = str(tmp_path / "oracle.o")
+    subprocess.check_call(["gcc", "-O2", "-c", os.path.join(ROOT, "oracle", "dfx_oracle.c"), "-o", obj])
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "native", "csv_walk_fuzz.cpp"), obj, "-lm"])
+    out = subprocess.run([exe, "1500", "3", str(tmp_path)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.startswith("ok:")
