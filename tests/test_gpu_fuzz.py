@@ -239,3 +239,55 @@ def test_fuzz_aggregate(with_nulls, strategy):
         del src
     print(f"fuzz aggregate nulls={with_nulls} strategy={strategy}: {stats}")
     assert stats["ok"] >= 40
+
+
+@pytest.mark.parametrize("fewgroup", [1, 0])
+def test_fuzz_few_groups_many_batches(fewgroup):
+    """<= 6 groups over 3..6 batches: from the second batch on the register-accumulator kernel (k_fewgroup_agg) runs --
+    its generic instances (1 or 2 key words, 1..4 aggregates of any accumulator kind, optional predicate) against the
+    oracle, and against the LDS path (agg.fewgroup=0)."""
+    ex.set_option("agg.fewgroup", fewgroup)
+    rng = np.random.default_rng(7000)
+    int_types = [i for i, (_dt, npt) in enumerate(NP_TYPES) if not np.issubdtype(npt, np.floating)]
+    done = 0
+    for case in range(60):
+        n_batches = int(rng.integers(3, 7))
+        batches = []
+        for _ in range(n_batches):
+            b = random_batch(rng, int(rng.integers(200, 5000)), False)
+            m = b.num_rows
+            g3 = pa.array(rng.integers(0, 3, m).astype(np.int64))
+            g2 = pa.array(rng.integers(-1, 1, m).astype(np.int16))
+            batches.append(pa.RecordBatch.from_arrays(list(b.columns) + [g3, g2], names=list(b.schema.names) + ["g3", "g2"]))
+        schema = batches[0].schema
+        keys = [Column(11)] if rng.random() < 0.5 else [Column(11), Column(12)]
+        g = Gen(rng, allow_divide=False)
+        aggs = []
+        for _ in range(int(rng.integers(1, 5))):
+            t = int(rng.integers(0, len(NP_TYPES)))
+            fn = str(rng.choice(["min", "max", "count", "sum"]))
+            if fn == "sum":
+                t = int(rng.choice(int_types))
+            rt = DataType.UInt64 if fn == "count" else NP_TYPES[t][0]
+            arg = Column(t) if rng.random() < 0.7 else g.numeric(t, 1)
+            aggs.append(AggregateFunction(fn, [arg], rt))
+        pred = None
+        if rng.random() < 0.5:
+            t = int(rng.integers(0, len(NP_TYPES)))
+            pred = BinaryExpr(Column(t), CMP[int(rng.integers(0, len(CMP)))], g.literal(t))
+        got = gpu_aggregate(keys, aggs, schema, batches, filter_expr=pred)
+        want = oracle.aggregate(keys, aggs, batches if pred is None else [oracle.filter_next(pred, b) for b in batches])
+
+        def as_dict(batch, nk=len(keys)):
+            cols = [canon(batch.column(i)) for i in range(nk)]
+            for i in range(nk, batch.num_columns):
+                col = batch.column(i)
+                if pa.types.is_floating(col.type):
+                    cols.append(["nan" if (v is not None and v != v) else (0.0 if v == 0 else v) for v in col.to_pylist()])
+                else:
+                    cols.append(canon(col))
+            return {tuple(c[r] for c in cols[:nk]): tuple(c[r] for c in cols[nk:]) for r in range(batch.num_rows)}
+        gd, wd = as_dict(got), as_dict(want)
+        assert gd == wd, f"few groups case {case}: {keys} {aggs} where {pred}: got {gd} want {wd}"
+        done += 1
+    assert done == 60
