@@ -759,7 +759,7 @@ __global__ __launch_bounds__(kABlock) void k_partition_agg(const DevTable T, con
         // Linear probing, FOUR slots per step (two 16-byte LDS reads of the aligned group): a wave pays for
         // the longest probe sequence among its 64 lanes.  The home slot is the group base (table_upsert_slot),
         // so the probe ORDER is exactly home, home + 1, ... and the block stays a valid linear-probing table for
-        // the global kernels; ~98 % of the lookups end in the first group.
+        // the global kernels; most lookups end in the first group.
         uint32_t g = slot >> 2;
         uint32_t vm = 0xFu;
         for (uint32_t it = 0; it <= (S >> 2) && found < 0;) {
