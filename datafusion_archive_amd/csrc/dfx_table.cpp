@@ -47,7 +47,9 @@ Status TableScanRelation::next(DeviceBatch* out, bool* has) {
 
 namespace {
 
-// concatenates device batches column-wise into one resident table
+// concatenates device batches column-wise into one resident table.  One batch is adopted as it is; several batches are
+// copied: fixed-width values with D2D copies, validity / Boolean bits and Utf8 cells with the multi-batch gathers of
+// dfx_k_sort.hip driven by the identity permutation (global row -> (batch, row)).
 Status build_table(Relation* rel, std::shared_ptr<TableData>* out) {
   std::shared_ptr<TableData> t(new TableData());
   t->schema = rel->schema();
@@ -59,38 +61,153 @@ Status build_table(Relation* rel, std::shared_ptr<TableData>* out) {
     DFX_RETURN_IF_ERROR(rel->next(&b, &has));
     if (!has) break;
     total += b.num_rows;
-    batches.push_back(std::move(b));
+    if (b.num_rows > 0 || batches.empty()) batches.push_back(std::move(b));
   }
   t->num_rows = total;
   const size_t nc = t->schema.fields.size();
   t->columns.resize(nc);
   hipStream_t s = ctx().stream;
+  if (batches.empty()) {
+    for (size_t c = 0; c < nc; ++c) {
+      t->columns[c].dtype = t->schema.fields[c].dtype;
+      t->columns[c].length = 0;
+    }
+    *out = t;
+    return Status::OK();
+  }
+  const bool single = batches.size() == 1;
+  Status st;
+  std::shared_ptr<void> loc;  // identity permutation resolved to (batch, row), built on first use
+  auto need_loc = [&]() -> Status {
+    if (loc) return Status::OK();
+    if (total >= (1ll << 32)) return Status::Err(DFX_NOT_IMPLEMENTED, "multi-batch upload of 2^32 or more rows with nullable / Utf8 / Boolean columns");
+    std::vector<uint64_t> starts(batches.size() + 1, 0);
+    for (size_t b = 0; b < batches.size(); ++b) starts[b + 1] = starts[b] + (uint64_t)batches[b].num_rows;
+    auto dstarts = device_alloc(sizeof(uint64_t) * starts.size(), &st);
+    if (!dstarts) return st;
+    DFX_HIP(hipMemcpyAsync(dstarts.get(), starts.data(), sizeof(uint64_t) * starts.size(), hipMemcpyHostToDevice, s));
+    auto idx = device_alloc(sizeof(uint32_t) * (size_t)std::max<int64_t>(total, 1), &st);
+    if (!idx) return st;
+    loc = device_alloc(sizeof(uint64_t) * (size_t)std::max<int64_t>(total, 1), &st);
+    if (!loc) return st;
+    DFX_HIP(launch_sort_iota((uint32_t*)idx.get(), total, s));
+    DFX_HIP(launch_sort_locate((const uint32_t*)idx.get(), total, (const uint64_t*)dstarts.get(), (int)batches.size(), (uint64_t*)loc.get(), s));
+    DFX_HIP(hipStreamSynchronize(s));  // `starts` is a stack vector
+    return Status::OK();
+  };
+  auto upload_ptrs = [&](const std::vector<const void*>& v, std::shared_ptr<void>* dev) -> Status {
+    *dev = device_alloc(sizeof(void*) * std::max<size_t>(v.size(), 1), &st);
+    if (!*dev) return st;
+    DFX_HIP(hipMemcpyAsync(dev->get(), v.data(), sizeof(void*) * v.size(), hipMemcpyHostToDevice, s));
+    DFX_HIP(hipStreamSynchronize(s));
+    return Status::OK();
+  };
+  auto upload_i64 = [&](const std::vector<int64_t>& v, std::shared_ptr<void>* dev) -> Status {
+    *dev = device_alloc(sizeof(int64_t) * std::max<size_t>(v.size(), 1), &st);
+    if (!*dev) return st;
+    DFX_HIP(hipMemcpyAsync(dev->get(), v.data(), sizeof(int64_t) * v.size(), hipMemcpyHostToDevice, s));
+    DFX_HIP(hipStreamSynchronize(s));
+    return Status::OK();
+  };
+  const size_t words = (size_t)(total + 63) / 64 + 1;
   for (size_t c = 0; c < nc; ++c) {
     DeviceColumn& col = t->columns[c];
-    col.dtype = t->schema.fields[c].dtype;
-    col.length = total;
-    if (batches.size() == 1 && batches[0].columns[c].bit_offset == 0) {  // common case: adopt
+    if (single && batches[0].columns[c].bit_offset == 0) {  // common case: adopt
       col = batches[0].columns[c];
       continue;
     }
-    if (col.dtype == DFX_UTF8 || col.dtype == DFX_BOOLEAN)
-      return Status::Err(DFX_NOT_IMPLEMENTED, "multi-batch upload of Utf8/Boolean columns into a resident table");
-    const int w = dtype_width(col.dtype);
-    Status st;
-    auto vals = device_alloc((size_t)std::max<int64_t>(total, 1) * w, &st);
-    if (!vals) return st;
-    int64_t pos = 0;
+    col.dtype = t->schema.fields[c].dtype;
+    col.length = total;
     bool any_nulls = false;
-    for (auto& b : batches) {
-      const DeviceColumn& bc = b.columns[c];
-      if (bc.length) DFX_HIP(hipMemcpyAsync((uint8_t*)vals.get() + (size_t)pos * w, bc.values, (size_t)bc.length * w, hipMemcpyDeviceToDevice, s));
-      if (bc.validity && bc.null_count != 0) any_nulls = true;
-      pos += bc.length;
+    for (auto& b : batches)
+      if (b.columns[c].validity && b.columns[c].null_count != 0) any_nulls = true;
+    if (any_nulls) {
+      DFX_RETURN_IF_ERROR(need_loc());
+      std::vector<const void*> vb;
+      std::vector<int64_t> vo;
+      for (auto& b : batches) {
+        const DeviceColumn& bc = b.columns[c];
+        vb.push_back((bc.validity && bc.null_count != 0) ? bc.validity : nullptr);
+        vo.push_back(bc.bit_offset);
+      }
+      std::shared_ptr<void> dvb, dvo;
+      DFX_RETURN_IF_ERROR(upload_ptrs(vb, &dvb));
+      DFX_RETURN_IF_ERROR(upload_i64(vo, &dvo));
+      auto valid = device_alloc(words * 8, &st);
+      if (!valid) return st;
+      auto zeros = device_alloc(sizeof(uint64_t), &st);
+      if (!zeros) return st;
+      DFX_HIP(hipMemsetAsync(zeros.get(), 0, sizeof(uint64_t), s));
+      DFX_HIP(launch_gather_bits((const uint8_t* const*)dvb.get(), (const int64_t*)dvo.get(), (const uint64_t*)loc.get(), total,
+                                 (uint64_t*)valid.get(), (uint64_t*)zeros.get(), s));
+      uint64_t nz = 0;
+      DFX_HIP(hipMemcpyAsync(&nz, zeros.get(), sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+      DFX_HIP(hipStreamSynchronize(s));
+      col.validity = (const uint8_t*)valid.get();
+      col.null_count = (int64_t)nz;
+      col.owners.push_back(valid);
     }
-    if (any_nulls)
-      return Status::Err(DFX_NOT_IMPLEMENTED, "multi-batch upload of nullable columns into a resident table");
-    col.values = vals.get();
-    col.owners.push_back(vals);
+    if (col.dtype == DFX_UTF8) {
+      DFX_RETURN_IF_ERROR(need_loc());
+      std::vector<const void*> ob, db;
+      for (auto& b : batches) {
+        ob.push_back(b.columns[c].offsets);
+        db.push_back(b.columns[c].data);
+      }
+      std::shared_ptr<void> dob, ddb;
+      DFX_RETURN_IF_ERROR(upload_ptrs(ob, &dob));
+      DFX_RETURN_IF_ERROR(upload_ptrs(db, &ddb));
+      auto lens = device_alloc(sizeof(int32_t) * (size_t)(total + 1), &st);
+      if (!lens) return st;
+      auto offs = device_alloc(sizeof(int32_t) * (size_t)(total + 1), &st);
+      if (!offs) return st;
+      auto tmp = device_alloc(sizeof(uint64_t) * (size_t)(total / 4096 + 4), &st);
+      if (!tmp) return st;
+      DFX_HIP(launch_gather_utf8_lens((const int32_t* const*)dob.get(), (const uint64_t*)loc.get(), total, (int32_t*)lens.get(), s));
+      DFX_HIP(launch_scan_i32((const int32_t*)lens.get(), (int32_t*)offs.get(), total, (uint64_t*)tmp.get(), s));
+      int32_t bytes = 0;
+      DFX_HIP(hipMemcpyAsync(&bytes, (int32_t*)offs.get() + total, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+      DFX_HIP(hipStreamSynchronize(s));
+      if (bytes < 0) return Status::Err(DFX_EXECUTION_ERROR, "Utf8 column of a resident table exceeds 2 GB (Arrow Utf8 offsets are 32-bit)");
+      auto data = device_alloc((size_t)std::max<int32_t>(bytes, 8), &st);
+      if (!data) return st;
+      DFX_HIP(launch_gather_utf8_copy((const int32_t* const*)dob.get(), (const uint8_t* const*)ddb.get(), (const uint64_t*)loc.get(), total,
+                                      (const int32_t*)offs.get(), (uint8_t*)data.get(), s));
+      col.offsets = (const int32_t*)offs.get();
+      col.data = (const uint8_t*)data.get();
+      col.data_bytes = bytes;
+      col.owners.push_back(offs);
+      col.owners.push_back(data);
+    } else if (col.dtype == DFX_BOOLEAN) {
+      DFX_RETURN_IF_ERROR(need_loc());
+      std::vector<const void*> vb;
+      std::vector<int64_t> vo;
+      for (auto& b : batches) {
+        vb.push_back(b.columns[c].values);
+        vo.push_back(b.columns[c].bit_offset);
+      }
+      std::shared_ptr<void> dvb, dvo;
+      DFX_RETURN_IF_ERROR(upload_ptrs(vb, &dvb));
+      DFX_RETURN_IF_ERROR(upload_i64(vo, &dvo));
+      auto vals = device_alloc(words * 8, &st);
+      if (!vals) return st;
+      DFX_HIP(launch_gather_bits((const uint8_t* const*)dvb.get(), (const int64_t*)dvo.get(), (const uint64_t*)loc.get(), total,
+                                 (uint64_t*)vals.get(), nullptr, s));
+      col.values = vals.get();
+      col.owners.push_back(vals);
+    } else {
+      const int w = dtype_width(col.dtype);
+      auto vals = device_alloc((size_t)std::max<int64_t>(total, 1) * w, &st);
+      if (!vals) return st;
+      int64_t pos = 0;
+      for (auto& b : batches) {
+        const DeviceColumn& bc = b.columns[c];
+        if (bc.length) DFX_HIP(hipMemcpyAsync((uint8_t*)vals.get() + (size_t)pos * w, bc.values, (size_t)bc.length * w, hipMemcpyDeviceToDevice, s));
+        pos += bc.length;
+      }
+      col.values = vals.get();
+      col.owners.push_back(vals);
+    }
   }
   DFX_HIP(hipStreamSynchronize(s));
   *out = t;

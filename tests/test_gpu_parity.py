@@ -862,3 +862,34 @@ def test_grouped_aggregate_of_computed_argument_reads_zero_in_null_slots():
     want = oracle.aggregate([Column(0)], aggs, [b])
     assert_groups_identical(got, want, 1, "null slots of computed arguments")
     assert got.column(1)[0].as_py() == 14 and got.column(2)[0].as_py() == 60  # computed: 0 in null slots; plain column: raw 60
+
+
+def test_resident_table_from_many_batches_with_nulls_strings_and_booleans():
+    """dfx_table_from_stream over several host batches (the in-memory DataSource, datasource.rs:27-30): nullable,
+    Utf8 and Boolean columns are concatenated on the device; scans of any batch size give the input back."""
+    rng = np.random.default_rng(55)
+
+    def mk(n):
+        b = _random_batch(rng, n, with_nulls=True)
+        s = pa.array([None if rng.random() < 0.1 else "s%d" % int(x) for x in rng.integers(0, 50, n)], pa.string())
+        t = pa.array(rng.random(n) < 0.4, mask=rng.random(n) < 0.2)
+        return pa.RecordBatch.from_arrays(list(b.columns) + [s, t], names=list(b.schema.names) + ["s", "t"])
+    whole = [mk(n) for n in (1000, 1, 777, 3000)]
+    batches = [whole[0].slice(3, 990), whole[1], whole[2].slice(64, 700), whole[3]]  # non-zero Arrow offsets too
+    schema = batches[0].schema
+    table = ex.DeviceTable.from_batches(schema, batches)
+    want = pa.Table.from_batches(batches).combine_chunks()
+    assert table.num_rows() == want.num_rows
+    for batch_rows in (0, 64, 1024):
+        got = pa.Table.from_batches(list(table.scan(batch_rows))).combine_chunks()
+        assert got.num_rows == want.num_rows
+        for c in range(want.num_columns):
+            g, w = got.column(c).combine_chunks(), want.column(c).combine_chunks()
+            assert g.null_count == w.null_count, (batch_rows, schema.names[c])
+            if pa.types.is_floating(w.type):
+                assert [None if x is None else repr(x) for x in g.to_pylist()] == [None if x is None else repr(x) for x in w.to_pylist()]
+            else:
+                assert g.to_pylist() == w.to_pylist(), (batch_rows, schema.names[c])
+    aggs = [agg("count", Column(0), DataType.UInt64), agg("max", Column(2), DataType.Int32)]
+    got = gpu_aggregate([Column(1)], aggs, schema, None, source=table.scan(1024))
+    assert_groups_identical(got, oracle.aggregate([Column(1)], aggs, batches), 1, "aggregate over a concatenated table")
