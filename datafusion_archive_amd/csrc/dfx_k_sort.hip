@@ -46,6 +46,44 @@ __global__ __launch_bounds__(kBlock) void k_sort_image(const void* __restrict__ 
   }
 }
 
+// Utf8 keys: byte-wise lexicographic order = LSD sort over (length, last 8-byte chunk, ..., first 8-byte chunk) where a chunk
+// is the big-endian image of bytes [8j, 8j + 8) padded with zeros: if all padded chunks of two strings are equal, one is
+// the other plus NUL bytes, and the shorter sorts first.  chunk < 0: the length image.
+__global__ __launch_bounds__(kBlock) void k_sort_image_utf8(const int32_t* __restrict__ offsets, const uint8_t* __restrict__ data,
+                                                           const uint8_t* __restrict__ validity, int64_t bit_offset, int chunk,
+                                                           int asc, int64_t n, uint64_t* __restrict__ image,
+                                                           uint64_t* __restrict__ null_image, unsigned int* __restrict__ max_len) {
+  unsigned int mx = 0;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+    const int32_t b = offsets[i], e = offsets[i + 1];
+    const uint32_t len = (uint32_t)(e - b);
+    mx = len > mx ? len : mx;
+    uint64_t img = 0;
+    if (chunk < 0) {
+      img = len;
+    } else {
+      const int64_t p0 = (int64_t)b + 8ll * chunk;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int64_t p = p0 + j;
+        img = (img << 8) | (p < e ? (uint64_t)data[p] : 0ull);
+      }
+    }
+    const bool valid = validity == nullptr || get_bit(validity, bit_offset + i);
+    if (!valid) img = 0;
+    image[i] = asc ? img : ~img;
+    if (null_image) null_image[i] = (uint64_t)((valid ? 0 : 1) ^ (asc ? 0 : 1));
+  }
+  if (max_len) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+      const unsigned int o = (unsigned int)__shfl_xor((int)mx, m, 64);
+      mx = o > mx ? o : mx;
+    }
+    if (lane_id() == 0 && mx) atomicMax(max_len, mx);
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void k_sort_iota(uint32_t* __restrict__ idx, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) idx[i] = (uint32_t)i;
 }
@@ -206,6 +244,15 @@ hipError_t launch_sort_image(const void* values, const uint8_t* validity, int64_
   if (n <= 0) return hipSuccess;
   Scope sc(KID_SORT, s, 0);
   hipLaunchKernelGGL(k_sort_image, dim3(sort_grid(n)), dim3(kBlock), 0, s, values, validity, bit_offset, dtype, asc, n, image, null_image);
+  return hipGetLastError();
+}
+
+hipError_t launch_sort_image_utf8(const int32_t* offsets, const uint8_t* data, const uint8_t* validity, int64_t bit_offset, int chunk,
+                                  int asc, int64_t n, uint64_t* image, uint64_t* null_image, uint32_t* max_len, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  Scope sc(KID_SORT, s, 0);
+  hipLaunchKernelGGL(k_sort_image_utf8, dim3(sort_grid(n)), dim3(kBlock), 0, s, offsets, data, validity, bit_offset, chunk, asc, n, image,
+                     null_image, max_len);
   return hipGetLastError();
 }
 

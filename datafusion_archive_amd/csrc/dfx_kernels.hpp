@@ -159,6 +159,10 @@ hipError_t launch_csv_utf8_gather(const uint8_t* buf, const uint64_t* row_start,
 // ORDER BY (dfx_k_sort.hip): order-preserving key images, stable LSD radix sort of (image, row) pairs, gathers
 hipError_t launch_sort_image(const void* values, const uint8_t* validity, int64_t bit_offset, uint8_t dtype, int asc, int64_t n,
                              uint64_t* image, uint64_t* null_image, hipStream_t s);
+// Utf8 key: chunk >= 0: big-endian image of bytes [8 * chunk, 8 * chunk + 8) zero padded; chunk < 0: the length.  max_len (may be
+// null): atomicMax of the string lengths
+hipError_t launch_sort_image_utf8(const int32_t* offsets, const uint8_t* data, const uint8_t* validity, int64_t bit_offset, int chunk,
+                                  int asc, int64_t n, uint64_t* image, uint64_t* null_image, uint32_t* max_len, hipStream_t s);
 hipError_t launch_sort_iota(uint32_t* idx, int64_t n, hipStream_t s);
 hipError_t launch_sort_gather_u64(const uint64_t* src, const uint32_t* idx, int64_t n, uint64_t* dst, hipStream_t s);
 hipError_t launch_radix_hist8(const uint64_t* img, int64_t n, uint64_t* hist /* [8][256], zeroed */, hipStream_t s);

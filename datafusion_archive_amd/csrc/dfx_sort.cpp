@@ -4,7 +4,8 @@
 // semantics are defined here and in the oracle (tests/oracle.py sort_batches / limit_batches), PARITY UNPINNED:
 //   * ORDER BY e1 [ASC|DESC], e2 ...: stable; NULL is larger than every value (last when ascending, first when
 //     descending); NaN is larger than every number; the result is ONE batch (like the aggregate's);
-//   * sort keys: any scalar expression of a fixed-width type (Utf8 keys: NotImplemented); payload: any column type;
+//   * sort keys: any scalar expression of a fixed-width type, or a Utf8 COLUMN (byte-wise lexicographic order, like Rust's
+//     `str` Ord); payload: any column type;
 //   * LIMIT n: the first n rows of the input stream, batch boundaries kept.
 #include <string.h>
 
@@ -76,11 +77,13 @@ class SortRelation : public Relation {
   bool done_ = false;
 };
 
-// one stable radix sort of the current permutation by sort key `key` (column n_payload_ + key of every batch)
+// one stable sort of the current permutation by sort key `key` (column n_payload_ + key of every batch).  A fixed-width
+// key is one 64-bit image; a Utf8 key is the sequence (length, last 8-byte chunk, ..., first chunk), least significant first.
 Status SortRelation::sort_by_key(const std::vector<DeviceBatch>& batches, int key, int64_t n, std::shared_ptr<void>* idx) {
   hipStream_t s = ctx().stream;
   Status st;
   const int col = n_payload_ + key;
+  const bool utf8 = batches[0].columns[(size_t)col].dtype == DFX_UTF8;
   bool any_nulls = false;
   for (const DeviceBatch& b : batches)
     if (b.columns[(size_t)col].validity && b.columns[(size_t)col].null_count != 0) any_nulls = true;
@@ -91,15 +94,26 @@ Status SortRelation::sort_by_key(const std::vector<DeviceBatch>& batches, int ke
     null_image = device_alloc(sizeof(uint64_t) * (size_t)n, &st);
     if (!null_image) return st;
   }
-  int64_t at = 0;
-  for (const DeviceBatch& b : batches) {
-    const DeviceColumn& c = b.columns[(size_t)col];
-    if (c.dtype == DFX_UTF8) return Status::Err(DFX_NOT_IMPLEMENTED, "ORDER BY a Utf8 expression");
-    const uint8_t* validity = (c.validity && c.null_count != 0) ? c.validity : nullptr;
-    DFX_HIP(launch_sort_image(c.values, validity, c.bit_offset, (uint8_t)c.dtype, asc_[(size_t)key], b.num_rows,
-                              (uint64_t*)image.get() + at, any_nulls ? (uint64_t*)null_image.get() + at : nullptr, s));
-    at += b.num_rows;
-  }
+  auto dmax = device_alloc(sizeof(uint32_t) * 2, &st);
+  if (!dmax) return st;
+  DFX_HIP(hipMemsetAsync(dmax.get(), 0, sizeof(uint32_t) * 2, s));
+  // fills `image` (and, once, `null_image`) with part `chunk` of the key: fixed width: chunk 0 only; Utf8: -1 = length
+  auto make_image = [&](int chunk, bool with_nulls, bool want_max) -> Status {
+    int64_t at = 0;
+    for (const DeviceBatch& b : batches) {
+      const DeviceColumn& c = b.columns[(size_t)col];
+      const uint8_t* validity = (c.validity && c.null_count != 0) ? c.validity : nullptr;
+      uint64_t* ni = (any_nulls && with_nulls) ? (uint64_t*)null_image.get() + at : nullptr;
+      if (utf8)
+        DFX_HIP(launch_sort_image_utf8(c.offsets, c.data, validity, c.bit_offset, chunk, asc_[(size_t)key], b.num_rows,
+                                       (uint64_t*)image.get() + at, ni, want_max ? (uint32_t*)dmax.get() : nullptr, s));
+      else
+        DFX_HIP(launch_sort_image(c.values, validity, c.bit_offset, (uint8_t)c.dtype, asc_[(size_t)key], b.num_rows,
+                                  (uint64_t*)image.get() + at, ni, s));
+      at += b.num_rows;
+    }
+    return Status::OK();
+  };
   const int64_t tiles = radix_tiles(n);
   auto counts = device_alloc(sizeof(uint32_t) * (size_t)(256 * tiles), &st);
   if (!counts) return st;
@@ -116,9 +130,8 @@ Status SortRelation::sort_by_key(const std::vector<DeviceBatch>& batches, int ke
   auto hist = device_alloc(sizeof(uint64_t) * 8 * 256, &st);
   if (!hist) return st;
   std::shared_ptr<void> idx_a = *idx;
-  // least significant first: the value image, then (most significant) the null flag
-  for (int part = 0; part < (any_nulls ? 2 : 1); ++part) {
-    const uint64_t* src = (const uint64_t*)(part == 0 ? image.get() : null_image.get());
+  // one stable 64-bit radix sort of the permutation by `src` (digits that are constant over the input are skipped)
+  auto sort_by_image = [&](const uint64_t* src) -> Status {
     DFX_HIP(hipMemsetAsync(hist.get(), 0, sizeof(uint64_t) * 8 * 256, s));
     DFX_HIP(launch_radix_hist8(src, n, (uint64_t*)hist.get(), s));
     uint64_t hh[8 * 256];
@@ -130,7 +143,7 @@ Status SortRelation::sort_by_key(const std::vector<DeviceBatch>& batches, int ke
       for (int b = 0; b < 256; ++b)
         if (hh[d * 256 + b] == (uint64_t)n) constant = true;
       if (constant) continue;  // every element has the same digit: the pass would be the identity
-      if (!gathered) {  // the key's image in the CURRENT order
+      if (!gathered) {  // the image in the CURRENT order
         DFX_HIP(launch_sort_gather_u64(src, (const uint32_t*)idx_a.get(), n, (uint64_t*)img_a.get(), s));
         gathered = true;
       }
@@ -141,7 +154,23 @@ Status SortRelation::sort_by_key(const std::vector<DeviceBatch>& batches, int ke
       std::swap(img_a, img_b);
       std::swap(idx_a, idx_b);
     }
+    return Status::OK();
+  };
+  if (!utf8) {
+    DFX_RETURN_IF_ERROR(make_image(0, true, false));
+    DFX_RETURN_IF_ERROR(sort_by_image((const uint64_t*)image.get()));
+  } else {
+    DFX_RETURN_IF_ERROR(make_image(-1, true, true));  // length: the least significant part
+    uint32_t max_len = 0;
+    DFX_HIP(hipMemcpyAsync(&max_len, dmax.get(), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    DFX_HIP(hipStreamSynchronize(s));
+    DFX_RETURN_IF_ERROR(sort_by_image((const uint64_t*)image.get()));
+    for (int chunk = (int)((max_len + 7) / 8) - 1; chunk >= 0; --chunk) {
+      DFX_RETURN_IF_ERROR(make_image(chunk, false, false));
+      DFX_RETURN_IF_ERROR(sort_by_image((const uint64_t*)image.get()));
+    }
   }
+  if (any_nulls) DFX_RETURN_IF_ERROR(sort_by_image((const uint64_t*)null_image.get()));  // most significant: NULLs last / first
   *idx = idx_a;
   DFX_HIP(hipStreamSynchronize(s));
   return Status::OK();

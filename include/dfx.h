@@ -291,8 +291,8 @@ int32_t dfx_csv_datasource_new(const char* filename, const struct ArrowSchema* s
  * behaviour, the semantics are this library's (parity unpinned): stable sort, NULL larger than every value (last
  * when ascending, first when descending), NaN larger than every number, ONE result batch.  `exprs` are the sort
  * expressions compiled with dfx_compile_scalar_expr (the inner `expr` of Expr::Sort; compile_scalar_expr itself
- * rejects Expr::Sort like the reference, expression.rs:380-399), `ascending[i]` their direction.  Keys of a
- * fixed-width type; Utf8 keys are DFX_NOT_IMPLEMENTED.  LIMIT keeps the first `limit` rows of the stream.
+ * rejects Expr::Sort like the reference, expression.rs:380-399), `ascending[i]` their direction.  Keys: any
+ * fixed-width scalar expression, or a Utf8 column (byte-wise lexicographic).  LIMIT keeps the first `limit` rows.
  * ---------------------------------------------------------------------------------------- */
 int32_t dfx_sort_relation_new(struct ArrowArrayStream* input, const dfx_runtime_expr* const* exprs,
                               const int32_t* ascending, int32_t n_exprs, const struct ArrowSchema* schema,

@@ -92,11 +92,33 @@ def test_sort_csv_top_cities():
     assert got.column(0)[0].as_py() == "Inverness, the UK" and got.column(1)[0].as_py() == 57.477772  # aggregate.rs:999-1031: max lat
 
 
-def test_sort_utf8_key_not_implemented():
-    b = pa.RecordBatch.from_arrays([pa.array(["b", "a"])], names=["s"])
-    with pytest.raises(ex.ExecutionError) as ei:
-        gpu_sort([b], b.schema, [(Column(0), True)])
-    assert ei.value.kind == "NotImplemented"
+@pytest.mark.parametrize("asc", [True, False])
+@pytest.mark.parametrize("with_nulls", [False, True])
+def test_sort_by_utf8_column(asc, with_nulls):
+    """ORDER BY a Utf8 column: byte-wise lexicographic (Rust `str` Ord == UTF-8 byte order == code-point order), stable,
+    NULL largest.  Strings of 0..40 bytes with shared prefixes (ties inside the first 8-byte chunks), non-ASCII text."""
+    rng = np.random.default_rng(17)
+    stems = ["", "a", "ab", "abc", "abcdefgh", "abcdefghi", "abcdefghijklmnop", "abcdefghijklmnopq", "b", "Zürich", "zebra", "éa", "日本語"]
+
+    def mk(n):
+        words = [stems[int(i)] + ("x" * int(j)) for i, j in zip(rng.integers(0, len(stems), n), rng.integers(0, 3, n) * rng.integers(0, 12, n))]
+        mask = (rng.random(n) < 0.1) if with_nulls else None
+        return pa.RecordBatch.from_arrays([pa.array(words, pa.string(), mask=mask), pa.array(rng.integers(0, 5, n).astype(np.int64)),
+                                           pa.array(np.arange(n, dtype=np.int64))], names=["s", "k", "row"])
+    batches = [mk(900), mk(1), mk(1500)]
+    schema = batches[0].schema
+    for keys in ([(Column(0), asc)], [(Column(1), True), (Column(0), asc)]):
+        got = gpu_sort(batches, schema, keys)
+        assert len(got) == 1
+        assert_batches_identical(got[0], oracle.sort_batches(batches, keys), f"utf8 sort asc={asc} nulls={with_nulls} keys={len(keys)}")
+
+
+def test_sort_cities_by_name():
+    schema = fixtures.uk_cities_schema()
+    src = ex.CsvDataSource(os.path.join(fixtures.DATA, "uk_cities.csv"), schema, 1024)
+    got = list(ex.LimitRelation(ex.SortRelation(src, [(ex.compile_scalar_expr(None, Column(0), schema), True)], schema), 4, schema))[0]
+    names = sorted(r["city"] for r in fixtures.load_csv("uk_cities.csv", schema)[0].to_pylist())
+    assert got.column(0).to_pylist() == names[:4]
 
 
 def test_sort_large_properties():
