@@ -109,6 +109,18 @@ def test_no_cpu_fallback_without_gpu():
     assert "no CPU fallback" in ei.value.message
     with pytest.raises(ex.ExecutionError):
         ex.DeviceTable.synth([("v", ex.SYNTH_F64_EXACT, 0, 0.0, 0.0)], 1, 0, 10)
+    # the sources / operators added next to the path fail the same way: the CSV text is parsed on the device or not at all
+    with pytest.raises(ex.ExecutionError) as ei:
+        ex.CsvDataSource(os.path.join(ROOT, "tests", "data", "uk_cities.csv"), SCHEMA, 1024)
+    assert "no CPU fallback" in ei.value.message
+    srt = ex.SortRelation(ex.DataSourceRelation(SCHEMA, [b]), [(ex.compile_scalar_expr(None, Column(1), SCHEMA), True)], SCHEMA)
+    with pytest.raises(ex.ExecutionError) as ei:
+        srt.next()
+    assert "no CPU fallback" in ei.value.message
+    lim = ex.LimitRelation(ex.DataSourceRelation(SCHEMA, [b]), 1, SCHEMA)
+    with pytest.raises(ex.ExecutionError) as ei:
+        lim.next()
+    assert "no CPU fallback" in ei.value.message
 
 
 def test_consumed_relation_cannot_be_pulled():
