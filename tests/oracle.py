@@ -59,7 +59,10 @@ class SynthColumn(ctypes.Structure):
 
 
 def build_oracle() -> str:
-    """Compile the oracle if needed (gcc, seconds). Returns the library path."""
+    """Compile the oracle if needed (gcc, seconds). Returns the library path.  DFX_ORACLE_SO: use this build instead
+    (tests/test_oracle_sanitized.py runs the oracle's own tests over an ASan + UBSan build)."""
+    if os.environ.get("DFX_ORACLE_SO"):
+        return os.environ["DFX_ORACLE_SO"]
     src = os.path.join(_ORACLE_DIR, "dfx_oracle.c")
     if (not os.path.exists(_LIB_PATH)) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
         subprocess.check_call(["make", "-C", _ORACLE_DIR, "-s"])
