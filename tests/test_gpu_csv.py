@@ -239,3 +239,20 @@ def test_csv_all_seven_reference_goldens_from_text():
                              [ex.compile_scalar_expr(None, Cast(Column(1), DataType.Int32), cs)], None)
     vals = [v for b in rel for v in b.column(0).to_pylist()]
     assert vals[:4] == [53, 52, 51, 50] and len(vals) == 36
+
+
+def test_csv_widest_schema(tmp_path):
+    """32 columns (the source's limit): the cell-span scratch of k_csv_parse is 64 KB of LDS per workgroup."""
+    rng = np.random.default_rng(3)
+    n, nc = 3000, 32
+    cols = [rng.integers(-1000, 1000, n) for _ in range(nc)]
+    p = str(tmp_path / "wide.csv")
+    with open(p, "w") as fh:
+        fh.write(",".join(f"c{i}" for i in range(nc)) + "\n")
+        for r in range(n):
+            fh.write(",".join(("" if (r + i) % 41 == 0 else str(int(cols[i][r]))) if i % 3 else repr(float(cols[i][r]) / 8) for i in range(nc)) + "\n")
+    schema = pa.schema([(f"c{i}", pa.int32() if i % 3 else pa.float64()) for i in range(nc)])
+    assert check_file(p, schema, 1024) == n
+    with pytest.raises(ex.ExecutionError) as ei:
+        ex.CsvDataSource(p, pa.schema([(f"c{i}", pa.int32()) for i in range(33)]), 1024)
+    assert ei.value.kind == "NotImplemented"
