@@ -167,6 +167,46 @@ __global__ __launch_bounds__(kBlock) void k_radix_scatter(const uint64_t* __rest
   }
 }
 
+// ---- top-k (ORDER BY ... LIMIT k): radix select on the first key's image ------------------------------------------------
+// histogram of digit `shift / 8` over the elements whose higher digits equal `prefix` (mask = the bits above the digit)
+__global__ __launch_bounds__(kBlock) void k_select_hist(const uint64_t* __restrict__ img, int64_t n, uint64_t prefix, uint64_t mask,
+                                                       int shift, unsigned long long* __restrict__ hist /* [256] */) {
+  __shared__ uint32_t h[256];
+  for (int i = threadIdx.x; i < 256; i += kBlock) h[i] = 0;
+  __syncthreads();
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+    const uint64_t v = img[i];
+    if ((v & mask) == prefix) atomicAdd(&h[(int)((v >> shift) & 255)], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 256; i += kBlock)
+    if (h[i]) atomicAdd(&hist[i], (unsigned long long)h[i]);
+}
+
+// bitmap of img <= threshold (+ counts per 4096-row tile, the layout launch_compact expects)
+__global__ __launch_bounds__(kBlock) void k_select_mask(const uint64_t* __restrict__ img, int64_t n, uint64_t threshold,
+                                                       uint64_t* __restrict__ mask_words, uint32_t* __restrict__ tile_counts) {
+  __shared__ uint32_t wave_cnt[kBlock / 64];
+  const int lane = lane_id();
+  const int wave = threadIdx.x >> 6;
+  const int64_t n_words = (n + 63) >> 6;
+  const int64_t n_tiles = (n + kTileRows - 1) / kTileRows;
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    uint32_t cnt = 0;
+    for (int i = 0; i < 16; ++i) {
+      const int64_t w = tile * 64 + wave * 16 + i;
+      const int64_t r = w * 64 + lane;
+      const uint64_t word = __ballot(r < n && img[r < n ? r : 0] <= threshold);
+      if (lane == 0 && w < n_words) mask_words[w] = word;
+      cnt += (uint32_t)__popcll(word);
+    }
+    if (lane == 0) wave_cnt[wave] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) tile_counts[tile] = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    __syncthreads();
+  }
+}
+
 // ---- gather ----------------------------------------------------------------------------------------
 // global row -> (batch << 32 | row in batch); starts[nb + 1] ascending
 __global__ __launch_bounds__(kBlock) void k_sort_locate(const uint32_t* __restrict__ idx, int64_t n,
@@ -274,6 +314,22 @@ hipError_t launch_radix_hist8(const uint64_t* img, int64_t n, uint64_t* hist, hi
   Scope sc(KID_SORT, s, 0);
   const int grid = (int)std::min<int64_t>((n + kBlock * 16 - 1) / (kBlock * 16), 2048);
   hipLaunchKernelGGL(k_radix_hist8, dim3(grid), dim3(kBlock), 0, s, img, n, (unsigned long long*)hist);
+  return hipGetLastError();
+}
+
+hipError_t launch_select_hist(const uint64_t* img, int64_t n, uint64_t prefix, uint64_t mask, int shift, uint64_t* hist, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  Scope sc(KID_SORT, s, (double)n * 8);
+  const int grid = (int)std::min<int64_t>((n + kBlock * 16 - 1) / (kBlock * 16), 2048);
+  hipLaunchKernelGGL(k_select_hist, dim3(grid), dim3(kBlock), 0, s, img, n, prefix, mask, shift, (unsigned long long*)hist);
+  return hipGetLastError();
+}
+
+hipError_t launch_select_mask(const uint64_t* img, int64_t n, uint64_t threshold, uint64_t* mask_words, uint32_t* tile_counts,
+                              hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  const int64_t tiles = (n + kTileRows - 1) / kTileRows;
+  hipLaunchKernelGGL(k_select_mask, dim3(stream_grid(tiles, 8)), dim3(kBlock), 0, s, img, n, threshold, mask_words, tile_counts);
   return hipGetLastError();
 }
 

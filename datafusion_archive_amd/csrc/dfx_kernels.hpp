@@ -166,6 +166,11 @@ hipError_t launch_sort_image_utf8(const int32_t* offsets, const uint8_t* data, c
 hipError_t launch_sort_iota(uint32_t* idx, int64_t n, hipStream_t s);
 hipError_t launch_sort_gather_u64(const uint64_t* src, const uint32_t* idx, int64_t n, uint64_t* dst, hipStream_t s);
 hipError_t launch_radix_hist8(const uint64_t* img, int64_t n, uint64_t* hist /* [8][256], zeroed */, hipStream_t s);
+// top-k: histogram of one digit over the elements matching a prefix (radix select), bitmap of img <= threshold
+hipError_t launch_select_hist(const uint64_t* img, int64_t n, uint64_t prefix, uint64_t mask, int shift, uint64_t* hist /* [256], zeroed */,
+                              hipStream_t s);
+hipError_t launch_select_mask(const uint64_t* img, int64_t n, uint64_t threshold, uint64_t* mask_words, uint32_t* tile_counts,
+                              hipStream_t s);
 int64_t radix_tiles(int64_t n);  // counts / offsets hold 256 * radix_tiles(n) entries, digit-major
 hipError_t launch_radix_count(const uint64_t* img, int64_t n, int shift, uint32_t* counts, hipStream_t s);
 hipError_t launch_radix_scatter(const uint64_t* img_in, const uint32_t* idx_in, int64_t n, int shift, const uint64_t* offsets,

@@ -65,9 +65,15 @@ class SortRelation : public Relation {
   RelationKind kind() const override { return REL_SORT; }
   const SchemaInfo& schema() const override { return schema_; }
   Status next(DeviceBatch* out, bool* has) override;
+  // ORDER BY ... LIMIT k: a LimitRelation directly above tells the sort that only the first k rows will be read
+  void set_limit(int64_t k) { limit_ = k; }
 
  private:
-  Status sort_by_key(const std::vector<DeviceBatch>& batches, int key, int64_t n, std::shared_ptr<void>* idx);
+  // sorts the m row indices of *idx (rows of the n-row input) by sort key `key`
+  Status sort_by_key(const std::vector<DeviceBatch>& batches, int key, int64_t n, int64_t m, std::shared_ptr<void>* idx);
+  // top-k: the rows whose FIRST key is <= the k-th smallest first key (>= k of them, input order kept)
+  Status select_candidates(const std::vector<DeviceBatch>& batches, int64_t n, int64_t k, std::shared_ptr<void>* idx, int64_t* m);
+  int64_t limit_ = -1;
   std::unique_ptr<Relation> projected_;
   std::vector<dfx_runtime_expr> keys_;
   std::vector<int> asc_;
@@ -79,7 +85,8 @@ class SortRelation : public Relation {
 
 // one stable sort of the current permutation by sort key `key` (column n_payload_ + key of every batch).  A fixed-width
 // key is one 64-bit image; a Utf8 key is the sequence (length, last 8-byte chunk, ..., first chunk), least significant first.
-Status SortRelation::sort_by_key(const std::vector<DeviceBatch>& batches, int key, int64_t n, std::shared_ptr<void>* idx) {
+Status SortRelation::sort_by_key(const std::vector<DeviceBatch>& batches, int key, int64_t n, int64_t m,
+                                 std::shared_ptr<void>* idx) {
   hipStream_t s = ctx().stream;
   Status st;
   const int col = n_payload_ + key;
@@ -114,42 +121,39 @@ Status SortRelation::sort_by_key(const std::vector<DeviceBatch>& batches, int ke
     }
     return Status::OK();
   };
-  const int64_t tiles = radix_tiles(n);
+  const int64_t tiles = radix_tiles(m);
   auto counts = device_alloc(sizeof(uint32_t) * (size_t)(256 * tiles), &st);
   if (!counts) return st;
   auto offsets = device_alloc(sizeof(uint64_t) * (size_t)(256 * tiles + 1), &st);
   if (!offsets) return st;
   auto tmp = device_alloc(sizeof(uint64_t) * (size_t)(256 * tiles / 4096 + 4), &st);
   if (!tmp) return st;
-  auto img_a = device_alloc(sizeof(uint64_t) * (size_t)n, &st);
+  auto img_a = device_alloc(sizeof(uint64_t) * (size_t)m, &st);
   if (!img_a) return st;
-  auto img_b = device_alloc(sizeof(uint64_t) * (size_t)n, &st);
+  auto img_b = device_alloc(sizeof(uint64_t) * (size_t)m, &st);
   if (!img_b) return st;
-  auto idx_b = device_alloc(sizeof(uint32_t) * (size_t)n, &st);
+  auto idx_b = device_alloc(sizeof(uint32_t) * (size_t)m, &st);
   if (!idx_b) return st;
   auto hist = device_alloc(sizeof(uint64_t) * 8 * 256, &st);
   if (!hist) return st;
   std::shared_ptr<void> idx_a = *idx;
   // one stable 64-bit radix sort of the permutation by `src` (digits that are constant over the input are skipped)
   auto sort_by_image = [&](const uint64_t* src) -> Status {
+    // the image of the m rows in their CURRENT order, then which of its 8 digits vary at all
+    DFX_HIP(launch_sort_gather_u64(src, (const uint32_t*)idx_a.get(), m, (uint64_t*)img_a.get(), s));
     DFX_HIP(hipMemsetAsync(hist.get(), 0, sizeof(uint64_t) * 8 * 256, s));
-    DFX_HIP(launch_radix_hist8(src, n, (uint64_t*)hist.get(), s));
+    DFX_HIP(launch_radix_hist8((const uint64_t*)img_a.get(), m, (uint64_t*)hist.get(), s));
     uint64_t hh[8 * 256];
     DFX_HIP(hipMemcpyAsync(hh, hist.get(), sizeof(hh), hipMemcpyDeviceToHost, s));
     DFX_HIP(hipStreamSynchronize(s));
-    bool gathered = false;
     for (int d = 0; d < 8; ++d) {
       bool constant = false;
       for (int b = 0; b < 256; ++b)
-        if (hh[d * 256 + b] == (uint64_t)n) constant = true;
+        if (hh[d * 256 + b] == (uint64_t)m) constant = true;
       if (constant) continue;  // every element has the same digit: the pass would be the identity
-      if (!gathered) {  // the image in the CURRENT order
-        DFX_HIP(launch_sort_gather_u64(src, (const uint32_t*)idx_a.get(), n, (uint64_t*)img_a.get(), s));
-        gathered = true;
-      }
-      DFX_HIP(launch_radix_count((const uint64_t*)img_a.get(), n, 8 * d, (uint32_t*)counts.get(), s));
+      DFX_HIP(launch_radix_count((const uint64_t*)img_a.get(), m, 8 * d, (uint32_t*)counts.get(), s));
       DFX_HIP(launch_scan_u32((const uint32_t*)counts.get(), (uint64_t*)offsets.get(), 256 * tiles, (uint64_t*)tmp.get(), s));
-      DFX_HIP(launch_radix_scatter((const uint64_t*)img_a.get(), (const uint32_t*)idx_a.get(), n, 8 * d,
+      DFX_HIP(launch_radix_scatter((const uint64_t*)img_a.get(), (const uint32_t*)idx_a.get(), m, 8 * d,
                                    (const uint64_t*)offsets.get(), (uint64_t*)img_b.get(), (uint32_t*)idx_b.get(), s));
       std::swap(img_a, img_b);
       std::swap(idx_a, idx_b);
@@ -173,6 +177,70 @@ Status SortRelation::sort_by_key(const std::vector<DeviceBatch>& batches, int ke
   if (any_nulls) DFX_RETURN_IF_ERROR(sort_by_image((const uint64_t*)null_image.get()));  // most significant: NULLs last / first
   *idx = idx_a;
   DFX_HIP(hipStreamSynchronize(s));
+  return Status::OK();
+}
+
+// ORDER BY ... LIMIT k without sorting everything: radix-select the k-th smallest image T of the first key (8 rounds of
+// one 256-bin histogram over the rows that still match the prefix), keep the rows with image <= T (at least k; ties
+// included, input order kept), and sort only those.  Not applicable (full sort instead): Utf8 or nullable first key.
+Status SortRelation::select_candidates(const std::vector<DeviceBatch>& batches, int64_t n, int64_t k, std::shared_ptr<void>* idx,
+                                       int64_t* m) {
+  hipStream_t s = ctx().stream;
+  Status st;
+  const int col = n_payload_;
+  for (const DeviceBatch& b : batches) {
+    const DeviceColumn& c = b.columns[(size_t)col];
+    if (c.dtype == DFX_UTF8 || (c.validity && c.null_count != 0)) return Status::OK();  // *m stays n: full sort
+  }
+  auto image = device_alloc(sizeof(uint64_t) * (size_t)n, &st);
+  if (!image) return st;
+  int64_t at = 0;
+  for (const DeviceBatch& b : batches) {
+    const DeviceColumn& c = b.columns[(size_t)col];
+    DFX_HIP(launch_sort_image(c.values, nullptr, c.bit_offset, (uint8_t)c.dtype, asc_[0], b.num_rows, (uint64_t*)image.get() + at, nullptr, s));
+    at += b.num_rows;
+  }
+  auto hist = device_alloc(sizeof(uint64_t) * 256, &st);
+  if (!hist) return st;
+  uint64_t prefix = 0, mask = 0;
+  int64_t rank = k;  // 1-based rank of the wanted element among the rows matching the prefix
+  for (int d = 7; d >= 0; --d) {
+    DFX_HIP(hipMemsetAsync(hist.get(), 0, sizeof(uint64_t) * 256, s));
+    DFX_HIP(launch_select_hist((const uint64_t*)image.get(), n, prefix, mask, 8 * d, (uint64_t*)hist.get(), s));
+    uint64_t hh[256];
+    DFX_HIP(hipMemcpyAsync(hh, hist.get(), sizeof(hh), hipMemcpyDeviceToHost, s));
+    DFX_HIP(hipStreamSynchronize(s));
+    int b = 0;
+    for (; b < 256; ++b) {
+      if ((int64_t)hh[b] >= rank) break;
+      rank -= (int64_t)hh[b];
+    }
+    if (b == 256) return Status::Err(DFX_INTERNAL_ERROR, "top-k selection lost its element");
+    prefix |= (uint64_t)b << (8 * d);
+    mask |= 0xFFull << (8 * d);
+  }
+  // rows with image <= prefix, in input order
+  const int64_t n_words = (n + 63) / 64, n_tiles = (n + kTileRows - 1) / kTileRows;
+  auto mw = device_alloc(sizeof(uint64_t) * (size_t)n_words, &st);
+  if (!mw) return st;
+  auto tc = device_alloc(sizeof(uint32_t) * (size_t)n_tiles, &st);
+  if (!tc) return st;
+  auto to = device_alloc(sizeof(uint64_t) * (size_t)(n_tiles + 1), &st);
+  if (!to) return st;
+  auto tmp = device_alloc(sizeof(uint64_t) * (size_t)(n_tiles / 4096 + 4), &st);
+  if (!tmp) return st;
+  DFX_HIP(launch_select_mask((const uint64_t*)image.get(), n, prefix, (uint64_t*)mw.get(), (uint32_t*)tc.get(), s));
+  DFX_HIP(launch_scan_u32((const uint32_t*)tc.get(), (uint64_t*)to.get(), n_tiles, (uint64_t*)tmp.get(), s));
+  uint64_t kept = 0;
+  DFX_HIP(hipMemcpyAsync(&kept, (uint64_t*)to.get() + n_tiles, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+  DFX_HIP(hipStreamSynchronize(s));
+  if ((int64_t)kept < k) return Status::Err(DFX_INTERNAL_ERROR, "top-k selection kept too few rows");
+  auto cand = device_alloc(sizeof(uint32_t) * (size_t)kept, &st);
+  if (!cand) return st;
+  DFX_HIP(launch_compact(idx->get(), 4, (const uint64_t*)mw.get(), (const uint64_t*)to.get(), n, cand.get(), 0, s));
+  DFX_HIP(hipStreamSynchronize(s));
+  *idx = cand;
+  *m = (int64_t)kept;
   return Status::OK();
 }
 
@@ -202,7 +270,15 @@ Status SortRelation::next(DeviceBatch* out, bool* has) {
   if (!idx0) return st;
   std::shared_ptr<void> idx = idx0;
   DFX_HIP(launch_sort_iota((uint32_t*)idx.get(), n, s));
-  for (int k = (int)keys_.size() - 1; k >= 0; --k) DFX_RETURN_IF_ERROR(sort_by_key(batches, k, n, &idx));
+  int64_t m = n;         // rows that take part in the sort
+  int64_t n_out = n;     // rows that are emitted
+  if (limit_ >= 0 && limit_ < n) {
+    n_out = limit_;
+    if (n_out == 0) return Status::OK();
+    if (limit_ <= n / 8) DFX_RETURN_IF_ERROR(select_candidates(batches, n, limit_, &idx, &m));  // else: sort everything
+  }
+  for (int k = (int)keys_.size() - 1; k >= 0; --k) DFX_RETURN_IF_ERROR(sort_by_key(batches, k, n, m, &idx));
+  n = n_out;  // from here on: the rows that are emitted (the first n_out of the sorted permutation)
   // (batch, row) of every output row, then gather the payload columns from the input batches
   const int nb = (int)batches.size();
   std::vector<uint64_t> starts((size_t)nb + 1, 0);
@@ -393,6 +469,7 @@ int32_t dfx_limit_relation_new(struct ArrowArrayStream* input, int64_t limit, co
     SchemaInfo si;
     st = schema_from_arrow(schema, &si);
     if (!st.ok()) return to_c(st, err, errlen);
+    if (in->kind() == REL_SORT) static_cast<SortRelation*>(in.get())->set_limit(limit);  // ORDER BY ... LIMIT k: top-k
     std::unique_ptr<Relation> rel(new LimitRelation(std::move(in), limit, si));
     export_relation(std::move(rel), out);
     return DFX_OK;

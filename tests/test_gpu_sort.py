@@ -139,3 +139,39 @@ def test_sort_large_properties():
     src = pa.Table.from_batches(list(table.scan(1 << 22)))
     assert float(np.sum(v)) == float(np.sum(src.column(1).to_numpy()))
     assert int(np.sum(out.column(2).to_numpy())) == int(np.sum(src.column(2).to_numpy()))
+
+
+@pytest.mark.parametrize("with_nulls", [False, True])
+def test_top_k_equals_full_sort_prefix(with_nulls):
+    """ORDER BY ... LIMIT k: the sort under a Limit selects candidates by the first key (radix select) instead of sorting
+    everything; every k, key shape and tie pattern must give the prefix of the full sort (with nulls in the first key the
+    full sort runs)."""
+    rng = np.random.default_rng(23)
+    batches = [_mixed_batch(rng, n, with_nulls) for n in (2500, 1, 4000)]
+    schema = batches[0].schema
+    n = sum(b.num_rows for b in batches)
+    for keys in ([(Column(1), True)], [(Column(1), False)], [(Column(0), True), (Column(4), False)],  # a: 10 distinct values: many ties
+                 [(Column(2), False), (Column(1), True)], [(Column(5), True), (Column(2), True)]):
+        full = oracle.sort_batches(batches, keys)
+        for k in (1, 17, 500, n // 8, n // 8 + 1, n - 1, n, n + 5):
+            got = gpu_sort(batches, schema, keys, limit=k)
+            want = full.slice(0, min(k, n))
+            assert len(got) == 1 and got[0].num_rows == min(k, n), (keys, k)
+            assert_batches_identical(got[0], want, f"top-{k} of {keys} nulls={with_nulls}")
+
+
+def test_top_k_large():
+    """2^26 resident rows, top 10 by a Float64 key: equals the 10 smallest of the column (numpy), in order."""
+    n = 1 << 26
+    syn = [("k", ex.SYNTH_I64_UNIFORM, 0, float(2**40), 0.0), ("v", ex.SYNTH_F64_UNIFORM, 1, -5.0, 10.0)]
+    schema = pa.schema([("k", pa.int64()), ("v", pa.float64())])
+    table = ex.DeviceTable.synth(syn, 0xDF06, 0, n)
+    rel = ex.LimitRelation(ex.SortRelation(table.scan(1 << 24), [(ex.compile_scalar_expr(None, Column(1), schema), True)], schema), 10, schema)
+    import time
+    t0 = time.perf_counter()
+    out = rel.next()
+    dt = time.perf_counter() - t0
+    v = pa.Table.from_batches(list(table.scan(1 << 24))).column(1).to_numpy()
+    want = np.sort(v)[:10]
+    assert out.num_rows == 10 and np.array_equal(out.column(1).to_numpy(), want)
+    print(f"top-10 of 2^26 rows: {dt * 1e3:.1f} ms = {n / dt / 1e9:.1f} G rows/s")
