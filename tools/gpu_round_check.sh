@@ -1,7 +1,6 @@
 #!/bin/bash
-# What the driver runs at round end, plus the rocprofv3 evidence: GPU test suite, smoke, default bench, profile passes.
+# What the driver runs at round end: GPU test suite, smoke, default bench.  (tools/gpu_profile_bench.sh adds the rocprofv3 passes.)
 mkdir -p gpurun_out; export TMPDIR=/tmp
 timeout 1500 python -m pytest tests -m gpu -q --timeout 600 > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -n 4 gpurun_out/pytest_gpu.log
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
 timeout 900 python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err; echo "bench rc=$?"
-bash tools/gpu_profile_bench.sh 2>&1 | tail -9
