@@ -44,8 +44,8 @@ def main():
     ap.add_argument("--cpu-sample-rows", type=float, default=3e8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
-    ap.add_argument("--prewarm-steps", type=int, default=150,
-                    help="untimed steps before the W warmup steps (~1 s: a fresh box runs its first moments slower); "
+    ap.add_argument("--prewarm-steps", type=int, default=600,
+                    help="untimed steps before the W warmup steps (~3.5 s: the first seconds of the first process on an idle box run ~4 % slower); "
                          "a fixed count so that every rank runs the same number of exchanges")
     args = ap.parse_args()
 
