@@ -17,6 +17,12 @@ Multi-GPU (--gpus N, launched by torch.distributed.run): weak scaling, every ran
 global row range, aggregates locally, exchanges GROUP partials with one RCCL all-to-all, merges and
 emits the groups it owns.  value = rows of all ranks / max-over-ranks time.
 
+Timing: `--prewarm-steps` untimed steps (idle-box clocks), W warm-up steps, then EXACTLY K steps between barrier +
+synchronize on both sides, un-instrumented -> value / ms_per_step; then K more steps with the library's HIP-event profiler
+on -> the per-kernel durations of the `roofline` object (extra.instrumented_ms_per_step is that region's time).  At N=1 the
+line also carries cpu_baseline (the C restatement of the reference on one host core, 3e8-row sample) and, in `extra`, the
+other BASELINE configs that fit one GPU (config 3: no filter; config 2: predicate + COUNT; config 5: the Q1 shape).
+
 Prints ONE JSON line on rank 0.
 """
 import argparse
