@@ -85,3 +85,27 @@ def test_oracle_filter_and_aggregates_agree_with_pyarrow(seed):
     tot = oracle.aggregate([], aggs, [bb])
     v, i = bb.column(1).to_numpy(), bb.column(2).to_numpy()
     assert tot.to_pylist()[0] == {"c0": float(v.min()), "c1": float(v.max()), "c2": len(v), "c3": int(i.sum())}
+
+
+def test_oracle_sort_agrees_with_pyarrow_and_limit():
+    """ORDER BY semantics the library defines (reference: unimplemented): on null-free, NaN-free data the naive oracle must
+    equal pyarrow's stable sort; NULL placement (largest) is checked against pyarrow's null_placement."""
+    rng = np.random.default_rng(11)
+    n = 4000
+    b = pa.RecordBatch.from_arrays([pa.array(rng.integers(-5, 5, n).astype(np.int64)), pa.array(rng.standard_normal(n)),
+                                    pa.array([f"s{int(x)}" for x in rng.integers(0, 50, n)]), pa.array(np.arange(n))],
+                                   names=["a", "f", "s", "row"])
+    t = pa.Table.from_batches([b])
+    for keys, pa_keys in [([(Column(0), True), (Column(1), False)], [("a", "ascending"), ("f", "descending")]),
+                          ([(Column(2), False), (Column(0), True)], [("s", "descending"), ("a", "ascending")]),
+                          ([(Column(1), True)], [("f", "ascending")])]:
+        got = oracle.sort_batches([b.slice(0, 1500), b.slice(1500)], keys)
+        want = t.take(pc.sort_indices(t, sort_keys=pa_keys))  # pyarrow's sort is stable
+        assert got.column(3).to_pylist() == want.column("row").to_pylist(), keys
+    bn = pa.RecordBatch.from_arrays([pa.array(rng.integers(0, 9, n).astype(np.int64), mask=rng.random(n) < 0.2), pa.array(np.arange(n))], names=["a", "row"])
+    tn = pa.Table.from_batches([bn])
+    asc = oracle.sort_batches([bn], [(Column(0), True)])
+    assert asc.column(1).to_pylist() == tn.take(pc.sort_indices(tn, sort_keys=[("a", "ascending")], null_placement="at_end")).column("row").to_pylist()
+    desc = oracle.sort_batches([bn], [(Column(0), False)])
+    assert desc.column(1).to_pylist() == tn.take(pc.sort_indices(tn, sort_keys=[("a", "descending")], null_placement="at_start")).column("row").to_pylist()
+    assert [x.num_rows for x in oracle.limit_batches([bn.slice(0, 10), bn.slice(10, 10)], 13)] == [10, 3]
