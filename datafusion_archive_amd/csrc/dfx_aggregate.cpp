@@ -1218,7 +1218,7 @@ int32_t dfx_aggregate_relation_new(const struct ArrowSchema* schema, struct Arro
                                    const dfx_runtime_expr* const* group_exprs, int32_t n_group,
                                    const dfx_runtime_expr* const* aggr_exprs, int32_t n_aggr,
                                    struct ArrowArrayStream* out, char* err, size_t errlen) {
-  try {
+  return c_abi_guard(err, errlen, [&]() -> int32_t {
     if (!out) return to_c(Status::Err(DFX_GENERAL, "null argument"), err, errlen);
     std::unique_ptr<Relation> in;
     Status st = adopt_input_stream(input, &in);
@@ -1232,9 +1232,7 @@ int32_t dfx_aggregate_relation_new(const struct ArrowSchema* schema, struct Arro
     std::unique_ptr<Relation> rel(new AggregateRelation(si, std::move(in), std::move(g), std::move(a)));
     export_relation(std::move(rel), out);
     return DFX_OK;
-  } catch (const std::exception& e) {
-    return to_c(Status::Err(DFX_INTERNAL_ERROR, e.what()), err, errlen);
-  }
+  });
 }
 
 static AggregateRelation* as_aggregate(struct ArrowArrayStream* s) {
@@ -1245,38 +1243,32 @@ static AggregateRelation* as_aggregate(struct ArrowArrayStream* s) {
 
 int32_t dfx_aggregate_partial_build(struct ArrowArrayStream* agg, int32_t world, int32_t* n_words, int64_t* counts,
                                     char* err, size_t errlen) {
-  try {
+  return c_abi_guard(err, errlen, [&]() -> int32_t {
     AggregateRelation* a = as_aggregate(agg);
     if (!a) return to_c(Status::Err(DFX_GENERAL, "not an aggregate stream of this library"), err, errlen);
     int nw = 0;
     Status st = a->partial_build(world, &nw, counts);
     if (n_words) *n_words = nw;
     return to_c(st, err, errlen);
-  } catch (const std::exception& e) {
-    return to_c(Status::Err(DFX_INTERNAL_ERROR, e.what()), err, errlen);
-  }
+  });
 }
 
 int32_t dfx_aggregate_partial_export(struct ArrowArrayStream* agg, void* dst_device, int64_t dst_words, char* err,
                                      size_t errlen) {
-  try {
+  return c_abi_guard(err, errlen, [&]() -> int32_t {
     AggregateRelation* a = as_aggregate(agg);
     if (!a) return to_c(Status::Err(DFX_GENERAL, "not an aggregate stream of this library"), err, errlen);
     return to_c(a->partial_export(dst_device, dst_words), err, errlen);
-  } catch (const std::exception& e) {
-    return to_c(Status::Err(DFX_INTERNAL_ERROR, e.what()), err, errlen);
-  }
+  });
 }
 
 int32_t dfx_aggregate_partial_import(struct ArrowArrayStream* agg, const void* src_device, const int64_t* counts,
                                      int32_t n_buckets, char* err, size_t errlen) {
-  try {
+  return c_abi_guard(err, errlen, [&]() -> int32_t {
     AggregateRelation* a = as_aggregate(agg);
     if (!a) return to_c(Status::Err(DFX_GENERAL, "not an aggregate stream of this library"), err, errlen);
     return to_c(a->partial_import(src_device, counts, n_buckets), err, errlen);
-  } catch (const std::exception& e) {
-    return to_c(Status::Err(DFX_INTERNAL_ERROR, e.what()), err, errlen);
-  }
+  });
 }
 
 }  // extern "C"

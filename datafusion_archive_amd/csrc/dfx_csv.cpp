@@ -288,7 +288,7 @@ extern "C" {
 
 int32_t dfx_csv_datasource_new(const char* filename, const struct ArrowSchema* schema, int64_t batch_size,
                                struct ArrowArrayStream* out, char* err, size_t errlen) {
-  try {
+  return c_abi_guard(err, errlen, [&]() -> int32_t {
     if (!filename || !schema || !out) return to_c(Status::Err(DFX_GENERAL, "null argument"), err, errlen);
     SchemaInfo si;
     Status st = schema_from_arrow(schema, &si);
@@ -298,9 +298,7 @@ int32_t dfx_csv_datasource_new(const char* filename, const struct ArrowSchema* s
     if (!st.ok()) return to_c(st, err, errlen);
     export_relation(std::move(rel), out);
     return DFX_OK;
-  } catch (const std::exception& e) {
-    return to_c(Status::Err(DFX_INTERNAL_ERROR, e.what()), err, errlen);
-  }
+  });
 }
 
 }  // extern "C"

@@ -461,59 +461,63 @@ int32_t dfx_abi_version(void) { return DFX_ABI_VERSION; }
 int32_t dfx_compile_scalar_expr(const dfx_expr_node* nodes, int32_t n_nodes, int32_t root,
                                 const struct ArrowSchema* input_schema, dfx_runtime_expr** out, char* err,
                                 size_t errlen) {
-  if (!out) return to_c(Status::Err(DFX_INTERNAL_ERROR, "null output"), err, errlen);
-  *out = nullptr;
-  SchemaInfo schema;
-  Status st = schema_from_arrow(input_schema, &schema);
-  if (!st.ok()) return to_c(st, err, errlen);
-  std::unique_ptr<dfx_runtime_expr> e(new dfx_runtime_expr());
-  st = copy_tree(nodes, n_nodes, root, e.get());
-  if (!st.ok()) return to_c(st, err, errlen);
-  st = validate_scalar(e->nodes, e->root, schema, &e->name);
-  if (!st.ok()) return to_c(st, err, errlen);
-  st = node_type(e->nodes, e->root, schema, &e->dtype);
-  if (!st.ok()) return to_c(st, err, errlen);
-  *out = e.release();
-  return DFX_OK;
+  return c_abi_guard(err, errlen, [&]() -> int32_t {
+    if (!out) return to_c(Status::Err(DFX_INTERNAL_ERROR, "null output"), err, errlen);
+    *out = nullptr;
+    SchemaInfo schema;
+    Status st = schema_from_arrow(input_schema, &schema);
+    if (!st.ok()) return to_c(st, err, errlen);
+    std::unique_ptr<dfx_runtime_expr> e(new dfx_runtime_expr());
+    st = copy_tree(nodes, n_nodes, root, e.get());
+    if (!st.ok()) return to_c(st, err, errlen);
+    st = validate_scalar(e->nodes, e->root, schema, &e->name);
+    if (!st.ok()) return to_c(st, err, errlen);
+    st = node_type(e->nodes, e->root, schema, &e->dtype);
+    if (!st.ok()) return to_c(st, err, errlen);
+    *out = e.release();
+    return DFX_OK;
+  });
 }
 
 int32_t dfx_compile_expr(const dfx_expr_node* nodes, int32_t n_nodes, int32_t root,
                          const struct ArrowSchema* input_schema, dfx_runtime_expr** out, char* err,
                          size_t errlen) {
-  if (!nodes || root < 0 || root >= n_nodes)
-    return to_c(Status::Err(DFX_INTERNAL_ERROR, "invalid expression tree"), err, errlen);
-  if (nodes[root].kind != DFX_EXPR_AGGREGATE_FUNCTION)  // expression.rs:119
-    return dfx_compile_scalar_expr(nodes, n_nodes, root, input_schema, out, err, errlen);
-  if (!out) return to_c(Status::Err(DFX_INTERNAL_ERROR, "null output"), err, errlen);
-  *out = nullptr;
-  SchemaInfo schema;
-  Status st = schema_from_arrow(input_schema, &schema);
-  if (!st.ok()) return to_c(st, err, errlen);
-  std::unique_ptr<dfx_runtime_expr> e(new dfx_runtime_expr());
-  st = copy_tree(nodes, n_nodes, root, e.get());
-  if (!st.ok()) return to_c(st, err, errlen);
-  const dfx_expr_node& n = e->nodes[root];
-  if (n.n_args != 1)  // assert_eq!(1, args.len()) (expression.rs:91)
-    return to_c(Status::Err(DFX_INTERNAL_ERROR, strfmt("assertion failed: `(left == right)` left: `1`, right: `%d`", n.n_args)), err, errlen);
-  st = validate_scalar(e->nodes, n.left, schema, nullptr);
-  if (!st.ok()) return to_c(st, err, errlen);
-  const char* nm = n.name ? n.name : "";
-  int f = -1;
-  if (!strcasecmp(nm, "min")) f = AGG_MIN;
-  else if (!strcasecmp(nm, "max")) f = AGG_MAX;
-  else if (!strcasecmp(nm, "count")) f = AGG_COUNT;
-  else if (!strcasecmp(nm, "sum")) f = AGG_SUM;
-  else if (!strcasecmp(nm, "avg")) f = AGG_AVG;  // deviation D7: typed by the planner (sqlplanner.rs:309-322), no executor in the reference
-  if (f < 0)  // expression.rs:103-106
-    return to_c(Status::Err(DFX_GENERAL, std::string("Unsupported aggregate function '") + nm + "'"), err, errlen);
-  e->is_aggregate = true;
-  e->agg_func = f;
-  e->agg_arg = n.left;
-  e->agg_type = n.dtype;
-  e->dtype = n.dtype;
-  e->name = nm;
-  *out = e.release();
-  return DFX_OK;
+  return c_abi_guard(err, errlen, [&]() -> int32_t {
+    if (!nodes || root < 0 || root >= n_nodes)
+      return to_c(Status::Err(DFX_INTERNAL_ERROR, "invalid expression tree"), err, errlen);
+    if (nodes[root].kind != DFX_EXPR_AGGREGATE_FUNCTION)  // expression.rs:119
+      return dfx_compile_scalar_expr(nodes, n_nodes, root, input_schema, out, err, errlen);
+    if (!out) return to_c(Status::Err(DFX_INTERNAL_ERROR, "null output"), err, errlen);
+    *out = nullptr;
+    SchemaInfo schema;
+    Status st = schema_from_arrow(input_schema, &schema);
+    if (!st.ok()) return to_c(st, err, errlen);
+    std::unique_ptr<dfx_runtime_expr> e(new dfx_runtime_expr());
+    st = copy_tree(nodes, n_nodes, root, e.get());
+    if (!st.ok()) return to_c(st, err, errlen);
+    const dfx_expr_node& n = e->nodes[root];
+    if (n.n_args != 1)  // assert_eq!(1, args.len()) (expression.rs:91)
+      return to_c(Status::Err(DFX_INTERNAL_ERROR, strfmt("assertion failed: `(left == right)` left: `1`, right: `%d`", n.n_args)), err, errlen);
+    st = validate_scalar(e->nodes, n.left, schema, nullptr);
+    if (!st.ok()) return to_c(st, err, errlen);
+    const char* nm = n.name ? n.name : "";
+    int f = -1;
+    if (!strcasecmp(nm, "min")) f = AGG_MIN;
+    else if (!strcasecmp(nm, "max")) f = AGG_MAX;
+    else if (!strcasecmp(nm, "count")) f = AGG_COUNT;
+    else if (!strcasecmp(nm, "sum")) f = AGG_SUM;
+    else if (!strcasecmp(nm, "avg")) f = AGG_AVG;  // deviation D7: typed by the planner (sqlplanner.rs:309-322), no executor in the reference
+    if (f < 0)  // expression.rs:103-106
+      return to_c(Status::Err(DFX_GENERAL, std::string("Unsupported aggregate function '") + nm + "'"), err, errlen);
+    e->is_aggregate = true;
+    e->agg_func = f;
+    e->agg_arg = n.left;
+    e->agg_type = n.dtype;
+    e->dtype = n.dtype;
+    e->name = nm;
+    *out = e.release();
+    return DFX_OK;
+  });
 }
 
 const char* dfx_runtime_expr_name(const dfx_runtime_expr* e) { return e ? e->name.c_str() : ""; }

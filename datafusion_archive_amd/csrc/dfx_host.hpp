@@ -8,7 +8,9 @@
 #include <hip/hip_runtime_api.h>
 #include <stdint.h>
 
+#include <exception>
 #include <memory>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -32,6 +34,21 @@ struct Status {
 };
 std::string strfmt(const char* fmt, ...);
 int32_t to_c(const Status& s, char* err, size_t errlen);
+
+// Every extern "C" entry point runs its body through this: nothing unwinds across the C ABI (a Rust / C caller cannot catch a
+// C++ exception), the caller gets DFX_INTERNAL_ERROR and the message instead.
+template <class Body>
+int32_t c_abi_guard(char* err, size_t errlen, Body&& body) noexcept {
+  try {
+    return body();
+  } catch (const std::bad_alloc&) {
+    return to_c(Status::Err(DFX_EXECUTION_ERROR, "out of host memory"), err, errlen);
+  } catch (const std::exception& e) {
+    return to_c(Status::Err(DFX_INTERNAL_ERROR, e.what()), err, errlen);
+  } catch (...) {
+    return to_c(Status::Err(DFX_INTERNAL_ERROR, "unknown C++ exception"), err, errlen);
+  }
+}
 
 #define DFX_RETURN_IF_ERROR(expr)   \
   do {                              \

@@ -689,7 +689,7 @@ extern "C" {
 int32_t dfx_filter_relation_new(struct ArrowArrayStream* input, const dfx_runtime_expr* expr,
                                 const struct ArrowSchema* schema, struct ArrowArrayStream* out, char* err,
                                 size_t errlen) {
-  try {
+  return c_abi_guard(err, errlen, [&]() -> int32_t {
     if (!expr || !out) return to_c(Status::Err(DFX_GENERAL, "null argument"), err, errlen);
     std::unique_ptr<Relation> in;
     Status st = adopt_input_stream(input, &in);
@@ -703,15 +703,13 @@ int32_t dfx_filter_relation_new(struct ArrowArrayStream* input, const dfx_runtim
     std::unique_ptr<Relation> rel(new FilterRelation(std::move(in), *expr, si));
     export_relation(std::move(rel), out);
     return DFX_OK;
-  } catch (const std::exception& e) {
-    return to_c(Status::Err(DFX_INTERNAL_ERROR, e.what()), err, errlen);
-  }
+  });
 }
 
 int32_t dfx_project_relation_new(struct ArrowArrayStream* input, const dfx_runtime_expr* const* exprs,
                                  int32_t n_exprs, const struct ArrowSchema* schema, struct ArrowArrayStream* out,
                                  char* err, size_t errlen) {
-  try {
+  return c_abi_guard(err, errlen, [&]() -> int32_t {
     if (!out || (n_exprs > 0 && !exprs)) return to_c(Status::Err(DFX_GENERAL, "null argument"), err, errlen);
     std::unique_ptr<Relation> in;
     Status st = adopt_input_stream(input, &in);
@@ -726,9 +724,7 @@ int32_t dfx_project_relation_new(struct ArrowArrayStream* input, const dfx_runti
     std::unique_ptr<Relation> rel(new ProjectRelation(std::move(in), std::move(ev), si));
     export_relation(std::move(rel), out);
     return DFX_OK;
-  } catch (const std::exception& e) {
-    return to_c(Status::Err(DFX_INTERNAL_ERROR, e.what()), err, errlen);
-  }
+  });
 }
 
 }  // extern "C"

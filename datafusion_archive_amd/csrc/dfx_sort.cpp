@@ -436,7 +436,7 @@ extern "C" {
 int32_t dfx_sort_relation_new(struct ArrowArrayStream* input, const dfx_runtime_expr* const* exprs, const int32_t* ascending,
                               int32_t n_exprs, const struct ArrowSchema* schema, struct ArrowArrayStream* out, char* err,
                               size_t errlen) {
-  try {
+  return c_abi_guard(err, errlen, [&]() -> int32_t {
     if (!out || n_exprs < 1 || !exprs || !ascending) return to_c(Status::Err(DFX_GENERAL, "invalid argument"), err, errlen);
     std::unique_ptr<Relation> in;
     Status st = adopt_input_stream(input, &in);
@@ -454,14 +454,12 @@ int32_t dfx_sort_relation_new(struct ArrowArrayStream* input, const dfx_runtime_
     std::unique_ptr<Relation> rel(new SortRelation(std::move(in), std::move(keys), std::move(asc), si));
     export_relation(std::move(rel), out);
     return DFX_OK;
-  } catch (const std::exception& e) {
-    return to_c(Status::Err(DFX_INTERNAL_ERROR, e.what()), err, errlen);
-  }
+  });
 }
 
 int32_t dfx_limit_relation_new(struct ArrowArrayStream* input, int64_t limit, const struct ArrowSchema* schema,
                                struct ArrowArrayStream* out, char* err, size_t errlen) {
-  try {
+  return c_abi_guard(err, errlen, [&]() -> int32_t {
     if (!out || limit < 0) return to_c(Status::Err(DFX_GENERAL, "invalid argument"), err, errlen);
     std::unique_ptr<Relation> in;
     Status st = adopt_input_stream(input, &in);
@@ -473,9 +471,7 @@ int32_t dfx_limit_relation_new(struct ArrowArrayStream* input, int64_t limit, co
     std::unique_ptr<Relation> rel(new LimitRelation(std::move(in), limit, si));
     export_relation(std::move(rel), out);
     return DFX_OK;
-  } catch (const std::exception& e) {
-    return to_c(Status::Err(DFX_INTERNAL_ERROR, e.what()), err, errlen);
-  }
+  });
 }
 
 }  // extern "C"

@@ -222,37 +222,43 @@ using namespace dfx;
 extern "C" {
 
 int32_t dfx_init(int32_t device_ordinal, char* err, size_t errlen) {
-  Context& c = ctx();
-  if (c.initialised && c.device != device_ordinal)
-    return to_c(Status::Err(DFX_GENERAL, "dfx_init: the library is already bound to another device"), err, errlen);
-  c.device = device_ordinal;
-  return to_c(ensure_init(), err, errlen);
+  return c_abi_guard(err, errlen, [&]() -> int32_t {
+    Context& c = ctx();
+    if (c.initialised && c.device != device_ordinal)
+      return to_c(Status::Err(DFX_GENERAL, "dfx_init: the library is already bound to another device"), err, errlen);
+    c.device = device_ordinal;
+    return to_c(ensure_init(), err, errlen);
+  });
 }
 
 int32_t dfx_device_info(char* name, size_t namelen, int32_t* n_cu, int64_t* hbm_bytes, int32_t* wavefront, char* err,
                         size_t errlen) {
-  Status st = ensure_init();
-  if (!st.ok()) return to_c(st, err, errlen);
-  hipDeviceProp_t prop;
-  hipError_t e = hipGetDeviceProperties(&prop, ctx().device);
-  if (e != hipSuccess) return to_c(Status::Err(DFX_EXECUTION_ERROR, hipGetErrorString(e)), err, errlen);
-  if (name && namelen) snprintf(name, namelen, "%s (%s)", prop.name, prop.gcnArchName);
-  if (n_cu) *n_cu = prop.multiProcessorCount;
-  if (hbm_bytes) *hbm_bytes = (int64_t)prop.totalGlobalMem;
-  if (wavefront) *wavefront = prop.warpSize;
-  return DFX_OK;
+  return c_abi_guard(err, errlen, [&]() -> int32_t {
+    Status st = ensure_init();
+    if (!st.ok()) return to_c(st, err, errlen);
+    hipDeviceProp_t prop;
+    hipError_t e = hipGetDeviceProperties(&prop, ctx().device);
+    if (e != hipSuccess) return to_c(Status::Err(DFX_EXECUTION_ERROR, hipGetErrorString(e)), err, errlen);
+    if (name && namelen) snprintf(name, namelen, "%s (%s)", prop.name, prop.gcnArchName);
+    if (n_cu) *n_cu = prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = (int64_t)prop.totalGlobalMem;
+    if (wavefront) *wavefront = prop.warpSize;
+    return DFX_OK;
+  });
 }
 
 int32_t dfx_synchronize(char* err, size_t errlen) {
-  Status st = ensure_init();
-  if (!st.ok()) return to_c(st, err, errlen);
-  hipError_t e = hipStreamSynchronize(ctx().stream);
-  if (e != hipSuccess) return to_c(Status::Err(DFX_EXECUTION_ERROR, hipGetErrorString(e)), err, errlen);
-  return DFX_OK;
+  return c_abi_guard(err, errlen, [&]() -> int32_t {
+    Status st = ensure_init();
+    if (!st.ok()) return to_c(st, err, errlen);
+    hipError_t e = hipStreamSynchronize(ctx().stream);
+    if (e != hipSuccess) return to_c(Status::Err(DFX_EXECUTION_ERROR, hipGetErrorString(e)), err, errlen);
+    return DFX_OK;
+  });
 }
 
 int32_t dfx_table_from_stream(struct ArrowArrayStream* input, dfx_table** out, char* err, size_t errlen) {
-  try {
+  return c_abi_guard(err, errlen, [&]() -> int32_t {
     if (!out) return to_c(Status::Err(DFX_GENERAL, "null argument"), err, errlen);
     *out = nullptr;
     Status st = ensure_init();
@@ -265,14 +271,12 @@ int32_t dfx_table_from_stream(struct ArrowArrayStream* input, dfx_table** out, c
     if (!st.ok()) return to_c(st, err, errlen);
     *out = new dfx_table{t};
     return DFX_OK;
-  } catch (const std::exception& e) {
-    return to_c(Status::Err(DFX_INTERNAL_ERROR, e.what()), err, errlen);
-  }
+  });
 }
 
 int32_t dfx_table_synth(const dfx_synth_column* cols, int32_t n_cols, uint64_t seed, int64_t row_begin, int64_t n_rows,
                         dfx_table** out, char* err, size_t errlen) {
-  try {
+  return c_abi_guard(err, errlen, [&]() -> int32_t {
     if (!out || !cols || n_cols < 1 || n_rows < 0) return to_c(Status::Err(DFX_GENERAL, "invalid argument"), err, errlen);
     *out = nullptr;
     Status st = ensure_init();
@@ -303,9 +307,7 @@ int32_t dfx_table_synth(const dfx_synth_column* cols, int32_t n_cols, uint64_t s
     if (e != hipSuccess) return to_c(Status::Err(DFX_EXECUTION_ERROR, hipGetErrorString(e)), err, errlen);
     *out = new dfx_table{t};
     return DFX_OK;
-  } catch (const std::exception& e) {
-    return to_c(Status::Err(DFX_INTERNAL_ERROR, e.what()), err, errlen);
-  }
+  });
 }
 
 int64_t dfx_table_num_rows(const dfx_table* t) { return t ? t->data->num_rows : 0; }
@@ -316,10 +318,12 @@ const void* dfx_table_column_device_ptr(const dfx_table* t, int32_t column) {
 }
 
 int32_t dfx_table_scan_new(const dfx_table* t, int64_t batch_rows, struct ArrowArrayStream* out, char* err, size_t errlen) {
-  if (!t || !out) return to_c(Status::Err(DFX_GENERAL, "null argument"), err, errlen);
-  std::unique_ptr<Relation> rel(new TableScanRelation(t->data, batch_rows));
-  export_relation(std::move(rel), out);
-  return DFX_OK;
+  return c_abi_guard(err, errlen, [&]() -> int32_t {
+    if (!t || !out) return to_c(Status::Err(DFX_GENERAL, "null argument"), err, errlen);
+    std::unique_ptr<Relation> rel(new TableScanRelation(t->data, batch_rows));
+    export_relation(std::move(rel), out);
+    return DFX_OK;
+  });
 }
 
 void dfx_table_free(dfx_table* t) { delete t; }
