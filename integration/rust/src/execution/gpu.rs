@@ -10,6 +10,7 @@
 //   context.rs:184-189           AggregateRelation::new                   -> GpuRelation::aggregate
 //   datasource.rs:39-43          CsvDataSource::new                       -> GpuRelation::csv
 //   context.rs:113,194           Sort / Limit (unimplemented!())          -> GpuRelation::sort / limit
+//   datasource.rs:27-30          trait DataSource (in-memory, reusable)   -> GpuTable::load / scan
 
 use std::cell::RefCell;
 use std::ffi::{CStr, CString};
@@ -27,7 +28,8 @@ use arrow::error::ArrowError;
 use arrow::record_batch::RecordBatch;
 
 use super::error::{ExecutionError, Result};
-use super::relation::Relation;
+use super::datasource::DataSource;
+use super::relation::{DataSourceRelation, Relation};
 use crate::logicalplan::{Expr, Operator, ScalarValue};
 
 // ---- raw bindings: exactly include/dfx.h -----------------------------------------------------------------
@@ -79,6 +81,8 @@ pub struct DfxExprNode {
     name: *const c_char,
 }
 pub enum DfxRuntimeExpr {}
+#[repr(C)]
+pub enum DfxTable {}
 
 #[link(name = "dfx_hip")]
 extern "C" {
@@ -104,6 +108,12 @@ extern "C" {
                              n: i32, schema: *const ArrowSchema, out: *mut ArrowArrayStream, err: *mut c_char, errlen: usize) -> i32;
     fn dfx_limit_relation_new(input: *mut ArrowArrayStream, limit: i64, schema: *const ArrowSchema,
                               out: *mut ArrowArrayStream, err: *mut c_char, errlen: usize) -> i32;
+    fn dfx_table_from_stream(input: *mut ArrowArrayStream, out: *mut *mut DfxTable, err: *mut c_char, errlen: usize) -> i32;
+    fn dfx_table_scan_new(t: *const DfxTable, batch_rows: i64, out: *mut ArrowArrayStream, err: *mut c_char, errlen: usize) -> i32;
+    fn dfx_table_num_rows(t: *const DfxTable) -> i64;
+    fn dfx_table_free(t: *mut DfxTable);
+    fn dfx_synchronize(err: *mut c_char, errlen: usize) -> i32;
+    fn dfx_set_option(key: *const c_char, value: i64) -> i32;
 }
 
 const ERRLEN: usize = 1024;
@@ -609,6 +619,59 @@ impl Drop for GpuRelation {
         if let Some(r) = self.stream.release {
             unsafe { r(&mut *self.stream) }
         }
+    }
+}
+
+// ---- the in-memory DataSource (datasource.rs:27-30), resident in HBM ------------------------------------------------
+/// A table uploaded once and scanned many times.  `ExecutionContext::register_datasource` keeps an
+/// `Rc<RefCell<DataSource>>` that is consumed by the first query (datasource.rs:55-57); registering a `GpuTable`
+/// instead lets every query start from `table.scan(batch_rows)`, a leaf whose batches never leave the device.
+pub struct GpuTable {
+    handle: *mut DfxTable,
+    schema: Arc<Schema>,
+}
+impl GpuTable {
+    /// Drains `ds` (CSV, Parquet, anything that implements DataSource) through DataSourceRelation into HBM.
+    pub fn load(ds: Rc<RefCell<DataSource>>) -> Result<Self> {
+        let schema = ds.borrow().schema().clone();
+        let rel: Rc<RefCell<Relation>> = Rc::new(RefCell::new(DataSourceRelation::new(ds)));
+        let (mut inp, mut err) = (export_relation(rel), [0 as c_char; ERRLEN]);
+        let mut handle: *mut DfxTable = ptr::null_mut();
+        check(unsafe { dfx_table_from_stream(&mut inp, &mut handle, err.as_mut_ptr(), ERRLEN) }, &err)?;
+        Ok(GpuTable { handle, schema })
+    }
+    pub fn num_rows(&self) -> usize {
+        unsafe { dfx_table_num_rows(self.handle) as usize }
+    }
+    pub fn schema(&self) -> &Arc<Schema> {
+        &self.schema
+    }
+    /// DataSourceRelation over the resident table; `batch_rows` = 0 hands the whole table over as one batch
+    /// (device batches are slices of the resident buffers, so a large batch costs nothing).
+    pub fn scan(&self, batch_rows: usize) -> Result<GpuRelation> {
+        let (mut out, mut err) = (GpuRelation::new_out(), [0 as c_char; ERRLEN]);
+        check(unsafe { dfx_table_scan_new(self.handle, batch_rows as i64, &mut *out, err.as_mut_ptr(), ERRLEN) }, &err)?;
+        GpuRelation::from_stream(out, self.schema.clone())
+    }
+}
+impl Drop for GpuTable {
+    fn drop(&mut self) {
+        unsafe { dfx_table_free(self.handle) } // streams created by scan() hold their own reference to the buffers
+    }
+}
+
+/// Blocks until everything the library has launched is complete (only needed around timing code).
+pub fn synchronize() -> Result<()> {
+    let mut err = [0 as c_char; ERRLEN];
+    check(unsafe { dfx_synchronize(err.as_mut_ptr(), ERRLEN) }, &err)
+}
+/// Tuning knobs of include/dfx.h (`agg.strategy`, `scan.fast`, ...); unknown keys are an error.
+pub fn set_option(key: &str, value: i64) -> Result<()> {
+    let k = CString::new(key).unwrap();
+    if unsafe { dfx_set_option(k.as_ptr(), value) } == 0 {
+        Ok(())
+    } else {
+        Err(ExecutionError::General(format!("unknown option '{}'", key)))
     }
 }
 

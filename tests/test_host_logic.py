@@ -154,3 +154,30 @@ def test_c_abi_header_compiles_as_c_and_fails_loudly_without_gpu(tmp_path):
     r = subprocess.run([exe, "1000", "10"], capture_output=True, text=True)
     assert r.returncode != 0 and r.stdout.startswith("ERR"), r.stdout + r.stderr
     assert "no CPU" in r.stdout or "HIP" in r.stdout, r.stdout
+
+
+def test_rust_binding_matches_header():
+    """integration/rust/src/execution/gpu.rs cannot be compiled here (no Rust toolchain): at least keep its extern "C" block
+    in step with include/dfx.h -- every bound function exists in the header with the same number of parameters."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, "include", "dfx.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    rust = open(os.path.join(root, "integration", "rust", "src", "execution", "gpu.rs")).read()
+    block = rust[rust.index('extern "C" {'):]
+    block = block[:block.index("\n}\n")]
+
+    def n_params(arglist):
+        arglist = arglist.strip()
+        return 0 if arglist in ("", "void") else arglist.count(",") + 1
+
+    c_protos = {m.group(1): n_params(m.group(2)) for m in re.finditer(r"\b(dfx_[a-z0-9_]+)\s*\(([^()]*)\)\s*;", header)}
+    rs_protos = {m.group(1): n_params(m.group(2)) for m in re.finditer(r"fn (dfx_[a-z0-9_]+)\s*\(([^()]*)\)", block)}
+    assert len(rs_protos) >= 18
+    for name, n in rs_protos.items():
+        assert name in c_protos, f"{name} is bound in gpu.rs but not declared in include/dfx.h"
+        assert c_protos[name] == n, f"{name}: {n} parameters in gpu.rs, {c_protos[name]} in include/dfx.h"
+    # the operators, the data sources and the resident table are all reachable from Rust
+    for must in ("dfx_filter_relation_new", "dfx_project_relation_new", "dfx_aggregate_relation_new", "dfx_csv_datasource_new",
+                 "dfx_sort_relation_new", "dfx_limit_relation_new", "dfx_table_from_stream", "dfx_table_scan_new"):
+        assert must in rs_protos
