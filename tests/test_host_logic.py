@@ -181,3 +181,34 @@ def test_rust_binding_matches_header():
     for must in ("dfx_filter_relation_new", "dfx_project_relation_new", "dfx_aggregate_relation_new", "dfx_csv_datasource_new",
                  "dfx_sort_relation_new", "dfx_limit_relation_new", "dfx_table_from_stream", "dfx_table_scan_new"):
         assert must in rs_protos
+
+
+def test_c_abi_rejects_null_arguments():
+    """Every constructor of include/dfx.h answers a null / missing argument with a status code and a message: nothing is
+    dereferenced blindly and nothing unwinds across the boundary (needs no GPU: the checks precede any device work)."""
+    import ctypes
+    from datafusion_archive_amd import _ffi
+    L = _ffi.lib()
+    err = ctypes.create_string_buffer(512)
+    out = _ffi.ArrowArrayStream()
+    handle = ctypes.c_void_p()
+    N = None
+    calls = {
+        "filter": lambda: L.dfx_filter_relation_new(N, N, N, ctypes.byref(out), err, 512),
+        "filter without out": lambda: L.dfx_filter_relation_new(N, N, N, N, err, 512),
+        "project": lambda: L.dfx_project_relation_new(N, N, 0, N, ctypes.byref(out), err, 512),
+        "aggregate": lambda: L.dfx_aggregate_relation_new(N, N, N, 0, N, 0, ctypes.byref(out), err, 512),
+        "sort": lambda: L.dfx_sort_relation_new(N, N, N, 0, N, ctypes.byref(out), err, 512),
+        "limit": lambda: L.dfx_limit_relation_new(N, 5, N, ctypes.byref(out), err, 512),
+        "csv": lambda: L.dfx_csv_datasource_new(N, N, 10, ctypes.byref(out), err, 512),
+        "compile_scalar_expr": lambda: L.dfx_compile_scalar_expr(N, 0, 0, N, ctypes.byref(handle), err, 512),
+        "compile_expr": lambda: L.dfx_compile_expr(N, 0, 0, N, ctypes.byref(handle), err, 512),
+        "table_scan": lambda: L.dfx_table_scan_new(N, 10, ctypes.byref(out), err, 512),
+    }
+    for name, call in calls.items():
+        err.value = b""
+        rc = call()
+        assert rc != 0, name
+        assert err.value, f"{name}: status {rc} without a message"
+    # a caller that passes no error buffer still gets the code
+    assert L.dfx_filter_relation_new(N, N, N, ctypes.byref(out), N, 0) != 0
