@@ -115,7 +115,7 @@ struct AggregateRelation::Impl {
   Status alloc_table(int cap_log2, DevTable* T, std::vector<std::shared_ptr<void>>* owners, bool new_ctrl);
   Status ensure_spill(int64_t rows);
   Status ensure_partition(int64_t rows);
-  Status grow_and_replay(uint64_t occupied, uint64_t spilled);
+  Status grow_and_replay(uint64_t occupied, uint64_t spilled, uint64_t replay_from = 0);
   Status consume_batch(const DeviceBatch& b);
   Status launch_rows(const DeviceBatch& b, const DevProgram& prog, const DevColumns& cols, int64_t row0, int64_t n);
   Status drain();
@@ -455,8 +455,31 @@ Status AggregateRelation::Impl::handle_ctrl(const uint32_t* hc, int64_t n) {
     ctrl_pending[0] = ctrl_pending[1] = false;
     unconfirmed_rows = 0;
     if (now[CTRL_ERROR]) return error_from_ctrl(now[CTRL_ERROR]);
-    const uint64_t spilled_now = ((uint64_t)now[CTRL_SPILL_HI] << 32) | now[CTRL_SPILL_LO];
-    DFX_RETURN_IF_ERROR(grow_and_replay(now[CTRL_OCCUPIED], spilled_now));
+    uint64_t spilled_now = ((uint64_t)now[CTRL_SPILL_HI] << 32) | now[CTRL_SPILL_LO];
+    uint64_t replay_from = 0;
+    if (agg_options().replay_in_place && spilled_now > 0 && !now[CTRL_SATURATED] && now[CTRL_OCCUPIED] <= T.load_limit &&
+        2 * spilled_now <= spill.capacity) {
+      // The table is not full: the rows were spilled by overflowing routing regions (a hot key).  Put them into the
+      // table as it is; a row it cannot take is appended to the list BEHIND the rows being replayed (the cursor is not
+      // reset), and only those make the table grow.
+      hipStream_t s = ctx().stream;
+      DFX_HIP(launch_merge_rows(spill, 0, (int64_t)spilled_now, T, spill, s));
+      uint32_t after[CTRL_WORDS];
+      DFX_RETURN_IF_ERROR(read_ctrl(after));
+      if (after[CTRL_ERROR]) return error_from_ctrl(after[CTRL_ERROR]);
+      const uint64_t cursor = ((uint64_t)after[CTRL_SPILL_HI] << 32) | after[CTRL_SPILL_LO];
+      if (cursor == spilled_now && !after[CTRL_SATURATED] && after[CTRL_OCCUPIED] <= T.load_limit) {
+        after[CTRL_SPILL_LO] = after[CTRL_SPILL_HI] = 0;
+        DFX_HIP(hipMemcpyAsync(ctrl.get(), after, sizeof(uint32_t) * CTRL_WORDS, hipMemcpyHostToDevice, s));
+        DFX_HIP(hipStreamSynchronize(s));  // `after` is a stack buffer
+        occupied_known = after[CTRL_OCCUPIED];
+        return Status::OK();
+      }
+      replay_from = spilled_now;
+      spilled_now = cursor;
+      memcpy(now, after, sizeof(now));
+    }
+    DFX_RETURN_IF_ERROR(grow_and_replay(now[CTRL_OCCUPIED], spilled_now, replay_from));
     DFX_RETURN_IF_ERROR(read_ctrl(now));
     occupied_known = now[CTRL_OCCUPIED];
   }
@@ -484,13 +507,13 @@ Status AggregateRelation::Impl::settle_ctrl() {
 
 // The table passed its load limit (or a probe sequence was exhausted): build a table at least 4x
 // larger, rehash, then replay the spilled rows into it.  Afterwards occupancy <= 1/4.
-Status AggregateRelation::Impl::grow_and_replay(uint64_t occupied, uint64_t spilled) {
+Status AggregateRelation::Impl::grow_and_replay(uint64_t occupied, uint64_t spilled, uint64_t replay_from) {
   hipStream_t s = ctx().stream;
   if (spilled > spill.capacity)
     return Status::Err(DFX_INTERNAL_ERROR, strfmt("group spill list overflow (%llu rows > capacity %llu)",
                                                   (unsigned long long)spilled, (unsigned long long)spill.capacity));
   const int cur_log2 = 64 - T.shift;
-  const int need_log2 = ceil_log2(4 * (occupied + spilled + 1));
+  const int need_log2 = ceil_log2(4 * (occupied + (spilled - replay_from) + 1));
   const int new_log2 = std::max(cur_log2 + 2, need_log2);
   if (new_log2 > 31) return Status::Err(DFX_EXECUTION_ERROR, "GROUP BY table would exceed 2^31 slots");
   DevTable Tn;
@@ -521,7 +544,7 @@ Status AggregateRelation::Impl::grow_and_replay(uint64_t occupied, uint64_t spil
   DevTable Told = T;
   Told.ctrl = (uint32_t*)old_ctrl.get();
   DFX_HIP(launch_rehash(Told, Tn, no_spill, s));
-  if (spilled > 0) DFX_HIP(launch_merge_rows(spill, 0, (int64_t)spilled, Tn, no_spill, s));
+  if (spilled > replay_from) DFX_HIP(launch_merge_rows(spill, (int64_t)replay_from, (int64_t)(spilled - replay_from), Tn, no_spill, s));
   T = Tn;
   table_owners = owners;  // old buffers return to the pool once the stream has passed them
   DFX_HIP(hipStreamSynchronize(s));

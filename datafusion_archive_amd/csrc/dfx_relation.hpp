@@ -103,6 +103,9 @@ struct AggOptions {
   int partition_pad = 0;       // bytes of padding between partitions in the routing scratch
   int partition_block = 1024;  // pass-1 workgroup size in mode 1 (512: two workgroups per CU)
   int fewgroup = 1;            // <= 8 groups after calibration: register accumulators (dfx_k_fewgroup.hip); 0: LDS front cache
+  int replay_in_place = 0;     // 1: rows spilled by a table that is NOT full (region overflow of a hot key) are replayed into the
+                               // table as it is, and only what it cannot take makes it grow.  EXPERIMENTAL: written without a GPU
+                               // at hand, off until tests/test_gpu_parity.py has run with it (skewed keys)
 };
 AggOptions& agg_options();
 

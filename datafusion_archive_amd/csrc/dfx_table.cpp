@@ -369,6 +369,7 @@ int32_t dfx_set_option(const char* key, int64_t value) {
   else if (!strcmp(key, "agg.partition_mode")) o.partition_mode = (int)value;
   else if (!strcmp(key, "agg.partition_block")) o.partition_block = (int)value;
   else if (!strcmp(key, "agg.fewgroup")) o.fewgroup = (int)value;
+  else if (!strcmp(key, "agg.replay_in_place")) o.replay_in_place = (int)value;
   else if (!strcmp(key, "agg.partition_pad")) o.partition_pad = (int)value;
   else if (!strcmp(key, "agg.dict_capacity_log2")) o.dict_capacity_log2 = (int)value;
   else if (!strcmp(key, "agg.partition_cap_rows")) o.partition_cap_rows = (int)value;

@@ -334,8 +334,19 @@ int32_t dfx_profile_count(void);
 int32_t dfx_profile_get(int32_t index, char* name, size_t namelen, int64_t* launches,
                         double* total_ms, double* algo_bytes);
 
-/* Tunables (bench/test only).  Known keys: "agg.strategy" (0 auto, 1 global-atomic table,
- * 2 LDS partial tables, 3 partitioned), "agg.capacity_log2", "batch.rows". */
+/* Tunables (bench/test only; process-wide, read when an operator is created or a batch is launched).
+ * Returns DFX_GENERAL for an unknown key.  Keys:
+ *   "agg.strategy"           0 auto (calibrated on the first rows of a stream), 1 global-atomic table only,
+ *                            2 LDS front cache, 3 partitioned (route rows to table blocks, aggregate blocks in LDS)
+ *   "agg.capacity_log2"      initial GROUP BY table slots (0: 2^21)
+ *   "agg.lds_slots" / "agg.lds_copies"   LDS front cache geometry (-1 auto)
+ *   "agg.fewgroup"           1: <= 8 groups run on register accumulators (default), 0: LDS front cache
+ *   "agg.partition_mode"     pass 1 of the partitioned strategy: 2 lock-free LDS rings (default), 1 LDS counting sort,
+ *                            0 direct routing; "agg.partition_block", "agg.partition_pad", "agg.partition_cap_rows"
+ *   "agg.replay_in_place"    experimental, default 0
+ *   "agg.dict_capacity_log2" initial slots of a Utf8 key dictionary (0: 2^16)
+ *   "scan.fast"              0: always the generic SSA interpreter instead of the shape-specialised kernels
+ *   "pool.trim"              (any value) return the cached device buffers to the driver */
 int32_t dfx_set_option(const char* key, int64_t value);
 /* Measurement counters: "h2d_bytes" (column bytes the uploaders copied host -> device), "csv_cells" (cells the CSV
  * source converted) -- what projection push-down saves.  -1: unknown name. */

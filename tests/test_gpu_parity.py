@@ -7,6 +7,7 @@ arbitrary data (eps = 2^-52) -- the reference sums sequentially in row order, a 
 cannot.  Group output order is unspecified in the reference (tests/sql.rs:47): compared as sets.
 """
 import math
+import os
 
 import numpy as np
 import pyarrow as pa
@@ -559,6 +560,27 @@ def test_skewed_keys_partitioned_strategy_spills_correctly():
     got = gpu_aggregate([Column(0)], aggs, schema, [], source=t.scan(1 << 20))
     want = oracle.aggregate([Column(0)], aggs, [oracle.synth_batch(syn, seed, 0, n)])
     assert_groups_identical(got, want, 1, "skewed keys")
+
+
+@pytest.mark.skipif(os.environ.get("DFX_TEST_EXPERIMENTAL") != "1",
+                    reason="agg.replay_in_place was written without a GPU at hand: opt in with DFX_TEST_EXPERIMENTAL=1")
+def test_skewed_keys_replayed_in_place_experimental():
+    """Same stream as above, longer (8 batches), with spilled rows replayed into the table as it is: the table must not
+    grow (1 M keys fit 2^21 slots) and the groups must still be the oracle's."""
+    ex.set_option("agg.strategy", 3)
+    ex.set_option("agg.replay_in_place", 1)
+    try:
+        syn = [("k", ex.SYNTH_I64_ZIPF, 0, 1000000.0, 0.0), ("v", ex.SYNTH_F64_EXACT, 1, 0.0, 0.0)]
+        n, seed = 1 << 23, 0xDF05
+        t = ex.DeviceTable.synth(syn, seed, 0, n)
+        aggs = [agg("sum", Column(1), F64), agg("count", Column(1), DataType.UInt64), agg("min", Column(1), F64)]
+        schema = pa.schema([("k", pa.int64()), ("v", pa.float64())])
+        got = gpu_aggregate([Column(0)], aggs, schema, [], source=t.scan(1 << 20))
+        want = oracle.aggregate([Column(0)], aggs, [oracle.synth_batch(syn, seed, 0, n)])
+        assert_groups_identical(got, want, 1, "skewed keys, in-place replay")
+    finally:
+        ex.set_option("agg.replay_in_place", 0)
+        ex.set_option("agg.strategy", 0)
 
 
 @pytest.mark.parametrize("mode", [0, 1, 2, 2 | 0x80])
