@@ -1,6 +1,8 @@
 #!/bin/bash
 # First GPU call of round 2 (one gpurun, ~6 min): is everything still green on a fresh box, and which pass-2 lookup variant wins?
 #   /usr/local/graft/bin/gpurun --timeout 900 -- 'bash tools/gpu_round2_first.sh'
+# Then, if the queue variant wins in the micro-benchmark: rebuild HERE with DFX_EXTRA_CXXFLAGS=-DDFX_PA_QUEUE (build.py reads it),
+# run the GPU suite and bench.py again, and compare partition_agg in extra.kernels.
 mkdir -p gpurun_out; export TMPDIR=/tmp
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -munsafe-fp-atomics tools/ubench_pass2.hip -o /tmp/ubench_pass2 \
   && timeout 120 /tmp/ubench_pass2 256 > gpurun_out/ubench_pass2.jsonl 2> gpurun_out/ubench_pass2.err; echo "ubench_pass2 rc=$?"; cat gpurun_out/ubench_pass2.jsonl
