@@ -20,9 +20,11 @@ LIB = os.path.join(LIBDIR, "libdfx_hip.so")
 
 # kernel translation units first (slowest): they compile in parallel
 SOURCES = ["dfx_k_table1.hip", "dfx_k_table2.hip", "dfx_k_table3.hip", "dfx_k_table4.hip", "dfx_k_core.hip",
-           "dfx_k_reduce.hip", "dfx_k_partition.hip", "dfx_k_fewgroup.hip", "dfx_k_csv.hip", "dfx_k_sort.hip", "dfx_k_dict.hip", "dfx_host.cpp", "dfx_expr.cpp", "dfx_relation.cpp", "dfx_aggregate.cpp",
+           "dfx_k_reduce.hip", "dfx_k_partition.hip", "dfx_k_partition_v0.hip", "dfx_k_partition_v1.hip", "dfx_k_partition_v2.hip",
+           "dfx_k_partition_v3.hip", "dfx_k_partition_v4.hip", "dfx_k_partition_v5.hip", "dfx_k_partition_v6.hip", "dfx_k_partition_v7.hip",
+           "dfx_k_fewgroup.hip", "dfx_k_csv.hip", "dfx_k_sort.hip", "dfx_k_dict.hip", "dfx_host.cpp", "dfx_expr.cpp", "dfx_relation.cpp", "dfx_aggregate.cpp",
            "dfx_table.cpp", "dfx_csv.cpp", "dfx_sort.cpp"]
-HEADERS = ["dfx_device.hpp", "dfx_sigs.hpp", "dfx_numparse.hpp", "dfx_pow5_table.hpp", "dfx_csv_walk.hpp", "dfx_kernels.hpp", "dfx_kernels_inl.hpp", "dfx_k_table_inl.hpp", "dfx_launch.hpp",
+HEADERS = ["dfx_device.hpp", "dfx_sigs.hpp", "dfx_numparse.hpp", "dfx_pow5_table.hpp", "dfx_csv_walk.hpp", "dfx_kernels.hpp", "dfx_kernels_inl.hpp", "dfx_k_table_inl.hpp", "dfx_k_partition_inl.hpp", "dfx_launch.hpp",
            "dfx_host.hpp", "dfx_relation.hpp", "../../include/dfx.h"]
 
 # -ffp-contract=off : the reference never fuses a*b+c; projections must be bit-exact
@@ -46,6 +48,26 @@ def _stale(target: str, deps: List[str]) -> bool:
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
+def _depfile_deps(depfile: str):
+    """Prerequisites recorded by the compiler (-MD -MF) the last time this object was built; None if there is no record."""
+    try:
+        text = open(depfile).read()
+    except OSError:
+        return None
+    text = text.replace("\\\n", " ")
+    if ":" not in text:
+        return None
+    deps = [d for d in text.split(":", 1)[1].split() if d.startswith(HERE) or d.startswith(os.path.dirname(HERE))]
+    return deps or None
+
+
+def _recorded_flags(obj: str) -> str:
+    try:
+        return open(obj + ".flags").read()
+    except OSError:
+        return ""
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     os.makedirs(OBJDIR, exist_ok=True)
@@ -57,8 +79,11 @@ def build(force: bool = False, verbose: bool = False) -> str:
         sp = os.path.join(CSRC, src)
         obj = os.path.join(OBJDIR, os.path.splitext(src)[0] + ".o")
         objs.append(obj)
-        if force or _stale(obj, [sp] + hdrs):
-            cmd = [hipcc] + CXXFLAGS + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", sp, "-o", obj]
+        depfile = obj + ".d"
+        recorded = _depfile_deps(depfile)  # exact per-object prerequisites when known, else every header
+        deps = ([sp] + recorded + [os.path.abspath(__file__)]) if recorded else ([sp] + hdrs)
+        if force or _stale(obj, deps) or os.environ.get("DFX_EXTRA_CXXFLAGS", "") != _recorded_flags(obj):
+            cmd = [hipcc] + CXXFLAGS + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-MD", "-MF", depfile, "-c", sp, "-o", obj]
             jobs.append(cmd)
 
     def run(cmd):
@@ -67,6 +92,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
+        if "-c" in cmd:  # remember the extra flags this object was built with (a -D switch must rebuild it)
+            with open(cmd[-1] + ".flags", "w") as fh:
+                fh.write(os.environ.get("DFX_EXTRA_CXXFLAGS", ""))
         return r
 
     if jobs:

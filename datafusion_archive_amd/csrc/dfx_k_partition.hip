@@ -1,634 +1,10 @@
-// dfx_k_partition.hip -- the partitioned GROUP BY strategy for high-cardinality single-key
-// aggregates (BASELINE config 3: 1 M Int64 keys).
-//
-// Why: global atomics on MI355X top out near 24 G updates/s whatever the table size or scope
-// (profiles/r01_ubench_mi355x.jsonl), i.e. ~42 ms for 1e9 rows, while LDS atomics run above 1 T/s.
-// With uniformly distributed keys a per-workgroup LDS cache never sees a key twice, so rows are
-// first ROUTED to the workgroup that owns their slice of the table:
-//
-//   pass 1  k_partition      every workgroup ("producer") scans its row tiles (predicate + key +
-//           argument expressions, same row-source policies as K7), stages the passing rows in LDS
-//           and appends them to per-(producer, partition) private regions of a scratch buffer.
-//           No global atomics: a region has exactly one writer.  partition = table block index.
-//   pass 2  k_partition_agg  one workgroup per partition copies its table block (keys + accumulator
-//           planes, 64 KB) into LDS, folds the partition's rows in with LDS CAS / LDS atomics
-//           (ds_cmpst_rtn_b64, ds_add_f64, ...), and writes the block back.
-//
-// Rows that do not fit (a region overflows: heavy skew; a block is full) go to the ordinary spill
-// list and are merged by the global-atomic path, so the strategy is correct for any distribution.
-#include "dfx_kernels_inl.hpp"
-#include "dfx_launch.hpp"
+// dfx_k_partition.hip -- partitioned GROUP BY: the pass-1 dispatcher, pass 2 (k_partition_agg) and the sizing helpers.
+// The pass-1 kernels and the description of the strategy are in dfx_k_partition_inl.hpp; their instantiations are in
+// dfx_k_partition_v0.hip ... _v7.hip.
+#define DFX_PARTITION_MAIN_TU
+#include "dfx_k_partition_inl.hpp"
 
 namespace dfx {
-
-constexpr int kPBlock = 1024;  // pass-1 workgroup (one per CU): 16 waves share one set of fill counters
-constexpr int kABlock = 1024;  // pass-2 workgroup (one per CU): 16 waves share a 128 KB LDS copy of a table block
-
-// address of row `row` of the region that producer `producer` fills for partition `part`
-DEV uint64_t* region_row(const DevPartition& PT, uint32_t part, uint32_t producer, uint32_t row) {
-  return PT.rows + (uint64_t)part * PT.part_stride + ((uint64_t)producer * PT.cap_rows + row) * PT.n_words;
-}
-
-DEV uint32_t partition_of(const DevTable& T, const DevPartition& PT, uint64_t h) {
-  return (uint32_t)(((h >> T.shift) & T.mask) >> PT.part_shift);
-}
-
-// pass 1.  No staging: a passing row is routed straight from registers.  Its position inside the
-// (producer, partition) region comes from an LDS atomic on the workgroup's per-partition fill
-// counter; the U row-groups of a trip issue their LDS atomics back to back, then their 16-byte row
-// stores.  The regions have exactly one writing workgroup, so there is no global atomic and no
-// barrier in the loop, and the only LDS is the counter array (occupancy is register-bound).
-template <typename POL>
-__global__ __launch_bounds__(kPBlock) void k_partition(const DevProgram P, const DevFastPlan F, const DevColumns C,
-                                                      const DevAggPlan plan, const DevTable T,
-                                                      const DevPartition PT, const DevRows spill, const int64_t n) {
-  typedef typename POL::COLV COLV;
-  constexpr int U = POL::U;
-  extern __shared__ __attribute__((aligned(16))) uint64_t lds[];
-  uint32_t* fill = (uint32_t*)lds;  // [n_parts] rows appended to each of this producer's regions
-  const int lane = lane_id();
-  const int wave = threadIdx.x >> 6;
-  const int NW = (int)PT.n_words;
-  for (uint32_t p = threadIdx.x; p < PT.n_parts; p += kPBlock) fill[p] = 0;
-  __syncthreads();
-  const uint32_t producer = blockIdx.x;
-  const int64_t n_groups = (n + 63) >> 6;
-  const int64_t wave_global = (int64_t)blockIdx.x * (kPBlock / 64) + wave;
-  const int64_t n_waves = (int64_t)gridDim.x * (kPBlock / 64);
-  uint32_t err = 0;
-  uint64_t passed = 0;
-  for (int64_t w0 = wave_global * U; w0 < n_groups; w0 += n_waves * U) {
-    COLV col[U];
-    uint32_t cv[U];
-    FOR_U {
-      const int64_t row = (w0 + u) * 64 + lane;
-      POL::load(P, C, row, row < n, col[u], cv[u]);
-    }
-    uint64_t key[U][1];
-    uint64_t val[U][kMaxAggs];
-    uint32_t part[U], pos[U];
-    uint32_t passbits = 0;
-    FOR_U {
-      const int64_t row = (w0 + u) * 64 + lane;
-      const bool inb = row < n;
-      u64x16 reg;
-      uint32_t rv = 0;
-      POL::eval(P, F, col[u], cv[u], reg, rv, inb, err);
-      bool pass = inb && POL::pass(P, F, plan.pred, col[u], cv[u], reg, rv);
-      key[u][0] = POL::key(P, F, plan.key[0], 0, col[u], cv[u], reg, rv);
-#pragma unroll
-      for (int a = 0; a < kMaxAggs; ++a) {
-        val[u][a] = 0;
-        if (a < POL::na(T)) {
-          uint64_t v;
-          bool valid;
-          POL::arg(P, F, plan.arg[a], a, col[u], cv[u], reg, rv, v, valid);
-          val[u][a] = transform_value(POL::xform(T, a), v, valid);
-        }
-      }
-      passed += pass ? 1 : 0;
-      if (pass && key[u][0] == kEmptyKey) {  // the claim-sentinel key lives outside the blocks
-        const bool ok = table_apply<1>(T, key[u], val[u]);
-        (void)ok;
-        pass = false;
-      }
-      part[u] = partition_of(T, PT, hash_keys<1>(key[u]));
-      passbits |= (pass ? 1u : 0u) << u;
-    }
-    FOR_U pos[u] = ((passbits >> u) & 1u) ? atomicAdd(&fill[part[u]], 1u) : 0xFFFFFFFFu;  // LDS atomics in flight together
-    FOR_U {
-      const bool pass = (passbits >> u) & 1u;
-      bool todo = pass;
-      if (pass && pos[u] < PT.cap_rows) {
-        uint64_t* dst = region_row(PT, part[u], producer, pos[u]);
-        if (POL::na(T) == 1) {  // 16-byte row: one store
-          *(ulonglong2*)dst = make_ulonglong2(key[u][0], val[u][0]);
-        } else {
-          dst[0] = key[u][0];
-#pragma unroll
-          for (int a = 0; a < kMaxAggs; ++a)
-            if (a < POL::na(T)) dst[1 + a] = val[u][a];
-        }
-        todo = false;
-      }
-      spill_row<1>(T, spill, todo, key[u], val[u]);  // region overflow (skewed keys): the general path takes it
-    }
-  }
-  __syncthreads();
-  for (uint32_t p = threadIdx.x; p < PT.n_parts; p += kPBlock) {
-    const uint32_t f = fill[p];
-    PT.counts[(uint64_t)p * PT.n_producers + producer] = f < PT.cap_rows ? f : PT.cap_rows;
-  }
-#pragma unroll
-  for (int mm = 32; mm >= 1; mm >>= 1) passed += shfl_xor_u64(passed, mm);
-  if (lane == 0) stat_add(T, STAT_PASSED, passed);
-  if (err) atomicOr(&T.ctrl[CTRL_ERROR], err);
-}
-
-
-// ---- pass 1, write-combining variant --------------------------------------------------------------
-// Measured on MI355X (tools/ubench2.hip, profiles/r01_ubench_mi355x.jsonl): scattered 16-byte stores
-// run at ~87 G/s chip-wide however L2-resident their lines are (transaction-bound), while runs of
-// >= 64 contiguous bytes written by adjacent lanes run at > 400 G rows/s.  So the workgroup first
-// COLLECTS passing rows in an LDS buffer (one wave-aggregated LDS atomic per trip), and when the
-// buffer is full the whole workgroup counting-sorts it by partition (LDS histogram -> scan ->
-// permutation) and copies it out in sorted order: adjacent lanes then write adjacent rows of the
-// same region.  The hash is computed once per PASSING row at full lane utilisation, not once per
-// scanned row.  A flush round is six barriers; all waves take part in every round (a wave that has
-// finished its input keeps joining rounds until every wave has finished).
-constexpr int kSortMaxCap = 8192;  // LDS buffer rows (upper bound: 13-bit row index in the permutation word)
-
-DEV uint32_t mbcnt64(uint64_t m) {
-  return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-}
-
-struct SortLds {
-  uint64_t* buf;    // [n_words][cap] word-major row buffer
-  uint32_t* perm;   // [cap] sorted position -> (partition << 16 | buffer row)
-  uint32_t* hist;   // [n_parts] rows of this round per partition; after the scan: exclusive offsets
-  uint32_t* fill;   // [n_parts] rows already written to this producer's region
-  uint32_t* delta;  // [n_parts] region row = sorted position + delta (mod 2^32)
-  uint32_t* misc;   // [0] claimed rows, [1] finished waves, [2..] wave totals of the scan
-  uint32_t cap;     // rows of the buffer (plane stride)
-  uint32_t limit;   // rows accepted before the next flush (<= cap)
-};
-
-template <int BLOCK>
-DEV bool partition_flush(const DevTable& T, const DevPartition& PT, const DevRows& spill, const SortLds& L,
-                         uint32_t producer, int na) {
-  constexpr int NWAVES = BLOCK / 64;
-  constexpr int ITEMS = kSortMaxCap / BLOCK;
-  const uint32_t tid = threadIdx.x;
-  const int lane = lane_id();
-  const uint32_t items = L.cap / BLOCK;
-  __syncthreads();  // B0: every append of this round is in the buffer
-  uint32_t R = L.misc[0];
-  if (R > L.limit) R = L.limit;
-  const bool last = L.misc[1] == (uint32_t)NWAVES;
-  uint32_t packed[ITEMS];
-#pragma unroll
-  for (int it = 0; it < ITEMS; ++it) {
-    packed[it] = 0xFFFFFFFFu;
-    const uint32_t i = tid + (uint32_t)it * BLOCK;
-    if ((uint32_t)it < items && i < R) {
-      uint64_t key[1] = {L.buf[i]};
-      const uint32_t part = partition_of(T, PT, hash_keys<1>(key));
-      const uint32_t rank = atomicAdd(&L.hist[part], 1u);
-      packed[it] = (part << 16) | rank;
-    }
-  }
-  __syncthreads();  // B1: histogram complete
-  // exclusive scan over partitions; PP consecutive partitions per thread
-  const uint32_t NPT = PT.n_parts;
-  const uint32_t PP = (NPT + BLOCK - 1) / BLOCK;
-  const uint32_t p0 = tid * PP;
-  uint32_t sum = 0;
-  for (uint32_t q = 0; q < PP; ++q)
-    if (p0 + q < NPT) sum += L.hist[p0 + q];
-  uint32_t inc = sum;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const uint32_t o = __shfl_up(inc, d, 64);
-    if (lane >= d) inc += o;
-  }
-  if (lane == 63) L.misc[2 + (tid >> 6)] = inc;
-  __syncthreads();  // B2
-  uint32_t excl = inc - sum;
-#pragma unroll
-  for (int w = 0; w < NWAVES; ++w)
-    if (w < (int)(tid >> 6)) excl += L.misc[2 + w];
-  for (uint32_t q = 0; q < PP; ++q) {
-    const uint32_t p = p0 + q;
-    if (p < NPT) {
-      const uint32_t h = L.hist[p];
-      const uint32_t f = L.fill[p];
-      L.hist[p] = excl;
-      L.delta[p] = f - excl;
-      L.fill[p] = f + h;
-      excl += h;
-    }
-  }
-  __syncthreads();  // B3: offsets ready
-#pragma unroll
-  for (int it = 0; it < ITEMS; ++it) {
-    if (packed[it] != 0xFFFFFFFFu) {
-      const uint32_t part = packed[it] >> 16, rank = packed[it] & 0xFFFFu;
-      L.perm[L.hist[part] + rank] = (part << 16) | (tid + (uint32_t)it * BLOCK);
-    }
-  }
-  __syncthreads();  // B4: permutation complete
-  for (uint32_t p = tid; p < NPT; p += BLOCK) L.hist[p] = 0;
-  if (tid == 0) L.misc[0] = 0;
-#pragma unroll
-  for (int it = 0; it < ITEMS; ++it) {
-    if ((uint32_t)it < items && (uint32_t)it * BLOCK < R) {  // wave-uniform
-      const uint32_t j = tid + (uint32_t)it * BLOCK;
-      const bool inb = j < R;
-      uint64_t key[1] = {0};
-      uint64_t val[kMaxAggs];
-#pragma unroll
-      for (int a = 0; a < kMaxAggs; ++a) val[a] = 0;
-      bool todo = false;
-      if (inb) {
-        const uint32_t e = L.perm[j];
-        const uint32_t part = e >> 16, i = e & 0xFFFFu;
-        const uint32_t row = j + L.delta[part];
-        key[0] = L.buf[i];
-#pragma unroll
-        for (int a = 0; a < kMaxAggs; ++a)
-          if (a < na) val[a] = L.buf[(size_t)(1 + a) * L.cap + i];
-        if (row < PT.cap_rows) {
-          uint64_t* dst = region_row(PT, part, producer, row);
-          if (na == 1) {
-            *(ulonglong2*)dst = make_ulonglong2(key[0], val[0]);
-          } else {
-            dst[0] = key[0];
-#pragma unroll
-            for (int a = 0; a < kMaxAggs; ++a)
-              if (a < na) dst[1 + a] = val[a];
-          }
-        } else {
-          todo = true;  // region overflow (skewed keys): the general path takes the row
-        }
-      }
-      spill_row<1>(T, spill, todo, key, val);
-    }
-  }
-  __syncthreads();  // B5: the buffer may be overwritten
-  return last;
-}
-
-template <typename POL, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_partition_sorted(const DevProgram P, const DevFastPlan F, const DevColumns C,
-                                                           const DevAggPlan plan, const DevTable T,
-                                                           const DevPartition PT, const DevRows spill, const int64_t n) {
-  typedef typename POL::COLV COLV;
-  constexpr int U = POL::U;
-  constexpr int NWAVES = BLOCK / 64;
-  extern __shared__ __attribute__((aligned(16))) uint64_t lds[];
-  SortLds L;
-  L.cap = PT.stage_rows;
-  // co-resident workgroups must not flush in lockstep (a flush leaves the CU's memory pipe idle unless the
-  // other workgroup is scanning): odd producers take a short first round
-  L.limit = (blockIdx.x & 1u) ? L.cap / 2 : L.cap;
-  L.buf = lds;
-  L.perm = (uint32_t*)(lds + (size_t)PT.n_words * L.cap);
-  L.hist = L.perm + L.cap;
-  L.fill = L.hist + PT.n_parts;
-  L.delta = L.fill + PT.n_parts;
-  L.misc = L.delta + PT.n_parts;
-  const int lane = lane_id();
-  const int wave = threadIdx.x >> 6;
-  const int na = POL::na(T);
-  for (uint32_t p = threadIdx.x; p < PT.n_parts; p += BLOCK) {
-    L.hist[p] = 0;
-    L.fill[p] = 0;
-  }
-  if (threadIdx.x < 2 + NWAVES) L.misc[threadIdx.x] = 0;
-  __syncthreads();
-  const uint32_t producer = blockIdx.x;
-  const int64_t n_groups = (n + 63) >> 6;
-  const int64_t wave_global = (int64_t)blockIdx.x * NWAVES + wave;
-  const int64_t n_waves = (int64_t)gridDim.x * NWAVES;
-  uint32_t err = 0;
-  uint64_t passed = 0;
-  for (int64_t w0 = wave_global * U; w0 < n_groups; w0 += n_waves * U) {
-    COLV col[U];
-    uint32_t cv[U];
-    FOR_U {
-      const int64_t row = (w0 + u) * 64 + lane;
-      POL::load(P, C, row, row < n, col[u], cv[u]);
-    }
-    uint64_t key[U][1];
-    uint64_t val[U][kMaxAggs];
-    uint32_t pend = 0;
-    FOR_U {
-      const int64_t row = (w0 + u) * 64 + lane;
-      const bool inb = row < n;
-      u64x16 reg;
-      uint32_t rv = 0;
-      POL::eval(P, F, col[u], cv[u], reg, rv, inb, err);
-      bool pass = inb && POL::pass(P, F, plan.pred, col[u], cv[u], reg, rv);
-      key[u][0] = POL::key(P, F, plan.key[0], 0, col[u], cv[u], reg, rv);
-#pragma unroll
-      for (int a = 0; a < kMaxAggs; ++a) {
-        val[u][a] = 0;
-        if (a < POL::na(T)) {
-          uint64_t v;
-          bool valid;
-          POL::arg(P, F, plan.arg[a], a, col[u], cv[u], reg, rv, v, valid);
-          val[u][a] = transform_value(POL::xform(T, a), v, valid);
-        }
-      }
-      passed += pass ? 1 : 0;
-      if (pass && key[u][0] == kEmptyKey) {  // the claim-sentinel key lives outside the blocks
-        const bool ok = table_apply<1>(T, key[u], val[u]);
-        (void)ok;
-        pass = false;
-      }
-      pend |= (pass ? 1u : 0u) << u;
-    }
-    while (true) {
-      uint64_t m[U];
-      uint32_t tot = 0;
-      FOR_U {
-        m[u] = __ballot((pend >> u) & 1u);
-        tot += (uint32_t)__popcll(m[u]);
-      }
-      if (tot == 0) break;
-      uint32_t base = 0;
-      if (lane == 0) base = atomicAdd(&L.misc[0], tot);
-      base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-      uint32_t b = base;
-      FOR_U {
-        const uint32_t pos = b + mbcnt64(m[u]);
-        if (((pend >> u) & 1u) && pos < L.limit) {
-          L.buf[pos] = key[u][0];
-#pragma unroll
-          for (int a = 0; a < kMaxAggs; ++a)
-            if (a < POL::na(T)) L.buf[(size_t)(1 + a) * L.cap + pos] = val[u][a];
-          pend &= ~(1u << u);
-        }
-        b += (uint32_t)__popcll(m[u]);
-      }
-      if (base + tot <= L.limit) break;
-      partition_flush<BLOCK>(T, PT, spill, L, producer, na);
-      L.limit = L.cap;
-    }
-  }
-  if (lane == 0) atomicAdd(&L.misc[1], 1u);
-  while (!partition_flush<BLOCK>(T, PT, spill, L, producer, na)) {
-  }
-  for (uint32_t p = threadIdx.x; p < PT.n_parts; p += BLOCK) {
-    const uint32_t f = L.fill[p];
-    PT.counts[(uint64_t)p * PT.n_producers + producer] = f < PT.cap_rows ? f : PT.cap_rows;
-  }
-#pragma unroll
-  for (int mm = 32; mm >= 1; mm >>= 1) passed += shfl_xor_u64(passed, mm);
-  if (lane == 0) stat_add(T, STAT_PASSED, passed);
-  if (err) atomicOr(&T.ctrl[CTRL_ERROR], err);
-}
-
-// ---- pass 1, lock-free write-combining variant ("ring") ----------------------------------------------
-// The counting-sort variant above pays for its barriers: while a workgroup sorts, its CU issues no
-// loads.  Here no wave ever waits for another one in the common case:
-//   * each wave compacts its passing rows into a wave-private LDS queue (ballot + mbcnt); whenever 64
-//     rows are queued it pops them and routes them at full lane utilisation;
-//   * routing a row: hash -> partition; pos = LDS atomic on the workgroup's fill[partition] = the row's
-//     final index in this producer's region; the row is parked in the partition's LDS ring
-//     (kRingNCH chunks of kRingCH rows); the lane that parks the last row of a chunk (per-chunk commit
-//     counter) owns the flush;
-//   * flush jobs of a wave are executed cooperatively: kRingCH adjacent lanes store one chunk, i.e. one
-//     64-byte run (>= 64-byte runs reach the coalesced store rate, tools/ubench2.hip);
-//   * a chunk slot is reused only after its previous generation was flushed (per-slot generation word).
-//     A lane whose slot is still busy keeps its row, helps with this wave's flush jobs and retries; the
-//     lowest incomplete chunk of a partition never depends on anything, so every retry loop terminates.
-// Leftover partial chunks are written row by row at the end.
-// ring rows per partition kRingRP = rows per chunk (CH: 4 or 8) x chunks (NCH).  (An 8-row ring with two
-// workgroups per CU -- 32 waves -- was measured ~20 % slower than 16 rows and one workgroup.)
-constexpr int ring_queue_rows(int rp) { return rp >= 16 ? 192 : 128; }
-constexpr int kRingBlock = 1024;
-#ifndef DFX_RING_DEPTH
-#define DFX_RING_DEPTH 1
-#endif
-
-struct RingLds {
-  uint64_t* ring;    // [n_parts][kRingRP][n_words]
-  uint64_t* queue;   // [waves][n_words][kRingQ]
-  uint32_t* jobs;    // [waves][64] partition << 20 | chunk
-  uint32_t* fill;    // [n_parts]
-  uint32_t* commit;  // [n_parts][kRingNCH]
-  uint32_t* gen;     // [n_parts][kRingNCH]
-};
-
-size_t partition_ring_bytes(uint32_t n_words, uint32_t n_parts, int kRingRP) {
-  const int kRingQ = ring_queue_rows(kRingRP);
-  return (size_t)n_parts * kRingRP * n_words * 8 + (size_t)(kRingBlock / 64) * kRingQ * n_words * 8 +
-         (size_t)(kRingBlock / 64) * 64 * (kRingRP >= 16 ? 8 : 4) + (size_t)n_parts * 4 * (1 + 2 * 4) + 64;
-}
-
-#define WG_SCOPE __HIP_MEMORY_SCOPE_WORKGROUP
-
-// route up to 64 rows (one per lane with have == true)
-template <int NV, int kRingCH, int kRingRP>
-DEV void ring_route(const DevTable& T, const DevPartition& PT, const DevRows& spill, const RingLds& L, uint32_t producer,
-                    int na, bool have, const uint64_t (&key)[1], const uint64_t (&val)[kMaxAggs], uint32_t& err) {
-  constexpr int kRingNCH = kRingRP / kRingCH;
-  const int lane = lane_id();
-  const int wave = threadIdx.x >> 6;
-  const int NW = (int)PT.n_words;
-  uint32_t part = 0, pos = 0;
-  bool pending = false, todo = false;
-  if (have) {
-    part = partition_of(T, PT, hash_keys<1>(key));
-    pos = atomicAdd(&L.fill[part], 1u);
-    pending = pos < PT.cap_rows;
-    todo = !pending;  // region overflow (skewed keys): the general path takes the row
-  }
-  spill_row<1>(T, spill, todo, key, val);
-  const uint32_t c = pos / kRingCH, sl = c % kRingNCH, g = c / kRingNCH, r = pos % kRingCH;
-  const uint32_t cs = part * kRingNCH + sl;
-  uint32_t* jobs = L.jobs + wave * 64;
-  uint32_t spins = 0;
-  while (true) {
-    bool job = false;
-    if (pending && __hip_atomic_load(&L.gen[cs], __ATOMIC_ACQUIRE, WG_SCOPE) == g) {
-      uint64_t* dst = L.ring + ((size_t)part * kRingRP + sl * kRingCH + r) * NW;
-      if (NV == 1) {
-        *(ulonglong2*)dst = make_ulonglong2(key[0], val[0]);
-      } else {
-        dst[0] = key[0];
-#pragma unroll
-        for (int a = 0; a < NV; ++a)
-          if (a < na) dst[1 + a] = val[a];
-      }
-      const uint32_t old = __hip_atomic_fetch_add(&L.commit[cs], 1u, __ATOMIC_ACQ_REL, WG_SCOPE);
-      job = old == (uint32_t)kRingCH - 1u;
-      pending = false;
-    }
-    const uint64_t jm = __ballot(job);
-    if (jm != 0) {
-      const uint32_t njobs = (uint32_t)__popcll(jm);
-      if (job) jobs[mbcnt64(jm)] = (part << 20) | c;
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      for (uint32_t j0 = 0; j0 < njobs; j0 += 64 / kRingCH) {
-        const uint32_t j = j0 + (uint32_t)lane / kRingCH;
-        if (j < njobs) {
-          const uint32_t jw = jobs[j];
-          const uint2 jb = make_uint2(jw >> 20, jw & 0xFFFFFu);
-          const uint32_t rr = (uint32_t)lane % kRingCH;
-          const uint64_t* src = L.ring + ((size_t)jb.x * kRingRP + (jb.y % kRingNCH) * kRingCH + rr) * NW;
-          uint64_t* out = region_row(PT, jb.x, producer, jb.y * kRingCH + rr);
-          if (NV == 1) {
-            *(ulonglong2*)out = *(const ulonglong2*)src;
-          } else {
-            for (int w = 0; w < NW; ++w) out[w] = src[w];
-          }
-        }
-      }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      if (job) {  // the slot belongs to the next generation
-        __hip_atomic_store(&L.commit[cs], 0u, __ATOMIC_RELAXED, WG_SCOPE);
-        __hip_atomic_fetch_add(&L.gen[cs], 1u, __ATOMIC_RELEASE, WG_SCOPE);
-      }
-    }
-    if (__ballot(pending) == 0) break;
-    if (++spins > (1u << 22)) {  // cannot happen (see above); never hang the device
-      err |= 4u;
-      break;
-    }
-    __builtin_amdgcn_s_sleep(1);
-  }
-}
-
-template <typename POL, int kRingCH, int kRingRP>
-__global__ __launch_bounds__(kRingBlock) void k_partition_ring(const DevProgram P, const DevFastPlan F, const DevColumns C,
-                                                              const DevAggPlan plan, const DevTable T,
-                                                              const DevPartition PT, const DevRows spill, const int64_t n) {
-  typedef typename POL::COLV COLV;
-  constexpr int U = POL::U;
-  static_assert(U == 1 || U == 2 || U == 4, "row-groups per trip");
-  constexpr int NWAVES = kRingBlock / 64;
-  constexpr int NV = POL::kStaticNa == 1 ? 1 : kMaxAggs;
-  constexpr int kRingNCH = kRingRP / kRingCH;
-  constexpr int kRingQ = ring_queue_rows(kRingRP);
-  extern __shared__ __attribute__((aligned(16))) uint64_t lds[];
-  const int NW = (int)PT.n_words;
-  RingLds L;
-  L.ring = lds;
-  L.queue = L.ring + (size_t)PT.n_parts * kRingRP * NW;
-  L.jobs = (uint32_t*)(L.queue + (size_t)NWAVES * kRingQ * NW);
-  L.fill = (uint32_t*)(L.jobs + NWAVES * 64 * (kRingRP >= 16 ? 2 : 1));
-  L.commit = L.fill + PT.n_parts;
-  L.gen = L.commit + (size_t)PT.n_parts * 4;
-  const int lane = lane_id();
-  const int wave = threadIdx.x >> 6;
-  const int na = POL::na(T);
-  for (uint32_t p = threadIdx.x; p < PT.n_parts * (1 + 2 * 4); p += kRingBlock) L.fill[p] = 0;  // fill, commit, gen
-  __syncthreads();
-  const uint32_t producer = blockIdx.x;
-  uint64_t* q = L.queue + (size_t)wave * kRingQ * NW;  // word-major planes [NW][kRingQ]
-  uint32_t qn = 0;                                     // queued rows (wave-uniform)
-  const int64_t n_groups = (n + 63) >> 6;
-  const int64_t wave_global = (int64_t)blockIdx.x * NWAVES + wave;
-  const int64_t n_waves = (int64_t)gridDim.x * NWAVES;
-  uint32_t err = 0;
-  uint64_t passed = 0;
-  // software pipeline, kRingDepth trips deep: the columns of trips t + 1 .. t + kRingDepth are in flight while trip t
-  // is evaluated and routed.  Depth 1 = 16 waves per CU x 4 KB = 16 MB in flight chip-wide.  Depths 2 and 3 (92 / 104
-  // VGPRs, -DDFX_RING_DEPTH) were measured: 3.46-3.66 ms per 1e9 rows against 3.24-3.62 ms at depth 1 -- no gain, the
-  // kernel is not short of bytes in flight; the run-to-run spread (+-6 % on one box) is larger than any difference.
-  constexpr int kRingDepth = DFX_RING_DEPTH;
-  COLV ncol[kRingDepth][U];
-  uint32_t ncv[kRingDepth][U];
-#pragma unroll
-  for (int d = 0; d < kRingDepth; ++d) {
-    const int64_t w0 = wave_global * U + (int64_t)d * n_waves * U;
-    FOR_U {
-      const int64_t row = (w0 + u) * 64 + lane;
-      POL::load(P, C, row, row < n && w0 < n_groups, ncol[d][u], ncv[d][u]);
-    }
-  }
-  for (int64_t w0 = wave_global * U; w0 < n_groups; w0 += n_waves * U) {
-    COLV col[U];
-    uint32_t cv[U];
-    FOR_U {
-      col[u] = ncol[0][u];
-      cv[u] = ncv[0][u];
-    }
-#pragma unroll
-    for (int d = 0; d + 1 < kRingDepth; ++d) {
-      FOR_U {
-        ncol[d][u] = ncol[d + 1][u];
-        ncv[d][u] = ncv[d + 1][u];
-      }
-    }
-    {
-      const int64_t w1 = w0 + (int64_t)kRingDepth * n_waves * U;
-      FOR_U {
-        const int64_t row = (w1 + u) * 64 + lane;
-        POL::load(P, C, row, row < n, ncol[kRingDepth - 1][u], ncv[kRingDepth - 1][u]);
-      }
-    }
-#ifdef DFX_RING_WAIT_ALL
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-    FOR_U {
-      const int64_t row = (w0 + u) * 64 + lane;
-      const bool inb = row < n;
-      u64x16 reg;
-      uint32_t rv = 0;
-      POL::eval(P, F, col[u], cv[u], reg, rv, inb, err);
-      bool pass = inb && POL::pass(P, F, plan.pred, col[u], cv[u], reg, rv);
-      uint64_t key[1];
-      uint64_t val[kMaxAggs];
-      key[0] = POL::key(P, F, plan.key[0], 0, col[u], cv[u], reg, rv);
-#pragma unroll
-      for (int a = 0; a < kMaxAggs; ++a) {
-        val[a] = 0;
-        if (a < POL::na(T)) {
-          uint64_t v;
-          bool valid;
-          POL::arg(P, F, plan.arg[a], a, col[u], cv[u], reg, rv, v, valid);
-          val[a] = transform_value(POL::xform(T, a), v, valid);
-        }
-      }
-      passed += pass ? 1 : 0;
-      if (__ballot(pass && key[0] == kEmptyKey) != 0) {  // the claim-sentinel key lives outside the blocks
-        if (pass && key[0] == kEmptyKey) {
-          sentinel_apply(T, val);
-          pass = false;
-        }
-      }
-      const uint64_t m = __ballot(pass);
-      if (pass) {
-        const uint32_t at = qn + mbcnt64(m);
-        q[at] = key[0];
-#pragma unroll
-        for (int a = 0; a < NV; ++a)
-          if (a < na) q[(size_t)(1 + a) * kRingQ + at] = val[a];
-      }
-      qn += (uint32_t)__popcll(m);
-      if (kRingQ < 192 || (u & 1) == 1 || u == U - 1) {  // the queue holds < 64 + (kRingQ - 64) rows
-        while (qn >= 64) {
-          qn -= 64;
-          uint64_t k2[1];
-          uint64_t v2[kMaxAggs];
-          k2[0] = q[qn + lane];
-#pragma unroll
-          for (int a = 0; a < kMaxAggs; ++a) v2[a] = (a < NV && a < na) ? q[(size_t)(1 + a) * kRingQ + qn + lane] : 0;
-          ring_route<NV, kRingCH, kRingRP>(T, PT, spill, L, producer, na, true, k2, v2, err);
-        }
-      }
-    }
-  }
-  {  // the wave's last < 64 rows
-    uint64_t k2[1];
-    uint64_t v2[kMaxAggs];
-    const bool have = (uint32_t)lane < qn;
-    k2[0] = have ? q[lane] : 0;
-#pragma unroll
-    for (int a = 0; a < kMaxAggs; ++a) v2[a] = (have && a < NV && a < na) ? q[(size_t)(1 + a) * kRingQ + lane] : 0;
-    if (qn != 0) ring_route<NV, kRingCH, kRingRP>(T, PT, spill, L, producer, na, have, k2, v2, err);
-  }
-  __syncthreads();
-  // partial chunks + region counts
-  for (uint32_t p = threadIdx.x; p < PT.n_parts; p += kRingBlock) {
-    uint32_t f = L.fill[p];
-    if (f > PT.cap_rows) f = PT.cap_rows;
-    const uint32_t c = f / kRingCH;
-    for (uint32_t r = 0; r < f % kRingCH; ++r) {
-      const uint64_t* src = L.ring + ((size_t)p * kRingRP + (c % kRingNCH) * kRingCH + r) * NW;
-      uint64_t* out = region_row(PT, p, producer, c * kRingCH + r);
-      for (int w = 0; w < NW; ++w) out[w] = src[w];
-    }
-    PT.counts[(uint64_t)p * PT.n_producers + producer] = f;
-  }
-#pragma unroll
-  for (int mm = 32; mm >= 1; mm >>= 1) passed += shfl_xor_u64(passed, mm);
-  if (lane == 0) stat_add(T, STAT_PASSED, passed);
-  if (err) atomicOr(&T.ctrl[CTRL_ERROR], err);
-}
 
 #ifdef DFX_PA_QUEUE
 // find-or-claim in the LDS copy of a table block: at most `max_steps` aligned 4-slot groups starting at group g.
@@ -953,22 +329,15 @@ uint32_t partition_sort_capacity(uint32_t n_words, uint32_t n_parts, uint32_t bl
   return (uint32_t)cap;
 }
 
-template <typename POL, typename POLS>  // POLS: the policy flavour used by the write-combining kernel
-static void launch_partition_pol(const DevProgram& P, const DevFastPlan& fast, const DevColumns& C, const DevAggPlan& plan,
-                                 const DevTable& T, const DevPartition& PT, const DevRows& spill, int64_t n,
-                                 size_t lds_bytes, hipStream_t s) {
-  const int grid = (int)PT.n_producers;  // every producer writes its counts, even with no rows
-  if ((PT.mode & 15u) == 0)
-    hipLaunchKernelGGL((k_partition<POL>), dim3(grid), dim3(kPBlock), lds_bytes, s, P, fast, C, plan, T, PT, spill, n);
-  else if ((PT.mode & 15u) == 2 && (PT.mode & 0x80u))  // 4-row chunks (64-byte runs)
-    hipLaunchKernelGGL((k_partition_ring<POLS, 4, 16>), dim3(grid), dim3(kRingBlock), lds_bytes, s, P, fast, C, plan, T, PT, spill, n);
-  else if ((PT.mode & 15u) == 2)  // 8-row chunks (full 128-byte lines): ~4 % faster on MI355X
-    hipLaunchKernelGGL((k_partition_ring<POLS, 8, 16>), dim3(grid), dim3(kRingBlock), lds_bytes, s, P, fast, C, plan, T, PT, spill, n);
-  else if (PT.block == 512)
-    hipLaunchKernelGGL((k_partition_sorted<POLS, 512>), dim3(grid), dim3(512), lds_bytes, s, P, fast, C, plan, T, PT, spill, n);
-  else
-    hipLaunchKernelGGL((k_partition_sorted<POLS, 1024>), dim3(grid), dim3(1024), lds_bytes, s, P, fast, C, plan, T, PT, spill, n);
-}
+// pass-1 variants (dfx_k_partition_v*.hip)
+void launch_partition_variant0(DFX_PARTITION_VARIANT_ARGS);
+void launch_partition_variant1(DFX_PARTITION_VARIANT_ARGS);
+void launch_partition_variant2(DFX_PARTITION_VARIANT_ARGS);
+void launch_partition_variant3(DFX_PARTITION_VARIANT_ARGS);
+void launch_partition_variant4(DFX_PARTITION_VARIANT_ARGS);
+void launch_partition_variant5(DFX_PARTITION_VARIANT_ARGS);
+void launch_partition_variant6(DFX_PARTITION_VARIANT_ARGS);
+void launch_partition_variant7(DFX_PARTITION_VARIANT_ARGS);
 
 hipError_t launch_partition(const DevProgram& P, const DevFastPlan& fast, const DevColumns& C, const DevAggPlan& plan,
                             const DevTable& T, const DevPartition& PT, const DevRows& spill, int64_t n,
@@ -981,20 +350,18 @@ hipError_t launch_partition(const DevProgram& P, const DevFastPlan& fast, const 
   if ((PT.mode & 15u) == 1 && (lds_bytes > 160 * 1024 || PT.stage_rows == 0 || PT.stage_rows > (uint32_t)kSortMaxCap ||
                        PT.n_parts > 4096 || (PT.block != 512 && PT.block != 1024)))
     return hipErrorInvalidValue;
-#define DFX_PT(POL, POLS) launch_partition_pol<POL, POLS>(P, fast, C, plan, T, PT, spill, n, lds_bytes, s)
   if (sig_matches<SigKeySumPred2F64>(P, fast, 1, T.na, T.acc_kind, T.val_xform)) {
-    DFX_PT(DFX_ARG(StaticPolicy<2, 4, SigKeySumPred2F64>), DFX_ARG(StaticPolicy<2, 4, SigKeySumPred2F64>));
+    launch_partition_variant0(P, fast, C, plan, T, PT, spill, n, lds_bytes, s);
     return hipGetLastError();
   }
   if (sig_matches<SigKeySum>(P, fast, 1, T.na, T.acc_kind, T.val_xform)) {
-    DFX_PT(DFX_ARG(StaticPolicy<2, 4, SigKeySum>), DFX_ARG(StaticPolicy<2, 4, SigKeySum>));
+    launch_partition_variant1(P, fast, C, plan, T, PT, spill, n, lds_bytes, s);
     return hipGetLastError();
   }
   const bool use_fast = fast.valid && !P.has_nulls;
-  if (P.n_cols <= 2) { if (use_fast) DFX_PT(DFX_ARG(FastPolicy<2, 4>), DFX_ARG(FastPolicy<2, 2>)); else DFX_PT(DFX_ARG(InterpPolicy<2, 2>), DFX_ARG(InterpPolicy<2, 1>)); }
-  else if (P.n_cols <= 4) { if (use_fast) DFX_PT(DFX_ARG(FastPolicy<4, 2>), DFX_ARG(FastPolicy<4, 2>)); else DFX_PT(DFX_ARG(InterpPolicy<4, 2>), DFX_ARG(InterpPolicy<4, 1>)); }
-  else { if (use_fast) DFX_PT(DFX_ARG(FastPolicy<8, 2>), DFX_ARG(FastPolicy<8, 1>)); else DFX_PT(DFX_ARG(InterpPolicy<8, 1>), DFX_ARG(InterpPolicy<8, 1>)); }
-#undef DFX_PT
+  if (P.n_cols <= 2) { if (use_fast) launch_partition_variant2(P, fast, C, plan, T, PT, spill, n, lds_bytes, s); else launch_partition_variant3(P, fast, C, plan, T, PT, spill, n, lds_bytes, s); }
+  else if (P.n_cols <= 4) { if (use_fast) launch_partition_variant4(P, fast, C, plan, T, PT, spill, n, lds_bytes, s); else launch_partition_variant5(P, fast, C, plan, T, PT, spill, n, lds_bytes, s); }
+  else { if (use_fast) launch_partition_variant6(P, fast, C, plan, T, PT, spill, n, lds_bytes, s); else launch_partition_variant7(P, fast, C, plan, T, PT, spill, n, lds_bytes, s); }
   return hipGetLastError();
 }
 
