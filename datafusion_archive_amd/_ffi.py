@@ -69,7 +69,7 @@ EXPORTED_SYMBOLS = [
     "dfx_sort_relation_new", "dfx_limit_relation_new",
     "dfx_aggregate_partial_build", "dfx_aggregate_partial_export", "dfx_aggregate_partial_import",
     "dfx_profile_enable", "dfx_profile_reset", "dfx_profile_count", "dfx_profile_get", "dfx_set_option",
-    "dfx_counter_get", "dfx_counter_reset",
+    "dfx_counter_get", "dfx_counter_reset", "dfx_relation_explain",
 ]
 
 _lib = None
@@ -149,6 +149,8 @@ def lib() -> ctypes.CDLL:
     L.dfx_profile_get.argtypes = [ctypes.c_int32, ctypes.c_char_p, ctypes.c_size_t, P(ctypes.c_int64),
                                   P(ctypes.c_double), P(ctypes.c_double)]
     L.dfx_set_option.argtypes = [ctypes.c_char_p, ctypes.c_int64]
+    L.dfx_relation_explain.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t]
+    L.dfx_relation_explain.restype = ctypes.c_int64
     L.dfx_counter_get.argtypes = [ctypes.c_char_p]
     L.dfx_counter_get.restype = ctypes.c_int64
     L.dfx_counter_reset.restype = None

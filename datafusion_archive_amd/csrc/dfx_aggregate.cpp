@@ -16,6 +16,7 @@
 #include <algorithm>
 
 #include "dfx_relation.hpp"
+#include "dfx_sigs.hpp"
 
 namespace dfx {
 
@@ -1135,6 +1136,36 @@ AggregateRelation::AggregateRelation(SchemaInfo schema, std::unique_ptr<Relation
 }
 
 AggregateRelation::~AggregateRelation() {}
+
+void AggregateRelation::explain(std::string* out, int depth) const {
+  const Impl& m = *impl_;
+  if (!m.deferred.ok()) {
+    explain_line(out, depth, "Aggregate: error deferred to next(): " + m.deferred.msg);
+  } else {
+    const DevProgram& P = m.builder->program();
+    const char* shape = "SSA interpreter";
+    if (m.kw == 0) {
+      if (sig_matches<SigCountPred2F64>(P, m.fast, 0, m.na, m.acc_kind, m.val_xform)) shape = "static shape CountPred2F64";
+      else if (sig_matches<SigSumCountPred2F64>(P, m.fast, 0, m.na, m.acc_kind, m.val_xform)) shape = "static shape SumCountPred2F64";
+      else if (m.fast.valid) shape = "column-op-literal shape (FastPolicy; interpreter when a batch has nulls)";
+    } else {
+      if (m.kw == 1 && sig_matches<SigKeySumPred2F64>(P, m.fast, 1, m.na, m.acc_kind, m.val_xform)) shape = "static shape KeySumPred2F64";
+      else if (m.kw == 1 && sig_matches<SigKeySum>(P, m.fast, 1, m.na, m.acc_kind, m.val_xform)) shape = "static shape KeySum";
+      else if (m.kw == 2 && sig_matches<SigQ1>(P, m.fast, 2, m.na, m.acc_kind, m.val_xform)) shape = "static shape Q1";
+      else if (m.fast.valid) shape = "column-op-literal shape (FastPolicy; interpreter when a batch has nulls)";
+    }
+    std::string text = strfmt("Aggregate: %d keys, %d accumulators", m.kw, m.na);
+    text += m.has_pred ? ", Filter below fused into the scan (un-fused for batches with nulls in its columns)" : ", no predicate";
+    text += ", " + explain_program(P) + ", " + shape;
+    if (m.kw == 0) text += ", ungrouped reduce (64 partial copies + fold)";
+    else if (m.kw == 1) text += ", strategy chosen on the first 2^18 rows: register accumulators (<= 8 groups) / LDS front cache (<= 8192) / table / "
+                               "partitioned (>= 16384 groups: pass 1 routes rows to table blocks, pass 2 aggregates blocks in LDS)";
+    else text += ", strategy chosen on the first 2^18 rows: register accumulators (<= 8 groups) / LDS front cache (<= 8192) / table";
+    if (!m.dicts.empty()) text += strfmt(", %d Utf8 keys dictionary-encoded on the device", (int)m.dicts.size());
+    explain_line(out, depth, text);
+  }
+  if (m.input) m.input->explain(out, depth + 1);
+}
 
 Status AggregateRelation::next(DeviceBatch* out, bool* has) {
   *has = false;

@@ -28,6 +28,12 @@ class CsvRelation : public Relation {
   const SchemaInfo& schema() const override { return schema_; }
   Status next(DeviceBatch* out, bool* has) override;
   void require_columns(const std::vector<char>& needed) override { needed_ = needed; }
+  void explain(std::string* out, int depth) const override {
+    int n = 0;
+    for (size_t i = 0; i < schema_.fields.size(); ++i) n += (needed_.empty() || needed_[i]) ? 1 : 0;
+    explain_line(out, depth, strfmt("CsvDataSource: %s, text parsed on the device, %d of %d columns converted, batches of %lld rows",
+                                    filename_.c_str(), n, (int)schema_.fields.size(), (long long)batch_size_));
+  }
   Status open();  // File::open(filename).unwrap() happens in the constructor of the reference: so does this
 
  private:

@@ -27,6 +27,19 @@ int32_t to_c(const Status& s, char* err, size_t errlen) {
   return s.code;
 }
 
+void explain_line(std::string* out, int depth, const std::string& text) {
+  out->append((size_t)depth * 2, ' ');
+  out->append(text);
+  out->push_back('\n');
+}
+std::string explain_program(const DevProgram& P) {
+  return strfmt("program: %d columns, %d instructions, %d literals", P.n_cols, P.n_ins, P.n_imm);
+}
+void Relation::explain(std::string* out, int depth) const {
+  static const char* const names[] = {"HostStream", "TableScan", "Filter", "Project", "Aggregate", "CsvDataSource", "Sort", "Limit"};
+  explain_line(out, depth, names[(int)kind()]);
+}
+
 const char* dtype_name(int dt) {
   switch (dt) {
     case DFX_BOOLEAN: return "Boolean";

@@ -142,7 +142,14 @@ struct Relation {
   // ever read; the producer may then leave the others `absent` (not uploaded / not parsed / not compacted).  Without
   // a call every column is produced.  needed.size() == schema().fields.size().
   virtual void require_columns(const std::vector<char>& needed) { (void)needed; }
+  // One line per operator, children indented below (dfx_relation_explain): what was fused, which kernel family a
+  // program will run on.  Host state only -- never touches the device, so it also works without one.
+  virtual void explain(std::string* out, int depth) const;
 };
+// "<indent><text>\n"
+void explain_line(std::string* out, int depth, const std::string& text);
+// "program: c columns, i instructions, l literals"
+std::string explain_program(const DevProgram& P);
 
 // ---- expressions (dfx_expr.cpp) ---------------------------------------------------------------
 enum AggregateType { AGG_MIN = 0, AGG_MAX = 1, AGG_SUM = 2, AGG_COUNT = 3, AGG_AVG = 4 };

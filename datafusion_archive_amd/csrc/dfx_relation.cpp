@@ -1,6 +1,7 @@
 // dfx_relation.cpp -- Arrow C stream adapters at the library edge, FilterRelation, ProjectRelation
 // and their C-ABI constructors.
 #include "dfx_relation.hpp"
+#include "dfx_sigs.hpp"
 
 #include <errno.h>
 #include <stdlib.h>
@@ -43,6 +44,11 @@ class HostStreamRelation : public Relation {
 
   const SchemaInfo& schema() const override { return schema_; }
   void require_columns(const std::vector<char>& needed) override { needed_ = needed; }
+  void explain(std::string* out, int depth) const override {
+    int n = 0;
+    for (size_t i = 0; i < schema_.fields.size(); ++i) n += (needed_.empty() || needed_[i]) ? 1 : 0;
+    explain_line(out, depth, strfmt("HostStream: host Arrow batches, %d of %d columns uploaded per batch", n, (int)schema_.fields.size()));
+  }
 
   Status next(DeviceBatch* out, bool* has) override {
     *has = false;
@@ -400,6 +406,23 @@ FilterRelation::FilterRelation(std::unique_ptr<Relation> input, const dfx_runtim
   if (deferred_.ok()) builder_->build_fast(pred_operand_, nullptr, 0, nullptr, 0, &fast_);
 }
 
+void FilterRelation::explain(std::string* out, int depth) const {
+  if (!deferred_.ok()) {
+    explain_line(out, depth, "Filter: error deferred to next(): " + deferred_.msg);
+  } else {
+    const uint8_t none[kMaxAggs] = {0};
+    const DevProgram& P = builder_->program();
+    const char* shape = sig_matches<SigPred2F64>(P, fast_, 0, 0, none, none) ? "static shape Pred2F64"
+                        : fast_.valid                                       ? "column-op-literal conjunction (FastPolicy; interpreter when a batch has nulls)"
+                                                                            : "SSA interpreter";
+    int n = 0;
+    for (size_t i = 0; i < schema_.fields.size() || i < out_needed_.size(); ++i) n += (out_needed_.empty() || (i < out_needed_.size() && out_needed_[i])) ? 1 : 0;
+    explain_line(out, depth, "Filter: mask + compaction, " + explain_program(P) + ", " + shape +
+                                 (out_needed_.empty() ? std::string(", every column compacted") : strfmt(", %d columns compacted", n)));
+  }
+  if (input_) input_->explain(out, depth + 1);
+}
+
 // the consumer reads only `needed` of the filter's output columns: the input must still deliver the predicate's
 // columns, and only the needed ones are compacted
 void FilterRelation::require_columns(const std::vector<char>& needed) {
@@ -600,6 +623,19 @@ ProjectRelation::ProjectRelation(std::unique_ptr<Relation> input, std::vector<df
   }
 }
 
+void ProjectRelation::explain(std::string* out, int depth) const {
+  if (!deferred_.ok()) {
+    explain_line(out, depth, "Project: error deferred to next(): " + deferred_.msg);
+  } else {
+    int pass = 0;
+    for (int p : passthrough_) pass += p >= 0 ? 1 : 0;
+    std::string text = strfmt("Project: %d outputs, %d zero-copy columns, %d fused programs", (int)exprs_.size(), pass, (int)groups_.size());
+    for (const Group& g : groups_) text += strfmt(" [%d outputs, %s]", (int)g.outputs.size(), explain_program(g.builder->program()).c_str());
+    explain_line(out, depth, text);
+  }
+  if (input_) input_->explain(out, depth + 1);
+}
+
 Status ProjectRelation::next(DeviceBatch* out, bool* has) {
   *has = false;
   DeviceBatch in;
@@ -704,6 +740,19 @@ int32_t dfx_filter_relation_new(struct ArrowArrayStream* input, const dfx_runtim
     export_relation(std::move(rel), out);
     return DFX_OK;
   });
+}
+
+int64_t dfx_relation_explain(struct ArrowArrayStream* stream, char* buf, size_t buflen) {
+  try {
+    Relation* r = peek_exported(stream);
+    if (!r) return -1;
+    std::string text;
+    r->explain(&text, 0);
+    if (buf && buflen) snprintf(buf, buflen, "%s", text.c_str());
+    return (int64_t)text.size();
+  } catch (...) {
+    return -1;
+  }
 }
 
 int32_t dfx_project_relation_new(struct ArrowArrayStream* input, const dfx_runtime_expr* const* exprs,

@@ -31,6 +31,7 @@ class TableScanRelation : public Relation {
   RelationKind kind() const override { return REL_TABLE_SCAN; }
   Status next(DeviceBatch* out, bool* has) override;
   const SchemaInfo& schema() const override { return table_->schema; }
+  void explain(std::string* out, int depth) const override;
 
  private:
   std::shared_ptr<const TableData> table_;
@@ -47,6 +48,7 @@ class FilterRelation : public Relation {
   Status next(DeviceBatch* out, bool* has) override;
   const SchemaInfo& schema() const override { return schema_; }
   void require_columns(const std::vector<char>& needed) override;
+  void explain(std::string* out, int depth) const override;
   // for Filter -> Aggregate fusion
   std::unique_ptr<Relation> release_input() { return std::move(input_); }
   const dfx_runtime_expr& predicate() const { return expr_; }
@@ -71,6 +73,7 @@ class ProjectRelation : public Relation {
   RelationKind kind() const override { return REL_PROJECT; }
   Status next(DeviceBatch* out, bool* has) override;
   const SchemaInfo& schema() const override { return schema_; }
+  void explain(std::string* out, int depth) const override;
 
  private:
   std::unique_ptr<Relation> input_;
@@ -117,6 +120,7 @@ class AggregateRelation : public Relation {
   RelationKind kind() const override { return REL_AGGREGATE; }
   Status next(DeviceBatch* out, bool* has) override;
   const SchemaInfo& schema() const override { return schema_; }
+  void explain(std::string* out, int depth) const override;
 
   // multi-GPU partial exchange (include/dfx.h: dfx_aggregate_partial_*)
   Status partial_build(int world, int* n_words, int64_t* counts);

@@ -67,6 +67,15 @@ class SortRelation : public Relation {
   Status next(DeviceBatch* out, bool* has) override;
   // ORDER BY ... LIMIT k: a LimitRelation directly above tells the sort that only the first k rows will be read
   void set_limit(int64_t k) { limit_ = k; }
+  void explain(std::string* out, int depth) const override {
+    std::string text = strfmt("Sort: %d keys (", (int)keys_.size());
+    for (size_t i = 0; i < keys_.size(); ++i) text += std::string(i ? ", " : "") + keys_[i].name + (asc_[i] ? " ASC" : " DESC");
+    text += "), stable LSD radix sort of key images";
+    if (limit_ >= 0) text += strfmt(", top-%lld by radix select", (long long)limit_);
+    if (!deferred_.ok()) text += ", error deferred to next(): " + deferred_.msg;
+    explain_line(out, depth, text);
+    if (projected_) projected_->explain(out, depth + 1);
+  }
 
  private:
   // sorts the m row indices of *idx (rows of the n-row input) by sort key `key`
@@ -402,6 +411,10 @@ class LimitRelation : public Relation {
   RelationKind kind() const override { return REL_LIMIT; }
   const SchemaInfo& schema() const override { return schema_; }
   void require_columns(const std::vector<char>& needed) override { input_->require_columns(needed); }
+  void explain(std::string* out, int depth) const override {
+    explain_line(out, depth, strfmt("Limit: %lld rows left", (long long)left_));
+    input_->explain(out, depth + 1);
+  }
   Status next(DeviceBatch* out, bool* has) override {
     *has = false;
     if (left_ <= 0) return Status::OK();

@@ -17,6 +17,11 @@ TableScanRelation::TableScanRelation(std::shared_ptr<const TableData> t, int64_t
   batch_rows_ = (batch_rows_ + 63) / 64 * 64;  // slices stay byte-aligned in every bitmap
 }
 
+void TableScanRelation::explain(std::string* out, int depth) const {
+  explain_line(out, depth, strfmt("TableScan: %lld rows resident in HBM, %d columns, batches of %lld rows (zero-copy slices)",
+                                  (long long)table_->num_rows, (int)table_->columns.size(), (long long)batch_rows_));
+}
+
 Status TableScanRelation::next(DeviceBatch* out, bool* has) {
   *has = false;
   if (pos_ >= table_->num_rows) return Status::OK();  // Ok(None)

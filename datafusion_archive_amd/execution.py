@@ -404,6 +404,18 @@ def set_option(key: str, value: int) -> None:
         raise ExecutionError(3, f"unknown option {key}")
 
 
+def explain(rel: "Relation") -> str:
+    """Physical plan of an operator tree of this library (dfx_relation_explain): one line per operator."""
+    st = rel._live_stream()
+    L = _ffi.lib()
+    n = L.dfx_relation_explain(ctypes.addressof(st), None, 0)
+    if n < 0:
+        raise ExecutionError(3, "not a stream of this library")
+    buf = ctypes.create_string_buffer(int(n) + 1)
+    L.dfx_relation_explain(ctypes.addressof(st), buf, int(n) + 1)
+    return buf.value.decode()
+
+
 def counter_get(name: str) -> int:
     return int(_ffi.lib().dfx_counter_get(name.encode()))
 

@@ -334,6 +334,14 @@ int32_t dfx_profile_count(void);
 int32_t dfx_profile_get(int32_t index, char* name, size_t namelen, int64_t* launches,
                         double* total_ms, double* algo_bytes);
 
+/* EXPLAIN of an operator tree created by this library: one line per operator, children indented by two spaces --
+ * what was fused (a Filter under an Aggregate), how large the fused program is and which kernel family will run it
+ * (a compile-time shape signature, the run-time decoded shape family, the SSA interpreter).  Host state only: works
+ * before the first get_next and without a GPU.  (The reference prints its logical plan upstream of this boundary,
+ * context.rs:105; this is the physical counterpart.)  Writes at most buflen - 1 bytes + NUL; returns the full length,
+ * or -1 if `stream` was not produced by this library. */
+int64_t dfx_relation_explain(struct ArrowArrayStream* stream, char* buf, size_t buflen);
+
 /* Tunables (bench/test only; process-wide, read when an operator is created or a batch is launched).
  * Returns DFX_GENERAL for an unknown key.  Keys:
  *   "agg.strategy"           0 auto (calibrated on the first rows of a stream), 1 global-atomic table only,

@@ -114,6 +114,7 @@ extern "C" {
     fn dfx_table_free(t: *mut DfxTable);
     fn dfx_synchronize(err: *mut c_char, errlen: usize) -> i32;
     fn dfx_set_option(key: *const c_char, value: i64) -> i32;
+    fn dfx_relation_explain(stream: *mut ArrowArrayStream, buf: *mut c_char, buflen: usize) -> i64;
 }
 
 const ERRLEN: usize = 1024;
@@ -587,6 +588,20 @@ impl GpuRelation {
         unsafe { release_schema(&mut cs) };
         check(code, &err)?;
         Self::from_stream(out, schema)
+    }
+}
+
+impl GpuRelation {
+    /// Physical plan of this operator and everything the library chained below it: what was fused, which kernel family
+    /// runs each program (the counterpart of the `println!("Logical plan: ...")` in context.rs:105).
+    pub fn explain(&mut self) -> String {
+        let n = unsafe { dfx_relation_explain(&mut *self.stream, ptr::null_mut(), 0) };
+        if n < 0 {
+            return String::new();
+        }
+        let mut buf = vec![0 as c_char; n as usize + 1];
+        unsafe { dfx_relation_explain(&mut *self.stream, buf.as_mut_ptr(), buf.len()) };
+        unsafe { CStr::from_ptr(buf.as_ptr()) }.to_string_lossy().into_owned()
     }
 }
 

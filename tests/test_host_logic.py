@@ -212,3 +212,72 @@ def test_c_abi_rejects_null_arguments():
         assert err.value, f"{name}: status {rc} without a message"
     # a caller that passes no error buffer still gets the code
     assert L.dfx_filter_relation_new(N, N, N, ctypes.byref(out), N, 0) != 0
+
+
+# ---- EXPLAIN: which kernel family every BASELINE query shape will run on (decided on the host, no GPU needed) ------------
+def _explain_aggregate(schema, filter_expr, group, aggs):
+    batch = pa.RecordBatch.from_pydict({f.name: pa.array([1], f.type) for f in schema}, schema=schema)
+    rel = ex.DataSourceRelation(schema, [batch])
+    if filter_expr is not None:
+        rel = ex.FilterRelation(rel, ex.compile_scalar_expr(None, filter_expr, schema), schema)
+    rel = ex.AggregateRelation(None, rel, [ex.compile_scalar_expr(None, g, schema) for g in group],
+                               [ex.compile_expr(None, a, schema) for a in aggs])
+    return ex.explain(rel)
+
+
+def test_explain_baseline_shapes_hit_their_static_signatures():
+    """A query that silently misses its compile-time signature still gives the right answer, only slower: pin the
+    plan of every BASELINE.json shape (bench.py builds exactly these trees)."""
+    f64 = DataType.Float64
+    kv = pa.schema([("k", pa.int64()), ("v", pa.float64())])
+
+    def l64(v):
+        return Literal(ScalarValue.Float64(v))
+    pred = BinaryExpr(BinaryExpr(Column(1), Operator.Gt, l64(204.8)), Operator.And, BinaryExpr(Column(1), Operator.Lt, l64(409.6)))
+    sum_v = AggregateFunction("SUM", [Column(1)], f64)
+    count_v = AggregateFunction("COUNT", [Column(1)], DataType.UInt64)
+    # the headline query: filter + GROUP BY SUM; the Filter is absorbed by the aggregate
+    text = _explain_aggregate(kv, pred, [Column(0)], [sum_v])
+    assert "static shape KeySumPred2F64" in text and "Filter below fused" in text and "\n  HostStream" in text
+    assert "Filter:" not in text  # no separate operator left
+    # config 3: no predicate
+    assert "static shape KeySum," in _explain_aggregate(kv, None, [Column(0)], [sum_v])
+    # config 2 flavours: predicate + COUNT, predicate + SUM + COUNT (bench.py's verification query)
+    assert "static shape CountPred2F64" in _explain_aggregate(kv, pred, [], [count_v])
+    assert "static shape SumCountPred2F64" in _explain_aggregate(kv, pred, [], [sum_v, count_v])
+    # config 5: the TPC-H Q1 shape
+    names = ["rf", "ls", "qty", "price", "disc", "tax", "ship"]
+    q1 = pa.schema([(n, pa.int64() if i < 2 else pa.float64()) for i, n in enumerate(names)])
+    dp = BinaryExpr(Column(3), Operator.Multiply, BinaryExpr(l64(1.0), Operator.Minus, Column(4)))
+    aggs = [AggregateFunction("sum", [Column(2)], f64), AggregateFunction("sum", [Column(3)], f64), AggregateFunction("sum", [dp], f64),
+            AggregateFunction("sum", [BinaryExpr(dp, Operator.Multiply, BinaryExpr(l64(1.0), Operator.Plus, Column(5)))], f64)]
+    pred5 = BinaryExpr(BinaryExpr(Column(6), Operator.LtEq, l64(2436.0)), Operator.And, BinaryExpr(Column(4), Operator.GtEq, l64(0.0)))
+    text = _explain_aggregate(q1, pred5, [Column(0), Column(1)], aggs)
+    assert "static shape Q1" in text and "2 keys, 4 accumulators" in text and "7 columns" in text
+    # anything else: the run-time decoded shape family, or the interpreter
+    assert "FastPolicy" in _explain_aggregate(kv, pred, [Column(0)], [AggregateFunction("MAX", [Column(1)], f64)])
+    assert "SSA interpreter" in _explain_aggregate(kv, pred, [Column(0)], [AggregateFunction("SUM", [BinaryExpr(Column(1), Operator.Plus, Column(1))], f64)])
+
+
+def test_explain_operator_tree_and_pushdown():
+    schema = pa.schema([("k", pa.int64()), ("v", pa.float64()), ("w", pa.float64())])
+    b = pa.RecordBatch.from_pydict({"k": [1], "v": [2.0], "w": [3.0]}, schema=schema)
+    pred = BinaryExpr(Column(1), Operator.Gt, Literal(ScalarValue.Float64(1.0)))
+    f = ex.FilterRelation(ex.DataSourceRelation(schema, [b]), ex.compile_scalar_expr(None, pred, schema), schema)
+    p = ex.ProjectRelation(f, [ex.compile_scalar_expr(None, Column(0), schema),
+                               ex.compile_scalar_expr(None, BinaryExpr(Column(1), Operator.Multiply, Column(1)), schema)], None)
+    out_schema = pa.schema([("k", pa.int64()), ("vv", pa.float64())])
+    top = ex.LimitRelation(ex.SortRelation(p, [(ex.compile_scalar_expr(None, Column(1), out_schema), False)], out_schema), 5, out_schema)
+    lines = ex.explain(top).splitlines()
+    assert [ln.strip().split(":")[0] for ln in lines] == ["Limit", "Sort", "Project", "Project", "Filter", "HostStream"]
+    assert [len(ln) - len(ln.lstrip()) for ln in lines] == [0, 2, 4, 6, 8, 10]
+    assert "top-5 by radix select" in lines[1] and "DESC" in lines[1]
+    assert "1 zero-copy columns, 1 fused programs" in lines[3]
+    # projection push-down is visible: the projection reads k and v, so w is neither compacted nor uploaded
+    assert "2 columns compacted" in lines[4]
+    assert "2 of 3 columns uploaded" in lines[5]
+    # a foreign stream is not explained
+    import ctypes
+    from datafusion_archive_amd import _ffi
+    foreign = _ffi.ArrowArrayStream()
+    assert _ffi.lib().dfx_relation_explain(ctypes.addressof(foreign), None, 0) == -1
