@@ -218,7 +218,12 @@ def main():
             ts, tc = float(t[0].item()), int(t[1].item())
         verified = bool(local_sum == ts and local_groups == GROUPS and abs(tc / total_rows - 0.2) < 1e-3)
 
-    extra = {"kernels": {k: {"launches": v["launches"], "total_ms": round(v["total_ms"], 3)} for k, v in prof.items()},
+    try:  # physical plan of the timed query (host state only: what was fused, which kernel family runs)
+        plan_text = ex.explain(build(pred, [Column(0)], [sum_v]))
+    except Exception as e:  # never lose the measurement over a description
+        plan_text = f"unavailable: {e}"
+    extra = {"plan": plan_text.strip().split("\n"),
+             "kernels": {k: {"launches": v["launches"], "total_ms": round(v["total_ms"], 3)} for k, v in prof.items()},
              "verified_sum_of_group_sums_equals_ungrouped_sum": verified, "device": info["name"],
              "groups": GROUPS, "selectivity": 0.2, "instrumented_ms_per_step": dt_instr / args.steps * 1e3}
 
