@@ -149,6 +149,15 @@ def main():
     for _ in range(args.warmup):
         step()
     dt, result = timed(step, args.steps, 0)
+    plan_text = "n/a"
+    if world == 1:  # physical plan of the timed query after one more (untimed) run: fusion, kernel family, strategy, groups
+        try:
+            plan_agg = build(pred, [Column(0)], [sum_v])
+            plan_agg.next()
+            plan_text = ex.explain(plan_agg)
+            del plan_agg
+        except Exception as e:  # never lose the measurement over a description
+            plan_text = f"unavailable: {e}"
     total_rows = n_rows * world
     value = total_rows * args.steps / dt
     ms_per_step = dt / args.steps * 1e3
@@ -218,10 +227,6 @@ def main():
             ts, tc = float(t[0].item()), int(t[1].item())
         verified = bool(local_sum == ts and local_groups == GROUPS and abs(tc / total_rows - 0.2) < 1e-3)
 
-    try:  # physical plan of the timed query (host state only: what was fused, which kernel family runs)
-        plan_text = ex.explain(build(pred, [Column(0)], [sum_v]))
-    except Exception as e:  # never lose the measurement over a description
-        plan_text = f"unavailable: {e}"
     extra = {"plan": plan_text.strip().split("\n"),
              "kernels": {k: {"launches": v["launches"], "total_ms": round(v["total_ms"], 3)} for k, v in prof.items()},
              "verified_sum_of_group_sums_equals_ungrouped_sum": verified, "device": info["name"],
