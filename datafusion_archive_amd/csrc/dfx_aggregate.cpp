@@ -1163,7 +1163,7 @@ void AggregateRelation::explain(std::string* out, int depth) const {
     else text += ", strategy chosen on the first 2^18 rows: register accumulators (<= 8 groups) / LDS front cache (<= 8192) / table";
     if (!m.dicts.empty()) text += strfmt(", %d Utf8 keys dictionary-encoded on the device", (int)m.dicts.size());
     if (m.built && m.kw > 0)  // after the input was drained: what actually ran
-      text += strfmt("; ran %lld rows: %s, %llu groups in a table of 2^%d slots", (long long)m.rows_seen,
+      text += strfmt("; ran %lld rows: %s, %llu of 2^%d table slots occupied", (long long)m.rows_seen,
                      m.use_partition ? "partitioned" : (m.lds_enabled && m.occupied_known <= 8 && agg_options().fewgroup) ? "few groups (register accumulators or LDS front cache)"
                                      : m.lds_enabled ? "LDS front cache + table" : "table (global atomics)",
                      (unsigned long long)m.occupied_known, 64 - m.T.shift);
