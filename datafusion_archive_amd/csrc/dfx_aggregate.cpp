@@ -297,10 +297,10 @@ Status AggregateRelation::Impl::alloc_table(int cap_log2, DevTable* Tn, std::vec
   owners->push_back(keys);
   owners->push_back(accs);
   if (kw > 1) {
-    auto state = device_alloc(sizeof(uint32_t) * Tn->stride, &st);
-    if (!state) return st;
-    Tn->state = (uint32_t*)state.get();
-    owners->push_back(state);
+    auto slot_state = device_alloc(sizeof(uint32_t) * Tn->stride, &st);
+    if (!slot_state) return st;
+    Tn->state = (uint32_t*)slot_state.get();
+    owners->push_back(slot_state);
     DFX_HIP(hipMemsetAsync(Tn->state, 0, sizeof(uint32_t) * Tn->stride, s));
   } else {
     DFX_HIP(launch_fill_u64(Tn->keys, kEmptyKey, (int64_t)Tn->stride, s));
@@ -743,8 +743,8 @@ Status AggregateRelation::Impl::dict_alloc(DictKey& d, int slots_log2, uint64_t 
   hipStream_t s = ctx().stream;
   const uint64_t slots = 1ull << slots_log2, id_cap = slots / 2;
   Status st;
-  auto state = device_alloc(sizeof(uint32_t) * slots, &st);
-  if (!state) return st;
+  auto dstate = device_alloc(sizeof(uint32_t) * slots, &st);
+  if (!dstate) return st;
   auto hash = device_alloc(sizeof(uint64_t) * slots, &st);
   if (!hash) return st;
   auto sid = device_alloc(sizeof(uint64_t) * slots, &st);
@@ -757,7 +757,7 @@ Status AggregateRelation::Impl::dict_alloc(DictKey& d, int slots_log2, uint64_t 
   if (!pool) return st;
   auto cursors = device_alloc(sizeof(uint64_t) * DICT_WORDS, &st);
   if (!cursors) return st;
-  DFX_HIP(hipMemsetAsync(state.get(), 0, sizeof(uint32_t) * slots, s));
+  DFX_HIP(hipMemsetAsync(dstate.get(), 0, sizeof(uint32_t) * slots, s));
   if (keep && d.allocated) {
     if (d.pool_used) DFX_HIP(hipMemcpyAsync(pool.get(), d.pool.get(), d.pool_used, hipMemcpyDeviceToDevice, s));
     if (d.ids_used) {
@@ -770,8 +770,8 @@ Status AggregateRelation::Impl::dict_alloc(DictKey& d, int slots_log2, uint64_t 
   const uint64_t hc[DICT_WORDS] = {d.pool_used, d.ids_used, 0, 0};
   DFX_HIP(hipMemcpyAsync(cursors.get(), hc, sizeof(hc), hipMemcpyHostToDevice, s));
   DFX_HIP(hipStreamSynchronize(s));  // hc is a stack buffer; the old arrays are released below
-  d.state = state; d.hash = hash; d.sid = sid; d.str_off = str_off; d.str_len = str_len; d.pool = pool; d.cursors = cursors;
-  d.D.state = (uint32_t*)state.get();
+  d.state = dstate; d.hash = hash; d.sid = sid; d.str_off = str_off; d.str_len = str_len; d.pool = pool; d.cursors = cursors;
+  d.D.state = (uint32_t*)dstate.get();
   d.D.hash = (uint64_t*)hash.get();
   d.D.sid = (uint64_t*)sid.get();
   d.D.str_off = (uint64_t*)str_off.get();
