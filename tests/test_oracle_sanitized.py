@@ -36,3 +36,9 @@ def test_host_builds_of_device_headers_under_asan_ubsan(tmp_path):
     subprocess.check_call(["g++"] + SAN + ["-std=c++17", "-o", num, os.path.join(ROOT, "tests", "native", "numparse_fuzz.cpp")])
     r = subprocess.run([num, "150000", "22"], capture_output=True, text=True)
     assert r.returncode == 0 and r.stdout.startswith("ok:"), r.stdout + r.stderr
+    # the whole-file emulation of the device CSV source over the fixture with every column type
+    chk = str(tmp_path / "csv_fixture_check_san")
+    subprocess.check_call(["g++"] + SAN + ["-std=c++17", "-o", chk, os.path.join(ROOT, "tests", "native", "csv_fixture_check.cpp"), obj, "-lm"])
+    r = subprocess.run([chk, os.path.join(ROOT, "tests", "data", "all_types_gen.csv"), "1,6,7,8,9,2,3,4,5,10,11,12"],
+                       capture_output=True, text=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
+    assert r.returncode == 0 and r.stdout.startswith("ok:"), r.stdout + r.stderr
