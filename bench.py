@@ -273,14 +273,40 @@ def main():
         extra["cfg5_groups"] = r5.num_rows
 
     cpu_baseline = None
+    verified_vs_oracle = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        import oracle  # tests/oracle.py: the CPU restatement, used here ONLY as the reported baseline
-        sample = int(args.cpu_sample_rows)
-        secs, kept, _ = oracle.run_synth_query(syn, seed, 0, sample, 1024, pred, [Column(0)], [sum_v], want_result=False)
+        import numpy as np
+        import oracle  # tests/oracle.py: the CPU restatement -- the reported baseline AND the checker of the GPU result
+        sample = min(int(args.cpu_sample_rows), n_rows)
+        secs, kept, want = oracle.run_synth_query(syn, seed, 0, sample, 1024, pred, [Column(0)], [sum_v, count_v], want_result=True)
         cpu_baseline = {"value": sample / secs, "unit": "rows/s", "cores": 1, "kind": "port",
-                        "sample": f"first {sample} rows of the same table, same query, 1024-row batches "
+                        "sample": f"first {sample} rows of the same table, same query (+ COUNT), 1024-row batches "
                                   f"(reference-shaped C restatement, oracle/dfx_oracle.c), {secs:.2f} s",
                         "host_cores_available": os.cpu_count()}
+        # per-group parity at the benchmark's size: the same row slice through the product path (same batch width, same
+        # automatic strategy => partitioned), every group compared with the oracle bit for bit (exact distribution)
+        try:
+            t_s = table if sample == n_rows else ex.DeviceTable.synth(syn, seed, 0, sample)
+            rel = ex.FilterRelation(t_s.scan(args.batch_rows), ex.compile_scalar_expr(None, pred, schema), schema)
+            rel = ex.AggregateRelation(None, rel, [ex.compile_scalar_expr(None, Column(0), schema)],
+                                       [ex.compile_expr(None, a, schema) for a in (sum_v, count_v)])
+            got = rel.next()
+
+            def by_key(b):
+                k = b.column(0).to_numpy()
+                o = np.argsort(k, kind="stable")
+                return k[o], b.column(1).to_numpy()[o].view(np.uint64), b.column(2).to_numpy()[o]
+            gk, gs, gc = by_key(got)
+            wk, ws, wc = by_key(want)
+            ok = bool(len(gk) == len(wk) and np.array_equal(gk, wk) and np.array_equal(gs, ws) and np.array_equal(gc, wc)
+                      and int(gc.sum()) == kept)
+            verified_vs_oracle = {"rows": sample, "groups": int(len(wk)), "rows_passing": int(kept), "ok": ok,
+                                  "what": "SUM bit-exact and COUNT equal for every group, GPU (partitioned strategy, "
+                                          f"{args.batch_rows}-row batches) vs CPU oracle over the same rows"}
+            del t_s, rel, got
+        except Exception as e:  # a failed check must show up in the line, not kill the measurement
+            verified_vs_oracle = {"rows": sample, "ok": False, "error": str(e)[:300]}
+        extra["verified_vs_oracle"] = verified_vs_oracle
 
     if rank == 0:
         line = {

@@ -659,6 +659,12 @@ Status AggregateRelation::Impl::consume_batch(const DeviceBatch& b) {
       return st;
     }
   }
+  // The absorbed FilterRelation's batch-level error survives the fusion: fn filter has no arm for Boolean
+  // (filter.rs:105-108), so a batch with a Boolean column fails under a Filter whether or not anybody reads that column
+  // and whether this batch runs fused (no nulls) or through a real FilterRelation (nulls in the program's columns)
+  if (has_pred && !unfused_now)
+    for (size_t c = 0; c < b.columns.size(); ++c)
+      if (b.columns[c].dtype == DFX_BOOLEAN) return Status::Err(DFX_EXECUTION_ERROR, "filter not supported for Boolean");
   const int64_t n = b.num_rows;
   if (n == 0 && kw > 0) return Status::OK();  // (ungrouped: an empty batch still folds Some(0) into COUNT)
   hipStream_t s = ctx().stream;

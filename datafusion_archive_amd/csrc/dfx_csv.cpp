@@ -166,9 +166,9 @@ Status CsvRelation::index_records() {
 
 // the failing cell's text, for the reference's message
 Status CsvRelation::cell_error(uint64_t packed) {
-  const int64_t record = (int64_t)(packed >> 16);
-  const int col = (int)((packed >> 8) & 0xFF);
-  const int code = (int)(packed & 0xFF);
+  int64_t record = 0;
+  int col = 0, code = 0;
+  csv_err_unpack(packed, &code, &col, &record);
   const int64_t line = record;  // arrow: line_number starts at 1 with a header, + index of the record in the file
   uint64_t span[2] = {0, 0};
   hipStream_t s = ctx().stream;

@@ -18,6 +18,25 @@
 
 namespace dfx {
 
+// The first error of a batch, as ONE 64-bit word that the device reduces with atomicMin.  arrow's csv::Reader first
+// reads every record of the batch (the csv crate reports UnequalLengths there: lowest record wins) and then converts
+// column by column (lowest column, then lowest row), so: UnequalLengths (code 3) sorts below every cell error, cell
+// errors sort by (column, record).  code: 1 value does not parse, 2 needs arbitrary precision, 3 UnequalLengths.
+DFX_HD uint64_t csv_err_pack(int code, int col, int64_t record) {
+  if (code == 3) return ((uint64_t)record << 8) | 3ull;
+  return (1ull << 63) | ((uint64_t)(col & 0xFF) << 55) | (((uint64_t)record & ((1ull << 47) - 1)) << 8) | (uint64_t)(code & 0xFF);
+}
+DFX_HD void csv_err_unpack(uint64_t e, int* code, int* col, int64_t* record) {
+  *code = (int)(e & 0xFF);
+  if (e >> 63) {
+    *col = (int)((e >> 55) & 0xFF);
+    *record = (int64_t)((e >> 8) & ((1ull << 47) - 1));
+  } else {
+    *col = 0;
+    *record = (int64_t)(e >> 8);
+  }
+}
+
 enum : uint32_t { CSV_Q = 0, CSV_D = 1, CSV_T = 2, CSV_O = 3 };
 DFX_HD uint32_t csv_class(uint8_t c) { return c == '"' ? CSV_Q : c == ',' ? CSV_D : (c == '\n' || c == '\r') ? CSV_T : CSV_O; }
 

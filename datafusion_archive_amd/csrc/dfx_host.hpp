@@ -83,6 +83,16 @@ struct SchemaInfo {
   std::vector<Field> fields;
 };
 Status schema_from_arrow(const struct ArrowSchema* s, SchemaInfo* out);
+// Schema of an operator whose arrays are its input's (Filter, Sort, Limit): the reference hands such operators an
+// arbitrary Arc<Schema> (often Schema::empty()) that nothing checks against the arrays.  Here the exported schema must
+// describe the arrays (consumers import buffers by it), so only the NAMES of a caller-supplied schema with the right
+// field count are kept; types and nullability are the input's.
+inline SchemaInfo schema_names_over(const SchemaInfo& caller, const SchemaInfo& input) {
+  SchemaInfo out = input;
+  if (caller.fields.size() == input.fields.size())
+    for (size_t i = 0; i < out.fields.size(); ++i) out.fields[i].name = caller.fields[i].name;
+  return out;
+}
 // exports a struct-typed ArrowSchema ("+s") owning all its memory
 void schema_to_arrow(const SchemaInfo& s, struct ArrowSchema* out);
 

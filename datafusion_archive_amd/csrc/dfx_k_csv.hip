@@ -252,7 +252,7 @@ __global__ __launch_bounds__(kBlock) void k_csv_parse(const uint8_t* __restrict_
       cell_len[fi * kBlock + threadIdx.x] = (f.ulen & 0x3FFFFFFFu) | (f.quoted ? 0x40000000u : 0u) | (f.complex ? 0x80000000u : 0u);
     });
     if ((uint32_t)nf != plan.expected_fields) {  // csv crate, flexible == false: UnequalLengths
-      const uint64_t e = ((uint64_t)(r0 + tid) << 16) | ((uint64_t)(nf & 0xFF) << 8) | 3ull;
+      const uint64_t e = csv_err_pack(3, 0, r0 + tid);
       err = e < err ? e : err;
     }
   }
@@ -305,13 +305,14 @@ __global__ __launch_bounds__(kBlock) void k_csv_parse(const uint8_t* __restrict_
       }
       if (rc == NP_OK) valid = true;
       else {
-        const uint64_t e = ((uint64_t)(r0 + tid) << 16) | ((uint64_t)c << 8) | (uint64_t)(rc == NP_INVALID ? 1 : 2);
+        const uint64_t e = csv_err_pack(rc == NP_INVALID ? 1 : 2, c, r0 + tid);
         err = e < err ? e : err;
       }
     }
     if (inb && !valid && col.dtype != T_BOOL) store_typed(col.dtype, col.values, tid, 0ull);
     const uint64_t vm = __ballot(valid);
-    if (lane == 0) {
+    const bool wave_inb = (tid & ~63ll) < nb;  // waves of the last workgroup that lie wholly past nb own no bitmap word
+    if (lane == 0 && wave_inb) {
       col.validity[tid >> 6] = vm;
       const int64_t rows_here = nb - (tid & ~63ll) < 64 ? nb - (tid & ~63ll) : 64;
       const int nulls = (int)rows_here - __popcll(vm);
@@ -319,7 +320,7 @@ __global__ __launch_bounds__(kBlock) void k_csv_parse(const uint8_t* __restrict_
     }
     if (col.dtype == T_BOOL) {
       const uint64_t bm = __ballot(valid && bval);
-      if (lane == 0) ((uint64_t*)col.values)[tid >> 6] = bm;
+      if (lane == 0 && wave_inb) ((uint64_t*)col.values)[tid >> 6] = bm;
     }
   }
   if (err != ~0ull) atomicMin((unsigned long long*)plan.err, (unsigned long long)err);

@@ -59,9 +59,9 @@ class HostStreamRelation : public Relation {
     if (rc != 0) return stream_error(rc, "get_next");
     if (arr.release == nullptr) return Status::OK();  // end of stream == Ok(None)
     Status st = upload(arr, out);
-    if (st.ok()) {
-      hipError_t e = hipStreamSynchronize(ctx().stream);  // host buffers are borrowed until here
-      if (e != hipSuccess) st = Status::Err(DFX_EXECUTION_ERROR, strfmt("HIP error %s after H2D", hipGetErrorString(e)));
+    {  // host buffers are borrowed until here -- also when upload failed part-way: earlier columns' copies may be queued
+      hipError_t e = hipStreamSynchronize(ctx().stream);
+      if (e != hipSuccess && st.ok()) st = Status::Err(DFX_EXECUTION_ERROR, strfmt("HIP error %s after H2D", hipGetErrorString(e)));
     }
     arr.release(&arr);
     if (st.ok()) *has = true;
@@ -115,11 +115,16 @@ class HostStreamRelation : public Relation {
       }
       if (dt == DFX_UTF8) {
         if (c->n_buffers < 3) return Status::Err(DFX_ARROW_ERROR, "Utf8 array without 3 buffers");
-        const int32_t* offs = (const int32_t*)c->buffers[1] + off;
+        // producers may export a zero-length string array with a null (or zero-sized) offsets buffer: offsets = {0}
+        static const int32_t kZeroOffset[1] = {0};
+        const bool no_offsets = c->buffers[1] == nullptr;
+        if (no_offsets && n != 0) return Status::Err(DFX_ARROW_ERROR, "Utf8 array without an offsets buffer");
+        const int32_t* offs = no_offsets ? kZeroOffset : (const int32_t*)c->buffers[1] + off;
         const uint8_t* data = (const uint8_t*)c->buffers[2];
         std::shared_ptr<void> doff, ddata;
         DFX_RETURN_IF_ERROR(h2d(offs, sizeof(int32_t) * (size_t)(n + 1), &doff));
         const int32_t o0 = offs[0], o1 = offs[n];
+        if (o1 < o0 || (o1 > o0 && !data)) return Status::Err(DFX_ARROW_ERROR, "Utf8 array with inconsistent offsets");
         DFX_RETURN_IF_ERROR(h2d(data ? data + o0 : nullptr, (size_t)(o1 - o0), &ddata));
         d.offsets = (const int32_t*)doff.get();
         d.data = (const uint8_t*)ddata.get() - o0;  // raw offsets index straight into it
@@ -455,6 +460,8 @@ Status FilterRelation::next(DeviceBatch* out, bool* has) {
   out->columns.clear();
   out->columns.resize(in.columns.size());
   if (n == 0) {  // zero-row batches are still emitted (filter.rs:55-62)
+    for (size_t c = 0; c < in.columns.size(); ++c)  // fn filter matches on the type before it looks at a row
+      if (in.columns[c].dtype == DFX_BOOLEAN) return Status::Err(DFX_EXECUTION_ERROR, "filter not supported for Boolean");
     for (size_t c = 0; c < in.columns.size(); ++c) {
       out->columns[c].dtype = in.columns[c].dtype;
       out->columns[c].length = 0;
@@ -733,7 +740,7 @@ int32_t dfx_filter_relation_new(struct ArrowArrayStream* input, const dfx_runtim
     SchemaInfo si;
     st = schema_from_arrow(schema, &si);
     if (!st.ok()) return to_c(st, err, errlen);
-    if (si.fields.empty()) si = in->schema();
+    si = schema_names_over(si, in->schema());
     if (expr->is_aggregate)
       return to_c(Status::Err(DFX_INTERNAL_ERROR, "explicit panic: get_func() on an aggregate expression"), err, errlen);
     std::unique_ptr<Relation> rel(new FilterRelation(std::move(in), *expr, si));

@@ -52,7 +52,7 @@ class SortRelation : public Relation {
   SortRelation(std::unique_ptr<Relation> input, std::vector<dfx_runtime_expr> keys, std::vector<int> asc, SchemaInfo schema)
       : keys_(std::move(keys)), asc_(std::move(asc)), schema_(std::move(schema)) {
     n_payload_ = (int)input->schema().fields.size();
-    if (schema_.fields.empty()) schema_ = input->schema();
+    schema_ = schema_names_over(schema_, input->schema());
     // payload columns pass through (zero copy), the keys are evaluated next to them by the projection machinery
     std::vector<dfx_runtime_expr> exprs;
     for (int i = 0; i < n_payload_; ++i) exprs.push_back(column_expr(i, input->schema()));
@@ -406,7 +406,7 @@ class LimitRelation : public Relation {
  public:
   LimitRelation(std::unique_ptr<Relation> input, int64_t limit, SchemaInfo schema)
       : input_(std::move(input)), left_(limit), schema_(std::move(schema)) {
-    if (schema_.fields.empty()) schema_ = input_->schema();
+    schema_ = schema_names_over(schema_, input_->schema());
   }
   RelationKind kind() const override { return REL_LIMIT; }
   const SchemaInfo& schema() const override { return schema_; }

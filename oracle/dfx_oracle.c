@@ -532,11 +532,19 @@ int32_t orc_filter_next(const dfx_expr_node* nodes, int32_t n_nodes, int32_t roo
     orc_array_free(mask);
     return fail(err, errlen, DFX_EXECUTION_ERROR, "Filter expression did not evaluate to boolean");
   }
+  /* fn filter has arms for Float64 and Utf8 only (filter.rs:105-108).  Deviation D2 widens that to every fixed-width
+   * numeric type; a Boolean column keeps the reference's error, for the batch as a whole and whatever its length */
+  for (int c = 0; c < batch->num_columns; ++c)
+    if (batch->columns[c]->dtype == DFX_BOOLEAN) {
+      orc_array_free(mask);
+      return fail(err, errlen, DFX_EXECUTION_ERROR, "filter not supported for Boolean");
+    }
   orc_batch* ob = (orc_batch*)calloc(1, sizeof(orc_batch));
   ob->owned = 1;
-  ob->num_columns = batch->num_columns;
-  ob->columns = (orc_array**)calloc((size_t)batch->num_columns, sizeof(orc_array*));
-  for (int c = 0; c < batch->num_columns; ++c) ob->columns[c] = filter_array(batch->columns[c], mask);
+  const int nc = batch->num_columns > 0 ? batch->num_columns : 0;
+  ob->num_columns = nc;
+  ob->columns = (orc_array**)calloc((size_t)nc + 1, sizeof(orc_array*));
+  for (int c = 0; c < nc; ++c) ob->columns[c] = filter_array(batch->columns[c], mask);
   ob->num_rows = batch->num_columns ? ob->columns[0]->length : 0;
   orc_array_free(mask);
   *out = ob;

@@ -178,6 +178,37 @@ def test_csv_errors_mirror_reference(tmp_path):
     assert list(ex.CsvDataSource(str(p), schema, 1024)) == []
 
 
+def test_csv_first_error_of_a_batch_follows_arrows_order(tmp_path):
+    """Two bad things in ONE batch: arrow's csv::Reader reads all records of the batch first (UnequalLengths wins over
+    any cell error, lowest record first) and then converts column by column (lowest column, then lowest row).  The
+    device reduces the failing cells with one atomicMin whose key has that order; the oracle reads the same way."""
+    schema = pa.schema([("a", pa.int32()), ("b", pa.float64()), ("c", pa.int64())])
+    rows = [f"{i},{i}.5,{i * 7}" for i in range(40)]
+    cases = []
+    r = list(rows); r[5] = "5,5.5,zzz"; r[9] = "9,yyy,63"          # row 5 col 2 vs row 9 col 1: the lower COLUMN wins
+    cases.append(("Error while parsing value yyy at line 10", r))
+    r = list(rows); r[3] = "xxx,3.5,21"; r[7] = "7,7.5"             # a parse error at row 3 vs a short record at row 7
+    cases.append(("UnequalLengths", r))
+    r = list(rows); r[20] = "20,q,140"; r[4] = "4,w,28"             # same column: the lower row wins
+    cases.append(("Error while parsing value w at line 5", r))
+    for want, body in cases:
+        p = tmp_path / "two_bad.csv"
+        p.write_text("a,b,c\n" + "\n".join(body) + "\n")
+        with pytest.raises(ex.ExecutionError) as ei:
+            list(ex.CsvDataSource(str(p), schema, 1024))
+        assert want in ei.value.message, (want, ei.value.message)
+        with pytest.raises(oracle.OracleError) as oi:
+            oracle.read_csv(str(p), schema, 1024)
+        assert want in oi.value.message, (want, oi.value.message)
+    # in different batches the earlier batch fails first, whatever the columns
+    r = list(rows); r[5] = "5,5.5,zzz"; r[25] = "yy,25.5,175"
+    p = tmp_path / "two_batches.csv"
+    p.write_text("a,b,c\n" + "\n".join(r) + "\n")
+    with pytest.raises(ex.ExecutionError) as ei:
+        list(ex.CsvDataSource(str(p), schema, 16))
+    assert "Error while parsing value zzz at line 6" in ei.value.message
+
+
 def test_csv_large_file_throughput(tmp_path):
     """~60 MB of numeric text: parity on a slice-independent property (column sums via the device aggregate equal the
     oracle's sums of the same file) and the device-side parse rate."""

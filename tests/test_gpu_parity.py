@@ -853,6 +853,27 @@ def test_projection_pushdown_keeps_filter_errors():
     assert "filter not supported" in ei.value.message
 
 
+@pytest.mark.parametrize("with_nulls", [False, True])
+@pytest.mark.parametrize("rows", [0, 5000])
+def test_aggregate_over_filter_keeps_boolean_column_error(with_nulls, rows):
+    """Aggregate(Filter(scan with a Boolean column)): the Filter fails the batch (filter.rs:105-108) whether the
+    aggregate absorbs it (null-free batch: fused launch) or runs it for real (nulls in the predicate's columns), and
+    whatever the batch length; the oracle's FilterRelation says the same."""
+    rng = np.random.default_rng(5)
+    v = rng.integers(0, 1 << 20, rows).astype(np.float64) / 1024.0
+    mask = (rng.random(rows) < 0.1) if with_nulls else None
+    b = pa.RecordBatch.from_arrays([pa.array(rng.integers(0, 50, rows).astype(np.int64)), pa.array(v, mask=mask),
+                                    pa.array(rng.random(rows) < 0.5)], names=["k", "v", "flag"])
+    pred = BinaryExpr(Column(1), Operator.Gt, lit(300.0))
+    for group in ([Column(0)], []):
+        with pytest.raises(ex.ExecutionError) as ei:
+            gpu_aggregate(group, [agg("sum", Column(1), F64)], b.schema, [b], filter_expr=pred)
+        assert ei.value.kind == "ExecutionError" and "filter not supported for Boolean" in ei.value.message
+    with pytest.raises(oracle.OracleError) as oi:
+        oracle.filter_next(pred, b)
+    assert "filter not supported for Boolean" in str(oi.value)
+
+
 # ---------------------------------------------------------------------------------------------------
 # two rules the randomised differential test (tests/test_gpu_fuzz.py) found the fused paths breaking
 # ---------------------------------------------------------------------------------------------------

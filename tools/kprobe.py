@@ -7,13 +7,15 @@ from datafusion_archive_amd.logicalplan import *
 rows = int(float(sys.argv[1])); groups = float(sys.argv[2]); filt = int(sys.argv[3])
 LO, HI = 204.8, 409.6
 UNGROUPED = False
+ZIPF = False
 for kv in sys.argv[4:]:
     if kv == "ungrouped": UNGROUPED = True; continue
+    if kv == "zipf": ZIPF = True; continue
     if kv.startswith("lo="): LO = float(kv[3:]); continue
     if kv.startswith("hi="): HI = float(kv[3:]); continue
     k, v = kv.split("="); ex.set_option(k, int(v))
 ex.init(0)
-syn = [("k", ex.SYNTH_I64_UNIFORM, 0, groups, 0.0), ("v", ex.SYNTH_F64_EXACT, 1, 0.0, 0.0)]
+syn = [("k", ex.SYNTH_I64_ZIPF if ZIPF else ex.SYNTH_I64_UNIFORM, 0, groups, 1.0 if ZIPF else 0.0), ("v", ex.SYNTH_F64_EXACT, 1, 0.0, 0.0)]
 schema = pa.schema([("k", pa.int64()), ("v", pa.float64())])
 t = ex.DeviceTable.synth(syn, 0xDF02, 0, rows)
 lit = lambda v: Literal(ScalarValue.Float64(v))
@@ -26,9 +28,14 @@ def run():
     else:
         rel = ex.AggregateRelation(None, rel, [ex.compile_scalar_expr(None, Column(0), schema)], [ex.compile_expr(None, AggregateFunction("SUM", [Column(1)], DataType.Float64), schema)])
     return rel.next()
-run(); ex.profile_reset(); ex.profile_enable(True)
+import time
+run(); ex.synchronize(); t0 = time.perf_counter()
+for _ in range(3): out = run()
+ex.synchronize(); dt = (time.perf_counter() - t0) / 3
+ex.profile_reset(); ex.profile_enable(True)
 for _ in range(3): out = run()
 ex.profile_enable(False)
+print(f"un-instrumented: {dt * 1e3:.3f} ms per query = {rows / dt / 1e9:.1f} G rows/s")
 print(f"rows={rows} groups={groups} filt={filt} opts={sys.argv[4:]} -> groups_out={out.num_rows}")
 for p in ex.profile_snapshot():
     print(f"   {p['kernel']:14s} launches={p['launches']:3d} avg_us={p['total_ms']/p['launches']*1e3:9.1f}")
