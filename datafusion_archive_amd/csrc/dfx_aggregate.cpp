@@ -95,6 +95,18 @@ struct AggregateRelation::Impl {
   DevPartition PT;
   std::shared_ptr<void> pt_rows, pt_counts;
   size_t pt_rows_bytes = 0, pt_cnt_bytes = 0;
+  // Pass 2 is DEFERRED: pass 1 of several batches appends to the same routing regions (their fill counters live in
+  // PT.counts between launches) and one pass 2 aggregates them all -- its table-block load/store, its launch and its
+  // short-region tails are paid once per window instead of once per batch.  The window closes when the regions could
+  // overflow: pt_fill_bound is an upper bound of the largest region fill, from the control-block snapshots
+  // (CTRL_MAX_FILL, one batch behind) plus pt_worst rows for every batch launched since.
+  bool pt_layout_valid = false;
+  int64_t pt_layout_rows = 0;     // batch length the region layout was sized for
+  uint32_t pt_worst = 0;          // rows one batch of that length adds to a region in the expected worst case (2 x average + 64)
+  int pt_pending = 0;             // pass-1 launches waiting for their pass 2
+  uint64_t pt_fill_bound = 0;
+  int64_t pt_last_p2_seq = -1;    // batch_seq at the last pass-2 launch: older snapshots say nothing about the current fills
+  int64_t pt_rows_in_flight = 0;  // input rows of the pending launches (all of them may still end up in the spill list)
   int64_t rows_seen = 0;
   uint64_t occupied_known = 0;
   // control block checks run ONE BATCH BEHIND the launches: after batch i its control block is copied to
@@ -105,6 +117,7 @@ struct AggregateRelation::Impl {
   hipEvent_t main_ev[2] = {nullptr, nullptr};  // "batch i launched" markers on the main stream
   bool ctrl_pending[2] = {false, false};
   int64_t ctrl_rows[2] = {0, 0};
+  int64_t ctrl_seq[2] = {0, 0};             // batch_seq of the launch each snapshot follows
   int64_t batch_seq = 0;
   uint64_t unconfirmed_rows = 0;            // rows of launched batches whose control block is not examined yet
   // ungrouped state
@@ -116,11 +129,14 @@ struct AggregateRelation::Impl {
   Status alloc_table(int cap_log2, DevTable* T, std::vector<std::shared_ptr<void>>* owners, bool new_ctrl);
   Status ensure_spill(int64_t rows);
   Status ensure_partition(int64_t rows);
+  Status flush_pass2();
+  uint64_t program_fingerprint() const;
   Status grow_and_replay(uint64_t occupied, uint64_t spilled, uint64_t replay_from = 0);
   Status consume_batch(const DeviceBatch& b);
   Status launch_rows(const DeviceBatch& b, const DevProgram& prog, const DevColumns& cols, int64_t row0, int64_t n);
   Status drain();
-  Status emit_grouped(DeviceBatch* out);
+  Status emit_grouped(DeviceBatch* out, int64_t expected);
+  std::shared_ptr<void> emit_total;  // pinned: the scan's group count
   Status emit_ungrouped(DeviceBatch* out);
   Status read_ctrl(uint32_t* host_ctrl);
   Status post_ctrl(int64_t rows);
@@ -261,6 +277,28 @@ Status AggregateRelation::Impl::setup(const SchemaInfo& input_schema) {
   return Status::OK();
 }
 
+// what the calibration slice's outcome depends on: the fused program (predicate, key and argument expressions with
+// their literals), the input columns it binds and the plan's operands (FNV-1a over the bytes)
+uint64_t AggregateRelation::Impl::program_fingerprint() const {
+  uint64_t h = 0xCBF29CE484222325ull;
+  auto mix = [&](const void* p, size_t n) {
+    const uint8_t* b = (const uint8_t*)p;
+    for (size_t i = 0; i < n; ++i) h = (h ^ b[i]) * 0x100000001B3ull;
+  };
+  const DevProgram& P = builder->program();
+  mix(&P.n_ins, sizeof(P.n_ins));
+  mix(&P.n_cols, sizeof(P.n_cols));
+  mix(&P.n_imm, sizeof(P.n_imm));
+  mix(P.ins, sizeof(DevIns) * (size_t)std::max(0, std::min<int>(P.n_ins, kMaxRegs)));
+  mix(P.imm, sizeof(uint64_t) * (size_t)std::max(0, std::min<int>(P.n_imm, kMaxImm)));
+  mix(P.col_dtype, sizeof(P.col_dtype));
+  for (int ci : builder->columns()) mix(&ci, sizeof(ci));
+  mix(&plan.pred, 1);
+  mix(plan.key, sizeof(plan.key));
+  mix(&kw, sizeof(kw));
+  return h;
+}
+
 // ---- table management ------------------------------------------------------------------------------
 Status AggregateRelation::Impl::alloc_table(int cap_log2, DevTable* Tn, std::vector<std::shared_ptr<void>>* owners,
                                             bool new_ctrl) {
@@ -335,8 +373,12 @@ Status AggregateRelation::Impl::ensure_spill(int64_t rows) {
 
 // scratch for the partitioned strategy, sized for a batch of `rows` rows (worst case: all pass)
 Status AggregateRelation::Impl::ensure_partition(int64_t rows) {
-  memset(&PT, 0, sizeof(PT));
   const uint64_t S = (uint64_t)T.block_mask + 1;
+  if (pt_layout_valid && rows <= pt_layout_rows && PT.n_parts == (uint32_t)((T.mask + 1) / S) && PT.n_words == (uint32_t)(kw + na))
+    return Status::OK();  // same table, a batch the regions were sized for: keep appending
+  DFX_RETURN_IF_ERROR(flush_pass2());  // rows routed under the old layout
+  pt_layout_valid = false;
+  memset(&PT, 0, sizeof(PT));
   PT.n_parts = (uint32_t)((T.mask + 1) / S);
   PT.n_words = (uint32_t)(kw + na);
   int ps = 0;
@@ -372,8 +414,14 @@ Status AggregateRelation::Impl::ensure_partition(int64_t rows) {
     PT.n_producers = (uint32_t)std::min(1024, device_cu_count());
   }
   const uint64_t avg = (uint64_t)rows / ((uint64_t)PT.n_producers * PT.n_parts) + 1;
-  PT.cap_rows = (uint32_t)((2 * avg + 64 + 63) / 64 * 64);
-  if (o.partition_cap_rows > 0) PT.cap_rows = (uint32_t)((o.partition_cap_rows + 63) / 64 * 64);
+  pt_worst = (uint32_t)((2 * avg + 64 + 63) / 64 * 64);
+  const int window = std::max(1, std::min(o.partition_defer, 16));  // regions hold `window` worst-case batches
+  PT.cap_rows = pt_worst * (uint32_t)window;
+  if (o.partition_cap_rows > 0) {  // tests: tiny regions (overflow -> spill list); no deferral
+    PT.cap_rows = (uint32_t)((o.partition_cap_rows + 63) / 64 * 64);
+    pt_worst = PT.cap_rows;
+  }
+  if (o.pass2_stream && na == 1 && kw == 1) PT.flags |= PTF_STREAM_PASS2;
   PT.part_stride = (uint64_t)PT.n_producers * PT.cap_rows * PT.n_words + (uint64_t)(o.partition_pad >= 0 ? o.partition_pad : 0) / 8;
   const size_t row_bytes = sizeof(uint64_t) * (size_t)PT.n_parts * PT.part_stride;
   const size_t cnt_bytes = sizeof(uint32_t) * (size_t)PT.n_parts * PT.n_producers;
@@ -392,6 +440,22 @@ Status AggregateRelation::Impl::ensure_partition(int64_t rows) {
   }
   PT.rows = (uint64_t*)pt_rows.get();
   PT.counts = (uint32_t*)pt_counts.get();
+  pt_layout_valid = true;
+  pt_layout_rows = rows;
+  pt_pending = 0;
+  pt_fill_bound = 0;
+  pt_rows_in_flight = 0;
+  return Status::OK();
+}
+
+// pass 2 over everything the pending pass-1 launches routed (no-op when nothing is pending)
+Status AggregateRelation::Impl::flush_pass2() {
+  if (pt_pending == 0) return Status::OK();
+  DFX_HIP(launch_partition_agg(T, PT, spill, 0, ctx().stream));
+  pt_pending = 0;
+  pt_fill_bound = 0;
+  pt_rows_in_flight = 0;
+  pt_last_p2_seq = batch_seq;
   return Status::OK();
 }
 
@@ -427,6 +491,7 @@ Status AggregateRelation::Impl::post_ctrl(int64_t rows) {
   DFX_HIP(hipEventRecord(ctrl_ev[slot], aux));
   ctrl_pending[slot] = true;
   ctrl_rows[slot] = rows;
+  ctrl_seq[slot] = batch_seq;
   unconfirmed_rows += (uint64_t)rows;
   ++batch_seq;
   return Status::OK();
@@ -450,7 +515,9 @@ Status AggregateRelation::Impl::handle_ctrl(const uint32_t* hc, int64_t n) {
             (unsigned long long)passed_total,
             (unsigned long long)(T.mask + 1), PT.n_parts, PT.cap_rows, PT.stage_rows, (unsigned long long)spill.capacity);
   if (spilled > 0 || hc[CTRL_SATURATED] || occupied_known > T.load_limit) {
-    // later batches may already be running against the saturated table: let them finish, then rebuild
+    // later batches may already be running against the saturated table: let them finish, then rebuild.  Rows still
+    // waiting in the routing regions belong to the blocks of THIS table: aggregate them first.
+    DFX_RETURN_IF_ERROR(flush_pass2());
     uint32_t now[CTRL_WORDS];
     DFX_RETURN_IF_ERROR(read_ctrl(now));
     ctrl_pending[0] = ctrl_pending[1] = false;
@@ -494,6 +561,12 @@ Status AggregateRelation::Impl::examine_ctrl(int slot) {
   unconfirmed_rows -= std::min<uint64_t>(unconfirmed_rows, (uint64_t)ctrl_rows[slot]);
   uint32_t hc[CTRL_WORDS];
   memcpy(hc, (const uint32_t*)ctrl_host.get() + slot * CTRL_WORDS, sizeof(hc));
+  if (use_partition && ctrl_seq[slot] > pt_last_p2_seq) {
+    // the snapshot was taken after the launch with sequence number ctrl_seq[slot] (it may already show later launches:
+    // only larger); every launch since then adds at most pt_worst rows to a region
+    const uint64_t later = (uint64_t)std::max<int64_t>(0, batch_seq - 1 - ctrl_seq[slot]);
+    pt_fill_bound = std::min<uint64_t>(pt_fill_bound, (uint64_t)hc[CTRL_MAX_FILL] + later * pt_worst);
+  }
   return handle_ctrl(hc, ctrl_rows[slot]);
 }
 
@@ -542,6 +615,7 @@ Status AggregateRelation::Impl::grow_and_replay(uint64_t occupied, uint64_t spil
   DFX_HIP(hipMemcpyAsync(old_ctrl.get(), ctrl.get(), sizeof(uint32_t) * CTRL_WORDS, hipMemcpyDeviceToDevice, s));
   DFX_HIP(hipMemcpyAsync(ctrl.get(), host_ctrl, sizeof(uint32_t) * CTRL_WORDS, hipMemcpyHostToDevice, s));
   DFX_HIP(hipStreamSynchronize(s));  // host_ctrl is a stack buffer
+  pt_layout_valid = false;  // the routing regions are per table block
   DevTable Told = T;
   Told.ctrl = (uint32_t*)old_ctrl.get();
   DFX_HIP(launch_rehash(Told, Tn, no_spill, s));
@@ -568,15 +642,23 @@ Status AggregateRelation::Impl::launch_rows(const DeviceBatch& b, const DevProgr
   DevAggPlan p = plan;
   bool partition_now = use_partition;
   if (partition_now) {
-    Status pst = ensure_partition(n);
+    Status pst = ensure_partition(std::max<int64_t>(n, b.num_rows));  // (the slice after the calibration rows: size for the whole batch)
     if (!pst.ok() && pst.code == DFX_NOT_IMPLEMENTED) partition_now = false;  // global-atomic path instead
     else if (!pst.ok()) return pst;
   }
   if (partition_now) {
     DevFastPlan fpp = fast;
     if (!agg_options().fast) fpp.valid = 0;
-    DFX_HIP(launch_partition(prog, fpp, cols, p, T, PT, spill, n, bytes, s));
-    DFX_HIP(launch_partition_agg(T, PT, spill, 0, s));
+    DevPartition pt = PT;
+    if (pt_pending > 0) pt.flags |= PTF_RESUME;
+    DFX_HIP(launch_partition(prog, fpp, cols, p, T, pt, spill, n, bytes, s));
+    ++pt_pending;
+    pt_fill_bound += pt_worst;
+    pt_rows_in_flight += n;
+    // close the window when one more batch could overflow a region (or the batch budget is used up; the calibration
+    // slice is aggregated at once: the strategy decision reads the group count)
+    const int max_batches = std::max(1, agg_options().partition_defer_batches);
+    if (calibrating || pt_pending >= max_batches || pt_fill_bound + pt_worst > PT.cap_rows) DFX_RETURN_IF_ERROR(flush_pass2());
     return Status::OK();
   }
   DevFastPlan fp = fast;
@@ -697,10 +779,26 @@ Status AggregateRelation::Impl::consume_batch(const DeviceBatch& b) {
   const AggOptions& oo = agg_options();
   if (oo.strategy == 3 && kw == 1) use_partition = true;
   const bool may_spill = use_partition || occupied_known + unconfirmed_rows + (uint64_t)n > T.load_limit;
-  if (may_spill) DFX_RETURN_IF_ERROR(ensure_spill(2 * n + 65536));  // two batches can be in flight unchecked
+  // two batches can be in flight unchecked; with a deferred pass 2 every row of the window may still be spilled (by pass 2
+  // itself, when its block is full)
+  const int64_t window_rows = use_partition ? (int64_t)std::max(1, agg_options().partition_defer_batches) * std::max(n, pt_layout_rows) : 0;
+  if (may_spill) DFX_RETURN_IF_ERROR(ensure_spill(2 * n + window_rows + 65536));
   T.max_probe = may_spill ? 128 : (int)std::min<uint64_t>(T.mask + 1, 1u << 30);
   int64_t row0 = 0;
   const AggOptions& o = agg_options();
+  ScanMemo* memo = o.calibration_memo ? input->scan_memo() : nullptr;
+  uint64_t remembered = 0;
+  if (!lds_calibrated && o.strategy == 0 && n > (1 << 21) && memo && memo->lookup(program_fingerprint(), &remembered)) {
+    // an earlier query of this shape over the same resident table already ran the calibration slice: same decision,
+    // no slice, no synchronous read-back (the real group count arrives with the control-block snapshots as always)
+    occupied_known = remembered;
+    lds_calibrated = true;
+    lds_enabled = remembered <= 8192;
+    if (!lds_enabled && kw == 1 && remembered >= 16384) {
+      use_partition = true;
+      DFX_RETURN_IF_ERROR(ensure_spill(2 * n + (int64_t)std::max(1, agg_options().partition_defer_batches) * n + 65536));
+    }
+  }
   if (!lds_calibrated && o.strategy == 0 && n > (1 << 21)) {
     // calibration slice: measure the LDS front-cache hit rate and the group count on the first
     // 2^18 rows before committing the rest of the stream to a strategy
@@ -716,11 +814,12 @@ Status AggregateRelation::Impl::consume_batch(const DeviceBatch& b) {
     // atomics would cap the query near 24 G rows/s, so rows are routed to their table blocks
     // instead (dfx_k_partition.hip); in between, the global table alone.
     occupied_known = hc[CTRL_OCCUPIED];
+    if (memo) memo->remember(program_fingerprint(), occupied_known);
     lds_calibrated = true;
     lds_enabled = occupied_known <= 8192;
     if (!lds_enabled && kw == 1 && occupied_known >= 16384) {
       use_partition = true;
-      DFX_RETURN_IF_ERROR(ensure_spill(2 * n + 65536));
+      DFX_RETURN_IF_ERROR(ensure_spill(2 * n + (int64_t)std::max(1, agg_options().partition_defer_batches) * n + 65536));
     }
     row0 = n0;
   } else if (!lds_calibrated) {
@@ -934,7 +1033,13 @@ Status AggregateRelation::Impl::drain() {
     DFX_RETURN_IF_ERROR(read_ctrl(hc));
     if (hc[CTRL_ERROR]) return error_from_ctrl(hc[CTRL_ERROR]);
   } else {
+    DFX_RETURN_IF_ERROR(flush_pass2());
     DFX_RETURN_IF_ERROR(settle_ctrl());
+    if (use_partition) {  // the last pass 2 ran after the last snapshot: errors, spilled rows, growth
+      uint32_t hc[CTRL_WORDS];
+      DFX_RETURN_IF_ERROR(read_ctrl(hc));
+      DFX_RETURN_IF_ERROR(handle_ctrl(hc, 0));
+    }
   }
   built = true;
   return Status::OK();
@@ -985,7 +1090,7 @@ Status AggregateRelation::Impl::emit_ungrouped(DeviceBatch* out) {  // aggregate
   return Status::OK();
 }
 
-Status AggregateRelation::Impl::emit_grouped(DeviceBatch* out) {  // aggregate.rs:877-951
+Status AggregateRelation::Impl::emit_grouped(DeviceBatch* out, int64_t expected) {  // aggregate.rs:877-951
   hipStream_t s = ctx().stream;
   const int64_t n_slots = (int64_t)T.mask + 2;
   const int64_t n_words = (n_slots + 63) / 64;
@@ -1001,10 +1106,18 @@ Status AggregateRelation::Impl::emit_grouped(DeviceBatch* out) {  // aggregate.r
   if (!tmp) return st;
   DFX_HIP(launch_table_mask(T, (uint64_t*)mask.get(), (uint32_t*)counts.get(), s));
   DFX_HIP(launch_scan_u32((const uint32_t*)counts.get(), (uint64_t*)offsets.get(), n_tiles, (uint64_t*)tmp.get(), s));
-  uint64_t total = 0;
-  DFX_HIP(hipMemcpyAsync(&total, (uint64_t*)offsets.get() + n_tiles, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
-  DFX_HIP(hipStreamSynchronize(s));
-  const int64_t g = (int64_t)total;
+  // The group count is already on the host (CTRL_OCCUPIED of the last control-block check), so the compaction kernels
+  // are queued without waiting for the scan's total; the total comes back with the final synchronisation and must
+  // agree.  `expected < 0`: second attempt after a disagreement, with the scan's own count (one extra round trip).
+  if (!emit_total) {
+    emit_total = pinned_alloc(sizeof(uint64_t), &st);
+    if (!emit_total) return st;
+  }
+  uint64_t* total = (uint64_t*)emit_total.get();
+  *total = ~0ull;
+  DFX_HIP(hipMemcpyAsync(total, (uint64_t*)offsets.get() + n_tiles, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+  if (expected < 0) DFX_HIP(hipStreamSynchronize(s));
+  const int64_t g = expected < 0 ? (int64_t)*total : expected;
   out->num_rows = g;
   out->columns.clear();
   out->columns.resize((size_t)kw + outs.size());
@@ -1018,7 +1131,7 @@ Status AggregateRelation::Impl::emit_grouped(DeviceBatch* out) {  // aggregate.r
     DeviceColumn& c = out->columns[k];
     c.dtype = dt;
     c.length = g;
-    DFX_HIP(launch_compact(plane, 8, (const uint64_t*)mask.get(), (const uint64_t*)offsets.get(), n_slots, dense.get(), 0, s));
+    DFX_HIP(launch_compact(plane, 8, (const uint64_t*)mask.get(), (const uint64_t*)offsets.get(), n_slots, dense.get(), 0, s, (uint64_t)g));
     const DictKey* dk = nullptr;
     for (const DictKey& d : dicts)
       if (d.key == k) dk = &d;
@@ -1041,7 +1154,7 @@ Status AggregateRelation::Impl::emit_grouped(DeviceBatch* out) {  // aggregate.r
     auto vals = device_alloc((size_t)std::max<int64_t>(g, 1) * dtype_width(dt), &st);
     if (!vals) return st;
     DFX_HIP(launch_compact(T.accs + (size_t)a * T.stride, 8, (const uint64_t*)mask.get(), (const uint64_t*)offsets.get(), n_slots,
-                           dense.get(), 0, s));
+                           dense.get(), 0, s, (uint64_t)g));
     if (!outs[j].avg) {
       DFX_HIP(launch_finalize((const uint64_t*)dense.get(), g, (uint8_t)dt, val_xform[a], vals.get(), s));
     } else {  // SUM plane / COUNT plane (deviation D7); groups that counted nothing are null
@@ -1053,7 +1166,7 @@ Status AggregateRelation::Impl::emit_grouped(DeviceBatch* out) {  // aggregate.r
       if (!nulls) return st;
       DFX_HIP(hipMemsetAsync(nulls.get(), 0, sizeof(uint64_t), s));
       DFX_HIP(launch_compact(T.accs + (size_t)(a + 1) * T.stride, 8, (const uint64_t*)mask.get(), (const uint64_t*)offsets.get(),
-                             n_slots, dense_cnt.get(), 0, s));
+                             n_slots, dense_cnt.get(), 0, s, (uint64_t)g));
       DFX_HIP(launch_finalize_avg((const uint64_t*)dense.get(), (const uint64_t*)dense_cnt.get(), g, (uint8_t)dt, vals.get(),
                                   (uint64_t*)valid.get(), (uint64_t*)nulls.get(), s));
       uint64_t n_null = 0;
@@ -1069,6 +1182,10 @@ Status AggregateRelation::Impl::emit_grouped(DeviceBatch* out) {  // aggregate.r
     c.owners.push_back(vals);
   }
   DFX_HIP(hipStreamSynchronize(s));
+  if ((int64_t)*total != g) {
+    if (expected < 0) return Status::Err(DFX_INTERNAL_ERROR, "group count changed during emit");
+    return emit_grouped(out, -1);  // the host's count was stale: redo with the table's own
+  }
   return Status::OK();
 }
 
@@ -1190,7 +1307,7 @@ Status AggregateRelation::next(DeviceBatch* out, bool* has) {
     return Status::Err(DFX_INTERNAL_ERROR, "assertion failed: record batch needs at least one column");
   DFX_RETURN_IF_ERROR(m.drain());
   if (m.kw == 0) DFX_RETURN_IF_ERROR(m.emit_ungrouped(out));
-  else DFX_RETURN_IF_ERROR(m.emit_grouped(out));
+  else DFX_RETURN_IF_ERROR(m.emit_grouped(out, agg_options().emit_async ? (int64_t)m.occupied_known : -1));
   *has = true;
   return Status::OK();
 }

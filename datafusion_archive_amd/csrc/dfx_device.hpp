@@ -138,6 +138,7 @@ enum : int {
   CTRL_LDS_MISS = 7,
   CTRL_PASSED_LO = 8,   // rows that passed the predicate (64-bit)
   CTRL_PASSED_HI = 9,
+  CTRL_MAX_FILL = 10,   // partitioned strategy: largest region fill any producer has seen since the last pass 2 (which resets it)
   CTRL_WORDS = 16
 };
 
@@ -200,6 +201,11 @@ struct DevPartition {
   uint32_t stage_rows; // mode 1: rows of the pass-1 workgroup's LDS write-combining buffer
   uint32_t mode;       // pass 1: 0 direct routing (one 16-byte store per row), 1 LDS counting sort + coalesced copy-out
   uint32_t block;      // pass-1 workgroup size (mode 1: 512 or 1024)
+  uint32_t flags;      // PTF_*
+};
+enum : uint32_t {
+  PTF_RESUME = 1u,        // pass 1 appends to the regions as `counts` left them (pass 2 of earlier batches is still pending)
+  PTF_STREAM_PASS2 = 2u   // pass 2: region-streaming kernel (one aggregate, 16-byte rows)
 };
 
 // ---- Utf8 GROUP BY keys: device string dictionary (dfx_k_dict.hip) ---------------------------------

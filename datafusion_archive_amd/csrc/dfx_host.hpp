@@ -155,6 +155,29 @@ struct Relation {
   // One line per operator, children indented below (dfx_relation_explain): what was fused, which kernel family a
   // program will run on.  Host state only -- never touches the device, so it also works without one.
   virtual void explain(std::string* out, int depth) const;
+  // What earlier queries learned about this input and may reuse (null: nothing is remembered).  A resident table keeps
+  // the number of groups an aggregate's calibration slice produced, keyed by a fingerprint of the fused program, so that
+  // the second query of the same shape does not pay for the slice and its synchronous read-back again.
+  virtual struct ScanMemo* scan_memo() { return nullptr; }
+};
+struct ScanMemo {
+  std::vector<std::pair<uint64_t, uint64_t>> calibrated_groups;  // (program fingerprint, groups in the first 2^18 rows)
+  bool lookup(uint64_t fp, uint64_t* groups) const {
+    for (const auto& e : calibrated_groups)
+      if (e.first == fp) {
+        *groups = e.second;
+        return true;
+      }
+    return false;
+  }
+  void remember(uint64_t fp, uint64_t groups) {
+    for (auto& e : calibrated_groups)
+      if (e.first == fp) {
+        e.second = groups;
+        return;
+      }
+    if (calibrated_groups.size() < 64) calibrated_groups.emplace_back(fp, groups);
+  }
 };
 // "<indent><text>\n"
 void explain_line(std::string* out, int depth, const std::string& text);

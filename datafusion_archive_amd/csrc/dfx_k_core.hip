@@ -171,7 +171,7 @@ template <typename T>
 __global__ __launch_bounds__(kBlock) void k_compact(const T* __restrict__ in,
                                                     const uint64_t* __restrict__ mask_words,
                                                     const uint64_t* __restrict__ tile_offsets,
-                                                    const int64_t n, T* __restrict__ out) {
+                                                    const int64_t n, T* __restrict__ out, const uint64_t out_limit) {
   __shared__ uint32_t word_off[64];
   const int lane = lane_id();
   const int wave = threadIdx.x >> 6;
@@ -195,7 +195,8 @@ __global__ __launch_bounds__(kBlock) void k_compact(const T* __restrict__ in,
         const int64_t row = w * 64 + lane;
         if ((word >> lane) & 1) {
           const uint32_t rank = (uint32_t)__popcll(word & ((1ull << lane) - 1ull));
-          out[tile_base + word_off[wi] + rank] = in[row];
+          const uint64_t at = tile_base + word_off[wi] + rank;
+          if (at < out_limit) out[at] = in[row];  // (emit sizes `out` from the host's group count before the scan's total is back)
         }
       }
     }
@@ -619,16 +620,16 @@ hipError_t launch_scan_i32(const int32_t* in, int32_t* out, int64_t n, uint64_t*
 }
 
 hipError_t launch_compact(const void* in, int width, const uint64_t* mask_words, const uint64_t* tile_offsets,
-                          int64_t n, void* out, double algo_bytes, hipStream_t s) {
+                          int64_t n, void* out, double algo_bytes, hipStream_t s, uint64_t out_limit) {
   if (n <= 0) return hipSuccess;
   Scope sc(KID_COMPACT, s, algo_bytes);
   const int64_t tiles = (n + kTileRows - 1) / kTileRows;
   const int grid = stream_grid(tiles, 8);
   switch (width) {
-    case 8: hipLaunchKernelGGL(k_compact<uint64_t>, dim3(grid), dim3(kBlock), 0, s, (const uint64_t*)in, mask_words, tile_offsets, n, (uint64_t*)out); break;
-    case 4: hipLaunchKernelGGL(k_compact<uint32_t>, dim3(grid), dim3(kBlock), 0, s, (const uint32_t*)in, mask_words, tile_offsets, n, (uint32_t*)out); break;
-    case 2: hipLaunchKernelGGL(k_compact<uint16_t>, dim3(grid), dim3(kBlock), 0, s, (const uint16_t*)in, mask_words, tile_offsets, n, (uint16_t*)out); break;
-    case 1: hipLaunchKernelGGL(k_compact<uint8_t>, dim3(grid), dim3(kBlock), 0, s, (const uint8_t*)in, mask_words, tile_offsets, n, (uint8_t*)out); break;
+    case 8: hipLaunchKernelGGL(k_compact<uint64_t>, dim3(grid), dim3(kBlock), 0, s, (const uint64_t*)in, mask_words, tile_offsets, n, (uint64_t*)out, out_limit); break;
+    case 4: hipLaunchKernelGGL(k_compact<uint32_t>, dim3(grid), dim3(kBlock), 0, s, (const uint32_t*)in, mask_words, tile_offsets, n, (uint32_t*)out, out_limit); break;
+    case 2: hipLaunchKernelGGL(k_compact<uint16_t>, dim3(grid), dim3(kBlock), 0, s, (const uint16_t*)in, mask_words, tile_offsets, n, (uint16_t*)out, out_limit); break;
+    case 1: hipLaunchKernelGGL(k_compact<uint8_t>, dim3(grid), dim3(kBlock), 0, s, (const uint8_t*)in, mask_words, tile_offsets, n, (uint8_t*)out, out_limit); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

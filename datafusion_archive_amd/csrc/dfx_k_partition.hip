@@ -163,6 +163,7 @@ __global__ __launch_bounds__(kABlock) void k_partition_agg(const DevTable T, con
 #endif
         typedef uint64_t u64x2_t __attribute__((ext_vector_type(2)));
         const u64x2_t kv = __builtin_nontemporal_load((const u64x2_t*)src);
+        ib[r] = ib[r] && kv.x != kEmptyKey;  // padding rows (pass 1 rounds every region up to whole chunks)
         k[r][0] = ib[r] ? kv.x : 0ull;
         v[r][0] = ib[r] ? kv.y : 0ull;
       } else if (ib[r]) {
@@ -180,6 +181,7 @@ __global__ __launch_bounds__(kABlock) void k_partition_agg(const DevTable T, con
 #pragma unroll
           for (int a = 0; a < NV; ++a)
             if (a < T.na) v[r][a] = src[1 + a];
+          if (k[r][0] == kEmptyKey) ib[r] = false;  // padding row
         }
       }
     }
@@ -299,6 +301,7 @@ __global__ __launch_bounds__(kABlock) void k_partition_agg(const DevTable T, con
 #pragma unroll
   for (int mm = 32; mm >= 1; mm >>= 1) new_keys += __shfl_xor(new_keys, mm, 64);
   if (lane == 0 && new_keys) atomicAdd(&T.ctrl[CTRL_OCCUPIED], new_keys);
+  if (p == 0 && threadIdx.x == 0) __hip_atomic_store(&T.ctrl[CTRL_MAX_FILL], 0u, RLX_AGENT);  // the regions are empty again
 #ifdef DFX_PA_TIMING
   if ((threadIdx.x == 0 || threadIdx.x == 1023) && (p == 0 || p == 100 || p == 255))
     printf("PA p=%u t=%u total=%u: load %lld prefix %lld loop %lld barrier %lld store %lld (100MHz ticks)\n", p, threadIdx.x, total,
@@ -311,6 +314,148 @@ __global__ __launch_bounds__(kABlock) void k_partition_agg(const DevTable T, con
            (hwid >> 8) & 15u, (hwid >> 13) & 7u);
   }
 #endif
+}
+
+// ---- pass 2, streaming form --------------------------------------------------------------------------------
+// The kernel above finds the producer region of every flattened row index per lane (float interpolation + LDS
+// prefix reads + 64-bit address arithmetic: ~130 VALU instructions per 64 rows, VALU-issue bound at ~0.4 rows per
+// cycle and CU).  Here a WAVE walks whole regions: wave w owns the regions of producers w, w + 16, ... (their row
+// counts sit in one VGPR, lane j = producer w + 16 j, read back with v_readlane), so the row address is a scalar base
+// plus lane * 16 and the per-row VALU work is the hash, the 4-slot group compare and the LDS atomic.  kPF trips of
+// row loads are in flight per wave (16 waves x kPF KB per CU): with 20 % of 2^26 rows routed the kernel has to read
+// back 0.2 GB in a few tens of microseconds, i.e. it is HBM-latency bound unless the loads run far ahead.
+// Rows whose key is kEmptyKey are padding (pass 1 rounds every region up to whole chunks) and are skipped.
+constexpr int kPF = 4;
+
+DEV int pa2_lookup(uint64_t* lkeys, uint32_t S, uint32_t slot, uint64_t kk, uint32_t& new_keys) {
+  int found = -1;
+  uint32_t g = slot >> 2;
+  for (uint32_t it = 0; it <= (S >> 2) && found < 0;) {
+    const ulonglong2 ka = *(const ulonglong2*)&lkeys[g * 4];
+    const ulonglong2 kb = *(const ulonglong2*)&lkeys[g * 4 + 2];
+    const uint32_t mm = (ka.x == kk ? 1u : 0u) | (ka.y == kk ? 2u : 0u) | (kb.x == kk ? 4u : 0u) | (kb.y == kk ? 8u : 0u);
+    if (mm) {
+      found = (int)(g * 4 + (uint32_t)__ffs((int)mm) - 1u);
+      break;
+    }
+    const uint32_t em = (ka.x == kEmptyKey ? 1u : 0u) | (ka.y == kEmptyKey ? 2u : 0u) | (kb.x == kEmptyKey ? 4u : 0u) |
+                        (kb.y == kEmptyKey ? 8u : 0u);
+    if (em) {
+      const uint32_t at = g * 4 + (uint32_t)__ffs((int)em) - 1u;
+      const uint64_t old = atomicCAS((unsigned long long*)&lkeys[at], (unsigned long long)kEmptyKey, (unsigned long long)kk);
+      if (old == kEmptyKey) {
+        found = (int)at;
+        ++new_keys;
+      } else if (old == kk) {
+        found = (int)at;
+      }  // else: another key claimed it meanwhile -- look at the same group again
+    } else {
+      g = (g + 1) & ((S >> 2) - 1);
+      ++it;
+    }
+  }
+  return found;
+}
+
+__global__ __launch_bounds__(kABlock) void k_partition_agg_stream(const DevTable T, const DevPartition PT, const DevRows spill) {
+  extern __shared__ __attribute__((aligned(16))) uint64_t lds[];
+  typedef uint64_t u64x2_t __attribute__((ext_vector_type(2)));
+  const uint32_t S = T.block_mask + 1;
+  uint64_t* lkeys = lds;
+  uint64_t* laccs = lds + S;
+  const uint32_t p = blockIdx.x;
+  const uint64_t slot0 = (uint64_t)p * S;
+  const int lane = lane_id();
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const uint32_t NP = PT.n_producers;
+  // this wave's regions: producer wave + 16 j lives in lane j
+  const uint32_t my_prod = wave + (uint32_t)(kABlock / 64) * (uint32_t)lane;
+  const uint32_t v_cnt = my_prod < NP ? PT.counts[(uint64_t)p * NP + my_prod] : 0u;
+  // table block -> LDS (16-byte loads, four in flight per lane)
+#pragma unroll
+  for (int w = 0; w < 2; ++w) {
+    const uint64_t* src = (w == 0 ? T.keys : T.accs) + slot0;
+    uint64_t* dst = lds + (size_t)w * S;
+    for (uint32_t i0 = threadIdx.x * 2; i0 < S; i0 += kABlock * 2 * 4) {
+      const uint32_t ia = i0, ib = i0 + kABlock * 2, ic = i0 + kABlock * 4, id = i0 + kABlock * 6;
+      const ulonglong2 ta = *(const ulonglong2*)(src + (ia < S ? ia : 0));
+      const ulonglong2 tb = *(const ulonglong2*)(src + (ib < S ? ib : 0));
+      const ulonglong2 tc = *(const ulonglong2*)(src + (ic < S ? ic : 0));
+      const ulonglong2 td = *(const ulonglong2*)(src + (id < S ? id : 0));
+      if (ia < S) *(ulonglong2*)(dst + ia) = ta;
+      if (ib < S) *(ulonglong2*)(dst + ib) = tb;
+      if (ic < S) *(ulonglong2*)(dst + ic) = tc;
+      if (id < S) *(ulonglong2*)(dst + id) = td;
+    }
+  }
+  const uint64_t* const part_rows = PT.rows + (uint64_t)p * PT.part_stride;
+  const uint64_t region_words = (uint64_t)PT.cap_rows * 2u;
+  // wave-uniform cursor over (region ordinal j, row offset i0)
+  uint32_t s_j = 0, s_i0 = 0;
+  uint32_t s_cnt = (uint32_t)__builtin_amdgcn_readlane((int)v_cnt, 0);
+  const uint32_t n_mine = (NP + (uint32_t)(kABlock / 64) - 1u - wave) / (uint32_t)(kABlock / 64);  // regions of this wave
+  auto fetch = [&](u64x2_t& kv, bool& act) {
+    while (s_i0 >= s_cnt && s_j < n_mine) {  // scalar loop: next non-empty region
+      ++s_j;
+      s_i0 = 0;
+      s_cnt = s_j < n_mine ? (uint32_t)__builtin_amdgcn_readlane((int)v_cnt, (int)(s_j & 63u)) : 0u;
+    }
+    const bool live = s_j < n_mine;
+    act = live && s_i0 + (uint32_t)lane < s_cnt;
+    const uint64_t* base = part_rows + (uint64_t)(wave + (uint32_t)(kABlock / 64) * (live ? s_j : 0u)) * region_words + (uint64_t)(live ? s_i0 : 0u) * 2u;
+    // unconditional load (idle lanes re-read the region's first row): the compiler can count the loads in flight
+    kv = __builtin_nontemporal_load((const u64x2_t*)(base + (act ? (uint32_t)lane * 2u : 0u)));
+    s_i0 += 64;
+  };
+  u64x2_t kv[kPF];
+  bool act[kPF];
+#pragma unroll
+  for (int d = 0; d < kPF; ++d) fetch(kv[d], act[d]);
+  __syncthreads();  // the block is in LDS
+  uint32_t new_keys = 0;
+  const uint8_t kind = T.acc_kind[0];
+  bool more = true;
+  while (more) {
+#pragma unroll
+    for (int d = 0; d < kPF; ++d) {
+      const u64x2_t cur = kv[d];
+      const bool a = act[d];
+      if (__ballot(a) == 0) {  // wave-uniform: the cursor is exhausted (trips are handed out in order)
+        more = false;
+        break;
+      }
+      fetch(kv[d], act[d]);
+      uint64_t key[1] = {cur.x};
+      const bool have = a && cur.x != kEmptyKey;  // padding rows
+      bool todo = have;
+      if (have) {
+        const uint64_t h = hash_keys<1>(key);
+        const uint32_t slot = (uint32_t)((h >> T.shift) & T.mask) & T.block_mask;
+        const int found = pa2_lookup(lkeys, S, slot, cur.x, new_keys);
+        if (found >= 0) {
+          acc_atomic(kind, &laccs[found], cur.y);
+          todo = false;
+        }
+      }
+      if (__ballot(todo) != 0) {  // block full: grow-and-replay takes the row
+        uint64_t sv[kMaxAggs];
+#pragma unroll
+        for (int q = 0; q < kMaxAggs; ++q) sv[q] = q == 0 ? cur.y : 0ull;
+        spill_row<1>(T, spill, todo, key, sv);
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int w = 0; w < 2; ++w) {
+    uint64_t* dst = (w == 0 ? T.keys : T.accs) + slot0;
+    const uint64_t* src = lds + (size_t)w * S;
+    for (uint32_t i = threadIdx.x * 2; i < S; i += kABlock * 2) *(ulonglong2*)(dst + i) = *(const ulonglong2*)(src + i);
+  }
+#pragma unroll
+  for (int mm = 32; mm >= 1; mm >>= 1) new_keys += __shfl_xor(new_keys, mm, 64);
+  if (lane == 0 && new_keys) atomicAdd(&T.ctrl[CTRL_OCCUPIED], new_keys);
+  if (p == 0 && threadIdx.x == 0) __hip_atomic_store(&T.ctrl[CTRL_MAX_FILL], 0u, RLX_AGENT);  // the regions are empty again
 }
 
 size_t partition_stage_bytes(const DevPartition& PT) {
@@ -373,7 +518,9 @@ hipError_t launch_partition_agg(const DevTable& T, const DevPartition& PT, const
   lds_bytes += 16 + (size_t)(kABlock / 64) * 128 * 4;  // per-wave queues of parked rows
 #endif
   if (lds_bytes > 160 * 1024 - 256 || PT.n_producers > 1024) return hipErrorInvalidValue;
-  if (T.na == 1) hipLaunchKernelGGL(k_partition_agg<1>, dim3(PT.n_parts), dim3(kABlock), lds_bytes, s, T, PT, spill);
+  if (T.na == 1 && (PT.flags & PTF_STREAM_PASS2) && PT.n_words == 2)
+    hipLaunchKernelGGL(k_partition_agg_stream, dim3(PT.n_parts), dim3(kABlock), (size_t)(T.block_mask + 1) * 16, s, T, PT, spill);
+  else if (T.na == 1) hipLaunchKernelGGL(k_partition_agg<1>, dim3(PT.n_parts), dim3(kABlock), lds_bytes, s, T, PT, spill);
   else hipLaunchKernelGGL(k_partition_agg<0>, dim3(PT.n_parts), dim3(kABlock), lds_bytes, s, T, PT, spill);
   return hipGetLastError();
 }

@@ -39,6 +39,23 @@ DEV uint32_t partition_of(const DevTable& T, const DevPartition& PT, uint64_t h)
   return (uint32_t)(((h >> T.shift) & T.mask) >> PT.part_shift);
 }
 
+// largest region fill of this launch -> T.ctrl[CTRL_MAX_FILL] (the host decides from it when pass 2 has to run).  One
+// candidate per workgroup, and only if it beats what is already there: same-address agent atomics serialise at
+// ~11 ns each, a thousand of them at the end of every launch would be 5 % of pass 1.
+DEV void publish_max_fill(const DevTable& T, uint32_t max_fill) {
+  __shared__ uint32_t wg_max_fill;
+  if (threadIdx.x == 0) wg_max_fill = 0;
+  __syncthreads();
+#pragma unroll
+  for (int mm = 32; mm >= 1; mm >>= 1) {
+    const uint32_t o = (uint32_t)__shfl_xor((int)max_fill, mm, 64);
+    max_fill = o > max_fill ? o : max_fill;
+  }
+  if (lane_id() == 0 && max_fill != 0) atomicMax(&wg_max_fill, max_fill);
+  __syncthreads();
+  if (threadIdx.x == 0 && wg_max_fill > __hip_atomic_load(&T.ctrl[CTRL_MAX_FILL], RLX_AGENT)) atomicMax(&T.ctrl[CTRL_MAX_FILL], wg_max_fill);
+}
+
 // pass 1.  No staging: a passing row is routed straight from registers.  Its position inside the
 // (producer, partition) region comes from an LDS atomic on the workgroup's per-partition fill
 // counter; the U row-groups of a trip issue their LDS atomics back to back, then their 16-byte row
@@ -55,9 +72,10 @@ __global__ __launch_bounds__(kPBlock) void k_partition(const DevProgram P, const
   const int lane = lane_id();
   const int wave = threadIdx.x >> 6;
   const int NW = (int)PT.n_words;
-  for (uint32_t p = threadIdx.x; p < PT.n_parts; p += kPBlock) fill[p] = 0;
-  __syncthreads();
   const uint32_t producer = blockIdx.x;
+  for (uint32_t p = threadIdx.x; p < PT.n_parts; p += kPBlock)
+    fill[p] = (PT.flags & PTF_RESUME) ? PT.counts[(uint64_t)p * PT.n_producers + producer] : 0u;
+  __syncthreads();
   const int64_t n_groups = (n + 63) >> 6;
   const int64_t wave_global = (int64_t)blockIdx.x * (kPBlock / 64) + wave;
   const int64_t n_waves = (int64_t)gridDim.x * (kPBlock / 64);
@@ -121,10 +139,13 @@ __global__ __launch_bounds__(kPBlock) void k_partition(const DevProgram P, const
     }
   }
   __syncthreads();
+  uint32_t max_fill = 0;
   for (uint32_t p = threadIdx.x; p < PT.n_parts; p += kPBlock) {
-    const uint32_t f = fill[p];
-    PT.counts[(uint64_t)p * PT.n_producers + producer] = f < PT.cap_rows ? f : PT.cap_rows;
+    const uint32_t f = fill[p] < PT.cap_rows ? fill[p] : PT.cap_rows;
+    PT.counts[(uint64_t)p * PT.n_producers + producer] = f;
+    max_fill = f > max_fill ? f : max_fill;
   }
+  publish_max_fill(T, max_fill);
 #pragma unroll
   for (int mm = 32; mm >= 1; mm >>= 1) passed += shfl_xor_u64(passed, mm);
   if (lane == 0) stat_add(T, STAT_PASSED, passed);
@@ -286,13 +307,13 @@ __global__ __launch_bounds__(BLOCK) void k_partition_sorted(const DevProgram P, 
   const int lane = lane_id();
   const int wave = threadIdx.x >> 6;
   const int na = POL::na(T);
+  const uint32_t producer = blockIdx.x;
   for (uint32_t p = threadIdx.x; p < PT.n_parts; p += BLOCK) {
     L.hist[p] = 0;
-    L.fill[p] = 0;
+    L.fill[p] = (PT.flags & PTF_RESUME) ? PT.counts[(uint64_t)p * PT.n_producers + producer] : 0u;
   }
   if (threadIdx.x < 2 + NWAVES) L.misc[threadIdx.x] = 0;
   __syncthreads();
-  const uint32_t producer = blockIdx.x;
   const int64_t n_groups = (n + 63) >> 6;
   const int64_t wave_global = (int64_t)blockIdx.x * NWAVES + wave;
   const int64_t n_waves = (int64_t)gridDim.x * NWAVES;
@@ -365,10 +386,13 @@ __global__ __launch_bounds__(BLOCK) void k_partition_sorted(const DevProgram P, 
   if (lane == 0) atomicAdd(&L.misc[1], 1u);
   while (!partition_flush<BLOCK>(T, PT, spill, L, producer, na)) {
   }
+  uint32_t max_fill = 0;
   for (uint32_t p = threadIdx.x; p < PT.n_parts; p += BLOCK) {
-    const uint32_t f = L.fill[p];
-    PT.counts[(uint64_t)p * PT.n_producers + producer] = f < PT.cap_rows ? f : PT.cap_rows;
+    const uint32_t f = L.fill[p] < PT.cap_rows ? L.fill[p] : PT.cap_rows;
+    PT.counts[(uint64_t)p * PT.n_producers + producer] = f;
+    max_fill = f > max_fill ? f : max_fill;
   }
+  publish_max_fill(T, max_fill);
 #pragma unroll
   for (int mm = 32; mm >= 1; mm >>= 1) passed += shfl_xor_u64(passed, mm);
   if (lane == 0) stat_add(T, STAT_PASSED, passed);
@@ -512,9 +536,21 @@ __global__ __launch_bounds__(kRingBlock) void k_partition_ring(const DevProgram 
   const int lane = lane_id();
   const int wave = threadIdx.x >> 6;
   const int na = POL::na(T);
-  for (uint32_t p = threadIdx.x; p < PT.n_parts * (1 + 2 * 4); p += kRingBlock) L.fill[p] = 0;  // fill, commit, gen
-  __syncthreads();
   const uint32_t producer = blockIdx.x;
+  // fill, commit, gen.  PTF_RESUME: pass 2 of the earlier batches is still pending and this producer's regions already
+  // hold counts[] rows -- a whole number of chunks, the epilogue below pads -- so chunk numbering goes on from there:
+  // ring slot sl first serves the lowest chunk >= c0 that maps to it
+  for (uint32_t p = threadIdx.x; p < PT.n_parts; p += kRingBlock) {
+    const uint32_t f0 = (PT.flags & PTF_RESUME) ? PT.counts[(uint64_t)p * PT.n_producers + producer] : 0u;
+    const uint32_t c0 = f0 / kRingCH;
+    L.fill[p] = f0;
+#pragma unroll
+    for (int sl = 0; sl < kRingNCH; ++sl) {
+      L.commit[p * kRingNCH + sl] = 0;
+      L.gen[p * kRingNCH + sl] = (c0 + (uint32_t)(kRingNCH - 1 - sl)) / (uint32_t)kRingNCH;
+    }
+  }
+  __syncthreads();
   uint64_t* q = L.queue + (size_t)wave * kRingQ * NW;  // word-major planes [NW][kRingQ]
   uint32_t qn = 0;                                     // queued rows (wave-uniform)
   const int64_t n_groups = (n + 63) >> 6;
@@ -620,18 +656,32 @@ __global__ __launch_bounds__(kRingBlock) void k_partition_ring(const DevProgram 
     if (qn != 0) ring_route<NV, kRingCH, kRingRP>(T, PT, spill, L, producer, na, have, k2, v2, err);
   }
   __syncthreads();
-  // partial chunks + region counts
+  // partial chunks + region counts.  A partial chunk is padded to a whole one with rows whose key is kEmptyKey (pass 2
+  // skips them; a real row never carries that key, it lives in slot `cap`), so that a later launch can go on appending
+  // at a chunk boundary (PTF_RESUME).  cap_rows is a multiple of 64, so the padding never leaves the region.
+  uint32_t max_fill = 0;
   for (uint32_t p = threadIdx.x; p < PT.n_parts; p += kRingBlock) {
     uint32_t f = L.fill[p];
     if (f > PT.cap_rows) f = PT.cap_rows;
     const uint32_t c = f / kRingCH;
-    for (uint32_t r = 0; r < f % kRingCH; ++r) {
+    const uint32_t rem = f % kRingCH;
+    for (uint32_t r = 0; r < rem; ++r) {
       const uint64_t* src = L.ring + ((size_t)p * kRingRP + (c % kRingNCH) * kRingCH + r) * NW;
       uint64_t* out = region_row(PT, p, producer, c * kRingCH + r);
       for (int w = 0; w < NW; ++w) out[w] = src[w];
     }
+    if (rem != 0) {
+      for (uint32_t r = rem; r < (uint32_t)kRingCH; ++r) {
+        uint64_t* out = region_row(PT, p, producer, c * kRingCH + r);
+        out[0] = kEmptyKey;
+        for (int w = 1; w < NW; ++w) out[w] = 0;
+      }
+      f = (c + 1) * kRingCH;
+    }
     PT.counts[(uint64_t)p * PT.n_producers + producer] = f;
+    max_fill = f > max_fill ? f : max_fill;
   }
+  publish_max_fill(T, max_fill);
 #pragma unroll
   for (int mm = 32; mm >= 1; mm >>= 1) passed += shfl_xor_u64(passed, mm);
   if (lane == 0) stat_add(T, STAT_PASSED, passed);

@@ -59,7 +59,7 @@ hipError_t launch_scan_i32(const int32_t* in, int32_t* out, int64_t n, uint64_t*
 //   replaces fn filter (filter.rs:79-110).  width in {1,2,4,8} bytes.
 hipError_t launch_compact(const void* in, int width, const uint64_t* mask_words,
                           const uint64_t* tile_offsets, int64_t n, void* out, double algo_bytes,
-                          hipStream_t s);
+                          hipStream_t s, uint64_t out_limit = ~0ull);
 // Utf8 support for K4: lengths from offsets, byte gather
 hipError_t launch_utf8_lengths(const int32_t* offsets, int64_t n, int32_t* lengths, int32_t* starts, hipStream_t s);
 hipError_t launch_utf8_gather(const uint8_t* data, const int32_t* src_starts, const int32_t* dst_offsets,

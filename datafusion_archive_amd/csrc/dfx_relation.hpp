@@ -24,6 +24,7 @@ struct TableData {
   SchemaInfo schema;
   int64_t num_rows = 0;
   std::vector<DeviceColumn> columns;  // whole-table columns
+  mutable ScanMemo memo;              // Relation::scan_memo()
 };
 class TableScanRelation : public Relation {
  public:
@@ -32,6 +33,7 @@ class TableScanRelation : public Relation {
   Status next(DeviceBatch* out, bool* has) override;
   const SchemaInfo& schema() const override { return table_->schema; }
   void explain(std::string* out, int depth) const override;
+  ScanMemo* scan_memo() override { return &table_->memo; }  // every scan starts at row 0
 
  private:
   std::shared_ptr<const TableData> table_;
@@ -105,6 +107,11 @@ struct AggOptions {
   int partition_cap_rows = 0;  // rows per (producer, partition) region; 0: sized from the batch
   int partition_pad = 0;       // bytes of padding between partitions in the routing scratch
   int partition_block = 1024;  // pass-1 workgroup size in mode 1 (512: two workgroups per CU)
+  int partition_defer = 4;     // routing regions hold this many worst-case batches (1: pass 2 after every batch)
+  int partition_defer_batches = 8;  // at most this many pass-1 launches share one pass 2
+  int emit_async = 1;          // 1: emit queues its compaction kernels with the host's group count and checks the table's afterwards
+  int calibration_memo = 1;    // 1: a resident table remembers the outcome of an aggregate's calibration slice per program shape
+  int pass2_stream = 1;        // pass 2 of one-aggregate queries: region-streaming kernel (0: the flattened-index kernel)
   int fewgroup = 1;            // <= 8 groups after calibration: register accumulators (dfx_k_fewgroup.hip); 0: LDS front cache
   int replay_in_place = 0;     // 1: rows spilled by a table that is NOT full (region overflow of a hot key) are replayed into the
                                // table as it is, and only what it cannot take makes it grow.  EXPERIMENTAL: written without a GPU
