@@ -92,6 +92,7 @@ struct AggregateRelation::Impl {
   bool lds_calibrated = false;
   bool calibrating = false;     // the launch in progress is the calibration slice
   bool use_partition = false;   // strategy 3: route rows to table blocks, aggregate blocks in LDS
+  bool skew_seen = false;       // the calibration slice's front cache absorbed a sizeable share of its rows: heavy keys
   DevPartition PT;
   std::shared_ptr<void> pt_rows, pt_counts;
   size_t pt_rows_bytes = 0, pt_cnt_bytes = 0;
@@ -397,10 +398,14 @@ Status AggregateRelation::Impl::ensure_partition(int64_t rows) {
   const uint32_t sort_cap = partition_sort_capacity(PT.n_words, PT.n_parts, block, budget);
   const int want = o.partition_mode & 15;
   if (want == 2 && partition_ring_bytes(PT.n_words, PT.n_parts, 16) <= (size_t)158 * 1024) {
+    const bool hot = o.hot_keys > 0 || (o.hot_keys < 0 && skew_seen);
+    if (hot && na == 1 && !((uint32_t)o.partition_mode & 0x80u) && partition_ring_bytes(PT.n_words, PT.n_parts, 16, true) <= (size_t)158 * 1024)
+      PT.flags |= PTF_HOT;
     PT.mode = 2u | ((uint32_t)o.partition_mode & ~15u);
     PT.block = 1024;
     PT.stage_rows = 0;
     PT.n_producers = (uint32_t)std::min(1024, device_cu_count());
+    if (o.partition_producers > 0) PT.n_producers = (uint32_t)std::min(1024, o.partition_producers);
   } else if (want != 0 && PT.n_parts <= 1024 && sort_cap >= 4 * PT.n_parts) {
     PT.mode = 1u | ((uint32_t)o.partition_mode & ~15u);
     PT.block = block;
@@ -422,8 +427,17 @@ Status AggregateRelation::Impl::ensure_partition(int64_t rows) {
     pt_worst = PT.cap_rows;
   }
   if (o.pass2_stream && na == 1 && kw == 1) PT.flags |= PTF_STREAM_PASS2;
-  PT.part_stride = (uint64_t)PT.n_producers * PT.cap_rows * PT.n_words + (uint64_t)(o.partition_pad >= 0 ? o.partition_pad : 0) / 8;
-  const size_t row_bytes = sizeof(uint64_t) * (size_t)PT.n_parts * PT.part_stride;
+  const uint64_t pad_words = (uint64_t)(o.partition_pad >= 0 ? o.partition_pad : 0) / 8;
+  size_t row_bytes;
+  if (o.partition_layout == 0) {  // partition-major (round 1)
+    PT.prod_stride = (uint64_t)PT.cap_rows * PT.n_words;
+    PT.part_stride = (uint64_t)PT.n_producers * PT.prod_stride + pad_words;
+    row_bytes = sizeof(uint64_t) * (size_t)PT.n_parts * PT.part_stride;
+  } else {  // producer-major
+    PT.part_stride = (uint64_t)PT.cap_rows * PT.n_words;
+    PT.prod_stride = (uint64_t)PT.n_parts * PT.part_stride + pad_words;
+    row_bytes = sizeof(uint64_t) * (size_t)PT.n_producers * PT.prod_stride;
+  }
   const size_t cnt_bytes = sizeof(uint32_t) * (size_t)PT.n_parts * PT.n_producers;
   Status st;
   if (!pt_rows || pt_rows_bytes < row_bytes) {
@@ -791,6 +805,8 @@ Status AggregateRelation::Impl::consume_batch(const DeviceBatch& b) {
   if (!lds_calibrated && o.strategy == 0 && n > (1 << 21) && memo && memo->lookup(program_fingerprint(), &remembered)) {
     // an earlier query of this shape over the same resident table already ran the calibration slice: same decision,
     // no slice, no synchronous read-back (the real group count arrives with the control-block snapshots as always)
+    skew_seen = (remembered >> 63) != 0;
+    remembered &= ~(1ull << 63);
     occupied_known = remembered;
     lds_calibrated = true;
     lds_enabled = remembered <= 8192;
@@ -814,7 +830,18 @@ Status AggregateRelation::Impl::consume_batch(const DeviceBatch& b) {
     // atomics would cap the query near 24 G rows/s, so rows are routed to their table blocks
     // instead (dfx_k_partition.hip); in between, the global table alone.
     occupied_known = hc[CTRL_OCCUPIED];
-    if (memo) memo->remember(program_fingerprint(), occupied_known);
+    {  // share of the slice's rows that a 512-slot front cache absorbed: ~0 for a million uniform keys, a third and
+       // more under a Zipf-like distribution (statistics stripes of K7; one more small synchronous copy, once per stream)
+      std::vector<uint64_t> hs((size_t)kStatStripes * STAT_WORDS, 0);
+      DFX_HIP(hipMemcpy(hs.data(), stats.get(), sizeof(uint64_t) * hs.size(), hipMemcpyDeviceToHost));
+      uint64_t hit = 0, miss = 0;
+      for (int i = 0; i < kStatStripes; ++i) {
+        hit += hs[(size_t)i * STAT_WORDS + STAT_LDS_HIT];
+        miss += hs[(size_t)i * STAT_WORDS + STAT_LDS_MISS];
+      }
+      skew_seen = occupied_known >= 16384 && miss > 0 && hit * 8 >= miss;  // (`miss` counts every row that went through the cache) >= 12.5 % reused although the groups do not fit
+    }
+    if (memo) memo->remember(program_fingerprint(), occupied_known | (skew_seen ? 1ull << 63 : 0ull));
     lds_calibrated = true;
     lds_enabled = occupied_known <= 8192;
     if (!lds_enabled && kw == 1 && occupied_known >= 16384) {

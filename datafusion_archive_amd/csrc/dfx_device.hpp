@@ -190,8 +190,12 @@ struct DevAggPlan {
 // partition is aggregated by one workgroup inside an LDS copy of its table block.
 struct DevPartition {
   uint64_t* rows;      // [partition][producer][cap_rows][n_words]  (row-major regions)
-  uint64_t part_stride;// words between the regions of consecutive partitions (>= n_producers * cap_rows * n_words;
-                       // padded so that the 256 streams a producer writes do not share an HBM channel)
+  uint64_t part_stride;// words between the regions of consecutive partitions of one producer
+  uint64_t prod_stride;// words between the regions of consecutive producers of one partition.  Producer-major (default):
+                       // part_stride = cap_rows * n_words, prod_stride = n_parts * part_stride (+ pad) -- the 256 streams a
+                       // pass-1 workgroup appends to lie within ONE contiguous piece of the scratch (a handful of TLB
+                       // entries per workgroup), pass 2 walks its 256 regions one after the other.  Partition-major: the
+                       // other way round (round 1's layout; pass 1 then touches a region every part_stride words)
   uint32_t* counts;    // [partition][producer]
   uint32_t n_parts;    // table blocks
   uint32_t n_producers;// pass-1 workgroups
@@ -205,7 +209,8 @@ struct DevPartition {
 };
 enum : uint32_t {
   PTF_RESUME = 1u,        // pass 1 appends to the regions as `counts` left them (pass 2 of earlier batches is still pending)
-  PTF_STREAM_PASS2 = 2u   // pass 2: region-streaming kernel (one aggregate, 16-byte rows)
+  PTF_STREAM_PASS2 = 2u,  // pass 2: region-streaming kernel (one aggregate, 16-byte rows)
+  PTF_HOT = 4u            // pass 1 (ring flavour, one aggregate): hot-key pairs in LDS (skewed keys)
 };
 
 // ---- Utf8 GROUP BY keys: device string dictionary (dfx_k_dict.hip) ---------------------------------

@@ -6,58 +6,6 @@
 
 namespace dfx {
 
-#ifdef DFX_PA_QUEUE
-// find-or-claim in the LDS copy of a table block: at most `max_steps` aligned 4-slot groups starting at group g.
-// Returns the slot, or -1 when none of those groups holds the key or an empty slot.
-DEV int pa_find_or_claim(uint64_t* lkeys, uint32_t S, uint32_t g, uint64_t kk, uint32_t max_steps, uint32_t& new_keys) {
-  for (uint32_t it = 0; it < max_steps;) {
-    const ulonglong2 ka = *(const ulonglong2*)&lkeys[g * 4];
-    const ulonglong2 kb = *(const ulonglong2*)&lkeys[g * 4 + 2];
-    const uint32_t mm = (ka.x == kk ? 1u : 0u) | (ka.y == kk ? 2u : 0u) | (kb.x == kk ? 4u : 0u) | (kb.y == kk ? 8u : 0u);
-    const uint32_t em = (ka.x == kEmptyKey ? 1u : 0u) | (ka.y == kEmptyKey ? 2u : 0u) | (kb.x == kEmptyKey ? 4u : 0u) |
-                        (kb.y == kEmptyKey ? 8u : 0u);
-    if (mm) return (int)(g * 4 + (uint32_t)__ffs((int)mm) - 1u);
-    if (em) {
-      const uint32_t at = g * 4 + (uint32_t)__ffs((int)em) - 1u;
-      const uint64_t old = atomicCAS((unsigned long long*)&lkeys[at], (unsigned long long)kEmptyKey, (unsigned long long)kk);
-      if (old == kEmptyKey) {
-        ++new_keys;
-        return (int)at;
-      }
-      if (old == kk) return (int)at;
-      continue;  // another key claimed it meanwhile: look at the same group again
-    }
-    g = (g + 1) & ((S >> 2) - 1);
-    ++it;
-  }
-  return -1;
-}
-
-// a parked row (re-read from the partition's region: L2-resident) looked up to the end; block full -> spill list
-template <int NV>
-DEV void pa_finish_parked(const DevTable& T, const DevRows& spill, uint64_t* lkeys, uint64_t* laccs, uint32_t S,
-                          const uint64_t* src, bool have, uint32_t& new_keys) {
-  uint64_t k2[1];
-  uint64_t v2[kMaxAggs];
-  k2[0] = have ? src[0] : 0;
-#pragma unroll
-  for (int a = 0; a < kMaxAggs; ++a) v2[a] = (have && a < NV && a < T.na) ? src[1 + a] : 0;
-  bool todo = have;
-  if (have) {
-    const uint64_t h = hash_keys<1>(k2);
-    const uint32_t g = ((uint32_t)((h >> T.shift) & T.mask) & T.block_mask) >> 2;
-    // from the home group again (its first step found neither the key nor room, but a neighbour may have claimed since)
-    const int found = pa_find_or_claim(lkeys, S, g, k2[0], (S >> 2) + 1u, new_keys);
-    if (found >= 0) {
-#pragma unroll
-      for (int a = 0; a < NV; ++a)
-        if (a < T.na) acc_atomic(T.acc_kind[a], &laccs[(size_t)a * S + found], v2[a]);
-      todo = false;
-    }
-  }
-  if (__ballot(todo) != 0) spill_row<1>(T, spill, todo, k2, v2);
-}
-#endif
 
 // pass 2: one workgroup per partition (= table block).  The rows of all producers are visited as
 // ONE flattened index space (prefix sums of the per-producer counts live in LDS), so all lanes stay
@@ -125,24 +73,11 @@ __global__ __launch_bounds__(kABlock) void k_partition_agg(const DevTable T, con
   uint64_t key[RU][1], nkey[RU][1];
   uint64_t val[RU][NV], nval[RU][NV];
   bool inb[RU], ninb[RU];
-#ifdef DFX_PA_QUEUE
-  // EXPERIMENTAL (written without a GPU at hand): straggler queue.  Every row gets ONE probe
-  // step; a lane that is not done parks the row's word offset in its wave's LDS queue and goes on, and the wave works
-  // 64 parked rows off at a time at full lane utilisation -- it no longer pays for its slowest lane on every row.
-  constexpr int kPaQueue = 128;
-  uint32_t* wq = pre + (((NP + 1) + 3) & ~3u) + (threadIdx.x >> 6) * kPaQueue;
-  uint32_t qn = 0;  // wave-uniform
-  uint32_t off[RU], noff[RU];
-  const uint64_t* const part_rows = PT.rows + (uint64_t)p * PT.part_stride;
-#endif
   auto fetch = [&](uint32_t i0, uint64_t (&k)[RU][1], uint64_t (&v)[RU][NV], bool (&ib)[RU]) {
 #pragma unroll
     for (int r = 0; r < RU; ++r) {
       const uint32_t i = i0 + (uint32_t)r * kABlock + threadIdx.x;
       ib[r] = i < total;
-#ifdef DFX_PA_QUEUE
-      noff[r] = 0;
-#endif
       k[r][0] = 0;
 #pragma unroll
       for (int a = 0; a < NV; ++a) v[r][a] = 0;
@@ -158,9 +93,6 @@ __global__ __launch_bounds__(kABlock) void k_partition_agg(const DevTable T, con
           while (pre[lo + 1] <= i) ++lo;
           src = region_row(PT, p, lo, i - pre[lo]);
         }
-#ifdef DFX_PA_QUEUE
-        noff[r] = (uint32_t)(src - part_rows);
-#endif
         typedef uint64_t u64x2_t __attribute__((ext_vector_type(2)));
         const u64x2_t kv = __builtin_nontemporal_load((const u64x2_t*)src);
         ib[r] = ib[r] && kv.x != kEmptyKey;  // padding rows (pass 1 rounds every region up to whole chunks)
@@ -173,9 +105,6 @@ __global__ __launch_bounds__(kABlock) void k_partition_agg(const DevTable T, con
         while (pre[lo] > i) --lo;
         while (pre[lo + 1] <= i) ++lo;
         const uint64_t* src = region_row(PT, p, lo, i - pre[lo]);
-#ifdef DFX_PA_QUEUE
-        noff[r] = (uint32_t)(src - part_rows);
-#endif
         {
           k[r][0] = src[0];
 #pragma unroll
@@ -195,41 +124,10 @@ __global__ __launch_bounds__(kABlock) void k_partition_agg(const DevTable T, con
     for (int r = 0; r < RU; ++r) {
       key[r][0] = nkey[r][0];
       inb[r] = ninb[r];
-#ifdef DFX_PA_QUEUE
-      off[r] = noff[r];
-#endif
 #pragma unroll
       for (int a = 0; a < NV; ++a) val[r][a] = nval[r][a];
     }
     if (i0 + kABlock * RU < total) fetch(i0 + kABlock * RU, nkey, nval, ninb);
-#ifdef DFX_PA_QUEUE
-#pragma unroll
-    for (int r = 0; r < RU; ++r) {
-      bool later = false;
-      if (inb[r]) {
-        const uint64_t h = hash_keys<1>(key[r]);
-        const uint32_t g = ((uint32_t)((h >> T.shift) & T.mask) & T.block_mask) >> 2;
-        const int found = pa_find_or_claim(lkeys, S, g, key[r][0], 1u, new_keys);
-        if (found >= 0) {
-#pragma unroll
-          for (int a = 0; a < NV; ++a)
-            if (a < T.na) acc_atomic(T.acc_kind[a], &laccs[(size_t)a * S + found], val[r][a]);
-        } else {
-          later = true;
-        }
-      }
-      const uint64_t qm = __ballot(later);
-      if (qm != 0) {
-        if (later) wq[qn + mbcnt64(qm)] = off[r];
-        qn += (uint32_t)__popcll(qm);
-        if (qn >= 64) {  // qn < 64 before the append, so one round empties it below 64 again
-          qn -= 64;
-          pa_finish_parked<NV>(T, spill, lkeys, laccs, S, part_rows + wq[qn + lane], true, new_keys);
-        }
-      }
-    }
-    continue;
-#endif
 #pragma unroll
     for (int r = 0; r < RU; ++r) {
       bool todo = inb[r];
@@ -282,10 +180,6 @@ __global__ __launch_bounds__(kABlock) void k_partition_agg(const DevTable T, con
       }
     }
   }
-#ifdef DFX_PA_QUEUE
-  if (qn != 0)  // the wave's last < 64 parked rows
-    pa_finish_parked<NV>(T, spill, lkeys, laccs, S, part_rows + ((uint32_t)lane < qn ? wq[lane] : 0u), (uint32_t)lane < qn, new_keys);
-#endif
 #ifdef DFX_PA_TIMING
   const long long tt3 = wall_clock64();
 #endif
@@ -389,7 +283,7 @@ __global__ __launch_bounds__(kABlock) void k_partition_agg_stream(const DevTable
     }
   }
   const uint64_t* const part_rows = PT.rows + (uint64_t)p * PT.part_stride;
-  const uint64_t region_words = (uint64_t)PT.cap_rows * 2u;
+  const uint64_t region_words = PT.prod_stride;  // words between this partition's regions of consecutive producers
   // wave-uniform cursor over (region ordinal j, row offset i0)
   uint32_t s_j = 0, s_i0 = 0;
   uint32_t s_cnt = (uint32_t)__builtin_amdgcn_readlane((int)v_cnt, 0);
@@ -460,7 +354,7 @@ __global__ __launch_bounds__(kABlock) void k_partition_agg_stream(const DevTable
 
 size_t partition_stage_bytes(const DevPartition& PT) {
   if ((PT.mode & 15u) == 0) return (size_t)PT.n_parts * 4 + 16;
-  if ((PT.mode & 15u) == 2) return partition_ring_bytes(PT.n_words, PT.n_parts, 16);
+  if ((PT.mode & 15u) == 2) return partition_ring_bytes(PT.n_words, PT.n_parts, 16, (PT.flags & PTF_HOT) != 0);
   return (size_t)PT.stage_rows * ((size_t)PT.n_words * 8 + 4) + (size_t)PT.n_parts * 12 + (2 + 16) * 4 + 16;
 }
 
@@ -514,9 +408,6 @@ hipError_t launch_partition_agg(const DevTable& T, const DevPartition& PT, const
                                 hipStream_t s) {
   Scope sc(KID_PARTITION_AGG, s, algo_bytes);
   size_t lds_bytes = (size_t)(T.block_mask + 1) * (size_t)(1 + T.na) * 8 + (size_t)(PT.n_producers + 1) * 4 + 16;
-#ifdef DFX_PA_QUEUE
-  lds_bytes += 16 + (size_t)(kABlock / 64) * 128 * 4;  // per-wave queues of parked rows
-#endif
   if (lds_bytes > 160 * 1024 - 256 || PT.n_producers > 1024) return hipErrorInvalidValue;
   if (T.na == 1 && (PT.flags & PTF_STREAM_PASS2) && PT.n_words == 2)
     hipLaunchKernelGGL(k_partition_agg_stream, dim3(PT.n_parts), dim3(kABlock), (size_t)(T.block_mask + 1) * 16, s, T, PT, spill);

@@ -32,7 +32,7 @@ constexpr int kABlock = 1024;  // pass-2 workgroup (one per CU): 16 waves share 
 
 // address of row `row` of the region that producer `producer` fills for partition `part`
 DEV uint64_t* region_row(const DevPartition& PT, uint32_t part, uint32_t producer, uint32_t row) {
-  return PT.rows + (uint64_t)part * PT.part_stride + ((uint64_t)producer * PT.cap_rows + row) * PT.n_words;
+  return PT.rows + (uint64_t)part * PT.part_stride + (uint64_t)producer * PT.prod_stride + (uint64_t)row * PT.n_words;
 }
 
 DEV uint32_t partition_of(const DevTable& T, const DevPartition& PT, uint64_t h) {
@@ -418,6 +418,7 @@ __global__ __launch_bounds__(BLOCK) void k_partition_sorted(const DevProgram P, 
 // workgroups per CU -- 32 waves -- was measured ~20 % slower than 16 rows and one workgroup.)
 constexpr int ring_queue_rows(int rp) { return rp >= 16 ? 192 : 128; }
 constexpr int kRingBlock = 1024;
+constexpr int kHotSlots = 1024;  // hot-key pairs per pass-1 workgroup (== kRingBlock: one slot per lane in the final flush)
 #ifndef DFX_RING_DEPTH
 #define DFX_RING_DEPTH 1
 #endif
@@ -432,10 +433,11 @@ struct RingLds {
 };
 
 #ifdef DFX_PARTITION_MAIN_TU  // a plain function: defined once, in dfx_k_partition.hip
-size_t partition_ring_bytes(uint32_t n_words, uint32_t n_parts, int kRingRP) {
+size_t partition_ring_bytes(uint32_t n_words, uint32_t n_parts, int kRingRP, bool hot) {
   const int kRingQ = ring_queue_rows(kRingRP);
   return (size_t)n_parts * kRingRP * n_words * 8 + (size_t)(kRingBlock / 64) * kRingQ * n_words * 8 +
-         (size_t)(kRingBlock / 64) * 64 * (kRingRP >= 16 ? 8 : 4) + (size_t)n_parts * 4 * (1 + 2 * 4) + 64;
+         (size_t)(kRingBlock / 64) * 64 * (kRingRP >= 16 ? 8 : 4) + (size_t)n_parts * 4 * (1 + 2 * 4) + 64 +
+         (hot ? (size_t)kHotSlots * 16 : 0);
 }
 #endif
 
@@ -444,7 +446,7 @@ size_t partition_ring_bytes(uint32_t n_words, uint32_t n_parts, int kRingRP) {
 // route up to 64 rows (one per lane with have == true)
 template <int NV, int kRingCH, int kRingRP>
 DEV void ring_route(const DevTable& T, const DevPartition& PT, const DevRows& spill, const RingLds& L, uint32_t producer,
-                    int na, bool have, const uint64_t (&key)[1], const uint64_t (&val)[kMaxAggs], uint32_t& err) {
+                    int na, bool have, const uint64_t (&key)[1], const uint64_t (&val)[kMaxAggs], uint64_t h, uint32_t& err) {
   constexpr int kRingNCH = kRingRP / kRingCH;
   const int lane = lane_id();
   const int wave = threadIdx.x >> 6;
@@ -452,7 +454,7 @@ DEV void ring_route(const DevTable& T, const DevPartition& PT, const DevRows& sp
   uint32_t part = 0, pos = 0;
   bool pending = false, todo = false;
   if (have) {
-    part = partition_of(T, PT, hash_keys<1>(key));
+    part = partition_of(T, PT, h);
     pos = atomicAdd(&L.fill[part], 1u);
     pending = pos < PT.cap_rows;
     todo = !pending;  // region overflow (skewed keys): the general path takes the row
@@ -513,7 +515,28 @@ DEV void ring_route(const DevTable& T, const DevPartition& PT, const DevRows& sp
   }
 }
 
-template <typename POL, int kRingCH, int kRingRP>
+// ---- hot keys (skewed inputs) --------------------------------------------------------------------------
+// A key that owns percent of the rows overflows its (producer, partition) regions (the overflow goes through the spill
+// list and global same-address atomics at ~11 ns each) and makes 64 lanes of pass 2 queue on one LDS address.  With
+// PTF_HOT every pass-1 workgroup keeps kHotSlots direct-mapped (key, accumulator) pairs in LDS, claimed once by the
+// first key that hashes there -- under a Zipf-like distribution the heavy keys turn up within the first rows and take
+// their slots -- and rows of a cached key are added there instead of being routed.  At the end every claimed slot is
+// routed as ONE row (key, partial accumulator): the accumulator algebra is associative, so pass 2 cannot tell.  The
+// slot index comes from the LOW hash bits (the partition from the high ones).  Switched on by the calibration slice
+// (a front cache that absorbs a sizeable share of the rows means skew); uniform keys never pay for it.
+DEV bool hot_absorb(uint64_t* hot_keys, uint64_t* hot_accs, uint8_t kind, uint64_t h, uint64_t key, uint64_t val) {
+  const uint32_t hs = (uint32_t)(h >> 32) & (uint32_t)(kHotSlots - 1);
+  uint64_t cur = hot_keys[hs];
+  if (cur == kEmptyKey) {
+    const uint64_t old = atomicCAS((unsigned long long*)&hot_keys[hs], (unsigned long long)kEmptyKey, (unsigned long long)key);
+    cur = old == kEmptyKey ? key : old;
+  }
+  if (cur != key) return false;
+  acc_atomic(kind, &hot_accs[hs], val);
+  return true;
+}
+
+template <typename POL, int kRingCH, int kRingRP, bool HOT = false>
 __global__ __launch_bounds__(kRingBlock) void k_partition_ring(const DevProgram P, const DevFastPlan F, const DevColumns C,
                                                               const DevAggPlan plan, const DevTable T,
                                                               const DevPartition PT, const DevRows spill, const int64_t n) {
@@ -533,9 +556,20 @@ __global__ __launch_bounds__(kRingBlock) void k_partition_ring(const DevProgram 
   L.fill = (uint32_t*)(L.jobs + NWAVES * 64 * (kRingRP >= 16 ? 2 : 1));
   L.commit = L.fill + PT.n_parts;
   L.gen = L.commit + (size_t)PT.n_parts * 4;
+  // hot-key pairs behind everything else, 16-byte aligned (as an offset from `lds`: keeps the LDS address space)
+  const size_t hot_word0 = ((size_t)PT.n_parts * kRingRP * NW + (size_t)NWAVES * kRingQ * NW) +
+                           ((size_t)(NWAVES * 64 * (kRingRP >= 16 ? 2 : 1) + PT.n_parts * (1 + 2 * 4)) * 4 + 15) / 16 * 2;
+  uint64_t* hot_keys = lds + hot_word0;
+  uint64_t* hot_accs = hot_keys + kHotSlots;
   const int lane = lane_id();
   const int wave = threadIdx.x >> 6;
   const int na = POL::na(T);
+  if (HOT) {
+    for (uint32_t i = threadIdx.x; i < (uint32_t)kHotSlots; i += kRingBlock) {
+      hot_keys[i] = kEmptyKey;
+      hot_accs[i] = T.acc_init[0];
+    }
+  }
   const uint32_t producer = blockIdx.x;
   // fill, commit, gen.  PTF_RESUME: pass 2 of the earlier batches is still pending and this producer's regions already
   // hold counts[] rows -- a whole number of chunks, the epilogue below pads -- so chunk numbering goes on from there:
@@ -641,7 +675,10 @@ __global__ __launch_bounds__(kRingBlock) void k_partition_ring(const DevProgram 
           k2[0] = q[qn + lane];
 #pragma unroll
           for (int a = 0; a < kMaxAggs; ++a) v2[a] = (a < NV && a < na) ? q[(size_t)(1 + a) * kRingQ + qn + lane] : 0;
-          ring_route<NV, kRingCH, kRingRP>(T, PT, spill, L, producer, na, true, k2, v2, err);
+          const uint64_t h2 = hash_keys<1>(k2);
+          bool have2 = true;
+          if (HOT && NV == 1) have2 = !hot_absorb(hot_keys, hot_accs, POL::acc_kind(T, 0), h2, k2[0], v2[0]);
+          ring_route<NV, kRingCH, kRingRP>(T, PT, spill, L, producer, na, have2, k2, v2, h2, err);
         }
       }
     }
@@ -649,11 +686,24 @@ __global__ __launch_bounds__(kRingBlock) void k_partition_ring(const DevProgram 
   {  // the wave's last < 64 rows
     uint64_t k2[1];
     uint64_t v2[kMaxAggs];
-    const bool have = (uint32_t)lane < qn;
+    bool have = (uint32_t)lane < qn;
     k2[0] = have ? q[lane] : 0;
 #pragma unroll
     for (int a = 0; a < kMaxAggs; ++a) v2[a] = (have && a < NV && a < na) ? q[(size_t)(1 + a) * kRingQ + lane] : 0;
-    if (qn != 0) ring_route<NV, kRingCH, kRingRP>(T, PT, spill, L, producer, na, have, k2, v2, err);
+    const uint64_t h2 = hash_keys<1>(k2);
+    if (HOT && NV == 1 && have) have = !hot_absorb(hot_keys, hot_accs, POL::acc_kind(T, 0), h2, k2[0], v2[0]);
+    if (qn != 0) ring_route<NV, kRingCH, kRingRP>(T, PT, spill, L, producer, na, have, k2, v2, h2, err);
+  }
+  if (HOT && NV == 1) {  // every claimed hot slot becomes one routed row (key, partial accumulator)
+    __syncthreads();     // all waves have finished absorbing
+    uint64_t k2[1];
+    uint64_t v2[kMaxAggs];
+#pragma unroll
+    for (int a = 0; a < kMaxAggs; ++a) v2[a] = 0;
+    k2[0] = hot_keys[threadIdx.x];
+    v2[0] = hot_accs[threadIdx.x];
+    const bool have = k2[0] != kEmptyKey;
+    if (__ballot(have) != 0) ring_route<NV, kRingCH, kRingRP>(T, PT, spill, L, producer, na, have, k2, v2, hash_keys<1>(k2), err);
   }
   __syncthreads();
   // partial chunks + region counts.  A partial chunk is padded to a whole one with rows whose key is kEmptyKey (pass 2
@@ -697,6 +747,8 @@ void launch_partition_pol(const DevProgram& P, const DevFastPlan& fast, const De
     hipLaunchKernelGGL((k_partition<POL>), dim3(grid), dim3(kPBlock), lds_bytes, s, P, fast, C, plan, T, PT, spill, n);
   else if ((PT.mode & 15u) == 2 && (PT.mode & 0x80u))  // 4-row chunks (64-byte runs)
     hipLaunchKernelGGL((k_partition_ring<POLS, 4, 16>), dim3(grid), dim3(kRingBlock), lds_bytes, s, P, fast, C, plan, T, PT, spill, n);
+  else if ((PT.mode & 15u) == 2 && (PT.flags & PTF_HOT))  // skewed keys: hot-key pairs in LDS
+    hipLaunchKernelGGL((k_partition_ring<POLS, 8, 16, true>), dim3(grid), dim3(kRingBlock), lds_bytes, s, P, fast, C, plan, T, PT, spill, n);
   else if ((PT.mode & 15u) == 2)  // 8-row chunks (full 128-byte lines): ~4 % faster on MI355X
     hipLaunchKernelGGL((k_partition_ring<POLS, 8, 16>), dim3(grid), dim3(kRingBlock), lds_bytes, s, P, fast, C, plan, T, PT, spill, n);
   else if (PT.block == 512)

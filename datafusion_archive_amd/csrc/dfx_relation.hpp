@@ -109,6 +109,9 @@ struct AggOptions {
   int partition_block = 1024;  // pass-1 workgroup size in mode 1 (512: two workgroups per CU)
   int partition_defer = 4;     // routing regions hold this many worst-case batches (1: pass 2 after every batch)
   int partition_defer_batches = 8;  // at most this many pass-1 launches share one pass 2
+  int partition_layout = 1;    // routing scratch: 1 producer-major, 0 partition-major (DevPartition::prod_stride)
+  int partition_producers = 0; // pass-1 workgroups of the ring flavour (0: one per CU)
+  int hot_keys = -1;           // pass 1 hot-key pairs in LDS: -1 when the calibration slice saw skew, 0 never, 1 always
   int emit_async = 1;          // 1: emit queues its compaction kernels with the host's group count and checks the table's afterwards
   int calibration_memo = 1;    // 1: a resident table remembers the outcome of an aggregate's calibration slice per program shape
   int pass2_stream = 1;        // pass 2 of one-aggregate queries: region-streaming kernel (0: the flattened-index kernel)

@@ -383,6 +383,9 @@ int32_t dfx_set_option(const char* key, int64_t value) {
   else if (!strcmp(key, "agg.pass2_stream")) o.pass2_stream = (int)value;
   else if (!strcmp(key, "agg.calibration_memo")) o.calibration_memo = (int)value;
   else if (!strcmp(key, "agg.emit_async")) o.emit_async = (int)value;
+  else if (!strcmp(key, "agg.hot_keys")) o.hot_keys = (int)value;
+  else if (!strcmp(key, "agg.partition_layout")) o.partition_layout = (int)value;
+  else if (!strcmp(key, "agg.partition_producers")) o.partition_producers = (int)value;
   else if (!strcmp(key, "pool.trim")) pool_trim();
   else return DFX_GENERAL;
   return DFX_OK;

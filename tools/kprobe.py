@@ -37,5 +37,4 @@ for _ in range(3): out = run()
 ex.profile_enable(False)
 print(f"un-instrumented: {dt * 1e3:.3f} ms per query = {rows / dt / 1e9:.1f} G rows/s")
 print(f"rows={rows} groups={groups} filt={filt} opts={sys.argv[4:]} -> groups_out={out.num_rows}")
-for p in ex.profile_snapshot():
-    print(f"   {p['kernel']:14s} launches={p['launches']:3d} avg_us={p['total_ms']/p['launches']*1e3:9.1f}")
+print("   " + "  ".join(f"{p['kernel']}:{p['launches'] // 3}x{p['total_ms'] / p['launches'] * 1e3:.1f}us" for p in ex.profile_snapshot()))
