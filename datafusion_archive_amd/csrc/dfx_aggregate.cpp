@@ -92,6 +92,7 @@ struct AggregateRelation::Impl {
   bool lds_calibrated = false;
   bool calibrating = false;     // the launch in progress is the calibration slice
   bool use_partition = false;   // strategy 3: route rows to table blocks, aggregate blocks in LDS
+  bool narrow = false;          // every key the calibration slice saw is below 2^32: 12-byte routed rows (PTF_NARROW)
   bool skew_seen = false;       // the calibration slice's front cache absorbed a sizeable share of its rows: heavy keys
   DevPartition PT;
   std::shared_ptr<void> pt_rows, pt_counts;
@@ -108,6 +109,8 @@ struct AggregateRelation::Impl {
   uint64_t pt_fill_bound = 0;
   int64_t pt_last_p2_seq = -1;    // batch_seq at the last pass-2 launch: older snapshots say nothing about the current fills
   int64_t pt_rows_in_flight = 0;  // input rows of the pending launches (all of them may still end up in the spill list)
+  std::shared_ptr<void> snap_done;  // device word of DevPartition::snap_done
+  bool snap_armed = false;          // the batch just launched writes its own control-block snapshot (no copy on the side stream)
   int64_t rows_seen = 0;
   uint64_t occupied_known = 0;
   // control block checks run ONE BATCH BEHIND the launches: after batch i its control block is copied to
@@ -141,6 +144,7 @@ struct AggregateRelation::Impl {
   Status emit_ungrouped(DeviceBatch* out);
   Status read_ctrl(uint32_t* host_ctrl);
   Status post_ctrl(int64_t rows);
+  Status alloc_ctrl_host();
   Status examine_ctrl(int slot);
   Status settle_ctrl();
   Status handle_ctrl(const uint32_t* hc, int64_t n);
@@ -364,6 +368,7 @@ Status AggregateRelation::Impl::ensure_spill(int64_t rows) {
   }
   if (spill.words && spill.capacity >= (uint64_t)rows) return Status::OK();
   DFX_RETURN_IF_ERROR(settle_ctrl());  // rows spilled by batches still in flight live in the old list
+  ScopedUs t_alloc(&counters().agg_alloc_us);
   Status st;
   spill_owner = device_alloc(sizeof(uint64_t) * (size_t)rows * (size_t)(kw + na), &st);
   if (!spill_owner) return st;
@@ -375,7 +380,9 @@ Status AggregateRelation::Impl::ensure_spill(int64_t rows) {
 // scratch for the partitioned strategy, sized for a batch of `rows` rows (worst case: all pass)
 Status AggregateRelation::Impl::ensure_partition(int64_t rows) {
   const uint64_t S = (uint64_t)T.block_mask + 1;
-  if (pt_layout_valid && rows <= pt_layout_rows && PT.n_parts == (uint32_t)((T.mask + 1) / S) && PT.n_words == (uint32_t)(kw + na))
+  const bool want_narrow = narrow && kw == 1 && na == 1 && agg_options().narrow_keys != 0;
+  if (pt_layout_valid && rows <= pt_layout_rows && PT.n_parts == (uint32_t)((T.mask + 1) / S) && PT.n_words == (uint32_t)(kw + na) &&
+      ((PT.flags & PTF_NARROW) != 0) == want_narrow)
     return Status::OK();  // same table, a batch the regions were sized for: keep appending
   DFX_RETURN_IF_ERROR(flush_pass2());  // rows routed under the old layout
   pt_layout_valid = false;
@@ -399,7 +406,9 @@ Status AggregateRelation::Impl::ensure_partition(int64_t rows) {
   const int want = o.partition_mode & 15;
   if (want == 2 && partition_ring_bytes(PT.n_words, PT.n_parts, 16) <= (size_t)158 * 1024) {
     const bool hot = o.hot_keys > 0 || (o.hot_keys < 0 && skew_seen);
-    if (hot && na == 1 && !((uint32_t)o.partition_mode & 0x80u) && partition_ring_bytes(PT.n_words, PT.n_parts, 16, true) <= (size_t)158 * 1024)
+    const bool chunks8 = !((uint32_t)o.partition_mode & 0x80u);
+    if (want_narrow && chunks8) PT.flags |= PTF_NARROW;
+    if (hot && na == 1 && chunks8 && partition_ring_bytes(PT.n_words, PT.n_parts, 16, true, (PT.flags & PTF_NARROW) != 0) <= (size_t)158 * 1024)
       PT.flags |= PTF_HOT;
     PT.mode = 2u | ((uint32_t)o.partition_mode & ~15u);
     PT.block = 1024;
@@ -429,17 +438,19 @@ Status AggregateRelation::Impl::ensure_partition(int64_t rows) {
   if (o.pass2_stream && na == 1 && kw == 1) PT.flags |= PTF_STREAM_PASS2;
   const uint64_t pad_words = (uint64_t)(o.partition_pad >= 0 ? o.partition_pad : 0) / 8;
   size_t row_bytes;
+  const uint64_t region_words = (PT.flags & PTF_NARROW) ? (uint64_t)PT.cap_rows * 12 / 8 : (uint64_t)PT.cap_rows * PT.n_words;
   if (o.partition_layout == 0) {  // partition-major (round 1)
-    PT.prod_stride = (uint64_t)PT.cap_rows * PT.n_words;
+    PT.prod_stride = region_words;
     PT.part_stride = (uint64_t)PT.n_producers * PT.prod_stride + pad_words;
     row_bytes = sizeof(uint64_t) * (size_t)PT.n_parts * PT.part_stride;
   } else {  // producer-major
-    PT.part_stride = (uint64_t)PT.cap_rows * PT.n_words;
+    PT.part_stride = region_words;
     PT.prod_stride = (uint64_t)PT.n_parts * PT.part_stride + pad_words;
     row_bytes = sizeof(uint64_t) * (size_t)PT.n_producers * PT.prod_stride;
   }
   const size_t cnt_bytes = sizeof(uint32_t) * (size_t)PT.n_parts * PT.n_producers;
   Status st;
+  ScopedUs t_alloc(&counters().agg_alloc_us);
   if (!pt_rows || pt_rows_bytes < row_bytes) {
     pt_rows.reset();
     pt_rows = device_alloc(row_bytes, &st);
@@ -465,6 +476,7 @@ Status AggregateRelation::Impl::ensure_partition(int64_t rows) {
 // pass 2 over everything the pending pass-1 launches routed (no-op when nothing is pending)
 Status AggregateRelation::Impl::flush_pass2() {
   if (pt_pending == 0) return Status::OK();
+  ++counters().agg_pass2_launches;
   DFX_HIP(launch_partition_agg(T, PT, spill, 0, ctx().stream));
   pt_pending = 0;
   pt_fill_bound = 0;
@@ -474,6 +486,7 @@ Status AggregateRelation::Impl::flush_pass2() {
 }
 
 Status AggregateRelation::Impl::read_ctrl(uint32_t* host_ctrl) {
+  ScopedUs t(&counters().agg_sync_us);
   hipStream_t s = ctx().stream;
   DFX_HIP(hipMemcpyAsync(host_ctrl, ctrl.get(), sizeof(uint32_t) * CTRL_WORDS, hipMemcpyDeviceToHost, s));
   DFX_HIP(hipStreamSynchronize(s));
@@ -484,25 +497,35 @@ Status AggregateRelation::Impl::read_ctrl(uint32_t* host_ctrl) {
 // stream behind an event, so the next batch's kernels follow this batch's directly (an in-stream D2H copy costs
 // ~10 us of idle device per batch: rocprofv3 timeline).  The snapshot may already contain counts of the NEXT batch;
 // every word is monotone (errors, occupancy, spill cursor), so that only makes the check earlier.
+Status AggregateRelation::Impl::alloc_ctrl_host() {
+  Status st;
+  ctrl_host = pinned_alloc(sizeof(uint32_t) * CTRL_WORDS * 2, &st);
+  if (!ctrl_host) return st;
+  for (int i = 0; i < 2; ++i) {
+    DFX_HIP(hipEventCreateWithFlags(&ctrl_ev[i], hipEventDisableTiming));
+    DFX_HIP(hipEventCreateWithFlags(&main_ev[i], hipEventDisableTiming));
+  }
+  return Status::OK();
+}
+
 Status AggregateRelation::Impl::post_ctrl(int64_t rows) {
   hipStream_t s = ctx().stream;
   hipStream_t aux = ctx().aux;
-  if (!ctrl_host) {
-    Status st;
-    ctrl_host = pinned_alloc(sizeof(uint32_t) * CTRL_WORDS * 2, &st);
-    if (!ctrl_host) return st;
-    for (int i = 0; i < 2; ++i) {
-      DFX_HIP(hipEventCreateWithFlags(&ctrl_ev[i], hipEventDisableTiming));
-      DFX_HIP(hipEventCreateWithFlags(&main_ev[i], hipEventDisableTiming));
-    }
-  }
+  if (!ctrl_host) DFX_RETURN_IF_ERROR(alloc_ctrl_host());
   const int slot = (int)(batch_seq & 1);
-  if (ctrl_pending[slot]) DFX_RETURN_IF_ERROR(examine_ctrl(slot));
-  DFX_HIP(hipEventRecord(main_ev[slot], s));
-  DFX_HIP(hipStreamWaitEvent(aux, main_ev[slot], 0));
-  DFX_HIP(hipMemcpyAsync((uint32_t*)ctrl_host.get() + slot * CTRL_WORDS, ctrl.get(), sizeof(uint32_t) * CTRL_WORDS,
-                         hipMemcpyDeviceToHost, aux));
-  DFX_HIP(hipEventRecord(ctrl_ev[slot], aux));
+  if (snap_armed) {
+    // the batch's last kernel writes the snapshot into this slot of the pinned buffer: all there is to wait for is the
+    // kernel itself.  (The previous occupant of the slot, two batches back, was examined after the previous launch.)
+    snap_armed = false;
+    DFX_HIP(hipEventRecord(ctrl_ev[slot], s));
+  } else {
+    if (ctrl_pending[slot]) DFX_RETURN_IF_ERROR(examine_ctrl(slot));
+    DFX_HIP(hipEventRecord(main_ev[slot], s));
+    DFX_HIP(hipStreamWaitEvent(aux, main_ev[slot], 0));
+    DFX_HIP(hipMemcpyAsync((uint32_t*)ctrl_host.get() + slot * CTRL_WORDS, ctrl.get(), sizeof(uint32_t) * CTRL_WORDS,
+                           hipMemcpyDeviceToHost, aux));
+    DFX_HIP(hipEventRecord(ctrl_ev[slot], aux));
+  }
   ctrl_pending[slot] = true;
   ctrl_rows[slot] = rows;
   ctrl_seq[slot] = batch_seq;
@@ -514,6 +537,11 @@ Status AggregateRelation::Impl::post_ctrl(int64_t rows) {
 // errors, growth: what the per-batch check has always done, on a (possibly one batch old) snapshot
 Status AggregateRelation::Impl::handle_ctrl(const uint32_t* hc, int64_t n) {
   if (hc[CTRL_ERROR]) return error_from_ctrl(hc[CTRL_ERROR]);
+  if (narrow && hc[CTRL_WIDE_KEYS]) {  // a key without a 32-bit image turned up (it went to the spill list): 16-byte rows from now on
+    DFX_RETURN_IF_ERROR(flush_pass2());
+    narrow = false;
+    pt_layout_valid = false;
+  }
   occupied_known = hc[CTRL_OCCUPIED];
   const uint64_t spilled = ((uint64_t)hc[CTRL_SPILL_HI] << 32) | hc[CTRL_SPILL_LO];
   uint64_t passed_total = 0;
@@ -570,7 +598,10 @@ Status AggregateRelation::Impl::handle_ctrl(const uint32_t* hc, int64_t n) {
 
 Status AggregateRelation::Impl::examine_ctrl(int slot) {
   if (!ctrl_pending[slot]) return Status::OK();
-  DFX_HIP(hipEventSynchronize(ctrl_ev[slot]));
+  {
+    ScopedUs t(&counters().agg_ctrl_wait_us);
+    DFX_HIP(hipEventSynchronize(ctrl_ev[slot]));
+  }
   ctrl_pending[slot] = false;
   unconfirmed_rows -= std::min<uint64_t>(unconfirmed_rows, (uint64_t)ctrl_rows[slot]);
   uint32_t hc[CTRL_WORDS];
@@ -596,6 +627,7 @@ Status AggregateRelation::Impl::settle_ctrl() {
 // The table passed its load limit (or a probe sequence was exhausted): build a table at least 4x
 // larger, rehash, then replay the spilled rows into it.  Afterwards occupancy <= 1/4.
 Status AggregateRelation::Impl::grow_and_replay(uint64_t occupied, uint64_t spilled, uint64_t replay_from) {
+  ++counters().agg_growths;
   hipStream_t s = ctx().stream;
   if (spilled > spill.capacity)
     return Status::Err(DFX_INTERNAL_ERROR, strfmt("group spill list overflow (%llu rows > capacity %llu)",
@@ -643,6 +675,7 @@ Status AggregateRelation::Impl::grow_and_replay(uint64_t occupied, uint64_t spil
 Status AggregateRelation::Impl::launch_rows(const DeviceBatch& b, const DevProgram& prog_in, const DevColumns& cols_in,
                                             int64_t row0, int64_t n) {
   hipStream_t s = ctx().stream;
+  snap_armed = false;
   DevProgram prog = prog_in;
   DevColumns cols = cols_in;
   double bytes = 0;
@@ -665,14 +698,40 @@ Status AggregateRelation::Impl::launch_rows(const DeviceBatch& b, const DevProgr
     if (!agg_options().fast) fpp.valid = 0;
     DevPartition pt = PT;
     if (pt_pending > 0) pt.flags |= PTF_RESUME;
+    // close the window when one more batch could overflow a region (or the batch budget is used up; the calibration
+    // slice is aggregated at once: the strategy decision reads the group count)
+    const int max_batches = std::max(1, agg_options().partition_defer_batches);
+    const bool close_window = calibrating || pt_pending + 1 >= max_batches || pt_fill_bound + 2 * (uint64_t)pt_worst > PT.cap_rows;
+    // the LAST kernel of this batch publishes the control block itself (examined one batch later, see post_ctrl)
+    snap_armed = false;
+    uint32_t* snap_to = nullptr;
+    if (agg_options().ctrl_snapshot == 1 && lds_calibrated && !calibrating) {
+      if (!ctrl_host) DFX_RETURN_IF_ERROR(alloc_ctrl_host());
+      if (!snap_done) {
+        Status st;
+        snap_done = device_alloc(sizeof(uint32_t) * 16, &st);
+        if (!snap_done) return st;
+        DFX_HIP(hipMemsetAsync(snap_done.get(), 0, sizeof(uint32_t) * 16, s));
+      }
+      snap_to = (uint32_t*)ctrl_host.get() + (size_t)(batch_seq & 1) * CTRL_WORDS;
+      snap_armed = true;
+    }
+    if (!close_window) {
+      pt.snap_host = snap_to;
+      pt.snap_done = (uint32_t*)snap_done.get();
+    }
     DFX_HIP(launch_partition(prog, fpp, cols, p, T, pt, spill, n, bytes, s));
     ++pt_pending;
     pt_fill_bound += pt_worst;
     pt_rows_in_flight += n;
-    // close the window when one more batch could overflow a region (or the batch budget is used up; the calibration
-    // slice is aggregated at once: the strategy decision reads the group count)
-    const int max_batches = std::max(1, agg_options().partition_defer_batches);
-    if (calibrating || pt_pending >= max_batches || pt_fill_bound + pt_worst > PT.cap_rows) DFX_RETURN_IF_ERROR(flush_pass2());
+    if (close_window) {
+      PT.snap_host = snap_to;
+      PT.snap_done = (uint32_t*)snap_done.get();
+      Status fst = flush_pass2();
+      PT.snap_host = nullptr;
+      PT.snap_done = nullptr;
+      DFX_RETURN_IF_ERROR(fst);
+    }
     return Status::OK();
   }
   DevFastPlan fp = fast;
@@ -791,7 +850,10 @@ Status AggregateRelation::Impl::consume_batch(const DeviceBatch& b) {
   }
   // grouped: can this batch overflow the table in the worst case (every row a new group)?
   const AggOptions& oo = agg_options();
-  if (oo.strategy == 3 && kw == 1) use_partition = true;
+  if (oo.strategy == 3 && kw == 1) {
+    if (!use_partition && oo.narrow_keys > 0) narrow = na == 1;  // forced strategy: no calibration slice -- optimistic (tests)
+    use_partition = true;
+  }
   const bool may_spill = use_partition || occupied_known + unconfirmed_rows + (uint64_t)n > T.load_limit;
   // two batches can be in flight unchecked; with a deferred pass 2 every row of the window may still be spilled (by pass 2
   // itself, when its block is full)
@@ -806,7 +868,8 @@ Status AggregateRelation::Impl::consume_batch(const DeviceBatch& b) {
     // an earlier query of this shape over the same resident table already ran the calibration slice: same decision,
     // no slice, no synchronous read-back (the real group count arrives with the control-block snapshots as always)
     skew_seen = (remembered >> 63) != 0;
-    remembered &= ~(1ull << 63);
+    narrow = ((remembered >> 62) & 1) != 0;
+    remembered &= ~(3ull << 62);
     occupied_known = remembered;
     lds_calibrated = true;
     lds_enabled = remembered <= 8192;
@@ -823,8 +886,10 @@ Status AggregateRelation::Impl::consume_batch(const DeviceBatch& b) {
     Status cst = launch_rows(b, prog, cols, 0, n0);
     calibrating = false;
     DFX_RETURN_IF_ERROR(cst);
+    if (kw == 1) DFX_HIP(launch_probe_wide_keys(T, ctx().stream));  // does any key of the slice lack a 32-bit image?
     uint32_t hc[CTRL_WORDS];
     DFX_RETURN_IF_ERROR(read_ctrl(hc));
+    narrow = kw == 1 && na == 1 && hc[CTRL_WIDE_KEYS] == 0;
     // strategy from the number of groups the calibration slice produced: the LDS front cache pays
     // when the groups fit it (every later row is an LDS atomic); for many groups per-row global
     // atomics would cap the query near 24 G rows/s, so rows are routed to their table blocks
@@ -841,7 +906,7 @@ Status AggregateRelation::Impl::consume_batch(const DeviceBatch& b) {
       }
       skew_seen = occupied_known >= 16384 && miss > 0 && hit * 8 >= miss;  // (`miss` counts every row that went through the cache) >= 12.5 % reused although the groups do not fit
     }
-    if (memo) memo->remember(program_fingerprint(), occupied_known | (skew_seen ? 1ull << 63 : 0ull));
+    if (memo) memo->remember(program_fingerprint(), occupied_known | (skew_seen ? 1ull << 63 : 0ull) | (narrow ? 1ull << 62 : 0ull));
     lds_calibrated = true;
     lds_enabled = occupied_known <= 8192;
     if (!lds_enabled && kw == 1 && occupied_known >= 16384) {
@@ -1001,6 +1066,7 @@ Status AggregateRelation::Impl::dict_emit(const DictKey& d, const uint64_t* ids,
 
 Status AggregateRelation::Impl::drain() {
   if (built) return Status::OK();
+  ScopedUs t_drain(&counters().agg_drain_us);
   DFX_RETURN_IF_ERROR(ensure_init());
   hipStream_t s = ctx().stream;
   Status st;
@@ -1118,6 +1184,7 @@ Status AggregateRelation::Impl::emit_ungrouped(DeviceBatch* out) {  // aggregate
 }
 
 Status AggregateRelation::Impl::emit_grouped(DeviceBatch* out, int64_t expected) {  // aggregate.rs:877-951
+  ScopedUs t_emit(&counters().agg_emit_us);
   hipStream_t s = ctx().stream;
   const int64_t n_slots = (int64_t)T.mask + 2;
   const int64_t n_words = (n_slots + 63) / 64;

@@ -119,6 +119,9 @@ enum : uint8_t {
 };
 
 constexpr uint64_t kEmptyKey = 0x8000000000000000ull;  // single-word key claim sentinel
+// PTF_NARROW: 32-bit hash images stand for keys; two images are reserved (keys that hash to them are not "narrow")
+constexpr uint32_t kTagEmpty = 0xFFFFFFFFu;    // empty slot of the LDS tag plane / padding row of a region
+constexpr uint32_t kTagForeign = 0xFFFFFFFEu;  // slot that holds a key without an image (>= 2^32): occupied, never matches
 
 // ungrouped aggregates: every workgroup of K5 adds its result to one of kReduceSlots copies of the batch
 // partial (slot = workgroup index mod kReduceSlots) -- thousands of agent-scope atomics on ONE address
@@ -138,6 +141,7 @@ enum : int {
   CTRL_LDS_MISS = 7,
   CTRL_PASSED_LO = 8,   // rows that passed the predicate (64-bit)
   CTRL_PASSED_HI = 9,
+  CTRL_WIDE_KEYS = 11,  // nonzero: a key >= 2^32 (or with a reserved hash image) has been seen -- no 12-byte rows (PTF_NARROW)
   CTRL_MAX_FILL = 10,   // partitioned strategy: largest region fill any producer has seen since the last pass 2 (which resets it)
   CTRL_WORDS = 16
 };
@@ -206,11 +210,19 @@ struct DevPartition {
   uint32_t mode;       // pass 1: 0 direct routing (one 16-byte store per row), 1 LDS counting sort + coalesced copy-out
   uint32_t block;      // pass-1 workgroup size (mode 1: 512 or 1024)
   uint32_t flags;      // PTF_*
+  uint32_t pad1;
+  // Control-block snapshot written BY THE KERNEL (null: none): the last workgroup to finish copies T.ctrl into this
+  // host-mapped pinned buffer.  The host reads it after the launch's completion event -- no copy engine, no blit kernel
+  // that would have to find room next to 256 persistent 1024-lane workgroups, nothing on a side stream.
+  uint32_t* snap_host; // [CTRL_WORDS], host memory (hipHostMalloc)
+  uint32_t* snap_done; // device word: workgroups of this launch that have finished (reset by the last one)
 };
 enum : uint32_t {
   PTF_RESUME = 1u,        // pass 1 appends to the regions as `counts` left them (pass 2 of earlier batches is still pending)
   PTF_STREAM_PASS2 = 2u,  // pass 2: region-streaming kernel (one aggregate, 16-byte rows)
-  PTF_HOT = 4u            // pass 1 (ring flavour, one aggregate): hot-key pairs in LDS (skewed keys)
+  PTF_HOT = 4u,           // pass 1 (ring flavour, one aggregate): hot-key pairs in LDS (skewed keys)
+  PTF_NARROW = 8u         // keys below 2^32 (seen by the calibration slice): 12-byte routed rows {hash image, operand}, pass 2
+                          // works on 32-bit images; needs ring flavour, one key word, one aggregate
 };
 
 // ---- Utf8 GROUP BY keys: device string dictionary (dfx_k_dict.hip) ---------------------------------

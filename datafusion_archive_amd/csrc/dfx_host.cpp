@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include <map>
 #include <mutex>
@@ -271,6 +272,12 @@ std::shared_ptr<void> pool_alloc(Pool& pool, size_t bytes, Status* st) {
   return std::shared_ptr<void>(p, [pp, cap](void* q) { pp->give(cap, q); });
 }
 }  // namespace
+
+long long ScopedUs::now() {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (long long)ts.tv_sec * 1000000ll + ts.tv_nsec / 1000;
+}
 
 Counters& counters() {
   static Counters c;

@@ -109,6 +109,21 @@ Status ensure_init();
 struct Counters {
   long long h2d_bytes = 0;
   long long csv_cells = 0;  // cells converted by the CSV source
+  // host-side time accounting of the aggregate (microseconds; tools/kprobe.py): where a query's wall time goes beyond its kernels
+  long long agg_ctrl_wait_us = 0;   // blocked on control-block snapshots (one batch behind the launches)
+  long long agg_sync_us = 0;        // other synchronous read-backs (calibration, growth, end of input)
+  long long agg_emit_us = 0;        // emit_grouped / emit_ungrouped, launch to final synchronisation
+  long long agg_drain_us = 0;       // drain(): every batch consumed and settled
+  long long agg_alloc_us = 0;       // routing scratch / spill list / table allocation
+  long long agg_pass2_launches = 0;
+  long long agg_growths = 0;
+};
+struct ScopedUs {  // adds the scope's wall time to a counter
+  long long* acc;
+  long long t0;
+  static long long now();
+  explicit ScopedUs(long long* a) : acc(a), t0(now()) {}
+  ~ScopedUs() { *acc += now() - t0; }
 };
 Counters& counters();
 

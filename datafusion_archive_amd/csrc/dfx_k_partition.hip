@@ -196,6 +196,7 @@ __global__ __launch_bounds__(kABlock) void k_partition_agg(const DevTable T, con
   for (int mm = 32; mm >= 1; mm >>= 1) new_keys += __shfl_xor(new_keys, mm, 64);
   if (lane == 0 && new_keys) atomicAdd(&T.ctrl[CTRL_OCCUPIED], new_keys);
   if (p == 0 && threadIdx.x == 0) __hip_atomic_store(&T.ctrl[CTRL_MAX_FILL], 0u, RLX_AGENT);  // the regions are empty again
+  snapshot_ctrl_if_last(T, PT);
 #ifdef DFX_PA_TIMING
   if ((threadIdx.x == 0 || threadIdx.x == 1023) && (p == 0 || p == 100 || p == 255))
     printf("PA p=%u t=%u total=%u: load %lld prefix %lld loop %lld barrier %lld store %lld (100MHz ticks)\n", p, threadIdx.x, total,
@@ -350,11 +351,166 @@ __global__ __launch_bounds__(kABlock) void k_partition_agg_stream(const DevTable
   for (int mm = 32; mm >= 1; mm >>= 1) new_keys += __shfl_xor(new_keys, mm, 64);
   if (lane == 0 && new_keys) atomicAdd(&T.ctrl[CTRL_OCCUPIED], new_keys);
   if (p == 0 && threadIdx.x == 0) __hip_atomic_store(&T.ctrl[CTRL_MAX_FILL], 0u, RLX_AGENT);  // the regions are empty again
+  snapshot_ctrl_if_last(T, PT);
+}
+
+// ---- pass 2, narrow keys (PTF_NARROW) ---------------------------------------------------------------------------
+// Same region walk as k_partition_agg_stream over 12-byte rows {hash image, operand}.  The LDS copy of the table block
+// holds a plane of 32-bit TAGS instead of 64-bit keys: tag = hash image of the slot's key (a bijection for keys below
+// 2^32, see ring_route), kTagEmpty for an empty slot, kTagForeign for a slot whose key has no image (>= 2^32, inserted
+// by the general path: occupied, never equal to a row's image).  One 16-byte LDS read shows a whole 4-slot group, the
+// compare is four 32-bit compares, a claim is a 32-bit LDS CAS; the row's slot is its image's top bits (no re-hash).
+// 12 bytes per slot: the block takes 96 KB of LDS instead of 128.  Claimed tags become keys again at write-back.
+DEV int pa2n_lookup(uint32_t* ltags, uint32_t S, uint32_t slot, uint32_t img, uint32_t& new_keys) {
+  uint32_t g = slot >> 2;
+  for (uint32_t it = 0; it <= (S >> 2);) {
+    const uint4 t = *(const uint4*)&ltags[g * 4];
+    const uint32_t mm = (t.x == img ? 1u : 0u) | (t.y == img ? 2u : 0u) | (t.z == img ? 4u : 0u) | (t.w == img ? 8u : 0u);
+    if (mm) return (int)(g * 4 + (uint32_t)__ffs((int)mm) - 1u);
+    const uint32_t em = (t.x == kTagEmpty ? 1u : 0u) | (t.y == kTagEmpty ? 2u : 0u) | (t.z == kTagEmpty ? 4u : 0u) | (t.w == kTagEmpty ? 8u : 0u);
+    if (em) {
+      const uint32_t at = g * 4 + (uint32_t)__ffs((int)em) - 1u;
+      const uint32_t old = atomicCAS(&ltags[at], kTagEmpty, img);
+      if (old == kTagEmpty) {
+        ++new_keys;
+        return (int)at;
+      }
+      if (old == img) return (int)at;
+      continue;  // another image claimed it meanwhile -- look at the same group again
+    }
+    g = (g + 1) & ((S >> 2) - 1);
+    ++it;
+  }
+  return -1;
+}
+
+__global__ __launch_bounds__(kABlock) void k_partition_agg_narrow(const DevTable T, const DevPartition PT, const DevRows spill) {
+  extern __shared__ __attribute__((aligned(16))) uint64_t lds[];
+  const uint32_t S = T.block_mask + 1;
+  uint64_t* laccs = lds;                      // [S]
+  uint32_t* ltags = (uint32_t*)(lds + S);     // [S]
+  const uint32_t p = blockIdx.x;
+  const uint64_t slot0 = (uint64_t)p * S;
+  const int lane = lane_id();
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const uint32_t NP = PT.n_producers;
+  const uint32_t my_prod = wave + (uint32_t)(kABlock / 64) * (uint32_t)lane;
+  const uint32_t v_cnt = my_prod < NP ? PT.counts[(uint64_t)p * NP + my_prod] : 0u;
+  // table block -> LDS: accumulators as they are, keys as tags
+  for (uint32_t i0 = threadIdx.x * 2; i0 < S; i0 += kABlock * 2) {
+    const ulonglong2 kk = *(const ulonglong2*)(T.keys + slot0 + i0);
+    const ulonglong2 aa = *(const ulonglong2*)(T.accs + slot0 + i0);
+    *(ulonglong2*)(laccs + i0) = aa;
+    uint32_t tg[2];
+    const uint64_t k2[2] = {kk.x, kk.y};
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      uint64_t key1[1] = {k2[j]};
+      const uint32_t im = (uint32_t)(hash_keys<1>(key1) >> 32);
+      tg[j] = k2[j] == kEmptyKey ? kTagEmpty : (((k2[j] >> 32) != 0 || im >= kTagForeign) ? kTagForeign : im);
+    }
+    *(uint2*)(ltags + i0) = make_uint2(tg[0], tg[1]);
+  }
+  const uint64_t* const part_rows = PT.rows + (uint64_t)p * PT.part_stride;
+  uint32_t s_j = 0, s_i0 = 0;
+  uint32_t s_cnt = (uint32_t)__builtin_amdgcn_readlane((int)v_cnt, 0);
+  const uint32_t n_mine = (NP + (uint32_t)(kABlock / 64) - 1u - wave) / (uint32_t)(kABlock / 64);
+  struct Row12 { uint32_t img, lo, hi; };
+  auto fetch = [&](Row12& r, bool& act) {
+    while (s_i0 >= s_cnt && s_j < n_mine) {
+      ++s_j;
+      s_i0 = 0;
+      s_cnt = s_j < n_mine ? (uint32_t)__builtin_amdgcn_readlane((int)v_cnt, (int)(s_j & 63u)) : 0u;
+    }
+    const bool live = s_j < n_mine;
+    act = live && s_i0 + (uint32_t)lane < s_cnt;
+    const uint32_t* base = (const uint32_t*)(part_rows + (uint64_t)(wave + (uint32_t)(kABlock / 64) * (live ? s_j : 0u)) * PT.prod_stride) +
+                           (uint64_t)(live ? s_i0 : 0u) * 3u;
+    const uint32_t* src = base + (act ? (uint32_t)lane * 3u : 0u);  // unconditional load: the compiler counts the loads in flight
+    r.img = __builtin_nontemporal_load(src);
+    r.lo = __builtin_nontemporal_load(src + 1);
+    r.hi = __builtin_nontemporal_load(src + 2);
+    s_i0 += 64;
+  };
+  Row12 rows[kPF];
+  bool act[kPF];
+#pragma unroll
+  for (int d = 0; d < kPF; ++d) fetch(rows[d], act[d]);
+  __syncthreads();  // the block is in LDS
+  uint32_t new_keys = 0;
+  const uint8_t kind = T.acc_kind[0];
+  const int tag_shift = T.shift - 32;  // slot = image >> tag_shift (the image is the hash's high half)
+  bool more = true;
+  while (more) {
+#pragma unroll
+    for (int d = 0; d < kPF; ++d) {
+      const Row12 cur = rows[d];
+      const bool a = act[d];
+      if (__ballot(a) == 0) {
+        more = false;
+        break;
+      }
+      fetch(rows[d], act[d]);
+      const bool have = a && cur.img != kTagEmpty;  // padding rows
+      const uint64_t val = ((uint64_t)cur.hi << 32) | cur.lo;
+      bool todo = have;
+      if (have) {
+        const uint32_t slot = (uint32_t)(((uint64_t)cur.img >> tag_shift) & T.mask) & T.block_mask;
+        const int found = pa2n_lookup(ltags, S, slot, cur.img, new_keys);
+        if (found >= 0) {
+          acc_atomic(kind, &laccs[found], val);
+          todo = false;
+        }
+      }
+      if (__ballot(todo) != 0) {  // block full: grow-and-replay takes the row (as a key again)
+        uint64_t key[1] = {(uint64_t)unhash_word32(cur.img)};
+        uint64_t sv[kMaxAggs];
+#pragma unroll
+        for (int q = 0; q < kMaxAggs; ++q) sv[q] = q == 0 ? val : 0ull;
+        spill_row<1>(T, spill, todo, key, sv);
+      }
+    }
+  }
+  __syncthreads();
+  for (uint32_t i0 = threadIdx.x * 2; i0 < S; i0 += kABlock * 2) {
+    *(ulonglong2*)(T.accs + slot0 + i0) = *(const ulonglong2*)(laccs + i0);
+    const uint2 tg = *(const uint2*)(ltags + i0);
+    // a tag that is an image is written back as its key (unchanged for slots that held it before, new for claimed ones);
+    // empty and foreign slots keep what the table holds
+    if (tg.x < kTagForeign) T.keys[slot0 + i0] = (uint64_t)unhash_word32(tg.x);
+    if (tg.y < kTagForeign) T.keys[slot0 + i0 + 1] = (uint64_t)unhash_word32(tg.y);
+  }
+#pragma unroll
+  for (int mm = 32; mm >= 1; mm >>= 1) new_keys += __shfl_xor(new_keys, mm, 64);
+  if (lane == 0 && new_keys) atomicAdd(&T.ctrl[CTRL_OCCUPIED], new_keys);
+  if (p == 0 && threadIdx.x == 0) __hip_atomic_store(&T.ctrl[CTRL_MAX_FILL], 0u, RLX_AGENT);
+  snapshot_ctrl_if_last(T, PT);
+}
+
+// does the (single-word-key) table hold a key that has no 32-bit image?  Run once, after the calibration slice.
+__global__ __launch_bounds__(256) void k_probe_wide_keys(const DevTable T) {
+  const uint64_t n = T.mask + 1;
+  bool wide = false;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+    const uint64_t k = T.keys[i];
+    if (k != kEmptyKey) {
+      uint64_t key1[1] = {k};
+      wide = wide || (k >> 32) != 0 || (uint32_t)(hash_keys<1>(key1) >> 32) >= kTagForeign;
+    }
+  }
+  if (__ballot(wide) != 0 && lane_id() == 0) __hip_atomic_store(&T.ctrl[CTRL_WIDE_KEYS], 1u, RLX_AGENT);
+  if (blockIdx.x == 0 && threadIdx.x == 0 && __hip_atomic_load(&T.ctrl[CTRL_SENTINEL], RLX_AGENT) != 0u)
+    __hip_atomic_store(&T.ctrl[CTRL_WIDE_KEYS], 1u, RLX_AGENT);  // the key i64::MIN lives outside the slots
+}
+hipError_t launch_probe_wide_keys(const DevTable& T, hipStream_t s) {
+  if (T.kw != 1) return hipSuccess;
+  hipLaunchKernelGGL(k_probe_wide_keys, dim3(1024), dim3(256), 0, s, T);
+  return hipGetLastError();
 }
 
 size_t partition_stage_bytes(const DevPartition& PT) {
   if ((PT.mode & 15u) == 0) return (size_t)PT.n_parts * 4 + 16;
-  if ((PT.mode & 15u) == 2) return partition_ring_bytes(PT.n_words, PT.n_parts, 16, (PT.flags & PTF_HOT) != 0);
+  if ((PT.mode & 15u) == 2) return partition_ring_bytes(PT.n_words, PT.n_parts, 16, (PT.flags & PTF_HOT) != 0, (PT.flags & PTF_NARROW) != 0);
   return (size_t)PT.stage_rows * ((size_t)PT.n_words * 8 + 4) + (size_t)PT.n_parts * 12 + (2 + 16) * 4 + 16;
 }
 
@@ -409,7 +565,10 @@ hipError_t launch_partition_agg(const DevTable& T, const DevPartition& PT, const
   Scope sc(KID_PARTITION_AGG, s, algo_bytes);
   size_t lds_bytes = (size_t)(T.block_mask + 1) * (size_t)(1 + T.na) * 8 + (size_t)(PT.n_producers + 1) * 4 + 16;
   if (lds_bytes > 160 * 1024 - 256 || PT.n_producers > 1024) return hipErrorInvalidValue;
-  if (T.na == 1 && (PT.flags & PTF_STREAM_PASS2) && PT.n_words == 2)
+  if (PT.flags & PTF_NARROW) {
+    if (T.na != 1 || T.kw != 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_partition_agg_narrow, dim3(PT.n_parts), dim3(kABlock), (size_t)(T.block_mask + 1) * 12, s, T, PT, spill);
+  } else if (T.na == 1 && (PT.flags & PTF_STREAM_PASS2) && PT.n_words == 2)
     hipLaunchKernelGGL(k_partition_agg_stream, dim3(PT.n_parts), dim3(kABlock), (size_t)(T.block_mask + 1) * 16, s, T, PT, spill);
   else if (T.na == 1) hipLaunchKernelGGL(k_partition_agg<1>, dim3(PT.n_parts), dim3(kABlock), lds_bytes, s, T, PT, spill);
   else hipLaunchKernelGGL(k_partition_agg<0>, dim3(PT.n_parts), dim3(kABlock), lds_bytes, s, T, PT, spill);

@@ -35,6 +35,11 @@ DEV uint64_t* region_row(const DevPartition& PT, uint32_t part, uint32_t produce
   return PT.rows + (uint64_t)part * PT.part_stride + (uint64_t)producer * PT.prod_stride + (uint64_t)row * PT.n_words;
 }
 
+// 12-byte rows (PTF_NARROW): the strides stay in 8-byte words (cap_rows is a multiple of 64), rows are 3 dwords
+DEV uint32_t* region_row12(const DevPartition& PT, uint32_t part, uint32_t producer, uint32_t row) {
+  return (uint32_t*)(PT.rows + (uint64_t)part * PT.part_stride + (uint64_t)producer * PT.prod_stride) + (uint64_t)row * 3u;
+}
+
 DEV uint32_t partition_of(const DevTable& T, const DevPartition& PT, uint64_t h) {
   return (uint32_t)(((h >> T.shift) & T.mask) >> PT.part_shift);
 }
@@ -54,6 +59,21 @@ DEV void publish_max_fill(const DevTable& T, uint32_t max_fill) {
   if (lane_id() == 0 && max_fill != 0) atomicMax(&wg_max_fill, max_fill);
   __syncthreads();
   if (threadIdx.x == 0 && wg_max_fill > __hip_atomic_load(&T.ctrl[CTRL_MAX_FILL], RLX_AGENT)) atomicMax(&T.ctrl[CTRL_MAX_FILL], wg_max_fill);
+}
+
+// DevPartition::snap_host: the last workgroup of the launch publishes the control block to the host.  Every update of
+// T.ctrl is an agent-scope atomic issued before the workgroup's increment of snap_done (release), so the workgroup that
+// sees the full count (acquire) reads final values.  Called by every thread at the very end of the kernel.
+DEV void snapshot_ctrl_if_last(const DevTable& T, const DevPartition& PT) {
+  if (PT.snap_host == nullptr) return;
+  __syncthreads();  // this workgroup's ctrl updates have been issued
+  if (threadIdx.x != 0) return;
+  const uint32_t done = __hip_atomic_fetch_add(PT.snap_done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+  if (done != gridDim.x - 1) return;
+  __hip_atomic_store(PT.snap_done, 0u, RLX_AGENT);  // ready for the next launch (stream order)
+  for (int w = 0; w < CTRL_WORDS; ++w)
+    __hip_atomic_store(&PT.snap_host[w], __hip_atomic_load(&T.ctrl[w], RLX_AGENT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __atomic_thread_fence(__ATOMIC_RELEASE);  // (the kernel's end-of-kernel release makes it visible to the host anyway)
 }
 
 // pass 1.  No staging: a passing row is routed straight from registers.  Its position inside the
@@ -150,6 +170,7 @@ __global__ __launch_bounds__(kPBlock) void k_partition(const DevProgram P, const
   for (int mm = 32; mm >= 1; mm >>= 1) passed += shfl_xor_u64(passed, mm);
   if (lane == 0) stat_add(T, STAT_PASSED, passed);
   if (err) atomicOr(&T.ctrl[CTRL_ERROR], err);
+  snapshot_ctrl_if_last(T, PT);
 }
 
 
@@ -397,6 +418,7 @@ __global__ __launch_bounds__(BLOCK) void k_partition_sorted(const DevProgram P, 
   for (int mm = 32; mm >= 1; mm >>= 1) passed += shfl_xor_u64(passed, mm);
   if (lane == 0) stat_add(T, STAT_PASSED, passed);
   if (err) atomicOr(&T.ctrl[CTRL_ERROR], err);
+  snapshot_ctrl_if_last(T, PT);
 }
 
 // ---- pass 1, lock-free write-combining variant ("ring") ----------------------------------------------
@@ -433,9 +455,9 @@ struct RingLds {
 };
 
 #ifdef DFX_PARTITION_MAIN_TU  // a plain function: defined once, in dfx_k_partition.hip
-size_t partition_ring_bytes(uint32_t n_words, uint32_t n_parts, int kRingRP, bool hot) {
+size_t partition_ring_bytes(uint32_t n_words, uint32_t n_parts, int kRingRP, bool hot, bool narrow) {
   const int kRingQ = ring_queue_rows(kRingRP);
-  return (size_t)n_parts * kRingRP * n_words * 8 + (size_t)(kRingBlock / 64) * kRingQ * n_words * 8 +
+  return (size_t)n_parts * kRingRP * (narrow ? 12 : n_words * 8) + (size_t)(kRingBlock / 64) * kRingQ * n_words * 8 +
          (size_t)(kRingBlock / 64) * 64 * (kRingRP >= 16 ? 8 : 4) + (size_t)n_parts * 4 * (1 + 2 * 4) + 64 +
          (hot ? (size_t)kHotSlots * 16 : 0);
 }
@@ -444,7 +466,12 @@ size_t partition_ring_bytes(uint32_t n_words, uint32_t n_parts, int kRingRP, boo
 #define WG_SCOPE __HIP_MEMORY_SCOPE_WORKGROUP
 
 // route up to 64 rows (one per lane with have == true)
-template <int NV, int kRingCH, int kRingRP>
+// NARROW (PTF_NARROW): 12-byte routed rows {32-bit hash image, 64-bit operand} instead of {key, operand}.  For a key
+// below 2^32 the group hash (hash_word) is a BIJECTION of the key's low word -- three odd multiplies and three
+// xor-shifts -- so the image identifies the key and pass 2 turns it back (unhash_word32) when it claims a slot.  The
+// partition is implied by the region, the slot by the image's top bits: pass 2 neither re-hashes nor compares 64-bit
+// keys.  A row whose key is not narrow (or whose image is one of the two reserved tags) takes the spill list.
+template <int NV, int kRingCH, int kRingRP, int NARROW = 0>
 DEV void ring_route(const DevTable& T, const DevPartition& PT, const DevRows& spill, const RingLds& L, uint32_t producer,
                     int na, bool have, const uint64_t (&key)[1], const uint64_t (&val)[kMaxAggs], uint64_t h, uint32_t& err) {
   constexpr int kRingNCH = kRingRP / kRingCH;
@@ -453,11 +480,17 @@ DEV void ring_route(const DevTable& T, const DevPartition& PT, const DevRows& sp
   const int NW = (int)PT.n_words;
   uint32_t part = 0, pos = 0;
   bool pending = false, todo = false;
+  const uint32_t img = (uint32_t)(h >> 32);
   if (have) {
-    part = partition_of(T, PT, h);
-    pos = atomicAdd(&L.fill[part], 1u);
-    pending = pos < PT.cap_rows;
-    todo = !pending;  // region overflow (skewed keys): the general path takes the row
+    if (NARROW && ((key[0] >> 32) != 0 || img >= kTagForeign)) {
+      todo = true;  // not representable as an image: the general path takes the row, and the host leaves narrow mode
+      if (__hip_atomic_load(&T.ctrl[CTRL_WIDE_KEYS], RLX_AGENT) == 0u) __hip_atomic_store(&T.ctrl[CTRL_WIDE_KEYS], 1u, RLX_AGENT);
+    } else {
+      part = partition_of(T, PT, h);
+      pos = atomicAdd(&L.fill[part], 1u);
+      pending = pos < PT.cap_rows;
+      todo = !pending;  // region overflow (skewed keys): the general path takes the row
+    }
   }
   spill_row<1>(T, spill, todo, key, val);
   const uint32_t c = pos / kRingCH, sl = c % kRingNCH, g = c / kRingNCH, r = pos % kRingCH;
@@ -468,7 +501,12 @@ DEV void ring_route(const DevTable& T, const DevPartition& PT, const DevRows& sp
     bool job = false;
     if (pending && __hip_atomic_load(&L.gen[cs], __ATOMIC_ACQUIRE, WG_SCOPE) == g) {
       uint64_t* dst = L.ring + ((size_t)part * kRingRP + sl * kRingCH + r) * NW;
-      if (NV == 1) {
+      if (NARROW) {
+        uint32_t* d32 = (uint32_t*)L.ring + ((size_t)part * kRingRP + sl * kRingCH + r) * 3;
+        d32[0] = img;
+        d32[1] = (uint32_t)val[0];
+        d32[2] = (uint32_t)(val[0] >> 32);
+      } else if (NV == 1) {
         *(ulonglong2*)dst = make_ulonglong2(key[0], val[0]);
       } else {
         dst[0] = key[0];
@@ -493,7 +531,14 @@ DEV void ring_route(const DevTable& T, const DevPartition& PT, const DevRows& sp
           const uint32_t rr = (uint32_t)lane % kRingCH;
           const uint64_t* src = L.ring + ((size_t)jb.x * kRingRP + (jb.y % kRingNCH) * kRingCH + rr) * NW;
           uint64_t* out = region_row(PT, jb.x, producer, jb.y * kRingCH + rr);
-          if (NV == 1) {
+          if (NARROW) {
+            const uint32_t* s32 = (const uint32_t*)L.ring + ((size_t)jb.x * kRingRP + (jb.y % kRingNCH) * kRingCH + rr) * 3;
+            uint32_t* o32 = region_row12(PT, jb.x, producer, jb.y * kRingCH + rr);
+            const uint32_t a = s32[0], b = s32[1], c3 = s32[2];
+            o32[0] = a;
+            o32[1] = b;
+            o32[2] = c3;
+          } else if (NV == 1) {
             *(ulonglong2*)out = *(const ulonglong2*)src;
           } else {
             for (int w = 0; w < NW; ++w) out[w] = src[w];
@@ -536,7 +581,7 @@ DEV bool hot_absorb(uint64_t* hot_keys, uint64_t* hot_accs, uint8_t kind, uint64
   return true;
 }
 
-template <typename POL, int kRingCH, int kRingRP, bool HOT = false>
+template <typename POL, int kRingCH, int kRingRP, bool HOT = false, int NARROW = 0>
 __global__ __launch_bounds__(kRingBlock) void k_partition_ring(const DevProgram P, const DevFastPlan F, const DevColumns C,
                                                               const DevAggPlan plan, const DevTable T,
                                                               const DevPartition PT, const DevRows spill, const int64_t n) {
@@ -551,13 +596,14 @@ __global__ __launch_bounds__(kRingBlock) void k_partition_ring(const DevProgram 
   const int NW = (int)PT.n_words;
   RingLds L;
   L.ring = lds;
-  L.queue = L.ring + (size_t)PT.n_parts * kRingRP * NW;
+  const size_t ring_words = NARROW ? (size_t)PT.n_parts * kRingRP * 3 / 2 : (size_t)PT.n_parts * kRingRP * NW;  // 12-byte rows
+  L.queue = L.ring + ring_words;
   L.jobs = (uint32_t*)(L.queue + (size_t)NWAVES * kRingQ * NW);
   L.fill = (uint32_t*)(L.jobs + NWAVES * 64 * (kRingRP >= 16 ? 2 : 1));
   L.commit = L.fill + PT.n_parts;
   L.gen = L.commit + (size_t)PT.n_parts * 4;
   // hot-key pairs behind everything else, 16-byte aligned (as an offset from `lds`: keeps the LDS address space)
-  const size_t hot_word0 = ((size_t)PT.n_parts * kRingRP * NW + (size_t)NWAVES * kRingQ * NW) +
+  const size_t hot_word0 = (ring_words + (size_t)NWAVES * kRingQ * NW) +
                            ((size_t)(NWAVES * 64 * (kRingRP >= 16 ? 2 : 1) + PT.n_parts * (1 + 2 * 4)) * 4 + 15) / 16 * 2;
   uint64_t* hot_keys = lds + hot_word0;
   uint64_t* hot_accs = hot_keys + kHotSlots;
@@ -678,7 +724,7 @@ __global__ __launch_bounds__(kRingBlock) void k_partition_ring(const DevProgram 
           const uint64_t h2 = hash_keys<1>(k2);
           bool have2 = true;
           if (HOT && NV == 1) have2 = !hot_absorb(hot_keys, hot_accs, POL::acc_kind(T, 0), h2, k2[0], v2[0]);
-          ring_route<NV, kRingCH, kRingRP>(T, PT, spill, L, producer, na, have2, k2, v2, h2, err);
+          ring_route<NV, kRingCH, kRingRP, NARROW>(T, PT, spill, L, producer, na, have2, k2, v2, h2, err);
         }
       }
     }
@@ -692,7 +738,7 @@ __global__ __launch_bounds__(kRingBlock) void k_partition_ring(const DevProgram 
     for (int a = 0; a < kMaxAggs; ++a) v2[a] = (have && a < NV && a < na) ? q[(size_t)(1 + a) * kRingQ + lane] : 0;
     const uint64_t h2 = hash_keys<1>(k2);
     if (HOT && NV == 1 && have) have = !hot_absorb(hot_keys, hot_accs, POL::acc_kind(T, 0), h2, k2[0], v2[0]);
-    if (qn != 0) ring_route<NV, kRingCH, kRingRP>(T, PT, spill, L, producer, na, have, k2, v2, h2, err);
+    if (qn != 0) ring_route<NV, kRingCH, kRingRP, NARROW>(T, PT, spill, L, producer, na, have, k2, v2, h2, err);
   }
   if (HOT && NV == 1) {  // every claimed hot slot becomes one routed row (key, partial accumulator)
     __syncthreads();     // all waves have finished absorbing
@@ -703,7 +749,7 @@ __global__ __launch_bounds__(kRingBlock) void k_partition_ring(const DevProgram 
     k2[0] = hot_keys[threadIdx.x];
     v2[0] = hot_accs[threadIdx.x];
     const bool have = k2[0] != kEmptyKey;
-    if (__ballot(have) != 0) ring_route<NV, kRingCH, kRingRP>(T, PT, spill, L, producer, na, have, k2, v2, hash_keys<1>(k2), err);
+    if (__ballot(have) != 0) ring_route<NV, kRingCH, kRingRP, NARROW>(T, PT, spill, L, producer, na, have, k2, v2, hash_keys<1>(k2), err);
   }
   __syncthreads();
   // partial chunks + region counts.  A partial chunk is padded to a whole one with rows whose key is kEmptyKey (pass 2
@@ -716,15 +762,27 @@ __global__ __launch_bounds__(kRingBlock) void k_partition_ring(const DevProgram 
     const uint32_t c = f / kRingCH;
     const uint32_t rem = f % kRingCH;
     for (uint32_t r = 0; r < rem; ++r) {
-      const uint64_t* src = L.ring + ((size_t)p * kRingRP + (c % kRingNCH) * kRingCH + r) * NW;
-      uint64_t* out = region_row(PT, p, producer, c * kRingCH + r);
-      for (int w = 0; w < NW; ++w) out[w] = src[w];
+      if (NARROW) {
+        const uint32_t* s32 = (const uint32_t*)L.ring + ((size_t)p * kRingRP + (c % kRingNCH) * kRingCH + r) * 3;
+        uint32_t* o32 = region_row12(PT, p, producer, c * kRingCH + r);
+        for (int w = 0; w < 3; ++w) o32[w] = s32[w];
+      } else {
+        const uint64_t* src = L.ring + ((size_t)p * kRingRP + (c % kRingNCH) * kRingCH + r) * NW;
+        uint64_t* out = region_row(PT, p, producer, c * kRingCH + r);
+        for (int w = 0; w < NW; ++w) out[w] = src[w];
+      }
     }
     if (rem != 0) {
       for (uint32_t r = rem; r < (uint32_t)kRingCH; ++r) {
-        uint64_t* out = region_row(PT, p, producer, c * kRingCH + r);
-        out[0] = kEmptyKey;
-        for (int w = 1; w < NW; ++w) out[w] = 0;
+        if (NARROW) {
+          uint32_t* o32 = region_row12(PT, p, producer, c * kRingCH + r);
+          o32[0] = kTagEmpty;
+          o32[1] = o32[2] = 0;
+        } else {
+          uint64_t* out = region_row(PT, p, producer, c * kRingCH + r);
+          out[0] = kEmptyKey;
+          for (int w = 1; w < NW; ++w) out[w] = 0;
+        }
       }
       f = (c + 1) * kRingCH;
     }
@@ -736,6 +794,7 @@ __global__ __launch_bounds__(kRingBlock) void k_partition_ring(const DevProgram 
   for (int mm = 32; mm >= 1; mm >>= 1) passed += shfl_xor_u64(passed, mm);
   if (lane == 0) stat_add(T, STAT_PASSED, passed);
   if (err) atomicOr(&T.ctrl[CTRL_ERROR], err);
+  snapshot_ctrl_if_last(T, PT);
 }
 
 template <typename POL, typename POLS>  // POLS: the policy flavour used by the write-combining kernel
@@ -747,6 +806,10 @@ void launch_partition_pol(const DevProgram& P, const DevFastPlan& fast, const De
     hipLaunchKernelGGL((k_partition<POL>), dim3(grid), dim3(kPBlock), lds_bytes, s, P, fast, C, plan, T, PT, spill, n);
   else if ((PT.mode & 15u) == 2 && (PT.mode & 0x80u))  // 4-row chunks (64-byte runs)
     hipLaunchKernelGGL((k_partition_ring<POLS, 4, 16>), dim3(grid), dim3(kRingBlock), lds_bytes, s, P, fast, C, plan, T, PT, spill, n);
+  else if ((PT.mode & 15u) == 2 && (PT.flags & PTF_NARROW) && (PT.flags & PTF_HOT))
+    hipLaunchKernelGGL((k_partition_ring<POLS, 8, 16, true, 1>), dim3(grid), dim3(kRingBlock), lds_bytes, s, P, fast, C, plan, T, PT, spill, n);
+  else if ((PT.mode & 15u) == 2 && (PT.flags & PTF_NARROW))  // narrow keys: 12-byte rows
+    hipLaunchKernelGGL((k_partition_ring<POLS, 8, 16, false, 1>), dim3(grid), dim3(kRingBlock), lds_bytes, s, P, fast, C, plan, T, PT, spill, n);
   else if ((PT.mode & 15u) == 2 && (PT.flags & PTF_HOT))  // skewed keys: hot-key pairs in LDS
     hipLaunchKernelGGL((k_partition_ring<POLS, 8, 16, true>), dim3(grid), dim3(kRingBlock), lds_bytes, s, P, fast, C, plan, T, PT, spill, n);
   else if ((PT.mode & 15u) == 2)  // 8-row chunks (full 128-byte lines): ~4 % faster on MI355X

@@ -44,9 +44,24 @@ __host__ __device__ inline uint32_t hash_word(uint64_t k, uint32_t seed) {
   x *= 0xC2B2AE35u;
   return x ^ (x >> 16);
 }
+// hash_word restricted to keys below 2^32 is a bijection of the low word (odd multiplies and xor-shifts, the high
+// word's xor is zero): its inverse, for the seed hash_keys<1> uses.  Multiplicative inverses modulo 2^32.
+constexpr uint32_t kHashSeed0 = 0x9E3779B9u;
+__host__ __device__ inline uint32_t unhash_word32(uint32_t h) {
+  uint32_t x = h;
+  x ^= x >> 16;
+  x *= 0x7ED1B41Du;  // 0xC2B2AE35^-1
+  x ^= x >> 13;
+  x ^= x >> 26;
+  x *= 0xA5CB9243u;  // 0x85EBCA6B^-1
+  x ^= x >> 15;
+  x ^= x >> 30;
+  x *= 0xDEE13BB1u;  // 0xCC9E2D51^-1
+  return x ^ kHashSeed0;
+}
 template <int KW>
 __host__ __device__ inline uint64_t hash_keys(const uint64_t* key) {
-  uint32_t h = hash_word(key[0], 0x9E3779B9u);
+  uint32_t h = hash_word(key[0], kHashSeed0);
 #pragma unroll
   for (int w = 1; w < KW; ++w) h = hash_word(key[w], h);
   return (uint64_t)h << 32;

@@ -109,6 +109,9 @@ struct AggOptions {
   int partition_block = 1024;  // pass-1 workgroup size in mode 1 (512: two workgroups per CU)
   int partition_defer = 4;     // routing regions hold this many worst-case batches (1: pass 2 after every batch)
   int partition_defer_batches = 8;  // at most this many pass-1 launches share one pass 2
+  int ctrl_snapshot = 1;       // partitioned strategy: 1 the batch's last kernel writes the control-block snapshot to pinned host
+                               // memory itself, 0 asynchronous copy on the side stream (round 1)
+  int narrow_keys = -1;        // 12-byte routed rows when the calibration slice saw only keys below 2^32: -1 auto, 0 never
   int partition_layout = 1;    // routing scratch: 1 producer-major, 0 partition-major (DevPartition::prod_stride)
   int partition_producers = 0; // pass-1 workgroups of the ring flavour (0: one per CU)
   int hot_keys = -1;           // pass 1 hot-key pairs in LDS: -1 when the calibration slice saw skew, 0 never, 1 always

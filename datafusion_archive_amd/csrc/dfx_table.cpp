@@ -359,6 +359,13 @@ int64_t dfx_counter_get(const char* name) {
   if (!name) return -1;
   if (!strcmp(name, "h2d_bytes")) return counters().h2d_bytes;
   if (!strcmp(name, "csv_cells")) return counters().csv_cells;
+  if (!strcmp(name, "agg_ctrl_wait_us")) return counters().agg_ctrl_wait_us;
+  if (!strcmp(name, "agg_sync_us")) return counters().agg_sync_us;
+  if (!strcmp(name, "agg_emit_us")) return counters().agg_emit_us;
+  if (!strcmp(name, "agg_drain_us")) return counters().agg_drain_us;
+  if (!strcmp(name, "agg_alloc_us")) return counters().agg_alloc_us;
+  if (!strcmp(name, "agg_pass2_launches")) return counters().agg_pass2_launches;
+  if (!strcmp(name, "agg_growths")) return counters().agg_growths;
   return -1;
 }
 void dfx_counter_reset(void) { counters() = Counters(); }
@@ -385,6 +392,8 @@ int32_t dfx_set_option(const char* key, int64_t value) {
   else if (!strcmp(key, "agg.emit_async")) o.emit_async = (int)value;
   else if (!strcmp(key, "agg.hot_keys")) o.hot_keys = (int)value;
   else if (!strcmp(key, "agg.partition_layout")) o.partition_layout = (int)value;
+  else if (!strcmp(key, "agg.narrow_keys")) o.narrow_keys = (int)value;
+  else if (!strcmp(key, "agg.ctrl_snapshot")) o.ctrl_snapshot = (int)value;
   else if (!strcmp(key, "agg.partition_producers")) o.partition_producers = (int)value;
   else if (!strcmp(key, "pool.trim")) pool_trim();
   else return DFX_GENERAL;

@@ -615,6 +615,61 @@ def test_partitioned_pass1_flavours(mode, skew):
     assert_groups_identical(got, want, 1, f"partition_mode={mode} sentinel key")
 
 
+@pytest.mark.parametrize("hot", [0, 1])
+@pytest.mark.parametrize("layout", [0, 1])
+def test_partitioned_narrow_rows_hot_keys_and_deferred_pass2(hot, layout):
+    """The round-2 flavours of the partitioned strategy against the oracle: 12-byte routed rows {hash image, operand} for
+    keys below 2^32 (the image is a bijection of the key; pass 2 turns claimed images back into keys), hot-key pairs in
+    pass 1, both scratch layouts, pass 2 deferred over several batches -- uniform and skewed keys, with a predicate, SUM
+    (exact) and MIN (ordered image) as the one aggregate, ragged last batch."""
+    ex.set_option("agg.strategy", 3)
+    ex.set_option("agg.narrow_keys", 1)
+    ex.set_option("agg.hot_keys", hot)
+    ex.set_option("agg.partition_layout", layout)
+    ex.set_option("agg.partition_defer", 4)
+    try:
+        schema = pa.schema([("k", pa.int64()), ("v", pa.float64())])
+        pred = BinaryExpr(Column(1), Operator.Lt, lit(700.0))
+        for kind, groups in ((ex.SYNTH_I64_UNIFORM, 300000.0), (ex.SYNTH_I64_ZIPF, 1000000.0)):
+            syn = [("k", kind, 0, groups, 1.0), ("v", ex.SYNTH_F64_EXACT, 1, 0.0, 0.0)]
+            n, seed = (1 << 22) + 12345, 0xDF21
+            t = ex.DeviceTable.synth(syn, seed, 0, n)
+            ob = oracle.synth_batch(syn, seed, 0, n)
+            for a in (agg("sum", Column(1), F64), agg("min", Column(1), F64)):
+                for f in (pred, None):
+                    got = gpu_aggregate([Column(0)], [a], schema, [], source=t.scan(1 << 19), filter_expr=f)
+                    want = oracle.aggregate([Column(0)], [a], [oracle.filter_next(f, ob) if f is not None else ob])
+                    assert_groups_identical(got, want, 1, f"narrow rows hot={hot} layout={layout} kind={kind} {a.name}")
+    finally:
+        for k, v in (("agg.strategy", 0), ("agg.narrow_keys", -1), ("agg.hot_keys", -1), ("agg.partition_layout", 1), ("agg.partition_defer", 4)):
+            ex.set_option(k, v)
+
+
+def test_narrow_rows_fall_back_when_a_wide_key_turns_up():
+    """Narrow mode is an assumption about keys not seen yet.  Keys >= 2^32, negative keys and i64::MIN arriving in later
+    batches go through the spill list, the stream leaves narrow mode, and the groups are still the oracle's."""
+    ex.set_option("agg.strategy", 3)
+    ex.set_option("agg.narrow_keys", 1)
+    try:
+        rng = np.random.default_rng(11)
+        n = 400000
+        k = rng.integers(0, 60000, n).astype(np.int64)
+        v = rng.integers(0, 1 << 20, n).astype(np.float64) / 1024.0
+        k2 = k.copy()
+        k2[::7] += 1 << 32
+        k2[::11] = -k2[::11] - 1
+        k2[::5003] = np.iinfo(np.int64).min
+        b1 = pa.RecordBatch.from_arrays([pa.array(k), pa.array(v)], names=["k", "v"])
+        b2 = pa.RecordBatch.from_arrays([pa.array(k2), pa.array(v)], names=["k", "v"])
+        aggs = [agg("sum", Column(1), F64)]
+        got = gpu_aggregate([Column(0)], aggs, b1.schema, [b1, b2, b1, b2])
+        want = oracle.aggregate([Column(0)], aggs, [b1, b2, b1, b2])
+        assert_groups_identical(got, want, 1, "narrow rows, wide keys later")
+    finally:
+        ex.set_option("agg.strategy", 0)
+        ex.set_option("agg.narrow_keys", -1)
+
+
 def test_aggregate_errors_mirror_reference():
     b = _exact_batch(np.random.default_rng(1), 100, 5)
     fb = pa.RecordBatch.from_arrays([pa.array([1.5, 2.5]), pa.array([1.0, 2.0])], names=["k", "v"])

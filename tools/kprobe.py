@@ -29,9 +29,14 @@ def run():
         rel = ex.AggregateRelation(None, rel, [ex.compile_scalar_expr(None, Column(0), schema)], [ex.compile_expr(None, AggregateFunction("SUM", [Column(1)], DataType.Float64), schema)])
     return rel.next()
 import time
-run(); ex.synchronize(); t0 = time.perf_counter()
-for _ in range(3): out = run()
-ex.synchronize(); dt = (time.perf_counter() - t0) / 3
+run(); ex.synchronize()
+per = []
+ex.counter_reset()
+for _ in range(5):
+    t0 = time.perf_counter(); out = run(); ex.synchronize(); per.append((time.perf_counter() - t0) * 1e3)
+dt = sum(per) / len(per) / 1e3
+print("per-query ms: " + " ".join(f"{x:.2f}" for x in per) + "   host us/query: " + " ".join(
+    f"{k}={ex.counter_get('agg_' + k) / len(per):.0f}" for k in ("ctrl_wait_us", "sync_us", "emit_us", "drain_us", "alloc_us", "pass2_launches", "growths")))
 ex.profile_reset(); ex.profile_enable(True)
 for _ in range(3): out = run()
 ex.profile_enable(False)
