@@ -9,6 +9,7 @@
 //     not fit are spilled and replayed); K8 emits dense arrays at end of input.
 //   A FilterRelation feeding the aggregate (context.rs:126-139,162-192) is absorbed: its predicate
 //   becomes part of the fused program and no filtered batch is ever materialised.
+#include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -1432,7 +1433,36 @@ Status AggregateRelation::partial_build(int world, int* n_words, int64_t* counts
 Status AggregateRelation::partial_export(void* dst_device, int64_t dst_words) {
   Impl& m = *impl_;
   if (m.export_counts.empty()) return Status::Err(DFX_GENERAL, "partial_build must precede partial_export");
-  const int world = (int)m.export_counts.size();
+  std::vector<int64_t> counts(m.export_counts.begin(), m.export_counts.end());
+  return partial_export_with(counts, dst_device, dst_words, true);
+}
+
+// the count step of partial_build with the counts left on the device: d_counts[0, world) = groups per destination
+// rank, d_counts[world, 2 world) = scratch for the counts received from the peers
+Status AggregateRelation::partial_count_device(int world, int* n_words, uint64_t** d_counts, std::shared_ptr<void>* owner) {
+  if (!impl_->dicts.empty())
+    return Status::Err(DFX_NOT_IMPLEMENTED, "multi-GPU exchange of Utf8 GROUP BY keys (dictionary ids are rank-local)");
+  Impl& m = *impl_;
+  if (!m.deferred.ok()) return m.deferred;
+  if (m.kw == 0) return Status::Err(DFX_INTERNAL_ERROR, "partial_count_device is for GROUP BY aggregates");
+  if (world < 1 || world > 1024) return Status::Err(DFX_GENERAL, "world must be in 1..1024");
+  DFX_RETURN_IF_ERROR(m.drain());
+  hipStream_t s = ctx().stream;
+  Status st;
+  *owner = device_alloc(sizeof(uint64_t) * (size_t)world * 2, &st);
+  if (!*owner) return st;
+  DFX_HIP(hipMemsetAsync(owner->get(), 0, sizeof(uint64_t) * (size_t)world * 2, s));
+  DFX_HIP(launch_partial_count(m.T, world, (uint64_t*)owner->get(), s));
+  *d_counts = (uint64_t*)owner->get();
+  *n_words = m.kw + m.na;
+  m.export_counts.assign((size_t)world, 0);  // (filled by partial_export_with)
+  return Status::OK();
+}
+
+Status AggregateRelation::partial_export_with(const std::vector<int64_t>& counts, void* dst_device, int64_t dst_words, bool sync) {
+  Impl& m = *impl_;
+  const int world = (int)counts.size();
+  m.export_counts.assign(counts.begin(), counts.end());
   std::vector<uint64_t> base((size_t)world, 0);
   uint64_t total = 0;
   for (int r = 0; r < world; ++r) {
@@ -1446,12 +1476,96 @@ Status AggregateRelation::partial_export(void* dst_device, int64_t dst_words) {
   auto dbase = device_alloc(sizeof(uint64_t) * (size_t)world * 3, &st);
   if (!dbase) return st;
   uint64_t* d = (uint64_t*)dbase.get();
-  DFX_HIP(hipMemcpyAsync(d, base.data(), sizeof(uint64_t) * (size_t)world, hipMemcpyHostToDevice, s));
-  DFX_HIP(hipMemcpyAsync(d + world, m.export_counts.data(), sizeof(uint64_t) * (size_t)world, hipMemcpyHostToDevice, s));
-  DFX_HIP(hipMemsetAsync(d + 2 * world, 0, sizeof(uint64_t) * (size_t)world, s));
+  {  // bucket bases, bucket counts, zeroed cursors: one blocking copy of 3 x world words (the host vector dies with this scope)
+    std::vector<uint64_t> hw((size_t)world * 3, 0);
+    for (int r = 0; r < world; ++r) {
+      hw[(size_t)r] = base[(size_t)r];
+      hw[(size_t)world + r] = m.export_counts[(size_t)r];
+    }
+    DFX_HIP(hipMemcpy(d, hw.data(), sizeof(uint64_t) * hw.size(), hipMemcpyHostToDevice));
+  }
   if (m.kw == 1) DFX_HIP(launch_fill_u64(m.T.keys + m.T.mask + 1, kEmptyKey, 1, s));
   DFX_HIP(launch_partial_scatter(m.T, world, d, d + world, d + 2 * world, (uint64_t*)dst_device, s));
-  DFX_HIP(hipStreamSynchronize(s));
+  if (sync) {
+    DFX_HIP(hipStreamSynchronize(s));
+  } else {
+    m.table_owners.push_back(dbase);  // the scatter kernel is still queued: keep its base / count words alive
+  }
+  return Status::OK();
+}
+
+static uint64_t host_wrap_to(uint8_t t, uint64_t x) {  // == wrap_to (dfx_kernels_inl.hpp)
+  switch (t) {
+    case DFX_INT8: return (uint64_t)(int64_t)(int8_t)x;
+    case DFX_INT16: return (uint64_t)(int64_t)(int16_t)x;
+    case DFX_INT32: return (uint64_t)(int64_t)(int32_t)x;
+    case DFX_UINT8: return (uint64_t)(uint8_t)x;
+    case DFX_UINT16: return (uint64_t)(uint16_t)x;
+    case DFX_UINT32: return (uint64_t)(uint32_t)x;
+    default: return x;
+  }
+}
+
+// ---- ungrouped aggregates across ranks ---------------------------------------------------------------
+bool AggregateRelation::is_ungrouped() const { return impl_->deferred.ok() && impl_->group.empty(); }
+Status AggregateRelation::ungrouped_state_begin() {
+  Impl& m = *impl_;
+  if (!m.deferred.ok()) return m.deferred;
+  if (m.group.empty() && m.aggr.empty())
+    return Status::Err(DFX_INTERNAL_ERROR, "assertion failed: record batch needs at least one column");
+  return m.drain();
+}
+int AggregateRelation::ungrouped_state_words() const { return 2 * kMaxAggs; }
+const void* AggregateRelation::ungrouped_state_device() const { return impl_->state.get(); }
+
+// AccumulatorSet::accumulate_scalar (aggregate.rs:107-145,176-214,245-283) between the ranks' scalars, folded in rank
+// order: the same arms as the device's batch fold (k_reduce_fold)
+Status AggregateRelation::ungrouped_state_merge(const uint64_t* all, int world, int rank) {
+  (void)rank;
+  Impl& m = *impl_;
+  uint64_t out[2 * kMaxAggs];
+  memset(out, 0, sizeof(out));
+  for (int a = 0; a < m.na; ++a) {
+    const int t = m.arg_dtype[a], f = m.func[a];
+    bool has = false;
+    uint64_t cur = 0;
+    for (int r = 0; r < world; ++r) {
+      const uint64_t* st = all + (size_t)r * 2 * kMaxAggs;
+      if (!st[2 * a]) continue;
+      const uint64_t val = st[2 * a + 1];
+      if (!has) {
+        has = true;
+        cur = val;
+        continue;
+      }
+      if (f == AGG_COUNT) {
+        cur += val;
+      } else if (t == DFX_FLOAT64) {
+        double x, y;
+        memcpy(&x, &cur, 8);
+        memcpy(&y, &val, 8);
+        const double o = f == AGG_MIN ? fmin(x, y) : f == AGG_MAX ? fmax(x, y) : x + y;
+        memcpy(&cur, &o, 8);
+      } else if (t == DFX_FLOAT32) {
+        float x, y;
+        const uint32_t cx = (uint32_t)cur, cy = (uint32_t)val;
+        memcpy(&x, &cx, 4);
+        memcpy(&y, &cy, 4);
+        const float o = f == AGG_MIN ? fminf(x, y) : f == AGG_MAX ? fmaxf(x, y) : x + y;
+        uint32_t ob;
+        memcpy(&ob, &o, 4);
+        cur = ob;
+      } else if (dtype_is_signed(t)) {
+        const int64_t x = (int64_t)cur, y = (int64_t)val;
+        cur = f == AGG_MIN ? (uint64_t)std::min(x, y) : f == AGG_MAX ? (uint64_t)std::max(x, y) : host_wrap_to((uint8_t)t, cur + val);
+      } else {
+        cur = f == AGG_MIN ? std::min(cur, val) : f == AGG_MAX ? std::max(cur, val) : host_wrap_to((uint8_t)t, cur + val);
+      }
+    }
+    out[2 * a] = has ? 1 : 0;
+    out[2 * a + 1] = cur;
+  }
+  DFX_HIP(hipMemcpy(m.state.get(), out, sizeof(out), hipMemcpyHostToDevice));
   return Status::OK();
 }
 

@@ -115,6 +115,7 @@ struct Counters {
   long long agg_emit_us = 0;        // emit_grouped / emit_ungrouped, launch to final synchronisation
   long long agg_drain_us = 0;       // drain(): every batch consumed and settled
   long long agg_alloc_us = 0;       // routing scratch / spill list / table allocation
+  long long export_us = 0;          // device batch -> host Arrow (allocation of the pinned result buffers, D2H, synchronisation)
   long long agg_pass2_launches = 0;
   long long agg_growths = 0;
 };

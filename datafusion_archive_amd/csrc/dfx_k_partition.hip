@@ -2,6 +2,8 @@
 // The pass-1 kernels and the description of the strategy are in dfx_k_partition_inl.hpp; their instantiations are in
 // dfx_k_partition_v0.hip ... _v7.hip.
 #define DFX_PARTITION_MAIN_TU
+#include <type_traits>
+
 #include "dfx_k_partition_inl.hpp"
 
 namespace dfx {
@@ -212,155 +214,58 @@ __global__ __launch_bounds__(kABlock) void k_partition_agg(const DevTable T, con
 }
 
 // ---- pass 2, streaming form --------------------------------------------------------------------------------
-// The kernel above finds the producer region of every flattened row index per lane (float interpolation + LDS
-// prefix reads + 64-bit address arithmetic: ~130 VALU instructions per 64 rows, VALU-issue bound at ~0.4 rows per
-// cycle and CU).  Here a WAVE walks whole regions: wave w owns the regions of producers w, w + 16, ... (their row
-// counts sit in one VGPR, lane j = producer w + 16 j, read back with v_readlane), so the row address is a scalar base
-// plus lane * 16 and the per-row VALU work is the hash, the 4-slot group compare and the LDS atomic.  kPF trips of
-// row loads are in flight per wave (16 waves x kPF KB per CU): with 20 % of 2^26 rows routed the kernel has to read
-// back 0.2 GB in a few tens of microseconds, i.e. it is HBM-latency bound unless the loads run far ahead.
-// Rows whose key is kEmptyKey are padding (pass 1 rounds every region up to whole chunks) and are skipped.
-constexpr int kPF = 4;
+// The kernel above finds the producer region of every flattened row index per lane (float interpolation + LDS prefix
+// reads + 64-bit address arithmetic) and keeps ONE trip of row loads in flight.  Measured (round 2): 4.9 us per million
+// routed rows + ~20 us per launch whatever the row width, the hash or the LDS traffic -- 1.3 us per 64-row trip and
+// wave, i.e. one HBM round trip per trip: the kernel is LATENCY bound, its software pipeline does not pipeline.  (The
+// compiler counts vector-memory operations in ONE in-order counter, vmcnt; the rare spill path's stores and atomics sit
+// in conditional code inside the loop, and after such a join the wait it inserts for the row load is pessimistic.)
+//
+// Here a WAVE walks whole regions -- wave w owns the regions of producers w, w + 16, ... (their row counts sit in one
+// VGPR, lane j = producer w + 16 j, read back with v_readlane), so a row's address is a scalar base plus lane * row
+// bytes -- and the row loads are issued by inline assembly with explicit `s_waitcnt vmcnt(kPF - 1)`: kPF trips (kPF KB
+// per wave, 16 waves per CU) are in flight while a trip is probed, whatever else the loop body contains.  (The compiler
+// does not know these are loads: every register they write is passed through the wait that covers it before it is read,
+// and through a final vmcnt(0) before it dies.)
+// NARROW (PTF_NARROW): 12-byte rows {hash image, operand}.  The LDS copy of the table block then holds a plane of 32-bit
+// TAGS instead of 64-bit keys: tag = hash image of the slot's key (a bijection for keys below 2^32, see ring_route),
+// kTagEmpty for an empty slot, kTagForeign for a slot whose key has no image (>= 2^32, inserted by the general path:
+// occupied, never equal to a row's image).  One 16-byte LDS read shows a whole 4-slot group, the compare is four 32-bit
+// compares, a claim is a 32-bit LDS CAS, the row's slot is its image's top bits (no re-hash); 12 bytes per slot: 96 KB
+// of LDS instead of 128.  Claimed tags become keys again at write-back.
+// Padding rows (pass 1 rounds every region up to whole chunks: key kEmptyKey / image kTagEmpty) are skipped.
+constexpr int kPF = 8;
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x3_t __attribute__((ext_vector_type(3)));
+DEV void row_load_issue(u32x4_t& r, const void* p) { asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(r) : "v"(p) : "memory"); }
+DEV void row_load_issue(u32x3_t& r, const void* p) { asm volatile("global_load_dwordx3 %0, %1, off nt" : "=v"(r) : "v"(p) : "memory"); }
+template <int N, typename R>
+DEV void row_load_wait(R& r) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(r) : "n"(N) : "memory"); }
 
 DEV int pa2_lookup(uint64_t* lkeys, uint32_t S, uint32_t slot, uint64_t kk, uint32_t& new_keys) {
-  int found = -1;
   uint32_t g = slot >> 2;
-  for (uint32_t it = 0; it <= (S >> 2) && found < 0;) {
+  for (uint32_t it = 0; it <= (S >> 2);) {
     const ulonglong2 ka = *(const ulonglong2*)&lkeys[g * 4];
     const ulonglong2 kb = *(const ulonglong2*)&lkeys[g * 4 + 2];
     const uint32_t mm = (ka.x == kk ? 1u : 0u) | (ka.y == kk ? 2u : 0u) | (kb.x == kk ? 4u : 0u) | (kb.y == kk ? 8u : 0u);
-    if (mm) {
-      found = (int)(g * 4 + (uint32_t)__ffs((int)mm) - 1u);
-      break;
-    }
+    if (mm) return (int)(g * 4 + (uint32_t)__ffs((int)mm) - 1u);
     const uint32_t em = (ka.x == kEmptyKey ? 1u : 0u) | (ka.y == kEmptyKey ? 2u : 0u) | (kb.x == kEmptyKey ? 4u : 0u) |
                         (kb.y == kEmptyKey ? 8u : 0u);
     if (em) {
       const uint32_t at = g * 4 + (uint32_t)__ffs((int)em) - 1u;
       const uint64_t old = atomicCAS((unsigned long long*)&lkeys[at], (unsigned long long)kEmptyKey, (unsigned long long)kk);
       if (old == kEmptyKey) {
-        found = (int)at;
         ++new_keys;
-      } else if (old == kk) {
-        found = (int)at;
-      }  // else: another key claimed it meanwhile -- look at the same group again
-    } else {
-      g = (g + 1) & ((S >> 2) - 1);
-      ++it;
+        return (int)at;
+      }
+      if (old == kk) return (int)at;
+      continue;  // another key claimed it meanwhile -- look at the same group again
     }
+    g = (g + 1) & ((S >> 2) - 1);
+    ++it;
   }
-  return found;
+  return -1;
 }
-
-__global__ __launch_bounds__(kABlock) void k_partition_agg_stream(const DevTable T, const DevPartition PT, const DevRows spill) {
-  extern __shared__ __attribute__((aligned(16))) uint64_t lds[];
-  typedef uint64_t u64x2_t __attribute__((ext_vector_type(2)));
-  const uint32_t S = T.block_mask + 1;
-  uint64_t* lkeys = lds;
-  uint64_t* laccs = lds + S;
-  const uint32_t p = blockIdx.x;
-  const uint64_t slot0 = (uint64_t)p * S;
-  const int lane = lane_id();
-  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const uint32_t NP = PT.n_producers;
-  // this wave's regions: producer wave + 16 j lives in lane j
-  const uint32_t my_prod = wave + (uint32_t)(kABlock / 64) * (uint32_t)lane;
-  const uint32_t v_cnt = my_prod < NP ? PT.counts[(uint64_t)p * NP + my_prod] : 0u;
-  // table block -> LDS (16-byte loads, four in flight per lane)
-#pragma unroll
-  for (int w = 0; w < 2; ++w) {
-    const uint64_t* src = (w == 0 ? T.keys : T.accs) + slot0;
-    uint64_t* dst = lds + (size_t)w * S;
-    for (uint32_t i0 = threadIdx.x * 2; i0 < S; i0 += kABlock * 2 * 4) {
-      const uint32_t ia = i0, ib = i0 + kABlock * 2, ic = i0 + kABlock * 4, id = i0 + kABlock * 6;
-      const ulonglong2 ta = *(const ulonglong2*)(src + (ia < S ? ia : 0));
-      const ulonglong2 tb = *(const ulonglong2*)(src + (ib < S ? ib : 0));
-      const ulonglong2 tc = *(const ulonglong2*)(src + (ic < S ? ic : 0));
-      const ulonglong2 td = *(const ulonglong2*)(src + (id < S ? id : 0));
-      if (ia < S) *(ulonglong2*)(dst + ia) = ta;
-      if (ib < S) *(ulonglong2*)(dst + ib) = tb;
-      if (ic < S) *(ulonglong2*)(dst + ic) = tc;
-      if (id < S) *(ulonglong2*)(dst + id) = td;
-    }
-  }
-  const uint64_t* const part_rows = PT.rows + (uint64_t)p * PT.part_stride;
-  const uint64_t region_words = PT.prod_stride;  // words between this partition's regions of consecutive producers
-  // wave-uniform cursor over (region ordinal j, row offset i0)
-  uint32_t s_j = 0, s_i0 = 0;
-  uint32_t s_cnt = (uint32_t)__builtin_amdgcn_readlane((int)v_cnt, 0);
-  const uint32_t n_mine = (NP + (uint32_t)(kABlock / 64) - 1u - wave) / (uint32_t)(kABlock / 64);  // regions of this wave
-  auto fetch = [&](u64x2_t& kv, bool& act) {
-    while (s_i0 >= s_cnt && s_j < n_mine) {  // scalar loop: next non-empty region
-      ++s_j;
-      s_i0 = 0;
-      s_cnt = s_j < n_mine ? (uint32_t)__builtin_amdgcn_readlane((int)v_cnt, (int)(s_j & 63u)) : 0u;
-    }
-    const bool live = s_j < n_mine;
-    act = live && s_i0 + (uint32_t)lane < s_cnt;
-    const uint64_t* base = part_rows + (uint64_t)(wave + (uint32_t)(kABlock / 64) * (live ? s_j : 0u)) * region_words + (uint64_t)(live ? s_i0 : 0u) * 2u;
-    // unconditional load (idle lanes re-read the region's first row): the compiler can count the loads in flight
-    kv = __builtin_nontemporal_load((const u64x2_t*)(base + (act ? (uint32_t)lane * 2u : 0u)));
-    s_i0 += 64;
-  };
-  u64x2_t kv[kPF];
-  bool act[kPF];
-#pragma unroll
-  for (int d = 0; d < kPF; ++d) fetch(kv[d], act[d]);
-  __syncthreads();  // the block is in LDS
-  uint32_t new_keys = 0;
-  const uint8_t kind = T.acc_kind[0];
-  bool more = true;
-  while (more) {
-#pragma unroll
-    for (int d = 0; d < kPF; ++d) {
-      const u64x2_t cur = kv[d];
-      const bool a = act[d];
-      if (__ballot(a) == 0) {  // wave-uniform: the cursor is exhausted (trips are handed out in order)
-        more = false;
-        break;
-      }
-      fetch(kv[d], act[d]);
-      uint64_t key[1] = {cur.x};
-      const bool have = a && cur.x != kEmptyKey;  // padding rows
-      bool todo = have;
-      if (have) {
-        const uint64_t h = hash_keys<1>(key);
-        const uint32_t slot = (uint32_t)((h >> T.shift) & T.mask) & T.block_mask;
-        const int found = pa2_lookup(lkeys, S, slot, cur.x, new_keys);
-        if (found >= 0) {
-          acc_atomic(kind, &laccs[found], cur.y);
-          todo = false;
-        }
-      }
-      if (__ballot(todo) != 0) {  // block full: grow-and-replay takes the row
-        uint64_t sv[kMaxAggs];
-#pragma unroll
-        for (int q = 0; q < kMaxAggs; ++q) sv[q] = q == 0 ? cur.y : 0ull;
-        spill_row<1>(T, spill, todo, key, sv);
-      }
-    }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int w = 0; w < 2; ++w) {
-    uint64_t* dst = (w == 0 ? T.keys : T.accs) + slot0;
-    const uint64_t* src = lds + (size_t)w * S;
-    for (uint32_t i = threadIdx.x * 2; i < S; i += kABlock * 2) *(ulonglong2*)(dst + i) = *(const ulonglong2*)(src + i);
-  }
-#pragma unroll
-  for (int mm = 32; mm >= 1; mm >>= 1) new_keys += __shfl_xor(new_keys, mm, 64);
-  if (lane == 0 && new_keys) atomicAdd(&T.ctrl[CTRL_OCCUPIED], new_keys);
-  if (p == 0 && threadIdx.x == 0) __hip_atomic_store(&T.ctrl[CTRL_MAX_FILL], 0u, RLX_AGENT);  // the regions are empty again
-  snapshot_ctrl_if_last(T, PT);
-}
-
-// ---- pass 2, narrow keys (PTF_NARROW) ---------------------------------------------------------------------------
-// Same region walk as k_partition_agg_stream over 12-byte rows {hash image, operand}.  The LDS copy of the table block
-// holds a plane of 32-bit TAGS instead of 64-bit keys: tag = hash image of the slot's key (a bijection for keys below
-// 2^32, see ring_route), kTagEmpty for an empty slot, kTagForeign for a slot whose key has no image (>= 2^32, inserted
-// by the general path: occupied, never equal to a row's image).  One 16-byte LDS read shows a whole 4-slot group, the
-// compare is four 32-bit compares, a claim is a 32-bit LDS CAS; the row's slot is its image's top bits (no re-hash).
-// 12 bytes per slot: the block takes 96 KB of LDS instead of 128.  Claimed tags become keys again at write-back.
 DEV int pa2n_lookup(uint32_t* ltags, uint32_t S, uint32_t slot, uint32_t img, uint32_t& new_keys) {
   uint32_t g = slot >> 2;
   for (uint32_t it = 0; it <= (S >> 2);) {
@@ -384,40 +289,50 @@ DEV int pa2n_lookup(uint32_t* ltags, uint32_t S, uint32_t slot, uint32_t img, ui
   return -1;
 }
 
-__global__ __launch_bounds__(kABlock) void k_partition_agg_narrow(const DevTable T, const DevPartition PT, const DevRows spill) {
+template <int NARROW>
+__global__ __launch_bounds__(kABlock) void k_partition_agg_pipe(const DevTable T, const DevPartition PT, const DevRows spill) {
   extern __shared__ __attribute__((aligned(16))) uint64_t lds[];
+  typedef typename std::conditional<NARROW != 0, u32x3_t, u32x4_t>::type ROW;
+  constexpr uint32_t kRowDwords = NARROW ? 3u : 4u;
   const uint32_t S = T.block_mask + 1;
-  uint64_t* laccs = lds;                      // [S]
-  uint32_t* ltags = (uint32_t*)(lds + S);     // [S]
+  // wide: keys[S] accs[S]; narrow: accs[S] tags[S]
+  uint64_t* lkeys = lds;
+  uint64_t* laccs = NARROW ? lds : lds + S;
+  uint32_t* ltags = (uint32_t*)(lds + S);
   const uint32_t p = blockIdx.x;
   const uint64_t slot0 = (uint64_t)p * S;
   const int lane = lane_id();
   const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const uint32_t NP = PT.n_producers;
+  // this wave's regions: producer wave + 16 j lives in lane j
   const uint32_t my_prod = wave + (uint32_t)(kABlock / 64) * (uint32_t)lane;
   const uint32_t v_cnt = my_prod < NP ? PT.counts[(uint64_t)p * NP + my_prod] : 0u;
-  // table block -> LDS: accumulators as they are, keys as tags
+  // table block -> LDS
   for (uint32_t i0 = threadIdx.x * 2; i0 < S; i0 += kABlock * 2) {
     const ulonglong2 kk = *(const ulonglong2*)(T.keys + slot0 + i0);
     const ulonglong2 aa = *(const ulonglong2*)(T.accs + slot0 + i0);
     *(ulonglong2*)(laccs + i0) = aa;
-    uint32_t tg[2];
-    const uint64_t k2[2] = {kk.x, kk.y};
+    if (NARROW) {
+      uint32_t tg[2];
+      const uint64_t k2[2] = {kk.x, kk.y};
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      uint64_t key1[1] = {k2[j]};
-      const uint32_t im = (uint32_t)(hash_keys<1>(key1) >> 32);
-      tg[j] = k2[j] == kEmptyKey ? kTagEmpty : (((k2[j] >> 32) != 0 || im >= kTagForeign) ? kTagForeign : im);
+      for (int j = 0; j < 2; ++j) {
+        uint64_t key1[1] = {k2[j]};
+        const uint32_t im = (uint32_t)(hash_keys<1>(key1) >> 32);
+        tg[j] = k2[j] == kEmptyKey ? kTagEmpty : (((k2[j] >> 32) != 0 || im >= kTagForeign) ? kTagForeign : im);
+      }
+      *(uint2*)(ltags + i0) = make_uint2(tg[0], tg[1]);
+    } else {
+      *(ulonglong2*)(lkeys + i0) = kk;
     }
-    *(uint2*)(ltags + i0) = make_uint2(tg[0], tg[1]);
   }
   const uint64_t* const part_rows = PT.rows + (uint64_t)p * PT.part_stride;
+  // wave-uniform cursor over (region ordinal j, row offset i0)
   uint32_t s_j = 0, s_i0 = 0;
   uint32_t s_cnt = (uint32_t)__builtin_amdgcn_readlane((int)v_cnt, 0);
-  const uint32_t n_mine = (NP + (uint32_t)(kABlock / 64) - 1u - wave) / (uint32_t)(kABlock / 64);
-  struct Row12 { uint32_t img, lo, hi; };
-  auto fetch = [&](Row12& r, bool& act) {
-    while (s_i0 >= s_cnt && s_j < n_mine) {
+  const uint32_t n_mine = (NP + (uint32_t)(kABlock / 64) - 1u - wave) / (uint32_t)(kABlock / 64);  // regions of this wave
+  auto fetch = [&](ROW& r, bool& act) {
+    while (s_i0 >= s_cnt && s_j < n_mine) {  // scalar loop: next non-empty region
       ++s_j;
       s_i0 = 0;
       s_cnt = s_j < n_mine ? (uint32_t)__builtin_amdgcn_readlane((int)v_cnt, (int)(s_j & 63u)) : 0u;
@@ -425,45 +340,59 @@ __global__ __launch_bounds__(kABlock) void k_partition_agg_narrow(const DevTable
     const bool live = s_j < n_mine;
     act = live && s_i0 + (uint32_t)lane < s_cnt;
     const uint32_t* base = (const uint32_t*)(part_rows + (uint64_t)(wave + (uint32_t)(kABlock / 64) * (live ? s_j : 0u)) * PT.prod_stride) +
-                           (uint64_t)(live ? s_i0 : 0u) * 3u;
-    const uint32_t* src = base + (act ? (uint32_t)lane * 3u : 0u);  // unconditional load: the compiler counts the loads in flight
-    r.img = __builtin_nontemporal_load(src);
-    r.lo = __builtin_nontemporal_load(src + 1);
-    r.hi = __builtin_nontemporal_load(src + 2);
+                           (uint64_t)(live ? s_i0 : 0u) * kRowDwords;
+    row_load_issue(r, base + (act ? (uint32_t)lane * kRowDwords : 0u));  // idle lanes re-read the region's first row
     s_i0 += 64;
   };
-  Row12 rows[kPF];
+  ROW rows[kPF];
   bool act[kPF];
 #pragma unroll
   for (int d = 0; d < kPF; ++d) fetch(rows[d], act[d]);
   __syncthreads();  // the block is in LDS
   uint32_t new_keys = 0;
   const uint8_t kind = T.acc_kind[0];
-  const int tag_shift = T.shift - 32;  // slot = image >> tag_shift (the image is the hash's high half)
+  const int tag_shift = T.shift - 32;  // narrow: slot = image >> tag_shift (the image is the hash's high half)
   bool more = true;
   while (more) {
 #pragma unroll
     for (int d = 0; d < kPF; ++d) {
-      const Row12 cur = rows[d];
       const bool a = act[d];
-      if (__ballot(a) == 0) {
+      if (__ballot(a) == 0) {  // wave-uniform: the cursor is exhausted (trips are handed out in order)
         more = false;
         break;
       }
+      row_load_wait<kPF - 1>(rows[d]);  // the oldest of the kPF loads in flight has landed
+      const ROW cur = rows[d];
       fetch(rows[d], act[d]);
-      const bool have = a && cur.img != kTagEmpty;  // padding rows
-      const uint64_t val = ((uint64_t)cur.hi << 32) | cur.lo;
+      uint64_t key[1], val;
+      bool have;
+      if (NARROW) {
+        have = a && cur[0] != kTagEmpty;
+        val = ((uint64_t)cur[2] << 32) | cur[1];
+        key[0] = 0;
+      } else {
+        key[0] = ((uint64_t)cur[1] << 32) | cur[0];
+        val = ((uint64_t)cur[NARROW ? 0 : 3] << 32) | cur[2];
+        have = a && key[0] != kEmptyKey;
+      }
       bool todo = have;
       if (have) {
-        const uint32_t slot = (uint32_t)(((uint64_t)cur.img >> tag_shift) & T.mask) & T.block_mask;
-        const int found = pa2n_lookup(ltags, S, slot, cur.img, new_keys);
+        int found;
+        if (NARROW) {
+          const uint32_t slot = (uint32_t)(((uint64_t)cur[0] >> tag_shift) & T.mask) & T.block_mask;
+          found = pa2n_lookup(ltags, S, slot, cur[0], new_keys);
+        } else {
+          const uint64_t h = hash_keys<1>(key);
+          const uint32_t slot = (uint32_t)((h >> T.shift) & T.mask) & T.block_mask;
+          found = pa2_lookup(lkeys, S, slot, key[0], new_keys);
+        }
         if (found >= 0) {
           acc_atomic(kind, &laccs[found], val);
           todo = false;
         }
       }
       if (__ballot(todo) != 0) {  // block full: grow-and-replay takes the row (as a key again)
-        uint64_t key[1] = {(uint64_t)unhash_word32(cur.img)};
+        if (NARROW) key[0] = (uint64_t)unhash_word32(cur[0]);
         uint64_t sv[kMaxAggs];
 #pragma unroll
         for (int q = 0; q < kMaxAggs; ++q) sv[q] = q == 0 ? val : 0ull;
@@ -471,19 +400,25 @@ __global__ __launch_bounds__(kABlock) void k_partition_agg_narrow(const DevTable
       }
     }
   }
+#pragma unroll
+  for (int d = 0; d < kPF; ++d) row_load_wait<0>(rows[d]);  // loads still in flight own these registers until they land
   __syncthreads();
   for (uint32_t i0 = threadIdx.x * 2; i0 < S; i0 += kABlock * 2) {
     *(ulonglong2*)(T.accs + slot0 + i0) = *(const ulonglong2*)(laccs + i0);
-    const uint2 tg = *(const uint2*)(ltags + i0);
-    // a tag that is an image is written back as its key (unchanged for slots that held it before, new for claimed ones);
-    // empty and foreign slots keep what the table holds
-    if (tg.x < kTagForeign) T.keys[slot0 + i0] = (uint64_t)unhash_word32(tg.x);
-    if (tg.y < kTagForeign) T.keys[slot0 + i0 + 1] = (uint64_t)unhash_word32(tg.y);
+    if (NARROW) {
+      const uint2 tg = *(const uint2*)(ltags + i0);
+      // a tag that is an image is written back as its key (unchanged for slots that held it before, new for claimed
+      // ones); empty and foreign slots keep what the table holds
+      if (tg.x < kTagForeign) T.keys[slot0 + i0] = (uint64_t)unhash_word32(tg.x);
+      if (tg.y < kTagForeign) T.keys[slot0 + i0 + 1] = (uint64_t)unhash_word32(tg.y);
+    } else {
+      *(ulonglong2*)(T.keys + slot0 + i0) = *(const ulonglong2*)(lkeys + i0);
+    }
   }
 #pragma unroll
   for (int mm = 32; mm >= 1; mm >>= 1) new_keys += __shfl_xor(new_keys, mm, 64);
   if (lane == 0 && new_keys) atomicAdd(&T.ctrl[CTRL_OCCUPIED], new_keys);
-  if (p == 0 && threadIdx.x == 0) __hip_atomic_store(&T.ctrl[CTRL_MAX_FILL], 0u, RLX_AGENT);
+  if (p == 0 && threadIdx.x == 0) __hip_atomic_store(&T.ctrl[CTRL_MAX_FILL], 0u, RLX_AGENT);  // the regions are empty again
   snapshot_ctrl_if_last(T, PT);
 }
 
@@ -567,9 +502,9 @@ hipError_t launch_partition_agg(const DevTable& T, const DevPartition& PT, const
   if (lds_bytes > 160 * 1024 - 256 || PT.n_producers > 1024) return hipErrorInvalidValue;
   if (PT.flags & PTF_NARROW) {
     if (T.na != 1 || T.kw != 1) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_partition_agg_narrow, dim3(PT.n_parts), dim3(kABlock), (size_t)(T.block_mask + 1) * 12, s, T, PT, spill);
+    hipLaunchKernelGGL(k_partition_agg_pipe<1>, dim3(PT.n_parts), dim3(kABlock), (size_t)(T.block_mask + 1) * 12, s, T, PT, spill);
   } else if (T.na == 1 && (PT.flags & PTF_STREAM_PASS2) && PT.n_words == 2)
-    hipLaunchKernelGGL(k_partition_agg_stream, dim3(PT.n_parts), dim3(kABlock), (size_t)(T.block_mask + 1) * 16, s, T, PT, spill);
+    hipLaunchKernelGGL(k_partition_agg_pipe<0>, dim3(PT.n_parts), dim3(kABlock), (size_t)(T.block_mask + 1) * 16, s, T, PT, spill);
   else if (T.na == 1) hipLaunchKernelGGL(k_partition_agg<1>, dim3(PT.n_parts), dim3(kABlock), lds_bytes, s, T, PT, spill);
   else hipLaunchKernelGGL(k_partition_agg<0>, dim3(PT.n_parts), dim3(kABlock), lds_bytes, s, T, PT, spill);
   return hipGetLastError();

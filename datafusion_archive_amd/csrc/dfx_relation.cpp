@@ -292,6 +292,7 @@ Status download_column(const DeviceColumn& c, struct ArrowArray* out, std::vecto
 }
 
 Status download_batch(const DeviceBatch& b, struct ArrowArray* out) {
+  ScopedUs t_export(&counters().export_us);
   ArrayPriv* p = new ArrayPriv();
   memset(out, 0, sizeof(*out));
   out->private_data = p;

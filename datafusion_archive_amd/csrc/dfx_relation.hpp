@@ -8,6 +8,8 @@
 #include "dfx_host.hpp"
 #include "dfx_kernels.hpp"
 
+struct dfx_comm;
+
 namespace dfx {
 
 // ---- stream adapters --------------------------------------------------------------------------
@@ -139,6 +141,16 @@ class AggregateRelation : public Relation {
   Status partial_build(int world, int* n_words, int64_t* counts);
   Status partial_export(void* dst_device, int64_t dst_words);
   Status partial_import(const void* src_device, const int64_t* counts, int n_buckets);
+  // the whole exchange inside the library over RCCL (dfx_exchange.cpp; include/dfx.h: dfx_aggregate_exchange)
+  Status exchange(struct ::dfx_comm* comm, int64_t* stats);
+  // pieces of the exchange that need the operator's state
+  bool is_ungrouped() const;
+  Status ungrouped_state_begin();                    // drains the input
+  int ungrouped_state_words() const;                 // 2 words per accumulator slot: has-value flag, value bits
+  const void* ungrouped_state_device() const;
+  Status ungrouped_state_merge(const uint64_t* all_states, int world, int rank);  // fold the ranks' states, in rank order
+  Status partial_count_device(int world, int* n_words, uint64_t** d_counts, std::shared_ptr<void>* owner);  // counts stay on the device
+  Status partial_export_with(const std::vector<int64_t>& counts, void* dst_device, int64_t dst_words, bool sync);
 
   struct Impl;
 

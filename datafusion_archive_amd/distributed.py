@@ -6,13 +6,31 @@ on hash(key): every rank aggregates its own row range into a local table (K7), b
 the buckets over xGMI (torch.distributed backend "nccl" == RCCL), each rank merges the buckets it
 received and emits the groups it owns.  Exchange volume is O(groups), never O(rows).
 
-torch / torch.distributed are plumbing here (buffers + the collective); the aggregate object only
-needs partial_build / partial_export / partial_import, so the CPU tests drive the same function over
-gloo with an oracle-backed stand-in.
+Two drivers of the same protocol:
+
+* `library_communicator` + `Communicator.exchange(agg)` -- the exchange INSIDE the library (dfx_aggregate_exchange:
+  grouped ncclSend/ncclRecv on the library's stream, one host read-back); torch.distributed only carries the 128-byte
+  RCCL unique id from rank 0 to the other ranks once per process.  This is what bench.py --gpus N runs.
+* `exchange_group_partials` -- the three device steps (partial_build / partial_export / partial_import) with the
+  collective done by the HOST plumbing (torch.distributed all_to_all_single; gloo on CPU).  The aggregate object only
+  needs those three methods, so the CPU tests drive this function over gloo with an oracle-backed stand-in, and
+  bench.py falls back to it if RCCL cannot be bound at run time.
 """
 from __future__ import annotations
 
 from typing import Sequence
+
+
+def library_communicator(world: int, rank: int, dist=None):
+    """One RCCL communicator owned by the library for this process: rank 0 draws the unique id, torch.distributed (any
+    backend) broadcasts its 128 bytes, every rank calls dfx_comm_init on the library's device."""
+    from . import execution as ex
+    uid = [ex.Communicator.unique_id() if rank == 0 else None]
+    if world > 1:
+        if dist is None:
+            import torch.distributed as dist  # type: ignore
+        dist.broadcast_object_list(uid, src=0)
+    return ex.Communicator(uid[0], world, rank)
 
 
 def exchange_group_partials(agg, world: int, device, dist=None, torch=None) -> dict:

@@ -315,6 +315,49 @@ class AggregateRelation(Relation):
                                               len(counts), err, 1024), err)
 
 
+class Communicator:
+    """RCCL communicator owned by the library (include/dfx.h: dfx_comm_*), one per process/GPU.  `unique_id()` on rank 0,
+    hand the 128 bytes to every rank (any host channel), then `Communicator(id, world, rank)` everywhere."""
+
+    COMM_ID_BYTES = 128
+
+    @staticmethod
+    def unique_id() -> bytes:
+        L = _ffi.lib()
+        buf = ctypes.create_string_buffer(Communicator.COMM_ID_BYTES)
+        err = _errbuf()
+        _check(L.dfx_comm_unique_id(buf, err, 1024), err)
+        return buf.raw
+
+    def __init__(self, unique_id: bytes, world: int, rank: int):
+        L = _ffi.lib()
+        assert len(unique_id) == Communicator.COMM_ID_BYTES
+        self._h = ctypes.c_void_p()
+        self.world, self.rank = world, rank
+        err = _errbuf()
+        _check(L.dfx_comm_init(ctypes.create_string_buffer(unique_id, Communicator.COMM_ID_BYTES), world, rank,
+                               ctypes.byref(self._h), err, 1024), err)
+
+    def exchange(self, agg: "AggregateRelation") -> dict:
+        """dfx_aggregate_exchange: counts + buckets over RCCL inside the library; then agg.next() emits the owned groups."""
+        L = _ffi.lib()
+        stats = (ctypes.c_int64 * 4)()
+        err = _errbuf()
+        _check(L.dfx_aggregate_exchange(ctypes.byref(agg._live_stream()), self._h, stats, err, 1024), err)
+        return {"sent_groups": stats[0], "received_groups": stats[1], "sent_bytes": stats[2], "host_syncs": stats[3]}
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) and self._h.value:
+            _ffi.lib().dfx_comm_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 # ---------------------------------------------------------------------------------------------------
 # HBM-resident tables (the in-memory DataSource)
 # ---------------------------------------------------------------------------------------------------

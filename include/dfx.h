@@ -322,6 +322,24 @@ int32_t dfx_aggregate_partial_import(struct ArrowArrayStream* agg, const void* s
                                      const int64_t* counts, int32_t n_buckets, char* err,
                                      size_t errlen);
 
+/* The same exchange as ONE library call over RCCL (counts, then variable-length buckets, as
+ * grouped ncclSend/ncclRecv on the library's stream; xGMI between the GPUs of a node).  One process per GPU:
+ *   rank 0:      dfx_comm_unique_id(id)           -- ncclGetUniqueId; the host plumbing hands `id` to every rank
+ *   every rank:  dfx_comm_init(id, world, rank)   -- ncclCommInitRank on the library's device (dfx_init)
+ *   per query:   dfx_aggregate_exchange(agg, comm, stats)  then get_next() emits the groups this rank owns
+ * dfx_aggregate_exchange drains the input, counts the groups per owner rank, exchanges counts and buckets, and replaces
+ * the stream's table by the merge of what it received -- one host read-back (the buffer sizes) plus the final
+ * synchronisation.  Ungrouped aggregates are combined with an all-gather of the per-rank scalars (every rank then emits
+ * the global row).  stats (may be NULL): [0] groups sent, [1] groups received, [2] bytes sent, [3] host synchronisations.
+ * RCCL is bound at run time (dlopen librccl.so.1); without it these calls return ExecutionError.  Utf8 keys:
+ * NotImplemented (dictionary ids are rank-local). */
+#define DFX_COMM_ID_BYTES 128
+typedef struct dfx_comm dfx_comm;
+int32_t dfx_comm_unique_id(uint8_t* id /* [DFX_COMM_ID_BYTES] */, char* err, size_t errlen);
+int32_t dfx_comm_init(const uint8_t* id, int32_t world, int32_t rank, dfx_comm** out, char* err, size_t errlen);
+void dfx_comm_destroy(dfx_comm* comm);
+int32_t dfx_aggregate_exchange(struct ArrowArrayStream* agg, dfx_comm* comm, int64_t* stats, char* err, size_t errlen);
+
 /* ------------------------------------------------------------------------------------------
  * Measurement hooks (used by bench.py; not part of the drop-in surface).
  * ---------------------------------------------------------------------------------------- */

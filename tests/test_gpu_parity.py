@@ -670,6 +670,37 @@ def test_narrow_rows_fall_back_when_a_wide_key_turns_up():
         ex.set_option("agg.narrow_keys", -1)
 
 
+def test_library_exchange_over_rccl_world_1():
+    """dfx_comm_* / dfx_aggregate_exchange with a one-rank RCCL communicator on this GPU: the library binds RCCL at run
+    time, creates the communicator on its own device, runs count -> (self) exchange -> merge on its stream, and the
+    emitted groups are the oracle's; ungrouped aggregates go through the scalar path (all ranks' states folded)."""
+    from datafusion_archive_amd.distributed import library_communicator
+    comm = library_communicator(1, 0)
+    try:
+        syn = [("k", ex.SYNTH_I64_UNIFORM, 0, 200000.0, 0.0), ("v", ex.SYNTH_F64_EXACT, 1, 0.0, 0.0)]
+        n, seed = 3 * (1 << 19), 0xDF09
+        schema = pa.schema([("k", pa.int64()), ("v", pa.float64())])
+        aggs = [agg("sum", Column(1), F64), agg("count", Column(1), DataType.UInt64), agg("max", Column(1), F64)]
+        pred = BinaryExpr(Column(1), Operator.Lt, lit(700.0))
+        t = ex.DeviceTable.synth(syn, seed, 0, n)
+        ob = oracle.synth_batch(syn, seed, 0, n)
+        for group in ([Column(0)], []):
+            rel = ex.FilterRelation(t.scan(1 << 18), ex.compile_scalar_expr(None, pred, schema), schema)
+            rel = ex.AggregateRelation(None, rel, [ex.compile_scalar_expr(None, g, schema) for g in group],
+                                       [ex.compile_expr(None, a, schema) for a in aggs])
+            stats = comm.exchange(rel)
+            got = rel.next()
+            assert rel.next() is None
+            want = oracle.aggregate(group, aggs, [oracle.filter_next(pred, ob)])
+            if group:
+                assert stats["sent_groups"] == stats["received_groups"] == want.num_rows and stats["host_syncs"] <= 2
+                assert_groups_identical(got, want, 1, "library exchange, world 1")
+            else:
+                assert_batches_identical(got, want, "library exchange, ungrouped, world 1")
+    finally:
+        comm.close()
+
+
 def test_aggregate_errors_mirror_reference():
     b = _exact_batch(np.random.default_rng(1), 100, 5)
     fb = pa.RecordBatch.from_arrays([pa.array([1.5, 2.5]), pa.array([1.0, 2.0])], names=["k", "v"])
