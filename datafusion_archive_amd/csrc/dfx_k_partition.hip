@@ -2,8 +2,6 @@
 // The pass-1 kernels and the description of the strategy are in dfx_k_partition_inl.hpp; their instantiations are in
 // dfx_k_partition_v0.hip ... _v7.hip.
 #define DFX_PARTITION_MAIN_TU
-#include <type_traits>
-
 #include "dfx_k_partition_inl.hpp"
 
 namespace dfx {
@@ -214,33 +212,84 @@ __global__ __launch_bounds__(kABlock) void k_partition_agg(const DevTable T, con
 }
 
 // ---- pass 2, streaming form --------------------------------------------------------------------------------
-// The kernel above finds the producer region of every flattened row index per lane (float interpolation + LDS prefix
-// reads + 64-bit address arithmetic) and keeps ONE trip of row loads in flight.  Measured (round 2): 4.9 us per million
-// routed rows + ~20 us per launch whatever the row width, the hash or the LDS traffic -- 1.3 us per 64-row trip and
-// wave, i.e. one HBM round trip per trip: the kernel is LATENCY bound, its software pipeline does not pipeline.  (The
-// compiler counts vector-memory operations in ONE in-order counter, vmcnt; the rare spill path's stores and atomics sit
-// in conditional code inside the loop, and after such a join the wait it inserts for the row load is pessimistic.)
+// What round 2 measured about the kernel above (and two rewrites of it): 4.9 us per million routed rows + ~20 us per
+// launch WHATEVER the row width (16 / 12 bytes), the hash (3 multiplies / none), the LDS traffic per probe (32 / 16
+// bytes) or the depth of the row prefetch -- 1.3 us per 64-row trip and wave.  The disassembly says why: ~110 vector,
+// ~180 scalar and ~45 branch instructions per trip (divergent find-or-claim with its EXEC bookkeeping, a run-time switch
+// over the accumulator kind, spill checks, 64-bit address arithmetic).  A wave issues one instruction at a time and a
+// SIMD one scalar instruction per cycle across its four waves: the loop is bound by instruction ISSUE, mostly scalar.
 //
-// Here a WAVE walks whole regions -- wave w owns the regions of producers w, w + 16, ... (their row counts sit in one
-// VGPR, lane j = producer w + 16 j, read back with v_readlane), so a row's address is a scalar base plus lane * row
-// bytes -- and the row loads are issued by inline assembly with explicit `s_waitcnt vmcnt(kPF - 1)`: kPF trips (kPF KB
-// per wave, 16 waves per CU) are in flight while a trip is probed, whatever else the loop body contains.  (The compiler
-// does not know these are loads: every register they write is passed through the wait that covers it before it is read,
-// and through a final vmcnt(0) before it dies.)
-// NARROW (PTF_NARROW): 12-byte rows {hash image, operand}.  The LDS copy of the table block then holds a plane of 32-bit
-// TAGS instead of 64-bit keys: tag = hash image of the slot's key (a bijection for keys below 2^32, see ring_route),
-// kTagEmpty for an empty slot, kTagForeign for a slot whose key has no image (>= 2^32, inserted by the general path:
-// occupied, never equal to a row's image).  One 16-byte LDS read shows a whole 4-slot group, the compare is four 32-bit
-// compares, a claim is a 32-bit LDS CAS, the row's slot is its image's top bits (no re-hash); 12 bytes per slot: 96 KB
-// of LDS instead of 128.  Claimed tags become keys again at write-back.
+// k_partition_agg_lean is the same algorithm with a short common path:
+//   * a WAVE walks whole regions (wave w owns the regions of producers w, w + 16, ...; their row counts sit in one VGPR,
+//     lane j = producer w + 16 j, read back with v_readlane), so a row's address is a scalar base + lane * row bytes;
+//   * the accumulator kind is a template parameter;
+//   * FAST PATH, branch-free: the row's home group of four slots is read (one 16-byte LDS read of 32-bit tags, or two of
+//     64-bit keys), four compares, the matching slot picked with v_cndmask, one LDS atomic under the match mask; rows that
+//     did not match look at the NEXT group the same way.  In a table that has seen its keys (every batch but the first)
+//     99.7 % of the rows end here;
+//   * only if a lane is still unmatched (empty slot to claim, longer probe sequence, full block) the wave takes the
+//     general find-or-claim for those lanes (same probe order as the global kernels: the block stays a valid
+//     linear-probing table);
+//   * the row loads of kPF trips are in flight per wave.  The compiler tracks vector-memory results with ONE in-order
+//     counter (vmcnt) and is pessimistic after conditional code that contains memory operations, so the loads are
+//     issued by inline assembly into VGPRs v88..v119, which the kernel withholds from the register allocator
+//     (amdgpu_num_vgpr(88)): nothing the compiler generates can read or reuse them while a load is in flight, and
+//     `s_waitcnt vmcnt(kPF - 1)` + v_mov hands a landed row over.  (A first version let the compiler allocate those
+//     registers and tied them through the wait with a "+v" constraint; it copied half of an in-flight row BEFORE the wait.)
+// NARROW (PTF_NARROW): 12-byte rows {hash image, operand}; the LDS block holds 32-bit TAGS instead of keys: tag = hash
+// image of the slot's key (a bijection for keys below 2^32, see ring_route), kTagEmpty for an empty slot, kTagForeign for
+// a slot whose key has no image (>= 2^32, inserted by the general path: occupied, never equal to a row's image).  12
+// bytes per slot: 96 KB of LDS instead of 128; claimed tags become keys again at write-back.
 // Padding rows (pass 1 rounds every region up to whole chunks: key kEmptyKey / image kTagEmpty) are skipped.
 constexpr int kPF = 8;
-typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-typedef uint32_t u32x3_t __attribute__((ext_vector_type(3)));
-DEV void row_load_issue(u32x4_t& r, const void* p) { asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(r) : "v"(p) : "memory"); }
-DEV void row_load_issue(u32x3_t& r, const void* p) { asm volatile("global_load_dwordx3 %0, %1, off nt" : "=v"(r) : "v"(p) : "memory"); }
-template <int N, typename R>
-DEV void row_load_wait(R& r) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(r) : "n"(N) : "memory"); }
+constexpr int kP2Vgprs = 88;  // v88..v119: kPF x 4 registers of in-flight rows, outside the register allocator's reach
+struct Row4 { uint32_t x, y, z, w; };
+template <int D, int NARROW>
+DEV void p2_issue(uint32_t voff, const void* base) {
+  if constexpr (NARROW != 0) {
+  if constexpr (D == 0) asm volatile("global_load_dwordx3 v[88:90], %0, %1 nt" ::"v"(voff), "s"(base) : "memory", "v88", "v89", "v90");
+  else if constexpr (D == 1) asm volatile("global_load_dwordx3 v[92:94], %0, %1 nt" ::"v"(voff), "s"(base) : "memory", "v92", "v93", "v94");
+  else if constexpr (D == 2) asm volatile("global_load_dwordx3 v[96:98], %0, %1 nt" ::"v"(voff), "s"(base) : "memory", "v96", "v97", "v98");
+  else if constexpr (D == 3) asm volatile("global_load_dwordx3 v[100:102], %0, %1 nt" ::"v"(voff), "s"(base) : "memory", "v100", "v101", "v102");
+  else if constexpr (D == 4) asm volatile("global_load_dwordx3 v[104:106], %0, %1 nt" ::"v"(voff), "s"(base) : "memory", "v104", "v105", "v106");
+  else if constexpr (D == 5) asm volatile("global_load_dwordx3 v[108:110], %0, %1 nt" ::"v"(voff), "s"(base) : "memory", "v108", "v109", "v110");
+  else if constexpr (D == 6) asm volatile("global_load_dwordx3 v[112:114], %0, %1 nt" ::"v"(voff), "s"(base) : "memory", "v112", "v113", "v114");
+  else if constexpr (D == 7) asm volatile("global_load_dwordx3 v[116:118], %0, %1 nt" ::"v"(voff), "s"(base) : "memory", "v116", "v117", "v118");
+  } else {
+  if constexpr (D == 0) asm volatile("global_load_dwordx4 v[88:91], %0, %1 nt" ::"v"(voff), "s"(base) : "memory", "v88", "v89", "v90", "v91");
+  else if constexpr (D == 1) asm volatile("global_load_dwordx4 v[92:95], %0, %1 nt" ::"v"(voff), "s"(base) : "memory", "v92", "v93", "v94", "v95");
+  else if constexpr (D == 2) asm volatile("global_load_dwordx4 v[96:99], %0, %1 nt" ::"v"(voff), "s"(base) : "memory", "v96", "v97", "v98", "v99");
+  else if constexpr (D == 3) asm volatile("global_load_dwordx4 v[100:103], %0, %1 nt" ::"v"(voff), "s"(base) : "memory", "v100", "v101", "v102", "v103");
+  else if constexpr (D == 4) asm volatile("global_load_dwordx4 v[104:107], %0, %1 nt" ::"v"(voff), "s"(base) : "memory", "v104", "v105", "v106", "v107");
+  else if constexpr (D == 5) asm volatile("global_load_dwordx4 v[108:111], %0, %1 nt" ::"v"(voff), "s"(base) : "memory", "v108", "v109", "v110", "v111");
+  else if constexpr (D == 6) asm volatile("global_load_dwordx4 v[112:115], %0, %1 nt" ::"v"(voff), "s"(base) : "memory", "v112", "v113", "v114", "v115");
+  else if constexpr (D == 7) asm volatile("global_load_dwordx4 v[116:119], %0, %1 nt" ::"v"(voff), "s"(base) : "memory", "v116", "v117", "v118", "v119");
+  }
+}
+template <int D, int NARROW, int N>
+DEV void p2_take(Row4& r) {  // waits until at most N younger loads are in flight, then copies slot D out
+  if constexpr (NARROW != 0) {
+    r.w = 0;
+  if constexpr (D == 0) asm volatile("s_waitcnt vmcnt(%3)\n\tv_mov_b32 %0, v88\n\tv_mov_b32 %1, v89\n\tv_mov_b32 %2, v90" : "=v"(r.x), "=v"(r.y), "=v"(r.z) : "n"(N) : "memory");
+  else if constexpr (D == 1) asm volatile("s_waitcnt vmcnt(%3)\n\tv_mov_b32 %0, v92\n\tv_mov_b32 %1, v93\n\tv_mov_b32 %2, v94" : "=v"(r.x), "=v"(r.y), "=v"(r.z) : "n"(N) : "memory");
+  else if constexpr (D == 2) asm volatile("s_waitcnt vmcnt(%3)\n\tv_mov_b32 %0, v96\n\tv_mov_b32 %1, v97\n\tv_mov_b32 %2, v98" : "=v"(r.x), "=v"(r.y), "=v"(r.z) : "n"(N) : "memory");
+  else if constexpr (D == 3) asm volatile("s_waitcnt vmcnt(%3)\n\tv_mov_b32 %0, v100\n\tv_mov_b32 %1, v101\n\tv_mov_b32 %2, v102" : "=v"(r.x), "=v"(r.y), "=v"(r.z) : "n"(N) : "memory");
+  else if constexpr (D == 4) asm volatile("s_waitcnt vmcnt(%3)\n\tv_mov_b32 %0, v104\n\tv_mov_b32 %1, v105\n\tv_mov_b32 %2, v106" : "=v"(r.x), "=v"(r.y), "=v"(r.z) : "n"(N) : "memory");
+  else if constexpr (D == 5) asm volatile("s_waitcnt vmcnt(%3)\n\tv_mov_b32 %0, v108\n\tv_mov_b32 %1, v109\n\tv_mov_b32 %2, v110" : "=v"(r.x), "=v"(r.y), "=v"(r.z) : "n"(N) : "memory");
+  else if constexpr (D == 6) asm volatile("s_waitcnt vmcnt(%3)\n\tv_mov_b32 %0, v112\n\tv_mov_b32 %1, v113\n\tv_mov_b32 %2, v114" : "=v"(r.x), "=v"(r.y), "=v"(r.z) : "n"(N) : "memory");
+  else if constexpr (D == 7) asm volatile("s_waitcnt vmcnt(%3)\n\tv_mov_b32 %0, v116\n\tv_mov_b32 %1, v117\n\tv_mov_b32 %2, v118" : "=v"(r.x), "=v"(r.y), "=v"(r.z) : "n"(N) : "memory");
+  } else {
+  if constexpr (D == 0) asm volatile("s_waitcnt vmcnt(%4)\n\tv_mov_b32 %0, v88\n\tv_mov_b32 %1, v89\n\tv_mov_b32 %2, v90\n\tv_mov_b32 %3, v91" : "=v"(r.x), "=v"(r.y), "=v"(r.z), "=v"(r.w) : "n"(N) : "memory");
+  else if constexpr (D == 1) asm volatile("s_waitcnt vmcnt(%4)\n\tv_mov_b32 %0, v92\n\tv_mov_b32 %1, v93\n\tv_mov_b32 %2, v94\n\tv_mov_b32 %3, v95" : "=v"(r.x), "=v"(r.y), "=v"(r.z), "=v"(r.w) : "n"(N) : "memory");
+  else if constexpr (D == 2) asm volatile("s_waitcnt vmcnt(%4)\n\tv_mov_b32 %0, v96\n\tv_mov_b32 %1, v97\n\tv_mov_b32 %2, v98\n\tv_mov_b32 %3, v99" : "=v"(r.x), "=v"(r.y), "=v"(r.z), "=v"(r.w) : "n"(N) : "memory");
+  else if constexpr (D == 3) asm volatile("s_waitcnt vmcnt(%4)\n\tv_mov_b32 %0, v100\n\tv_mov_b32 %1, v101\n\tv_mov_b32 %2, v102\n\tv_mov_b32 %3, v103" : "=v"(r.x), "=v"(r.y), "=v"(r.z), "=v"(r.w) : "n"(N) : "memory");
+  else if constexpr (D == 4) asm volatile("s_waitcnt vmcnt(%4)\n\tv_mov_b32 %0, v104\n\tv_mov_b32 %1, v105\n\tv_mov_b32 %2, v106\n\tv_mov_b32 %3, v107" : "=v"(r.x), "=v"(r.y), "=v"(r.z), "=v"(r.w) : "n"(N) : "memory");
+  else if constexpr (D == 5) asm volatile("s_waitcnt vmcnt(%4)\n\tv_mov_b32 %0, v108\n\tv_mov_b32 %1, v109\n\tv_mov_b32 %2, v110\n\tv_mov_b32 %3, v111" : "=v"(r.x), "=v"(r.y), "=v"(r.z), "=v"(r.w) : "n"(N) : "memory");
+  else if constexpr (D == 6) asm volatile("s_waitcnt vmcnt(%4)\n\tv_mov_b32 %0, v112\n\tv_mov_b32 %1, v113\n\tv_mov_b32 %2, v114\n\tv_mov_b32 %3, v115" : "=v"(r.x), "=v"(r.y), "=v"(r.z), "=v"(r.w) : "n"(N) : "memory");
+  else if constexpr (D == 7) asm volatile("s_waitcnt vmcnt(%4)\n\tv_mov_b32 %0, v116\n\tv_mov_b32 %1, v117\n\tv_mov_b32 %2, v118\n\tv_mov_b32 %3, v119" : "=v"(r.x), "=v"(r.y), "=v"(r.z), "=v"(r.w) : "n"(N) : "memory");
+  }
+}
+DEV void p2_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 DEV int pa2_lookup(uint64_t* lkeys, uint32_t S, uint32_t slot, uint64_t kk, uint32_t& new_keys) {
   uint32_t g = slot >> 2;
@@ -289,11 +338,32 @@ DEV int pa2n_lookup(uint32_t* ltags, uint32_t S, uint32_t slot, uint32_t img, ui
   return -1;
 }
 
-template <int NARROW>
-__global__ __launch_bounds__(kABlock) void k_partition_agg_pipe(const DevTable T, const DevPartition PT, const DevRows spill) {
+// branch-free look at ONE aligned group of four slots: index of the slot that holds the row's key / image, or -1
+DEV int p2_match_group_tags(const uint32_t* ltags, uint32_t slot4, uint32_t img) {
+  const uint4 t = *(const uint4*)&ltags[slot4];
+  int idx = -1;
+  idx = t.w == img ? 3 : idx;
+  idx = t.z == img ? 2 : idx;
+  idx = t.y == img ? 1 : idx;
+  idx = t.x == img ? 0 : idx;
+  return idx;
+}
+DEV int p2_match_group_keys(const uint64_t* lkeys, uint32_t slot4, uint64_t kk) {
+  const ulonglong2 ka = *(const ulonglong2*)&lkeys[slot4];
+  const ulonglong2 kb = *(const ulonglong2*)&lkeys[slot4 + 2];
+  int idx = -1;
+  idx = kb.y == kk ? 3 : idx;
+  idx = kb.x == kk ? 2 : idx;
+  idx = ka.y == kk ? 1 : idx;
+  idx = ka.x == kk ? 0 : idx;
+  return idx;
+}
+
+template <int NARROW, int KIND>
+__global__ __launch_bounds__(kABlock) __attribute__((amdgpu_num_vgpr(kP2Vgprs))) void k_partition_agg_lean(const DevTable T, const DevPartition PT,
+                                                                                                             const DevRows spill) {
   extern __shared__ __attribute__((aligned(16))) uint64_t lds[];
-  typedef typename std::conditional<NARROW != 0, u32x3_t, u32x4_t>::type ROW;
-  constexpr uint32_t kRowDwords = NARROW ? 3u : 4u;
+  constexpr uint32_t kRowBytes = NARROW ? 12u : 16u;
   const uint32_t S = T.block_mask + 1;
   // wide: keys[S] accs[S]; narrow: accs[S] tags[S]
   uint64_t* lkeys = lds;
@@ -326,82 +396,111 @@ __global__ __launch_bounds__(kABlock) void k_partition_agg_pipe(const DevTable T
       *(ulonglong2*)(lkeys + i0) = kk;
     }
   }
-  const uint64_t* const part_rows = PT.rows + (uint64_t)p * PT.part_stride;
-  // wave-uniform cursor over (region ordinal j, row offset i0)
-  uint32_t s_j = 0, s_i0 = 0;
-  uint32_t s_cnt = (uint32_t)__builtin_amdgcn_readlane((int)v_cnt, 0);
+  p2_drain();  // (the block's loads have landed anyway; from here on vmcnt belongs to the row loads below)
+  // wave-uniform cursor: region ordinal, rows left in it, address of the next trip's first row
+  const uint8_t* const part_bytes = (const uint8_t*)(PT.rows + (uint64_t)p * PT.part_stride);
+  const uint64_t prod_bytes = PT.prod_stride * 8ull;
+  const uint8_t* const safe_ptr = part_bytes + (uint64_t)wave * prod_bytes;  // always a readable trip (>= 64 rows per region)
   const uint32_t n_mine = (NP + (uint32_t)(kABlock / 64) - 1u - wave) / (uint32_t)(kABlock / 64);  // regions of this wave
-  auto fetch = [&](ROW& r, bool& act) {
-    while (s_i0 >= s_cnt && s_j < n_mine) {  // scalar loop: next non-empty region
+  uint32_t s_j = 0;
+  uint32_t s_rem = (uint32_t)__builtin_amdgcn_readlane((int)v_cnt, 0);
+  const uint8_t* s_ptr = safe_ptr;
+  const uint32_t voff = (uint32_t)lane * kRowBytes;  // lanes past the trip's rows read on inside the region (cap_rows is a multiple of 64)
+  uint32_t take[kPF];
+  auto advance = [&]() -> uint32_t {  // rows of the next trip (0: exhausted); leaves its address in s_ptr_trip
+    while (s_rem == 0 && s_j < n_mine) {
       ++s_j;
-      s_i0 = 0;
-      s_cnt = s_j < n_mine ? (uint32_t)__builtin_amdgcn_readlane((int)v_cnt, (int)(s_j & 63u)) : 0u;
+      if (s_j < n_mine) {
+        s_rem = (uint32_t)__builtin_amdgcn_readlane((int)v_cnt, (int)(s_j & 63u));
+        s_ptr = part_bytes + (uint64_t)(wave + (uint32_t)(kABlock / 64) * s_j) * prod_bytes;
+      }
     }
-    const bool live = s_j < n_mine;
-    act = live && s_i0 + (uint32_t)lane < s_cnt;
-    const uint32_t* base = (const uint32_t*)(part_rows + (uint64_t)(wave + (uint32_t)(kABlock / 64) * (live ? s_j : 0u)) * PT.prod_stride) +
-                           (uint64_t)(live ? s_i0 : 0u) * kRowDwords;
-    row_load_issue(r, base + (act ? (uint32_t)lane * kRowDwords : 0u));  // idle lanes re-read the region's first row
-    s_i0 += 64;
+    return s_rem < 64u ? s_rem : 64u;
   };
-  ROW rows[kPF];
-  bool act[kPF];
-#pragma unroll
-  for (int d = 0; d < kPF; ++d) fetch(rows[d], act[d]);
+#define DFX_P2_FETCH(D)                                                   \
+  {                                                                       \
+    const uint32_t tk = advance();                                        \
+    take[D] = tk;                                                         \
+    p2_issue<D, NARROW>(voff, tk ? (const void*)s_ptr : (const void*)safe_ptr); \
+    s_ptr += 64u * kRowBytes;                                             \
+    s_rem -= tk;                                                          \
+  }
+  DFX_P2_FETCH(0) DFX_P2_FETCH(1) DFX_P2_FETCH(2) DFX_P2_FETCH(3) DFX_P2_FETCH(4) DFX_P2_FETCH(5) DFX_P2_FETCH(6) DFX_P2_FETCH(7)
+  static_assert(kPF == 8, "eight row slots");
   __syncthreads();  // the block is in LDS
   uint32_t new_keys = 0;
-  const uint8_t kind = T.acc_kind[0];
-  const int tag_shift = T.shift - 32;  // narrow: slot = image >> tag_shift (the image is the hash's high half)
+  const int tag_shift = T.shift - 32;                 // narrow: slot = image >> tag_shift (the image is the hash's high half)
+  const uint32_t mask4 = T.block_mask & ~3u;          // home slot = base of the aligned group of four
   bool more = true;
-  while (more) {
-#pragma unroll
-    for (int d = 0; d < kPF; ++d) {
-      const bool a = act[d];
-      if (__ballot(a) == 0) {  // wave-uniform: the cursor is exhausted (trips are handed out in order)
-        more = false;
-        break;
+#define DFX_P2_TRIP(D)                                                                                            \
+  if (more) {                                                                                                     \
+    const uint32_t tk = take[D];                                                                                  \
+    if (tk == 0) {                                                                                                \
+      more = false;                                                                                               \
+    } else {                                                                                                      \
+      Row4 r;                                                                                                     \
+      p2_take<D, NARROW, kPF - 1>(r);                                                                             \
+      DFX_P2_FETCH(D)                                                                                             \
+      process(r, tk);                                                                                             \
+    }                                                                                                             \
+  }
+  auto process = [&](const Row4& r, uint32_t tk) {
+    const bool inb = (uint32_t)lane < tk;
+    uint64_t val;
+    uint32_t home4;
+    int idx;
+    bool real;
+    uint64_t kk = 0;
+    if (NARROW) {
+      val = ((uint64_t)r.z << 32) | r.y;
+      real = inb && r.x != kTagEmpty;
+      home4 = (uint32_t)(r.x >> tag_shift) & mask4;
+      idx = p2_match_group_tags(ltags, home4, r.x);
+    } else {
+      kk = ((uint64_t)r.y << 32) | r.x;
+      val = ((uint64_t)r.w << 32) | r.z;
+      real = inb && kk != kEmptyKey;
+      uint64_t key1[1] = {kk};
+      home4 = (uint32_t)(hash_keys<1>(key1) >> T.shift) & mask4;
+      idx = p2_match_group_keys(lkeys, home4, kk);
+    }
+    uint32_t at = home4 + (uint32_t)idx;
+    bool hit = real && idx >= 0;
+    if (__ballot(real && !hit) != 0) {  // second group, same way (4 % of the keys live there at load 0.5)
+      const uint32_t next4 = (home4 + 4u) & mask4;
+      const int idx2 = NARROW ? p2_match_group_tags(ltags, next4, r.x) : p2_match_group_keys(lkeys, next4, kk);
+      if (!hit && real && idx2 >= 0) {
+        at = next4 + (uint32_t)idx2;
+        hit = true;
       }
-      row_load_wait<kPF - 1>(rows[d]);  // the oldest of the kPF loads in flight has landed
-      const ROW cur = rows[d];
-      fetch(rows[d], act[d]);
-      uint64_t key[1], val;
-      bool have;
-      if (NARROW) {
-        have = a && cur[0] != kTagEmpty;
-        val = ((uint64_t)cur[2] << 32) | cur[1];
-        key[0] = 0;
-      } else {
-        key[0] = ((uint64_t)cur[1] << 32) | cur[0];
-        val = ((uint64_t)cur[NARROW ? 0 : 3] << 32) | cur[2];
-        have = a && key[0] != kEmptyKey;
-      }
-      bool todo = have;
-      if (have) {
-        int found;
-        if (NARROW) {
-          const uint32_t slot = (uint32_t)(((uint64_t)cur[0] >> tag_shift) & T.mask) & T.block_mask;
-          found = pa2n_lookup(ltags, S, slot, cur[0], new_keys);
-        } else {
-          const uint64_t h = hash_keys<1>(key);
-          const uint32_t slot = (uint32_t)((h >> T.shift) & T.mask) & T.block_mask;
-          found = pa2_lookup(lkeys, S, slot, key[0], new_keys);
-        }
+    }
+    if (hit) acc_atomic((uint8_t)KIND, &laccs[at], val);
+    const bool miss = real && !hit;
+    if (__ballot(miss) != 0) {  // general find-or-claim for the rest: new keys, longer probe sequences, a full block
+      bool todo = miss;
+      uint64_t key[1] = {NARROW ? 0ull : kk};
+      if (miss) {
+        const int found = NARROW ? pa2n_lookup(ltags, S, home4, r.x, new_keys) : pa2_lookup(lkeys, S, home4, kk, new_keys);
         if (found >= 0) {
-          acc_atomic(kind, &laccs[found], val);
+          acc_atomic((uint8_t)KIND, &laccs[found], val);
           todo = false;
         }
       }
       if (__ballot(todo) != 0) {  // block full: grow-and-replay takes the row (as a key again)
-        if (NARROW) key[0] = (uint64_t)unhash_word32(cur[0]);
+        if (NARROW) key[0] = (uint64_t)unhash_word32(r.x);
         uint64_t sv[kMaxAggs];
 #pragma unroll
         for (int q = 0; q < kMaxAggs; ++q) sv[q] = q == 0 ? val : 0ull;
         spill_row<1>(T, spill, todo, key, sv);
       }
     }
+  };
+  while (more) {
+    DFX_P2_TRIP(0) DFX_P2_TRIP(1) DFX_P2_TRIP(2) DFX_P2_TRIP(3) DFX_P2_TRIP(4) DFX_P2_TRIP(5) DFX_P2_TRIP(6) DFX_P2_TRIP(7)
   }
-#pragma unroll
-  for (int d = 0; d < kPF; ++d) row_load_wait<0>(rows[d]);  // loads still in flight own these registers until they land
+#undef DFX_P2_TRIP
+#undef DFX_P2_FETCH
+  p2_drain();  // loads still in flight own v88..v119 until they land
   __syncthreads();
   for (uint32_t i0 = threadIdx.x * 2; i0 < S; i0 += kABlock * 2) {
     *(ulonglong2*)(T.accs + slot0 + i0) = *(const ulonglong2*)(laccs + i0);
@@ -420,6 +519,21 @@ __global__ __launch_bounds__(kABlock) void k_partition_agg_pipe(const DevTable T
   if (lane == 0 && new_keys) atomicAdd(&T.ctrl[CTRL_OCCUPIED], new_keys);
   if (p == 0 && threadIdx.x == 0) __hip_atomic_store(&T.ctrl[CTRL_MAX_FILL], 0u, RLX_AGENT);  // the regions are empty again
   snapshot_ctrl_if_last(T, PT);
+}
+
+template <int NARROW>
+static void launch_agg_lean(const DevTable& T, const DevPartition& PT, const DevRows& spill, size_t lds_bytes, hipStream_t s) {
+#define DFX_LEAN(K) hipLaunchKernelGGL((k_partition_agg_lean<NARROW, K>), dim3(PT.n_parts), dim3(kABlock), lds_bytes, s, T, PT, spill)
+  switch (T.acc_kind[0]) {
+    case ACC_ADD_F64: DFX_LEAN(ACC_ADD_F64); break;
+    case ACC_ADD_F32: DFX_LEAN(ACC_ADD_F32); break;
+    case ACC_ADD_U64: DFX_LEAN(ACC_ADD_U64); break;
+    case ACC_MIN_S64: DFX_LEAN(ACC_MIN_S64); break;
+    case ACC_MAX_S64: DFX_LEAN(ACC_MAX_S64); break;
+    case ACC_MIN_U64: DFX_LEAN(ACC_MIN_U64); break;
+    default: DFX_LEAN(ACC_MAX_U64); break;
+  }
+#undef DFX_LEAN
 }
 
 // does the (single-word-key) table hold a key that has no 32-bit image?  Run once, after the calibration slice.
@@ -502,9 +616,9 @@ hipError_t launch_partition_agg(const DevTable& T, const DevPartition& PT, const
   if (lds_bytes > 160 * 1024 - 256 || PT.n_producers > 1024) return hipErrorInvalidValue;
   if (PT.flags & PTF_NARROW) {
     if (T.na != 1 || T.kw != 1) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_partition_agg_pipe<1>, dim3(PT.n_parts), dim3(kABlock), (size_t)(T.block_mask + 1) * 12, s, T, PT, spill);
+    launch_agg_lean<1>(T, PT, spill, (size_t)(T.block_mask + 1) * 12, s);
   } else if (T.na == 1 && (PT.flags & PTF_STREAM_PASS2) && PT.n_words == 2)
-    hipLaunchKernelGGL(k_partition_agg_pipe<0>, dim3(PT.n_parts), dim3(kABlock), (size_t)(T.block_mask + 1) * 16, s, T, PT, spill);
+    launch_agg_lean<0>(T, PT, spill, (size_t)(T.block_mask + 1) * 16, s);
   else if (T.na == 1) hipLaunchKernelGGL(k_partition_agg<1>, dim3(PT.n_parts), dim3(kABlock), lds_bytes, s, T, PT, spill);
   else hipLaunchKernelGGL(k_partition_agg<0>, dim3(PT.n_parts), dim3(kABlock), lds_bytes, s, T, PT, spill);
   return hipGetLastError();
