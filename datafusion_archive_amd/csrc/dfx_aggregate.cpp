@@ -63,6 +63,29 @@ struct AggregateRelation::Impl {
     std::string name;
   };
   std::vector<OutAgg> outs;
+  // More than kMaxAggs accumulators (the reference has no limit: create_accumulators builds any number,
+  // aggregate.rs:319-342; real TPC-H Q1 needs 11) are split into CHUNKS of <= kMaxAggs: one fused program per chunk
+  // (predicate + keys + that chunk's arguments), all chunks updating their own accumulator planes of the SAME table --
+  // the second chunk's kernels find the key the first one inserted.  `builder / plan / fast / na / acc_kind ...` and the
+  // table view T always describe the ACTIVE chunk; the others rest in `chunks`.  One chunk (the common case) never
+  // touches any of this.
+  static constexpr int kMaxAccsTotal = 32;
+  struct Chunk {
+    int a0 = 0, n = 0;  // accumulators [a0, a0 + n)
+    std::unique_ptr<ProgramBuilder> builder, builder_np;
+    DevAggPlan plan, plan_np;
+    DevFastPlan fast, fast_np;
+    std::shared_ptr<void> partial, state, dev_arg_dtype, dev_func;  // ungrouped state of this chunk
+  };
+  std::vector<Chunk> chunks;
+  int cur_chunk = 0;
+  int na_total = 0;
+  uint8_t acc_kind_all[kMaxAccsTotal], val_xform_all[kMaxAccsTotal];
+  uint64_t acc_init_all[kMaxAccsTotal];
+  uint64_t* accs_full = nullptr;  // plane 0 of the table's accumulators (T.accs is the active chunk's first plane)
+  void activate(int c);
+  DevTable view_of(const DevTable& any_view, uint64_t* full_accs, int c) const;
+  Status build_chunk_programs(Chunk& ch);
   std::unique_ptr<ProgramBuilder> builder;
   DevAggPlan plan;
   DevFastPlan fast;
@@ -131,13 +154,14 @@ struct AggregateRelation::Impl {
   std::vector<uint64_t> export_counts;
 
   Status setup(const SchemaInfo& input_schema);
-  Status alloc_table(int cap_log2, DevTable* T, std::vector<std::shared_ptr<void>>* owners, bool new_ctrl);
+  Status alloc_table(int cap_log2, DevTable* T, std::vector<std::shared_ptr<void>>* owners, bool new_ctrl, uint64_t** full_accs_out);
   Status ensure_spill(int64_t rows);
   Status ensure_partition(int64_t rows);
   Status flush_pass2();
   uint64_t program_fingerprint() const;
   Status grow_and_replay(uint64_t occupied, uint64_t spilled, uint64_t replay_from = 0);
   Status consume_batch(const DeviceBatch& b);
+  Status consume_batch_chunk(const DeviceBatch& b);
   Status launch_rows(const DeviceBatch& b, const DevProgram& prog, const DevColumns& cols, int64_t row0, int64_t n);
   Status drain();
   Status emit_grouped(DeviceBatch* out, int64_t expected);
@@ -186,20 +210,54 @@ Status AggregateRelation::Impl::setup(const SchemaInfo& input_schema) {
     key_out_dtype[k] = DFX_UTF8;
     dicts.push_back(std::move(d));
   }
-  builder.reset(new ProgramBuilder(bind_schema));
+  kw = (int)group.size();
+  na_total = (int)aggr.size();
+  if (kw > kMaxKeys) return Status::Err(DFX_NOT_IMPLEMENTED, strfmt("more than %d GROUP BY expressions", kMaxKeys));
+  if (na_total > kMaxAccsTotal) return Status::Err(DFX_NOT_IMPLEMENTED, strfmt("more than %d accumulators", kMaxAccsTotal));
+  key_dtype.assign(kw, 0);
+  arg_dtype.assign(na_total, 0);
+  out_dtype.assign(na_total, 0);
+  func.assign(na_total, 0);
+  chunks.clear();
+  for (int a0 = 0; a0 == 0 || a0 < na_total; a0 += kMaxAggs) {
+    chunks.emplace_back();
+    Chunk& ch = chunks.back();
+    ch.a0 = a0;
+    ch.n = std::min(kMaxAggs, na_total - a0);
+    DFX_RETURN_IF_ERROR(build_chunk_programs(ch));
+  }
+  // chunk 0 becomes the active one
+  cur_chunk = 0;
+  Chunk& c0 = chunks[0];
+  builder = std::move(c0.builder);
+  builder_np = std::move(c0.builder_np);
+  plan = c0.plan;
+  plan_np = c0.plan_np;
+  fast = c0.fast;
+  fast_np = c0.fast_np;
+  na = c0.n;
+  for (int a = 0; a < na; ++a) {
+    acc_kind[a] = acc_kind_all[a];
+    val_xform[a] = val_xform_all[a];
+    acc_init[a] = acc_init_all[a];
+  }
+  return Status::OK();
+}
+
+// the fused programs of one chunk: predicate + keys + arguments [a0, a0 + n), and the predicate-free twin
+Status AggregateRelation::Impl::build_chunk_programs(Chunk& ch) {
+  ch.builder.reset(new ProgramBuilder(bind_schema));
+  ProgramBuilder* builder = ch.builder.get();
+  DevAggPlan& plan = ch.plan;
+  DevFastPlan& fast = ch.fast;
   memset(&plan, 0, sizeof(plan));
   memset(&fast, 0, sizeof(fast));
   plan.pred = kNoOperand;
-  kw = (int)group.size();
-  na = (int)aggr.size();
-  if (kw > kMaxKeys) return Status::Err(DFX_NOT_IMPLEMENTED, strfmt("more than %d GROUP BY expressions", kMaxKeys));
-  if (na > kMaxAggs) return Status::Err(DFX_NOT_IMPLEMENTED, strfmt("more than %d aggregate expressions", kMaxAggs));
   if (has_pred) {
     int dt = 0;
     DFX_RETURN_IF_ERROR(builder->add(pred, pred.root, &plan.pred, &dt));
     if (dt != DFX_BOOLEAN) return Status::Err(DFX_EXECUTION_ERROR, "Filter expression did not evaluate to boolean");
   }
-  key_dtype.assign(kw, 0);
   for (int k = 0; k < kw; ++k) {
     if (group[k].is_aggregate) return Status::Err(DFX_INTERNAL_ERROR, "explicit panic: get_func() on an aggregate expression");
     int dt = 0;
@@ -210,24 +268,25 @@ Status AggregateRelation::Impl::setup(const SchemaInfo& input_schema) {
     if (!key_out_dtype[k]) key_out_dtype[k] = dt;
     plan.key_dtype[k] = (uint8_t)dt;
   }
-  arg_dtype.assign(na, 0);
-  out_dtype.assign(na, 0);
-  func.assign(na, 0);
-  for (int a = 0; a < na; ++a) {
+  for (int a = ch.a0; a < ch.a0 + ch.n; ++a) {
+    const int la = a - ch.a0;  // index inside the chunk
     const dfx_runtime_expr& e = aggr[a];
     if (!e.is_aggregate)  // create_accumulators (aggregate.rs:335-337)
       return Status::Err(DFX_EXECUTION_ERROR, "invalid aggregate expression");
     int dt = 0;
-    DFX_RETURN_IF_ERROR(builder->add(e, e.agg_arg, &plan.arg[a], &dt));
+    DFX_RETURN_IF_ERROR(builder->add(e, e.agg_arg, &plan.arg[la], &dt));
     arg_dtype[a] = dt;
-    plan.arg_dtype[a] = (uint8_t)dt;
+    plan.arg_dtype[la] = (uint8_t)dt;
     func[a] = e.agg_func;
     const int t = e.agg_type;
+    uint8_t& acc_kind_a = acc_kind_all[a];
+    uint8_t& val_xform_a = val_xform_all[a];
+    uint64_t& acc_init_a = acc_init_all[a];
     if (e.agg_func == AGG_COUNT) {  // deviation D3 (reference: "unsupported aggregate function")
       out_dtype[a] = DFX_UINT64;
-      acc_kind[a] = ACC_ADD_U64;
-      val_xform[a] = VT_COUNT_VALID;
-      acc_init[a] = 0;
+      acc_kind_a = ACC_ADD_U64;
+      val_xform_a = VT_COUNT_VALID;
+      acc_init_a = 0;
       continue;
     }
     if (!dtype_is_numeric(t)) {  // array_min/max/sum `_ =>` arms (aggregate.rs:406-408 ...)
@@ -240,47 +299,97 @@ Status AggregateRelation::Impl::setup(const SchemaInfo& input_schema) {
     out_dtype[a] = t;
     const bool grouped = kw > 0;
     if (e.agg_func == AGG_SUM) {
-      val_xform[a] = VT_RAW;
+      val_xform_a = VT_RAW;
       if (t == DFX_FLOAT64) {
-        acc_kind[a] = ACC_ADD_F64;
+        acc_kind_a = ACC_ADD_F64;
         // grouped: the first value initialises the accumulator => identity is -0.0 (x + -0.0 == x
         // bit for bit); ungrouped: array_ops::sum starts from 0.0 (aggregate.rs:480-546)
-        acc_init[a] = grouped ? 0x8000000000000000ull : 0ull;
+        acc_init_a = grouped ? 0x8000000000000000ull : 0ull;
       } else if (t == DFX_FLOAT32) {
-        acc_kind[a] = ACC_ADD_F32;
-        acc_init[a] = grouped ? 0x80000000ull : 0ull;
+        acc_kind_a = ACC_ADD_F32;
+        acc_init_a = grouped ? 0x80000000ull : 0ull;
       } else {
-        acc_kind[a] = ACC_ADD_U64;
-        acc_init[a] = 0;
+        acc_kind_a = ACC_ADD_U64;
+        acc_init_a = 0;
       }
     } else {
       const bool is_min = e.agg_func == AGG_MIN;
       if (t == DFX_FLOAT64 || t == DFX_FLOAT32) {
-        val_xform[a] = t == DFX_FLOAT64 ? (is_min ? VT_F64_ORD_MIN : VT_F64_ORD_MAX) : (is_min ? VT_F32_ORD_MIN : VT_F32_ORD_MAX);
-        acc_kind[a] = is_min ? ACC_MIN_U64 : ACC_MAX_U64;
-        acc_init[a] = is_min ? ~0ull : 0ull;
+        val_xform_a = t == DFX_FLOAT64 ? (is_min ? VT_F64_ORD_MIN : VT_F64_ORD_MAX) : (is_min ? VT_F32_ORD_MIN : VT_F32_ORD_MAX);
+        acc_kind_a = is_min ? ACC_MIN_U64 : ACC_MAX_U64;
+        acc_init_a = is_min ? ~0ull : 0ull;
       } else if (dtype_is_signed(t)) {
-        val_xform[a] = VT_RAW;
-        acc_kind[a] = is_min ? ACC_MIN_S64 : ACC_MAX_S64;
-        acc_init[a] = is_min ? 0x7FFFFFFFFFFFFFFFull : 0x8000000000000000ull;
+        val_xform_a = VT_RAW;
+        acc_kind_a = is_min ? ACC_MIN_S64 : ACC_MAX_S64;
+        acc_init_a = is_min ? 0x7FFFFFFFFFFFFFFFull : 0x8000000000000000ull;
       } else {
-        val_xform[a] = VT_RAW;
-        acc_kind[a] = is_min ? ACC_MIN_U64 : ACC_MAX_U64;
-        acc_init[a] = is_min ? ~0ull : 0ull;
+        val_xform_a = VT_RAW;
+        acc_kind_a = is_min ? ACC_MIN_U64 : ACC_MAX_U64;
+        acc_init_a = is_min ? ~0ull : 0ull;
       }
     }
   }
-  builder->build_fast(plan.pred, plan.key, kw, plan.arg, na, &fast);
+  builder->build_fast(plan.pred, plan.key, kw, plan.arg, ch.n, &fast);
   if (has_pred) {  // predicate-free twin (operands are numbered differently: its own plan)
-    builder_np.reset(new ProgramBuilder(bind_schema));
-    plan_np = plan;
-    plan_np.pred = kNoOperand;
+    ch.builder_np.reset(new ProgramBuilder(bind_schema));
+    ch.plan_np = plan;
+    ch.plan_np.pred = kNoOperand;
     int dt = 0;
-    for (int k = 0; k < kw; ++k) DFX_RETURN_IF_ERROR(builder_np->add(group_rw[k], group_rw[k].root, &plan_np.key[k], &dt));
-    for (int a = 0; a < na; ++a) DFX_RETURN_IF_ERROR(builder_np->add(aggr[a], aggr[a].agg_arg, &plan_np.arg[a], &dt));
-    builder_np->build_fast(plan_np.pred, plan_np.key, kw, plan_np.arg, na, &fast_np);
+    for (int k = 0; k < kw; ++k) DFX_RETURN_IF_ERROR(ch.builder_np->add(group_rw[k], group_rw[k].root, &ch.plan_np.key[k], &dt));
+    for (int a = ch.a0; a < ch.a0 + ch.n; ++a) DFX_RETURN_IF_ERROR(ch.builder_np->add(aggr[a], aggr[a].agg_arg, &ch.plan_np.arg[a - ch.a0], &dt));
+    ch.builder_np->build_fast(ch.plan_np.pred, ch.plan_np.key, kw, ch.plan_np.arg, ch.n, &ch.fast_np);
   }
   return Status::OK();
+}
+
+// Make chunk c the active one: programs, accumulator algebra, ungrouped buffers and the table view.
+void AggregateRelation::Impl::activate(int c) {
+  if (c == cur_chunk) return;
+  auto swap_with = [&](Chunk& ch) {
+    std::swap(builder, ch.builder);
+    std::swap(builder_np, ch.builder_np);
+    std::swap(plan, ch.plan);
+    std::swap(plan_np, ch.plan_np);
+    std::swap(fast, ch.fast);
+    std::swap(fast_np, ch.fast_np);
+    std::swap(partial, ch.partial);
+    std::swap(state, ch.state);
+    std::swap(dev_arg_dtype, ch.dev_arg_dtype);
+    std::swap(dev_func, ch.dev_func);
+  };
+  swap_with(chunks[(size_t)cur_chunk]);  // the active members go back to their chunk
+  swap_with(chunks[(size_t)c]);          // chunk c's become active
+  cur_chunk = c;
+  const Chunk& ch = chunks[(size_t)c];
+  na = ch.n;
+  for (int a = 0; a < na; ++a) {
+    acc_kind[a] = acc_kind_all[ch.a0 + a];
+    val_xform[a] = val_xform_all[ch.a0 + a];
+    acc_init[a] = acc_init_all[ch.a0 + a];
+  }
+  if (kw > 0 && accs_full) T = view_of(T, accs_full, c);
+  else if (kw == 0) {
+    T.na = na;
+    for (int a = 0; a < na; ++a) {
+      T.acc_kind[a] = acc_kind[a];
+      T.val_xform[a] = val_xform[a];
+      T.acc_init[a] = acc_init[a];
+    }
+  }
+}
+
+// chunk c's view of a table: same keys / control block, accumulator planes [a0, a0 + n)
+DevTable AggregateRelation::Impl::view_of(const DevTable& any_view, uint64_t* full_accs, int c) const {
+  DevTable v = any_view;
+  const Chunk& ch = chunks[(size_t)c];
+  v.accs = full_accs + (uint64_t)ch.a0 * v.stride;
+  v.na = ch.n;
+  for (int a = 0; a < kMaxAggs; ++a) {
+    v.acc_kind[a] = a < ch.n ? acc_kind_all[ch.a0 + a] : 0;
+    v.val_xform[a] = a < ch.n ? val_xform_all[ch.a0 + a] : 0;
+    v.acc_init[a] = a < ch.n ? acc_init_all[ch.a0 + a] : 0;
+  }
+  return v;
 }
 
 // what the calibration slice's outcome depends on: the fused program (predicate, key and argument expressions with
@@ -307,7 +416,7 @@ uint64_t AggregateRelation::Impl::program_fingerprint() const {
 
 // ---- table management ------------------------------------------------------------------------------
 Status AggregateRelation::Impl::alloc_table(int cap_log2, DevTable* Tn, std::vector<std::shared_ptr<void>>* owners,
-                                            bool new_ctrl) {
+                                            bool new_ctrl, uint64_t** full_accs_out) {
   hipStream_t s = ctx().stream;
   memset(Tn, 0, sizeof(*Tn));
   const uint64_t cap = 1ull << cap_log2;
@@ -318,8 +427,10 @@ Status AggregateRelation::Impl::alloc_table(int cap_log2, DevTable* Tn, std::vec
   Tn->na = na;
   Tn->load_limit = cap / 2;
   Tn->max_probe = (int)std::min<uint64_t>(cap, 1u << 30);
-  {  // probing block = what one workgroup can hold in 64 KB of LDS (keys + accumulators)
-    uint64_t blk = 16384 / (uint64_t)(std::max(kw, 1) + std::max(na, 1));  // 128 KB of LDS per block (pass 2: one workgroup per CU)
+  {  // probing block = what one workgroup can hold in 128 KB of LDS (keys + the accumulators of the widest chunk)
+    int widest = 1;
+    for (const Chunk& ch : chunks) widest = std::max(widest, ch.n);
+    uint64_t blk = 16384 / (uint64_t)(std::max(kw, 1) + widest);  // 128 KB of LDS per block (pass 2: one workgroup per CU)
     uint64_t p2 = 64;
     while (p2 * 2 <= blk) p2 *= 2;
     if (p2 > cap) p2 = cap;
@@ -333,7 +444,7 @@ Status AggregateRelation::Impl::alloc_table(int cap_log2, DevTable* Tn, std::vec
   Status st;
   auto keys = device_alloc(sizeof(uint64_t) * Tn->stride * (size_t)std::max(kw, 1), &st);
   if (!keys) return st;
-  auto accs = device_alloc(sizeof(uint64_t) * Tn->stride * (size_t)std::max(na, 1), &st);
+  auto accs = device_alloc(sizeof(uint64_t) * Tn->stride * (size_t)std::max(na_total, 1), &st);  // every chunk's planes
   if (!accs) return st;
   Tn->keys = (uint64_t*)keys.get();
   Tn->accs = (uint64_t*)accs.get();
@@ -349,7 +460,9 @@ Status AggregateRelation::Impl::alloc_table(int cap_log2, DevTable* Tn, std::vec
   } else {
     DFX_HIP(launch_fill_u64(Tn->keys, kEmptyKey, (int64_t)Tn->stride, s));
   }
-  for (int a = 0; a < na; ++a) DFX_HIP(launch_fill_u64(Tn->accs + (size_t)a * Tn->stride, acc_init[a], (int64_t)Tn->stride, s));
+  for (int a = 0; a < na_total; ++a) DFX_HIP(launch_fill_u64(Tn->accs + (size_t)a * Tn->stride, acc_init_all[a], (int64_t)Tn->stride, s));
+  if (full_accs_out) *full_accs_out = Tn->accs;
+  Tn->accs += (uint64_t)chunks[(size_t)cur_chunk].a0 * Tn->stride;  // the caller gets the ACTIVE chunk's view
   if (new_ctrl) {
     ctrl = device_alloc(sizeof(uint32_t) * CTRL_WORDS, &st);
     if (!ctrl) return st;
@@ -371,7 +484,9 @@ Status AggregateRelation::Impl::ensure_spill(int64_t rows) {
   DFX_RETURN_IF_ERROR(settle_ctrl());  // rows spilled by batches still in flight live in the old list
   ScopedUs t_alloc(&counters().agg_alloc_us);
   Status st;
-  spill_owner = device_alloc(sizeof(uint64_t) * (size_t)rows * (size_t)(kw + na), &st);
+  int widest = na;  // the list is shared by every chunk of accumulators: planes for the widest one
+  for (const Chunk& ch : chunks) widest = std::max(widest, ch.n);
+  spill_owner = device_alloc(sizeof(uint64_t) * (size_t)rows * (size_t)(kw + widest), &st);
   if (!spill_owner) return st;
   spill.words = (uint64_t*)spill_owner.get();
   spill.capacity = (uint64_t)rows;
@@ -440,7 +555,13 @@ Status AggregateRelation::Impl::ensure_partition(int64_t rows) {
   const uint64_t pad_words = (uint64_t)(o.partition_pad >= 0 ? o.partition_pad : 0) / 8;
   size_t row_bytes;
   const uint64_t region_words = (PT.flags & PTF_NARROW) ? (uint64_t)PT.cap_rows * 12 / 8 : (uint64_t)PT.cap_rows * PT.n_words;
-  if (o.partition_layout == 0) {  // partition-major (round 1)
+  PT.win_stride = region_words / (PT.cap_rows / 64);  // 64 rows' worth: regions are contiguous (layouts 0 and 1)
+  if (o.partition_layout == 2) {  // windowed: window w of every partition of a producer side by side
+    PT.part_stride = PT.win_stride;
+    PT.win_stride = (uint64_t)PT.n_parts * PT.part_stride;
+    PT.prod_stride = (uint64_t)(PT.cap_rows / 64) * PT.win_stride + pad_words;
+    row_bytes = sizeof(uint64_t) * (size_t)PT.n_producers * PT.prod_stride;
+  } else if (o.partition_layout == 0) {  // partition-major (round 1)
     PT.prod_stride = region_words;
     PT.part_stride = (uint64_t)PT.n_producers * PT.prod_stride + pad_words;
     row_bytes = sizeof(uint64_t) * (size_t)PT.n_parts * PT.part_stride;
@@ -639,7 +760,8 @@ Status AggregateRelation::Impl::grow_and_replay(uint64_t occupied, uint64_t spil
   if (new_log2 > 31) return Status::Err(DFX_EXECUTION_ERROR, "GROUP BY table would exceed 2^31 slots");
   DevTable Tn;
   std::vector<std::shared_ptr<void>> owners;
-  DFX_RETURN_IF_ERROR(alloc_table(new_log2, &Tn, &owners, false));
+  uint64_t* accs_full_new = nullptr;
+  DFX_RETURN_IF_ERROR(alloc_table(new_log2, &Tn, &owners, false, &accs_full_new));
   // reset the shared control words that describe the (new) table
   uint32_t zeros[CTRL_WORDS];
   memset(zeros, 0, sizeof(zeros));
@@ -666,8 +788,13 @@ Status AggregateRelation::Impl::grow_and_replay(uint64_t occupied, uint64_t spil
   DevTable Told = T;
   Told.ctrl = (uint32_t*)old_ctrl.get();
   DFX_HIP(launch_rehash(Told, Tn, no_spill, s));
+  for (int c = 0; c < (int)chunks.size(); ++c) {  // the other chunks' planes move the same way (their keys are already in place)
+    if (c == cur_chunk) continue;
+    DFX_HIP(launch_rehash(view_of(Told, accs_full, c), view_of(Tn, accs_full_new, c), no_spill, s));
+  }
   if (spilled > replay_from) DFX_HIP(launch_merge_rows(spill, (int64_t)replay_from, (int64_t)(spilled - replay_from), Tn, no_spill, s));
   T = Tn;
+  accs_full = accs_full_new;
   table_owners = owners;  // old buffers return to the pool once the stream has passed them
   DFX_HIP(hipStreamSynchronize(s));
   return Status::OK();
@@ -783,7 +910,7 @@ struct OneBatchRelation : Relation {
 };
 }  // namespace
 
-Status AggregateRelation::Impl::consume_batch(const DeviceBatch& b) {
+Status AggregateRelation::Impl::consume_batch_chunk(const DeviceBatch& b) {
   if (has_pred && !unfused_now && b.num_rows > 0) {
     bool nulls = false;
     for (int ci : builder->columns())
@@ -807,7 +934,7 @@ Status AggregateRelation::Impl::consume_batch(const DeviceBatch& b) {
       std::swap(plan, plan_np);
       std::swap(fast, fast_np);
       unfused_now = true;
-      Status st = consume_batch(fb);
+      Status st = consume_batch_chunk(fb);
       unfused_now = false;
       std::swap(builder, builder_np);
       std::swap(plan, plan_np);
@@ -931,6 +1058,29 @@ Status AggregateRelation::Impl::consume_batch(const DeviceBatch& b) {
     DFX_RETURN_IF_ERROR(examine_ctrl(prev)); // the previous batch's snapshot (normally complete by now)
   }
   rows_seen += n;
+  return Status::OK();
+}
+
+// One input batch through every chunk of accumulators.  With several chunks each chunk's kernels are checked
+// synchronously (errors, spilled rows, growth) before the next chunk runs: the spill list and the routing scratch carry
+// rows of ONE chunk's width at a time.
+Status AggregateRelation::Impl::consume_batch(const DeviceBatch& b) {
+  if (chunks.size() <= 1) return consume_batch_chunk(b);
+  for (int c = 0; c < (int)chunks.size(); ++c) {
+    activate(c);
+    const int64_t seen = rows_seen;
+    DFX_RETURN_IF_ERROR(consume_batch_chunk(b));
+    rows_seen = seen;
+    if (kw > 0) {
+      DFX_RETURN_IF_ERROR(flush_pass2());
+      DFX_RETURN_IF_ERROR(settle_ctrl());
+      uint32_t hc[CTRL_WORDS];
+      DFX_RETURN_IF_ERROR(read_ctrl(hc));
+      DFX_RETURN_IF_ERROR(handle_ctrl(hc, b.num_rows));
+    }
+  }
+  activate(0);
+  rows_seen += b.num_rows;
   return Status::OK();
 }
 
@@ -1073,45 +1223,49 @@ Status AggregateRelation::Impl::drain() {
   Status st;
   if (kw == 0) {
     memset(&T, 0, sizeof(T));
+    ctrl = device_alloc(sizeof(uint32_t) * CTRL_WORDS, &st);
+    if (!ctrl) return st;
+    DFX_HIP(hipMemsetAsync(ctrl.get(), 0, sizeof(uint32_t) * CTRL_WORDS, s));
+    for (int c = (int)chunks.size() - 1; c >= 0; --c) {  // every chunk: batch partials, running state, type tables (chunk 0 last: it stays active)
+      activate(c);
+      partial = device_alloc(sizeof(uint64_t) * kReduceSlots * kReduceSlotWords, &st);
+      if (!partial) return st;
+      state = device_alloc(sizeof(uint64_t) * 2 * kMaxAggs, &st);
+      if (!state) return st;
+      dev_arg_dtype = device_alloc(kMaxAggs, &st);
+      if (!dev_arg_dtype) return st;
+      dev_func = device_alloc(kMaxAggs, &st);
+      if (!dev_func) return st;
+      std::vector<uint64_t> hpv((size_t)kReduceSlots * kReduceSlotWords, 0);
+      uint64_t* hp = hpv.data();
+      uint8_t hd[kMaxAggs], hf[kMaxAggs];
+      memset(hd, 0, sizeof(hd));
+      memset(hf, 0, sizeof(hf));
+      const int a0 = chunks[(size_t)c].a0;
+      for (int a = 0; a < na; ++a) {
+        for (int sl = 0; sl < kReduceSlots; ++sl) {
+          hp[(size_t)sl * kReduceSlotWords + 4 * a] = acc_init[a];
+          hp[(size_t)sl * kReduceSlotWords + 4 * a + 2] = ~0ull;
+        }
+        hd[a] = (uint8_t)arg_dtype[a0 + a];
+        hf[a] = (uint8_t)func[a0 + a];
+      }
+      DFX_HIP(hipMemcpy(partial.get(), hp, sizeof(uint64_t) * hpv.size(), hipMemcpyHostToDevice));  // (blocking: stack / loop-local sources)
+      DFX_HIP(hipMemcpy(dev_arg_dtype.get(), hd, sizeof(hd), hipMemcpyHostToDevice));
+      DFX_HIP(hipMemcpy(dev_func.get(), hf, sizeof(hf), hipMemcpyHostToDevice));
+      DFX_HIP(hipMemsetAsync(state.get(), 0, sizeof(uint64_t) * 2 * kMaxAggs, s));
+    }
     T.na = na;
     for (int a = 0; a < na; ++a) {
       T.acc_kind[a] = acc_kind[a];
       T.val_xform[a] = val_xform[a];
       T.acc_init[a] = acc_init[a];
     }
-    partial = device_alloc(sizeof(uint64_t) * kReduceSlots * kReduceSlotWords, &st);
-    if (!partial) return st;
-    state = device_alloc(sizeof(uint64_t) * 2 * kMaxAggs, &st);
-    if (!state) return st;
-    ctrl = device_alloc(sizeof(uint32_t) * CTRL_WORDS, &st);
-    if (!ctrl) return st;
-    dev_arg_dtype = device_alloc(kMaxAggs, &st);
-    if (!dev_arg_dtype) return st;
-    dev_func = device_alloc(kMaxAggs, &st);
-    if (!dev_func) return st;
-    std::vector<uint64_t> hpv((size_t)kReduceSlots * kReduceSlotWords, 0);
-    uint64_t* hp = hpv.data();
-    uint8_t hd[kMaxAggs], hf[kMaxAggs];
-    memset(hd, 0, sizeof(hd));
-    memset(hf, 0, sizeof(hf));
-    for (int a = 0; a < na; ++a) {
-      for (int sl = 0; sl < kReduceSlots; ++sl) {
-        hp[(size_t)sl * kReduceSlotWords + 4 * a] = acc_init[a];
-        hp[(size_t)sl * kReduceSlotWords + 4 * a + 2] = ~0ull;
-      }
-      hd[a] = (uint8_t)arg_dtype[a];
-      hf[a] = (uint8_t)func[a];
-    }
-    DFX_HIP(hipMemcpyAsync(partial.get(), hp, sizeof(uint64_t) * hpv.size(), hipMemcpyHostToDevice, s));
-    DFX_HIP(hipMemcpyAsync(dev_arg_dtype.get(), hd, sizeof(hd), hipMemcpyHostToDevice, s));
-    DFX_HIP(hipMemcpyAsync(dev_func.get(), hf, sizeof(hf), hipMemcpyHostToDevice, s));
-    DFX_HIP(hipMemsetAsync(state.get(), 0, sizeof(uint64_t) * 2 * kMaxAggs, s));
-    DFX_HIP(hipMemsetAsync(ctrl.get(), 0, sizeof(uint32_t) * CTRL_WORDS, s));
     DFX_HIP(hipStreamSynchronize(s));
   } else {
     int cap_log2 = agg_options().capacity_log2 > 0 ? agg_options().capacity_log2 : 21;
     cap_log2 = std::max(6, std::min(cap_log2, 31));
-    DFX_RETURN_IF_ERROR(alloc_table(cap_log2, &T, &table_owners, true));
+    DFX_RETURN_IF_ERROR(alloc_table(cap_log2, &T, &table_owners, true, &accs_full));
     spill.words = nullptr;
     spill.capacity = 0;
   }
@@ -1149,8 +1303,12 @@ static Status upload_small(const void* host, size_t bytes, std::shared_ptr<void>
 }
 
 Status AggregateRelation::Impl::emit_ungrouped(DeviceBatch* out) {  // aggregate.rs:745-784
-  uint64_t hs[2 * kMaxAggs];
-  DFX_HIP(hipMemcpy(hs, state.get(), sizeof(hs), hipMemcpyDeviceToHost));
+  uint64_t hs[2 * kMaxAccsTotal];
+  memset(hs, 0, sizeof(hs));
+  for (int c = 0; c < (int)chunks.size(); ++c) {  // every chunk keeps its own (has-value, bits) pairs
+    const void* st_c = c == cur_chunk ? state.get() : chunks[(size_t)c].state.get();
+    DFX_HIP(hipMemcpy(hs + 2 * chunks[(size_t)c].a0, st_c, sizeof(uint64_t) * 2 * (size_t)chunks[(size_t)c].n, hipMemcpyDeviceToHost));
+  }
   out->num_rows = 1;
   out->columns.clear();
   out->columns.resize(outs.size());
@@ -1248,10 +1406,10 @@ Status AggregateRelation::Impl::emit_grouped(DeviceBatch* out, int64_t expected)
     c.length = g;
     auto vals = device_alloc((size_t)std::max<int64_t>(g, 1) * dtype_width(dt), &st);
     if (!vals) return st;
-    DFX_HIP(launch_compact(T.accs + (size_t)a * T.stride, 8, (const uint64_t*)mask.get(), (const uint64_t*)offsets.get(), n_slots,
+    DFX_HIP(launch_compact(accs_full + (size_t)a * T.stride, 8, (const uint64_t*)mask.get(), (const uint64_t*)offsets.get(), n_slots,
                            dense.get(), 0, s, (uint64_t)g));
     if (!outs[j].avg) {
-      DFX_HIP(launch_finalize((const uint64_t*)dense.get(), g, (uint8_t)dt, val_xform[a], vals.get(), s));
+      DFX_HIP(launch_finalize((const uint64_t*)dense.get(), g, (uint8_t)dt, val_xform_all[a], vals.get(), s));
     } else {  // SUM plane / COUNT plane (deviation D7); groups that counted nothing are null
       auto dense_cnt = device_alloc(sizeof(uint64_t) * (size_t)std::max<int64_t>(g, 1), &st);
       if (!dense_cnt) return st;
@@ -1260,7 +1418,7 @@ Status AggregateRelation::Impl::emit_grouped(DeviceBatch* out, int64_t expected)
       auto nulls = device_alloc(sizeof(uint64_t), &st);
       if (!nulls) return st;
       DFX_HIP(hipMemsetAsync(nulls.get(), 0, sizeof(uint64_t), s));
-      DFX_HIP(launch_compact(T.accs + (size_t)(a + 1) * T.stride, 8, (const uint64_t*)mask.get(), (const uint64_t*)offsets.get(),
+      DFX_HIP(launch_compact(accs_full + (size_t)(a + 1) * T.stride, 8, (const uint64_t*)mask.get(), (const uint64_t*)offsets.get(),
                              n_slots, dense_cnt.get(), 0, s, (uint64_t)g));
       DFX_HIP(launch_finalize_avg((const uint64_t*)dense.get(), (const uint64_t*)dense_cnt.get(), g, (uint8_t)dt, vals.get(),
                                   (uint64_t*)valid.get(), (uint64_t*)nulls.get(), s));
@@ -1372,7 +1530,8 @@ void AggregateRelation::explain(std::string* out, int depth) const {
       else if (m.kw == 2 && sig_matches<SigQ1>(P, m.fast, 2, m.na, m.acc_kind, m.val_xform)) shape = "static shape Q1";
       else if (m.fast.valid) shape = "column-op-literal shape (FastPolicy; interpreter when a batch has nulls)";
     }
-    std::string text = strfmt("Aggregate: %d keys, %d accumulators", m.kw, m.na);
+    std::string text = strfmt("Aggregate: %d keys, %d accumulators", m.kw, m.na_total);
+    if (m.chunks.size() > 1) text += strfmt(" in %d chunks of <= %d (one fused program each, the same table)", (int)m.chunks.size(), kMaxAggs);
     text += m.has_pred ? ", Filter below fused into the scan (un-fused for batches with nulls in its columns)" : ", no predicate";
     text += ", " + explain_program(P) + ", " + shape;
     if (m.kw == 0) text += ", ungrouped reduce (64 partial copies + fold)";
@@ -1414,6 +1573,7 @@ Status AggregateRelation::partial_build(int world, int* n_words, int64_t* counts
   Impl& m = *impl_;
   if (!m.deferred.ok()) return m.deferred;
   if (m.kw == 0) return Status::Err(DFX_NOT_IMPLEMENTED, "partial exchange is for GROUP BY aggregates");
+  if (m.chunks.size() > 1) return Status::Err(DFX_NOT_IMPLEMENTED, strfmt("multi-GPU exchange of more than %d accumulators", kMaxAggs));
   if (world < 1 || world > 1024) return Status::Err(DFX_GENERAL, "world must be in 1..1024");
   DFX_RETURN_IF_ERROR(m.drain());
   hipStream_t s = ctx().stream;
@@ -1445,6 +1605,7 @@ Status AggregateRelation::partial_count_device(int world, int* n_words, uint64_t
   Impl& m = *impl_;
   if (!m.deferred.ok()) return m.deferred;
   if (m.kw == 0) return Status::Err(DFX_INTERNAL_ERROR, "partial_count_device is for GROUP BY aggregates");
+  if (m.chunks.size() > 1) return Status::Err(DFX_NOT_IMPLEMENTED, strfmt("multi-GPU exchange of more than %d accumulators", kMaxAggs));
   if (world < 1 || world > 1024) return Status::Err(DFX_GENERAL, "world must be in 1..1024");
   DFX_RETURN_IF_ERROR(m.drain());
   hipStream_t s = ctx().stream;
@@ -1511,6 +1672,7 @@ bool AggregateRelation::is_ungrouped() const { return impl_->deferred.ok() && im
 Status AggregateRelation::ungrouped_state_begin() {
   Impl& m = *impl_;
   if (!m.deferred.ok()) return m.deferred;
+  if (m.chunks.size() > 1) return Status::Err(DFX_NOT_IMPLEMENTED, strfmt("multi-GPU exchange of more than %d accumulators", kMaxAggs));
   if (m.group.empty() && m.aggr.empty())
     return Status::Err(DFX_INTERNAL_ERROR, "assertion failed: record batch needs at least one column");
   return m.drain();
@@ -1579,7 +1741,8 @@ Status AggregateRelation::partial_import(const void* src_device, const int64_t* 
   if (cap_log2 > 31) return Status::Err(DFX_EXECUTION_ERROR, "GROUP BY table would exceed 2^31 slots");
   DevTable Tn;
   std::vector<std::shared_ptr<void>> owners;
-  DFX_RETURN_IF_ERROR(m.alloc_table(cap_log2, &Tn, &owners, true));
+  uint64_t* accs_full_new = nullptr;
+  DFX_RETURN_IF_ERROR(m.alloc_table(cap_log2, &Tn, &owners, true, &accs_full_new));
   DevRows no_spill;
   no_spill.words = nullptr;
   no_spill.capacity = 0;
@@ -1592,6 +1755,7 @@ Status AggregateRelation::partial_import(const void* src_device, const int64_t* 
   }
   DFX_HIP(hipStreamSynchronize(s));
   m.T = Tn;
+  m.accs_full = accs_full_new;
   m.table_owners = owners;
   m.export_counts.clear();
   uint32_t hc[CTRL_WORDS];

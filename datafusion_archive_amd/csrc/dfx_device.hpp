@@ -200,6 +200,11 @@ struct DevPartition {
                        // pass-1 workgroup appends to lie within ONE contiguous piece of the scratch (a handful of TLB
                        // entries per workgroup), pass 2 walks its 256 regions one after the other.  Partition-major: the
                        // other way round (round 1's layout; pass 1 then touches a region every part_stride words)
+  uint64_t win_stride; // words between consecutive 64-row WINDOWS of one region.  Layouts 0 / 1: 64 rows' worth (a region is
+                       // contiguous).  Layout 2 (windowed, default): n_parts * part_stride -- window w of EVERY partition of
+                       // a producer lies side by side, so the 256 append positions of a pass-1 workgroup (fills are near
+                       // uniform) stay within a megabyte however large the regions are: a handful of TLB entries instead
+                       // of one page per region, and the region capacity (deferred pass 2) no longer costs pass 1 anything
   uint32_t* counts;    // [partition][producer]
   uint32_t n_parts;    // table blocks
   uint32_t n_producers;// pass-1 workgroups

@@ -400,6 +400,7 @@ __global__ __launch_bounds__(kABlock) __attribute__((amdgpu_num_vgpr(kP2Vgprs)))
   // wave-uniform cursor: region ordinal, rows left in it, address of the next trip's first row
   const uint8_t* const part_bytes = (const uint8_t*)(PT.rows + (uint64_t)p * PT.part_stride);
   const uint64_t prod_bytes = PT.prod_stride * 8ull;
+  const uint64_t win_bytes = PT.win_stride * 8ull;  // from one 64-row trip of a region to the next
   const uint8_t* const safe_ptr = part_bytes + (uint64_t)wave * prod_bytes;  // always a readable trip (>= 64 rows per region)
   const uint32_t n_mine = (NP + (uint32_t)(kABlock / 64) - 1u - wave) / (uint32_t)(kABlock / 64);  // regions of this wave
   uint32_t s_j = 0;
@@ -422,7 +423,7 @@ __global__ __launch_bounds__(kABlock) __attribute__((amdgpu_num_vgpr(kP2Vgprs)))
     const uint32_t tk = advance();                                        \
     take[D] = tk;                                                         \
     p2_issue<D, NARROW>(voff, tk ? (const void*)s_ptr : (const void*)safe_ptr); \
-    s_ptr += 64u * kRowBytes;                                             \
+    s_ptr += win_bytes;                                                   \
     s_rem -= tk;                                                          \
   }
   DFX_P2_FETCH(0) DFX_P2_FETCH(1) DFX_P2_FETCH(2) DFX_P2_FETCH(3) DFX_P2_FETCH(4) DFX_P2_FETCH(5) DFX_P2_FETCH(6) DFX_P2_FETCH(7)

@@ -32,12 +32,14 @@ constexpr int kABlock = 1024;  // pass-2 workgroup (one per CU): 16 waves share 
 
 // address of row `row` of the region that producer `producer` fills for partition `part`
 DEV uint64_t* region_row(const DevPartition& PT, uint32_t part, uint32_t producer, uint32_t row) {
-  return PT.rows + (uint64_t)part * PT.part_stride + (uint64_t)producer * PT.prod_stride + (uint64_t)row * PT.n_words;
+  return PT.rows + (uint64_t)part * PT.part_stride + (uint64_t)producer * PT.prod_stride + (uint64_t)(row >> 6) * PT.win_stride +
+         (uint64_t)(row & 63u) * PT.n_words;
 }
 
 // 12-byte rows (PTF_NARROW): the strides stay in 8-byte words (cap_rows is a multiple of 64), rows are 3 dwords
 DEV uint32_t* region_row12(const DevPartition& PT, uint32_t part, uint32_t producer, uint32_t row) {
-  return (uint32_t*)(PT.rows + (uint64_t)part * PT.part_stride + (uint64_t)producer * PT.prod_stride) + (uint64_t)row * 3u;
+  return (uint32_t*)(PT.rows + (uint64_t)part * PT.part_stride + (uint64_t)producer * PT.prod_stride + (uint64_t)(row >> 6) * PT.win_stride) +
+         (uint64_t)(row & 63u) * 3u;
 }
 
 DEV uint32_t partition_of(const DevTable& T, const DevPartition& PT, uint64_t h) {

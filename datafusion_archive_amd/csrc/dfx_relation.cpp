@@ -750,6 +750,31 @@ int32_t dfx_filter_relation_new(struct ArrowArrayStream* input, const dfx_runtim
   });
 }
 
+// Measurement hook: pull every batch of a library stream and leave it ON THE DEVICE (no host RecordBatch is built, no
+// D2H copy) -- what an operator stacked on top would see.  bench.py times FilterRelation's mask + compaction kernels
+// with it (BASELINE config 2 as written); rows / batches count what came out.
+int32_t dfx_relation_drain_device(struct ArrowArrayStream* stream, int64_t* rows, int64_t* batches, char* err, size_t errlen) {
+  return c_abi_guard(err, errlen, [&]() -> int32_t {
+    Relation* r = peek_exported(stream);
+    if (!r) return to_c(Status::Err(DFX_GENERAL, "not a stream of this library"), err, errlen);
+    int64_t nr = 0, nb = 0;
+    for (;;) {
+      DeviceBatch b;
+      bool has = false;
+      Status st = r->next(&b, &has);
+      if (!st.ok()) return to_c(st, err, errlen);
+      if (!has) break;
+      nr += b.num_rows;
+      ++nb;
+    }
+    hipError_t e = hipStreamSynchronize(ctx().stream);
+    if (e != hipSuccess) return to_c(Status::Err(DFX_EXECUTION_ERROR, strfmt("HIP error %s", hipGetErrorString(e))), err, errlen);
+    if (rows) *rows = nr;
+    if (batches) *batches = nb;
+    return DFX_OK;
+  });
+}
+
 int64_t dfx_relation_explain(struct ArrowArrayStream* stream, char* buf, size_t buflen) {
   try {
     Relation* r = peek_exported(stream);

@@ -115,7 +115,7 @@ struct AggOptions {
   int ctrl_snapshot = 1;       // partitioned strategy: 1 the batch's last kernel writes the control-block snapshot to pinned host
                                // memory itself, 0 asynchronous copy on the side stream (round 1)
   int narrow_keys = -1;        // 12-byte routed rows when the calibration slice saw only keys below 2^32: -1 auto, 0 never
-  int partition_layout = 1;    // routing scratch: 1 producer-major, 0 partition-major (DevPartition::prod_stride)
+  int partition_layout = 2;    // routing scratch: 2 windowed (DevPartition::win_stride), 1 producer-major, 0 partition-major (round 1)
   int partition_producers = 0; // pass-1 workgroups of the ring flavour (0: one per CU)
   int hot_keys = -1;           // pass 1 hot-key pairs in LDS: -1 when the calibration slice saw skew, 0 never, 1 always
   int emit_async = 1;          // 1: emit queues its compaction kernels with the host's group count and checks the table's afterwards

@@ -459,6 +459,15 @@ def explain(rel: "Relation") -> str:
     return buf.value.decode()
 
 
+def drain_on_device(rel: "Relation"):
+    """Measurement hook (dfx_relation_drain_device): run `rel` to the end keeping its batches on the device. -> (rows, batches)"""
+    L = _ffi.lib()
+    rows, batches = ctypes.c_int64(), ctypes.c_int64()
+    err = _errbuf()
+    _check(L.dfx_relation_drain_device(ctypes.byref(rel._live_stream()), ctypes.byref(rows), ctypes.byref(batches), err, 1024), err)
+    return rows.value, batches.value
+
+
 def counter_get(name: str) -> int:
     return int(_ffi.lib().dfx_counter_get(name.encode()))
 

@@ -343,6 +343,9 @@ int32_t dfx_aggregate_exchange(struct ArrowArrayStream* agg, dfx_comm* comm, int
 /* ------------------------------------------------------------------------------------------
  * Measurement hooks (used by bench.py; not part of the drop-in surface).
  * ---------------------------------------------------------------------------------------- */
+/* Pulls every batch of a library stream and drops it on the device: no host RecordBatch, no D2H copy (what a stacked
+ * operator would see).  rows / batches (may be NULL): what came out. */
+int32_t dfx_relation_drain_device(struct ArrowArrayStream* stream, int64_t* rows, int64_t* batches, char* err, size_t errlen);
 /* When enabled every tracked kernel launch is bracketed by HIP events on its launch stream. */
 int32_t dfx_profile_enable(int32_t on);
 int32_t dfx_profile_reset(void);

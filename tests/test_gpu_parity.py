@@ -460,6 +460,62 @@ def test_aggregate_computed_arguments_q1_shape(fast):
             assert abs(a - bb) <= 2 * EPS * abs(bb) * 4 + 1e-300, (k, a, bb)
 
 
+@pytest.mark.parametrize("strategy", [0, 1, 3])
+def test_more_than_eight_accumulators_run_in_chunks(strategy):
+    """The reference builds any number of accumulators (create_accumulators, aggregate.rs:319-342).  Real TPC-H Q1 --
+    4 SUMs, 3 AVGs (a SUM / COUNT pair each) and a COUNT: 11 accumulators -- and a 13-aggregate single-key query run as
+    chunks of <= 8 accumulators over one table; every column against the oracle (exact data: bit for bit), grouped and
+    ungrouped, with an AVG pair that straddles the chunk boundary."""
+    ex.set_option("agg.strategy", strategy)
+    try:
+        rng = np.random.default_rng(33)
+        n = 120000
+        cols = {"rf": rng.integers(0, 3, n).astype(np.int64), "ls": rng.integers(0, 2, n).astype(np.int64),
+                "qty": rng.integers(1, 51, n).astype(np.float64), "price": rng.integers(900, 105000, n).astype(np.float64),
+                "disc": rng.integers(0, 11, n).astype(np.float64) / 128.0, "tax": rng.integers(0, 9, n).astype(np.float64) / 128.0,
+                "ship": rng.integers(0, 2526, n).astype(np.float64)}
+        b = pa.RecordBatch.from_arrays([pa.array(v) for v in cols.values()], names=list(cols))
+        one_minus = BinaryExpr(lit(1.0), Operator.Minus, Column(4))
+        one_plus = BinaryExpr(lit(1.0), Operator.Plus, Column(5))
+        disc_price = BinaryExpr(Column(3), Operator.Multiply, one_minus)
+        q1 = [agg("sum", Column(2), F64), agg("sum", Column(3), F64), agg("sum", disc_price, F64),
+              agg("sum", BinaryExpr(disc_price, Operator.Multiply, one_plus), F64),
+              agg("avg", Column(2), F64), agg("avg", Column(3), F64), agg("avg", Column(4), F64), agg("count", Column(0), DataType.UInt64)]
+        pred = BinaryExpr(Column(6), Operator.LtEq, lit(2436.0))
+        batches = [b.slice(0, 50000), b.slice(50000, 70000)]
+        for group in ([Column(0), Column(1)], []):
+            got = gpu_aggregate(group, q1, b.schema, batches, filter_expr=pred)
+            want = oracle.aggregate(group, q1, [oracle.filter_next(pred, x) for x in batches])
+            if group:
+                g, w = groups_as_dict(got, 2), groups_as_dict(want, 2)
+                assert set(g) == set(w) and len(g) == 6
+                for k in w:
+                    for i, (x, y) in enumerate(zip(g[k], w[k])):
+                        if i in (2, 3):  # SUMs of products: not exact, parallel order (same tolerance as the Q1-shape test)
+                            assert abs(np.uint64(x).view(np.float64) - np.uint64(y).view(np.float64)) <= 8 * EPS * abs(np.uint64(y).view(np.float64)), (k, i)
+                        else:
+                            assert x == y, (k, i, x, y)
+            else:
+                assert got.num_rows == 1 and got.num_columns == 8
+        # 13 aggregates over the exact distribution, one high-cardinality key (partitioned strategy when forced)
+        eb = _exact_batch(rng, 200000, 30000)
+        many = [agg("sum", Column(1), F64), agg("min", Column(1), F64), agg("max", Column(1), F64), agg("count", Column(1), DataType.UInt64),
+                agg("sum", Column(2), DataType.Int64), agg("min", Column(2), DataType.Int64), agg("max", Column(2), DataType.Int64),
+                agg("avg", Column(1), F64), agg("sum", BinaryExpr(Column(1), Operator.Plus, Column(1)), F64),
+                agg("max", BinaryExpr(Column(1), Operator.Multiply, lit(2.0)), F64), agg("count", Column(2), DataType.UInt64),
+                agg("min", BinaryExpr(Column(2), Operator.Plus, Column(2)), DataType.Int64)]
+        p2 = BinaryExpr(Column(1), Operator.Gt, lit(100.0))
+        parts = [eb.slice(0, 90001), eb.slice(90001, 109999)]
+        got = gpu_aggregate([Column(0)], many, eb.schema, parts, filter_expr=p2)
+        want = oracle.aggregate([Column(0)], many, [oracle.filter_next(p2, x) for x in parts])
+        assert_groups_identical(got, want, 1, f"13 accumulators in chunks, strategy {strategy}")
+        got = gpu_aggregate([], many, eb.schema, parts, filter_expr=p2)
+        want = oracle.aggregate([], many, [oracle.filter_next(p2, x) for x in parts])
+        assert_batches_identical(got, want, "13 accumulators in chunks, ungrouped")
+    finally:
+        ex.set_option("agg.strategy", 0)
+
+
 FEW_AGGS = [agg("sum", Column(1), F64), agg("min", Column(1), F64), agg("count", Column(1), DataType.UInt64),
             agg("max", Column(2), DataType.Int64)]
 
