@@ -107,9 +107,35 @@ def main():
         return ex.AggregateRelation(None, rel, [ex.compile_scalar_expr(None, g, schema) for g in group],
                                     [ex.compile_expr(None, a, schema) for a in aggs])
 
+    # multi-GPU: the exchange of group partials runs INSIDE the library over RCCL (dfx_aggregate_exchange); torch.distributed
+    # only carries the communicator's 128-byte id once.  If RCCL cannot be bound / initialised on some rank, every rank
+    # falls back to the host-driven exchange (torch.distributed all_to_all_single around the three device steps).
+    comm = None
+    exchange_mode = "single GPU"
+    if world > 1:
+        ok = 1
+        try:
+            if shared_gpu:
+                raise RuntimeError("dry run: every rank on one GPU (RCCL needs one device per rank)")
+            from datafusion_archive_amd.distributed import library_communicator
+            comm = library_communicator(world, rank, dist)
+        except Exception as e:
+            ok = 0
+            comm_error = str(e)[:200]
+        t_ok = torch.tensor([ok], dtype=torch.int32, device=coll_device)
+        dist.all_reduce(t_ok, op=dist.ReduceOp.MIN)
+        if int(t_ok.item()) == 1:
+            exchange_mode = "library: dfx_aggregate_exchange (grouped ncclSend/ncclRecv on the library's stream)"
+        else:
+            comm = None
+            exchange_mode = "host: torch.distributed all_to_all_single around dfx_aggregate_partial_* (library communicator unavailable" + \
+                            (": " + comm_error if not ok else " on another rank") + ")"
+
     def step(filter_expr=pred, group=(Column(0),), aggs=(sum_v,)):
         agg = build(filter_expr, list(group), list(aggs))
-        if world > 1:
+        if world > 1 and comm is not None:
+            comm.exchange(agg)
+        elif world > 1:
             exchange_group_partials(agg, world, device, dist, torch)
         out = agg.next()
         assert agg.next() is None
@@ -408,7 +434,7 @@ def main():
                                    f"{n_rows} rows/GPU, k Int64 uniform 1e6 keys, v Float64 exact (m*2^-10)",
                        "rows_per_gpu": n_rows, "rows_total": total_rows, "batch_rows": args.batch_rows,
                        "algorithmic_bytes_per_row": 16, "parallelism": f"rows range-partitioned x{world}, "
-                       "group partials all-to-all" if world > 1 else "single GPU"},
+                       "group partials all-to-all" if world > 1 else "single GPU", "exchange": exchange_mode},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "extra": extra,
         }
         print(json.dumps(line), flush=True)

@@ -1482,6 +1482,10 @@ AggregateRelation::AggregateRelation(SchemaInfo schema, std::unique_ptr<Relation
     std::vector<char> needed(m.input->schema().fields.size(), 0);
     for (int ci : m.builder->columns())
       if (ci >= 0 && ci < (int)needed.size()) needed[ci] = 1;
+    for (const Impl::Chunk& ch : m.chunks)  // every chunk of accumulators reads its own columns from the same batches
+      if (ch.builder)
+        for (int ci : ch.builder->columns())
+          if (ci >= 0 && ci < (int)needed.size()) needed[ci] = 1;
     for (const Impl::DictKey& d : m.dicts)
       if (d.src_col >= 0 && d.src_col < (int)needed.size()) needed[d.src_col] = 1;
     m.input->require_columns(needed);

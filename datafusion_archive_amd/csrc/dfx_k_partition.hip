@@ -338,24 +338,44 @@ DEV int pa2n_lookup(uint32_t* ltags, uint32_t S, uint32_t slot, uint32_t img, ui
   return -1;
 }
 
-// branch-free look at ONE aligned group of four slots: index of the slot that holds the row's key / image, or -1
-DEV int p2_match_group_tags(const uint32_t* ltags, uint32_t slot4, uint32_t img) {
-  const uint4 t = *(const uint4*)&ltags[slot4];
-  int idx = -1;
-  idx = t.w == img ? 3 : idx;
-  idx = t.z == img ? 2 : idx;
-  idx = t.y == img ? 1 : idx;
-  idx = t.x == img ? 0 : idx;
-  return idx;
+// branch-free look at ONE aligned group of four slots.  The LDS read and the compare are separate steps so that the
+// reads of two rows can be issued together; p2_pin keeps the compiler from sinking a read under the condition its
+// result is used in (it would then wait for each read on its own).
+struct Group4 {
+  uint4 t;           // narrow: four tags
+  ulonglong2 ka, kb; // wide: four keys
+};
+template <int NARROW>
+DEV void p2_read_group(const uint32_t* ltags, const uint64_t* lkeys, uint32_t slot4, Group4& g) {
+  if (NARROW) {
+    g.t = *(const uint4*)&ltags[slot4];
+  } else {
+    g.ka = *(const ulonglong2*)&lkeys[slot4];
+    g.kb = *(const ulonglong2*)&lkeys[slot4 + 2];
+  }
 }
-DEV int p2_match_group_keys(const uint64_t* lkeys, uint32_t slot4, uint64_t kk) {
-  const ulonglong2 ka = *(const ulonglong2*)&lkeys[slot4];
-  const ulonglong2 kb = *(const ulonglong2*)&lkeys[slot4 + 2];
+template <int NARROW>
+DEV void p2_pin(Group4& a, Group4& b) {
+  if (NARROW) {
+    asm volatile("" : "+v"(a.t.x), "+v"(a.t.y), "+v"(a.t.z), "+v"(a.t.w), "+v"(b.t.x), "+v"(b.t.y), "+v"(b.t.z), "+v"(b.t.w));
+  } else {
+    asm volatile("" : "+v"(a.ka.x), "+v"(a.ka.y), "+v"(a.kb.x), "+v"(a.kb.y), "+v"(b.ka.x), "+v"(b.ka.y), "+v"(b.kb.x), "+v"(b.kb.y));
+  }
+}
+template <int NARROW>
+DEV int p2_match(const Group4& g, uint32_t img, uint64_t kk) {
   int idx = -1;
-  idx = kb.y == kk ? 3 : idx;
-  idx = kb.x == kk ? 2 : idx;
-  idx = ka.y == kk ? 1 : idx;
-  idx = ka.x == kk ? 0 : idx;
+  if (NARROW) {
+    idx = g.t.w == img ? 3 : idx;
+    idx = g.t.z == img ? 2 : idx;
+    idx = g.t.y == img ? 1 : idx;
+    idx = g.t.x == img ? 0 : idx;
+  } else {
+    idx = g.kb.y == kk ? 3 : idx;
+    idx = g.kb.x == kk ? 2 : idx;
+    idx = g.ka.y == kk ? 1 : idx;
+    idx = g.ka.x == kk ? 0 : idx;
+  }
   return idx;
 }
 
@@ -433,73 +453,99 @@ __global__ __launch_bounds__(kABlock) __attribute__((amdgpu_num_vgpr(kP2Vgprs)))
   const int tag_shift = T.shift - 32;                 // narrow: slot = image >> tag_shift (the image is the hash's high half)
   const uint32_t mask4 = T.block_mask & ~3u;          // home slot = base of the aligned group of four
   bool more = true;
-#define DFX_P2_TRIP(D)                                                                                            \
-  if (more) {                                                                                                     \
-    const uint32_t tk = take[D];                                                                                  \
-    if (tk == 0) {                                                                                                \
-      more = false;                                                                                               \
-    } else {                                                                                                      \
-      Row4 r;                                                                                                     \
-      p2_take<D, NARROW, kPF - 1>(r);                                                                             \
-      DFX_P2_FETCH(D)                                                                                             \
-      process(r, tk);                                                                                             \
-    }                                                                                                             \
-  }
-  auto process = [&](const Row4& r, uint32_t tk) {
+  // TWO trips are probed together: their home-group reads (and, when needed, their next-group reads) are in flight at
+  // the same time, so a wave exposes one LDS round trip per pair of trips instead of one per trip (with 4 waves per SIMD
+  // the probe loop was bound by that latency: 3.9 us per million rows whatever the instruction count).
+  struct Probe {
+    uint64_t val, kk;
+    uint32_t home4, at, img;
+    bool real, hit;
+  };
+  auto decode = [&](const Row4& r, uint32_t tk, Probe& q) {
     const bool inb = (uint32_t)lane < tk;
-    uint64_t val;
-    uint32_t home4;
-    int idx;
-    bool real;
-    uint64_t kk = 0;
     if (NARROW) {
-      val = ((uint64_t)r.z << 32) | r.y;
-      real = inb && r.x != kTagEmpty;
-      home4 = (uint32_t)(r.x >> tag_shift) & mask4;
-      idx = p2_match_group_tags(ltags, home4, r.x);
+      q.val = ((uint64_t)r.z << 32) | r.y;
+      q.img = r.x;
+      q.kk = 0;
+      q.real = inb && r.x != kTagEmpty;
+      q.home4 = (uint32_t)(r.x >> tag_shift) & mask4;
     } else {
-      kk = ((uint64_t)r.y << 32) | r.x;
-      val = ((uint64_t)r.w << 32) | r.z;
-      real = inb && kk != kEmptyKey;
-      uint64_t key1[1] = {kk};
-      home4 = (uint32_t)(hash_keys<1>(key1) >> T.shift) & mask4;
-      idx = p2_match_group_keys(lkeys, home4, kk);
+      q.kk = ((uint64_t)r.y << 32) | r.x;
+      q.val = ((uint64_t)r.w << 32) | r.z;
+      q.img = 0;
+      q.real = inb && q.kk != kEmptyKey;
+      uint64_t key1[1] = {q.kk};
+      q.home4 = (uint32_t)(hash_keys<1>(key1) >> T.shift) & mask4;
     }
-    uint32_t at = home4 + (uint32_t)idx;
-    bool hit = real && idx >= 0;
-    if (__ballot(real && !hit) != 0) {  // second group, same way (4 % of the keys live there at load 0.5)
-      const uint32_t next4 = (home4 + 4u) & mask4;
-      const int idx2 = NARROW ? p2_match_group_tags(ltags, next4, r.x) : p2_match_group_keys(lkeys, next4, kk);
-      if (!hit && real && idx2 >= 0) {
-        at = next4 + (uint32_t)idx2;
-        hit = true;
-      }
+    q.at = 0;
+    q.hit = false;
+  };
+  auto look2 = [&](Probe& q0, uint32_t g0, Probe& q1, uint32_t g1) {  // both rows' groups: two LDS reads in flight, then the compares
+    Group4 a, b;
+    p2_read_group<NARROW>(ltags, lkeys, g0, a);
+    p2_read_group<NARROW>(ltags, lkeys, g1, b);
+    p2_pin<NARROW>(a, b);
+    const int i0 = p2_match<NARROW>(a, q0.img, q0.kk), i1 = p2_match<NARROW>(b, q1.img, q1.kk);
+    if (!q0.hit && q0.real && i0 >= 0) {
+      q0.at = g0 + (uint32_t)i0;
+      q0.hit = true;
     }
-    if (hit) acc_atomic((uint8_t)KIND, &laccs[at], val);
-    const bool miss = real && !hit;
+    if (!q1.hit && q1.real && i1 >= 0) {
+      q1.at = g1 + (uint32_t)i1;
+      q1.hit = true;
+    }
+  };
+  auto finish = [&](Probe& q) {
+    if (q.hit) acc_atomic((uint8_t)KIND, &laccs[q.at], q.val);
+    const bool miss = q.real && !q.hit;
     if (__ballot(miss) != 0) {  // general find-or-claim for the rest: new keys, longer probe sequences, a full block
       bool todo = miss;
-      uint64_t key[1] = {NARROW ? 0ull : kk};
+      uint64_t key[1] = {q.kk};
       if (miss) {
-        const int found = NARROW ? pa2n_lookup(ltags, S, home4, r.x, new_keys) : pa2_lookup(lkeys, S, home4, kk, new_keys);
+        const int found = NARROW ? pa2n_lookup(ltags, S, q.home4, q.img, new_keys) : pa2_lookup(lkeys, S, q.home4, q.kk, new_keys);
         if (found >= 0) {
-          acc_atomic((uint8_t)KIND, &laccs[found], val);
+          acc_atomic((uint8_t)KIND, &laccs[found], q.val);
           todo = false;
         }
       }
       if (__ballot(todo) != 0) {  // block full: grow-and-replay takes the row (as a key again)
-        if (NARROW) key[0] = (uint64_t)unhash_word32(r.x);
+        if (NARROW) key[0] = (uint64_t)unhash_word32(q.img);
         uint64_t sv[kMaxAggs];
 #pragma unroll
-        for (int q = 0; q < kMaxAggs; ++q) sv[q] = q == 0 ? val : 0ull;
+        for (int j = 0; j < kMaxAggs; ++j) sv[j] = j == 0 ? q.val : 0ull;
         spill_row<1>(T, spill, todo, key, sv);
       }
     }
   };
-  while (more) {
-    DFX_P2_TRIP(0) DFX_P2_TRIP(1) DFX_P2_TRIP(2) DFX_P2_TRIP(3) DFX_P2_TRIP(4) DFX_P2_TRIP(5) DFX_P2_TRIP(6) DFX_P2_TRIP(7)
+  auto process2 = [&](const Row4& r0, uint32_t tk0, const Row4& r1, uint32_t tk1) {
+    Probe q0, q1;
+    decode(r0, tk0, q0);
+    decode(r1, tk1, q1);
+    look2(q0, q0.home4, q1, q1.home4);
+    if (__ballot((q0.real && !q0.hit) || (q1.real && !q1.hit)) != 0)  // second group (4 % of the keys live there at load 0.5)
+      look2(q0, (q0.home4 + 4u) & mask4, q1, (q1.home4 + 4u) & mask4);
+    finish(q0);
+    finish(q1);
+  };
+#define DFX_P2_PAIR(D0, D1)                                                                                       \
+  if (more) {                                                                                                     \
+    const uint32_t tk0 = take[D0], tk1 = take[D1];                                                                \
+    if (tk0 == 0) {                                                                                               \
+      more = false;                                                                                               \
+    } else {                                                                                                      \
+      Row4 r0, r1;                                                                                                \
+      p2_take<D0, NARROW, kPF - 1>(r0);                                                                           \
+      p2_take<D1, NARROW, kPF - 2>(r1);                                                                           \
+      DFX_P2_FETCH(D0)                                                                                            \
+      DFX_P2_FETCH(D1)                                                                                            \
+      process2(r0, tk0, r1, tk1);                                                                                 \
+      if (tk1 == 0) more = false;                                                                                 \
+    }                                                                                                             \
   }
-#undef DFX_P2_TRIP
+  while (more) {
+    DFX_P2_PAIR(0, 1) DFX_P2_PAIR(2, 3) DFX_P2_PAIR(4, 5) DFX_P2_PAIR(6, 7)
+  }
+#undef DFX_P2_PAIR
 #undef DFX_P2_FETCH
   p2_drain();  // loads still in flight own v88..v119 until they land
   __syncthreads();

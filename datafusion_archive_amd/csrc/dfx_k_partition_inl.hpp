@@ -442,7 +442,8 @@ __global__ __launch_bounds__(BLOCK) void k_partition_sorted(const DevProgram P, 
 // workgroups per CU -- 32 waves -- was measured ~20 % slower than 16 rows and one workgroup.)
 constexpr int ring_queue_rows(int rp) { return rp >= 16 ? 192 : 128; }
 constexpr int kRingBlock = 1024;
-constexpr int kHotSlots = 1024;  // hot-key pairs per pass-1 workgroup (== kRingBlock: one slot per lane in the final flush)
+constexpr int kHotSlots = 1024;        // hot-key pairs per pass-1 workgroup, 16-byte rows
+constexpr int kHotSlotsNarrow = 2048;  // ... with 12-byte rows (the ring is 16 KB smaller)
 #ifndef DFX_RING_DEPTH
 #define DFX_RING_DEPTH 1
 #endif
@@ -461,7 +462,7 @@ size_t partition_ring_bytes(uint32_t n_words, uint32_t n_parts, int kRingRP, boo
   const int kRingQ = ring_queue_rows(kRingRP);
   return (size_t)n_parts * kRingRP * (narrow ? 12 : n_words * 8) + (size_t)(kRingBlock / 64) * kRingQ * n_words * 8 +
          (size_t)(kRingBlock / 64) * 64 * (kRingRP >= 16 ? 8 : 4) + (size_t)n_parts * 4 * (1 + 2 * 4) + 64 +
-         (hot ? (size_t)kHotSlots * 16 : 0);
+         (hot ? (size_t)(narrow ? kHotSlotsNarrow : kHotSlots) * 16 : 0);
 }
 #endif
 
@@ -571,16 +572,27 @@ DEV void ring_route(const DevTable& T, const DevPartition& PT, const DevRows& sp
 // routed as ONE row (key, partial accumulator): the accumulator algebra is associative, so pass 2 cannot tell.  The
 // slot index comes from the LOW hash bits (the partition from the high ones).  Switched on by the calibration slice
 // (a front cache that absorbs a sizeable share of the rows means skew); uniform keys never pay for it.
+// Up to kHotWays consecutive slots are tried (first free one is claimed): with one slot per hash two of the top-64 keys
+// collide with probability ~0.9 in 1024 slots, and a heavy key that loses its slot overflows its regions again (measured:
+// Zipf without a filter 4.7x slower in pass 1 and 12 ms of spill replay per query).
+constexpr int kHotWays = 4;
+template <int SLOTS>
 DEV bool hot_absorb(uint64_t* hot_keys, uint64_t* hot_accs, uint8_t kind, uint64_t h, uint64_t key, uint64_t val) {
-  const uint32_t hs = (uint32_t)(h >> 32) & (uint32_t)(kHotSlots - 1);
-  uint64_t cur = hot_keys[hs];
-  if (cur == kEmptyKey) {
-    const uint64_t old = atomicCAS((unsigned long long*)&hot_keys[hs], (unsigned long long)kEmptyKey, (unsigned long long)key);
-    cur = old == kEmptyKey ? key : old;
+  uint32_t hs = (uint32_t)(h >> 32) & (uint32_t)(SLOTS - 1);
+#pragma unroll
+  for (int w = 0; w < kHotWays; ++w) {
+    uint64_t cur = hot_keys[hs];
+    if (cur == kEmptyKey) {
+      const uint64_t old = atomicCAS((unsigned long long*)&hot_keys[hs], (unsigned long long)kEmptyKey, (unsigned long long)key);
+      cur = old == kEmptyKey ? key : old;
+    }
+    if (cur == key) {
+      acc_atomic(kind, &hot_accs[hs], val);
+      return true;
+    }
+    hs = (hs + 1u) & (uint32_t)(SLOTS - 1);
   }
-  if (cur != key) return false;
-  acc_atomic(kind, &hot_accs[hs], val);
-  return true;
+  return false;
 }
 
 template <typename POL, int kRingCH, int kRingRP, bool HOT = false, int NARROW = 0>
@@ -607,13 +619,14 @@ __global__ __launch_bounds__(kRingBlock) void k_partition_ring(const DevProgram 
   // hot-key pairs behind everything else, 16-byte aligned (as an offset from `lds`: keeps the LDS address space)
   const size_t hot_word0 = (ring_words + (size_t)NWAVES * kRingQ * NW) +
                            ((size_t)(NWAVES * 64 * (kRingRP >= 16 ? 2 : 1) + PT.n_parts * (1 + 2 * 4)) * 4 + 15) / 16 * 2;
+  constexpr int kHot = NARROW ? kHotSlotsNarrow : kHotSlots;
   uint64_t* hot_keys = lds + hot_word0;
-  uint64_t* hot_accs = hot_keys + kHotSlots;
+  uint64_t* hot_accs = hot_keys + kHot;
   const int lane = lane_id();
   const int wave = threadIdx.x >> 6;
   const int na = POL::na(T);
   if (HOT) {
-    for (uint32_t i = threadIdx.x; i < (uint32_t)kHotSlots; i += kRingBlock) {
+    for (uint32_t i = threadIdx.x; i < (uint32_t)kHot; i += kRingBlock) {
       hot_keys[i] = kEmptyKey;
       hot_accs[i] = T.acc_init[0];
     }
@@ -725,7 +738,7 @@ __global__ __launch_bounds__(kRingBlock) void k_partition_ring(const DevProgram 
           for (int a = 0; a < kMaxAggs; ++a) v2[a] = (a < NV && a < na) ? q[(size_t)(1 + a) * kRingQ + qn + lane] : 0;
           const uint64_t h2 = hash_keys<1>(k2);
           bool have2 = true;
-          if (HOT && NV == 1) have2 = !hot_absorb(hot_keys, hot_accs, POL::acc_kind(T, 0), h2, k2[0], v2[0]);
+          if (HOT && NV == 1) have2 = !hot_absorb<kHot>(hot_keys, hot_accs, POL::acc_kind(T, 0), h2, k2[0], v2[0]);
           ring_route<NV, kRingCH, kRingRP, NARROW>(T, PT, spill, L, producer, na, have2, k2, v2, h2, err);
         }
       }
@@ -739,19 +752,21 @@ __global__ __launch_bounds__(kRingBlock) void k_partition_ring(const DevProgram 
 #pragma unroll
     for (int a = 0; a < kMaxAggs; ++a) v2[a] = (have && a < NV && a < na) ? q[(size_t)(1 + a) * kRingQ + lane] : 0;
     const uint64_t h2 = hash_keys<1>(k2);
-    if (HOT && NV == 1 && have) have = !hot_absorb(hot_keys, hot_accs, POL::acc_kind(T, 0), h2, k2[0], v2[0]);
+    if (HOT && NV == 1 && have) have = !hot_absorb<kHot>(hot_keys, hot_accs, POL::acc_kind(T, 0), h2, k2[0], v2[0]);
     if (qn != 0) ring_route<NV, kRingCH, kRingRP, NARROW>(T, PT, spill, L, producer, na, have, k2, v2, h2, err);
   }
   if (HOT && NV == 1) {  // every claimed hot slot becomes one routed row (key, partial accumulator)
     __syncthreads();     // all waves have finished absorbing
-    uint64_t k2[1];
-    uint64_t v2[kMaxAggs];
+    for (int i0 = 0; i0 < kHot; i0 += kRingBlock) {
+      uint64_t k2[1];
+      uint64_t v2[kMaxAggs];
 #pragma unroll
-    for (int a = 0; a < kMaxAggs; ++a) v2[a] = 0;
-    k2[0] = hot_keys[threadIdx.x];
-    v2[0] = hot_accs[threadIdx.x];
-    const bool have = k2[0] != kEmptyKey;
-    if (__ballot(have) != 0) ring_route<NV, kRingCH, kRingRP, NARROW>(T, PT, spill, L, producer, na, have, k2, v2, hash_keys<1>(k2), err);
+      for (int a = 0; a < kMaxAggs; ++a) v2[a] = 0;
+      k2[0] = hot_keys[i0 + threadIdx.x];
+      v2[0] = hot_accs[i0 + threadIdx.x];
+      const bool have = k2[0] != kEmptyKey;
+      if (__ballot(have) != 0) ring_route<NV, kRingCH, kRingRP, NARROW>(T, PT, spill, L, producer, na, have, k2, v2, hash_keys<1>(k2), err);
+    }
   }
   __syncthreads();
   // partial chunks + region counts.  A partial chunk is padded to a whole one with rows whose key is kEmptyKey (pass 2

