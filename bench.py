@@ -222,20 +222,22 @@ def main():
                     "all_aggregation_kernels_GBps": round(n_rows * args.steps * 16 / pipeline_ms * 1e-6, 1)
                     if pipeline_ms > 0 else None}
 
-    # HBM traffic of the dominant kernel from the rocprofv3 PMC passes of this same command
-    # (tools/gpu_profile_bench.sh -> profiles/r01_bench_hbm_counters.json; FETCH_SIZE and WRITE_SIZE
-    # collected in separate passes; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950 --
-    # with the doubling it equals the table bytes read, our calibration point).  null if absent.
+    # HBM traffic of the dominant kernel: rocprofv3 PMC passes over the same query (tools/gpu_profile_r2.sh ->
+    # profiles/r02_partition_counters.json; FETCH_SIZE and WRITE_SIZE collected in SEPARATE passes; FETCH_SIZE doubled as
+    # MI355X_MICROARCH.md prescribes for gfx950 -- doubled it equals the table bytes read, the calibration point).  It is a
+    # committed measurement of this kernel, not something this run collected; null if the file is absent.
     if roofline is not None:
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_bench_hbm_counters.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r02_partition_counters.json")) as f:
                 ctr = json.load(f)
-            key = [k for k in ctr if (("k_partition_ring<" in k or "k_partition<" in k or "k_partition_sorted<" in k)
-                                    if dom == "partition" else dom in k)]
+            want = "headline | pass1" if dom == "partition" else None
+            key = [k for k in ctr if want and k.startswith(want)]
             if key:
                 c = ctr[key[0]]
-                roofline["traffic"] = (2.0 * c["FETCH_SIZE_KB_per_dispatch"] + c["WRITE_SIZE_KB_per_dispatch"]) * 1024.0
-                roofline["traffic_source"] = "profiles/r01_bench_hbm_counters.json (rocprofv3 --pmc, 2*FETCH_SIZE + WRITE_SIZE per dispatch)"
+                roofline["traffic"] = (2.0 * c["FETCH_SIZE_per_dispatch"] + c["WRITE_SIZE_per_dispatch"]) * 1024.0
+                roofline["traffic_over_algorithmic"] = round(roofline["traffic"] / roofline["algo_bytes_per_launch"], 3)
+                roofline["traffic_source"] = ("profiles/r02_partition_counters.json (rocprofv3 --pmc in separate passes over tools/prof_query.py headline, "
+                                              "2*FETCH_SIZE + WRITE_SIZE per dispatch of the pass-1 kernel; committed, not collected by this run)")
         except Exception:
             pass
 

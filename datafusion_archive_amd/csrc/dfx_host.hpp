@@ -116,6 +116,7 @@ struct Counters {
   long long agg_drain_us = 0;       // drain(): every batch consumed and settled
   long long agg_alloc_us = 0;       // routing scratch / spill list / table allocation
   long long export_us = 0;          // device batch -> host Arrow (allocation of the pinned result buffers, D2H, synchronisation)
+  long long export_alloc_us = 0;    // ... of which: result buffer allocation (pinned pool)
   long long agg_pass2_launches = 0;
   long long agg_growths = 0;
 };

@@ -192,6 +192,7 @@ void* host_alloc(size_t bytes) {
 // result buffer owned by the exported array: pinned (pooled) when large, so the D2H copy runs at
 // PCIe speed instead of through a pageable staging copy
 void* alloc_result(ArrayPriv* p, size_t bytes) {
+  ScopedUs t_alloc(&counters().export_alloc_us);
   if (bytes >= (1u << 16)) {
     Status st;
     std::shared_ptr<void> b = pinned_alloc(bytes + 64, &st);

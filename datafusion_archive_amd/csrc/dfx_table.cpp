@@ -367,6 +367,7 @@ int64_t dfx_counter_get(const char* name) {
   if (!strcmp(name, "agg_pass2_launches")) return counters().agg_pass2_launches;
   if (!strcmp(name, "agg_growths")) return counters().agg_growths;
   if (!strcmp(name, "export_us")) return counters().export_us;
+  if (!strcmp(name, "export_alloc_us")) return counters().export_alloc_us;
   return -1;
 }
 void dfx_counter_reset(void) { counters() = Counters(); }

@@ -37,10 +37,10 @@ if os.environ.get("KPROBE_NOGC") == "1": gc.disable()
 NQ = int(os.environ.get("KPROBE_QUERIES", "5"))
 marks = []
 for _ in range(NQ):
-    c0 = {k: ex.counter_get(k) for k in ("agg_drain_us", "agg_emit_us", "export_us")}
+    c0 = {k: ex.counter_get(k) for k in ("agg_drain_us", "agg_emit_us", "export_us", "export_alloc_us")}
     t0 = time.perf_counter(); out = run(); ex.synchronize(); per.append((time.perf_counter() - t0) * 1e3)
-    marks.append("/".join(str(ex.counter_get(k) - c0[k]) for k in ("agg_drain_us", "agg_emit_us", "export_us")))
-if max(per) > 1.5 * min(per): print("   slow query breakdown (drain/emit/export us per query): " + " ".join(marks))
+    marks.append("/".join(str(ex.counter_get(k) - c0[k]) for k in ("agg_drain_us", "agg_emit_us", "export_us", "export_alloc_us")))
+if max(per) > 1.5 * min(per): print("   slow query breakdown (drain/emit/export/export-alloc us per query): " + " ".join(marks))
 dt = sum(per) / len(per) / 1e3
 print("per-query ms: " + " ".join(f"{x:.2f}" for x in per) + "   host us/query: " + " ".join(
     f"{k}={ex.counter_get('agg_' + k) / len(per):.0f}" for k in ("ctrl_wait_us", "sync_us", "emit_us", "drain_us", "alloc_us", "pass2_launches", "growths")) + f" export_us={ex.counter_get('export_us') / len(per):.0f}")
