@@ -17,7 +17,7 @@ Multi-GPU (--gpus N, launched by torch.distributed.run): weak scaling, every ran
 global row range, aggregates locally, exchanges GROUP partials with one RCCL all-to-all, merges and
 emits the groups it owns.  value = rows of all ranks / max-over-ranks time.
 
-Timing: `--prewarm-steps` untimed steps (idle-box clocks), W warm-up steps, then EXACTLY K steps between barrier +
+Timing: one cold step (reported as extra.cold_first_step_ms), W warm-up steps, then EXACTLY K steps between barrier +
 synchronize on both sides, un-instrumented -> value / ms_per_step; then K more steps with the library's HIP-event profiler
 on -> the per-kernel durations of the `roofline` object (extra.instrumented_ms_per_step is that region's time).  At N=1 the
 line also carries cpu_baseline (the C restatement of the reference on one host core, 3e8-row sample) and, in `extra`, the
@@ -50,9 +50,12 @@ def main():
     ap.add_argument("--cpu-sample-rows", type=float, default=3e8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
-    ap.add_argument("--prewarm-steps", type=int, default=600,
-                    help="untimed steps before the W warmup steps (~3.5 s: the first seconds of the first process on an idle box run ~4 % slower); "
-                         "a fixed count so that every rank runs the same number of exchanges")
+    ap.add_argument("--prewarm-steps", type=int, default=0,
+                    help="extra untimed steps before the W warmup steps.  Round 1 ran 600 of them (~3.5 s) believing the first seconds of a "
+                         "process are slower; round 2 measured the opposite on most boxes -- after seconds of sustained load pass 1 runs "
+                         "8-10 %% slower (0.250 ms per launch against 0.229 ms in a short run on the same box, DESIGN.md section 5) -- so the "
+                         "default is the contract's: W warm-up steps, then K timed ones.  The process's very first step (pools, calibration) "
+                         "is reported as extra.cold_first_step_ms")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
