@@ -23,6 +23,7 @@
 
 namespace dfx {
 
+uint32_t host_unhash_word32(uint32_t image) { return unhash_word32(image); }
 uint64_t host_hash_keys(const uint64_t* key, int kw) {
   switch (kw) {
     case 1: return hash_keys<1>(key);

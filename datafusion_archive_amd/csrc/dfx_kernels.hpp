@@ -190,5 +190,6 @@ hipError_t launch_synth(int kind, int column_id, double p0, double p1, uint64_t 
 
 // host mirror of the device hash (rank ownership in tests)
 uint64_t host_hash_keys(const uint64_t* key, int kw);
+uint32_t host_unhash_word32(uint32_t image);
 
 }  // namespace dfx

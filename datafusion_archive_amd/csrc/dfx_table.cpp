@@ -355,6 +355,9 @@ int32_t dfx_profile_get(int32_t index, char* name, size_t namelen, int64_t* laun
   return DFX_OK;
 }
 
+uint64_t dfx_debug_group_hash(uint64_t key) { return host_hash_keys(&key, 1); }
+uint32_t dfx_debug_unhash32(uint32_t image) { return host_unhash_word32(image); }
+
 int64_t dfx_counter_get(const char* name) {
   if (!name) return -1;
   if (!strcmp(name, "h2d_bytes")) return counters().h2d_bytes;

@@ -343,6 +343,12 @@ int32_t dfx_aggregate_exchange(struct ArrowArrayStream* agg, dfx_comm* comm, int
 /* ------------------------------------------------------------------------------------------
  * Measurement hooks (used by bench.py; not part of the drop-in surface).
  * ---------------------------------------------------------------------------------------- */
+/* The group hash of a single-word key (its 32 bits sit in the HIGH half: table slot = hash >> (64 - log2 capacity)) and,
+ * for keys below 2^32, its inverse: the hash restricted to such keys is a bijection of the low word, which is what lets
+ * the partitioned GROUP BY route 12-byte rows {hash image, operand} and turn claimed images back into keys.  Host code,
+ * no GPU needed; used by the CPU tests. */
+uint64_t dfx_debug_group_hash(uint64_t key);
+uint32_t dfx_debug_unhash32(uint32_t image);
 /* Pulls every batch of a library stream and drops it on the device: no host RecordBatch, no D2H copy (what a stacked
  * operator would see).  rows / batches (may be NULL): what came out. */
 int32_t dfx_relation_drain_device(struct ArrowArrayStream* stream, int64_t* rows, int64_t* batches, char* err, size_t errlen);

@@ -197,8 +197,17 @@ def test_fuzz_aggregate(with_nulls, strategy):
         keys = [Column(int(rng.choice(int_types))) for _ in range(n_keys)]
         if keys and strategy != 3 and rng.random() < 0.25:
             keys[0] = Column(10)  # a Utf8 key (device dictionary)
+        if strategy == 3:  # the partitioned strategy's flavours, at random: 12-byte rows, hot-key pairs, deferred pass 2, layouts
+            flavour = {"agg.narrow_keys": int(rng.choice([-1, 1])), "agg.hot_keys": int(rng.choice([0, 1])),
+                       "agg.partition_defer": int(rng.choice([1, 4])), "agg.partition_layout": int(rng.integers(0, 3)),
+                       "agg.pass2_stream": int(rng.choice([0, 1])), "agg.ctrl_snapshot": int(rng.choice([0, 1]))}
+            for k, v in flavour.items():
+                ex.set_option(k, v)
         aggs = []
-        for _ in range(int(rng.integers(1, 5))):
+        n_aggs = int(rng.integers(1, 5)) if rng.random() < 0.85 else int(rng.integers(5, 13))  # sometimes more than 8 accumulators: chunks
+        if strategy == 3 and rng.random() < 0.5:
+            n_aggs = 1  # the one-aggregate kernels (narrow rows, lean pass 2) are the partitioned strategy's main line
+        for _ in range(n_aggs):
             t = int(rng.integers(0, len(NP_TYPES)))
             fn = str(rng.choice(["min", "max", "count", "sum", "avg"]))
             if fn in ("sum", "avg"):
@@ -237,6 +246,9 @@ def test_fuzz_aggregate(with_nulls, strategy):
         else:
             stats[r] += 1
         del src
+    for k, v in (("agg.narrow_keys", -1), ("agg.hot_keys", -1), ("agg.partition_defer", 1), ("agg.partition_layout", 1),
+                 ("agg.pass2_stream", 1), ("agg.ctrl_snapshot", 1)):
+        ex.set_option(k, v)
     print(f"fuzz aggregate nulls={with_nulls} strategy={strategy}: {stats}")
     assert stats["ok"] >= 40
 

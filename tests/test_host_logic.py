@@ -21,7 +21,7 @@ SCHEMA = pa.schema([pa.field("city", pa.string(), False), pa.field("lat", pa.flo
 def test_library_exports_every_declared_symbol():
     L = _ffi.lib()
     header = open(os.path.join(ROOT, "include", "dfx.h")).read()
-    declared = sorted(set(re.findall(r"^(?:int32_t|int64_t|void|const char\*|const void\*)\s+(dfx_[a-z0-9_]+)\(", header, re.M)))
+    declared = sorted(set(re.findall(r"^(?:int32_t|int64_t|uint32_t|uint64_t|void|const char\*|const void\*)\s+(dfx_[a-z0-9_]+)\(", header, re.M)))
     assert declared, "no declarations parsed from include/dfx.h"
     for name in declared:
         assert hasattr(L, name), f"libdfx_hip.so does not export {name}"
@@ -284,3 +284,21 @@ def test_explain_operator_tree_and_pushdown():
     from datafusion_archive_amd import _ffi
     foreign = _ffi.ArrowArrayStream()
     assert _ffi.lib().dfx_relation_explain(ctypes.addressof(foreign), None, 0) == -1
+
+
+def test_group_hash_is_a_bijection_of_narrow_keys():
+    """Narrow rows (PTF_NARROW) stand on this: for keys below 2^32 the 32-bit image of the group hash identifies the key
+    (dfx_debug_unhash32 inverts it), images of different keys differ, and a key with high bits hashes differently from its
+    low word alone (so it must not be sent as an image)."""
+    import numpy as np
+    from datafusion_archive_amd import _ffi
+    L = _ffi.lib()
+    rng = np.random.default_rng(3)
+    keys = np.unique(np.concatenate([np.arange(0, 5000), rng.integers(0, 1 << 32, 200000), [(1 << 32) - 1, 999999, 1 << 31]]).astype(np.uint64))
+    images = np.array([L.dfx_debug_group_hash(int(k)) >> 32 for k in keys], dtype=np.uint64)
+    assert all(L.dfx_debug_group_hash(int(k)) & 0xFFFFFFFF == 0 for k in keys[:100])  # the hash lives in the high half
+    assert len(np.unique(images)) == len(keys)
+    for k, im in zip(keys[::37], images[::37]):
+        assert L.dfx_debug_unhash32(int(im)) == int(k)
+    wide = int(keys[1234]) | (5 << 32)
+    assert L.dfx_debug_group_hash(wide) != L.dfx_debug_group_hash(int(keys[1234]))
