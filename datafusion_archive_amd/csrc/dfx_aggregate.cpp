@@ -63,8 +63,9 @@ struct AggregateRelation::Impl {
     std::string name;
   };
   std::vector<OutAgg> outs;
-  // More than kMaxAggs accumulators (the reference has no limit: create_accumulators builds any number,
-  // aggregate.rs:319-342; real TPC-H Q1 needs 11) are split into CHUNKS of <= kMaxAggs: one fused program per chunk
+  // More accumulators than one fused program takes (the reference has no limit: create_accumulators builds any number,
+  // aggregate.rs:319-342; real TPC-H Q1 needs 11) are split into CHUNKS -- <= kMaxAggs accumulators whose arguments fit the
+  // program's limits on columns / computed values / literals: one fused program per chunk
   // (predicate + keys + that chunk's arguments), all chunks updating their own accumulator planes of the SAME table --
   // the second chunk's kernels find the key the first one inserted.  `builder / plan / fast / na / acc_kind ...` and the
   // table view T always describe the ACTIVE chunk; the others rest in `chunks`.  One chunk (the common case) never
@@ -219,12 +220,23 @@ Status AggregateRelation::Impl::setup(const SchemaInfo& input_schema) {
   out_dtype.assign(na_total, 0);
   func.assign(na_total, 0);
   chunks.clear();
-  for (int a0 = 0; a0 == 0 || a0 < na_total; a0 += kMaxAggs) {
-    chunks.emplace_back();
-    Chunk& ch = chunks.back();
-    ch.a0 = a0;
-    ch.n = std::min(kMaxAggs, na_total - a0);
-    DFX_RETURN_IF_ERROR(build_chunk_programs(ch));
+  for (int a0 = 0; a0 == 0 || a0 < na_total;) {
+    // as many of the next accumulators as ONE fused program takes: <= kMaxAggs, and within the program's limits on
+    // distinct columns, computed values and literals (a chunk that does not fit is rebuilt one accumulator shorter)
+    int n = std::min(kMaxAggs, na_total - a0);
+    for (;;) {
+      Chunk ch;
+      ch.a0 = a0;
+      ch.n = n;
+      Status st = build_chunk_programs(ch);
+      if (st.ok()) {
+        chunks.push_back(std::move(ch));
+        break;
+      }
+      if (st.code != DFX_NOT_IMPLEMENTED || n <= 1) return st;
+      --n;
+    }
+    a0 += std::max(n, 1);
   }
   // chunk 0 becomes the active one
   cur_chunk = 0;

@@ -273,7 +273,11 @@ Status ProgramBuilder::emit(const dfx_runtime_expr& e, int32_t idx, uint8_t* ope
       int ta = 0, tb = 0;
       DFX_RETURN_IF_ERROR(emit(e, n.left, &a, &ta));
       if (n.kind == DFX_EXPR_CAST) {
-        if (ta == n.dtype) {  // `as` to the same type is the identity
+        // `as` to the same type is the identity -- for a computed value or a literal.  A COLUMN keeps its instruction:
+        // cast_column! builds a NEW array (expression.rs:246-270), whose null slots hold zero, and the grouped aggregates
+        // read value(row) of their argument without a null check (aggregate.rs:561-603), so MAX(CAST(c AS its own type))
+        // over a null slot sees 0, not the column's raw content (found by tests/test_gpu_fuzz.py)
+        if (ta == n.dtype && (a >> 6) != OPK_COL) {
           *operand = a;
           *dtype = ta;
           return Status::OK();

@@ -18,6 +18,8 @@
 #include <string>
 #include <vector>
 
+#include <algorithm>
+
 #include "dfx_kernels_inl.hpp"
 #include "dfx_launch.hpp"
 
@@ -740,6 +742,32 @@ hipError_t launch_partial_scatter(const DevTable& T, int world, const uint64_t* 
 #define CALL(K) table_partial_scatter<K>(T, world, bucket_base, bucket_count, cursors, dst, s)
   DFX_KW_DISPATCH(T.kw, CALL)
 #undef CALL
+}
+
+// Result download by the shader: 16-byte loads from HBM, 16-byte stores to host-mapped pinned memory (the destination
+// is hipHostMalloc'd, device-accessible).  The copy engines' path showed sporadic 6 - 150 ms stalls on these boxes for an
+// 8 MB device-to-host copy (tools/d2h_probe.py: 1 in 300 with torch's own copy, too); a kernel on the query's stream has
+// no such outliers and needs no engine hand-over.  `bytes` any value; src / dst 16-byte aligned (pool allocations are).
+__global__ __launch_bounds__(256) void k_copy_to_host(const uint4* __restrict__ src, uint4* __restrict__ dst, int64_t n16,
+                                                      const uint8_t* __restrict__ src_tail, uint8_t* __restrict__ dst_tail, int tail) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 256) {
+    const uint4 v = src[i];
+    __builtin_nontemporal_store(v.x, &dst[i].x);
+    __builtin_nontemporal_store(v.y, &dst[i].y);
+    __builtin_nontemporal_store(v.z, &dst[i].z);
+    __builtin_nontemporal_store(v.w, &dst[i].w);
+  }
+  if (blockIdx.x == 0 && (int)threadIdx.x < tail) dst_tail[threadIdx.x] = src_tail[threadIdx.x];
+}
+hipError_t launch_copy_to_host(const void* src_device, void* dst_pinned, size_t bytes, hipStream_t s) {
+  if (bytes == 0) return hipSuccess;
+  if ((((uintptr_t)src_device) | ((uintptr_t)dst_pinned)) & 15u) return hipMemcpyAsync(dst_pinned, src_device, bytes, hipMemcpyDeviceToHost, s);
+  const int64_t n16 = (int64_t)(bytes / 16);
+  const int tail = (int)(bytes % 16);
+  const int grid = (int)std::min<int64_t>(1024, std::max<int64_t>(1, (n16 + 255) / 256));
+  hipLaunchKernelGGL(k_copy_to_host, dim3(grid), dim3(256), 0, s, (const uint4*)src_device, (uint4*)dst_pinned, n16,
+                     (const uint8_t*)src_device + n16 * 16, (uint8_t*)dst_pinned + n16 * 16, tail);
+  return hipGetLastError();
 }
 
 hipError_t launch_fill_u64(uint64_t* p, uint64_t v, int64_t n, hipStream_t s) {

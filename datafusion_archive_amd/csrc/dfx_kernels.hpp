@@ -98,6 +98,8 @@ hipError_t launch_merge_rows(const DevRows& rows, int64_t row_begin, int64_t n_r
                              const DevRows& spill, hipStream_t s);
 hipError_t launch_rehash(const DevTable& from, const DevTable& to, const DevRows& spill, hipStream_t s);
 hipError_t launch_fill_u64(uint64_t* p, uint64_t v, int64_t n, hipStream_t s);
+// device -> host-mapped pinned memory by a kernel on `s` (falls back to hipMemcpyAsync for unaligned pointers)
+hipError_t launch_copy_to_host(const void* src_device, void* dst_pinned, size_t bytes, hipStream_t s);
 hipError_t launch_fill_u32(uint32_t* p, uint32_t v, int64_t n, hipStream_t s);
 
 // K8 emit_groups: occupancy bitmap of the table (then launch_scan_u32 + launch_compact on each

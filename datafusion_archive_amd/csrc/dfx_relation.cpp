@@ -283,7 +283,13 @@ Status download_column(const DeviceColumn& c, struct ArrowArray* out, std::vecto
     const size_t bytes = (size_t)n * dtype_width(c.dtype);
     void* raw = alloc_result(p, bytes);
     if (!raw) return Status::Err(DFX_EXECUTION_ERROR, "host allocation failed");
-    if (bytes) DFX_HIP(hipMemcpyAsync(raw, c.values, bytes, hipMemcpyDeviceToHost, s));
+    // large fixed-width result columns (pinned destination): copied by a kernel on the query's stream when the option
+    // says so (export.kernel_copy; the copy engines' path has sporadic multi-millisecond stalls on these boxes)
+    if (bytes >= (1u << 16) && agg_options().export_kernel_copy && !p->pinned.empty() && p->pinned.back().get() == raw) {
+      DFX_HIP(launch_copy_to_host(c.values, raw, bytes, s));
+    } else if (bytes) {
+      DFX_HIP(hipMemcpyAsync(raw, c.values, bytes, hipMemcpyDeviceToHost, s));
+    }
     p->buffer_ptrs.push_back(raw);
     out->n_buffers = 2;
   }

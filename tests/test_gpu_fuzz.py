@@ -117,21 +117,21 @@ def same_batches(got, want, what):
 
 
 def run_both(dev, ora, what):
-    """Both succeed with equal results, or both fail with the same error class. 'needs more than' = the fused program
-    limits of the device (kMaxRegs / kMaxCols / kMaxImm): skipped."""
+    """Both succeed with equal results, or both fail with the same error class. NotImplemented '... more than ...' = the fused program
+    limits of the device (kMaxRegs / kMaxCols / kMaxImm) hit by ONE expression tree (aggregates beyond them are chunked): skipped."""
     try:
         want = ora()
     except oracle.OracleError as e:
         with pytest.raises(ex.ExecutionError) as ei:
             dev()
-        if "needs more than" in ei.value.message:
+        if "more than" in ei.value.message and ei.value.kind == "NotImplemented":
             return "skipped"
         assert ei.value.code == e.code, (what, str(e), ei.value.message)
         return "error"
     try:
         got = dev()
     except ex.ExecutionError as e:
-        if "needs more than" in e.message:
+        if "more than" in e.message and e.kind == "NotImplemented":
             return "skipped"
         raise AssertionError(f"{what}: device failed with {e}, oracle succeeded")
     return got, want
@@ -246,7 +246,7 @@ def test_fuzz_aggregate(with_nulls, strategy):
         else:
             stats[r] += 1
         del src
-    for k, v in (("agg.narrow_keys", -1), ("agg.hot_keys", -1), ("agg.partition_defer", 1), ("agg.partition_layout", 1),
+    for k, v in (("agg.narrow_keys", -1), ("agg.hot_keys", -1), ("agg.partition_defer", 2), ("agg.partition_layout", 1),
                  ("agg.pass2_stream", 1), ("agg.ctrl_snapshot", 1)):
         ex.set_option(k, v)
     print(f"fuzz aggregate nulls={with_nulls} strategy={strategy}: {stats}")

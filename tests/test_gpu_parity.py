@@ -1019,6 +1019,22 @@ def test_aggregate_over_filter_keeps_boolean_column_error(with_nulls, rows):
     assert "filter not supported for Boolean" in str(oi.value)
 
 
+def test_identity_cast_of_a_column_zeroes_its_null_slots():
+    """Third rule found by tests/test_gpu_fuzz.py: CAST(c AS <c's own type>) is not the column -- cast_column! builds a new
+    array whose null slots hold zero (expression.rs:246-270), and the grouped aggregates read value(row) of their argument
+    without a null check (aggregate.rs:561-603): MAX(CAST(i AS Int64)) over a group whose only i is NULL is 0, MAX(i) is the
+    slot's raw content."""
+    rng = np.random.default_rng(9)
+    b = _exact_batch(rng, 40000, 300, with_nulls=True)
+    aggs = [agg("max", Cast(Column(2), DataType.Int64), DataType.Int64), agg("max", Column(2), DataType.Int64),
+            agg("min", Cast(Column(1), F64), F64)]
+    for strategy in (1, 0):
+        ex.set_option("agg.strategy", strategy)
+        got = gpu_aggregate([Column(0)], aggs, b.schema, [b.slice(0, 15000), b.slice(15000, 25000)])
+        want = oracle.aggregate([Column(0)], aggs, [b.slice(0, 15000), b.slice(15000, 25000)])
+        assert_groups_identical(got, want, 1, f"identity cast over nulls, strategy {strategy}")
+
+
 # ---------------------------------------------------------------------------------------------------
 # two rules the randomised differential test (tests/test_gpu_fuzz.py) found the fused paths breaking
 # ---------------------------------------------------------------------------------------------------
