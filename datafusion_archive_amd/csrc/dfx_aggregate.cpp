@@ -538,7 +538,16 @@ Status AggregateRelation::Impl::ensure_partition(int64_t rows) {
     if (want_narrow && chunks8) PT.flags |= PTF_NARROW;
     if (hot && na == 1 && chunks8 && partition_ring_bytes(PT.n_words, PT.n_parts, 16, true, (PT.flags & PTF_NARROW) != 0) <= (size_t)158 * 1024)
       PT.flags |= PTF_HOT;
+    if ((PT.flags & PTF_NARROW) && !(PT.flags & PTF_HOT) && o.narrow_chunk16 && partition_ring_bytes(PT.n_words, PT.n_parts, 32, false, true) <= (size_t)158 * 1024)
+      PT.flags |= PTF_CHUNK16;
     PT.mode = 2u | ((uint32_t)o.partition_mode & ~15u);
+    PT.block = 1024;
+    PT.stage_rows = 0;
+    PT.n_producers = (uint32_t)std::min(1024, device_cu_count());
+    if (o.partition_producers > 0) PT.n_producers = (uint32_t)std::min(1024, o.partition_producers);
+  } else if (want == 2 && partition_ring_bytes(PT.n_words, PT.n_parts, 8) <= (size_t)158 * 1024) {
+    // several aggregates: rows of 3+ words.  8-row rings (two 4-row chunks) still fit where 16-row ones do not
+    PT.mode = 2u | 0x100u;
     PT.block = 1024;
     PT.stage_rows = 0;
     PT.n_producers = (uint32_t)std::min(1024, device_cu_count());

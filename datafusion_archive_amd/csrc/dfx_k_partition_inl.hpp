@@ -444,7 +444,7 @@ __global__ __launch_bounds__(BLOCK) void k_partition_sorted(const DevProgram P, 
 // Leftover partial chunks are written row by row at the end.
 // ring rows per partition kRingRP = rows per chunk (CH: 4 or 8) x chunks (NCH).  (An 8-row ring with two
 // workgroups per CU -- 32 waves -- was measured ~20 % slower than 16 rows and one workgroup.)
-constexpr int ring_queue_rows(int rp) { return rp >= 16 ? 192 : 128; }
+constexpr int ring_queue_rows(int rp) { return rp == 16 ? 192 : 128; }  // (32-row rings: 16-row chunks of 12-byte rows need the LDS)
 constexpr int kRingBlock = 1024;
 constexpr int kHotSlots = 1024;        // hot-key pairs per pass-1 workgroup, 16-byte rows
 constexpr int kHotSlotsNarrow = 2048;  // ... with 12-byte rows (the ring is 16 KB smaller)
@@ -825,10 +825,17 @@ void launch_partition_pol(const DevProgram& P, const DevFastPlan& fast, const De
   const int grid = (int)PT.n_producers;  // every producer writes its counts, even with no rows
   if ((PT.mode & 15u) == 0)
     hipLaunchKernelGGL((k_partition<POL>), dim3(grid), dim3(kPBlock), lds_bytes, s, P, fast, C, plan, T, PT, spill, n);
+  else if ((PT.mode & 15u) == 2 && (PT.mode & 0x100u))  // rows of 3+ words: 8-row rings of 4-row chunks (a 16-row ring of
+                                                       // 24-byte rows + its queues do not fit LDS; the counting sort is 2-3 x slower)
+    hipLaunchKernelGGL((k_partition_ring<POLS, 4, 8>), dim3(grid), dim3(kRingBlock), lds_bytes, s, P, fast, C, plan, T, PT, spill, n);
   else if ((PT.mode & 15u) == 2 && (PT.mode & 0x80u))  // 4-row chunks (64-byte runs)
     hipLaunchKernelGGL((k_partition_ring<POLS, 4, 16>), dim3(grid), dim3(kRingBlock), lds_bytes, s, P, fast, C, plan, T, PT, spill, n);
   else if ((PT.mode & 15u) == 2 && (PT.flags & PTF_NARROW) && (PT.flags & PTF_HOT))
     hipLaunchKernelGGL((k_partition_ring<POLS, 8, 16, true, 1>), dim3(grid), dim3(kRingBlock), lds_bytes, s, P, fast, C, plan, T, PT, spill, n);
+  else if ((PT.mode & 15u) == 2 && (PT.flags & PTF_NARROW) && (PT.flags & PTF_CHUNK16))
+    // 16-row chunks: 192 bytes = three whole 64-byte sectors (a 96-byte chunk of 8 rows straddles sectors: WRITE_SIZE was
+    // 1.26 x the routed bytes)
+    hipLaunchKernelGGL((k_partition_ring<POLS, 16, 32, false, 1>), dim3(grid), dim3(kRingBlock), lds_bytes, s, P, fast, C, plan, T, PT, spill, n);
   else if ((PT.mode & 15u) == 2 && (PT.flags & PTF_NARROW))  // narrow keys: 12-byte rows
     hipLaunchKernelGGL((k_partition_ring<POLS, 8, 16, false, 1>), dim3(grid), dim3(kRingBlock), lds_bytes, s, P, fast, C, plan, T, PT, spill, n);
   else if ((PT.mode & 15u) == 2 && (PT.flags & PTF_HOT))  // skewed keys: hot-key pairs in LDS

@@ -398,6 +398,7 @@ int32_t dfx_set_option(const char* key, int64_t value) {
   else if (!strcmp(key, "agg.hot_keys")) o.hot_keys = (int)value;
   else if (!strcmp(key, "agg.partition_layout")) o.partition_layout = (int)value;
   else if (!strcmp(key, "agg.narrow_keys")) o.narrow_keys = (int)value;
+  else if (!strcmp(key, "agg.narrow_chunk16")) o.narrow_chunk16 = (int)value;
   else if (!strcmp(key, "agg.ctrl_snapshot")) o.ctrl_snapshot = (int)value;
   else if (!strcmp(key, "export.kernel_copy")) o.export_kernel_copy = (int)value;
   else if (!strcmp(key, "agg.partition_producers")) o.partition_producers = (int)value;

@@ -200,7 +200,8 @@ def test_fuzz_aggregate(with_nulls, strategy):
         if strategy == 3:  # the partitioned strategy's flavours, at random: 12-byte rows, hot-key pairs, deferred pass 2, layouts
             flavour = {"agg.narrow_keys": int(rng.choice([-1, 1])), "agg.hot_keys": int(rng.choice([0, 1])),
                        "agg.partition_defer": int(rng.choice([1, 4])), "agg.partition_layout": int(rng.integers(0, 3)),
-                       "agg.pass2_stream": int(rng.choice([0, 1])), "agg.ctrl_snapshot": int(rng.choice([0, 1]))}
+                       "agg.pass2_stream": int(rng.choice([0, 1])), "agg.ctrl_snapshot": int(rng.choice([0, 1])),
+                       "agg.narrow_chunk16": int(rng.choice([0, 1]))}
             for k, v in flavour.items():
                 ex.set_option(k, v)
         aggs = []
@@ -247,7 +248,7 @@ def test_fuzz_aggregate(with_nulls, strategy):
             stats[r] += 1
         del src
     for k, v in (("agg.narrow_keys", -1), ("agg.hot_keys", -1), ("agg.partition_defer", 2), ("agg.partition_layout", 1),
-                 ("agg.pass2_stream", 1), ("agg.ctrl_snapshot", 1)):
+                 ("agg.pass2_stream", 1), ("agg.ctrl_snapshot", 1), ("agg.narrow_chunk16", 1)):
         ex.set_option(k, v)
     print(f"fuzz aggregate nulls={with_nulls} strategy={strategy}: {stats}")
     assert stats["ok"] >= 40

@@ -699,6 +699,29 @@ def test_partitioned_narrow_rows_hot_keys_and_deferred_pass2(hot, layout):
             ex.set_option(k, v)
 
 
+def test_partitioned_three_word_rows_use_the_small_ring():
+    """Two aggregates = 24-byte routed rows: with 256 table blocks (2^20 slots) the 16-row rings do not fit LDS and pass 1
+    runs the 8-row-ring flavour (two 4-row chunks) instead of the counting sort; uniform and skewed keys, with a predicate,
+    several batches (deferred pass 2), against the oracle."""
+    ex.set_option("agg.strategy", 3)
+    ex.set_option("agg.capacity_log2", 20)
+    try:
+        schema = pa.schema([("k", pa.int64()), ("v", pa.float64())])
+        pred = BinaryExpr(Column(1), Operator.Lt, lit(800.0))
+        aggs = [agg("sum", Column(1), F64), agg("max", Column(1), F64)]
+        for kind in (ex.SYNTH_I64_UNIFORM, ex.SYNTH_I64_ZIPF):
+            syn = [("k", kind, 0, 200000.0, 1.0), ("v", ex.SYNTH_F64_EXACT, 1, 0.0, 0.0)]
+            n, seed = (1 << 21) + 999, 0xDF31
+            t = ex.DeviceTable.synth(syn, seed, 0, n)
+            ob = oracle.synth_batch(syn, seed, 0, n)
+            got = gpu_aggregate([Column(0)], aggs, schema, [], source=t.scan(1 << 19), filter_expr=pred)
+            want = oracle.aggregate([Column(0)], aggs, [oracle.filter_next(pred, ob)])
+            assert_groups_identical(got, want, 1, f"three-word rows, kind {kind}")
+    finally:
+        ex.set_option("agg.strategy", 0)
+        ex.set_option("agg.capacity_log2", 0)
+
+
 def test_narrow_rows_fall_back_when_a_wide_key_turns_up():
     """Narrow mode is an assumption about keys not seen yet.  Keys >= 2^32, negative keys and i64::MIN arriving in later
     batches go through the spill list, the stream leaves narrow mode, and the groups are still the oracle's."""

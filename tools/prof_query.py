@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Runs one workload a few times (no CPU baseline): the target of rocprofv3 runs.
-usage: prof_query.py <headline|cfg3|cfg2|q1> [rows] [iters]"""
+usage: prof_query.py <headline|cfg3|cfg2|q1|neighbour> [rows] [iters] [option=value ...]
+(neighbour: SELECT k, SUM(v), MIN(v) WHERE v >= lo AND v < hi GROUP BY k -- no static signature, generic row width)"""
 import os
 import sys
 import time
@@ -53,6 +54,10 @@ else:
     aggs = [AggregateFunction("SUM", [Column(1)], f64)]
     group = [Column(0)]
     bytes_per_row = 16
+    if wl == "neighbour":
+        pred = BinaryExpr(BinaryExpr(Column(1), Operator.GtEq, lit(204.8)), Operator.And,
+                          BinaryExpr(Column(1), Operator.Lt, lit(409.6)))
+        aggs = [AggregateFunction("SUM", [Column(1)], f64), AggregateFunction("MIN", [Column(1)], f64)]
     if wl == "cfg3":
         pred = None
     if wl == "cfg2":
