@@ -118,6 +118,7 @@ struct AggregateRelation::Impl {
   bool calibrating = false;     // the launch in progress is the calibration slice
   bool use_partition = false;   // strategy 3: route rows to table blocks, aggregate blocks in LDS
   bool narrow = false;          // every key the calibration slice saw is below 2^32: 12-byte routed rows (PTF_NARROW)
+  bool dense_seen = false;      // more than half of the calibration slice's rows passed the predicate: pass 2 after every batch
   bool skew_seen = false;       // the calibration slice's front cache absorbed a sizeable share of its rows: heavy keys
   DevPartition PT;
   std::shared_ptr<void> pt_rows, pt_counts;
@@ -157,7 +158,8 @@ struct AggregateRelation::Impl {
   Status setup(const SchemaInfo& input_schema);
   Status alloc_table(int cap_log2, DevTable* T, std::vector<std::shared_ptr<void>>* owners, bool new_ctrl, uint64_t** full_accs_out);
   Status ensure_spill(int64_t rows);
-  Status ensure_partition(int64_t rows);
+  Status ensure_partition(int64_t rows, bool nulls_now = false);
+  bool shared_operand() const;
   Status flush_pass2();
   uint64_t program_fingerprint() const;
   Status grow_and_replay(uint64_t occupied, uint64_t spilled, uint64_t replay_from = 0);
@@ -422,7 +424,9 @@ uint64_t AggregateRelation::Impl::program_fingerprint() const {
   for (int ci : builder->columns()) mix(&ci, sizeof(ci));
   mix(&plan.pred, 1);
   mix(plan.key, sizeof(plan.key));
+  mix(plan.arg, sizeof(plan.arg));
   mix(&kw, sizeof(kw));
+  mix(&na, sizeof(na));
   return h;
 }
 
@@ -506,17 +510,30 @@ Status AggregateRelation::Impl::ensure_spill(int64_t rows) {
 }
 
 // scratch for the partitioned strategy, sized for a batch of `rows` rows (worst case: all pass)
-Status AggregateRelation::Impl::ensure_partition(int64_t rows) {
+// the active chunk's 2..3 aggregates all take the same operand (AVG's SUM and COUNT, SUM + MIN + MAX of one column ...):
+// with narrow keys and no nulls in this batch, routed rows carry that one operand (PTF_SHARED)
+bool AggregateRelation::Impl::shared_operand() const {
+  if (kw != 1 || na < 2 || na > 3 || !agg_options().shared_operand) return false;
+  for (int a = 1; a < na; ++a)
+    if (plan.arg[a] != plan.arg[0]) return false;
+  return true;
+}
+
+Status AggregateRelation::Impl::ensure_partition(int64_t rows, bool nulls_now) {
   const uint64_t S = (uint64_t)T.block_mask + 1;
-  const bool want_narrow = narrow && kw == 1 && na == 1 && agg_options().narrow_keys != 0;
-  if (pt_layout_valid && rows <= pt_layout_rows && PT.n_parts == (uint32_t)((T.mask + 1) / S) && PT.n_words == (uint32_t)(kw + na) &&
-      ((PT.flags & PTF_NARROW) != 0) == want_narrow)
+  const bool want_shared = narrow && agg_options().narrow_keys != 0 && !nulls_now && shared_operand() &&
+                           ((uint32_t)agg_options().partition_mode & 0x8Fu) == 2u &&
+                           partition_ring_bytes(2, (uint32_t)((T.mask + 1) / S), 16, false, true, 128) <= (size_t)158 * 1024;
+  const bool want_narrow = narrow && kw == 1 && (na == 1 || want_shared) && agg_options().narrow_keys != 0;
+  const uint32_t n_words = want_shared ? 2u : (uint32_t)(kw + na);
+  if (pt_layout_valid && rows <= pt_layout_rows && PT.n_parts == (uint32_t)((T.mask + 1) / S) && PT.n_words == n_words &&
+      ((PT.flags & PTF_NARROW) != 0) == want_narrow && ((PT.flags & PTF_SHARED) != 0) == want_shared)
     return Status::OK();  // same table, a batch the regions were sized for: keep appending
   DFX_RETURN_IF_ERROR(flush_pass2());  // rows routed under the old layout
   pt_layout_valid = false;
   memset(&PT, 0, sizeof(PT));
   PT.n_parts = (uint32_t)((T.mask + 1) / S);
-  PT.n_words = (uint32_t)(kw + na);
+  PT.n_words = n_words;
   int ps = 0;
   while ((1ull << ps) < S) ++ps;
   PT.part_shift = (uint32_t)ps;
@@ -532,7 +549,14 @@ Status AggregateRelation::Impl::ensure_partition(int64_t rows) {
   const size_t budget = block == 512 ? (size_t)79 * 1024 : (size_t)156 * 1024;
   const uint32_t sort_cap = partition_sort_capacity(PT.n_words, PT.n_parts, block, budget);
   const int want = o.partition_mode & 15;
-  if (want == 2 && partition_ring_bytes(PT.n_words, PT.n_parts, 16) <= (size_t)158 * 1024) {
+  if (want_shared) {
+    PT.flags |= PTF_NARROW | PTF_SHARED;
+    PT.mode = 2u;
+    PT.block = 1024;
+    PT.stage_rows = 0;
+    PT.n_producers = (uint32_t)std::min(1024, device_cu_count());
+    if (o.partition_producers > 0) PT.n_producers = (uint32_t)std::min(1024, o.partition_producers);
+  } else if (want == 2 && partition_ring_bytes(PT.n_words, PT.n_parts, 16) <= (size_t)158 * 1024) {
     const bool hot = o.hot_keys > 0 || (o.hot_keys < 0 && skew_seen);
     const bool chunks8 = !((uint32_t)o.partition_mode & 0x80u);
     if (want_narrow && chunks8) PT.flags |= PTF_NARROW;
@@ -566,7 +590,10 @@ Status AggregateRelation::Impl::ensure_partition(int64_t rows) {
   }
   const uint64_t avg = (uint64_t)rows / ((uint64_t)PT.n_producers * PT.n_parts) + 1;
   pt_worst = (uint32_t)((2 * avg + 64 + 63) / 64 * 64);
-  const int window = std::max(1, std::min(o.partition_defer, 16));  // regions hold `window` worst-case batches
+  // regions hold `window` worst-case batches.  Deferral pays when few rows are routed (headline, 20 %: 2 batches per
+  // pass 2 = -3 % per query); when most rows are, the twice-as-long regions cost pass 1 more than the saved launches
+  // give back (config 3, 1e9 rows: 11.05 ms at 2, 10.08 ms at 1)
+  const int window = dense_seen ? 1 : std::max(1, std::min(o.partition_defer, 16));
   PT.cap_rows = pt_worst * (uint32_t)window;
   if (o.partition_cap_rows > 0) {  // tests: tiny regions (overflow -> spill list); no deferral
     PT.cap_rows = (uint32_t)((o.partition_cap_rows + 63) / 64 * 64);
@@ -838,7 +865,7 @@ Status AggregateRelation::Impl::launch_rows(const DeviceBatch& b, const DevProgr
   DevAggPlan p = plan;
   bool partition_now = use_partition;
   if (partition_now) {
-    Status pst = ensure_partition(std::max<int64_t>(n, b.num_rows));  // (the slice after the calibration rows: size for the whole batch)
+    Status pst = ensure_partition(std::max<int64_t>(n, b.num_rows), prog.has_nulls != 0);  // (the slice after the calibration rows: size for the whole batch)
     if (!pst.ok() && pst.code == DFX_NOT_IMPLEMENTED) partition_now = false;  // global-atomic path instead
     else if (!pst.ok()) return pst;
   }
@@ -870,6 +897,7 @@ Status AggregateRelation::Impl::launch_rows(const DeviceBatch& b, const DevProgr
       pt.snap_done = (uint32_t*)snap_done.get();
     }
     DFX_HIP(launch_partition(prog, fpp, cols, p, T, pt, spill, n, bytes, s));
+    if (pt.flags & PTF_SHARED) ++counters().agg_shared_operand_launches;
     ++pt_pending;
     pt_fill_bound += pt_worst;
     pt_rows_in_flight += n;
@@ -1000,7 +1028,7 @@ Status AggregateRelation::Impl::consume_batch_chunk(const DeviceBatch& b) {
   // grouped: can this batch overflow the table in the worst case (every row a new group)?
   const AggOptions& oo = agg_options();
   if (oo.strategy == 3 && kw == 1) {
-    if (!use_partition && oo.narrow_keys > 0) narrow = na == 1;  // forced strategy: no calibration slice -- optimistic (tests)
+    if (!use_partition && oo.narrow_keys > 0) narrow = na == 1 || shared_operand();  // forced strategy: no calibration slice -- optimistic (tests)
     use_partition = true;
   }
   const bool may_spill = use_partition || occupied_known + unconfirmed_rows + (uint64_t)n > T.load_limit;
@@ -1018,7 +1046,8 @@ Status AggregateRelation::Impl::consume_batch_chunk(const DeviceBatch& b) {
     // no slice, no synchronous read-back (the real group count arrives with the control-block snapshots as always)
     skew_seen = (remembered >> 63) != 0;
     narrow = ((remembered >> 62) & 1) != 0;
-    remembered &= ~(3ull << 62);
+    dense_seen = ((remembered >> 61) & 1) != 0;
+    remembered &= ~(7ull << 61);
     occupied_known = remembered;
     lds_calibrated = true;
     lds_enabled = remembered <= 8192;
@@ -1038,7 +1067,7 @@ Status AggregateRelation::Impl::consume_batch_chunk(const DeviceBatch& b) {
     if (kw == 1) DFX_HIP(launch_probe_wide_keys(T, ctx().stream));  // does any key of the slice lack a 32-bit image?
     uint32_t hc[CTRL_WORDS];
     DFX_RETURN_IF_ERROR(read_ctrl(hc));
-    narrow = kw == 1 && na == 1 && hc[CTRL_WIDE_KEYS] == 0;
+    narrow = kw == 1 && (na == 1 || shared_operand()) && hc[CTRL_WIDE_KEYS] == 0;
     // strategy from the number of groups the calibration slice produced: the LDS front cache pays
     // when the groups fit it (every later row is an LDS atomic); for many groups per-row global
     // atomics would cap the query near 24 G rows/s, so rows are routed to their table blocks
@@ -1048,14 +1077,16 @@ Status AggregateRelation::Impl::consume_batch_chunk(const DeviceBatch& b) {
        // more under a Zipf-like distribution (statistics stripes of K7; one more small synchronous copy, once per stream)
       std::vector<uint64_t> hs((size_t)kStatStripes * STAT_WORDS, 0);
       DFX_HIP(hipMemcpy(hs.data(), stats.get(), sizeof(uint64_t) * hs.size(), hipMemcpyDeviceToHost));
-      uint64_t hit = 0, miss = 0;
+      uint64_t hit = 0, miss = 0, passed = 0;
       for (int i = 0; i < kStatStripes; ++i) {
         hit += hs[(size_t)i * STAT_WORDS + STAT_LDS_HIT];
         miss += hs[(size_t)i * STAT_WORDS + STAT_LDS_MISS];
+        passed += hs[(size_t)i * STAT_WORDS + STAT_PASSED];
       }
+      dense_seen = passed * 2 > (uint64_t)n0;
       skew_seen = occupied_known >= 16384 && miss > 0 && hit * 8 >= miss;  // (`miss` counts every row that went through the cache) >= 12.5 % reused although the groups do not fit
     }
-    if (memo) memo->remember(program_fingerprint(), occupied_known | (skew_seen ? 1ull << 63 : 0ull) | (narrow ? 1ull << 62 : 0ull));
+    if (memo) memo->remember(program_fingerprint(), occupied_known | (skew_seen ? 1ull << 63 : 0ull) | (narrow ? 1ull << 62 : 0ull) | (dense_seen ? 1ull << 61 : 0ull));
     lds_calibrated = true;
     lds_enabled = occupied_known <= 8192;
     if (!lds_enabled && kw == 1 && occupied_known >= 16384) {

@@ -226,6 +226,9 @@ enum : uint32_t {
   PTF_RESUME = 1u,        // pass 1 appends to the regions as `counts` left them (pass 2 of earlier batches is still pending)
   PTF_STREAM_PASS2 = 2u,  // pass 2: region-streaming kernel (one aggregate, 16-byte rows)
   PTF_HOT = 4u,           // pass 1 (ring flavour, one aggregate): hot-key pairs in LDS (skewed keys)
+  PTF_SHARED = 32u,       // with PTF_NARROW, 2..3 aggregates that all take the SAME null-free operand (AVG = SUM + COUNT,
+                          // SUM + MIN + MAX of one column ...): routed rows stay {hash image, RAW operand}; pass 2 applies every
+                          // aggregate's own transform and atomic to it (n_words is 2 whatever the aggregate count)
   PTF_CHUNK16 = 16u,      // narrow rows, no hot keys: 16-row chunks (sector-aligned 192-byte runs), 32-row rings
   PTF_NARROW = 8u         // keys below 2^32 (seen by the calibration slice): 12-byte routed rows {hash image, operand}, pass 2
                           // works on 32-bit images; needs ring flavour, one key word, one aggregate

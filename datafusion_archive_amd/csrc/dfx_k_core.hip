@@ -750,13 +750,17 @@ hipError_t launch_partial_scatter(const DevTable& T, int world, const uint64_t* 
 // no such outliers and needs no engine hand-over.  `bytes` any value; src / dst 16-byte aligned (pool allocations are).
 __global__ __launch_bounds__(256) void k_copy_to_host(const uint4* __restrict__ src, uint4* __restrict__ dst, int64_t n16,
                                                       const uint8_t* __restrict__ src_tail, uint8_t* __restrict__ dst_tail, int tail) {
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 256) {
-    const uint4 v = src[i];
-    __builtin_nontemporal_store(v.x, &dst[i].x);
-    __builtin_nontemporal_store(v.y, &dst[i].y);
-    __builtin_nontemporal_store(v.z, &dst[i].z);
-    __builtin_nontemporal_store(v.w, &dst[i].w);
+  // four 16-byte pieces per lane in flight (the PCIe writes are posted; the loads are what a lane waits for)
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  for (; i + 3 * stride < n16; i += 4 * stride) {
+    const uint4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+    dst[i] = a;
+    dst[i + stride] = b;
+    dst[i + 2 * stride] = c;
+    dst[i + 3 * stride] = d;
   }
+  for (; i < n16; i += stride) dst[i] = src[i];
   if (blockIdx.x == 0 && (int)threadIdx.x < tail) dst_tail[threadIdx.x] = src_tail[threadIdx.x];
 }
 hipError_t launch_copy_to_host(const void* src_device, void* dst_pinned, size_t bytes, hipStream_t s) {
@@ -764,7 +768,7 @@ hipError_t launch_copy_to_host(const void* src_device, void* dst_pinned, size_t 
   if ((((uintptr_t)src_device) | ((uintptr_t)dst_pinned)) & 15u) return hipMemcpyAsync(dst_pinned, src_device, bytes, hipMemcpyDeviceToHost, s);
   const int64_t n16 = (int64_t)(bytes / 16);
   const int tail = (int)(bytes % 16);
-  const int grid = (int)std::min<int64_t>(1024, std::max<int64_t>(1, (n16 + 255) / 256));
+  const int grid = (int)std::min<int64_t>(512, std::max<int64_t>(1, (n16 + 1023) / 1024));
   hipLaunchKernelGGL(k_copy_to_host, dim3(grid), dim3(256), 0, s, (const uint4*)src_device, (uint4*)dst_pinned, n16,
                      (const uint8_t*)src_device + n16 * 16, (uint8_t*)dst_pinned + n16 * 16, tail);
   return hipGetLastError();

@@ -241,6 +241,7 @@ __global__ __launch_bounds__(kABlock) void k_partition_agg(const DevTable T, con
 // a slot whose key has no image (>= 2^32, inserted by the general path: occupied, never equal to a row's image).  12
 // bytes per slot: 96 KB of LDS instead of 128; claimed tags become keys again at write-back.
 // Padding rows (pass 1 rounds every region up to whole chunks: key kEmptyKey / image kTagEmpty) are skipped.
+constexpr int kSharedMaxAggs = 3;  // PTF_SHARED: 4096 slots x (4-byte tag + 3 accumulators) = 112 KB of LDS
 constexpr int kPF = 8;
 constexpr int kP2Vgprs = 88;  // v88..v119: kPF x 4 registers of in-flight rows, outside the register allocator's reach
 struct Row4 { uint32_t x, y, z, w; };
@@ -384,11 +385,25 @@ __global__ __launch_bounds__(kABlock) __attribute__((amdgpu_num_vgpr(kP2Vgprs)))
                                                                                                              const DevRows spill) {
   extern __shared__ __attribute__((aligned(16))) uint64_t lds[];
   constexpr uint32_t kRowBytes = NARROW ? 12u : 16u;
+  // KIND < 0 (PTF_SHARED): T.na (2..kSharedMaxAggs) aggregates of ONE operand -- the row carries the raw operand, every
+  // aggregate applies its own transform and atomic to it (kinds and transforms are wave-uniform kernel arguments)
+  constexpr bool MULTI = KIND < 0;
+  static_assert(!MULTI || NARROW != 0, "shared-operand rows are narrow rows");
+  const uint32_t NA = MULTI ? (uint32_t)T.na : 1u;
   const uint32_t S = T.block_mask + 1;
-  // wide: keys[S] accs[S]; narrow: accs[S] tags[S]
+  // wide: keys[S] accs[S]; narrow: accs[NA][S] tags[S]
   uint64_t* lkeys = lds;
   uint64_t* laccs = NARROW ? lds : lds + S;
-  uint32_t* ltags = (uint32_t*)(lds + S);
+  uint32_t* ltags = (uint32_t*)(lds + (size_t)(NARROW ? NA : 1u) * S);
+  auto apply = [&](uint32_t at, uint64_t val) {
+    if constexpr (MULTI) {
+#pragma unroll
+      for (uint32_t a = 0; a < (uint32_t)kSharedMaxAggs; ++a)
+        if (a < NA) acc_atomic(T.acc_kind[a], &laccs[(size_t)a * S + at], transform_value(T.val_xform[a], val, true));
+    } else {
+      acc_atomic((uint8_t)KIND, &laccs[at], val);
+    }
+  };
   const uint32_t p = blockIdx.x;
   const uint64_t slot0 = (uint64_t)p * S;
   const int lane = lane_id();
@@ -400,8 +415,8 @@ __global__ __launch_bounds__(kABlock) __attribute__((amdgpu_num_vgpr(kP2Vgprs)))
   // table block -> LDS
   for (uint32_t i0 = threadIdx.x * 2; i0 < S; i0 += kABlock * 2) {
     const ulonglong2 kk = *(const ulonglong2*)(T.keys + slot0 + i0);
-    const ulonglong2 aa = *(const ulonglong2*)(T.accs + slot0 + i0);
-    *(ulonglong2*)(laccs + i0) = aa;
+    for (uint32_t a = 0; a < NA; ++a)
+      *(ulonglong2*)(laccs + (size_t)a * S + i0) = *(const ulonglong2*)(T.accs + (uint64_t)a * T.stride + slot0 + i0);
     if (NARROW) {
       uint32_t tg[2];
       const uint64_t k2[2] = {kk.x, kk.y};
@@ -496,7 +511,7 @@ __global__ __launch_bounds__(kABlock) __attribute__((amdgpu_num_vgpr(kP2Vgprs)))
     }
   };
   auto finish = [&](Probe& q) {
-    if (q.hit) acc_atomic((uint8_t)KIND, &laccs[q.at], q.val);
+    if (q.hit) apply(q.at, q.val);
     const bool miss = q.real && !q.hit;
     if (__ballot(miss) != 0) {  // general find-or-claim for the rest: new keys, longer probe sequences, a full block
       bool todo = miss;
@@ -504,7 +519,7 @@ __global__ __launch_bounds__(kABlock) __attribute__((amdgpu_num_vgpr(kP2Vgprs)))
       if (miss) {
         const int found = NARROW ? pa2n_lookup(ltags, S, q.home4, q.img, new_keys) : pa2_lookup(lkeys, S, q.home4, q.kk, new_keys);
         if (found >= 0) {
-          acc_atomic((uint8_t)KIND, &laccs[found], q.val);
+          apply((uint32_t)found, q.val);
           todo = false;
         }
       }
@@ -512,7 +527,8 @@ __global__ __launch_bounds__(kABlock) __attribute__((amdgpu_num_vgpr(kP2Vgprs)))
         if (NARROW) key[0] = (uint64_t)unhash_word32(q.img);
         uint64_t sv[kMaxAggs];
 #pragma unroll
-        for (int j = 0; j < kMaxAggs; ++j) sv[j] = j == 0 ? q.val : 0ull;
+        for (int j = 0; j < kMaxAggs; ++j)
+          sv[j] = MULTI ? ((uint32_t)j < NA ? transform_value(T.val_xform[j], q.val, true) : 0ull) : (j == 0 ? q.val : 0ull);
         spill_row<1>(T, spill, todo, key, sv);
       }
     }
@@ -550,7 +566,8 @@ __global__ __launch_bounds__(kABlock) __attribute__((amdgpu_num_vgpr(kP2Vgprs)))
   p2_drain();  // loads still in flight own v88..v119 until they land
   __syncthreads();
   for (uint32_t i0 = threadIdx.x * 2; i0 < S; i0 += kABlock * 2) {
-    *(ulonglong2*)(T.accs + slot0 + i0) = *(const ulonglong2*)(laccs + i0);
+    for (uint32_t a = 0; a < NA; ++a)
+      *(ulonglong2*)(T.accs + (uint64_t)a * T.stride + slot0 + i0) = *(const ulonglong2*)(laccs + (size_t)a * S + i0);
     if (NARROW) {
       const uint2 tg = *(const uint2*)(ltags + i0);
       // a tag that is an image is written back as its key (unchanged for slots that held it before, new for claimed
@@ -608,7 +625,7 @@ size_t partition_stage_bytes(const DevPartition& PT) {
   if ((PT.mode & 15u) == 0) return (size_t)PT.n_parts * 4 + 16;
   if ((PT.mode & 15u) == 2)
     return partition_ring_bytes(PT.n_words, PT.n_parts, (PT.flags & PTF_CHUNK16) ? 32 : (PT.mode & 0x100u) ? 8 : 16, (PT.flags & PTF_HOT) != 0,
-                                (PT.flags & PTF_NARROW) != 0);
+                                (PT.flags & PTF_NARROW) != 0, (PT.flags & PTF_SHARED) ? 128 : 0);
   return (size_t)PT.stage_rows * ((size_t)PT.n_words * 8 + 4) + (size_t)PT.n_parts * 12 + (2 + 16) * 4 + 16;
 }
 
@@ -643,11 +660,16 @@ hipError_t launch_partition(const DevProgram& P, const DevFastPlan& fast, const 
   if ((PT.mode & 15u) == 1 && (lds_bytes > 160 * 1024 || PT.stage_rows == 0 || PT.stage_rows > (uint32_t)kSortMaxCap ||
                        PT.n_parts > 4096 || (PT.block != 512 && PT.block != 1024)))
     return hipErrorInvalidValue;
-  if (sig_matches<SigKeySumPred2F64>(P, fast, 1, T.na, T.acc_kind, T.val_xform)) {
+  // PTF_SHARED: pass 1 routes the aggregates' common RAW operand -- the shape of a one-aggregate query whose operand is
+  // that column (what the accumulators do with it is pass 2's business)
+  const bool shared = (PT.flags & PTF_SHARED) != 0;
+  const uint8_t raw_kind0[1] = {SigKeySumPred2F64::acc(0)}, raw_kind1[1] = {SigKeySum::acc(0)}, raw_xf[1] = {VT_RAW};
+  static_assert(SigKeySumPred2F64::xf(0) == VT_RAW && SigKeySum::xf(0) == VT_RAW, "the one-aggregate signatures route the raw operand");
+  if (shared ? sig_matches<SigKeySumPred2F64>(P, fast, 1, 1, raw_kind0, raw_xf) : sig_matches<SigKeySumPred2F64>(P, fast, 1, T.na, T.acc_kind, T.val_xform)) {
     launch_partition_variant0(P, fast, C, plan, T, PT, spill, n, lds_bytes, s);
     return hipGetLastError();
   }
-  if (sig_matches<SigKeySum>(P, fast, 1, T.na, T.acc_kind, T.val_xform)) {
+  if (shared ? sig_matches<SigKeySum>(P, fast, 1, 1, raw_kind1, raw_xf) : sig_matches<SigKeySum>(P, fast, 1, T.na, T.acc_kind, T.val_xform)) {
     launch_partition_variant1(P, fast, C, plan, T, PT, spill, n, lds_bytes, s);
     return hipGetLastError();
   }
@@ -663,7 +685,11 @@ hipError_t launch_partition_agg(const DevTable& T, const DevPartition& PT, const
   Scope sc(KID_PARTITION_AGG, s, algo_bytes);
   size_t lds_bytes = (size_t)(T.block_mask + 1) * (size_t)(1 + T.na) * 8 + (size_t)(PT.n_producers + 1) * 4 + 16;
   if (lds_bytes > 160 * 1024 - 256 || PT.n_producers > 1024) return hipErrorInvalidValue;
-  if (PT.flags & PTF_NARROW) {
+  if ((PT.flags & PTF_NARROW) && (PT.flags & PTF_SHARED)) {
+    const size_t shared_lds = (size_t)(T.block_mask + 1) * (size_t)(4 + 8 * T.na);
+    if (T.na < 2 || T.na > kSharedMaxAggs || T.kw != 1 || shared_lds > 160 * 1024 - 256) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((k_partition_agg_lean<1, -1>), dim3(PT.n_parts), dim3(kABlock), shared_lds, s, T, PT, spill);
+  } else if (PT.flags & PTF_NARROW) {
     if (T.na != 1 || T.kw != 1) return hipErrorInvalidValue;
     launch_agg_lean<1>(T, PT, spill, (size_t)(T.block_mask + 1) * 12, s);
   } else if (T.na == 1 && (PT.flags & PTF_STREAM_PASS2) && PT.n_words == 2)

@@ -462,8 +462,8 @@ struct RingLds {
 };
 
 #ifdef DFX_PARTITION_MAIN_TU  // a plain function: defined once, in dfx_k_partition.hip
-size_t partition_ring_bytes(uint32_t n_words, uint32_t n_parts, int kRingRP, bool hot, bool narrow) {
-  const int kRingQ = ring_queue_rows(kRingRP);
+size_t partition_ring_bytes(uint32_t n_words, uint32_t n_parts, int kRingRP, bool hot, bool narrow, int queue_rows) {
+  const int kRingQ = queue_rows > 0 ? queue_rows : ring_queue_rows(kRingRP);
   return (size_t)n_parts * kRingRP * (narrow ? 12 : n_words * 8) + (size_t)(kRingBlock / 64) * kRingQ * n_words * 8 +
          (size_t)(kRingBlock / 64) * 64 * (kRingRP >= 16 ? 8 : 4) + (size_t)n_parts * 4 * (1 + 2 * 4) + 64 +
          (hot ? (size_t)(narrow ? kHotSlotsNarrow : kHotSlots) * 16 : 0);
@@ -478,6 +478,13 @@ size_t partition_ring_bytes(uint32_t n_words, uint32_t n_parts, int kRingRP, boo
 // xor-shifts -- so the image identifies the key and pass 2 turns it back (unhash_word32) when it claims a slot.  The
 // partition is implied by the region, the slot by the image's top bits: pass 2 neither re-hashes nor compares 64-bit
 // keys.  A row whose key is not narrow (or whose image is one of the two reserved tags) takes the spill list.
+// PTF_SHARED: the routed value is the aggregates' common RAW operand; a row that leaves the routed path (spill list,
+// sentinel key) needs every aggregate's own accumulator operand again
+DEV void expand_shared_operand(const DevTable& T, const uint64_t raw, uint64_t (&out)[kMaxAggs]) {
+#pragma unroll
+  for (int a = 0; a < kMaxAggs; ++a) out[a] = a < T.na ? transform_value(T.val_xform[a], raw, true) : 0ull;
+}
+
 template <int NV, int kRingCH, int kRingRP, int NARROW = 0>
 DEV void ring_route(const DevTable& T, const DevPartition& PT, const DevRows& spill, const RingLds& L, uint32_t producer,
                     int na, bool have, const uint64_t (&key)[1], const uint64_t (&val)[kMaxAggs], uint64_t h, uint32_t& err) {
@@ -499,7 +506,15 @@ DEV void ring_route(const DevTable& T, const DevPartition& PT, const DevRows& sp
       todo = !pending;  // region overflow (skewed keys): the general path takes the row
     }
   }
-  spill_row<1>(T, spill, todo, key, val);
+  if (NARROW && (PT.flags & PTF_SHARED)) {
+    if (__ballot(todo) != 0) {
+      uint64_t sv[kMaxAggs];
+      expand_shared_operand(T, val[0], sv);
+      spill_row<1>(T, spill, todo, key, sv);
+    }
+  } else {
+    spill_row<1>(T, spill, todo, key, val);
+  }
   const uint32_t c = pos / kRingCH, sl = c % kRingNCH, g = c / kRingNCH, r = pos % kRingCH;
   const uint32_t cs = part * kRingNCH + sl;
   uint32_t* jobs = L.jobs + wave * 64;
@@ -599,7 +614,7 @@ DEV bool hot_absorb(uint64_t* hot_keys, uint64_t* hot_accs, uint8_t kind, uint64
   return false;
 }
 
-template <typename POL, int kRingCH, int kRingRP, bool HOT = false, int NARROW = 0>
+template <typename POL, int kRingCH, int kRingRP, bool HOT = false, int NARROW = 0, int QROWS = 0>
 __global__ __launch_bounds__(kRingBlock) void k_partition_ring(const DevProgram P, const DevFastPlan F, const DevColumns C,
                                                               const DevAggPlan plan, const DevTable T,
                                                               const DevPartition PT, const DevRows spill, const int64_t n) {
@@ -609,7 +624,7 @@ __global__ __launch_bounds__(kRingBlock) void k_partition_ring(const DevProgram 
   constexpr int NWAVES = kRingBlock / 64;
   constexpr int NV = POL::kStaticNa == 1 ? 1 : kMaxAggs;
   constexpr int kRingNCH = kRingRP / kRingCH;
-  constexpr int kRingQ = ring_queue_rows(kRingRP);
+  constexpr int kRingQ = QROWS > 0 ? QROWS : ring_queue_rows(kRingRP);
   extern __shared__ __attribute__((aligned(16))) uint64_t lds[];
   const int NW = (int)PT.n_words;
   RingLds L;
@@ -628,7 +643,9 @@ __global__ __launch_bounds__(kRingBlock) void k_partition_ring(const DevProgram 
   uint64_t* hot_accs = hot_keys + kHot;
   const int lane = lane_id();
   const int wave = threadIdx.x >> 6;
-  const int na = POL::na(T);
+  // PTF_SHARED: one routed value (the aggregates' common raw operand) whatever the aggregate count
+  const bool shared = NARROW && (PT.flags & PTF_SHARED) != 0;
+  const int na = (POL::kStaticNa == 1 || shared) ? 1 : POL::na(T);
   if (HOT) {
     for (uint32_t i = threadIdx.x; i < (uint32_t)kHot; i += kRingBlock) {
       hot_keys[i] = kEmptyKey;
@@ -709,17 +726,23 @@ __global__ __launch_bounds__(kRingBlock) void k_partition_ring(const DevProgram 
 #pragma unroll
       for (int a = 0; a < kMaxAggs; ++a) {
         val[a] = 0;
-        if (a < POL::na(T)) {
+        if (a < na) {
           uint64_t v;
           bool valid;
           POL::arg(P, F, plan.arg[a], a, col[u], cv[u], reg, rv, v, valid);
-          val[a] = transform_value(POL::xform(T, a), v, valid);
+          val[a] = transform_value(shared ? (uint8_t)VT_RAW : POL::xform(T, a), v, valid);
         }
       }
       passed += pass ? 1 : 0;
       if (__ballot(pass && key[0] == kEmptyKey) != 0) {  // the claim-sentinel key lives outside the blocks
         if (pass && key[0] == kEmptyKey) {
-          sentinel_apply(T, val);
+          if (shared) {
+            uint64_t sv[kMaxAggs];
+            expand_shared_operand(T, val[0], sv);
+            sentinel_apply(T, sv);
+          } else {
+            sentinel_apply(T, val);
+          }
           pass = false;
         }
       }
@@ -830,6 +853,9 @@ void launch_partition_pol(const DevProgram& P, const DevFastPlan& fast, const De
     hipLaunchKernelGGL((k_partition_ring<POLS, 4, 8>), dim3(grid), dim3(kRingBlock), lds_bytes, s, P, fast, C, plan, T, PT, spill, n);
   else if ((PT.mode & 15u) == 2 && (PT.mode & 0x80u))  // 4-row chunks (64-byte runs)
     hipLaunchKernelGGL((k_partition_ring<POLS, 4, 16>), dim3(grid), dim3(kRingBlock), lds_bytes, s, P, fast, C, plan, T, PT, spill, n);
+  else if ((PT.mode & 15u) == 2 && (PT.flags & PTF_NARROW) && (PT.flags & PTF_SHARED))
+    // 2..3 aggregates of one operand: 4096-slot blocks, so twice the partitions -- 128-row wave queues make room for their rings
+    hipLaunchKernelGGL((k_partition_ring<POLS, 8, 16, false, 1, 128>), dim3(grid), dim3(kRingBlock), lds_bytes, s, P, fast, C, plan, T, PT, spill, n);
   else if ((PT.mode & 15u) == 2 && (PT.flags & PTF_NARROW) && (PT.flags & PTF_HOT))
     hipLaunchKernelGGL((k_partition_ring<POLS, 8, 16, true, 1>), dim3(grid), dim3(kRingBlock), lds_bytes, s, P, fast, C, plan, T, PT, spill, n);
   else if ((PT.mode & 15u) == 2 && (PT.flags & PTF_NARROW) && (PT.flags & PTF_CHUNK16))

@@ -116,6 +116,7 @@ struct AggOptions {
   int ctrl_snapshot = 1;       // partitioned strategy: 1 the batch's last kernel writes the control-block snapshot to pinned host
                                // memory itself, 0 asynchronous copy on the side stream (round 1)
   int narrow_chunk16 = 1;      // narrow rows are written in 16-row chunks (sector-aligned) when no hot-key pairs need the LDS
+  int shared_operand = 1;      // 2..3 aggregates of one null-free operand over narrow keys: 12-byte routed rows {image, raw operand}
   int narrow_keys = -1;        // 12-byte routed rows when the calibration slice saw only keys below 2^32: -1 auto, 0 never
   int partition_layout = 1;    // routing scratch: 1 producer-major, 0 partition-major (round 1), 2 windowed (DevPartition::win_stride;
                                // measured no better for the filtered query and 17 % worse in pass 1 when every row is routed)

@@ -369,6 +369,7 @@ int64_t dfx_counter_get(const char* name) {
   if (!strcmp(name, "agg_alloc_us")) return counters().agg_alloc_us;
   if (!strcmp(name, "agg_pass2_launches")) return counters().agg_pass2_launches;
   if (!strcmp(name, "agg_growths")) return counters().agg_growths;
+  if (!strcmp(name, "agg_shared_operand_launches")) return counters().agg_shared_operand_launches;
   if (!strcmp(name, "export_us")) return counters().export_us;
   if (!strcmp(name, "export_alloc_us")) return counters().export_alloc_us;
   return -1;
@@ -399,6 +400,7 @@ int32_t dfx_set_option(const char* key, int64_t value) {
   else if (!strcmp(key, "agg.partition_layout")) o.partition_layout = (int)value;
   else if (!strcmp(key, "agg.narrow_keys")) o.narrow_keys = (int)value;
   else if (!strcmp(key, "agg.narrow_chunk16")) o.narrow_chunk16 = (int)value;
+  else if (!strcmp(key, "agg.shared_operand")) o.shared_operand = (int)value;
   else if (!strcmp(key, "agg.ctrl_snapshot")) o.ctrl_snapshot = (int)value;
   else if (!strcmp(key, "export.kernel_copy")) o.export_kernel_copy = (int)value;
   else if (!strcmp(key, "agg.partition_producers")) o.partition_producers = (int)value;

@@ -722,6 +722,92 @@ def test_partitioned_three_word_rows_use_the_small_ring():
         ex.set_option("agg.capacity_log2", 0)
 
 
+def _shared_operand_sets():
+    I64 = DataType.Int64
+    return [
+        ("avg", 1, [agg("avg", Column(1), F64)]),
+        ("sum+count", 1, [agg("sum", Column(1), F64), agg("count", Column(1), DataType.UInt64)]),
+        ("sum+min+max", 1, [agg("sum", Column(1), F64), agg("min", Column(1), F64), agg("max", Column(1), F64)]),
+        ("min+max int", 2, [agg("min", Column(2), I64), agg("max", Column(2), I64)]),
+        ("count+sum int", 2, [agg("count", Column(2), DataType.UInt64), agg("sum", Column(2), I64)]),
+    ]
+
+
+def test_aggregates_of_one_operand_share_the_routed_value():
+    """2..3 aggregates that take the same null-free operand (AVG = SUM + COUNT, SUM + MIN + MAX of one column ...) over
+    narrow keys: pass 1 routes 12-byte rows {hash image, RAW operand}, pass 2 applies every aggregate's own transform and
+    atomic.  Uniform and skewed keys, with and without a predicate, several batches; the shared path must really have run
+    (counter), and the groups are the oracle's bit for bit.  With agg.shared_operand = 0 the general path gives the same."""
+    ex.set_option("agg.strategy", 3)
+    ex.set_option("agg.capacity_log2", 20)
+    ex.set_option("agg.narrow_keys", 1)  # (a forced strategy skips the calibration slice that would find the keys narrow)
+    try:
+        schema = pa.schema([("k", pa.int64()), ("v", pa.float64()), ("w", pa.int64())])
+        pred = BinaryExpr(Column(1), Operator.Lt, lit(800.0))
+        for kind in (ex.SYNTH_I64_UNIFORM, ex.SYNTH_I64_ZIPF):
+            syn = [("k", kind, 0, 200000.0, 1.0), ("v", ex.SYNTH_F64_EXACT, 1, 0.0, 0.0), ("w", ex.SYNTH_I64_UNIFORM, 2, 1e9, 0.0)]
+            n, seed = (1 << 21) + 777, 0xDF41
+            t = ex.DeviceTable.synth(syn, seed, 0, n)
+            ob = oracle.synth_batch(syn, seed, 0, n)
+            for name, _col, aggs in _shared_operand_sets():
+                for filt in (pred, None):
+                    want = oracle.aggregate([Column(0)], aggs, [oracle.filter_next(filt, ob) if filt is not None else ob])
+                    for shared in (1, 0):
+                        ex.set_option("agg.shared_operand", shared)
+                        ex.counter_reset()
+                        got = gpu_aggregate([Column(0)], aggs, schema, [], source=t.scan(1 << 19), filter_expr=filt)
+                        launches = ex.counter_get("agg_shared_operand_launches")
+                        assert (launches > 0) == (shared == 1), f"{name}: shared={shared} but {launches} shared-operand launches"
+                        assert_groups_identical(got, want, 1, f"{name}, kind {kind}, filter {filt is not None}, shared {shared}")
+    finally:
+        ex.set_option("agg.strategy", 0)
+        ex.set_option("agg.capacity_log2", 0)
+        ex.set_option("agg.shared_operand", 1)
+        ex.set_option("agg.narrow_keys", -1)
+
+
+def test_shared_operand_rows_leave_the_fast_path_correctly():
+    """What takes a shared-operand row off the routed path: (a) tiny regions overflow -> spill list (the raw operand is
+    expanded into every aggregate's operand again), (b) nulls in the operand from the second batch on -> general rows from
+    there, (c) wide keys and i64::MIN in later batches -> spill list / sentinel slot, narrow mode left, (d) a table that
+    has to grow (pass 2 finds its block full)."""
+    aggs = [agg("sum", Column(1), F64), agg("count", Column(1), DataType.UInt64), agg("min", Column(1), F64)]
+    rng = np.random.default_rng(23)
+    n = 300000
+    k = rng.integers(0, 50000, n).astype(np.int64)
+    v = rng.integers(0, 1 << 20, n).astype(np.float64) / 1024.0
+    plain = pa.RecordBatch.from_arrays([pa.array(k), pa.array(v)], names=["k", "v"])
+    mask = rng.random(n) < 0.1
+    nulls = pa.RecordBatch.from_arrays([pa.array(k), pa.array(v, mask=mask)], names=["k", "v"])
+    k2 = k.copy()
+    k2[::7] += 1 << 32
+    k2[::11] = -k2[::11] - 1
+    k2[::5003] = np.iinfo(np.int64).min
+    wide = pa.RecordBatch.from_arrays([pa.array(k2), pa.array(v)], names=["k", "v"])
+    many = pa.RecordBatch.from_arrays([pa.array(rng.integers(0, 900000, n).astype(np.int64)), pa.array(v)], names=["k", "v"])
+    ex.set_option("agg.strategy", 3)
+    ex.set_option("agg.narrow_keys", 1)
+    try:
+        for what, batches, opts in (
+            ("region overflow", [plain, plain, plain], {"agg.partition_cap_rows": 64, "agg.capacity_log2": 20}),
+            ("nulls later", [plain, nulls, plain, nulls], {"agg.capacity_log2": 20}),
+            ("wide keys later", [plain, wide, plain, wide], {"agg.capacity_log2": 20}),
+            ("table growth", [plain, many, many, plain], {"agg.capacity_log2": 17}),
+        ):
+            for kk, vv in opts.items():
+                ex.set_option(kk, vv)
+            ex.counter_reset()
+            got = gpu_aggregate([Column(0)], aggs, plain.schema, batches)
+            assert ex.counter_get("agg_shared_operand_launches") > 0, what
+            want = oracle.aggregate([Column(0)], aggs, batches)
+            assert_groups_identical(got, want, 1, f"shared operand, {what}")
+            for kk in opts:
+                ex.set_option(kk, 0)
+    finally:
+        for kk, vv in (("agg.strategy", 0), ("agg.narrow_keys", -1), ("agg.partition_cap_rows", 0), ("agg.capacity_log2", 0)):
+            ex.set_option(kk, vv)
+
+
 def test_narrow_rows_fall_back_when_a_wide_key_turns_up():
     """Narrow mode is an assumption about keys not seen yet.  Keys >= 2^32, negative keys and i64::MIN arriving in later
     batches go through the spill list, the stream leaves narrow mode, and the groups are still the oracle's."""

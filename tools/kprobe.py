@@ -21,7 +21,7 @@ t = ex.DeviceTable.synth(syn, 0xDF02, 0, rows)
 lit = lambda v: Literal(ScalarValue.Float64(v))
 pred = BinaryExpr(BinaryExpr(Column(1), Operator.Gt, lit(LO)), Operator.And, BinaryExpr(Column(1), Operator.Lt, lit(HI)))
 def run():
-    rel = t.scan(1 << 26)
+    rel = t.scan(int(os.environ.get("KPROBE_BATCH_LOG2", "26")) and 1 << int(os.environ.get("KPROBE_BATCH_LOG2", "26")))
     if filt: rel = ex.FilterRelation(rel, ex.compile_scalar_expr(None, pred, schema), schema)
     if UNGROUPED:
         rel = ex.AggregateRelation(None, rel, [], [ex.compile_expr(None, AggregateFunction("COUNT", [Column(1)], DataType.UInt64), schema)])
