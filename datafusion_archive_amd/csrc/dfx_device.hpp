@@ -47,6 +47,8 @@ struct DevProgram {
   int32_t n_cols;
   int32_t n_imm;
   int32_t has_nulls;  // any referenced column carries a validity bitmap in this batch
+  int32_t wide8;      // every referenced column is 8 bytes wide (Int64 / UInt64 / Float64) and none has nulls in this batch:
+                      // the generic policies load them branch-free, all loads of a trip in flight together
   DevIns ins[kMaxRegs];
   uint64_t imm[kMaxImm];
   uint8_t col_dtype[kMaxCols];

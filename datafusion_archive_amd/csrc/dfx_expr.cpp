@@ -436,6 +436,7 @@ Status ProgramBuilder::bind(const DeviceBatch& batch, DevProgram* prog, DevColum
   *prog = prog_;
   memset(cols, 0, sizeof(*cols));
   prog->has_nulls = 0;
+  prog->wide8 = 0;
   for (size_t i = 0; i < cols_.size(); ++i) {
     const int ci = cols_[i];
     if (ci >= (int)batch.columns.size())
@@ -447,6 +448,11 @@ Status ProgramBuilder::bind(const DeviceBatch& batch, DevProgram* prog, DevColum
     cols->c[i].validity = c.null_count != 0 ? c.validity : nullptr;
     cols->c[i].bit_offset = c.bit_offset;
     if (cols->c[i].validity) prog->has_nulls = 1;
+  }
+  prog->wide8 = !prog->has_nulls && !cols_.empty();
+  for (size_t i = 0; i < cols_.size(); ++i) {
+    const uint8_t t = prog_.col_dtype[i];
+    if (t != T_I64 && t != T_U64 && t != T_F64) prog->wide8 = 0;
   }
   return Status::OK();
 }

@@ -841,7 +841,7 @@ __global__ __launch_bounds__(kRingBlock) void k_partition_ring(const DevProgram 
   snapshot_ctrl_if_last(T, PT);
 }
 
-template <typename POL, typename POLS>  // POLS: the policy flavour used by the write-combining kernel
+template <typename POL, typename POLS, typename POLN = POLS>  // POLS: the policy flavour used by the write-combining kernel; POLN: by its narrow-row flavours (one routed value)
 void launch_partition_pol(const DevProgram& P, const DevFastPlan& fast, const DevColumns& C, const DevAggPlan& plan,
                                  const DevTable& T, const DevPartition& PT, const DevRows& spill, int64_t n,
                                  size_t lds_bytes, hipStream_t s) {
@@ -855,15 +855,15 @@ void launch_partition_pol(const DevProgram& P, const DevFastPlan& fast, const De
     hipLaunchKernelGGL((k_partition_ring<POLS, 4, 16>), dim3(grid), dim3(kRingBlock), lds_bytes, s, P, fast, C, plan, T, PT, spill, n);
   else if ((PT.mode & 15u) == 2 && (PT.flags & PTF_NARROW) && (PT.flags & PTF_SHARED))
     // 2..3 aggregates of one operand: 4096-slot blocks, so twice the partitions -- 128-row wave queues make room for their rings
-    hipLaunchKernelGGL((k_partition_ring<POLS, 8, 16, false, 1, 128>), dim3(grid), dim3(kRingBlock), lds_bytes, s, P, fast, C, plan, T, PT, spill, n);
+    hipLaunchKernelGGL((k_partition_ring<POLN, 8, 16, false, 1, 128>), dim3(grid), dim3(kRingBlock), lds_bytes, s, P, fast, C, plan, T, PT, spill, n);
   else if ((PT.mode & 15u) == 2 && (PT.flags & PTF_NARROW) && (PT.flags & PTF_HOT))
-    hipLaunchKernelGGL((k_partition_ring<POLS, 8, 16, true, 1>), dim3(grid), dim3(kRingBlock), lds_bytes, s, P, fast, C, plan, T, PT, spill, n);
+    hipLaunchKernelGGL((k_partition_ring<POLN, 8, 16, true, 1>), dim3(grid), dim3(kRingBlock), lds_bytes, s, P, fast, C, plan, T, PT, spill, n);
   else if ((PT.mode & 15u) == 2 && (PT.flags & PTF_NARROW) && (PT.flags & PTF_CHUNK16))
     // 16-row chunks: 192 bytes = three whole 64-byte sectors (a 96-byte chunk of 8 rows straddles sectors: WRITE_SIZE was
     // 1.26 x the routed bytes)
-    hipLaunchKernelGGL((k_partition_ring<POLS, 16, 32, false, 1>), dim3(grid), dim3(kRingBlock), lds_bytes, s, P, fast, C, plan, T, PT, spill, n);
+    hipLaunchKernelGGL((k_partition_ring<POLN, 16, 32, false, 1>), dim3(grid), dim3(kRingBlock), lds_bytes, s, P, fast, C, plan, T, PT, spill, n);
   else if ((PT.mode & 15u) == 2 && (PT.flags & PTF_NARROW))  // narrow keys: 12-byte rows
-    hipLaunchKernelGGL((k_partition_ring<POLS, 8, 16, false, 1>), dim3(grid), dim3(kRingBlock), lds_bytes, s, P, fast, C, plan, T, PT, spill, n);
+    hipLaunchKernelGGL((k_partition_ring<POLN, 8, 16, false, 1>), dim3(grid), dim3(kRingBlock), lds_bytes, s, P, fast, C, plan, T, PT, spill, n);
   else if ((PT.mode & 15u) == 2 && (PT.flags & PTF_HOT))  // skewed keys: hot-key pairs in LDS
     hipLaunchKernelGGL((k_partition_ring<POLS, 8, 16, true>), dim3(grid), dim3(kRingBlock), lds_bytes, s, P, fast, C, plan, T, PT, spill, n);
   else if ((PT.mode & 15u) == 2)  // 8-row chunks (full 128-byte lines): ~4 % faster on MI355X
@@ -878,9 +878,9 @@ void launch_partition_pol(const DevProgram& P, const DevFastPlan& fast, const De
 #define DFX_PARTITION_VARIANT_ARGS                                                                                         \
   const DevProgram &P, const DevFastPlan &fast, const DevColumns &C, const DevAggPlan &plan, const DevTable &T,            \
       const DevPartition &PT, const DevRows &spill, int64_t n, size_t lds_bytes, hipStream_t s
-#define DFX_PARTITION_VARIANT(ID, POL, POLS)                                                                               \
+#define DFX_PARTITION_VARIANT(ID, POL, POLS, ...)                                                                          \
   void launch_partition_variant##ID(DFX_PARTITION_VARIANT_ARGS) {                                                          \
-    launch_partition_pol<POL, POLS>(P, fast, C, plan, T, PT, spill, n, lds_bytes, s);                                     \
+    launch_partition_pol<POL, POLS, ##__VA_ARGS__>(P, fast, C, plan, T, PT, spill, n, lds_bytes, s);                      \
   }
 
 }  // namespace dfx

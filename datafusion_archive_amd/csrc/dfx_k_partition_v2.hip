@@ -2,5 +2,5 @@
 #include "dfx_k_partition_inl.hpp"
 
 namespace dfx {
-DFX_PARTITION_VARIANT(2, DFX_ARG(FastPolicy<2, 4>), DFX_ARG(FastPolicy<2, 2>))
+DFX_PARTITION_VARIANT(2, DFX_ARG(FastPolicy<2, 4>), DFX_ARG(FastPolicy<2, 2>), DFX_ARG(FastPolicy1<2, 4>))
 }  // namespace dfx

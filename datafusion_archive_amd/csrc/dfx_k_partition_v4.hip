@@ -2,5 +2,5 @@
 #include "dfx_k_partition_inl.hpp"
 
 namespace dfx {
-DFX_PARTITION_VARIANT(4, DFX_ARG(FastPolicy<4, 2>), DFX_ARG(FastPolicy<4, 2>))
+DFX_PARTITION_VARIANT(4, DFX_ARG(FastPolicy<4, 2>), DFX_ARG(FastPolicy<4, 2>), DFX_ARG(FastPolicy1<4, 2>))
 }  // namespace dfx

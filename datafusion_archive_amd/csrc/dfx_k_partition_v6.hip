@@ -2,5 +2,5 @@
 #include "dfx_k_partition_inl.hpp"
 
 namespace dfx {
-DFX_PARTITION_VARIANT(6, DFX_ARG(FastPolicy<8, 2>), DFX_ARG(FastPolicy<8, 1>))
+DFX_PARTITION_VARIANT(6, DFX_ARG(FastPolicy<8, 2>), DFX_ARG(FastPolicy<8, 1>), DFX_ARG(FastPolicy1<8, 1>))
 }  // namespace dfx

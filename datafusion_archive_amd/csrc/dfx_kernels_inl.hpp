@@ -182,6 +182,17 @@ DEV void load_columns(const DevProgram& P, const DevColumns& C, int64_t row, boo
                       uint32_t& s_colvalid) {
   constexpr int BANK = (int)(sizeof(COLV) / 8);
   s_colvalid = 0xFFFFFFFFu;
+  if (P.wide8) {  // wave-uniform.  8-byte columns without nulls: one unconditional load per bank slot (a slot past n_cols
+                  // re-reads column 0 -- a cache hit), nothing between the loads, so all of them are in flight together.
+                  // The dtype switch below waits for each load on its own (sub-word loads are widened at once): a
+                  // wave then has ONE load in flight, and pass 1 of the partitioned GROUP BY ran at 1.7 TB/s.
+#pragma unroll
+    for (int c = 0; c < BANK; ++c) {
+      const uint64_t* base = (const uint64_t*)C.c[c < P.n_cols ? c : 0].values;
+      s_col[c] = __builtin_nontemporal_load(base + (inb ? row : 0));
+    }
+    return;
+  }
 #pragma unroll
   for (int c = 0; c < BANK; ++c) {
     if (c < P.n_cols) {
@@ -483,6 +494,14 @@ struct FastPolicy {
     if (A.nf > 2) acc = acc * factor(F, a, 2, cur);
     v = f64_bits(acc);
   }
+};
+
+// FastPolicy for scans that route ONE value per row (one aggregate, or PTF_SHARED's common operand): the per-aggregate
+// loops and their plan words (8 aggregates x 3 factors) drop out of the kernel
+template <int BANK, int U_>
+struct FastPolicy1 : FastPolicy<BANK, U_> {
+  static constexpr int kStaticNa = 1;
+  static DEV int na(const DevTable&) { return 1; }
 };
 
 // compile-time shape signature (dfx_sigs.hpp): column slots, term types, accumulator kinds and

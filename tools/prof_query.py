@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Runs one workload a few times (no CPU baseline): the target of rocprofv3 runs.
-usage: prof_query.py <headline|cfg3|cfg2|q1|neighbour> [rows] [iters] [option=value ...]
-(neighbour: SELECT k, SUM(v), MIN(v) WHERE v >= lo AND v < hi GROUP BY k -- no static signature, generic row width)"""
+usage: prof_query.py <headline|cfg3|cfg2|q1|neighbour|oneterm|threecol|product> [rows] [iters] [option=value ...]
+(neighbour: SELECT k, SUM(v), MIN(v) WHERE v >= lo AND v < hi GROUP BY k -- two aggregates of one operand;
+ oneterm: SELECT k, SUM(v) WHERE v < 204.8 GROUP BY k; threecol: SELECT k, SUM(w) WHERE v > lo AND v < hi GROUP BY k;
+ product: SELECT k, SUM(v * 2.0) WHERE v > lo AND v < hi GROUP BY k -- shapes without a static signature: FastPolicy)"""
 import os
 import sys
 import time
@@ -58,6 +60,15 @@ else:
         pred = BinaryExpr(BinaryExpr(Column(1), Operator.GtEq, lit(204.8)), Operator.And,
                           BinaryExpr(Column(1), Operator.Lt, lit(409.6)))
         aggs = [AggregateFunction("SUM", [Column(1)], f64), AggregateFunction("MIN", [Column(1)], f64)]
+    if wl == "oneterm":
+        pred = BinaryExpr(Column(1), Operator.Lt, lit(204.8))
+    if wl == "threecol":
+        syn = syn + [("w", ex.SYNTH_F64_EXACT, 2, 0.0, 0.0)]
+        schema = pa.schema([("k", pa.int64()), ("v", pa.float64()), ("w", pa.float64())])
+        aggs = [AggregateFunction("SUM", [Column(2)], f64)]
+        bytes_per_row = 24
+    if wl == "product":
+        aggs = [AggregateFunction("SUM", [BinaryExpr(Column(1), Operator.Multiply, lit(2.0))], f64)]
     if wl == "cfg3":
         pred = None
     if wl == "cfg2":
