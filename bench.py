@@ -324,7 +324,15 @@ def main():
                             BinaryExpr(Column(1), Operator.Lt, Literal(ScalarValue.Float64(HI))))
         min_v = AggregateFunction("MIN", [Column(1)], f64)
         dgn, _ = timed(lambda: step(pred_n, (Column(0),), (sum_v, min_v)), k3, 1)
-        extra["neighbour_query_sum_min"] = rate(n_rows * k3, dgn, 16, "SELECT k, SUM(v), MIN(v) WHERE v >= lo AND v < hi GROUP BY k (no static signature)")
+        extra["neighbour_query_sum_min"] = rate(n_rows * k3, dgn, 16, "SELECT k, SUM(v), MIN(v) WHERE v >= lo AND v < hi GROUP BY k "
+                                                "(two aggregates of one operand: 12-byte routed rows {image, raw operand})")
+        # shapes without a compile-time signature (FastPolicy: run-time decoded column-op-literal terms)
+        pred_1 = BinaryExpr(Column(1), Operator.Lt, Literal(ScalarValue.Float64(LO)))
+        dg1, _ = timed(lambda: step(pred_1, (Column(0),), (sum_v,)), k3, 1)
+        extra["one_term_predicate_query"] = rate(n_rows * k3, dg1, 16, "SELECT k, SUM(v) WHERE v < lo GROUP BY k (no static signature: FastPolicy)")
+        sum_2v = AggregateFunction("SUM", [BinaryExpr(Column(1), Operator.Multiply, Literal(ScalarValue.Float64(2.0)))], f64)
+        dg2, _ = timed(lambda: step(pred, (Column(0),), (sum_2v,)), k3, 1)
+        extra["product_argument_query"] = rate(n_rows * k3, dg2, 16, "SELECT k, SUM(v * 2.0) WHERE v > lo AND v < hi GROUP BY k (no static signature: FastPolicy)")
 
         # skewed keys (Zipf s = 1.0; the generator is log-uniform, p(k) ~ 1/k), same query
         syn_z = [("k", ex.SYNTH_I64_ZIPF, 0, float(GROUPS), 1.0), ("v", ex.SYNTH_F64_EXACT, 1, 0.0, 0.0)]
