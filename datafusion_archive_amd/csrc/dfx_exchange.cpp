@@ -225,6 +225,10 @@ int32_t dfx_comm_init(const uint8_t* id, int32_t world, int32_t rank, dfx_comm**
     std::unique_ptr<dfx_comm> c(new dfx_comm());
     c->world = world;
     c->rank = rank;
+    {  // ncclCommInitRank binds the communicator to the calling thread's CURRENT device
+      hipError_t e = hipSetDevice(ctx().device);
+      if (e != hipSuccess) return to_c(Status::Err(DFX_EXECUTION_ERROR, strfmt("hipSetDevice(%d): %s", ctx().device, hipGetErrorString(e))), err, errlen);
+    }
     st = nccl_status(r.CommInitRank(&c->comm, world, u, rank), "ncclCommInitRank");
     if (!st.ok()) return to_c(st, err, errlen);
     *out = c.release();

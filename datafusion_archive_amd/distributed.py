@@ -25,11 +25,18 @@ def library_communicator(world: int, rank: int, dist=None):
     """One RCCL communicator owned by the library for this process: rank 0 draws the unique id, torch.distributed (any
     backend) broadcasts its 128 bytes, every rank calls dfx_comm_init on the library's device."""
     from . import execution as ex
-    uid = [ex.Communicator.unique_id() if rank == 0 else None]
+    uid = [None]
+    if rank == 0:
+        try:
+            uid[0] = ex.Communicator.unique_id()
+        except Exception as e:  # every rank must still take part in the broadcast (and then fail together)
+            uid[0] = ("error", str(e))
     if world > 1:
         if dist is None:
             import torch.distributed as dist  # type: ignore
         dist.broadcast_object_list(uid, src=0)
+    if isinstance(uid[0], tuple):
+        raise RuntimeError("rank 0 could not create the RCCL unique id: " + uid[0][1])
     return ex.Communicator(uid[0], world, rank)
 
 
