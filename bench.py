@@ -46,7 +46,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--rows", type=float, default=1e9, help="rows per GPU")
-    ap.add_argument("--batch-rows", type=int, default=1 << 26)
+    ap.add_argument("--batch-rows", type=int, default=1 << 27)
     ap.add_argument("--cpu-sample-rows", type=float, default=3e8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
@@ -237,8 +237,11 @@ def main():
             key = [k for k in ctr if want and k.startswith(want)]
             if key:
                 c = ctr[key[0]]
-                roofline["traffic"] = (2.0 * c["FETCH_SIZE_per_dispatch"] + c["WRITE_SIZE_per_dispatch"]) * 1024.0
-                roofline["traffic_over_algorithmic"] = round(roofline["traffic"] / roofline["algo_bytes_per_launch"], 3)
+                measured = (2.0 * c["FETCH_SIZE_per_dispatch"] + c["WRITE_SIZE_per_dispatch"]) * 1024.0
+                # per launch of THIS run: the profiled dispatches scanned rows_per_dispatch rows each (2^26 if the file predates the field)
+                per_row = measured / float(c.get("rows_per_dispatch", 1 << 26))
+                roofline["traffic"] = per_row * roofline["algo_bytes_per_launch"] / 16.0
+                roofline["traffic_over_algorithmic"] = round(per_row / 16.0, 3)
                 roofline["traffic_source"] = ("profiles/r02_partition_counters.json (rocprofv3 --pmc in separate passes over tools/prof_query.py headline, "
                                               "2*FETCH_SIZE + WRITE_SIZE per dispatch of the pass-1 kernel; committed, not collected by this run)")
         except Exception:

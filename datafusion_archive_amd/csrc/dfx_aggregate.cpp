@@ -118,6 +118,7 @@ struct AggregateRelation::Impl {
   bool calibrating = false;     // the launch in progress is the calibration slice
   bool use_partition = false;   // strategy 3: route rows to table blocks, aggregate blocks in LDS
   bool narrow = false;          // every key the calibration slice saw is below 2^32: 12-byte routed rows (PTF_NARROW)
+  int64_t launch_rows_hint = 0;  // > 0: the current batch is routed in launches of at most this many rows
   bool dense_seen = false;      // more than half of the calibration slice's rows passed the predicate: pass 2 after every batch
   bool skew_seen = false;       // the calibration slice's front cache absorbed a sizeable share of its rows: heavy keys
   DevPartition PT;
@@ -593,7 +594,8 @@ Status AggregateRelation::Impl::ensure_partition(int64_t rows, bool nulls_now) {
   // regions hold `window` worst-case batches.  Deferral pays when few rows are routed (headline, 20 %: 2 batches per
   // pass 2 = -3 % per query); when most rows are, the twice-as-long regions cost pass 1 more than the saved launches
   // give back (config 3, 1e9 rows: 11.05 ms at 2, 10.08 ms at 1)
-  const int window = dense_seen ? 1 : std::max(1, std::min(o.partition_defer, 16));
+  int window = o.partition_defer > 0 ? std::min(o.partition_defer, 16) : (int)std::max<int64_t>(1, std::min<int64_t>(8, ((int64_t)1 << 27) / std::max<int64_t>(rows, 1)));
+  if (dense_seen) window = 1;
   PT.cap_rows = pt_worst * (uint32_t)window;
   if (o.partition_cap_rows > 0) {  // tests: tiny regions (overflow -> spill list); no deferral
     PT.cap_rows = (uint32_t)((o.partition_cap_rows + 63) / 64 * 64);
@@ -865,7 +867,7 @@ Status AggregateRelation::Impl::launch_rows(const DeviceBatch& b, const DevProgr
   DevAggPlan p = plan;
   bool partition_now = use_partition;
   if (partition_now) {
-    Status pst = ensure_partition(std::max<int64_t>(n, b.num_rows), prog.has_nulls != 0);  // (the slice after the calibration rows: size for the whole batch)
+    Status pst = ensure_partition(launch_rows_hint > 0 ? std::max<int64_t>(n, std::min<int64_t>(launch_rows_hint, b.num_rows)) : std::max<int64_t>(n, b.num_rows), prog.has_nulls != 0);  // (the slice after the calibration rows: size for the whole batch)
     if (!pst.ok() && pst.code == DFX_NOT_IMPLEMENTED) partition_now = false;  // global-atomic path instead
     else if (!pst.ok()) return pst;
   }
@@ -1097,7 +1099,19 @@ Status AggregateRelation::Impl::consume_batch_chunk(const DeviceBatch& b) {
   } else if (!lds_calibrated) {
     if (o.strategy == 1) lds_enabled = false;
   }
-  DFX_RETURN_IF_ERROR(launch_rows(b, prog, cols, row0, n - row0));
+  {  // a scan that routes most of its rows: launches of at most partition_split_rows rows (regions sized for that many)
+    // (selective scans: twice that -- 2^27-row launches measured best, 2^28-row ones 7 % slower)
+    const int64_t split = (use_partition && o.partition_split_rows >= (1 << 20)) ? (((int64_t)o.partition_split_rows * (dense_seen ? 1 : 2)) & ~(int64_t)63) : 0;
+    launch_rows_hint = split;
+    Status lst = Status::OK();
+    if (split > 0 && n - row0 > split) {
+      for (int64_t at = row0; at < n && lst.ok(); at += split) lst = launch_rows(b, prog, cols, at, std::min(split, n - at));
+    } else {
+      lst = launch_rows(b, prog, cols, row0, n - row0);
+    }
+    launch_rows_hint = 0;
+    DFX_RETURN_IF_ERROR(lst);
+  }
   if (!lds_calibrated) {  // first batch of a stream that skipped the calibration slice: decide now
     uint32_t hc[CTRL_WORDS];
     DFX_RETURN_IF_ERROR(read_ctrl(hc));

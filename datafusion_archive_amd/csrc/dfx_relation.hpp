@@ -109,8 +109,12 @@ struct AggOptions {
   int partition_cap_rows = 0;  // rows per (producer, partition) region; 0: sized from the batch
   int partition_pad = 0;       // bytes of padding between partitions in the routing scratch
   int partition_block = 1024;  // pass-1 workgroup size in mode 1 (512: two workgroups per CU)
-  int partition_defer = 2;     // routing regions hold this many worst-case batches (1: pass 2 after every batch; measured: 2 saves
-                               // 1.5 % of the filtered query and 5 % when every row is routed, 4 and more slow pass 1 down again)
+  int partition_defer = 0;     // routing regions hold this many worst-case batches (1: pass 2 after every batch).  0 (default):
+                               // as many batches as make up ~2^27 rows, at most 8 -- a pass 2 per 2^27 scanned rows is what
+                               // measured best for selective scans whatever the batch size (2^26-row batches: 2 saves 3 %,
+                               // 4 and more lose it again; 2^27-row batches: 1); scans that route most of their rows get 1
+  int partition_split_rows = 1 << 26;  // a batch of a scan that routes most of its rows is routed in launches of at most this
+                               // many rows (0: never split): the regions of a 2^27-row launch cost pass 1 +20 %
   int partition_defer_batches = 8;  // at most this many pass-1 launches share one pass 2
   int export_kernel_copy = 1;  // large result columns reach the host by a copy kernel writing pinned memory (0: hipMemcpyAsync / copy engines)
   int ctrl_snapshot = 1;       // partitioned strategy: 1 the batch's last kernel writes the control-block snapshot to pinned host

@@ -393,6 +393,7 @@ int32_t dfx_set_option(const char* key, int64_t value) {
   else if (!strcmp(key, "agg.partition_cap_rows")) o.partition_cap_rows = (int)value;
   else if (!strcmp(key, "agg.partition_defer")) o.partition_defer = (int)value;
   else if (!strcmp(key, "agg.partition_defer_batches")) o.partition_defer_batches = (int)value;
+  else if (!strcmp(key, "agg.partition_split_rows")) o.partition_split_rows = (int)value;
   else if (!strcmp(key, "agg.pass2_stream")) o.pass2_stream = (int)value;
   else if (!strcmp(key, "agg.calibration_memo")) o.calibration_memo = (int)value;
   else if (!strcmp(key, "agg.emit_async")) o.emit_async = (int)value;

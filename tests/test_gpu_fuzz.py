@@ -247,7 +247,7 @@ def test_fuzz_aggregate(with_nulls, strategy):
         else:
             stats[r] += 1
         del src
-    for k, v in (("agg.narrow_keys", -1), ("agg.hot_keys", -1), ("agg.partition_defer", 2), ("agg.partition_layout", 1),
+    for k, v in (("agg.narrow_keys", -1), ("agg.hot_keys", -1), ("agg.partition_defer", 0), ("agg.partition_layout", 1),
                  ("agg.pass2_stream", 1), ("agg.ctrl_snapshot", 1), ("agg.narrow_chunk16", 1)):
         ex.set_option(k, v)
     print(f"fuzz aggregate nulls={with_nulls} strategy={strategy}: {stats}")

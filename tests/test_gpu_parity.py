@@ -695,7 +695,7 @@ def test_partitioned_narrow_rows_hot_keys_and_deferred_pass2(hot, layout):
                     want = oracle.aggregate([Column(0)], [a], [oracle.filter_next(f, ob) if f is not None else ob])
                     assert_groups_identical(got, want, 1, f"narrow rows hot={hot} layout={layout} kind={kind} {a.name}")
     finally:
-        for k, v in (("agg.strategy", 0), ("agg.narrow_keys", -1), ("agg.hot_keys", -1), ("agg.partition_layout", 1), ("agg.partition_defer", 4)):
+        for k, v in (("agg.strategy", 0), ("agg.narrow_keys", -1), ("agg.hot_keys", -1), ("agg.partition_layout", 1), ("agg.partition_defer", 0)):
             ex.set_option(k, v)
 
 

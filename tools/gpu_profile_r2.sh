@@ -9,7 +9,7 @@ $BENCH > $OUT/bench_plain.json 2> $OUT/bench_plain.err
 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/stats -o out -- $BENCH > $OUT/bench_under_rocprof.json 2>/dev/null
 cp $OUT/stats/out_kernel_stats.csv $OUT/bench_kernel_stats.csv 2>/dev/null
 Q="python $R/tools/prof_query.py"
-pmc() { name=$1; wl=$2; shift; shift; rocprofv3 --output-format csv --pmc "$@" -d $OUT/$name -o out -- $Q $wl 268435456 1 > /dev/null 2>&1; }
+pmc() { name=$1; wl=$2; shift; shift; rocprofv3 --output-format csv --pmc "$@" -d $OUT/$name -o out -- $Q $wl 268435456 1 batch=134217728 > /dev/null 2>&1; }
 pmc fetch_headline headline FETCH_SIZE
 pmc write_headline headline WRITE_SIZE
 pmc fetch_cfg3 cfg3 FETCH_SIZE
@@ -35,6 +35,8 @@ for d in sorted(glob.glob("*_headline") + glob.glob("*_cfg3")):
             for c, x in v.items():
                 res[d.split("_", 1)[1] + " | " + k][c + "_per_dispatch"] = x / cnt[(k, c)]
                 res[d.split("_", 1)[1] + " | " + k]["dispatches"] = cnt[(k, c)]
+                # prof_query runs the query twice (warm-up + 1 iteration) over 2^28 rows: rows one dispatch scanned / aggregated
+                res[d.split("_", 1)[1] + " | " + k]["rows_per_dispatch"] = 2.0 * 268435456 / cnt[(k, c)]
 json.dump(res, open("partition_counters.json", "w"), indent=1, sort_keys=True)
 for k, v in sorted(res.items()): print(k, {a: round(b, 1) for a, b in v.items()})
 PY
