@@ -1535,7 +1535,20 @@ AggregateRelation::AggregateRelation(SchemaInfo schema, std::unique_ptr<Relation
   // Filter -> Aggregate fusion (K7)
   if (input->kind() == REL_FILTER) {
     FilterRelation* f = static_cast<FilterRelation*>(input.get());
-    if (!f->predicate().is_aggregate) {
+    // the predicate joins the scan's fused program only if it fits next to the keys and at least one argument; otherwise
+    // (or when the Filter itself needed several programs) the Filter stays a relation of its own below the aggregate
+    bool fits = f->single_program();
+    if (fits && !f->predicate().is_aggregate) {
+      ProgramBuilder trial(f->input()->schema());
+      uint8_t opnd = kNoOperand;
+      int dt = 0;
+      Status tst = trial.add(f->predicate(), f->predicate().root, &opnd, &dt);
+      for (size_t k = 0; k < m.group.size() && tst.ok(); ++k)
+        if (!m.group[k].is_aggregate) tst = trial.add(m.group[k], m.group[k].root, &opnd, &dt);
+      if (tst.ok() && !m.aggr.empty() && m.aggr[0].is_aggregate && m.aggr[0].agg_arg >= 0) tst = trial.add(m.aggr[0], m.aggr[0].agg_arg, &opnd, &dt);
+      if (program_limit_error(tst)) fits = false;
+    }
+    if (fits && !f->predicate().is_aggregate) {
       m.has_pred = true;
       m.pred = f->predicate();
       std::unique_ptr<Relation> inner = f->release_input();

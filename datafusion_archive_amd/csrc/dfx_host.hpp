@@ -197,6 +197,11 @@ struct ScanMemo {
     if (calibrated_groups.size() < 64) calibrated_groups.emplace_back(fp, groups);
   }
 };
+// a fused device program ran out of columns / computed values / literals (ProgramBuilder::emit): callers that can split
+// their work into several programs do so on this error
+inline bool program_limit_error(const Status& st) {
+  return !st.ok() && st.code == DFX_NOT_IMPLEMENTED && st.msg.compare(0, 16, "fused expression") == 0;
+}
 // "<indent><text>\n"
 void explain_line(std::string* out, int depth, const std::string& text);
 // "program: c columns, i instructions, l literals"

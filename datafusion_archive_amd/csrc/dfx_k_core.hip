@@ -606,6 +606,32 @@ hipError_t launch_predicate_mask(const DevProgram& P, const DevFastPlan& fast, c
   return hipGetLastError();
 }
 
+// mask &= other, per-tile counts of the result: a predicate too large for one fused program is evaluated as several
+// conjuncts (FilterRelation, dfx_relation.cpp); one wave per 64-word tile
+__global__ __launch_bounds__(256) void k_mask_and_count(uint64_t* __restrict__ mask, const uint64_t* __restrict__ other,
+                                                        uint32_t* __restrict__ tile_counts, const int64_t n_words,
+                                                        const int64_t n_tiles) {
+  const int lane = lane_id();
+  const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tile >= n_tiles) return;
+  const int64_t w = tile * 64 + lane;
+  uint64_t word = 0;
+  if (w < n_words) {
+    word = mask[w] & other[w];
+    mask[w] = word;
+  }
+  uint32_t cnt = (uint32_t)__popcll(word);
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, m, 64);
+  if (lane == 0) tile_counts[tile] = cnt;
+}
+hipError_t launch_mask_and_count(uint64_t* mask, const uint64_t* other, uint32_t* tile_counts, int64_t n, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  const int64_t n_words = (n + 63) / 64, n_tiles = (n + kTileRows - 1) / kTileRows;
+  hipLaunchKernelGGL(k_mask_and_count, dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, s, mask, other, tile_counts, n_words, n_tiles);
+  return hipGetLastError();
+}
+
 template <typename TIN, typename TOUT>
 static hipError_t scan_impl(const TIN* in, TOUT* out, int64_t n, uint64_t* tmp, hipStream_t s) {
   Scope sc(KID_SCAN, s, 0);

@@ -46,6 +46,7 @@ int device_cu_count();
 //   replaces comparison_ops!/boolean_ops!/literal_array! closures (expression.rs:171-243, :410-465)
 // tile_counts (may be null): popcount per 4096-row tile, for the compaction offsets.
 // fast: shape-specialised plan (valid == 0 or nulls present: the generic interpreter runs)
+hipError_t launch_mask_and_count(uint64_t* mask, const uint64_t* other, uint32_t* tile_counts, int64_t n, hipStream_t s);
 hipError_t launch_predicate_mask(const DevProgram& P, const DevFastPlan& fast, const DevColumns& C, uint8_t pred,
                                  int64_t n, uint64_t* mask_words, uint32_t* tile_counts, uint32_t* ctrl,
                                  double algo_bytes, hipStream_t s);

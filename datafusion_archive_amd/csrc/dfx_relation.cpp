@@ -416,7 +416,81 @@ FilterRelation::FilterRelation(std::unique_ptr<Relation> input, const dfx_runtim
   if (deferred_.ok() && dt != DFX_BOOLEAN)  // filter.rs:64-66
     deferred_ = Status::Err(DFX_EXECUTION_ERROR, "Filter expression did not evaluate to boolean");
   memset(&fast_, 0, sizeof(fast_));
-  if (deferred_.ok()) builder_->build_fast(pred_operand_, nullptr, 0, nullptr, 0, &fast_);
+  if (!deferred_.ok() && program_limit_error(deferred_)) deferred_ = build_parts();
+  else if (deferred_.ok()) builder_->build_fast(pred_operand_, nullptr, 0, nullptr, 0, &fast_);
+}
+
+// the predicate does not fit one fused program: split its top-level AND chain
+Status FilterRelation::build_parts() {
+  const Status whole = deferred_;
+  std::vector<int32_t> conj;  // roots of the conjuncts, left to right
+  {
+    std::vector<int32_t> stack{expr_.root};
+    while (!stack.empty()) {
+      const int32_t at = stack.back();
+      stack.pop_back();
+      if (at < 0 || at >= (int32_t)expr_.nodes.size()) return whole;
+      const dfx_expr_node& n = expr_.nodes[(size_t)at];
+      if (n.kind == DFX_EXPR_BINARY && n.op == DFX_OP_AND) {
+        stack.push_back(n.right);
+        stack.push_back(n.left);
+      } else {
+        conj.push_back(at);
+      }
+    }
+  }
+  if (conj.size() < 2) return whole;  // nothing to split (one oversized comparison / OR tree)
+  // AND chain over conj[from, to) as an expression of its own (the original nodes plus the new AND nodes)
+  auto chain = [&](size_t from, size_t to) {
+    dfx_runtime_expr e = expr_;
+    int32_t root = conj[from];
+    for (size_t i = from + 1; i < to; ++i) {
+      dfx_expr_node a;
+      memset(&a, 0, sizeof(a));
+      a.kind = DFX_EXPR_BINARY;
+      a.op = DFX_OP_AND;
+      a.dtype = DFX_BOOLEAN;
+      a.left = root;
+      a.right = conj[i];
+      a.column = -1;
+      e.nodes.push_back(a);
+      e.strings.emplace_back();
+      e.has_name.push_back(0);
+      root = (int32_t)e.nodes.size() - 1;
+    }
+    e.root = root;
+    e.rebind();
+    return e;
+  };
+  std::vector<Part> parts;
+  size_t from = 0;
+  while (from < conj.size()) {
+    Part best;
+    size_t best_to = from;
+    for (size_t to = from + 1; to <= conj.size(); ++to) {  // the longest prefix of the remaining conjuncts that fits
+      Part p;
+      p.builder.reset(new ProgramBuilder(input_->schema()));
+      memset(&p.fast, 0, sizeof(p.fast));
+      const dfx_runtime_expr e = chain(from, to);
+      int dt = DFX_TYPE_NONE;
+      Status st = p.builder->add(e, e.root, &p.operand, &dt);
+      if (!st.ok()) {
+        if (program_limit_error(st) && best_to > from) break;  // the previous prefix is this part
+        return st;                                             // a single conjunct that does not fit, or a real error
+      }
+      if (dt != DFX_BOOLEAN) return Status::Err(DFX_EXECUTION_ERROR, "Filter expression did not evaluate to boolean");
+      p.builder->build_fast(p.operand, nullptr, 0, nullptr, 0, &p.fast);
+      best = std::move(p);
+      best_to = to;
+    }
+    parts.push_back(std::move(best));
+    from = best_to;
+  }
+  builder_ = std::move(parts[0].builder);
+  pred_operand_ = parts[0].operand;
+  fast_ = parts[0].fast;
+  for (size_t i = 1; i < parts.size(); ++i) more_.push_back(std::move(parts[i]));
+  return Status::OK();
 }
 
 void FilterRelation::explain(std::string* out, int depth) const {
@@ -431,7 +505,8 @@ void FilterRelation::explain(std::string* out, int depth) const {
     int n = 0;
     for (size_t i = 0; i < schema_.fields.size() || i < out_needed_.size(); ++i) n += (out_needed_.empty() || (i < out_needed_.size() && out_needed_[i])) ? 1 : 0;
     explain_line(out, depth, "Filter: mask + compaction, " + explain_program(P) + ", " + shape +
-                                 (out_needed_.empty() ? std::string(", every column compacted") : strfmt(", %d columns compacted", n)));
+                                 (out_needed_.empty() ? std::string(", every column compacted") : strfmt(", %d columns compacted", n)) +
+                                 (more_.empty() ? std::string() : strfmt(", conjunction evaluated by %zu fused programs (masks ANDed)", more_.size() + 1)));
   }
   if (input_) input_->explain(out, depth + 1);
 }
@@ -444,6 +519,9 @@ void FilterRelation::require_columns(const std::vector<char>& needed) {
   in_needed.resize(input_->schema().fields.size(), 1);
   for (int ci : builder_->columns())
     if (ci >= 0 && ci < (int)in_needed.size()) in_needed[ci] = 1;
+  for (const Part& p : more_)
+    for (int ci : p.builder->columns())
+      if (ci >= 0 && ci < (int)in_needed.size()) in_needed[ci] = 1;
   input_->require_columns(in_needed);
 }
 
@@ -499,6 +577,21 @@ Status FilterRelation::next(DeviceBatch* out, bool* has) {
   if (!agg_options().fast) fp.valid = 0;
   DFX_HIP(launch_predicate_mask(prog, fp, cols, pred_operand_, n, (uint64_t*)mask.get(), (uint32_t*)counts.get(),
                                 (uint32_t*)ctrl_.get(), in_bytes, s));
+  if (!more_.empty()) {  // the other conjuncts: their masks are ANDed into the first, the tile counts redone
+    auto mask2 = device_alloc(sizeof(uint64_t) * (size_t)n_words, &st);
+    if (!mask2) return st;
+    for (const Part& p : more_) {
+      DevProgram prog2;
+      DevColumns cols2;
+      DFX_RETURN_IF_ERROR(p.builder->bind(in, &prog2, &cols2));
+      double bytes2 = (double)n / 8.0;
+      for (int ci : p.builder->columns()) bytes2 += (double)n * (in.columns[ci].dtype == DFX_BOOLEAN ? 0.125 : dtype_width(in.columns[ci].dtype));
+      DevFastPlan fp2 = p.fast;
+      if (!agg_options().fast) fp2.valid = 0;
+      DFX_HIP(launch_predicate_mask(prog2, fp2, cols2, p.operand, n, (uint64_t*)mask2.get(), nullptr, (uint32_t*)ctrl_.get(), bytes2, s));
+      DFX_HIP(launch_mask_and_count((uint64_t*)mask.get(), (const uint64_t*)mask2.get(), (uint32_t*)counts.get(), n, s));
+    }
+  }
   DFX_HIP(launch_scan_u32((const uint32_t*)counts.get(), (uint64_t*)offsets.get(), n_tiles, (uint64_t*)tmp.get(), s));
   uint64_t kept = 0;
   uint32_t errbits = 0;

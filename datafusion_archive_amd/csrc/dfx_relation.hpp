@@ -57,6 +57,7 @@ class FilterRelation : public Relation {
   std::unique_ptr<Relation> release_input() { return std::move(input_); }
   const dfx_runtime_expr& predicate() const { return expr_; }
   Relation* input() { return input_.get(); }
+  bool single_program() const { return more_.empty(); }  // false: the predicate is evaluated as several conjuncts
 
  private:
   std::unique_ptr<Relation> input_;
@@ -68,6 +69,17 @@ class FilterRelation : public Relation {
   Status deferred_;  // evaluation-time type errors of the reference surface on next()
   std::shared_ptr<void> ctrl_;
   std::vector<char> out_needed_;  // empty: every column is compacted
+  // A conjunction that exceeds the limits of ONE fused program (kMaxCols columns, kMaxRegs computed values, kMaxImm
+  // literals -- the reference has none, expression.rs:171-243 builds closures of any size): its top-level AND chain is
+  // packed greedily into several programs; builder_ / pred_operand_ / fast_ are the first, these the others, and the
+  // masks are ANDed (kept(A AND B) == kept(A) && kept(B): a null conjunct keeps nothing on either side)
+  struct Part {
+    std::unique_ptr<ProgramBuilder> builder;
+    uint8_t operand = kNoOperand;
+    DevFastPlan fast;
+  };
+  std::vector<Part> more_;
+  Status build_parts();
 };
 
 // ---- ProjectRelation (src/execution/projection.rs) ----------------------------------------------

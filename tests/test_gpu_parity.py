@@ -229,6 +229,60 @@ def test_filter_multi_batch_and_slices():
         assert_batches_identical(g, oracle.filter_next(pred, b), "sliced batch")
 
 
+def _wide_conjunction(n_cols, rng, nulls):
+    """A batch of n_cols numeric columns and `c0 > a0 AND c0 < b0 AND c1 > a1 AND ...` over all of them."""
+    n = 50021
+    arrays, names, terms = [], [], []
+    for c in range(n_cols):
+        if c % 3 == 2:
+            vals = rng.integers(-1000, 1000, n).astype(np.int64)
+            lo, hi = Literal(ScalarValue.Int64(-900)), Literal(ScalarValue.Int64(950))
+        else:
+            vals = rng.integers(0, 1 << 20, n).astype(np.float64) / 1024.0
+            lo, hi = lit(8.0 + c), lit(1000.0 - c)
+        mask = (rng.random(n) < 0.03) if (nulls and c % 4 == 1) else None
+        arrays.append(pa.array(vals, mask=mask))
+        names.append(f"c{c}")
+        terms.append(BinaryExpr(Column(c), Operator.Gt, lo))
+        terms.append(BinaryExpr(Column(c), Operator.Lt, hi))
+    pred = terms[0]
+    for t in terms[1:]:
+        pred = BinaryExpr(pred, Operator.And, t)
+    return pa.RecordBatch.from_arrays(arrays, names=names), pred
+
+
+def test_filter_conjunction_wider_than_one_fused_program():
+    """The reference builds closures of any size (expression.rs:171-243); a fused device program holds 8 columns, 16
+    computed values, 16 literals.  A top-level AND chain beyond that is evaluated by several programs whose masks are
+    ANDed: 12 columns x 2 comparisons = 24 literals, 47 computed values.  With and without nulls, against the oracle;
+    the same predicate under an aggregate (the Filter then stays a relation of its own)."""
+    rng = np.random.default_rng(77)
+    for nulls in (False, True):
+        b, pred = _wide_conjunction(12, rng, nulls)
+        got = gpu_filter(pred, b.schema, [b, b.slice(1000, 30000)])
+        assert_batches_identical(got[0], oracle.filter_next(pred, b), f"wide conjunction, nulls {nulls}")
+        assert_batches_identical(got[1], oracle.filter_next(pred, b.slice(1000, 30000)), f"wide conjunction, slice, nulls {nulls}")
+        aggs = [agg("sum", Column(0), F64), agg("count", Column(3), DataType.UInt64), agg("max", Column(2), DataType.Int64)]
+        for group in ([], [Column(5)]):
+            g = gpu_aggregate(group, aggs, b.schema, [b], filter_expr=pred)
+            w = oracle.aggregate(group, aggs, [oracle.filter_next(pred, b)])
+            if group:
+                assert_groups_identical(g, w, 1, f"aggregate over wide conjunction, nulls {nulls}")
+            else:
+                assert_batches_identical(g, w, f"ungrouped aggregate over wide conjunction, nulls {nulls}")
+    # a disjunction that does not fit is not split: the limit is still reported
+    b, pred = _wide_conjunction(12, rng, False)
+    terms = []
+    for c in range(12):
+        terms.append(BinaryExpr(Column(c), Operator.Gt, lit(1.0 + c) if c % 3 != 2 else Literal(ScalarValue.Int64(5))))
+    orp = terms[0]
+    for t in terms[1:]:
+        orp = BinaryExpr(orp, Operator.Or, t)
+    with pytest.raises(ex.ExecutionError) as ei:
+        gpu_filter(orp, b.schema, [b])
+    assert ei.value.kind == "NotImplemented" and "more than" in ei.value.message
+
+
 def test_filter_errors_mirror_reference():
     b = _random_batch(np.random.default_rng(1), 10)
     with pytest.raises(ex.ExecutionError) as ei:  # filter.rs:64-66
