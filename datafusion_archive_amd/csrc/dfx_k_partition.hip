@@ -241,6 +241,8 @@ __global__ __launch_bounds__(kABlock) void k_partition_agg(const DevTable T, con
 // a slot whose key has no image (>= 2^32, inserted by the general path: occupied, never equal to a row's image).  12
 // bytes per slot: 96 KB of LDS instead of 128; claimed tags become keys again at write-back.
 // Padding rows (pass 1 rounds every region up to whole chunks: key kEmptyKey / image kTagEmpty) are skipped.
+constexpr int kP2RetryRows = 128;     // per-wave queue of rows that missed their home group (narrow rows: 12 bytes each)
+constexpr int kP2RetryRowsWide = 96;  // ... 16-byte rows: 128 KB of block + 16 x 96 x 16 B = 152 KB of LDS
 constexpr int kSharedMaxAggs = 3;  // PTF_SHARED: 4096 slots x (4-byte tag + 3 accumulators) = 112 KB of LDS
 constexpr int kPF = 8;
 constexpr int kP2Vgprs = 88;  // v88..v119: kPF x 4 registers of in-flight rows, outside the register allocator's reach
@@ -510,26 +512,71 @@ __global__ __launch_bounds__(kABlock) __attribute__((amdgpu_num_vgpr(kP2Vgprs)))
       q1.hit = true;
     }
   };
-  auto finish = [&](Probe& q) {
-    if (q.hit) apply(q.at, q.val);
-    const bool miss = q.real && !q.hit;
-    if (__ballot(miss) != 0) {  // general find-or-claim for the rest: new keys, longer probe sequences, a full block
-      bool todo = miss;
-      uint64_t key[1] = {q.kk};
-      if (miss) {
-        const int found = NARROW ? pa2n_lookup(ltags, S, q.home4, q.img, new_keys) : pa2_lookup(lkeys, S, q.home4, q.kk, new_keys);
-        if (found >= 0) {
-          apply((uint32_t)found, q.val);
-          todo = false;
-        }
+  // Rows whose home group does not hold their key (4 % at load 0.5, every row of a block's first batch) are parked in a
+  // per-wave LDS queue and go through the general find-or-claim up to 64 at a time.  Handling them in place costs the
+  // WHOLE wave a second group look on 99.5 % of the trip pairs (1 - 0.96^128) and the divergent general path on a third
+  // of them: more than half of the kernel's vector instructions for 4 % of the rows (pass 2: -20 %).
+  constexpr uint32_t kRQ = NARROW ? (uint32_t)kP2RetryRows : (uint32_t)kP2RetryRowsWide;  // rows per wave
+  constexpr uint32_t kRW = NARROW ? 3u : 4u;  // words per parked row: {image | key lo, key hi} + {operand lo, operand hi}
+  uint32_t* const rq = (NARROW ? (uint32_t*)(ltags + S) : (uint32_t*)(lds + 2 * (size_t)S)) + (size_t)wave * kRQ * kRW;
+  uint32_t rqn = 0;  // queued rows (wave-uniform)
+  auto retry = [&](bool active, uint32_t at) {  // one queued row per active lane
+    uint32_t img = 0;
+    uint64_t kk = 0, val = 0;
+    if (active) {
+      if (NARROW) {
+        img = rq[at * kRW];
+      } else {
+        kk = ((uint64_t)rq[at * kRW + 1] << 32) | rq[at * kRW];
       }
-      if (__ballot(todo) != 0) {  // block full: grow-and-replay takes the row (as a key again)
-        if (NARROW) key[0] = (uint64_t)unhash_word32(q.img);
-        uint64_t sv[kMaxAggs];
+      val = ((uint64_t)rq[at * kRW + kRW - 1] << 32) | rq[at * kRW + kRW - 2];
+    }
+    bool todo = active;
+    if (active) {
+      int found;
+      if (NARROW) {
+        found = pa2n_lookup(ltags, S, (uint32_t)(img >> tag_shift) & mask4, img, new_keys);
+      } else {
+        uint64_t key1[1] = {kk};
+        found = pa2_lookup(lkeys, S, (uint32_t)(hash_keys<1>(key1) >> T.shift) & mask4, kk, new_keys);
+      }
+      if (found >= 0) {
+        apply((uint32_t)found, val);
+        todo = false;
+      }
+    }
+    if (__ballot(todo) != 0) {  // block full: grow-and-replay takes the row (as a key again)
+      uint64_t key[1] = {NARROW ? (uint64_t)unhash_word32(img) : kk};
+      uint64_t sv[kMaxAggs];
 #pragma unroll
-        for (int j = 0; j < kMaxAggs; ++j)
-          sv[j] = MULTI ? ((uint32_t)j < NA ? transform_value(T.val_xform[j], q.val, true) : 0ull) : (j == 0 ? q.val : 0ull);
-        spill_row<1>(T, spill, todo, key, sv);
+      for (int j = 0; j < kMaxAggs; ++j)
+        sv[j] = MULTI ? ((uint32_t)j < NA ? transform_value(T.val_xform[j], val, true) : 0ull) : (j == 0 ? val : 0ull);
+      spill_row<1>(T, spill, todo, key, sv);
+    }
+  };
+  auto park = [&](const Probe& q) {
+    const bool miss = q.real && !q.hit;
+    const uint64_t m = __ballot(miss);
+    if (m != 0) {
+      if (miss) {
+        const uint32_t at = rqn + mbcnt64(m);
+        if (NARROW) {
+          rq[at * kRW] = q.img;
+        } else {
+          rq[at * kRW] = (uint32_t)q.kk;
+          rq[at * kRW + 1] = (uint32_t)(q.kk >> 32);
+        }
+        rq[at * kRW + kRW - 2] = (uint32_t)q.val;
+        rq[at * kRW + kRW - 1] = (uint32_t)(q.val >> 32);
+      }
+      rqn += (uint32_t)__popcll(m);
+      // at most kRQ - 64 rows may stay queued: the next trip parks up to 64 more
+      while (rqn > kRQ - 64u) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const uint32_t take_n = rqn < 64u ? rqn : 64u;
+        rqn -= take_n;
+        retry((uint32_t)lane < take_n, rqn + (uint32_t)lane);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       }
     }
   };
@@ -538,10 +585,10 @@ __global__ __launch_bounds__(kABlock) __attribute__((amdgpu_num_vgpr(kP2Vgprs)))
     decode(r0, tk0, q0);
     decode(r1, tk1, q1);
     look2(q0, q0.home4, q1, q1.home4);
-    if (__ballot((q0.real && !q0.hit) || (q1.real && !q1.hit)) != 0)  // second group (4 % of the keys live there at load 0.5)
-      look2(q0, (q0.home4 + 4u) & mask4, q1, (q1.home4 + 4u) & mask4);
-    finish(q0);
-    finish(q1);
+    if (q0.hit) apply(q0.at, q0.val);
+    if (q1.hit) apply(q1.at, q1.val);
+    park(q0);
+    park(q1);
   };
 #define DFX_P2_PAIR(D0, D1)                                                                                       \
   if (more) {                                                                                                     \
@@ -563,6 +610,10 @@ __global__ __launch_bounds__(kABlock) __attribute__((amdgpu_num_vgpr(kP2Vgprs)))
   }
 #undef DFX_P2_PAIR
 #undef DFX_P2_FETCH
+  if (rqn != 0) {  // the wave's last parked rows (at most kRQ - 64 <= 64)
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    retry((uint32_t)lane < rqn, (uint32_t)lane);
+  }
   p2_drain();  // loads still in flight own v88..v119 until they land
   __syncthreads();
   for (uint32_t i0 = threadIdx.x * 2; i0 < S; i0 += kABlock * 2) {
@@ -686,14 +737,14 @@ hipError_t launch_partition_agg(const DevTable& T, const DevPartition& PT, const
   size_t lds_bytes = (size_t)(T.block_mask + 1) * (size_t)(1 + T.na) * 8 + (size_t)(PT.n_producers + 1) * 4 + 16;
   if (lds_bytes > 160 * 1024 - 256 || PT.n_producers > 1024) return hipErrorInvalidValue;
   if ((PT.flags & PTF_NARROW) && (PT.flags & PTF_SHARED)) {
-    const size_t shared_lds = (size_t)(T.block_mask + 1) * (size_t)(4 + 8 * T.na);
+    const size_t shared_lds = (size_t)(T.block_mask + 1) * (size_t)(4 + 8 * T.na) + (size_t)(kABlock / 64) * kP2RetryRows * 12;
     if (T.na < 2 || T.na > kSharedMaxAggs || T.kw != 1 || shared_lds > 160 * 1024 - 256) return hipErrorInvalidValue;
     hipLaunchKernelGGL((k_partition_agg_lean<1, -1>), dim3(PT.n_parts), dim3(kABlock), shared_lds, s, T, PT, spill);
   } else if (PT.flags & PTF_NARROW) {
     if (T.na != 1 || T.kw != 1) return hipErrorInvalidValue;
-    launch_agg_lean<1>(T, PT, spill, (size_t)(T.block_mask + 1) * 12, s);
+    launch_agg_lean<1>(T, PT, spill, (size_t)(T.block_mask + 1) * 12 + (size_t)(kABlock / 64) * kP2RetryRows * 12, s);
   } else if (T.na == 1 && (PT.flags & PTF_STREAM_PASS2) && PT.n_words == 2)
-    launch_agg_lean<0>(T, PT, spill, (size_t)(T.block_mask + 1) * 16, s);
+    launch_agg_lean<0>(T, PT, spill, (size_t)(T.block_mask + 1) * 16 + (size_t)(kABlock / 64) * kP2RetryRowsWide * 16, s);
   else if (T.na == 1) hipLaunchKernelGGL(k_partition_agg<1>, dim3(PT.n_parts), dim3(kABlock), lds_bytes, s, T, PT, spill);
   else hipLaunchKernelGGL(k_partition_agg<0>, dim3(PT.n_parts), dim3(kABlock), lds_bytes, s, T, PT, spill);
   return hipGetLastError();
