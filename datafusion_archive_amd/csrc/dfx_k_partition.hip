@@ -224,12 +224,11 @@ __global__ __launch_bounds__(kABlock) void k_partition_agg(const DevTable T, con
 //     lane j = producer w + 16 j, read back with v_readlane), so a row's address is a scalar base + lane * row bytes;
 //   * the accumulator kind is a template parameter;
 //   * FAST PATH, branch-free: the row's home group of four slots is read (one 16-byte LDS read of 32-bit tags, or two of
-//     64-bit keys), four compares, the matching slot picked with v_cndmask, one LDS atomic under the match mask; rows that
-//     did not match look at the NEXT group the same way.  In a table that has seen its keys (every batch but the first)
-//     99.7 % of the rows end here;
-//   * only if a lane is still unmatched (empty slot to claim, longer probe sequence, full block) the wave takes the
-//     general find-or-claim for those lanes (same probe order as the global kernels: the block stays a valid
-//     linear-probing table);
+//     64-bit keys), four compares, the matching slot picked with v_cndmask, one LDS atomic under the match mask.  In a
+//     table that has seen its keys (every batch but the first) 96 % of the rows end here;
+//   * a row whose home group does not hold its key (it lives further along the probe sequence, or is new, or the block is
+//     full) is parked in a per-wave LDS queue; up to 64 parked rows at a time take the general find-or-claim (same probe
+//     order as the global kernels: the block stays a valid linear-probing table) at full lane utilisation;
 //   * the row loads of kPF trips are in flight per wave.  The compiler tracks vector-memory results with ONE in-order
 //     counter (vmcnt) and is pessimistic after conditional code that contains memory operations, so the loads are
 //     issued by inline assembly into VGPRs v88..v119, which the kernel withholds from the register allocator
