@@ -862,6 +862,37 @@ def test_shared_operand_rows_leave_the_fast_path_correctly():
             ex.set_option(kk, vv)
 
 
+def test_large_batches_are_routed_in_several_launches():
+    """A batch larger than the routing window is split into pass-1 launches (agg.partition_split_rows; twice that for
+    selective scans): one 5.2 M-row batch with the split at 2^20 rows -- dense scan (calibrated: every row routed, 5
+    launches), selective scan (3 launches), and a forced strategy without calibration -- against the oracle."""
+    ex.set_option("agg.partition_split_rows", 1 << 20)
+    try:
+        schema = pa.schema([("k", pa.int64()), ("v", pa.float64())])
+        syn = [("k", ex.SYNTH_I64_UNIFORM, 0, 200000.0, 0.0), ("v", ex.SYNTH_F64_EXACT, 1, 0.0, 0.0)]
+        n, seed = 5 * (1 << 20) + 777, 0xDF51
+        t = ex.DeviceTable.synth(syn, seed, 0, n)
+        ob = oracle.synth_batch(syn, seed, 0, n)
+        aggs = [agg("sum", Column(1), F64)]
+        pred = BinaryExpr(Column(1), Operator.Lt, lit(200.0))
+        for strategy in (0, 3):
+            ex.set_option("agg.strategy", strategy)
+            for filt in (None, pred):
+                ex.profile_reset()
+                ex.profile_enable(True)
+                try:
+                    got = gpu_aggregate([Column(0)], aggs, schema, [], source=t.scan(n), filter_expr=filt)
+                finally:
+                    ex.profile_enable(False)
+                launches = {p["kernel"]: p["launches"] for p in ex.profile_snapshot()}.get("partition", 0)
+                want = oracle.aggregate([Column(0)], aggs, [oracle.filter_next(filt, ob) if filt is not None else ob])
+                assert_groups_identical(got, want, 1, f"split launches, strategy {strategy}, filter {filt is not None}")
+                assert launches >= 3, f"strategy {strategy}, filter {filt is not None}: {launches} pass-1 launches, the batch was not split"
+    finally:
+        ex.set_option("agg.partition_split_rows", 1 << 26)
+        ex.set_option("agg.strategy", 0)
+
+
 def test_narrow_rows_fall_back_when_a_wide_key_turns_up():
     """Narrow mode is an assumption about keys not seen yet.  Keys >= 2^32, negative keys and i64::MIN arriving in later
     batches go through the spill list, the stream leaves narrow mode, and the groups are still the oracle's."""
