@@ -286,6 +286,37 @@ def test_explain_operator_tree_and_pushdown():
     assert _ffi.lib().dfx_relation_explain(ctypes.addressof(foreign), None, 0) == -1
 
 
+def test_conjunction_beyond_one_fused_program_is_split_on_the_host():
+    """FilterRelation packs the top-level AND chain of an oversized predicate into several fused programs (8 columns, 16
+    computed values, 16 literals each) -- decided at construction, visible in the plan; under an aggregate such a Filter
+    stays a relation of its own (no fusion).  A disjunction of the same size is not split: the limit is reported on
+    next() (the reference's errors surface there as well), so construction still succeeds."""
+    n_cols = 12
+    schema = pa.schema([(f"c{i}", pa.float64()) for i in range(n_cols)])
+    b = pa.RecordBatch.from_pydict({f"c{i}": [1.0] for i in range(n_cols)}, schema=schema)
+    terms = []
+    for c in range(n_cols):
+        terms.append(BinaryExpr(Column(c), Operator.Gt, Literal(ScalarValue.Float64(float(c)))))
+        terms.append(BinaryExpr(Column(c), Operator.Lt, Literal(ScalarValue.Float64(100.0 + c))))
+
+    def chain(op):
+        e = terms[0]
+        for t in terms[1:]:
+            e = BinaryExpr(e, op, t)
+        return e
+    f = ex.FilterRelation(ex.DataSourceRelation(schema, [b]), ex.compile_scalar_expr(None, chain(Operator.And), schema), schema)
+    text = ex.explain(f)
+    assert "conjunction evaluated by" in text and "fused programs (masks ANDed)" in text, text
+    n_prog = int(text.split("conjunction evaluated by ")[1].split()[0])
+    assert 3 <= n_prog <= 6, text  # 24 literals / 16 per program, 47 values / 16: at least three
+    agg = ex.AggregateRelation(None, ex.FilterRelation(ex.DataSourceRelation(schema, [b]), ex.compile_scalar_expr(None, chain(Operator.And), schema), schema),
+                               [], [ex.compile_expr(None, AggregateFunction("SUM", [Column(0)], DataType.Float64), schema)])
+    lines = [ln.strip().split(":")[0] for ln in ex.explain(agg).splitlines()]
+    assert lines[:2] == ["Aggregate", "Filter"], lines  # the Filter was not absorbed into the aggregate's scan
+    g = ex.FilterRelation(ex.DataSourceRelation(schema, [b]), ex.compile_scalar_expr(None, chain(Operator.Or), schema), schema)
+    assert "error deferred to next()" in ex.explain(g) and "more than" in ex.explain(g)
+
+
 def test_group_hash_is_a_bijection_of_narrow_keys():
     """Narrow rows (PTF_NARROW) stand on this: for keys below 2^32 the 32-bit image of the group hash identifies the key
     (dfx_debug_unhash32 inverts it), images of different keys differ, and a key with high bits hashes differently from its
