@@ -1621,6 +1621,9 @@ void AggregateRelation::explain(std::string* out, int depth) const {
     else if (m.kw == 1) text += ", strategy chosen on the first 2^18 rows: register accumulators (<= 8 groups) / LDS front cache (<= 8192) / table / "
                                "partitioned (>= 16384 groups: pass 1 routes rows to table blocks, pass 2 aggregates blocks in LDS)";
     else text += ", strategy chosen on the first 2^18 rows: register accumulators (<= 8 groups) / LDS front cache (<= 8192) / table";
+    if (m.shared_operand())
+      text += strfmt("; %d aggregates of ONE operand: the partitioned strategy routes 12-byte rows {hash image, raw operand} while keys are "
+                     "narrow and batches have no nulls, pass 2 applies every aggregate to it", m.na);
     if (!m.dicts.empty()) text += strfmt(", %d Utf8 keys dictionary-encoded on the device", (int)m.dicts.size());
     if (m.built && m.kw > 0)  // after the input was drained: what actually ran
       text += strfmt("; ran %lld rows: %s, %llu of 2^%d table slots occupied", (long long)m.rows_seen,

@@ -259,6 +259,11 @@ def test_explain_baseline_shapes_hit_their_static_signatures():
     assert "static shape Q1" in text and "2 keys, 4 accumulators" in text and "7 columns" in text
     # anything else: the run-time decoded shape family, or the interpreter
     assert "FastPolicy" in _explain_aggregate(kv, pred, [Column(0)], [AggregateFunction("MAX", [Column(1)], f64)])
+    # AVG = SUM + COUNT of one operand, SUM + MIN + MAX of one column: shared routed value; different operands: not
+    assert "2 aggregates of ONE operand" in _explain_aggregate(kv, pred, [Column(0)], [AggregateFunction("AVG", [Column(1)], f64)])
+    assert "3 aggregates of ONE operand" in _explain_aggregate(kv, None, [Column(0)], [sum_v, AggregateFunction("MIN", [Column(1)], f64), AggregateFunction("MAX", [Column(1)], f64)])
+    assert "ONE operand" not in _explain_aggregate(kv, None, [Column(0)], [sum_v, AggregateFunction("MAX", [Column(0)], DataType.Int64)])
+    assert "ONE operand" not in _explain_aggregate(kv, pred, [Column(0)], [sum_v])
     assert "SSA interpreter" in _explain_aggregate(kv, pred, [Column(0)], [AggregateFunction("SUM", [BinaryExpr(Column(1), Operator.Plus, Column(1))], f64)])
 
 
