@@ -145,3 +145,38 @@ def test_group_partial_exchange_world2_gloo():
         assert stats["n_words"] == 4
     assert got == want_d  # exact data: SUM is order-independent, so bit-exact across the exchange
     assert sum(ret[r][1]["sent_groups"] for r in range(world)) == sum(ret[r][1]["received_groups"] for r in range(world))
+
+
+def _comm_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from datafusion_archive_amd.distributed import library_communicator
+        outcome = "created"
+        try:
+            library_communicator(world, rank, dist)
+        except Exception as e:  # no GPU here: the unique id (rank 0) or dfx_comm_init (every rank) fails
+            outcome = type(e).__name__ + ": " + str(e)[:160]
+        # bench.py's next step: agree on the outcome.  Both ranks must arrive here (nobody is left inside a broadcast)
+        t = torch.tensor([1 if outcome == "created" else 0], dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        ret[rank] = (outcome, int(t.item()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_library_communicator_fails_on_every_rank_together_without_a_gpu():
+    """bench.py --gpus N creates the library's RCCL communicator on every rank and then all-reduces whether that worked
+    (falling back to the host-driven exchange if not).  Whatever fails -- rank 0's unique id, or dfx_comm_init without a
+    device -- every rank has to come out of library_communicator and reach that all-reduce: a rank stuck in the id
+    broadcast would hang the job.  World 2 over gloo, no GPU: both ranks report a failure and agree on it."""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_comm_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    for rank in range(world):
+        outcome, agreed = ret[rank]
+        assert agreed == 0
+        assert outcome != "created", "a communicator was created without a GPU?"
+        assert "Error" in outcome or "error" in outcome, outcome
