@@ -70,7 +70,7 @@ EXPORTED_SYMBOLS = [
     "dfx_aggregate_partial_build", "dfx_aggregate_partial_export", "dfx_aggregate_partial_import",
     "dfx_comm_unique_id", "dfx_comm_init", "dfx_comm_destroy", "dfx_aggregate_exchange",
     "dfx_profile_enable", "dfx_profile_reset", "dfx_profile_count", "dfx_profile_get", "dfx_set_option",
-    "dfx_counter_get", "dfx_counter_reset", "dfx_relation_explain", "dfx_relation_drain_device",
+    "dfx_counter_get", "dfx_counter_reset", "dfx_relation_explain", "dfx_relation_drain_device", "dfx_filter_debug_mask",
     "dfx_debug_group_hash", "dfx_debug_unhash32",
 ]
 
@@ -159,6 +159,7 @@ def lib() -> ctypes.CDLL:
     L.dfx_relation_explain.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t]
     L.dfx_relation_explain.restype = ctypes.c_int64
     L.dfx_relation_drain_device.argtypes = [ctypes.c_void_p, P(ctypes.c_int64), P(ctypes.c_int64)] + c_err
+    L.dfx_filter_debug_mask.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, P(ctypes.c_int64)] + c_err
     L.dfx_debug_group_hash.argtypes = [ctypes.c_uint64]
     L.dfx_debug_group_hash.restype = ctypes.c_uint64
     L.dfx_debug_unhash32.argtypes = [ctypes.c_uint32]

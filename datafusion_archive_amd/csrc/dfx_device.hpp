@@ -269,6 +269,16 @@ struct DevCsvPlan {
   DevCsvCol col[kCsvMaxCols];
 };
 
+// single-pass FilterRelation (k_filter_fused): bank columns (columns the predicate reads anyway) that are compacted by the
+// kernel that evaluates the predicate -- they are read from HBM once
+constexpr int kFusedOutCols = 2;
+struct DevFusedOut {
+  int32_t n;                     // 0..kFusedOutCols
+  uint8_t slot[kFusedOutCols];   // column slot of the fused program
+  uint8_t dtype[kFusedOutCols];
+  void* out[kFusedOutCols];      // room for every row of the batch (the kept count is known when the kernel ends)
+};
+
 struct DevProjectPlan {
   int32_t n_out;
   uint8_t out[kMaxOut];        // operands

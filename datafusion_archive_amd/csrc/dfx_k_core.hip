@@ -89,6 +89,173 @@ __global__ __launch_bounds__(kBlock) void k_predicate_mask(const DevProgram P, c
 }
 
 // ---------------------------------------------------------------------------------------------
+// K1 + K4 in one pass: single-pass FilterRelation
+// ---------------------------------------------------------------------------------------------
+// The two-pass form (k_predicate_mask -> scan of the tile counts -> k_compact) reads a predicate column twice: once to
+// evaluate it, once to compact it.  Here a workgroup evaluates a 4096-row tile, parks the passing rows' values of up to
+// kFusedOutCols of the predicate's own columns in LDS (wave-private segments: position = rows the wave kept so far +
+// rank inside the ballot word), learns where its tile starts in the output from a DECOUPLED LOOK-BACK over the tiles'
+// kept counts (one 64-bit status word per tile: flag | count; a wave inspects 64 predecessors per step), and copies its
+// segments out in whole coalesced runs.  Row order is preserved (filter.rs:86-90).  The Arrow bitmap and the per-tile
+// exclusive offsets are written as well: every OTHER column of the batch is compacted by k_compact from them, reading
+// it once, too.
+// Forward progress: tiles are dealt round-robin to a grid that is co-resident (launch_filter_fused sizes it from the
+// occupancy API), every workgroup takes its tiles in increasing order and publishes a tile's count BEFORE it looks back,
+// so the smallest unpublished tile never waits for anything.  The spin is bounded all the same (error bit 8).
+constexpr uint64_t kLbAggregate = 1ull << 62, kLbInclusive = 2ull << 62, kLbFlags = 3ull << 62;
+
+DEV uint32_t mbcnt_u64(uint64_t m) {
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+template <typename POL>
+__global__ __launch_bounds__(kBlock) void k_filter_fused(const DevProgram P, const DevFastPlan F, const DevColumns C,
+                                                         const uint8_t pred, const int64_t n,
+                                                         uint64_t* __restrict__ mask_words,
+                                                         uint64_t* __restrict__ tile_offsets,
+                                                         uint64_t* __restrict__ sync, const DevFusedOut O,
+                                                         uint32_t* __restrict__ ctrl) {
+  typedef typename POL::COLV COLV;
+  constexpr int U = POL::U;
+  constexpr int BANK = (int)(sizeof(COLV) / 8);
+  constexpr int NW = kBlock / 64;                 // waves per workgroup
+  constexpr int kWaveRows = kTileRows / NW;       // 1024: rows (16 bitmap words) per wave and tile
+  extern __shared__ __attribute__((aligned(16))) uint64_t stage[];  // [O.n][NW][kWaveRows] kept values
+  __shared__ uint64_t s_words[kTileRows / 64];
+  __shared__ uint32_t s_wave_cnt[NW];
+  __shared__ uint64_t s_base;
+  const int lane = lane_id();
+  const int wave = threadIdx.x >> 6;
+  const int64_t n_words = (n + 63) >> 6;
+  const int64_t n_tiles = (n + kTileRows - 1) / kTileRows;
+  uint64_t* const state = sync + 2;
+  uint32_t err = 0;
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    uint32_t cnt = 0;  // rows this wave has kept in this tile (wave-uniform)
+    for (int i0 = 0; i0 < kWaveRows / 64; i0 += U) {
+      const int64_t w0 = tile * (kTileRows / 64) + wave * (kWaveRows / 64) + i0;
+      COLV col[U];
+      uint32_t cv[U];
+      FOR_U {
+        const int64_t row = (w0 + u) * 64 + lane;
+        POL::load(P, C, row, row < n, col[u], cv[u]);
+      }
+#pragma nounroll
+      for (int uu = 0; uu < U; ++uu) {
+        COLV cur;
+        uint32_t curv;
+        DFX_SELECT_BANK(uu, col, cv, cur, curv)
+        const int64_t w = w0 + uu;
+        const bool inb = w * 64 + lane < n;
+        u64x16 reg;
+        uint32_t rv = 0;
+        POL::eval(P, F, cur, curv, reg, rv, inb, err);
+        const bool pass = inb && POL::pass(P, F, pred, cur, curv, reg, rv);
+        const uint64_t word = __ballot(pass);
+        if (lane == 0) s_words[wave * (kWaveRows / 64) + i0 + uu] = word;
+        if (pass) {
+          const uint32_t at = cnt + mbcnt_u64(word);
+#pragma unroll
+          for (int o = 0; o < kFusedOutCols; ++o) {
+            if (o < O.n) {
+              uint64_t v = cur[0];
+#pragma unroll
+              for (int c = 1; c < BANK; ++c) v = (O.slot[o] == c) ? cur[c] : v;
+              stage[(size_t)(o * NW + wave) * kWaveRows + at] = v;
+            }
+          }
+        }
+        cnt += (uint32_t)__popcll(word);
+      }
+    }
+    if (lane == 0) s_wave_cnt[wave] = cnt;
+    __syncthreads();
+    uint32_t wc[NW];
+    uint32_t A = 0;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) {
+      wc[k] = s_wave_cnt[k];
+      A += wc[k];
+    }
+    if (wave == 0) {
+      const int64_t w = tile * (kTileRows / 64) + lane;  // the tile's 64 bitmap words: one coalesced 512-byte store
+      if (w < n_words) mask_words[w] = s_words[lane];
+      uint64_t base = 0;
+      if (tile > 0) {
+        if (lane == 0) __hip_atomic_store(&state[tile], kLbAggregate | (uint64_t)A, RLX_AGENT);
+        int64_t hi = tile - 1;  // lane l looks at tile hi - l
+        uint32_t spins = 0;
+        for (;;) {
+          const int64_t j = hi - lane;
+          const uint64_t st = j >= 0 ? __hip_atomic_load(&state[j], RLX_AGENT) : kLbInclusive;  // before tile 0: inclusive 0
+          const uint64_t fl = st & kLbFlags;
+          const uint64_t not_ready = __ballot(fl == 0);
+          const uint64_t incl = __ballot(fl == kLbInclusive);
+          uint64_t take = 0;  // lanes whose count is added
+          bool done = false, step = false;
+          if (incl != 0) {
+            const int pl = __ffsll((unsigned long long)incl) - 1;  // nearest tile with an inclusive prefix
+            const uint64_t upto = pl == 63 ? ~0ull : ((1ull << (pl + 1)) - 1ull);
+            if ((not_ready & upto) == 0) {
+              take = upto;
+              done = true;
+            }
+          } else if (not_ready == 0) {  // 64 counts, no prefix yet: add them all, look 64 tiles further back
+            take = ~0ull;
+            step = true;
+          }
+          if (done || step) {
+            uint64_t v = ((take >> lane) & 1ull) ? (st & ~kLbFlags) : 0ull;
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) v += shfl_xor_u64(v, m);
+            base += v;
+            if (done) break;
+            hi -= 64;
+            continue;
+          }
+          if (++spins > (1u << 22)) {  // cannot happen (see above); never hang the device
+            err |= 8u;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(2);
+        }
+      }
+      if (lane == 0) {
+        __hip_atomic_store(&state[tile], kLbInclusive | (base + (uint64_t)A), RLX_AGENT);
+        tile_offsets[tile] = base;
+        s_base = base;
+        if (tile == n_tiles - 1) {
+          tile_offsets[n_tiles] = base + (uint64_t)A;
+          sync[1] = base + (uint64_t)A;  // kept rows of the batch
+        }
+      }
+    }
+    __syncthreads();
+    if (O.n > 0) {
+      uint64_t my_base = s_base;
+#pragma unroll
+      for (int k = 0; k < NW; ++k)
+        if (k < wave) my_base += wc[k];
+#pragma unroll
+      for (int o = 0; o < kFusedOutCols; ++o) {
+        if (o < O.n) {
+          const uint64_t* src = stage + (size_t)(o * NW + wave) * kWaveRows;
+          const uint8_t t = O.dtype[o];
+          if (t == T_F64 || t == T_I64 || t == T_U64) {
+            uint64_t* dst = (uint64_t*)O.out[o] + my_base;
+            for (uint32_t j = (uint32_t)lane; j < cnt; j += 64) dst[j] = src[j];
+          } else {
+            for (uint32_t j = (uint32_t)lane; j < cnt; j += 64) store_typed(t, O.out[o], (int64_t)(my_base + j), src[j]);
+          }
+        }
+      }
+    }
+    // (the next tile's first barrier separates these reads of s_base / stage from their next writes)
+  }
+  if (err) atomicOr(&ctrl[CTRL_ERROR], err);
+}
+
+// ---------------------------------------------------------------------------------------------
 // exclusive scans (tile counts -> offsets; string lengths -> offsets)
 // ---------------------------------------------------------------------------------------------
 constexpr int kScanChunk = 4096;  // elements per block (256 threads x 16)
@@ -454,6 +621,8 @@ __global__ __launch_bounds__(kBlock) void k_synth(int kind, int column_id, doubl
                                                   int64_t row_begin, int64_t n, void* __restrict__ out) {
   int zipf_bits = 0;
   const uint64_t G = (uint64_t)(int64_t)p0;
+  const int exact_shift = 64 - (p0 > 0.0 ? (int)p0 : 20);
+  const double exact_scale = __longlong_as_double((long long)(1023 - (p1 > 0.0 ? (int)p1 : 10)) << 52);  // 2^-S
   if (kind == 3) {
     while ((1ull << zipf_bits) < G && zipf_bits < 62) ++zipf_bits;
   }
@@ -463,8 +632,8 @@ __global__ __launch_bounds__(kBlock) void k_synth(int kind, int column_id, doubl
       const double u = (double)(r >> 11) * 0x1.0p-53;
       const double t = p1 * u;
       ((double*)out)[i] = p0 + t;
-    } else if (kind == 1) {
-      ((double*)out)[i] = (double)(r >> 44) * 0x1.0p-10;
+    } else if (kind == 1) {  // m * 2^-S, m below 2^B (B = p0 or 20, S = p1 or 10): exact products / sums within the bit budget
+      ((double*)out)[i] = (double)(r >> exact_shift) * exact_scale;
     } else if (kind == 2) {
       ((int64_t*)out)[i] = (int64_t)__umul64hi(r, G);
     } else {
@@ -604,6 +773,47 @@ hipError_t launch_predicate_mask(const DevProgram& P, const DevFastPlan& fast, c
   else { if (use_fast) DFX_MASK(DFX_ARG(FastPolicy<8, 2>)); else DFX_MASK(DFX_ARG(InterpPolicy<8, 2>)); }
 #undef DFX_MASK
   return hipGetLastError();
+}
+
+size_t filter_fused_sync_words(int64_t n) { return 2 + (size_t)((n + kTileRows - 1) / kTileRows); }
+
+template <typename POL>
+static hipError_t filter_fused_launch(const DevProgram& P, const DevFastPlan& fast, const DevColumns& C, uint8_t pred, int64_t n,
+                                      uint64_t* mask_words, uint64_t* tile_offsets, uint64_t* sync, const DevFusedOut& O,
+                                      uint32_t* ctrl, hipStream_t s) {
+  const size_t lds = (size_t)O.n * kTileRows * sizeof(uint64_t);
+  // the grid must be co-resident (the look-back waits for other workgroups): workgroups per CU from the occupancy API,
+  // asked once per (policy, LDS size)
+  static int per_cu[kFusedOutCols + 1] = {0, 0, 0};
+  if (per_cu[O.n] == 0) {
+    int nb = 0;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_filter_fused<POL>, kBlock, lds);
+    if (e != hipSuccess) return e;
+    per_cu[O.n] = nb > 0 ? nb : 1;
+  }
+  const int64_t tiles = (n + kTileRows - 1) / kTileRows;
+  const int64_t cap = (int64_t)device_cu_count() * per_cu[O.n];
+  const int grid = (int)(tiles < cap ? tiles : cap);
+  hipLaunchKernelGGL((k_filter_fused<POL>), dim3(grid), dim3(kBlock), lds, s, P, fast, C, pred, n, mask_words, tile_offsets, sync, O, ctrl);
+  return hipGetLastError();
+}
+
+hipError_t launch_filter_fused(const DevProgram& P, const DevFastPlan& fast, const DevColumns& C, uint8_t pred, int64_t n,
+                               uint64_t* mask_words, uint64_t* tile_offsets, uint64_t* sync, const DevFusedOut& O,
+                               uint32_t* ctrl, double algo_bytes, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  if (O.n < 0 || O.n > kFusedOutCols) return hipErrorInvalidValue;
+  Scope sc(KID_PREDICATE_MASK, s, algo_bytes);
+#define DFX_FUSED(POL) return filter_fused_launch<POL>(P, fast, C, pred, n, mask_words, tile_offsets, sync, O, ctrl, s)
+  {
+    const uint8_t none[kMaxAggs] = {0};
+    if (sig_matches<SigPred2F64>(P, fast, 0, 0, none, none)) DFX_FUSED(DFX_ARG(StaticPolicy<2, 8, SigPred2F64>));
+  }
+  const bool use_fast = fast.valid && !P.has_nulls;
+  if (P.n_cols <= 2) { if (use_fast) DFX_FUSED(DFX_ARG(FastPolicy<2, 8>)); else DFX_FUSED(DFX_ARG(InterpPolicy<2, 8>)); }
+  else if (P.n_cols <= 4) { if (use_fast) DFX_FUSED(DFX_ARG(FastPolicy<4, 4>)); else DFX_FUSED(DFX_ARG(InterpPolicy<4, 4>)); }
+  else { if (use_fast) DFX_FUSED(DFX_ARG(FastPolicy<8, 2>)); else DFX_FUSED(DFX_ARG(InterpPolicy<8, 2>)); }
+#undef DFX_FUSED
 }
 
 // mask &= other, per-tile counts of the result: a predicate too large for one fused program is evaluated as several

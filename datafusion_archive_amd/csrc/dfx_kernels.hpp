@@ -51,6 +51,15 @@ hipError_t launch_predicate_mask(const DevProgram& P, const DevFastPlan& fast, c
                                  int64_t n, uint64_t* mask_words, uint32_t* tile_counts, uint32_t* ctrl,
                                  double algo_bytes, hipStream_t s);
 
+// K1 + K4 in ONE pass (single-pass FilterRelation, filter.rs:46-110): evaluates the predicate, writes the Arrow bitmap
+// words, the per-tile exclusive offsets (decoupled look-back over the tiles' kept counts: what launch_scan_u32 of the tile
+// counts would give, tile_offsets[n_tiles] = kept rows) and compacts up to kFusedOutCols of the predicate's own columns
+// from the values already in registers.  sync: filter_fused_sync_words(n) words, zeroed before the launch; sync[1] = kept.
+size_t filter_fused_sync_words(int64_t n);
+hipError_t launch_filter_fused(const DevProgram& P, const DevFastPlan& fast, const DevColumns& C, uint8_t pred, int64_t n,
+                               uint64_t* mask_words, uint64_t* tile_offsets, uint64_t* sync, const DevFusedOut& O,
+                               uint32_t* ctrl, double algo_bytes, hipStream_t s);
+
 // exclusive scan of uint32 counts into uint64 offsets (out[n] = total); tmp: >= (n/4096 + 2) u64
 hipError_t launch_scan_u32(const uint32_t* in, uint64_t* out, int64_t n, uint64_t* tmp, hipStream_t s);
 // exclusive scan of int32 lengths into int32 offsets (out[n] = total); tmp as above

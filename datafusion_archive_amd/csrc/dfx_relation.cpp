@@ -13,6 +13,7 @@ Status error_from_ctrl(uint32_t bits) {
   if (bits & 1u) return Status::Err(DFX_ARROW_ERROR, "DivideByZero");  // arrow 0.12 array_ops::divide
   if (bits & 2u) return Status::Err(DFX_INTERNAL_ERROR, "attempt to divide with overflow");
   if (bits & 4u) return Status::Err(DFX_INTERNAL_ERROR, "partitioned aggregation: LDS ring stalled");
+  if (bits & 8u) return Status::Err(DFX_INTERNAL_ERROR, "single-pass filter: look-back stalled");
   return Status::OK();
 }
 
@@ -575,32 +576,74 @@ Status FilterRelation::next(DeviceBatch* out, bool* has) {
   for (int ci : builder_->columns()) in_bytes += (double)n * (in.columns[ci].dtype == DFX_BOOLEAN ? 0.125 : dtype_width(in.columns[ci].dtype));
   DevFastPlan fp = fast_;
   if (!agg_options().fast) fp.valid = 0;
-  DFX_HIP(launch_predicate_mask(prog, fp, cols, pred_operand_, n, (uint64_t*)mask.get(), (uint32_t*)counts.get(),
-                                (uint32_t*)ctrl_.get(), in_bytes, s));
-  if (!more_.empty()) {  // the other conjuncts: their masks are ANDed into the first, the tile counts redone
-    auto mask2 = device_alloc(sizeof(uint64_t) * (size_t)n_words, &st);
-    if (!mask2) return st;
-    for (const Part& p : more_) {
-      DevProgram prog2;
-      DevColumns cols2;
-      DFX_RETURN_IF_ERROR(p.builder->bind(in, &prog2, &cols2));
-      double bytes2 = (double)n / 8.0;
-      for (int ci : p.builder->columns()) bytes2 += (double)n * (in.columns[ci].dtype == DFX_BOOLEAN ? 0.125 : dtype_width(in.columns[ci].dtype));
-      DevFastPlan fp2 = p.fast;
-      if (!agg_options().fast) fp2.valid = 0;
-      DFX_HIP(launch_predicate_mask(prog2, fp2, cols2, p.operand, n, (uint64_t*)mask2.get(), nullptr, (uint32_t*)ctrl_.get(), bytes2, s));
-      DFX_HIP(launch_mask_and_count((uint64_t*)mask.get(), (const uint64_t*)mask2.get(), (uint32_t*)counts.get(), n, s));
-    }
-  }
-  DFX_HIP(launch_scan_u32((const uint32_t*)counts.get(), (uint64_t*)offsets.get(), n_tiles, (uint64_t*)tmp.get(), s));
   uint64_t kept = 0;
   uint32_t errbits = 0;
-  DFX_HIP(hipMemcpyAsync(&kept, (uint64_t*)offsets.get() + n_tiles, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+  // columns the fused kernel compacts itself (index into in.columns -> its output buffer)
+  std::vector<std::shared_ptr<void>> fused_vals(in.columns.size());
+  bool any_boolean = false;
+  for (size_t c = 0; c < in.columns.size(); ++c) any_boolean = any_boolean || in.columns[c].dtype == DFX_BOOLEAN;
+  if (more_.empty() && agg_options().filter_single_pass) {
+    // SINGLE PASS: predicate, bitmap, tile offsets (decoupled look-back) and the compaction of up to kFusedOutCols of
+    // the predicate's own columns in one kernel -- such a column is read from HBM once (filter.rs:46-110)
+    DevFusedOut O;
+    memset(&O, 0, sizeof(O));
+    double out_bytes = 0;
+    const std::vector<int>& pcols = builder_->columns();
+    for (size_t slot = 0; slot < pcols.size() && O.n < kFusedOutCols && !any_boolean; ++slot) {
+      const int ci = pcols[slot];
+      if (ci < 0 || ci >= (int)in.columns.size()) continue;
+      const DeviceColumn& ic = in.columns[ci];
+      if (ic.absent || ic.dtype == DFX_UTF8 || ic.dtype == DFX_BOOLEAN) continue;
+      if ((size_t)ci < out_needed_.size() && !out_needed_[ci]) continue;  // projection push-down: nobody reads it
+      if (fused_vals[ci]) continue;
+      const int w = dtype_width(ic.dtype);
+      auto vals = device_alloc((size_t)n * w, &st);  // worst case: every row kept (the count is known when the kernel ends)
+      if (!vals) return st;
+      fused_vals[ci] = vals;
+      O.slot[O.n] = (uint8_t)slot;
+      O.dtype[O.n] = (uint8_t)ic.dtype;
+      O.out[O.n] = vals.get();
+      ++O.n;
+      out_bytes += (double)n * w;  // (upper bound; the profiler's byte count is corrected by the selectivity in bench.py)
+    }
+    (void)out_bytes;
+    const size_t sync_words = filter_fused_sync_words(n);
+    auto sync = device_alloc(sizeof(uint64_t) * sync_words, &st);
+    if (!sync) return st;
+    DFX_HIP(hipMemsetAsync(sync.get(), 0, sizeof(uint64_t) * sync_words, s));
+    DFX_HIP(launch_filter_fused(prog, fp, cols, pred_operand_, n, (uint64_t*)mask.get(), (uint64_t*)offsets.get(), (uint64_t*)sync.get(), O,
+                                (uint32_t*)ctrl_.get(), in_bytes, s));
+    DFX_HIP(hipMemcpyAsync(&kept, (uint64_t*)sync.get() + 1, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+  } else {
+    DFX_HIP(launch_predicate_mask(prog, fp, cols, pred_operand_, n, (uint64_t*)mask.get(), (uint32_t*)counts.get(),
+                                  (uint32_t*)ctrl_.get(), in_bytes, s));
+    if (!more_.empty()) {  // the other conjuncts: their masks are ANDed into the first, the tile counts redone
+      auto mask2 = device_alloc(sizeof(uint64_t) * (size_t)n_words, &st);
+      if (!mask2) return st;
+      for (const Part& p : more_) {
+        DevProgram prog2;
+        DevColumns cols2;
+        DFX_RETURN_IF_ERROR(p.builder->bind(in, &prog2, &cols2));
+        double bytes2 = (double)n / 8.0;
+        for (int ci : p.builder->columns()) bytes2 += (double)n * (in.columns[ci].dtype == DFX_BOOLEAN ? 0.125 : dtype_width(in.columns[ci].dtype));
+        DevFastPlan fp2 = p.fast;
+        if (!agg_options().fast) fp2.valid = 0;
+        DFX_HIP(launch_predicate_mask(prog2, fp2, cols2, p.operand, n, (uint64_t*)mask2.get(), nullptr, (uint32_t*)ctrl_.get(), bytes2, s));
+        DFX_HIP(launch_mask_and_count((uint64_t*)mask.get(), (const uint64_t*)mask2.get(), (uint32_t*)counts.get(), n, s));
+      }
+    }
+    DFX_HIP(launch_scan_u32((const uint32_t*)counts.get(), (uint64_t*)offsets.get(), n_tiles, (uint64_t*)tmp.get(), s));
+    DFX_HIP(hipMemcpyAsync(&kept, (uint64_t*)offsets.get() + n_tiles, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+  }
   DFX_HIP(hipMemcpyAsync(&errbits, (uint32_t*)ctrl_.get() + CTRL_ERROR, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
   DFX_HIP(hipStreamSynchronize(s));
   if (errbits) {
     DFX_HIP(hipMemsetAsync(ctrl_.get(), 0, sizeof(uint32_t) * CTRL_WORDS, s));
     return error_from_ctrl(errbits);
+  }
+  if (keep_mask_) {
+    last_mask_ = mask;
+    last_mask_rows_ = n;
   }
   const int64_t m = (int64_t)kept;
   for (size_t c = 0; c < in.columns.size(); ++c)  // fn filter errs for the batch whatever is projected later
@@ -645,6 +688,9 @@ Status FilterRelation::next(DeviceBatch* out, bool* has) {
       oc.owners = {offs, bytes};
     } else if (ic.dtype == DFX_BOOLEAN) {
       return Status::Err(DFX_EXECUTION_ERROR, "filter not supported for Boolean");  // filter.rs:105-108
+    } else if (fused_vals[c]) {  // compacted by the kernel that evaluated the predicate
+      oc.values = fused_vals[c].get();
+      oc.owners = {fused_vals[c]};
     } else {  // deviation D2: every fixed-width type, not just Float64
       const int w = dtype_width(ic.dtype);
       auto vals = device_alloc((size_t)(m > 0 ? m : 1) * w, &st);
@@ -871,6 +917,27 @@ int32_t dfx_relation_drain_device(struct ArrowArrayStream* stream, int64_t* rows
     if (e != hipSuccess) return to_c(Status::Err(DFX_EXECUTION_ERROR, strfmt("HIP error %s", hipGetErrorString(e))), err, errlen);
     if (rows) *rows = nr;
     if (batches) *batches = nb;
+    return DFX_OK;
+  });
+}
+
+// Test hook: the Arrow bitmap FilterRelation computed for its most recent input batch (the BooleanArray of the reference's
+// predicate closure, filter.rs:53).  out == NULL switches the keeping on (call before next()); else (rows + 7) / 8 bytes
+// are copied to `out`.
+int32_t dfx_filter_debug_mask(struct ArrowArrayStream* stream, uint8_t* out, int64_t out_bytes, int64_t* rows, char* err, size_t errlen) {
+  return c_abi_guard(err, errlen, [&]() -> int32_t {
+    Relation* r = peek_exported(stream);
+    if (!r || r->kind() != REL_FILTER) return to_c(Status::Err(DFX_GENERAL, "not a FilterRelation of this library"), err, errlen);
+    FilterRelation* f = static_cast<FilterRelation*>(r);
+    if (!out) {
+      f->keep_mask(true);
+      return DFX_OK;
+    }
+    const int64_t n = f->last_mask_rows();
+    if (!f->last_mask() || out_bytes < (n + 7) / 8) return to_c(Status::Err(DFX_GENERAL, "no bitmap kept, or the buffer is too small"), err, errlen);
+    hipError_t e = hipMemcpy(out, f->last_mask().get(), (size_t)((n + 7) / 8), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return to_c(Status::Err(DFX_EXECUTION_ERROR, strfmt("HIP error %s", hipGetErrorString(e))), err, errlen);
+    if (rows) *rows = n;
     return DFX_OK;
   });
 }

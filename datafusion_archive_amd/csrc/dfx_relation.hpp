@@ -58,6 +58,10 @@ class FilterRelation : public Relation {
   const dfx_runtime_expr& predicate() const { return expr_; }
   Relation* input() { return input_.get(); }
   bool single_program() const { return more_.empty(); }  // false: the predicate is evaluated as several conjuncts
+  // test hook (dfx_filter_debug_mask): keep the bitmap of the most recent input batch
+  void keep_mask(bool on) { keep_mask_ = on; }
+  const std::shared_ptr<void>& last_mask() const { return last_mask_; }
+  int64_t last_mask_rows() const { return last_mask_rows_; }
 
  private:
   std::unique_ptr<Relation> input_;
@@ -69,6 +73,9 @@ class FilterRelation : public Relation {
   Status deferred_;  // evaluation-time type errors of the reference surface on next()
   std::shared_ptr<void> ctrl_;
   std::vector<char> out_needed_;  // empty: every column is compacted
+  bool keep_mask_ = false;
+  std::shared_ptr<void> last_mask_;
+  int64_t last_mask_rows_ = 0;
   // A conjunction that exceeds the limits of ONE fused program (kMaxCols columns, kMaxRegs computed values, kMaxImm
   // literals -- the reference has none, expression.rs:171-243 builds closures of any size): its top-level AND chain is
   // packed greedily into several programs; builder_ / pred_operand_ / fast_ are the first, these the others, and the
@@ -142,6 +149,8 @@ struct AggOptions {
   int calibration_memo = 1;    // 1: a resident table remembers the outcome of an aggregate's calibration slice per program shape
   int pass2_stream = 1;        // pass 2 of one-aggregate queries: region-streaming kernel (0: the flattened-index kernel)
   int fewgroup = 1;            // <= 8 groups after calibration: register accumulators (dfx_k_fewgroup.hip); 0: LDS front cache
+  int filter_single_pass = 1;  // FilterRelation: predicate + bitmap + tile offsets (decoupled look-back) + compaction of the predicate's own
+                               // columns in ONE kernel (0: k_predicate_mask -> scan -> k_compact, the column is read twice)
   int replay_in_place = 1;     // 1: rows spilled by a table that is NOT full (region overflow of a heavy key) are replayed into the
                                // table as it is, and only what it cannot take makes it grow (0: every spill quadruples the table)
 };

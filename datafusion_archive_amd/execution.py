@@ -217,6 +217,22 @@ class FilterRelation(Relation):
         self._keep = [input, expr]
 
 
+    # test hook (include/dfx.h: dfx_filter_debug_mask)
+    def keep_mask(self) -> None:
+        err = _errbuf()
+        _check(_ffi.lib().dfx_filter_debug_mask(ctypes.byref(self._live_stream()), None, 0, None, err, 1024), err)
+
+    def last_mask(self, rows: int):
+        """The LSB-first bitmap of the most recent input batch (numpy uint8, (rows + 7) // 8 bytes) and its row count."""
+        import numpy as np
+        buf = np.zeros((rows + 7) // 8, dtype=np.uint8)
+        got = ctypes.c_int64()
+        err = _errbuf()
+        _check(_ffi.lib().dfx_filter_debug_mask(ctypes.byref(self._live_stream()), buf.ctypes.data_as(ctypes.c_void_p), buf.nbytes,
+                                                ctypes.byref(got), err, 1024), err)
+        return buf[:(got.value + 7) // 8], got.value
+
+
 class ProjectRelation(Relation):
     """projection::ProjectRelation::new(input, expr, schema) (projection.rs:36)."""
 

@@ -245,7 +245,7 @@ int32_t dfx_table_from_stream(struct ArrowArrayStream* input, dfx_table** out, c
  * oracle reproduces any slice -- SURVEY.md section 8(d)). */
 typedef enum dfx_synth_kind {
   DFX_SYNTH_F64_UNIFORM = 0, /* p0 + p1 * u,  u in [0,1) 53-bit          (dtype Float64) */
-  DFX_SYNTH_F64_EXACT = 1,   /* m * 2^-10, m uniform integer in [0,2^20)  (dtype Float64) */
+  DFX_SYNTH_F64_EXACT = 1,   /* m * 2^-S, m uniform integer in [0,2^B): B = p0 (0: 20), S = p1 (0: 10)  (dtype Float64) */
   DFX_SYNTH_I64_UNIFORM = 2, /* uniform integer in [0, (int64)p0)          (dtype Int64)   */
   DFX_SYNTH_I64_ZIPF = 3     /* floor(p0 ^ u) - 1 clipped to [0,p0): log-uniform skew (dtype Int64) */
 } dfx_synth_kind;
@@ -352,6 +352,10 @@ uint32_t dfx_debug_unhash32(uint32_t image);
 /* Pulls every batch of a library stream and drops it on the device: no host RecordBatch, no D2H copy (what a stacked
  * operator would see).  rows / batches (may be NULL): what came out. */
 int32_t dfx_relation_drain_device(struct ArrowArrayStream* stream, int64_t* rows, int64_t* batches, char* err, size_t errlen);
+/* Test hook: the Arrow bitmap (LSB first) a FilterRelation computed for its most recent input batch -- the BooleanArray of
+ * the reference's predicate closure (filter.rs:53-66), which the operator itself never hands out.  out == NULL: start
+ * keeping it (call before next()); else copies (rows + 7) / 8 bytes to `out` (host memory). */
+int32_t dfx_filter_debug_mask(struct ArrowArrayStream* filter_stream, uint8_t* out, int64_t out_bytes, int64_t* rows, char* err, size_t errlen);
 /* When enabled every tracked kernel launch is bracketed by HIP events on its launch stream. */
 int32_t dfx_profile_enable(int32_t on);
 int32_t dfx_profile_reset(void);

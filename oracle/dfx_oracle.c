@@ -985,7 +985,13 @@ int32_t orc_synth_fill(int32_t kind, int32_t column_id, double p0, double p1, ui
         ((double*)out)[i] = p0 + t;
         break;
       }
-      case DFX_SYNTH_F64_EXACT: ((double*)out)[i] = (double)(r >> 44) * 0x1.0p-10; break;
+      case DFX_SYNTH_F64_EXACT: {
+        /* m * 2^-S, m uniform integer in [0, 2^B): B = p0 (0: 20 bits), S = p1 (0: 10).  Every value, product of a
+         * few values and partial sum stays exactly representable when the bit budget allows -- order-independent sums */
+        const int B = p0 > 0.0 ? (int)p0 : 20, S = p1 > 0.0 ? (int)p1 : 10;
+        ((double*)out)[i] = ldexp((double)(r >> (64 - B)), -S);
+        break;
+      }
       case DFX_SYNTH_I64_UNIFORM: ((int64_t*)out)[i] = (int64_t)mulhi64(r, (uint64_t)(int64_t)p0); break;
       case DFX_SYNTH_I64_ZIPF: {
         /* log-uniform skew: k = floor(2^(u * log2(G))) - 1, computed in integers:
@@ -1078,6 +1084,67 @@ int32_t orc_run_synth_query(const dfx_synth_column* cols, int32_t n_cols, uint64
   for (int c = 0; c < n_cols; ++c) orc_array_free(b.columns[c]);
   free(b.columns);
   orc_agg_free(agg);
+  if (seconds) *seconds = t;
+  if (rows_out) *rows_out = kept;
+  return st;
+}
+
+/* FilterRelation (filter.rs:46-110) reference-shaped over synthetic columns: batch_rows-row batches (0: 1024), predicate
+ * closure tree -> BooleanArray, fn filter per column; the compacted batches are concatenated into the caller's buffers.
+ *   out_values[c]: room for n_rows 8-byte elements per column (every synthetic column is Int64 / Float64), or NULL
+ *   mask_bits:     the concatenated BooleanArray of the predicate, LSB first, (n_rows + 7) / 8 bytes (zeroed here), or NULL
+ * Test infrastructure for the parity tests at the benchmark's batch sizes (tests/test_gpu_scale.py, bench.py). */
+int32_t orc_run_synth_filter(const dfx_synth_column* cols, int32_t n_cols, uint64_t seed, int64_t row_begin,
+                             int64_t n_rows, int64_t batch_rows, const dfx_expr_node* nodes, int32_t n_nodes,
+                             int32_t filter_root, void** out_values, uint8_t* mask_bits, int64_t* rows_out,
+                             double* seconds, char* err, size_t errlen) {
+  if (batch_rows <= 0) batch_rows = 1024;
+  int32_t st = DFX_OK;
+  orc_batch b;
+  memset(&b, 0, sizeof(b));
+  b.num_columns = n_cols;
+  b.columns = (orc_array**)calloc((size_t)n_cols, sizeof(orc_array*));
+  for (int c = 0; c < n_cols; ++c) {
+    int dt = (cols[c].kind == DFX_SYNTH_I64_UNIFORM || cols[c].kind == DFX_SYNTH_I64_ZIPF) ? DFX_INT64 : DFX_FLOAT64;
+    b.columns[c] = arr_new(dt, batch_rows, 0);
+  }
+  if (mask_bits) memset(mask_bits, 0, (size_t)((n_rows + 7) / 8));
+  double t = 0.0;
+  int64_t kept = 0;
+  for (int64_t r0 = 0; r0 < n_rows && !st; r0 += batch_rows) {
+    int64_t n = n_rows - r0 < batch_rows ? n_rows - r0 : batch_rows;
+    for (int c = 0; c < n_cols; ++c) {
+      b.columns[c]->length = n;
+      orc_synth_fill(cols[c].kind, cols[c].column_id, cols[c].p0, cols[c].p1, seed, row_begin + r0, n, b.columns[c]->values);
+    }
+    b.num_rows = n;
+    double t0 = now_s();
+    if (mask_bits) {
+      orc_array* m = NULL;
+      st = eval_node(nodes, n_nodes, filter_root, &b, &m, err, errlen);
+      if (st) break;
+      if (m->dtype != DFX_BOOLEAN) {
+        orc_array_free(m);
+        st = fail(err, errlen, DFX_EXECUTION_ERROR, "Filter expression did not evaluate to boolean");
+        break;
+      }
+      const uint8_t* bits = (const uint8_t*)m->values;
+      for (int64_t i = 0; i < n; ++i)
+        if (bit_get(bits, i)) mask_bits[(r0 + i) >> 3] |= (uint8_t)(1u << ((r0 + i) & 7));
+      orc_array_free(m);
+    }
+    orc_batch* fb = NULL;
+    st = orc_filter_next(nodes, n_nodes, filter_root, &b, &fb, err, errlen);
+    t += now_s() - t0;
+    if (st) break;
+    if (out_values)
+      for (int c = 0; c < n_cols; ++c)
+        if (out_values[c]) memcpy((uint8_t*)out_values[c] + (size_t)kept * 8, fb->columns[c]->values, (size_t)fb->num_rows * 8);
+    kept += fb->num_rows;
+    orc_batch_free(fb);
+  }
+  for (int c = 0; c < n_cols; ++c) orc_array_free(b.columns[c]);
+  free(b.columns);
   if (seconds) *seconds = t;
   if (rows_out) *rows_out = kept;
   return st;

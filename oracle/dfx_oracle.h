@@ -86,6 +86,14 @@ int32_t orc_run_synth_query(const dfx_synth_column* cols, int32_t n_cols, uint64
                             int32_t n_aggr, int32_t mask_only, double* seconds, orc_batch** out,
                             int64_t* rows_out, char* err, size_t errlen);
 
+/* FilterRelation reference-shaped over synthetic columns: the compacted batches concatenated into out_values[c] (room for
+ * n_rows 8-byte elements each; entries / the array may be NULL) and the predicate's BooleanArray concatenated into
+ * mask_bits (LSB first, (n_rows + 7) / 8 bytes; may be NULL). */
+int32_t orc_run_synth_filter(const dfx_synth_column* cols, int32_t n_cols, uint64_t seed, int64_t row_begin,
+                             int64_t n_rows, int64_t batch_rows, const dfx_expr_node* nodes, int32_t n_nodes,
+                             int32_t filter_root, void** out_values, uint8_t* mask_bits, int64_t* rows_out,
+                             double* seconds, char* err, size_t errlen);
+
 /* CsvDataSource::new(filename, schema, batch_size) + next() (datasource.rs:33-58): arrow 0.12 csv::Reader with
  * has_headers = true over the csv crate's defaults.  *out == NULL at end of input (Ok(None)). */
 typedef struct orc_csv orc_csv;

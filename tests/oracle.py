@@ -305,6 +305,37 @@ def run_synth_query(cols: Sequence[tuple], seed: int, row_begin: int, n_rows: in
     return secs.value, kept.value, res
 
 
+def run_synth_filter(cols: Sequence[tuple], seed: int, row_begin: int, n_rows: int, batch_rows: int, filter_expr: Expr,
+                     want_columns: Sequence[int] = (0,), want_mask: bool = True):
+    """FilterRelation reference-shaped (batch_rows-row batches through orc_filter_next) over generated batches.
+    Returns (seconds, kept, {column index: compacted values as numpy}, mask bits as numpy uint8 or None)."""
+    s = serialize([filter_expr])
+    names = [c[0].encode() for c in cols]
+    carr = (SynthColumn * len(cols))()
+    for i, (_, k, cid, p0, p1) in enumerate(cols):
+        carr[i].name = names[i]
+        carr[i].kind, carr[i].column_id, carr[i].p0, carr[i].p1 = k, cid, p0, p1
+    outs = {}
+    ptrs = (ctypes.c_void_p * len(cols))()
+    for c in want_columns:
+        k = cols[c][1]
+        outs[c] = np.empty(n_rows, dtype=np.int64 if k in (SYNTH_I64_UNIFORM, SYNTH_I64_ZIPF) else np.float64)
+        ptrs[c] = outs[c].ctypes.data
+    mask = np.empty((n_rows + 7) // 8, dtype=np.uint8) if want_mask else None
+    secs = ctypes.c_double()
+    kept = ctypes.c_int64()
+    err = ctypes.create_string_buffer(512)
+    L = lib()
+    L.orc_run_synth_filter.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_uint64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+                                       ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
+                                       ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_double), ctypes.c_char_p, ctypes.c_size_t]
+    code = L.orc_run_synth_filter(ctypes.cast(carr, ctypes.c_void_p), len(cols), seed, row_begin, n_rows, batch_rows,
+                                  ctypes.cast(s.nodes, ctypes.c_void_p), s.n_nodes, s.roots[0], ctypes.cast(ptrs, ctypes.c_void_p),
+                                  mask.ctypes.data if mask is not None else None, ctypes.byref(kept), ctypes.byref(secs), err, 512)
+    _check(code, err)
+    return secs.value, kept.value, {c: v[:kept.value] for c, v in outs.items()}, mask
+
+
 def read_csv(filename: str, schema: pa.Schema, batch_size: int = 1024) -> List[pa.RecordBatch]:
     """CsvDataSource::new(filename, schema, batch_size) drained (datasource.rs:33-58): every batch next() yields."""
     dts = (ctypes.c_int32 * len(schema))(*[int(_PA_TO_DT[f.type]) for f in schema])

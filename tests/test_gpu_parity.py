@@ -229,6 +229,45 @@ def test_filter_multi_batch_and_slices():
         assert_batches_identical(g, oracle.filter_next(pred, b), "sliced batch")
 
 
+@pytest.mark.parametrize("single_pass", [1, 0])
+@pytest.mark.parametrize("fast", [1, 0])
+def test_filter_single_pass_and_two_pass_agree_with_the_oracle(single_pass, fast):
+    """filter.single_pass = 1 (default): predicate, bitmap, decoupled look-back over the tiles' kept counts and the
+    compaction of the predicate's own columns in ONE kernel; = 0: k_predicate_mask -> scan -> k_compact.  Both against
+    fn filter (filter.rs:79-110): predicates over 1, 2 and 3 columns of different widths (at most two are compacted in the
+    kernel, the others and the Utf8 passenger by k_compact from the same bitmap), nulls, selectivities from nothing to
+    everything, 300 tiles so that the look-back walks several windows."""
+    ex.set_option("filter.single_pass", single_pass)
+    ex.set_option("scan.fast", fast)
+    rng = np.random.default_rng(4242)
+    n = 300 * 4096 + 1234
+    lat = 49.0 + 10.0 * rng.random(n)
+    k = rng.integers(-5, 5, n, dtype=np.int64)
+    i32 = rng.integers(-2**31, 2**31 - 1, n, dtype=np.int32)
+    f32 = rng.standard_normal(n).astype(np.float32)
+    u8 = rng.integers(0, 255, n, dtype=np.uint8)
+    city = pa.array([("c%d" % (i % 97)) * (i % 3) for i in range(n)])
+    for with_nulls in (False, True):
+        arrays = [pa.array(lat), pa.array(k), pa.array(i32), pa.array(f32), pa.array(u8)]
+        if with_nulls:
+            arrays = [pa.array(a.to_numpy(zero_copy_only=False), mask=rng.random(n) < 0.1) for a in arrays]
+        b = pa.RecordBatch.from_arrays(arrays + [city], names=["lat", "k", "i32", "f32", "u8", "city"])
+        preds = [
+            BinaryExpr(BinaryExpr(Column(0), Operator.Gt, lit(51.0)), Operator.And, BinaryExpr(Column(0), Operator.Lt, lit(53.0))),
+            BinaryExpr(Column(0), Operator.Gt, lit(0.0)),    # everything
+            BinaryExpr(Column(0), Operator.Lt, lit(0.0)),    # nothing
+            BinaryExpr(BinaryExpr(Column(2), Operator.Gt, Literal(ScalarValue.Int32(0))), Operator.And,
+                       BinaryExpr(Column(4), Operator.Lt, Literal(ScalarValue.UInt8(200)))),  # 4- and 1-byte columns in the kernel
+            BinaryExpr(BinaryExpr(BinaryExpr(Column(3), Operator.Gt, Literal(ScalarValue.Float32(-0.5))), Operator.And,
+                                  BinaryExpr(Column(1), Operator.GtEq, ilit(-2))), Operator.Or,
+                       BinaryExpr(Column(0), Operator.Gt, lit(58.5))),  # three predicate columns: two in the kernel, one by k_compact
+        ]
+        for pred in preds:
+            got = gpu_filter(pred, b.schema, [b, b.slice(777, 4096 * 3 + 5)])
+            assert_batches_identical(got[0], oracle.filter_next(pred, b), f"single_pass={single_pass} nulls={with_nulls} {pred!r}")
+            assert_batches_identical(got[1], oracle.filter_next(pred, b.slice(777, 4096 * 3 + 5)), "sliced")
+
+
 def _wide_conjunction(n_cols, rng, nulls):
     """A batch of n_cols numeric columns and `c0 > a0 AND c0 < b0 AND c1 > a1 AND ...` over all of them."""
     n = 50021

@@ -64,6 +64,31 @@ QUERIES = {
     "zipf_filtered": (SYN_ZIPF, PRED, [SUM_V, COUNT_V]),
     "zipf_all": (SYN_ZIPF, None, [SUM_V, COUNT_V]),
 }
+# ---- BASELINE config 2 as written and config 5 (TPC-H Q1 shape) at the benchmark's batch sizes ----------------------
+N2 = 1 << 28                 # config 2: one Float64 column, lat = 49 + 10 u, seed 0xDF01, 2^27-row batches
+BATCH2 = 1 << 27
+SEED2 = 0xDF01
+SYN_LAT = [("lat", ex.SYNTH_F64_UNIFORM, 0, 49.0, 10.0)]
+SCHEMA2 = pa.schema([("lat", pa.float64())])
+PRED2 = BinaryExpr(BinaryExpr(Column(0), Operator.Gt, lit(51.0)), Operator.And, BinaryExpr(Column(0), Operator.Lt, lit(53.0)))
+N5 = 1 << 27                 # config 5: 7 columns (56 B/row), 2 predicates, 2 keys, 4 SUMs of expressions, 6 groups
+SEED5 = 0xDF05
+# exact-arithmetic variant: qty, price = m * 2^-2 (12 bits), disc, tax in {0, .25, .5, .75}: every product has <= 18
+# significant bits and every partial sum over 2^27 rows <= 45 -- any summation order gives the same doubles
+SYN_Q1_EXACT = [("rf", ex.SYNTH_I64_UNIFORM, 0, 3.0, 0.0), ("ls", ex.SYNTH_I64_UNIFORM, 1, 2.0, 0.0),
+                ("qty", ex.SYNTH_F64_EXACT, 2, 12.0, 2.0), ("price", ex.SYNTH_F64_EXACT, 3, 12.0, 2.0),
+                ("disc", ex.SYNTH_F64_EXACT, 4, 2.0, 2.0), ("tax", ex.SYNTH_F64_EXACT, 5, 2.0, 2.0),
+                ("ship", ex.SYNTH_F64_UNIFORM, 6, 0.0, 2526.0)]
+# bench.py's columns (uniform doubles: sums are order-dependent, checked within the stated tolerance)
+SYN_Q1_UNIFORM = SYN_Q1_EXACT[:2] + [("qty", ex.SYNTH_F64_UNIFORM, 2, 1.0, 49.0), ("price", ex.SYNTH_F64_UNIFORM, 3, 900.0, 104100.0),
+                                     ("disc", ex.SYNTH_F64_UNIFORM, 4, 0.0, 0.10), ("tax", ex.SYNTH_F64_UNIFORM, 5, 0.0, 0.08),
+                                     ("ship", ex.SYNTH_F64_UNIFORM, 6, 0.0, 2526.0)]
+SCHEMA5 = pa.schema([(c[0], pa.int64() if i < 2 else pa.float64()) for i, c in enumerate(SYN_Q1_EXACT)])
+_DP = BinaryExpr(Column(3), Operator.Multiply, BinaryExpr(lit(1.0), Operator.Minus, Column(4)))
+AGGS5 = [AggregateFunction("sum", [Column(2)], F64), AggregateFunction("sum", [Column(3)], F64), AggregateFunction("sum", [_DP], F64),
+         AggregateFunction("sum", [BinaryExpr(_DP, Operator.Multiply, BinaryExpr(lit(1.0), Operator.Plus, Column(5)))], F64)]
+PRED5 = BinaryExpr(BinaryExpr(Column(6), Operator.LtEq, lit(2436.0)), Operator.And, BinaryExpr(Column(4), Operator.GtEq, lit(0.0)))
+
 _pool = None
 _futures = {}
 
@@ -72,9 +97,13 @@ def _oracle_result(name):
     """(seconds, rows kept, result batch) of the oracle for QUERIES[name]; every query is started on first use."""
     global _pool
     if _pool is None:
-        _pool = ThreadPoolExecutor(len(QUERIES))
+        _pool = ThreadPoolExecutor(len(QUERIES) + 3)
         for q, (syn, pred, aggs) in QUERIES.items():
             _futures[q] = _pool.submit(oracle.run_synth_query, syn, SEED, 0, N, 1024, pred, [Column(0)], aggs)
+        # config 2: FilterRelation reference-shaped, 1024-row batches, compacted column + the predicate's BooleanArray
+        _futures["cfg2_filter"] = _pool.submit(oracle.run_synth_filter, SYN_LAT, SEED2, 0, N2, 1024, PRED2)
+        for q, syn in (("q1_exact", SYN_Q1_EXACT), ("q1_uniform", SYN_Q1_UNIFORM)):  # + COUNT: rows per group for the tolerance
+            _futures[q] = _pool.submit(oracle.run_synth_query, syn, SEED5, 0, N5, 1024, PRED5, [Column(0), Column(1)], AGGS5 + [COUNT_V])
     return _futures[name].result()
 
 
@@ -146,3 +175,75 @@ def test_zipf_keys_per_group_vs_oracle_at_2_28_rows():
     for name in ("zipf_filtered", "zipf_all"):
         got = _gpu(name)
         _assert_bit_exact(got, _oracle_result(name)[2], name + " 2^28")
+
+
+@pytest.mark.parametrize("fast", [1, 0])
+def test_config2_filter_as_written_mask_and_compaction_at_2_27_row_batches(fast):
+    """BASELINE config 2 as written: FilterRelation (filter.rs:46-110) over lat = 49 + 10 u, WHERE lat > 51 AND lat < 53,
+    2^28 rows in 2^27-row batches.  The bitmap of every batch and the compacted column are compared with the oracle's
+    (orc_filter_next over 1024-row batches) bit for bit; scan.fast = 1 is the static signature, 0 the SSA interpreter."""
+    ex.set_option("scan.fast", fast)
+    secs, kept, want_cols, want_mask = _oracle_result("cfg2_filter")
+    want = want_cols[0]
+    t = ex.DeviceTable.synth(SYN_LAT, SEED2, 0, N2)
+    rel = ex.FilterRelation(t.scan(BATCH2), ex.compile_scalar_expr(None, PRED2, SCHEMA2), SCHEMA2)
+    rel.keep_mask()
+    at = 0
+    row0 = 0
+    while True:
+        b = rel.next()
+        if b is None:
+            break
+        bits, rows = rel.last_mask(BATCH2)
+        assert rows == min(BATCH2, N2 - row0)
+        assert row0 % 8 == 0 and np.array_equal(bits, want_mask[row0 // 8:(row0 + rows + 7) // 8]), f"bitmap of the batch at row {row0} differs"
+        got = b.column(0).to_numpy()
+        assert b.column(0).null_count == 0
+        assert np.array_equal(got.view(np.uint64), want[at:at + len(got)].view(np.uint64)), f"compacted rows of the batch at row {row0} differ"
+        assert len(got) == int(np.unpackbits(bits, bitorder="little")[:rows].sum())
+        at += len(got)
+        row0 += rows
+    assert row0 == N2 and at == kept and abs(kept / N2 - 0.2) < 1e-3
+
+
+def _q1_gpu(syn, batch):
+    t = ex.DeviceTable.synth(syn, SEED5, 0, N5)
+    return gpu_aggregate([Column(0), Column(1)], AGGS5, SCHEMA5, [], filter_expr=PRED5, source=t.scan(batch))
+
+
+def _q1_sorted(batch, n_aggr):
+    key = batch.column(0).to_numpy() * 2 + batch.column(1).to_numpy()
+    order = np.argsort(key, kind="stable")
+    return key[order], [batch.column(2 + i).to_numpy()[order] for i in range(n_aggr)]
+
+
+def test_config5_q1_shape_exact_variant_bit_for_bit():
+    """BASELINE config 5's shape through the synth generator, 2^27 rows in 2^26-row batches, exact-arithmetic columns: the
+    four SUMs of every group equal the oracle's bit for bit (aggregate.rs:787-952 + update_accumulators :548-612)."""
+    got = _q1_gpu(SYN_Q1_EXACT, 1 << 26)
+    _secs, kept, want = _oracle_result("q1_exact")
+    gk, gv = _q1_sorted(got, 4)
+    wk, wv = _q1_sorted(want, 5)
+    assert len(gk) == 6 and np.array_equal(gk, wk)
+    assert int(wv[4].sum()) == kept
+    for i in range(4):
+        assert np.array_equal(gv[i].view(np.uint64), wv[i].view(np.uint64)), f"Q1 exact: SUM #{i} differs: {gv[i]} vs {wv[i]}"
+
+
+def test_config5_q1_shape_uniform_variant_within_tolerance():
+    """bench.py's columns (uniform doubles), one 2^27-row batch.  A parallel sum cannot reproduce the reference's sequential
+    rounding: per group with n rows, |gpu - reference| <= n * eps * sum|v| (eps = 2^-52; every term is positive, so
+    sum|v| is the sum).  The observed distance in ULPs of the reference result is printed (pytest -s)."""
+    got = _q1_gpu(SYN_Q1_UNIFORM, 1 << 27)
+    want = _oracle_result("q1_uniform")[2]
+    gk, gv = _q1_sorted(got, 4)
+    wk, wv = _q1_sorted(want, 5)
+    assert len(gk) == 6 and np.array_equal(gk, wk)
+    n = wv[4].astype(np.float64)
+    eps = 2.0 ** -52
+    for i in range(4):
+        err = np.abs(gv[i] - wv[i])
+        tol = n * eps * wv[i]
+        ulps = err / np.spacing(wv[i])
+        print(f"\nQ1 uniform SUM #{i}: max |gpu - reference| = {ulps.max():.0f} ULP of the reference sum; groups of up to {int(n.max())} rows")
+        assert np.all(err <= tol), f"Q1 uniform: SUM #{i} outside n*eps*sum|v|: {err} vs {tol}"
