@@ -565,6 +565,12 @@ Status AggregateRelation::Impl::ensure_partition(int64_t rows, bool nulls_now) {
       PT.flags |= PTF_HOT;
     if ((PT.flags & PTF_NARROW) && !(PT.flags & PTF_HOT) && o.narrow_chunk16 && partition_ring_bytes(PT.n_words, PT.n_parts, 32, false, true) <= (size_t)158 * 1024)
       PT.flags |= PTF_CHUNK16;
+    // selective scans: the scanning and the routing belong to different waves (dfx_k_partition_ws_inl.hpp).  When most rows
+    // pass, every wave has rows to route all the time and the ring kernel's symmetric waves are the better fit
+    if ((PT.flags & PTF_CHUNK16) && o.pass1_ws > 0 && !dense_seen && !(((uint32_t)o.partition_mode) & ~15u)) {
+      PT.ws_scanners = o.pass1_ws == 8 ? 8u : o.pass1_ws == 14 ? 14u : 12u;
+      if (partition_ws_bytes(PT.n_parts, (int)PT.ws_scanners) <= (size_t)158 * 1024) PT.flags |= PTF_WS;
+    }
     PT.mode = 2u | ((uint32_t)o.partition_mode & ~15u);
     PT.block = 1024;
     PT.stage_rows = 0;

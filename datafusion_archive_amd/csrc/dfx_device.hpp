@@ -217,7 +217,7 @@ struct DevPartition {
   uint32_t mode;       // pass 1: 0 direct routing (one 16-byte store per row), 1 LDS counting sort + coalesced copy-out
   uint32_t block;      // pass-1 workgroup size (mode 1: 512 or 1024)
   uint32_t flags;      // PTF_*
-  uint32_t pad1;
+  uint32_t ws_scanners;// PTF_WS: scanner waves per pass-1 workgroup (8, 12 or 14 of 16)
   // Control-block snapshot written BY THE KERNEL (null: none): the last workgroup to finish copies T.ctrl into this
   // host-mapped pinned buffer.  The host reads it after the launch's completion event -- no copy engine, no blit kernel
   // that would have to find room next to 256 persistent 1024-lane workgroups, nothing on a side stream.
@@ -232,6 +232,8 @@ enum : uint32_t {
                           // SUM + MIN + MAX of one column ...): routed rows stay {hash image, RAW operand}; pass 2 applies every
                           // aggregate's own transform and atomic to it (n_words is 2 whatever the aggregate count)
   PTF_CHUNK16 = 16u,      // narrow rows, no hot keys: 16-row chunks (sector-aligned 192-byte runs), 32-row rings
+  PTF_WS = 64u,           // pass 1, wave-specialised flavour (dfx_k_partition_ws_inl.hpp): DevPartition::ws_scanners of the 16 waves scan,
+                          // the others route; needs PTF_NARROW | PTF_CHUNK16, no PTF_HOT / PTF_SHARED
   PTF_NARROW = 8u         // keys below 2^32 (seen by the calibration slice): 12-byte routed rows {hash image, operand}, pass 2
                           // works on 32-bit images; needs ring flavour, one key word, one aggregate
 };

@@ -94,18 +94,40 @@ __global__ __launch_bounds__(kBlock) void k_predicate_mask(const DevProgram P, c
 // The two-pass form (k_predicate_mask -> scan of the tile counts -> k_compact) reads a predicate column twice: once to
 // evaluate it, once to compact it.  Here a workgroup evaluates a 4096-row tile, parks the passing rows' values of up to
 // kFusedOutCols of the predicate's own columns in LDS (wave-private segments: position = rows the wave kept so far +
-// rank inside the ballot word), learns where its tile starts in the output from a DECOUPLED LOOK-BACK over the tiles'
-// kept counts (one 64-bit status word per tile: flag | count; a wave inspects 64 predecessors per step), and copies its
-// segments out in whole coalesced runs.  Row order is preserved (filter.rs:86-90).  The Arrow bitmap and the per-tile
-// exclusive offsets are written as well: every OTHER column of the batch is compacted by k_compact from them, reading
-// it once, too.
-// Forward progress: tiles are dealt round-robin to a grid that is co-resident (launch_filter_fused sizes it from the
-// occupancy API), every workgroup takes its tiles in increasing order and publishes a tile's count BEFORE it looks back,
-// so the smallest unpublished tile never waits for anything.  The spin is bounded all the same (error bit 8).
+// rank inside the ballot word), learns where its tile starts in the output from a LOOK-BACK over the kept counts of the
+// tiles before it, and copies its segments out in whole coalesced runs.  Row order is preserved (filter.rs:86-90).  The
+// Arrow bitmap and the per-tile exclusive offsets are written as well: every OTHER column of the batch is compacted by
+// k_compact from them, reading it once, too.
+//
+// Look-back, two levels.  Tiles are dealt round-robin to a co-resident grid (G ~ 1000 workgroups), which therefore runs
+// in lockstep: the G tiles of a round publish their counts at about the same time and every one of them needs the sum
+// of all earlier ones.  A flat decoupled look-back (64 predecessors per step) walks G/128 windows on average -- first
+// version of this kernel: ~12 us per tile against 5 us of streaming.  So: one status word per TILE {ready, count}, one per
+// GROUP of 64 consecutive tiles {aggregate | inclusive prefix}.  A tile adds up (a) the counts of the tiles before it in
+// its own group -- one 64-wide load -- and (b) the prefix before its group from the group words -- one more 64-wide load
+// that covers 4096 tiles; both loads are in flight together.  The last tile of a group publishes the group's aggregate
+// as soon as it has (a), and the group's inclusive prefix when it has (b).
+// Forward progress: every workgroup takes its tiles in increasing order, publishes a tile's count BEFORE it waits, a
+// group aggregate needs tile counts only, a group prefix needs aggregates and the nearest earlier prefix (group 0 needs
+// none): the smallest unpublished word never waits for anything unpublished.  The grid must be co-resident
+// (launch_filter_fused sizes it from the occupancy API); the spin is bounded all the same (error bit 8).
+// The column loads are software-pipelined ACROSS tiles: the first loads of a workgroup's next tile are in flight while it
+// sits in the two barriers and the look-back of the current one.
 constexpr uint64_t kLbAggregate = 1ull << 62, kLbInclusive = 2ull << 62, kLbFlags = 3ull << 62;
+constexpr int kLbGroup = 64;  // tiles per second-level word
+
+size_t filter_fused_sync_words(int64_t n) {
+  const size_t tiles = (size_t)((n + kTileRows - 1) / kTileRows);
+  return 2 + tiles + (tiles + kLbGroup - 1) / kLbGroup;
+}
 
 DEV uint32_t mbcnt_u64(uint64_t m) {
   return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+DEV uint64_t wave_sum_u64(uint64_t v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += shfl_xor_u64(v, m);
+  return v;
 }
 
 template <typename POL>
@@ -120,6 +142,8 @@ __global__ __launch_bounds__(kBlock) void k_filter_fused(const DevProgram P, con
   constexpr int BANK = (int)(sizeof(COLV) / 8);
   constexpr int NW = kBlock / 64;                 // waves per workgroup
   constexpr int kWaveRows = kTileRows / NW;       // 1024: rows (16 bitmap words) per wave and tile
+  constexpr int kWaveWords = kWaveRows / 64;
+  static_assert(kLbGroup == 64, "one lane per tile of a group");
   extern __shared__ __attribute__((aligned(16))) uint64_t stage[];  // [O.n][NW][kWaveRows] kept values
   __shared__ uint64_t s_words[kTileRows / 64];
   __shared__ uint32_t s_wave_cnt[NW];
@@ -128,17 +152,37 @@ __global__ __launch_bounds__(kBlock) void k_filter_fused(const DevProgram P, con
   const int wave = threadIdx.x >> 6;
   const int64_t n_words = (n + 63) >> 6;
   const int64_t n_tiles = (n + kTileRows - 1) / kTileRows;
-  uint64_t* const state = sync + 2;
+  uint64_t* const state = sync + 2;          // per tile
+  uint64_t* const gstate = state + n_tiles;  // per group of kLbGroup tiles
   uint32_t err = 0;
-  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+  int64_t tile = blockIdx.x;
+  COLV ncol[U];
+  uint32_t ncv[U];
+  if (tile < n_tiles) {  // the very first loads of this workgroup
+    const int64_t w0 = tile * (kTileRows / 64) + wave * kWaveWords;
+    FOR_U {
+      const int64_t row = (w0 + u) * 64 + lane;
+      POL::load(P, C, row, row < n, ncol[u], ncv[u]);
+    }
+  }
+  for (; tile < n_tiles; tile += gridDim.x) {
     uint32_t cnt = 0;  // rows this wave has kept in this tile (wave-uniform)
-    for (int i0 = 0; i0 < kWaveRows / 64; i0 += U) {
-      const int64_t w0 = tile * (kTileRows / 64) + wave * (kWaveRows / 64) + i0;
+    for (int i0 = 0; i0 < kWaveWords; i0 += U) {
+      const int64_t w0 = tile * (kTileRows / 64) + wave * kWaveWords + i0;
       COLV col[U];
       uint32_t cv[U];
       FOR_U {
-        const int64_t row = (w0 + u) * 64 + lane;
-        POL::load(P, C, row, row < n, col[u], cv[u]);
+        col[u] = ncol[u];
+        cv[u] = ncv[u];
+      }
+      {  // the next trip's loads (of this tile, or the first ones of the workgroup's next tile) before this trip is evaluated
+        const bool same = i0 + U < kWaveWords;
+        const int64_t nt = same ? tile : tile + gridDim.x;
+        const int64_t w1 = nt * (kTileRows / 64) + wave * kWaveWords + (same ? i0 + U : 0);
+        FOR_U {
+          const int64_t row = (w1 + u) * 64 + lane;
+          POL::load(P, C, row, row < n && nt < n_tiles, ncol[u], ncv[u]);
+        }
       }
 #pragma nounroll
       for (int uu = 0; uu < U; ++uu) {
@@ -152,7 +196,7 @@ __global__ __launch_bounds__(kBlock) void k_filter_fused(const DevProgram P, con
         POL::eval(P, F, cur, curv, reg, rv, inb, err);
         const bool pass = inb && POL::pass(P, F, pred, cur, curv, reg, rv);
         const uint64_t word = __ballot(pass);
-        if (lane == 0) s_words[wave * (kWaveRows / 64) + i0 + uu] = word;
+        if (lane == 0) s_words[wave * kWaveWords + i0 + uu] = word;
         if (pass) {
           const uint32_t at = cnt + mbcnt_u64(word);
 #pragma unroll
@@ -180,48 +224,60 @@ __global__ __launch_bounds__(kBlock) void k_filter_fused(const DevProgram P, con
     if (wave == 0) {
       const int64_t w = tile * (kTileRows / 64) + lane;  // the tile's 64 bitmap words: one coalesced 512-byte store
       if (w < n_words) mask_words[w] = s_words[lane];
-      uint64_t base = 0;
-      if (tile > 0) {
-        if (lane == 0) __hip_atomic_store(&state[tile], kLbAggregate | (uint64_t)A, RLX_AGENT);
-        int64_t hi = tile - 1;  // lane l looks at tile hi - l
-        uint32_t spins = 0;
-        for (;;) {
-          const int64_t j = hi - lane;
-          const uint64_t st = j >= 0 ? __hip_atomic_load(&state[j], RLX_AGENT) : kLbInclusive;  // before tile 0: inclusive 0
-          const uint64_t fl = st & kLbFlags;
+      if (lane == 0) __hip_atomic_store(&state[tile], kLbAggregate | (uint64_t)A, RLX_AGENT);
+      const int64_t g = tile / kLbGroup;
+      const int q = (int)(tile % kLbGroup);
+      const bool last_of_group = q == kLbGroup - 1 || tile == n_tiles - 1;
+      bool need_w = q > 0, need_g = g > 0, agg_pending = last_of_group && g > 0;
+      uint64_t within = 0, before = 0;
+      int64_t ghi = g - 1;  // lane l looks at group ghi - l
+      uint32_t spins = 0;
+      while (need_w || need_g) {
+        uint64_t st = 0, gs = 0;
+        if (need_w) st = __hip_atomic_load(&state[lane < q ? tile - 1 - lane : tile], RLX_AGENT);
+        if (need_g) {
+          const int64_t gj = ghi - lane;
+          gs = __hip_atomic_load(&gstate[gj >= 0 ? gj : 0], RLX_AGENT);
+          if (gj < 0) gs = kLbInclusive;  // before group 0: inclusive prefix 0
+        }
+        bool moved = false;
+        if (need_w) {
+          if (__ballot(lane < q && (st & kLbFlags) == 0) == 0) {  // every tile before this one in its group has published
+            within = wave_sum_u64(lane < q ? (st & ~kLbFlags) : 0ull);
+            need_w = false;
+          }
+        }
+        if (!need_w && agg_pending) {  // the group's aggregate: everybody after this group waits for it
+          if (lane == 0) __hip_atomic_store(&gstate[g], kLbAggregate | (within + (uint64_t)A), RLX_AGENT);
+          agg_pending = false;
+        }
+        if (need_g) {
+          const uint64_t fl = gs & kLbFlags;
           const uint64_t not_ready = __ballot(fl == 0);
           const uint64_t incl = __ballot(fl == kLbInclusive);
-          uint64_t take = 0;  // lanes whose count is added
-          bool done = false, step = false;
           if (incl != 0) {
-            const int pl = __ffsll((unsigned long long)incl) - 1;  // nearest tile with an inclusive prefix
+            const int pl = __ffsll((unsigned long long)incl) - 1;  // nearest group with an inclusive prefix
             const uint64_t upto = pl == 63 ? ~0ull : ((1ull << (pl + 1)) - 1ull);
             if ((not_ready & upto) == 0) {
-              take = upto;
-              done = true;
+              before += wave_sum_u64(((upto >> lane) & 1ull) ? (gs & ~kLbFlags) : 0ull);
+              need_g = false;
             }
-          } else if (not_ready == 0) {  // 64 counts, no prefix yet: add them all, look 64 tiles further back
-            take = ~0ull;
-            step = true;
+          } else if (not_ready == 0) {  // 64 aggregates, no prefix among them: add them all, look 64 groups further back
+            before += wave_sum_u64(gs & ~kLbFlags);
+            ghi -= 64;
+            moved = true;
           }
-          if (done || step) {
-            uint64_t v = ((take >> lane) & 1ull) ? (st & ~kLbFlags) : 0ull;
-#pragma unroll
-            for (int m = 32; m >= 1; m >>= 1) v += shfl_xor_u64(v, m);
-            base += v;
-            if (done) break;
-            hi -= 64;
-            continue;
-          }
-          if (++spins > (1u << 22)) {  // cannot happen (see above); never hang the device
-            err |= 8u;
-            break;
-          }
-          __builtin_amdgcn_s_sleep(2);
         }
+        if (!(need_w || need_g) || moved) continue;
+        if (++spins > (1u << 22)) {  // cannot happen (see above); never hang the device
+          err |= 8u;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
       }
+      const uint64_t base = before + within;
       if (lane == 0) {
-        __hip_atomic_store(&state[tile], kLbInclusive | (base + (uint64_t)A), RLX_AGENT);
+        if (last_of_group) __hip_atomic_store(&gstate[g], kLbInclusive | (base + (uint64_t)A), RLX_AGENT);
         tile_offsets[tile] = base;
         s_base = base;
         if (tile == n_tiles - 1) {
@@ -774,8 +830,6 @@ hipError_t launch_predicate_mask(const DevProgram& P, const DevFastPlan& fast, c
 #undef DFX_MASK
   return hipGetLastError();
 }
-
-size_t filter_fused_sync_words(int64_t n) { return 2 + (size_t)((n + kTileRows - 1) / kTileRows); }
 
 template <typename POL>
 static hipError_t filter_fused_launch(const DevProgram& P, const DevFastPlan& fast, const DevColumns& C, uint8_t pred, int64_t n,

@@ -2,7 +2,7 @@
 // The pass-1 kernels and the description of the strategy are in dfx_k_partition_inl.hpp; their instantiations are in
 // dfx_k_partition_v0.hip ... _v7.hip.
 #define DFX_PARTITION_MAIN_TU
-#include "dfx_k_partition_inl.hpp"
+#include "dfx_k_partition_ws_inl.hpp"
 
 namespace dfx {
 
@@ -673,6 +673,7 @@ hipError_t launch_probe_wide_keys(const DevTable& T, hipStream_t s) {
 
 size_t partition_stage_bytes(const DevPartition& PT) {
   if ((PT.mode & 15u) == 0) return (size_t)PT.n_parts * 4 + 16;
+  if ((PT.mode & 15u) == 2 && (PT.flags & PTF_WS)) return partition_ws_bytes(PT.n_parts, (int)PT.ws_scanners);
   if ((PT.mode & 15u) == 2)
     return partition_ring_bytes(PT.n_words, PT.n_parts, (PT.flags & PTF_CHUNK16) ? 32 : (PT.mode & 0x100u) ? 8 : 16, (PT.flags & PTF_HOT) != 0,
                                 (PT.flags & PTF_NARROW) != 0, (PT.flags & PTF_SHARED) ? 128 : 0);

@@ -1,0 +1,293 @@
+// dfx_k_partition_ws_inl.hpp -- pass 1 of the partitioned GROUP BY, WAVE-SPECIALISED flavour (PTF_WS).
+//
+// k_partition_ring (dfx_k_partition_inl.hpp) lets every one of a workgroup's 16 waves both scan and route.  Its
+// decomposition says where the time goes when a fifth of the rows pass: the scan skeleton alone
+// streams at 6.67 TB/s, routing 20 % of the rows adds 45 % per scanned row although its traffic explains 17 % -- the LDS
+// ring protocol (fill / commit atomics, generation checks, waiting for a busy chunk slot, flush jobs) runs on the waves
+// that own the outstanding column loads, and every wave carries four inlined copies of it (17 850 instructions, 106
+// spilled SGPRs in the round-2 build).  Here the two jobs belong to different waves of the workgroup:
+//   * NS SCANNER waves only load, compare and ballot-compact the passing rows {key (32 bits: narrow keys), operand} into
+//     their own single-producer / single-consumer LDS queue: ~30 vector instructions per 64-row group, nothing in their
+//     loop ever waits for a chunk slot or issues a global store;
+//   * 16 - NS ROUTER waves poll the queues of "their" scanners (scanner s belongs to router s mod NR), take 64 rows at a
+//     time at full lane utilisation and run the ring protocol (ring_route, one inlined copy): hash -> partition -> fill
+//     atomic -> ring -> commit -> cooperative 192-byte flushes.
+// A scanner stalls only when its queue is full (the router then has >= 64 rows to take, so it cannot be a deadlock);
+// a router waits only for rows or for another router's flush of a LOWER chunk -- the argument of the ring kernel.
+// Narrow 12-byte rows in 16-row chunks only (PTF_NARROW | PTF_CHUNK16: one routed value, keys below 2^32, no hot-key
+// pairs); rows the narrow form cannot carry (wide keys, the claim sentinel, reserved images, region overflow) take the
+// spill list exactly as in the ring kernel.  Same scratch layout, counts and padding: pass 2 cannot tell the flavours apart.
+#pragma once
+#include "dfx_k_partition_inl.hpp"
+
+namespace dfx {
+
+constexpr int kWsQueueRows = 256;  // per scanner wave (power of two): 3 KB {u32 key, u64 operand}
+constexpr int kWsCH = 16, kWsRP = 32, kWsNCH = kWsRP / kWsCH;
+
+struct WsCtl {  // one per scanner wave
+  uint32_t tail;  // rows produced (written by the scanner)
+  uint32_t head;  // rows consumed (written by its router)
+  uint32_t done;  // the scanner has published its last row
+  uint32_t pad;
+};
+
+#ifdef DFX_PARTITION_MAIN_TU
+size_t partition_ws_bytes(uint32_t n_parts, int ns) {
+  return (size_t)n_parts * kWsRP * 12 + (size_t)(kRingBlock / 64) * 64 * 8 /* jobs */ + (size_t)n_parts * 4 * (1 + 2 * kWsNCH) +
+         (size_t)ns * kWsQueueRows * 12 + (size_t)ns * sizeof(WsCtl) + 64;
+}
+#else
+size_t partition_ws_bytes(uint32_t n_parts, int ns);
+#endif
+
+// rows the narrow routed form cannot carry: a key >= 2^32 (the claim sentinel i64::MIN among them).  No row of a stream whose
+// calibration slice saw narrow keys only takes this path unless the data changes under it.
+DEV void ws_slow_rows(const DevTable& T, const DevRows& spill, bool slow, uint64_t key0, uint64_t val0) {
+  uint64_t key[1] = {key0};
+  uint64_t val[kMaxAggs];
+#pragma unroll
+  for (int a = 0; a < kMaxAggs; ++a) val[a] = a == 0 ? val0 : 0ull;
+  if (__ballot(slow && key0 == kEmptyKey) != 0) {
+    if (slow && key0 == kEmptyKey) {
+      sentinel_apply(T, val);
+      slow = false;
+    }
+  }
+  if (slow && __hip_atomic_load(&T.ctrl[CTRL_WIDE_KEYS], RLX_AGENT) == 0u) __hip_atomic_store(&T.ctrl[CTRL_WIDE_KEYS], 1u, RLX_AGENT);
+  spill_row<1>(T, spill, slow, key, val);
+}
+
+template <typename POL, int NS>
+__global__ __launch_bounds__(kRingBlock) void k_partition_ws(const DevProgram P, const DevFastPlan F, const DevColumns C,
+                                                            const DevAggPlan plan, const DevTable T,
+                                                            const DevPartition PT, const DevRows spill, const int64_t n) {
+  typedef typename POL::COLV COLV;
+  constexpr int U = POL::U;
+  constexpr int NWAVES = kRingBlock / 64;
+  constexpr int NR = NWAVES - NS;             // router waves
+  constexpr int SPR = (NS + NR - 1) / NR;     // scanners per router
+  static_assert(NS >= 1 && NR >= 1, "both roles need a wave");
+  extern __shared__ __attribute__((aligned(16))) uint64_t lds[];
+  RingLds L;
+  L.ring = lds;
+  const size_t ring_words = (size_t)PT.n_parts * kWsRP * 3 / 2;  // 12-byte rows
+  L.queue = nullptr;                                             // (the ring kernel's wave queues: not used here)
+  L.jobs = (uint32_t*)(L.ring + ring_words);
+  L.fill = L.jobs + NWAVES * 64 * 2;
+  L.commit = L.fill + PT.n_parts;
+  L.gen = L.commit + (size_t)PT.n_parts * kWsNCH;
+  uint32_t* const qkeys = L.gen + (size_t)PT.n_parts * kWsNCH;                   // [NS][kWsQueueRows]
+  WsCtl* const ctl = (WsCtl*)(qkeys + (size_t)NS * kWsQueueRows);                // [NS]
+  // the operand planes behind everything else, 8-byte aligned (as an offset from `lds`: keeps the LDS address space)
+  const size_t qv_word0 = ring_words + ((size_t)(NWAVES * 64 * 2 + PT.n_parts * (1 + 2 * kWsNCH) + NS * kWsQueueRows) * 4 + (size_t)NS * sizeof(WsCtl) + 7) / 8;
+  uint64_t* const qvals = lds + qv_word0;                                        // [NS][kWsQueueRows]
+  const int lane = lane_id();
+  const int wave = (int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const uint32_t producer = blockIdx.x;
+  // fill, commit, gen exactly as k_partition_ring initialises them (PTF_RESUME: chunk numbering goes on from counts[])
+  for (uint32_t p = threadIdx.x; p < PT.n_parts; p += kRingBlock) {
+    const uint32_t f0 = (PT.flags & PTF_RESUME) ? PT.counts[(uint64_t)p * PT.n_producers + producer] : 0u;
+    const uint32_t c0 = f0 / kWsCH;
+    L.fill[p] = f0;
+#pragma unroll
+    for (int sl = 0; sl < kWsNCH; ++sl) {
+      L.commit[p * kWsNCH + sl] = 0;
+      L.gen[p * kWsNCH + sl] = (c0 + (uint32_t)(kWsNCH - 1 - sl)) / (uint32_t)kWsNCH;
+    }
+  }
+  if (threadIdx.x < (unsigned)NS) {
+    ctl[threadIdx.x].tail = 0;
+    ctl[threadIdx.x].head = 0;
+    ctl[threadIdx.x].done = 0;
+  }
+  __syncthreads();
+  uint32_t err = 0;
+  if (wave < NS) {
+    // ---------------------------------------------------------------- scanner -----------------------------------
+    uint32_t* const qk = qkeys + (size_t)wave * kWsQueueRows;
+    uint64_t* const qv = qvals + (size_t)wave * kWsQueueRows;
+    WsCtl* const my = ctl + wave;
+    uint32_t tail = 0;    // rows produced so far (wave-uniform)
+    uint32_t head_c = 0;  // last consumer position seen
+    uint64_t passed = 0;  // wave-uniform
+    const int64_t n_groups = (n + 63) >> 6;
+    const int64_t wave_global = (int64_t)blockIdx.x * NS + wave;
+    const int64_t n_waves = (int64_t)gridDim.x * NS;
+    // software pipeline, one trip deep (as in k_partition_ring: deeper was measured no faster)
+    COLV ncol[U];
+    uint32_t ncv[U];
+    {
+      const int64_t w0 = wave_global * U;
+      FOR_U {
+        const int64_t row = (w0 + u) * 64 + lane;
+        POL::load(P, C, row, row < n && w0 < n_groups, ncol[u], ncv[u]);
+      }
+    }
+    for (int64_t w0 = wave_global * U; w0 < n_groups; w0 += n_waves * U) {
+      COLV col[U];
+      uint32_t cv[U];
+      FOR_U {
+        col[u] = ncol[u];
+        cv[u] = ncv[u];
+      }
+      {
+        const int64_t w1 = w0 + n_waves * U;
+        FOR_U {
+          const int64_t row = (w1 + u) * 64 + lane;
+          POL::load(P, C, row, row < n, ncol[u], ncv[u]);
+        }
+      }
+      FOR_U {  // (unrolled, like the ring kernel's scan: a run-time loop over the U banks costs a scalar branch chain per group)
+        const COLV cur = col[u];
+        const uint32_t curv = cv[u];
+        const int64_t row = (w0 + u) * 64 + lane;
+        const bool inb = row < n;
+        u64x16 reg;
+        uint32_t rv = 0;
+        POL::eval(P, F, cur, curv, reg, rv, inb, err);
+        bool pass = inb && POL::pass(P, F, plan.pred, cur, curv, reg, rv);
+        const uint64_t key = POL::key(P, F, plan.key[0], 0, cur, curv, reg, rv);
+        uint64_t v;
+        bool valid;
+        POL::arg(P, F, plan.arg[0], 0, cur, curv, reg, rv, v, valid);
+        const uint64_t val = transform_value(POL::xform(T, 0), v, valid);
+        passed += (uint64_t)__popcll(__ballot(pass));
+        const bool slow = pass && (key >> 32) != 0;  // no 32-bit form (wide key, or the claim sentinel)
+        if (__ballot(slow) != 0) {
+          ws_slow_rows(T, spill, slow, key, val);
+          pass = pass && !slow;
+        }
+        const uint64_t m = __ballot(pass);
+        const uint32_t c = (uint32_t)__popcll(m);
+        if (c != 0) {
+          // room for c rows?  (the router publishes its position after every batch of 64 it takes)
+          uint32_t spins = 0;
+          while (tail + c - head_c > (uint32_t)kWsQueueRows) {
+            head_c = __hip_atomic_load(&my->head, __ATOMIC_ACQUIRE, WG_SCOPE);
+            if (tail + c - head_c <= (uint32_t)kWsQueueRows) break;
+            if (++spins > (1u << 22)) {  // cannot happen (a full queue always has 64 rows for its router); never hang the device
+              err |= 4u;
+              break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+          }
+          if (pass) {
+            const uint32_t at = (tail + mbcnt64(m)) & (uint32_t)(kWsQueueRows - 1);
+            qk[at] = (uint32_t)key;
+            qv[at] = val;
+          }
+          tail += c;
+        }
+      }
+      if (lane == 0) __hip_atomic_store(&my->tail, tail, __ATOMIC_RELEASE, WG_SCOPE);  // once per trip: the rows above are visible first
+    }
+    if (lane == 0) {
+      __hip_atomic_store(&my->tail, tail, __ATOMIC_RELEASE, WG_SCOPE);
+      __hip_atomic_store(&my->done, 1u, __ATOMIC_RELEASE, WG_SCOPE);
+      stat_add(T, STAT_PASSED, passed);
+    }
+  } else {
+    // ---------------------------------------------------------------- router ------------------------------------
+    const int r = wave - NS;
+    uint32_t fin = 0;  // bit j: scanner r + j NR has been drained (or does not exist)
+    for (int j = 0; j < SPR; ++j)
+      if (r + j * NR >= NS) fin |= 1u << j;
+    constexpr uint32_t kAllFin = (1u << SPR) - 1u;
+    uint32_t idle = 0;
+    while (fin != kAllFin) {
+      bool progress = false;
+#pragma nounroll
+      for (int j = 0; j < SPR; ++j) {  // ONE copy of the routing code: a run-time loop over this router's scanners
+        if ((fin >> j) & 1u) continue;
+        const int s = r + j * NR;
+        WsCtl* const sc = ctl + s;
+        const uint32_t head = sc->head;  // (only this wave writes it)
+        uint32_t tail = __hip_atomic_load(&sc->tail, __ATOMIC_ACQUIRE, WG_SCOPE);
+        uint32_t avail = tail - head;
+        uint32_t take = avail >= 64u ? 64u : 0u;
+        if (take == 0 && __hip_atomic_load(&sc->done, __ATOMIC_ACQUIRE, WG_SCOPE) != 0u) {
+          tail = __hip_atomic_load(&sc->tail, __ATOMIC_ACQUIRE, WG_SCOPE);  // the final count was published before `done`
+          avail = tail - head;
+          take = avail < 64u ? avail : 64u;
+          if (avail == 0) fin |= 1u << j;
+        }
+        if (take == 0) continue;
+        const bool have = (uint32_t)lane < take;
+        const uint32_t at = (head + (uint32_t)lane) & (uint32_t)(kWsQueueRows - 1);
+        uint64_t k2[1];
+        uint64_t v2[kMaxAggs];
+#pragma unroll
+        for (int a = 0; a < kMaxAggs; ++a) v2[a] = 0;
+        k2[0] = have ? (uint64_t)qkeys[(size_t)s * kWsQueueRows + at] : 0ull;
+        v2[0] = have ? qvals[(size_t)s * kWsQueueRows + at] : 0ull;
+        // the slots are free again as soon as the rows sit in registers
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (lane == 0) __hip_atomic_store(&sc->head, head + take, __ATOMIC_RELEASE, WG_SCOPE);
+        const uint64_t h2 = hash_keys<1>(k2);
+        ring_route<1, kWsCH, kWsRP, 1>(T, PT, spill, L, producer, 1, have, k2, v2, h2, err);
+        progress = true;
+      }
+      if (!progress) {
+        if (++idle > (1u << 24)) {  // a scanner that never finishes: cannot happen; never hang the device
+          err |= 4u;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(2);
+      } else {
+        idle = 0;
+      }
+    }
+  }
+  __syncthreads();
+  // partial chunks + region counts: as in k_partition_ring (a partial chunk is padded to a whole one with kTagEmpty rows)
+  uint32_t max_fill = 0;
+  for (uint32_t p = threadIdx.x; p < PT.n_parts; p += kRingBlock) {
+    uint32_t f = L.fill[p];
+    if (f > PT.cap_rows) f = PT.cap_rows;
+    const uint32_t c = f / kWsCH;
+    const uint32_t rem = f % kWsCH;
+    for (uint32_t rr = 0; rr < rem; ++rr) {
+      const uint32_t* s32 = (const uint32_t*)L.ring + ((size_t)p * kWsRP + (c % kWsNCH) * kWsCH + rr) * 3;
+      uint32_t* o32 = region_row12(PT, p, producer, c * kWsCH + rr);
+      for (int w = 0; w < 3; ++w) o32[w] = s32[w];
+    }
+    if (rem != 0) {
+      for (uint32_t rr = rem; rr < (uint32_t)kWsCH; ++rr) {
+        uint32_t* o32 = region_row12(PT, p, producer, c * kWsCH + rr);
+        o32[0] = kTagEmpty;
+        o32[1] = o32[2] = 0;
+      }
+      f = (c + 1) * kWsCH;
+    }
+    PT.counts[(uint64_t)p * PT.n_producers + producer] = f;
+    max_fill = f > max_fill ? f : max_fill;
+  }
+  publish_max_fill(T, max_fill);
+  if (err) atomicOr(&T.ctrl[CTRL_ERROR], err);
+  snapshot_ctrl_if_last(T, PT);
+}
+
+// WSALL: also instantiate the 8- and 14-scanner splits (the headline's variant: A/B runs by agg.pass1_ws)
+template <typename POLN, bool WSALL>
+void launch_partition_ws(const DevProgram& P, const DevFastPlan& fast, const DevColumns& C, const DevAggPlan& plan, const DevTable& T,
+                         const DevPartition& PT, const DevRows& spill, int64_t n, size_t lds_bytes, hipStream_t s) {
+  const int grid = (int)PT.n_producers;
+  if (WSALL && PT.ws_scanners == 8)
+    hipLaunchKernelGGL((k_partition_ws<POLN, WSALL ? 8 : 12>), dim3(grid), dim3(kRingBlock), lds_bytes, s, P, fast, C, plan, T, PT, spill, n);
+  else if (WSALL && PT.ws_scanners == 14)
+    hipLaunchKernelGGL((k_partition_ws<POLN, WSALL ? 14 : 12>), dim3(grid), dim3(kRingBlock), lds_bytes, s, P, fast, C, plan, T, PT, spill, n);
+  else
+    hipLaunchKernelGGL((k_partition_ws<POLN, 12>), dim3(grid), dim3(kRingBlock), lds_bytes, s, P, fast, C, plan, T, PT, spill, n);
+}
+
+// one pass-1 variant = one translation unit: the ring / sorted / direct kernels of the policy plus its wave-specialised kernel
+#define DFX_PARTITION_VARIANT_WS(ID, WSALL, POL, POLS, POLN)                                                               \
+  void launch_partition_variant##ID(DFX_PARTITION_VARIANT_ARGS) {                                                          \
+    if (PT.flags & PTF_WS)                                                                                                 \
+      launch_partition_ws<POLN, WSALL>(P, fast, C, plan, T, PT, spill, n, lds_bytes, s);                                   \
+    else                                                                                                                   \
+      launch_partition_pol<POL, POLS, POLN>(P, fast, C, plan, T, PT, spill, n, lds_bytes, s);                              \
+  }
+
+}  // namespace dfx

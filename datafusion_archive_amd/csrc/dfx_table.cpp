@@ -405,6 +405,7 @@ int32_t dfx_set_option(const char* key, int64_t value) {
   else if (!strcmp(key, "agg.ctrl_snapshot")) o.ctrl_snapshot = (int)value;
   else if (!strcmp(key, "export.kernel_copy")) o.export_kernel_copy = (int)value;
   else if (!strcmp(key, "agg.partition_producers")) o.partition_producers = (int)value;
+  else if (!strcmp(key, "agg.pass1_ws")) o.pass1_ws = (int)value;
   else if (!strcmp(key, "filter.single_pass")) o.filter_single_pass = (int)value;
   else if (!strcmp(key, "pool.trim")) pool_trim();
   else return DFX_GENERAL;
