@@ -84,6 +84,9 @@ struct AggregateRelation::Impl {
   uint8_t acc_kind_all[kMaxAccsTotal], val_xform_all[kMaxAccsTotal];
   uint64_t acc_init_all[kMaxAccsTotal];
   uint64_t* accs_full = nullptr;  // plane 0 of the table's accumulators (T.accs is the active chunk's first plane)
+  DevTable import_T;              // multi-GPU exchange: the table the received group partials are merged into
+  uint64_t* import_accs_full = nullptr;
+  std::vector<std::shared_ptr<void>> import_owners, import_keep;
   void activate(int c);
   DevTable view_of(const DevTable& any_view, uint64_t* full_accs, int c) const;
   Status build_chunk_programs(Chunk& ch);
@@ -568,8 +571,8 @@ Status AggregateRelation::Impl::ensure_partition(int64_t rows, bool nulls_now) {
     // selective scans: the scanning and the routing belong to different waves (dfx_k_partition_ws_inl.hpp).  When most rows
     // pass, every wave has rows to route all the time and the ring kernel's symmetric waves are the better fit
     if ((PT.flags & PTF_CHUNK16) && o.pass1_ws > 0 && !dense_seen && !(((uint32_t)o.partition_mode) & ~15u)) {
-      PT.ws_scanners = o.pass1_ws == 8 ? 8u : o.pass1_ws == 14 ? 14u : 12u;
-      if (partition_ws_bytes(PT.n_parts, (int)PT.ws_scanners) <= (size_t)158 * 1024) PT.flags |= PTF_WS;
+      PT.ws_scanners = (uint32_t)o.pass1_ws;  // scanner waves (+ 100: eight row groups per trip); unknown values run the default split
+      if (partition_ws_bytes(PT.n_parts, 12) <= (size_t)158 * 1024) PT.flags |= PTF_WS;
     }
     PT.mode = 2u | ((uint32_t)o.partition_mode & ~15u);
     PT.block = 1024;
@@ -1747,6 +1750,154 @@ Status AggregateRelation::partial_export_with(const std::vector<int64_t>& counts
   return Status::OK();
 }
 
+// ---- the in-library exchange, piece by piece (dfx_exchange.cpp drives the collectives between them) ---------------------
+int AggregateRelation::exchange_chunks() const { return std::max<int>(1, (int)impl_->chunks.size()); }
+int AggregateRelation::exchange_chunk_words(int c) const {
+  const Impl& m = *impl_;
+  return m.kw + (m.chunks.empty() ? m.na : m.chunks[(size_t)c].n);
+}
+int AggregateRelation::exchange_dicts() const { return (int)impl_->dicts.size(); }
+
+Status AggregateRelation::exchange_drain() {
+  Impl& m = *impl_;
+  if (!m.deferred.ok()) return m.deferred;
+  if (m.kw == 0) return Status::Err(DFX_INTERNAL_ERROR, "exchange_drain is for GROUP BY aggregates");
+  return m.drain();
+}
+
+Status AggregateRelation::exchange_count(int world, uint64_t* d_counts) {
+  Impl& m = *impl_;
+  if (world < 1 || world > 1024) return Status::Err(DFX_GENERAL, "world must be in 1..1024");
+  hipStream_t s = ctx().stream;
+  DFX_HIP(hipMemsetAsync(d_counts, 0, sizeof(uint64_t) * (size_t)world, s));
+  DFX_HIP(launch_partial_count(m.T, world, d_counts, s));
+  return Status::OK();
+}
+
+Status AggregateRelation::exchange_export_chunk(int c, const std::vector<int64_t>& counts, void* dst_device, int64_t dst_words) {
+  Impl& m = *impl_;
+  if (m.chunks.size() > 1) m.activate(c);
+  return partial_export_with(counts, dst_device, dst_words, /*sync=*/false);
+}
+
+Status AggregateRelation::exchange_import_begin(uint64_t total_groups) {
+  Impl& m = *impl_;
+  if (!m.built) return Status::Err(DFX_GENERAL, "the input must be drained before the import");
+  const int cap_log2 = std::max(10, ceil_log2(4 * (total_groups + 1)));
+  if (cap_log2 > 31) return Status::Err(DFX_EXECUTION_ERROR, "GROUP BY table would exceed 2^31 slots");
+  m.import_owners.clear();
+  m.import_accs_full = nullptr;
+  if (m.chunks.size() > 1) m.activate(0);
+  m.import_keep = {m.ctrl, m.stats};  // the OLD table's control block stays readable: later chunks are still exported from it
+  DFX_RETURN_IF_ERROR(m.alloc_table(cap_log2, &m.import_T, &m.import_owners, true, &m.import_accs_full));
+  return Status::OK();
+}
+
+Status AggregateRelation::exchange_import_chunk(int c, const void* src_device, const int64_t* counts, int n_buckets) {
+  Impl& m = *impl_;
+  hipStream_t s = ctx().stream;
+  DevRows no_spill;
+  no_spill.words = nullptr;
+  no_spill.capacity = 0;
+  // chunk c's planes of the NEW table; the first chunk inserts the keys, the others find them
+  const DevTable Tc = m.chunks.size() > 1 ? m.view_of(m.import_T, m.import_accs_full, c) : m.import_T;
+  const int nw = exchange_chunk_words(c);
+  uint64_t off = 0;
+  for (int b = 0; b < n_buckets; ++b) {
+    if (counts[b] > 0)
+      DFX_HIP(launch_merge_bucket((const uint64_t*)src_device + (size_t)nw * off, (uint64_t)counts[b], Tc, no_spill, s));
+    off += (uint64_t)counts[b];
+  }
+  return Status::OK();
+}
+
+Status AggregateRelation::exchange_import_finish() {
+  Impl& m = *impl_;
+  DFX_HIP(hipStreamSynchronize(ctx().stream));
+  m.T = m.import_T;
+  m.accs_full = m.import_accs_full;
+  m.table_owners = m.import_owners;
+  m.import_owners.clear();
+  m.import_keep.clear();
+  m.export_counts.clear();
+  if (m.chunks.size() > 1) m.activate(0);
+  uint32_t hc[CTRL_WORDS];
+  DFX_RETURN_IF_ERROR(m.read_ctrl(hc));
+  if (hc[CTRL_ERROR]) return error_from_ctrl(hc[CTRL_ERROR]);
+  m.occupied_known = hc[CTRL_OCCUPIED];
+  return Status::OK();
+}
+
+// the strings of dictionary d in local-id order (lengths + bytes back to back)
+Status AggregateRelation::exchange_dict_local(int d, std::vector<uint32_t>* lens, std::vector<uint8_t>* pool) {
+  Impl& m = *impl_;
+  const Impl::DictKey& k = m.dicts[(size_t)d];
+  lens->assign((size_t)k.ids_used, 0);
+  pool->clear();
+  if (!k.allocated || k.ids_used == 0) return Status::OK();
+  std::vector<uint64_t> offs((size_t)k.ids_used);
+  std::vector<uint8_t> raw((size_t)k.pool_used);
+  DFX_HIP(hipStreamSynchronize(ctx().stream));
+  DFX_HIP(hipMemcpy(lens->data(), k.D.str_len, sizeof(uint32_t) * lens->size(), hipMemcpyDeviceToHost));
+  DFX_HIP(hipMemcpy(offs.data(), k.D.str_off, sizeof(uint64_t) * offs.size(), hipMemcpyDeviceToHost));
+  if (!raw.empty()) DFX_HIP(hipMemcpy(raw.data(), k.D.pool, raw.size(), hipMemcpyDeviceToHost));
+  size_t total = 0;
+  for (uint32_t l : *lens) total += l;
+  pool->reserve(total);
+  for (size_t i = 0; i < lens->size(); ++i) {  // the pool is filled by atomics: put the strings in id order
+    if (offs[i] + (*lens)[i] > raw.size()) return Status::Err(DFX_INTERNAL_ERROR, "Utf8 key dictionary: string outside the pool");
+    pool->insert(pool->end(), raw.begin() + (ptrdiff_t)offs[i], raw.begin() + (ptrdiff_t)(offs[i] + (*lens)[i]));
+  }
+  return Status::OK();
+}
+
+// installs the GLOBAL dictionary (strings by global id: lens + bytes back to back) as dictionary d and rewrites the key
+// plane of that GROUP BY column: local id -> remap[local id].  The table is not probed again before the exchange scatters
+// it (count / scatter walk the slots), and what the import builds is keyed by global ids from the start.
+Status AggregateRelation::exchange_dict_globalise(int d, const std::vector<uint32_t>& lens, const std::vector<uint8_t>& pool,
+                                                   const std::vector<uint64_t>& remap) {
+  Impl& m = *impl_;
+  Impl::DictKey& k = m.dicts[(size_t)d];
+  hipStream_t s = ctx().stream;
+  Status st;
+  if (!remap.empty()) {
+    auto dremap = device_alloc(sizeof(uint64_t) * remap.size(), &st);
+    if (!dremap) return st;
+    DFX_HIP(hipMemcpy(dremap.get(), remap.data(), sizeof(uint64_t) * remap.size(), hipMemcpyHostToDevice));
+    uint64_t* plane = m.T.keys + (uint64_t)k.key * m.T.stride;
+    DFX_HIP(launch_dict_remap_plane(plane, m.T.mask + 2, (const uint64_t*)dremap.get(), (uint64_t)remap.size(), s));
+    DFX_HIP(hipStreamSynchronize(s));  // dremap dies with this scope
+  }
+  const uint64_t g = lens.size();
+  int lg = 4;
+  while ((1ull << lg) / 2 < std::max<uint64_t>(g, 1) && lg < 31) ++lg;
+  k.ids_used = k.pool_used = 0;
+  DFX_RETURN_IF_ERROR(m.dict_alloc(k, lg, std::max<uint64_t>(pool.size(), 64), false));
+  std::vector<uint64_t> offs((size_t)g);
+  uint64_t at = 0;
+  for (size_t i = 0; i < (size_t)g; ++i) {
+    offs[i] = at;
+    at += lens[i];
+  }
+  if (g) {
+    DFX_HIP(hipMemcpy(k.D.str_len, lens.data(), sizeof(uint32_t) * (size_t)g, hipMemcpyHostToDevice));
+    DFX_HIP(hipMemcpy(k.D.str_off, offs.data(), sizeof(uint64_t) * (size_t)g, hipMemcpyHostToDevice));
+    if (!pool.empty()) DFX_HIP(hipMemcpy(k.D.pool, pool.data(), pool.size(), hipMemcpyHostToDevice));
+  }
+  k.ids_used = g;
+  k.pool_used = pool.size();
+  const uint64_t hc[DICT_WORDS] = {k.pool_used, k.ids_used, 0, 0};
+  DFX_HIP(hipMemcpy(k.D.cursors, hc, sizeof(hc), hipMemcpyHostToDevice));
+  return Status::OK();
+}
+
+Status AggregateRelation::ungrouped_select_chunk(int c) {
+  Impl& m = *impl_;
+  if (c < 0 || c >= exchange_chunks()) return Status::Err(DFX_GENERAL, "no such chunk");
+  if (m.chunks.size() > 1) m.activate(c);
+  return Status::OK();
+}
+
 static uint64_t host_wrap_to(uint8_t t, uint64_t x) {  // == wrap_to (dfx_kernels_inl.hpp)
   switch (t) {
     case DFX_INT8: return (uint64_t)(int64_t)(int8_t)x;
@@ -1764,7 +1915,6 @@ bool AggregateRelation::is_ungrouped() const { return impl_->deferred.ok() && im
 Status AggregateRelation::ungrouped_state_begin() {
   Impl& m = *impl_;
   if (!m.deferred.ok()) return m.deferred;
-  if (m.chunks.size() > 1) return Status::Err(DFX_NOT_IMPLEMENTED, strfmt("multi-GPU exchange of more than %d accumulators", kMaxAggs));
   if (m.group.empty() && m.aggr.empty())
     return Status::Err(DFX_INTERNAL_ERROR, "assertion failed: record batch needs at least one column");
   return m.drain();

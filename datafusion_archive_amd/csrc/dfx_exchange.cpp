@@ -14,10 +14,14 @@
 // load the library -- dfx_comm_* then fail with ExecutionError.
 #include <dlfcn.h>
 #include <rccl/rccl.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
 #include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
 
 #include "dfx_relation.hpp"
 
@@ -42,10 +46,14 @@ Rccl& rccl() {
   static Rccl r;
   static std::once_flag once;
   std::call_once(once, [] {
-    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    // DFX_RCCL_LIB: bind this library instead (a differently named RCCL build; the tests' host-staged stand-in that lets
+    // several ranks share one GPU, tests/native/rccl_stub.cpp)
+    const char* override_lib = getenv("DFX_RCCL_LIB");
+    const char* names[] = {override_lib, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     for (const char* n : names) {
-      r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-      if (r.handle) break;
+      if (!n || !*n) continue;
+      r.handle = dlopen(n, RTLD_NOW | (n == override_lib ? RTLD_LOCAL : RTLD_GLOBAL));
+      if (r.handle || n == override_lib) break;  // an override that does not load is an error, not a reason to look elsewhere
     }
     if (!r.handle) {
       const char* e = dlerror();
@@ -121,6 +129,93 @@ static Status all_to_all_words(dfx_comm* c, SendAt send_at, RecvAt recv_at, hipS
   return st;
 }
 
+// every rank's variable-sized blob to every rank: `mine` (device, n_mine words) lands in all[r] on rank r's peers.  sizes[]
+// (words per rank) is known to everybody beforehand.  Grouped sends / receives like the all-to-all.
+static Status all_gather_v_words(dfx_comm* c, const uint64_t* mine, const std::vector<uint64_t>& sizes, uint64_t* all, hipStream_t s) {
+  std::vector<uint64_t> base((size_t)c->world + 1, 0);
+  for (int r = 0; r < c->world; ++r) base[(size_t)r + 1] = base[(size_t)r] + sizes[(size_t)r];
+  return all_to_all_words(
+      c, [&](int, const void** p, size_t* n) { *p = mine; *n = (size_t)sizes[(size_t)c->rank]; },
+      [&](int peer, void** p, size_t* n) { *p = all + base[(size_t)peer]; *n = (size_t)sizes[(size_t)peer]; }, s);
+}
+
+constexpr uint64_t kPeerFailed = ~0ull;  // travels instead of a count: the sender hit an error, every rank gives up together
+
+// Utf8 GROUP BY keys: dictionary ids are rank-local.  Every rank learns every rank's strings (sizes first, then lengths +
+// bytes), builds the SAME global dictionary on the host (rank 0's strings in id order, then rank 1's new ones, ...), rewrites
+// its key plane to global ids and installs the global dictionary for the emit.  O(distinct strings of all ranks) on the host.
+static Status globalise_dictionaries(AggregateRelation* a, dfx_comm* c, Status local, int64_t* host_syncs) {
+  const int world = c->world;
+  hipStream_t s = ctx().stream;
+  for (int d = 0; d < a->exchange_dicts(); ++d) {
+    std::vector<uint32_t> lens;
+    std::vector<uint8_t> pool;
+    if (local.ok()) local = a->exchange_dict_local(d, &lens, &pool);
+    // blob = lens (u32, padded to words) + bytes (padded to words)
+    const uint64_t len_words = ((uint64_t)lens.size() + 1) / 2, pool_words = ((uint64_t)pool.size() + 7) / 8;
+    Status st;
+    auto dsz = device_alloc(sizeof(uint64_t) * (size_t)world * 3 * 2, &st);  // mine [3], all [3 * world]
+    if (!dsz) return st;
+    uint64_t hmine[3] = {local.ok() ? (uint64_t)lens.size() : kPeerFailed, (uint64_t)pool.size(), 0};
+    uint64_t* dmine = (uint64_t*)dsz.get();
+    uint64_t* dall = dmine + 3;
+    DFX_HIP(hipMemcpy(dmine, hmine, sizeof(hmine), hipMemcpyHostToDevice));
+    std::vector<uint64_t> three((size_t)world, 3);
+    DFX_RETURN_IF_ERROR(all_gather_v_words(c, dmine, three, dall, s));
+    std::vector<uint64_t> hall((size_t)world * 3, 0);
+    DFX_HIP(hipMemcpyAsync(hall.data(), dall, sizeof(uint64_t) * hall.size(), hipMemcpyDeviceToHost, s));
+    DFX_HIP(hipStreamSynchronize(s));
+    ++*host_syncs;
+    hall[(size_t)c->rank * 3] = hmine[0];
+    hall[(size_t)c->rank * 3 + 1] = hmine[1];
+    for (int r = 0; r < world; ++r)
+      if (hall[(size_t)r * 3] == kPeerFailed)
+        return local.ok() ? Status::Err(DFX_EXECUTION_ERROR, strfmt("multi-GPU exchange: rank %d failed before the exchange", r)) : local;
+    std::vector<uint64_t> sizes((size_t)world), base((size_t)world + 1, 0);
+    for (int r = 0; r < world; ++r) {
+      sizes[(size_t)r] = (hall[(size_t)r * 3] + 1) / 2 + (hall[(size_t)r * 3 + 1] + 7) / 8;
+      base[(size_t)r + 1] = base[(size_t)r] + sizes[(size_t)r];
+    }
+    std::vector<uint64_t> blob((size_t)std::max<uint64_t>(1, len_words + pool_words), 0);
+    if (!lens.empty()) memcpy(blob.data(), lens.data(), sizeof(uint32_t) * lens.size());
+    if (!pool.empty()) memcpy(blob.data() + len_words, pool.data(), pool.size());
+    auto dblob = device_alloc(sizeof(uint64_t) * blob.size(), &st);
+    if (!dblob) return st;
+    auto dblobs = device_alloc(sizeof(uint64_t) * (size_t)std::max<uint64_t>(1, base[(size_t)world]), &st);
+    if (!dblobs) return st;
+    DFX_HIP(hipMemcpy(dblob.get(), blob.data(), sizeof(uint64_t) * blob.size(), hipMemcpyHostToDevice));
+    DFX_RETURN_IF_ERROR(all_gather_v_words(c, (const uint64_t*)dblob.get(), sizes, (uint64_t*)dblobs.get(), s));
+    std::vector<uint64_t> blobs((size_t)std::max<uint64_t>(1, base[(size_t)world]), 0);
+    DFX_HIP(hipMemcpyAsync(blobs.data(), dblobs.get(), sizeof(uint64_t) * blobs.size(), hipMemcpyDeviceToHost, s));
+    DFX_HIP(hipStreamSynchronize(s));
+    ++*host_syncs;
+    // the same global dictionary on every rank
+    std::unordered_map<std::string, uint64_t> ids;
+    std::vector<uint32_t> glens;
+    std::vector<uint8_t> gpool;
+    std::vector<uint64_t> remap;
+    for (int r = 0; r < world; ++r) {
+      const uint64_t n_ids = hall[(size_t)r * 3], n_bytes = hall[(size_t)r * 3 + 1];
+      const uint32_t* rl = r == c->rank ? lens.data() : (const uint32_t*)(blobs.data() + base[(size_t)r]);
+      const uint8_t* rp = r == c->rank ? pool.data() : (const uint8_t*)(blobs.data() + base[(size_t)r] + (n_ids + 1) / 2);
+      uint64_t at = 0;
+      for (uint64_t i = 0; i < n_ids; ++i) {
+        if (at + rl[i] > n_bytes) return Status::Err(DFX_INTERNAL_ERROR, "multi-GPU exchange: malformed dictionary blob");
+        std::string str((const char*)rp + at, (size_t)rl[i]);
+        at += rl[i];
+        auto ins = ids.emplace(std::move(str), (uint64_t)glens.size());
+        if (ins.second) {
+          glens.push_back(rl[i]);
+          gpool.insert(gpool.end(), (const uint8_t*)ins.first->first.data(), (const uint8_t*)ins.first->first.data() + ins.first->first.size());
+        }
+        if (r == c->rank) remap.push_back(ins.first->second);
+      }
+    }
+    DFX_RETURN_IF_ERROR(a->exchange_dict_globalise(d, glens, gpool, remap));
+  }
+  return local;
+}
+
 Status AggregateRelation::exchange(dfx_comm* c, int64_t* stats) {
   if (!c) return Status::Err(DFX_GENERAL, "null communicator");
   const int world = c->world;
@@ -133,37 +228,50 @@ Status AggregateRelation::exchange(dfx_comm* c, int64_t* stats) {
     Status st;
     auto all = device_alloc(sizeof(uint64_t) * (size_t)nw * (size_t)world, &st);
     if (!all) return st;
-    if (world > 1) {
-      DFX_NCCL(rccl().AllGather(ungrouped_state_device(), all.get(), (size_t)nw, ncclUint64, c->comm, s), "ncclAllGather");
-    } else {
-      DFX_HIP(hipMemcpyAsync(all.get(), ungrouped_state_device(), sizeof(uint64_t) * (size_t)nw, hipMemcpyDeviceToDevice, s));
+    for (int ch = 0; ch < exchange_chunks(); ++ch) {  // more than kMaxAggs accumulators: one state block per chunk
+      DFX_RETURN_IF_ERROR(ungrouped_select_chunk(ch));
+      if (world > 1) {
+        DFX_NCCL(rccl().AllGather(ungrouped_state_device(), all.get(), (size_t)nw, ncclUint64, c->comm, s), "ncclAllGather");
+      } else {
+        DFX_HIP(hipMemcpyAsync(all.get(), ungrouped_state_device(), sizeof(uint64_t) * (size_t)nw, hipMemcpyDeviceToDevice, s));
+      }
+      std::vector<uint64_t> host((size_t)nw * (size_t)world);
+      DFX_HIP(hipMemcpyAsync(host.data(), all.get(), sizeof(uint64_t) * host.size(), hipMemcpyDeviceToHost, s));
+      DFX_HIP(hipStreamSynchronize(s));
+      ++host_syncs;
+      DFX_RETURN_IF_ERROR(ungrouped_state_merge(host.data(), world, c->rank));
     }
-    std::vector<uint64_t> host((size_t)nw * (size_t)world);
-    DFX_HIP(hipMemcpyAsync(host.data(), all.get(), sizeof(uint64_t) * host.size(), hipMemcpyDeviceToHost, s));
-    DFX_HIP(hipStreamSynchronize(s));
-    ++host_syncs;
-    DFX_RETURN_IF_ERROR(ungrouped_state_merge(host.data(), world, c->rank));
+    DFX_RETURN_IF_ERROR(ungrouped_select_chunk(0));
     if (stats) {
       stats[0] = stats[1] = 1;
-      stats[2] = (int64_t)(sizeof(uint64_t) * (size_t)nw);
+      stats[2] = (int64_t)(sizeof(uint64_t) * (size_t)nw * (size_t)exchange_chunks());
       stats[3] = host_syncs;
     }
     return Status::OK();
   }
   // ---- grouped ----
-  int nw = 0;
-  std::vector<int64_t> send_counts((size_t)world, 0);
-  uint64_t* d_counts = nullptr;
-  std::shared_ptr<void> counts_owner;
-  DFX_RETURN_IF_ERROR(partial_count_device(world, &nw, &d_counts, &counts_owner));  // [0, world): send counts, [world, 2 world): room for the received ones
+  // A rank that fails locally (drain error, out of memory ...) still takes part in the first all-to-all and sends
+  // kPeerFailed instead of its counts: every rank then returns an error instead of waiting for buckets that never come.
+  Status st;
+  auto counts_owner = device_alloc(sizeof(uint64_t) * (size_t)world * 2, &st);  // [0, world): send counts, [world, 2 world): received ones
+  if (!counts_owner) return st;
+  uint64_t* d_counts = (uint64_t*)counts_owner.get();
+  Status local = exchange_drain();
+  if (exchange_dicts() > 0) local = globalise_dictionaries(this, c, local, &host_syncs);
+  if (local.ok()) local = exchange_count(world, d_counts);
+  if (!local.ok()) DFX_HIP(hipMemsetAsync(d_counts, 0xFF, sizeof(uint64_t) * (size_t)world, s));
+  DFX_HIP(hipMemsetAsync(d_counts + world, 0, sizeof(uint64_t) * (size_t)world, s));
   DFX_RETURN_IF_ERROR(all_to_all_words(
       c, [&](int peer, const void** p, size_t* n) { *p = d_counts + peer; *n = 1; },
       [&](int peer, void** p, size_t* n) { *p = d_counts + world + peer; *n = 1; }, s));
   std::vector<uint64_t> hc((size_t)world * 2);
   DFX_HIP(hipMemcpyAsync(hc.data(), d_counts, sizeof(uint64_t) * hc.size(), hipMemcpyDeviceToHost, s));
-  DFX_HIP(hipStreamSynchronize(s));  // the ONE read-back of the exchange: buffer sizes
+  DFX_HIP(hipStreamSynchronize(s));  // the ONE read-back of the exchange proper: buffer sizes
   ++host_syncs;
-  std::vector<int64_t> recv_counts((size_t)world, 0);
+  if (!local.ok()) return local;
+  for (int r = 0; r < world; ++r)
+    if (hc[(size_t)world + r] == kPeerFailed) return Status::Err(DFX_EXECUTION_ERROR, strfmt("multi-GPU exchange: rank %d failed before the exchange", r));
+  std::vector<int64_t> send_counts((size_t)world, 0), recv_counts((size_t)world, 0);
   std::vector<uint64_t> sbase((size_t)world + 1, 0), rbase((size_t)world + 1, 0);
   for (int r = 0; r < world; ++r) {
     send_counts[r] = (int64_t)hc[r];
@@ -171,23 +279,50 @@ Status AggregateRelation::exchange(dfx_comm* c, int64_t* stats) {
     sbase[r + 1] = sbase[r] + hc[r];
     rbase[r + 1] = rbase[r] + hc[(size_t)world + r];
   }
-  Status st;
-  auto send = device_alloc(sizeof(uint64_t) * (size_t)std::max<uint64_t>(1, sbase[world] * (uint64_t)nw), &st);
-  if (!send) return st;
-  auto recv = device_alloc(sizeof(uint64_t) * (size_t)std::max<uint64_t>(1, rbase[world] * (uint64_t)nw), &st);
-  if (!recv) return st;
-  DFX_RETURN_IF_ERROR(partial_export_with(send_counts, send.get(), (int64_t)(sbase[world] * (uint64_t)nw), /*sync=*/false));
+  const int n_chunks = exchange_chunks();
+  int widest = 0;
+  for (int ch = 0; ch < n_chunks; ++ch) widest = std::max(widest, exchange_chunk_words(ch));
+  // every allocation of the payload rounds happens BEFORE them, and the ranks tell each other whether it worked
+  auto send = device_alloc(sizeof(uint64_t) * (size_t)std::max<uint64_t>(1, sbase[world] * (uint64_t)widest), &st);
+  std::shared_ptr<void> recv;
+  Status ready = st;
+  if (send) recv = device_alloc(sizeof(uint64_t) * (size_t)std::max<uint64_t>(1, rbase[world] * (uint64_t)widest), &ready);
+  if (ready.ok() && send && recv) ready = exchange_import_begin(rbase[world]);
+  if (world > 1) {
+    const uint64_t flag = (ready.ok() && send && recv) ? 1ull : kPeerFailed;
+    std::vector<uint64_t> hf((size_t)world * 2, flag);
+    DFX_HIP(hipMemcpy(d_counts, hf.data(), sizeof(uint64_t) * hf.size(), hipMemcpyHostToDevice));
+    DFX_RETURN_IF_ERROR(all_to_all_words(
+        c, [&](int peer, const void** p, size_t* n) { *p = d_counts + peer; *n = 1; },
+        [&](int peer, void** p, size_t* n) { *p = d_counts + world + peer; *n = 1; }, s));
+    DFX_HIP(hipMemcpyAsync(hf.data(), d_counts, sizeof(uint64_t) * hf.size(), hipMemcpyDeviceToHost, s));
+    DFX_HIP(hipStreamSynchronize(s));
+    ++host_syncs;
+    if (!ready.ok() || !send || !recv) return ready.ok() ? Status::Err(DFX_EXECUTION_ERROR, "multi-GPU exchange: out of device memory") : ready;
+    for (int r = 0; r < world; ++r)
+      if (r != c->rank && hf[(size_t)world + r] == kPeerFailed)
+        return Status::Err(DFX_EXECUTION_ERROR, strfmt("multi-GPU exchange: rank %d could not allocate its buffers", r));
+  } else if (!ready.ok() || !send || !recv) {
+    return ready.ok() ? Status::Err(DFX_EXECUTION_ERROR, "multi-GPU exchange: out of device memory") : ready;
+  }
   uint64_t* sw = (uint64_t*)send.get();
   uint64_t* rw = (uint64_t*)recv.get();
-  DFX_RETURN_IF_ERROR(all_to_all_words(
-      c, [&](int peer, const void** p, size_t* n) { *p = sw + sbase[peer] * (uint64_t)nw; *n = (size_t)(hc[peer] * (uint64_t)nw); },
-      [&](int peer, void** p, size_t* n) { *p = rw + rbase[peer] * (uint64_t)nw; *n = (size_t)(hc[(size_t)world + peer] * (uint64_t)nw); }, s));
-  DFX_RETURN_IF_ERROR(partial_import(recv.get(), recv_counts.data(), world));  // merges on the same stream, synchronises once
+  int64_t sent_words = 0;
+  for (int ch = 0; ch < n_chunks; ++ch) {  // accumulators beyond kMaxAggs: one round per chunk of planes, the same keys every time
+    const uint64_t nw = (uint64_t)exchange_chunk_words(ch);
+    DFX_RETURN_IF_ERROR(exchange_export_chunk(ch, send_counts, send.get(), (int64_t)(sbase[world] * nw)));
+    DFX_RETURN_IF_ERROR(all_to_all_words(
+        c, [&](int peer, const void** p, size_t* n) { *p = sw + sbase[peer] * nw; *n = (size_t)(hc[peer] * nw); },
+        [&](int peer, void** p, size_t* n) { *p = rw + rbase[peer] * nw; *n = (size_t)(hc[(size_t)world + peer] * nw); }, s));
+    DFX_RETURN_IF_ERROR(exchange_import_chunk(ch, recv.get(), recv_counts.data(), world));  // merges on the same stream
+    sent_words += (int64_t)(sbase[world] * nw);
+  }
+  DFX_RETURN_IF_ERROR(exchange_import_finish());  // the one synchronisation of the payload rounds
   ++host_syncs;
   if (stats) {
     stats[0] = (int64_t)sbase[world];
     stats[1] = (int64_t)rbase[world];
-    stats[2] = (int64_t)(sizeof(uint64_t) * sbase[world] * (uint64_t)nw);
+    stats[2] = (int64_t)sizeof(uint64_t) * sent_words;
     stats[3] = host_syncs;
   }
   return Status::OK();
@@ -238,6 +373,7 @@ int32_t dfx_comm_init(const uint8_t* id, int32_t world, int32_t rank, dfx_comm**
 
 void dfx_comm_destroy(dfx_comm* c) {
   if (!c) return;
+  (void)hipStreamSynchronize(ctx().stream);  // nothing of this communicator is still queued on the library's stream
   if (c->comm && rccl().CommDestroy) (void)rccl().CommDestroy(c->comm);
   delete c;
 }

@@ -92,33 +92,41 @@ __global__ __launch_bounds__(kBlock) void k_predicate_mask(const DevProgram P, c
 // K1 + K4 in one pass: single-pass FilterRelation
 // ---------------------------------------------------------------------------------------------
 // The two-pass form (k_predicate_mask -> scan of the tile counts -> k_compact) reads a predicate column twice: once to
-// evaluate it, once to compact it.  Here a workgroup evaluates a 4096-row tile, parks the passing rows' values of up to
-// kFusedOutCols of the predicate's own columns in LDS (wave-private segments: position = rows the wave kept so far +
-// rank inside the ballot word), learns where its tile starts in the output from a LOOK-BACK over the kept counts of the
-// tiles before it, and copies its segments out in whole coalesced runs.  Row order is preserved (filter.rs:86-90).  The
-// Arrow bitmap and the per-tile exclusive offsets are written as well: every OTHER column of the batch is compacted by
-// k_compact from them, reading it once, too.
+// evaluate it, once to compact it.  Here a workgroup evaluates a SUPER-TILE of four 4096-row tiles (one tile per wave),
+// parks the passing rows' values of up to kFusedOutCols of the predicate's own columns in LDS (wave-private segments:
+// position = rows the wave kept so far + rank inside the ballot word), learns where its super-tile starts in the output
+// from a LOOK-BACK over the kept counts of the super-tiles before it, and copies its segments out in whole coalesced
+// runs.  Row order is preserved (filter.rs:86-90).  The Arrow bitmap and the per-tile exclusive offsets are written as
+// well: every OTHER column of the batch is compacted by k_compact from them, reading it once, too.
 //
-// Look-back, two levels.  Tiles are dealt round-robin to a co-resident grid (G ~ 1000 workgroups), which therefore runs
-// in lockstep: the G tiles of a round publish their counts at about the same time and every one of them needs the sum
-// of all earlier ones.  A flat decoupled look-back (64 predecessors per step) walks G/128 windows on average -- first
-// version of this kernel: ~12 us per tile against 5 us of streaming.  So: one status word per TILE {ready, count}, one per
-// GROUP of 64 consecutive tiles {aggregate | inclusive prefix}.  A tile adds up (a) the counts of the tiles before it in
-// its own group -- one 64-wide load -- and (b) the prefix before its group from the group words -- one more 64-wide load
-// that covers 4096 tiles; both loads are in flight together.  The last tile of a group publishes the group's aggregate
-// as soon as it has (a), and the group's inclusive prefix when it has (b).
-// Forward progress: every workgroup takes its tiles in increasing order, publishes a tile's count BEFORE it waits, a
-// group aggregate needs tile counts only, a group prefix needs aggregates and the nearest earlier prefix (group 0 needs
-// none): the smallest unpublished word never waits for anything unpublished.  The grid must be co-resident
-// (launch_filter_fused sizes it from the occupancy API); the spin is bounded all the same (error bit 8).
-// The column loads are software-pipelined ACROSS tiles: the first loads of a workgroup's next tile are in flight while it
-// sits in the two barriers and the look-back of the current one.
+// Look-back, two levels.  Super-tiles are dealt round-robin to a co-resident grid (G ~ 1000 workgroups), which therefore
+// runs in lockstep: the G super-tiles of a round publish their counts at about the same time and every one of them needs
+// the sum of all earlier ones.  A flat decoupled look-back (64 predecessors per step) walks G/128 windows on average, and
+// a status round trip under a streaming load costs microseconds (first version of this kernel, 4096-row units: 12 us of
+// look-back per 5 us of streaming; two levels: still ~10 us, three dependent round trips).  So: (a) one status word per
+// SUPER-TILE {ready, count} and one per GROUP of 64 consecutive super-tiles {aggregate | inclusive prefix}: a super-tile
+// adds up the counts of the super-tiles before it in its own group -- one 64-wide load -- and the prefix before its group
+// from the group words -- one more 64-wide load that covers 4096 units; both loads are in flight together; the last
+// super-tile of a group publishes the group's aggregate as soon as it has the former, and the group's inclusive prefix
+// when it has the latter; (b) 128 KB of column per synchronisation instead of 32; (c) the column loads are
+// software-pipelined ACROSS super-tiles: a workgroup's first loads of its next super-tile are in flight while it sits in
+// the two barriers and the look-back of the current one.
+// LDS: a wave parks at most kFusedStage values per column (a quarter of its tile: selectivities up to ~24 %); a wave that
+// keeps more reads its tile's passing rows AGAIN after the look-back (the bitmap words are in LDS) -- dense filters fall
+// back to two reads of the column for those tiles, never to a wrong result.
+// Forward progress: every workgroup takes its super-tiles in increasing order, publishes a count BEFORE it waits, a group
+// aggregate needs counts only, a group prefix needs aggregates and the nearest earlier prefix (group 0 needs none): the
+// smallest unpublished word never waits for anything unpublished.  The grid must be co-resident (launch_filter_fused
+// sizes it from the occupancy API); the spin is bounded all the same (error bit 8).
 constexpr uint64_t kLbAggregate = 1ull << 62, kLbInclusive = 2ull << 62, kLbFlags = 3ull << 62;
-constexpr int kLbGroup = 64;  // tiles per second-level word
+constexpr int kLbGroup = 64;            // super-tiles per second-level word
+constexpr int kFusedTiles = kBlock / 64;  // tiles per super-tile: one per wave
+constexpr int kFusedStage = 1024;       // values a wave can park per column
 
 size_t filter_fused_sync_words(int64_t n) {
   const size_t tiles = (size_t)((n + kTileRows - 1) / kTileRows);
-  return 2 + tiles + (tiles + kLbGroup - 1) / kLbGroup;
+  const size_t units = (tiles + kFusedTiles - 1) / kFusedTiles;
+  return 2 + units + (units + kLbGroup - 1) / kLbGroup;
 }
 
 DEV uint32_t mbcnt_u64(uint64_t m) {
@@ -130,8 +138,9 @@ DEV uint64_t wave_sum_u64(uint64_t v) {
   return v;
 }
 
+// (a compile-time signature fits 128 VGPRs -- four workgroups per CU --, the generic policies take what they need)
 template <typename POL>
-__global__ __launch_bounds__(kBlock) void k_filter_fused(const DevProgram P, const DevFastPlan F, const DevColumns C,
+__global__ __launch_bounds__(kBlock, (POL::kStaticNa == 0 && sizeof(typename POL::COLV) == 16 && POL::U == 8 && POL::kIsStatic) ? 4 : 1) void k_filter_fused(const DevProgram P, const DevFastPlan F, const DevColumns C,
                                                          const uint8_t pred, const int64_t n,
                                                          uint64_t* __restrict__ mask_words,
                                                          uint64_t* __restrict__ tile_offsets,
@@ -140,48 +149,49 @@ __global__ __launch_bounds__(kBlock) void k_filter_fused(const DevProgram P, con
   typedef typename POL::COLV COLV;
   constexpr int U = POL::U;
   constexpr int BANK = (int)(sizeof(COLV) / 8);
-  constexpr int NW = kBlock / 64;                 // waves per workgroup
-  constexpr int kWaveRows = kTileRows / NW;       // 1024: rows (16 bitmap words) per wave and tile
-  constexpr int kWaveWords = kWaveRows / 64;
-  static_assert(kLbGroup == 64, "one lane per tile of a group");
-  extern __shared__ __attribute__((aligned(16))) uint64_t stage[];  // [O.n][NW][kWaveRows] kept values
-  __shared__ uint64_t s_words[kTileRows / 64];
+  constexpr int NW = kFusedTiles;              // waves per workgroup = tiles per super-tile
+  constexpr int kTileWords = kTileRows / 64;   // 64 bitmap words per tile
+  static_assert(kLbGroup == 64 && kTileWords == 64, "one lane per unit of a group / per bitmap word of a tile");
+  extern __shared__ __attribute__((aligned(16))) uint64_t stage[];  // [O.n][NW][kFusedStage] kept values
+  __shared__ uint64_t s_words[NW * kTileWords];
   __shared__ uint32_t s_wave_cnt[NW];
   __shared__ uint64_t s_base;
   const int lane = lane_id();
   const int wave = threadIdx.x >> 6;
   const int64_t n_words = (n + 63) >> 6;
   const int64_t n_tiles = (n + kTileRows - 1) / kTileRows;
-  uint64_t* const state = sync + 2;          // per tile
-  uint64_t* const gstate = state + n_tiles;  // per group of kLbGroup tiles
+  const int64_t n_units = (n_tiles + NW - 1) / NW;
+  uint64_t* const state = sync + 2;          // per super-tile
+  uint64_t* const gstate = state + n_units;  // per group of kLbGroup super-tiles
   uint32_t err = 0;
-  int64_t tile = blockIdx.x;
+  int64_t unit = blockIdx.x;
   COLV ncol[U];
   uint32_t ncv[U];
-  if (tile < n_tiles) {  // the very first loads of this workgroup
-    const int64_t w0 = tile * (kTileRows / 64) + wave * kWaveWords;
+  if (unit < n_units) {  // the very first loads of this workgroup
+    const int64_t w0 = (unit * NW + wave) * kTileWords;
     FOR_U {
       const int64_t row = (w0 + u) * 64 + lane;
       POL::load(P, C, row, row < n, ncol[u], ncv[u]);
     }
   }
-  for (; tile < n_tiles; tile += gridDim.x) {
-    uint32_t cnt = 0;  // rows this wave has kept in this tile (wave-uniform)
-    for (int i0 = 0; i0 < kWaveWords; i0 += U) {
-      const int64_t w0 = tile * (kTileRows / 64) + wave * kWaveWords + i0;
+  for (; unit < n_units; unit += gridDim.x) {
+    const int64_t tile = unit * NW + wave;  // this wave's tile
+    uint32_t cnt = 0;                       // rows this wave has kept in its tile (wave-uniform)
+    for (int i0 = 0; i0 < kTileWords; i0 += U) {
+      const int64_t w0 = tile * kTileWords + i0;
       COLV col[U];
       uint32_t cv[U];
       FOR_U {
         col[u] = ncol[u];
         cv[u] = ncv[u];
       }
-      {  // the next trip's loads (of this tile, or the first ones of the workgroup's next tile) before this trip is evaluated
-        const bool same = i0 + U < kWaveWords;
-        const int64_t nt = same ? tile : tile + gridDim.x;
-        const int64_t w1 = nt * (kTileRows / 64) + wave * kWaveWords + (same ? i0 + U : 0);
+      {  // the next trip's loads (of this tile, or the first ones of the workgroup's next super-tile) before this trip is evaluated
+        const bool same = i0 + U < kTileWords;
+        const int64_t nu = same ? unit : unit + gridDim.x;
+        const int64_t w1 = (nu * NW + wave) * kTileWords + (same ? i0 + U : 0);
         FOR_U {
           const int64_t row = (w1 + u) * 64 + lane;
-          POL::load(P, C, row, row < n && nt < n_tiles, ncol[u], ncv[u]);
+          POL::load(P, C, row, row < n && nu < n_units, ncol[u], ncv[u]);
         }
       }
 #pragma nounroll
@@ -196,21 +206,26 @@ __global__ __launch_bounds__(kBlock) void k_filter_fused(const DevProgram P, con
         POL::eval(P, F, cur, curv, reg, rv, inb, err);
         const bool pass = inb && POL::pass(P, F, pred, cur, curv, reg, rv);
         const uint64_t word = __ballot(pass);
-        if (lane == 0) s_words[wave * kWaveWords + i0 + uu] = word;
-        if (pass) {
-          const uint32_t at = cnt + mbcnt_u64(word);
+        if (lane == 0) s_words[wave * kTileWords + i0 + uu] = word;
+        const uint32_t at = cnt + mbcnt_u64(word);
+        if (pass && at < (uint32_t)kFusedStage) {
 #pragma unroll
           for (int o = 0; o < kFusedOutCols; ++o) {
             if (o < O.n) {
               uint64_t v = cur[0];
 #pragma unroll
               for (int c = 1; c < BANK; ++c) v = (O.slot[o] == c) ? cur[c] : v;
-              stage[(size_t)(o * NW + wave) * kWaveRows + at] = v;
+              stage[(size_t)(o * NW + wave) * kFusedStage + at] = v;
             }
           }
         }
         cnt += (uint32_t)__popcll(word);
       }
+    }
+    {  // this tile's 64 bitmap words: one coalesced 512-byte store per wave
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      const int64_t w = tile * kTileWords + lane;
+      if (w < n_words) mask_words[w] = s_words[wave * kTileWords + lane];
     }
     if (lane == 0) s_wave_cnt[wave] = cnt;
     __syncthreads();
@@ -222,19 +237,17 @@ __global__ __launch_bounds__(kBlock) void k_filter_fused(const DevProgram P, con
       A += wc[k];
     }
     if (wave == 0) {
-      const int64_t w = tile * (kTileRows / 64) + lane;  // the tile's 64 bitmap words: one coalesced 512-byte store
-      if (w < n_words) mask_words[w] = s_words[lane];
-      if (lane == 0) __hip_atomic_store(&state[tile], kLbAggregate | (uint64_t)A, RLX_AGENT);
-      const int64_t g = tile / kLbGroup;
-      const int q = (int)(tile % kLbGroup);
-      const bool last_of_group = q == kLbGroup - 1 || tile == n_tiles - 1;
+      if (lane == 0) __hip_atomic_store(&state[unit], kLbAggregate | (uint64_t)A, RLX_AGENT);
+      const int64_t g = unit / kLbGroup;
+      const int q = (int)(unit % kLbGroup);
+      const bool last_of_group = q == kLbGroup - 1 || unit == n_units - 1;
       bool need_w = q > 0, need_g = g > 0, agg_pending = last_of_group && g > 0;
       uint64_t within = 0, before = 0;
       int64_t ghi = g - 1;  // lane l looks at group ghi - l
       uint32_t spins = 0;
       while (need_w || need_g) {
         uint64_t st = 0, gs = 0;
-        if (need_w) st = __hip_atomic_load(&state[lane < q ? tile - 1 - lane : tile], RLX_AGENT);
+        if (need_w) st = __hip_atomic_load(&state[lane < q ? unit - 1 - lane : unit], RLX_AGENT);
         if (need_g) {
           const int64_t gj = ghi - lane;
           gs = __hip_atomic_load(&gstate[gj >= 0 ? gj : 0], RLX_AGENT);
@@ -242,7 +255,7 @@ __global__ __launch_bounds__(kBlock) void k_filter_fused(const DevProgram P, con
         }
         bool moved = false;
         if (need_w) {
-          if (__ballot(lane < q && (st & kLbFlags) == 0) == 0) {  // every tile before this one in its group has published
+          if (__ballot(lane < q && (st & kLbFlags) == 0) == 0) {  // every unit before this one in its group has published
             within = wave_sum_u64(lane < q ? (st & ~kLbFlags) : 0ull);
             need_w = false;
           }
@@ -278,35 +291,47 @@ __global__ __launch_bounds__(kBlock) void k_filter_fused(const DevProgram P, con
       const uint64_t base = before + within;
       if (lane == 0) {
         if (last_of_group) __hip_atomic_store(&gstate[g], kLbInclusive | (base + (uint64_t)A), RLX_AGENT);
-        tile_offsets[tile] = base;
         s_base = base;
-        if (tile == n_tiles - 1) {
+        if (unit == n_units - 1) {
           tile_offsets[n_tiles] = base + (uint64_t)A;
           sync[1] = base + (uint64_t)A;  // kept rows of the batch
         }
       }
     }
     __syncthreads();
-    if (O.n > 0) {
-      uint64_t my_base = s_base;
+    uint64_t my_base = s_base;
 #pragma unroll
-      for (int k = 0; k < NW; ++k)
-        if (k < wave) my_base += wc[k];
+    for (int k = 0; k < NW; ++k)
+      if (k < wave) my_base += wc[k];
+    if (lane == 0 && tile < n_tiles) tile_offsets[tile] = my_base;
 #pragma unroll
-      for (int o = 0; o < kFusedOutCols; ++o) {
-        if (o < O.n) {
-          const uint64_t* src = stage + (size_t)(o * NW + wave) * kWaveRows;
-          const uint8_t t = O.dtype[o];
+    for (int o = 0; o < kFusedOutCols; ++o) {
+      if (o < O.n) {
+        const uint8_t t = O.dtype[o];
+        if (cnt <= (uint32_t)kFusedStage) {  // (wave-uniform) everything this wave kept is parked in LDS
+          const uint64_t* src = stage + (size_t)(o * NW + wave) * kFusedStage;
           if (t == T_F64 || t == T_I64 || t == T_U64) {
             uint64_t* dst = (uint64_t*)O.out[o] + my_base;
             for (uint32_t j = (uint32_t)lane; j < cnt; j += 64) dst[j] = src[j];
           } else {
             for (uint32_t j = (uint32_t)lane; j < cnt; j += 64) store_typed(t, O.out[o], (int64_t)(my_base + j), src[j]);
           }
+        } else {  // a dense tile: its passing rows are read again (bitmap words from LDS), as k_compact would
+          const int slot = O.slot[o];
+          uint32_t run = 0;
+          for (int i = 0; i < kTileWords; ++i) {
+            const uint64_t word = s_words[wave * kTileWords + i];
+            if ((word >> lane) & 1ull) {
+              const int64_t row = (tile * kTileWords + i) * 64 + lane;
+              const uint64_t v = load_canonical(t, C.c[slot].values, row, C.c[slot].bit_offset);
+              store_typed(t, O.out[o], (int64_t)(my_base + run + mbcnt_u64(word)), v);
+            }
+            run += (uint32_t)__popcll(word);
+          }
         }
       }
     }
-    // (the next tile's first barrier separates these reads of s_base / stage from their next writes)
+    // (the next super-tile's first barrier separates these reads of s_base / s_words / stage from their next writes)
   }
   if (err) atomicOr(&ctrl[CTRL_ERROR], err);
 }
@@ -835,7 +860,7 @@ template <typename POL>
 static hipError_t filter_fused_launch(const DevProgram& P, const DevFastPlan& fast, const DevColumns& C, uint8_t pred, int64_t n,
                                       uint64_t* mask_words, uint64_t* tile_offsets, uint64_t* sync, const DevFusedOut& O,
                                       uint32_t* ctrl, hipStream_t s) {
-  const size_t lds = (size_t)O.n * kTileRows * sizeof(uint64_t);
+  const size_t lds = (size_t)O.n * kFusedTiles * kFusedStage * sizeof(uint64_t);
   // the grid must be co-resident (the look-back waits for other workgroups): workgroups per CU from the occupancy API,
   // asked once per (policy, LDS size)
   static int per_cu[kFusedOutCols + 1] = {0, 0, 0};
@@ -846,8 +871,9 @@ static hipError_t filter_fused_launch(const DevProgram& P, const DevFastPlan& fa
     per_cu[O.n] = nb > 0 ? nb : 1;
   }
   const int64_t tiles = (n + kTileRows - 1) / kTileRows;
+  const int64_t units = (tiles + kFusedTiles - 1) / kFusedTiles;
   const int64_t cap = (int64_t)device_cu_count() * per_cu[O.n];
-  const int grid = (int)(tiles < cap ? tiles : cap);
+  const int grid = (int)(units < cap ? units : cap);
   hipLaunchKernelGGL((k_filter_fused<POL>), dim3(grid), dim3(kBlock), lds, s, P, fast, C, pred, n, mask_words, tile_offsets, sync, O, ctrl);
   return hipGetLastError();
 }

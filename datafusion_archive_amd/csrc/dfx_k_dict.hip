@@ -10,6 +10,8 @@
 // publishes inside the loop iteration in which it won, so lanes of the same wave that wait on it cannot
 // starve it.  Ids never change when the slot table is rebuilt (growth), hence ids already stored in the
 // group table stay valid.
+#include <algorithm>
+
 #include "dfx_kernels_inl.hpp"
 #include "dfx_launch.hpp"
 
@@ -131,6 +133,20 @@ hipError_t launch_dict_encode(const int32_t* offsets, const uint8_t* data, int64
 hipError_t launch_dict_rebuild(const DevDict& D, uint64_t n_ids, hipStream_t s) {
   if (n_ids == 0) return hipSuccess;
   hipLaunchKernelGGL(k_dict_rebuild, dim3((unsigned)((n_ids + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, D, n_ids);
+  return hipGetLastError();
+}
+// multi-GPU exchange of Utf8 keys: the rank-local ids of a key plane become GLOBAL ids (remap[local id]); slots that hold no
+// id (empty: kEmptyKey or stale words >= n_ids) are left alone
+__global__ __launch_bounds__(kBlock) void k_dict_remap_plane(uint64_t* __restrict__ plane, uint64_t n_slots, const uint64_t* __restrict__ remap,
+                                                             uint64_t n_ids) {
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n_slots; i += (uint64_t)gridDim.x * kBlock) {
+    const uint64_t v = plane[i];
+    if (v < n_ids) plane[i] = remap[v];
+  }
+}
+hipError_t launch_dict_remap_plane(uint64_t* plane, uint64_t n_slots, const uint64_t* remap, uint64_t n_ids, hipStream_t s) {
+  if (n_slots == 0 || n_ids == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_dict_remap_plane, dim3((unsigned)std::min<uint64_t>((n_slots + kBlock - 1) / kBlock, 4096)), dim3(kBlock), 0, s, plane, n_slots, remap, n_ids);
   return hipGetLastError();
 }
 hipError_t launch_dict_lengths(const uint64_t* ids, int64_t g, const DevDict& D, uint32_t* lens, hipStream_t s) {

@@ -268,24 +268,28 @@ __global__ __launch_bounds__(kRingBlock) void k_partition_ws(const DevProgram P,
   snapshot_ctrl_if_last(T, PT);
 }
 
-// WSALL: also instantiate the 8- and 14-scanner splits (the headline's variant: A/B runs by agg.pass1_ws)
-template <typename POLN, bool WSALL>
+// DevPartition::ws_scanners = scanner waves + 100 if the scanners take 8 row groups per trip instead of the policy's own U.
+// WSALL (the headline's variant): every split is instantiated (A/B runs by agg.pass1_ws); the other variants have the default only.
+constexpr uint32_t kWsDefault = 8;
+template <typename POLN, typename POLN8, bool WSALL>
 void launch_partition_ws(const DevProgram& P, const DevFastPlan& fast, const DevColumns& C, const DevAggPlan& plan, const DevTable& T,
                          const DevPartition& PT, const DevRows& spill, int64_t n, size_t lds_bytes, hipStream_t s) {
   const int grid = (int)PT.n_producers;
-  if (WSALL && PT.ws_scanners == 8)
-    hipLaunchKernelGGL((k_partition_ws<POLN, WSALL ? 8 : 12>), dim3(grid), dim3(kRingBlock), lds_bytes, s, P, fast, C, plan, T, PT, spill, n);
-  else if (WSALL && PT.ws_scanners == 14)
-    hipLaunchKernelGGL((k_partition_ws<POLN, WSALL ? 14 : 12>), dim3(grid), dim3(kRingBlock), lds_bytes, s, P, fast, C, plan, T, PT, spill, n);
-  else
-    hipLaunchKernelGGL((k_partition_ws<POLN, 12>), dim3(grid), dim3(kRingBlock), lds_bytes, s, P, fast, C, plan, T, PT, spill, n);
+#define DFX_WS(POLX, NSX) hipLaunchKernelGGL((k_partition_ws<POLX, NSX>), dim3(grid), dim3(kRingBlock), lds_bytes, s, P, fast, C, plan, T, PT, spill, n)
+  if (WSALL && PT.ws_scanners == 108) DFX_WS(POLN8, WSALL ? 8 : (int)kWsDefault);
+  else if (WSALL && PT.ws_scanners == 106) DFX_WS(POLN8, WSALL ? 6 : (int)kWsDefault);
+  else if (WSALL && PT.ws_scanners == 110) DFX_WS(POLN8, WSALL ? 10 : (int)kWsDefault);
+  else if (WSALL && PT.ws_scanners == 10) DFX_WS(POLN, WSALL ? 10 : (int)kWsDefault);
+  else if (WSALL && PT.ws_scanners == 12) DFX_WS(POLN, WSALL ? 12 : (int)kWsDefault);
+  else DFX_WS(POLN, (int)kWsDefault);
+#undef DFX_WS
 }
 
 // one pass-1 variant = one translation unit: the ring / sorted / direct kernels of the policy plus its wave-specialised kernel
-#define DFX_PARTITION_VARIANT_WS(ID, WSALL, POL, POLS, POLN)                                                               \
+#define DFX_PARTITION_VARIANT_WS(ID, WSALL, POL, POLS, POLN, POLN8)                                                        \
   void launch_partition_variant##ID(DFX_PARTITION_VARIANT_ARGS) {                                                          \
     if (PT.flags & PTF_WS)                                                                                                 \
-      launch_partition_ws<POLN, WSALL>(P, fast, C, plan, T, PT, spill, n, lds_bytes, s);                                   \
+      launch_partition_ws<POLN, POLN8, WSALL>(P, fast, C, plan, T, PT, spill, n, lds_bytes, s);                            \
     else                                                                                                                   \
       launch_partition_pol<POL, POLS, POLN>(P, fast, C, plan, T, PT, spill, n, lds_bytes, s);                              \
   }

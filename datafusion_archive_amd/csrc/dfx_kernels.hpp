@@ -137,6 +137,7 @@ hipError_t launch_merge_bucket(const uint64_t* bucket, uint64_t count, const Dev
 hipError_t launch_dict_encode(const int32_t* offsets, const uint8_t* data, int64_t n, const DevDict& D, uint64_t* ids,
                               hipStream_t s);
 hipError_t launch_dict_rebuild(const DevDict& D, uint64_t n_ids, hipStream_t s);
+hipError_t launch_dict_remap_plane(uint64_t* plane, uint64_t n_slots, const uint64_t* remap, uint64_t n_ids, hipStream_t s);
 hipError_t launch_dict_lengths(const uint64_t* ids, int64_t g, const DevDict& D, uint32_t* lens, hipStream_t s);
 hipError_t launch_dict_gather(const uint64_t* ids, int64_t g, const DevDict& D, const uint64_t* starts, int32_t* offsets,
                               uint8_t* out, hipStream_t s);

@@ -374,6 +374,7 @@ DEV bool eval_predicate(const DevProgram& P, ROWSTATE_CPARAMS, uint8_t pred) {
 // generic: the SSA register program (any expression the compiler accepts, nulls included)
 template <int BANK, int U_>
 struct InterpPolicy {
+  static constexpr bool kIsStatic = false;
   static constexpr int U = U_;
   static constexpr int kStaticNa = 0;  // aggregates known at compile time (0: run-time)
   typedef typename Bank<BANK>::type COLV;
@@ -442,6 +443,7 @@ DEV bool lane_of_mask(uint64_t mask) { return __builtin_amdgcn_inverse_ballot_w6
 // short-product arguments; no nulls.  Straight-line code, the only scalar work is reading the plan.
 template <int BANK, int U_>
 struct FastPolicy {
+  static constexpr bool kIsStatic = false;
   static constexpr int U = U_;
   static constexpr int kStaticNa = 0;  // aggregates known at compile time (0: run-time)
   typedef typename Bank<BANK>::type COLV;
@@ -509,6 +511,7 @@ struct FastPolicy1 : FastPolicy<BANK, U_> {
 // run-time inputs are the comparison masks and the literals.
 template <int BANK, int U_, typename SIG>
 struct StaticPolicy {
+  static constexpr bool kIsStatic = true;
   static constexpr int U = U_;
   static constexpr int kStaticNa = SIG::NA;
   typedef typename Bank<BANK>::type COLV;

@@ -149,8 +149,9 @@ struct AggOptions {
   int calibration_memo = 1;    // 1: a resident table remembers the outcome of an aggregate's calibration slice per program shape
   int pass2_stream = 1;        // pass 2 of one-aggregate queries: region-streaming kernel (0: the flattened-index kernel)
   int fewgroup = 1;            // <= 8 groups after calibration: register accumulators (dfx_k_fewgroup.hip); 0: LDS front cache
-  int pass1_ws = 12;           // pass 1 of selective scans over narrow keys: wave-specialised kernel with this many scanner waves of 16
-                               // (8, 12 or 14; 0: the ring kernel, every wave scans and routes)
+  int pass1_ws = 8;            // pass 1 of selective scans over narrow keys: wave-specialised kernel with this many scanner waves of 16
+                               // (0: the ring kernel, every wave scans and routes; the headline's signature also has 6 / 10 / 12
+                               // and, + 100, eight row groups per scanner trip: A/B runs)
   int filter_single_pass = 1;  // FilterRelation: predicate + bitmap + tile offsets (decoupled look-back) + compaction of the predicate's own
                                // columns in ONE kernel (0: k_predicate_mask -> scan -> k_compact, the column is read twice)
   int replay_in_place = 1;     // 1: rows spilled by a table that is NOT full (region overflow of a heavy key) are replayed into the
@@ -182,6 +183,22 @@ class AggregateRelation : public Relation {
   Status ungrouped_state_merge(const uint64_t* all_states, int world, int rank);  // fold the ranks' states, in rank order
   Status partial_count_device(int world, int* n_words, uint64_t** d_counts, std::shared_ptr<void>* owner);  // counts stay on the device
   Status partial_export_with(const std::vector<int64_t>& counts, void* dst_device, int64_t dst_words, bool sync);
+  // the pieces of the in-library exchange (dfx_exchange.cpp).  Accumulators beyond kMaxAggs live in several chunks of planes
+  // over the same keys: groups are counted once, every chunk is exported / sent / merged with its own planes.  Utf8 keys:
+  // the rank-local dictionary ids are turned into ids of a dictionary every rank builds identically (all ranks' strings
+  // in rank order), the key planes are rewritten, and the groups travel like integer keys.
+  int exchange_chunks() const;
+  int exchange_chunk_words(int c) const;           // key words + accumulators of chunk c
+  Status exchange_drain();                          // drains the input (grouped), no device work otherwise
+  Status exchange_count(int world, uint64_t* d_counts);  // groups per destination rank into d_counts[0, world) (zeroed here)
+  Status exchange_export_chunk(int c, const std::vector<int64_t>& counts, void* dst_device, int64_t dst_words);
+  Status exchange_import_begin(uint64_t total_groups);
+  Status exchange_import_chunk(int c, const void* src_device, const int64_t* counts, int n_buckets);
+  Status exchange_import_finish();
+  int exchange_dicts() const;                       // Utf8 GROUP BY keys
+  Status exchange_dict_local(int d, std::vector<uint32_t>* lens, std::vector<uint8_t>* pool);  // strings by local id
+  Status exchange_dict_globalise(int d, const std::vector<uint32_t>& lens, const std::vector<uint8_t>& pool, const std::vector<uint64_t>& remap);
+  Status ungrouped_select_chunk(int c);
 
   struct Impl;
 
