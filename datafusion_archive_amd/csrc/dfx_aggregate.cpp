@@ -239,7 +239,7 @@ Status AggregateRelation::Impl::setup(const SchemaInfo& input_schema) {
         chunks.push_back(std::move(ch));
         break;
       }
-      if (st.code != DFX_NOT_IMPLEMENTED || n <= 1) return st;
+      if (!program_limit_error(st) || n <= 1) return st;  // (a genuinely unsupported aggregate is not rebuilt kMaxAggs times)
       --n;
     }
     a0 += std::max(n, 1);
@@ -1050,7 +1050,8 @@ Status AggregateRelation::Impl::consume_batch_chunk(const DeviceBatch& b) {
   T.max_probe = may_spill ? 128 : (int)std::min<uint64_t>(T.mask + 1, 1u << 30);
   int64_t row0 = 0;
   const AggOptions& o = agg_options();
-  ScanMemo* memo = o.calibration_memo ? input->scan_memo() : nullptr;
+  // (a batch that went through a real FilterRelation is not the table's first rows: its calibration says nothing about them)
+  ScanMemo* memo = (o.calibration_memo && !unfused_now) ? input->scan_memo() : nullptr;
   uint64_t remembered = 0;
   if (!lds_calibrated && o.strategy == 0 && n > (1 << 21) && memo && memo->lookup(program_fingerprint(), &remembered)) {
     // an earlier query of this shape over the same resident table already ran the calibration slice: same decision,
@@ -1656,7 +1657,9 @@ Status AggregateRelation::next(DeviceBatch* out, bool* has) {
     return Status::Err(DFX_INTERNAL_ERROR, "assertion failed: record batch needs at least one column");
   DFX_RETURN_IF_ERROR(m.drain());
   if (m.kw == 0) DFX_RETURN_IF_ERROR(m.emit_ungrouped(out));
-  else DFX_RETURN_IF_ERROR(m.emit_grouped(out, agg_options().emit_async ? (int64_t)m.occupied_known : -1));
+  // (Utf8 keys: dict_emit indexes the dictionary with the compacted ids before the scan's total could contradict the host's
+  // count -- the table's own count first, one round trip more)
+  else DFX_RETURN_IF_ERROR(m.emit_grouped(out, (agg_options().emit_async && m.dicts.empty()) ? (int64_t)m.occupied_known : -1));
   *has = true;
   return Status::OK();
 }
@@ -1930,7 +1933,8 @@ Status AggregateRelation::ungrouped_state_merge(const uint64_t* all, int world, 
   uint64_t out[2 * kMaxAggs];
   memset(out, 0, sizeof(out));
   for (int a = 0; a < m.na; ++a) {
-    const int t = m.arg_dtype[a], f = m.func[a];
+    const int a0 = m.chunks[(size_t)m.cur_chunk].a0;  // arg_dtype / func are indexed over ALL accumulators, the state block over the active chunk's
+    const int t = m.arg_dtype[a0 + a], f = m.func[a0 + a];
     bool has = false;
     uint64_t cur = 0;
     for (int r = 0; r < world; ++r) {

@@ -213,6 +213,8 @@ struct Pool {
     const size_t q = 1u << 20;  // 1 MiB granules above 1 MiB
     return (b + q - 1) / q * q;
   }
+  static constexpr size_t kSpareBudget = (size_t)1 << 30;
+  size_t spare_bytes = 0;  // (only read / written on the allocation path of the pinned pool)
   void* take(size_t bytes, hipError_t* e) {
     {
       std::lock_guard<std::mutex> lk(mu);
@@ -232,9 +234,16 @@ struct Pool {
     // Pinning a large host buffer costs milliseconds (measured: 13-17 ms for the two 8 MB result columns of a 10^6-group
     // aggregate whenever a query found the pool empty because the consumer still held the previous result).  A miss on
     // a large pinned block therefore stocks one spare of the same size: the next miss becomes a hit.
-    if (p && pinned && bytes >= (1u << 20) && bytes <= (256u << 20)) {
+    // Bounded: at most kSpareBudget bytes of spares over the life of the pool (workloads with many distinct result sizes would
+    // otherwise double their locked host memory), and a spare that cannot be had leaves no sticky HIP error behind.
+    if (p && pinned && bytes >= (1u << 20) && bytes <= (256u << 20) && spare_bytes + bytes <= kSpareBudget) {
       void* spare = nullptr;
-      if (hipHostMalloc(&spare, bytes, hipHostMallocDefault) == hipSuccess && spare) give(bytes, spare);
+      if (hipHostMalloc(&spare, bytes, hipHostMallocDefault) == hipSuccess && spare) {
+        spare_bytes += bytes;
+        give(bytes, spare);
+      } else {
+        (void)hipGetLastError();  // (the next launch_* that returns hipGetLastError() must not report this)
+      }
     }
     return p;
   }

@@ -10,6 +10,7 @@
 
 #include <exception>
 #include <memory>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -178,9 +179,11 @@ struct Relation {
   // the second query of the same shape does not pay for the slice and its synchronous read-back again.
   virtual struct ScanMemo* scan_memo() { return nullptr; }
 };
-struct ScanMemo {
+struct ScanMemo {  // shared by every scan of a resident table (a `mutable` member of a const TableData): guarded
+  mutable std::mutex mu;
   std::vector<std::pair<uint64_t, uint64_t>> calibrated_groups;  // (program fingerprint, groups in the first 2^18 rows)
   bool lookup(uint64_t fp, uint64_t* groups) const {
+    std::lock_guard<std::mutex> lk(mu);
     for (const auto& e : calibrated_groups)
       if (e.first == fp) {
         *groups = e.second;
@@ -189,6 +192,7 @@ struct ScanMemo {
     return false;
   }
   void remember(uint64_t fp, uint64_t groups) {
+    std::lock_guard<std::mutex> lk(mu);
     for (auto& e : calibrated_groups)
       if (e.first == fp) {
         e.second = groups;

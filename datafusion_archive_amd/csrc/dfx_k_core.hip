@@ -16,6 +16,7 @@
 
 #include <mutex>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include <algorithm>
@@ -164,16 +165,13 @@ __global__ __launch_bounds__(kBlock, (POL::kStaticNa == 0 && sizeof(typename POL
   uint64_t* const state = sync + 2;          // per super-tile
   uint64_t* const gstate = state + n_units;  // per group of kLbGroup super-tiles
   uint32_t err = 0;
+  // the whole loop once per comparison FORM (StaticPolicy::pass_form: compile-time operators; 0: run-time masks)
+  auto run = [&](auto form_tag) {
+  constexpr int FORM = decltype(form_tag)::value;
   int64_t unit = blockIdx.x;
   COLV ncol[U];
   uint32_t ncv[U];
-  if (unit < n_units) {  // the very first loads of this workgroup
-    const int64_t w0 = (unit * NW + wave) * kTileWords;
-    FOR_U {
-      const int64_t row = (w0 + u) * 64 + lane;
-      POL::load(P, C, row, row < n, ncol[u], ncv[u]);
-    }
-  }
+  load_trip<POL>(P, C, (unit * NW + wave) * kTileWords, unit < n_units, n, lane, ncol, ncv);  // the very first loads of this workgroup
   for (; unit < n_units; unit += gridDim.x) {
     const int64_t tile = unit * NW + wave;  // this wave's tile
     uint32_t cnt = 0;                       // rows this wave has kept in its tile (wave-uniform)
@@ -188,23 +186,15 @@ __global__ __launch_bounds__(kBlock, (POL::kStaticNa == 0 && sizeof(typename POL
       {  // the next trip's loads (of this tile, or the first ones of the workgroup's next super-tile) before this trip is evaluated
         const bool same = i0 + U < kTileWords;
         const int64_t nu = same ? unit : unit + gridDim.x;
-        const int64_t w1 = (nu * NW + wave) * kTileWords + (same ? i0 + U : 0);
-        FOR_U {
-          const int64_t row = (w1 + u) * 64 + lane;
-          POL::load(P, C, row, row < n && nu < n_units, ncol[u], ncv[u]);
-        }
+        load_trip<POL>(P, C, (nu * NW + wave) * kTileWords + (same ? i0 + U : 0), nu < n_units, n, lane, ncol, ncv);
       }
-#pragma nounroll
-      for (int uu = 0; uu < U; ++uu) {
-        COLV cur;
-        uint32_t curv;
-        DFX_SELECT_BANK(uu, col, cv, cur, curv)
+      auto one_group = [&](const COLV& cur, uint32_t curv, int uu) {
         const int64_t w = w0 + uu;
         const bool inb = w * 64 + lane < n;
         u64x16 reg;
         uint32_t rv = 0;
         POL::eval(P, F, cur, curv, reg, rv, inb, err);
-        const bool pass = inb && POL::pass(P, F, pred, cur, curv, reg, rv);
+        const bool pass = inb && POL::template pass_form<FORM>(P, F, pred, cur, curv, reg, rv);
         const uint64_t word = __ballot(pass);
         if (lane == 0) s_words[wave * kTileWords + i0 + uu] = word;
         const uint32_t at = cnt + mbcnt_u64(word);
@@ -220,6 +210,17 @@ __global__ __launch_bounds__(kBlock, (POL::kStaticNa == 0 && sizeof(typename POL
           }
         }
         cnt += (uint32_t)__popcll(word);
+      };
+      if constexpr (POL::kIsStatic) {  // straight-line code is short here: unrolled (no scalar branch chain to pick the bank)
+        FOR_U one_group(col[u], cv[u], u);
+      } else {  // the interpreter's body is long: ONE copy, the group's bank re-selected at run time
+#pragma nounroll
+        for (int uu = 0; uu < U; ++uu) {
+          COLV cur;
+          uint32_t curv;
+          DFX_SELECT_BANK(uu, col, cv, cur, curv)
+          one_group(cur, curv, uu);
+        }
       }
     }
     {  // this tile's 64 bitmap words: one coalesced 512-byte store per wave
@@ -295,6 +296,8 @@ __global__ __launch_bounds__(kBlock, (POL::kStaticNa == 0 && sizeof(typename POL
         if (unit == n_units - 1) {
           tile_offsets[n_tiles] = base + (uint64_t)A;
           sync[1] = base + (uint64_t)A;  // kept rows of the batch
+          ctrl[CTRL_PASSED_LO] = (uint32_t)(base + (uint64_t)A);  // ... and next to the error word: ONE read-back per batch
+          ctrl[CTRL_PASSED_HI] = (uint32_t)((base + (uint64_t)A) >> 32);
         }
       }
     }
@@ -332,6 +335,14 @@ __global__ __launch_bounds__(kBlock, (POL::kStaticNa == 0 && sizeof(typename POL
       }
     }
     // (the next super-tile's first barrier separates these reads of s_base / s_words / stage from their next writes)
+  }
+  };
+  switch (POL::form_of(F)) {  // (wave-uniform: the plan sits in the kernarg segment)
+    case 4 | (1 << 3): run(std::integral_constant<int, (POL::kIsStatic ? (4 | (1 << 3)) : 0)>{}); break;  // x >  a AND x <  b
+    case 6 | (1 << 3): run(std::integral_constant<int, (POL::kIsStatic ? (6 | (1 << 3)) : 0)>{}); break;  // x >= a AND x <  b
+    case 4 | (3 << 3): run(std::integral_constant<int, (POL::kIsStatic ? (4 | (3 << 3)) : 0)>{}); break;  // x >  a AND x <= b
+    case 6 | (3 << 3): run(std::integral_constant<int, (POL::kIsStatic ? (6 | (3 << 3)) : 0)>{}); break;  // x >= a AND x <= b
+    default: run(std::integral_constant<int, 0>{}); break;
   }
   if (err) atomicOr(&ctrl[CTRL_ERROR], err);
 }

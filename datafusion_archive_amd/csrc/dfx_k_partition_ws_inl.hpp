@@ -18,6 +18,8 @@
 // pairs); rows the narrow form cannot carry (wide keys, the claim sentinel, reserved images, region overflow) take the
 // spill list exactly as in the ring kernel.  Same scratch layout, counts and padding: pass 2 cannot tell the flavours apart.
 #pragma once
+#include <type_traits>
+
 #include "dfx_k_partition_inl.hpp"
 
 namespace dfx {
@@ -114,73 +116,73 @@ __global__ __launch_bounds__(kRingBlock) void k_partition_ws(const DevProgram P,
     const int64_t n_groups = (n + 63) >> 6;
     const int64_t wave_global = (int64_t)blockIdx.x * NS + wave;
     const int64_t n_waves = (int64_t)gridDim.x * NS;
-    // software pipeline, one trip deep (as in k_partition_ring: deeper was measured no faster)
-    COLV ncol[U];
-    uint32_t ncv[U];
-    {
-      const int64_t w0 = wave_global * U;
-      FOR_U {
-        const int64_t row = (w0 + u) * 64 + lane;
-        POL::load(P, C, row, row < n && w0 < n_groups, ncol[u], ncv[u]);
-      }
-    }
-    for (int64_t w0 = wave_global * U; w0 < n_groups; w0 += n_waves * U) {
-      COLV col[U];
-      uint32_t cv[U];
-      FOR_U {
-        col[u] = ncol[u];
-        cv[u] = ncv[u];
-      }
-      {
-        const int64_t w1 = w0 + n_waves * U;
+    // The scan loop, once per comparison FORM (StaticPolicy::pass_form: the operators as compile-time constants -- one v_cmp
+    // per term instead of three and no scalar selects; 0: run-time masks).  Software pipeline, one trip deep (as in
+    // k_partition_ring: deeper was measured no faster).
+    auto scan = [&](auto form_tag) {
+      constexpr int FORM = decltype(form_tag)::value;
+      COLV ncol[U];
+      uint32_t ncv[U];
+      load_trip<POL>(P, C, wave_global * U, wave_global * U < n_groups, n, lane, ncol, ncv);
+      for (int64_t w0 = wave_global * U; w0 < n_groups; w0 += n_waves * U) {
+        COLV col[U];
+        uint32_t cv[U];
         FOR_U {
-          const int64_t row = (w1 + u) * 64 + lane;
-          POL::load(P, C, row, row < n, ncol[u], ncv[u]);
+          col[u] = ncol[u];
+          cv[u] = ncv[u];
         }
-      }
-      FOR_U {  // (unrolled, like the ring kernel's scan: a run-time loop over the U banks costs a scalar branch chain per group)
-        const COLV cur = col[u];
-        const uint32_t curv = cv[u];
-        const int64_t row = (w0 + u) * 64 + lane;
-        const bool inb = row < n;
-        u64x16 reg;
-        uint32_t rv = 0;
-        POL::eval(P, F, cur, curv, reg, rv, inb, err);
-        bool pass = inb && POL::pass(P, F, plan.pred, cur, curv, reg, rv);
-        const uint64_t key = POL::key(P, F, plan.key[0], 0, cur, curv, reg, rv);
-        uint64_t v;
-        bool valid;
-        POL::arg(P, F, plan.arg[0], 0, cur, curv, reg, rv, v, valid);
-        const uint64_t val = transform_value(POL::xform(T, 0), v, valid);
-        passed += (uint64_t)__popcll(__ballot(pass));
-        const bool slow = pass && (key >> 32) != 0;  // no 32-bit form (wide key, or the claim sentinel)
-        if (__ballot(slow) != 0) {
-          ws_slow_rows(T, spill, slow, key, val);
-          pass = pass && !slow;
-        }
-        const uint64_t m = __ballot(pass);
-        const uint32_t c = (uint32_t)__popcll(m);
-        if (c != 0) {
-          // room for c rows?  (the router publishes its position after every batch of 64 it takes)
-          uint32_t spins = 0;
-          while (tail + c - head_c > (uint32_t)kWsQueueRows) {
-            head_c = __hip_atomic_load(&my->head, __ATOMIC_ACQUIRE, WG_SCOPE);
-            if (tail + c - head_c <= (uint32_t)kWsQueueRows) break;
-            if (++spins > (1u << 22)) {  // cannot happen (a full queue always has 64 rows for its router); never hang the device
-              err |= 4u;
-              break;
+        load_trip<POL>(P, C, w0 + n_waves * U, w0 + n_waves * U < n_groups, n, lane, ncol, ncv);
+        FOR_U {  // (unrolled, like the ring kernel's scan: a run-time loop over the U banks costs a scalar branch chain per group)
+          const COLV cur = col[u];
+          const uint32_t curv = cv[u];
+          const int64_t row = (w0 + u) * 64 + lane;
+          const bool inb = row < n;
+          u64x16 reg;
+          uint32_t rv = 0;
+          POL::eval(P, F, cur, curv, reg, rv, inb, err);
+          bool pass = inb && POL::template pass_form<FORM>(P, F, plan.pred, cur, curv, reg, rv);
+          const uint64_t key = POL::key(P, F, plan.key[0], 0, cur, curv, reg, rv);
+          uint64_t v;
+          bool valid;
+          POL::arg(P, F, plan.arg[0], 0, cur, curv, reg, rv, v, valid);
+          const uint64_t val = transform_value(POL::xform(T, 0), v, valid);
+          passed += (uint64_t)__popcll(__ballot(pass));
+          const bool slow = pass && (key >> 32) != 0;  // no 32-bit form (wide key, or the claim sentinel)
+          if (__ballot(slow) != 0) {
+            ws_slow_rows(T, spill, slow, key, val);
+            pass = pass && !slow;
+          }
+          const uint64_t m = __ballot(pass);
+          const uint32_t c = (uint32_t)__popcll(m);
+          if (c != 0) {
+            // room for c rows?  (the router publishes its position after every batch of 64 it takes)
+            uint32_t spins = 0;
+            while (tail + c - head_c > (uint32_t)kWsQueueRows) {
+              head_c = __hip_atomic_load(&my->head, __ATOMIC_ACQUIRE, WG_SCOPE);
+              if (tail + c - head_c <= (uint32_t)kWsQueueRows) break;
+              if (++spins > (1u << 22)) {  // cannot happen (a full queue always has 64 rows for its router); never hang the device
+                err |= 4u;
+                break;
+              }
+              __builtin_amdgcn_s_sleep(1);
             }
-            __builtin_amdgcn_s_sleep(1);
+            if (pass) {
+              const uint32_t at = (tail + mbcnt64(m)) & (uint32_t)(kWsQueueRows - 1);
+              qk[at] = (uint32_t)key;
+              qv[at] = val;
+            }
+            tail += c;
           }
-          if (pass) {
-            const uint32_t at = (tail + mbcnt64(m)) & (uint32_t)(kWsQueueRows - 1);
-            qk[at] = (uint32_t)key;
-            qv[at] = val;
-          }
-          tail += c;
         }
+        if (lane == 0) __hip_atomic_store(&my->tail, tail, __ATOMIC_RELEASE, WG_SCOPE);  // once per trip: the rows above are visible first
       }
-      if (lane == 0) __hip_atomic_store(&my->tail, tail, __ATOMIC_RELEASE, WG_SCOPE);  // once per trip: the rows above are visible first
+    };
+    switch (POL::form_of(F)) {  // (wave-uniform: the plan sits in the kernarg segment)
+      case 4 | (1 << 3): scan(std::integral_constant<int, (POL::kIsStatic ? (4 | (1 << 3)) : 0)>{}); break;  // x >  a AND x <  b
+      case 6 | (1 << 3): scan(std::integral_constant<int, (POL::kIsStatic ? (6 | (1 << 3)) : 0)>{}); break;  // x >= a AND x <  b
+      case 4 | (3 << 3): scan(std::integral_constant<int, (POL::kIsStatic ? (4 | (3 << 3)) : 0)>{}); break;  // x >  a AND x <= b
+      case 6 | (3 << 3): scan(std::integral_constant<int, (POL::kIsStatic ? (6 | (3 << 3)) : 0)>{}); break;  // x >= a AND x <= b
+      default: scan(std::integral_constant<int, 0>{}); break;
     }
     if (lane == 0) {
       __hip_atomic_store(&my->tail, tail, __ATOMIC_RELEASE, WG_SCOPE);

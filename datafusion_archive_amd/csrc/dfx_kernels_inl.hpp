@@ -378,6 +378,7 @@ struct InterpPolicy {
   static constexpr int U = U_;
   static constexpr int kStaticNa = 0;  // aggregates known at compile time (0: run-time)
   typedef typename Bank<BANK>::type COLV;
+  // (defined after pass below)
   static DEV void load(const DevProgram& P, const DevColumns& C, int64_t row, bool inb, COLV& col, uint32_t& cv) {
     load_columns(P, C, row, inb, col, cv);
   }
@@ -394,6 +395,12 @@ struct InterpPolicy {
                        const u64x16& reg, uint32_t rv) {
     return eval_predicate(P, cur, reg, curv, rv, pred);
   }
+  static DEV int form_of(const DevFastPlan&) { return 0; }
+  template <int FORM>
+  static DEV bool pass_form(const DevProgram& P, const DevFastPlan& F, uint8_t pred, const COLV& cur, uint32_t cv, const u64x16& reg, uint32_t rv) {
+    return pass(P, F, pred, cur, cv, reg, rv);
+  }
+  static DEV void load_trip(const DevColumns&, int64_t, bool, int64_t, int, COLV (&)[U_], uint32_t (&)[U_]) {}  // (kIsStatic only)
   static DEV uint64_t key(const DevProgram& P, const DevFastPlan&, uint8_t opnd, int, const COLV& cur, uint32_t curv,
                           const u64x16& reg, uint32_t rv) {
     uint64_t v;
@@ -467,6 +474,12 @@ struct FastPolicy {
     }
     return lane_of_mask(ok);
   }
+  static DEV int form_of(const DevFastPlan&) { return 0; }
+  template <int FORM>
+  static DEV bool pass_form(const DevProgram& P, const DevFastPlan& F, uint8_t pred, const COLV& cur, uint32_t cv, const u64x16& reg, uint32_t rv) {
+    return pass(P, F, pred, cur, cv, reg, rv);
+  }
+  static DEV void load_trip(const DevColumns&, int64_t, bool, int64_t, int, COLV (&)[U_], uint32_t (&)[U_]) {}  // (kIsStatic only)
   static DEV uint64_t key(const DevProgram&, const DevFastPlan& F, uint8_t, int k, const COLV& cur, uint32_t,
                           const u64x16&, uint32_t) {
     return cur[F.keycol[k] & (BANK - 1)];
@@ -528,6 +541,29 @@ struct StaticPolicy {
         col[c] = __builtin_nontemporal_load((const uint64_t*)C.c[c].values + (inb ? row : 0));
 #endif
   }
+  // The U row groups of one trip, starting at group w0 (wave-uniform): ONE scalar base per column and a 32-bit lane index
+  // clamped to the last row of the batch (v_min_u32 + shift per load; the per-row form clamps a 64-bit index: six vector
+  // instructions per load).  Lanes past the end re-read the last row (their rows are masked out by `row < n` later); an
+  // inactive trip (w0 past the end: the software pipeline's last prefetch) reads row 0.  Unconditional loads: the compiler
+  // can count them (vmcnt(N), not vmcnt(0)).
+  static DEV void load_trip(const DevColumns& C, int64_t w0, bool active, int64_t n, int lane, COLV (&col)[U], uint32_t (&cv)[U]) {
+    const int64_t r0 = active ? w0 * 64 : 0;
+    const int64_t left = n - r0;
+    const uint32_t last = (!active || left <= 0) ? 0u : (uint32_t)((left < (int64_t)U * 64 ? left : (int64_t)U * 64) - 1);
+#pragma unroll
+    for (int u = 0; u < U; ++u) cv[u] = 0xFFFFFFFFu;
+#pragma unroll
+    for (int c = 0; c < BANK; ++c) {
+      if (c < SIG::NCOL) {
+        const uint64_t* p = (const uint64_t*)C.c[c].values + ((!active || left <= 0) ? 0 : r0);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const uint32_t i = (uint32_t)(u * 64 + lane);
+          col[u][c] = __builtin_nontemporal_load(p + (i < last ? i : last));
+        }
+      }
+    }
+  }
   static DEV int na(const DevTable&) { return SIG::NA; }
   static DEV uint8_t acc_kind(const DevTable&, int a) { return SIG::acc(a); }
   static DEV uint8_t xform(const DevTable&, int a) { return SIG::xf(a); }
@@ -543,6 +579,49 @@ struct StaticPolicy {
               (F.term[i].inv ? ~0ull : 0ull);
     }
     return lane_of_mask(ok);
+  }
+  // Comparison operators as COMPILE-TIME constants.  With run-time masks a term costs three v_cmp (less / equal / greater)
+  // and a dozen scalar selects per row group; the operators of a query do not change while it runs, so the scan kernels
+  // pick one of a few loop bodies once per wave: FORM = m0 | m1 << 3 | ... (three-way masks of the terms, none inverted),
+  // 0 = the run-time form above.  form_of() names the FORM a plan matches (0 if none is instantiated).
+  static DEV int form_of(const DevFastPlan& F) {
+    int form = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (i < SIG::NP) {
+        if (F.term[i].inv || F.term[i].m < 1 || F.term[i].m > 6) return 0;
+        form |= (int)F.term[i].m << (3 * i);
+      }
+    return form;
+  }
+  template <int M, typename TT>
+  static DEV bool cmp_ct(TT a, TT b) {
+    if constexpr (M == 1) return a < b;
+    else if constexpr (M == 2) return a == b;
+    else if constexpr (M == 3) return a <= b;
+    else if constexpr (M == 4) return a > b;
+    else if constexpr (M == 5) return a < b || a > b;
+    else return a >= b;
+  }
+  template <int M>
+  static DEV bool term_ct(uint8_t t, uint64_t x, uint64_t y) {
+    if (t == T_F64) return cmp_ct<M, double>(as_f64(x), as_f64(y));
+    if (t == T_F32) return cmp_ct<M, float>(as_f32(x), as_f32(y));
+    if (t == T_U64) return cmp_ct<M, uint64_t>(x, y);
+    return cmp_ct<M, int64_t>((int64_t)x, (int64_t)y);
+  }
+  template <int FORM>
+  static DEV bool pass_form(const DevProgram& P, const DevFastPlan& F, uint8_t pred, const COLV& cur, uint32_t cv, const u64x16& reg, uint32_t rv) {
+    if constexpr (FORM == 0) {
+      return pass(P, F, pred, cur, cv, reg, rv);
+    } else {
+      bool ok = true;
+      if constexpr (SIG::NP > 0) ok = ok && term_ct<((FORM >> 0) & 7) ? ((FORM >> 0) & 7) : 1>(SIG::term_cls(0), cur[SIG::term_col(0)], F.term_imm[0]);
+      if constexpr (SIG::NP > 1) ok = ok && term_ct<((FORM >> 3) & 7) ? ((FORM >> 3) & 7) : 1>(SIG::term_cls(1), cur[SIG::term_col(1)], F.term_imm[1]);
+      if constexpr (SIG::NP > 2) ok = ok && term_ct<((FORM >> 6) & 7) ? ((FORM >> 6) & 7) : 1>(SIG::term_cls(2), cur[SIG::term_col(2)], F.term_imm[2]);
+      if constexpr (SIG::NP > 3) ok = ok && term_ct<((FORM >> 9) & 7) ? ((FORM >> 9) & 7) : 1>(SIG::term_cls(3), cur[SIG::term_col(3)], F.term_imm[3]);
+      return ok;
+    }
   }
   static DEV uint64_t key(const DevProgram&, const DevFastPlan&, uint8_t, int k, const COLV& cur, uint32_t,
                           const u64x16&, uint32_t) {
@@ -583,6 +662,22 @@ struct StaticPolicy {
     }
   }
 };
+
+// the column loads of one trip of U row groups starting at group w0 (wave-uniform); `active` false: nothing is needed (the
+// software pipeline's prefetch past the end), the loads still happen (row 0) so that their count stays fixed
+template <typename POL>
+DEV void load_trip(const DevProgram& P, const DevColumns& C, int64_t w0, bool active, int64_t n, int lane,
+                   typename POL::COLV (&col)[POL::U], uint32_t (&cv)[POL::U]) {
+  if constexpr (POL::kIsStatic) {
+    POL::load_trip(C, w0, active, n, lane, col, cv);
+  } else {
+#pragma unroll
+    for (int u = 0; u < POL::U; ++u) {
+      const int64_t row = (w0 + u) * 64 + lane;
+      POL::load(P, C, row, active && row < n, col[u], cv[u]);
+    }
+  }
+}
 
 // signature list: index == sig id handed to the launchers; -1: none
 template <int BANK, int U> using PolPred2F64 = StaticPolicy<BANK, U, SigPred2F64>;

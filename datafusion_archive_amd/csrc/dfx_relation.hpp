@@ -72,6 +72,7 @@ class FilterRelation : public Relation {
   DevFastPlan fast_;
   Status deferred_;  // evaluation-time type errors of the reference surface on next()
   std::shared_ptr<void> ctrl_;
+  std::shared_ptr<void> ctrl_host_;  // pinned copy of the control block (kept count + error bits of a batch)
   std::vector<char> out_needed_;  // empty: every column is compacted
   bool keep_mask_ = false;
   std::shared_ptr<void> last_mask_;
