@@ -53,6 +53,10 @@ ArrowArrayStream._fields_ = [
 ]
 
 
+class OptionC(ctypes.Structure):
+    _fields_ = [("key", ctypes.c_char_p), ("value", ctypes.c_int64)]
+
+
 class SynthColumnC(ctypes.Structure):
     _fields_ = [("name", ctypes.c_char_p), ("kind", ctypes.c_int32), ("column_id", ctypes.c_int32),
                 ("p0", ctypes.c_double), ("p1", ctypes.c_double)]
@@ -64,6 +68,7 @@ EXPORTED_SYMBOLS = [
     "dfx_compile_scalar_expr", "dfx_compile_expr", "dfx_runtime_expr_name", "dfx_runtime_expr_type",
     "dfx_runtime_expr_is_aggregate", "dfx_runtime_expr_free",
     "dfx_filter_relation_new", "dfx_project_relation_new", "dfx_aggregate_relation_new",
+    "dfx_filter_relation_new_with_options", "dfx_aggregate_relation_new_with_options",
     "dfx_table_from_stream", "dfx_table_synth", "dfx_table_num_rows", "dfx_table_num_columns",
     "dfx_table_column_device_ptr", "dfx_table_scan_new", "dfx_table_free", "dfx_csv_datasource_new",
     "dfx_sort_relation_new", "dfx_limit_relation_new",
@@ -122,6 +127,11 @@ def lib() -> ctypes.CDLL:
     L.dfx_runtime_expr_free.restype = None
     L.dfx_filter_relation_new.argtypes = [P(ArrowArrayStream), ctypes.c_void_p, P(ArrowSchema),
                                           P(ArrowArrayStream)] + c_err
+    L.dfx_filter_relation_new_with_options.argtypes = [P(ArrowArrayStream), ctypes.c_void_p, P(ArrowSchema), P(OptionC), ctypes.c_int32,
+                                                       P(ArrowArrayStream)] + c_err
+    L.dfx_aggregate_relation_new_with_options.argtypes = [P(ArrowSchema), P(ArrowArrayStream), P(ctypes.c_void_p), ctypes.c_int32,
+                                                          P(ctypes.c_void_p), ctypes.c_int32, P(OptionC), ctypes.c_int32,
+                                                          P(ArrowArrayStream)] + c_err
     L.dfx_project_relation_new.argtypes = [P(ArrowArrayStream), P(ctypes.c_void_p), ctypes.c_int32,
                                            P(ArrowSchema), P(ArrowArrayStream)] + c_err
     L.dfx_aggregate_relation_new.argtypes = [P(ArrowSchema), P(ArrowArrayStream), P(ctypes.c_void_p),

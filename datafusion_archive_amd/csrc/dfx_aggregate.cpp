@@ -158,6 +158,8 @@ struct AggregateRelation::Impl {
   std::shared_ptr<void> partial, state, dev_arg_dtype, dev_func;
   // export
   std::vector<uint64_t> export_counts;
+  mutable OperatorOptions options;  // this operator's option set (process defaults + its own overrides, frozen at first use)
+  const AggOptions& opt() const { return options.get(); }
 
   Status setup(const SchemaInfo& input_schema);
   Status alloc_table(int cap_log2, DevTable* T, std::vector<std::shared_ptr<void>>* owners, bool new_ctrl, uint64_t** full_accs_out);
@@ -517,7 +519,7 @@ Status AggregateRelation::Impl::ensure_spill(int64_t rows) {
 // the active chunk's 2..3 aggregates all take the same operand (AVG's SUM and COUNT, SUM + MIN + MAX of one column ...):
 // with narrow keys and no nulls in this batch, routed rows carry that one operand (PTF_SHARED)
 bool AggregateRelation::Impl::shared_operand() const {
-  if (kw != 1 || na < 2 || na > 3 || !agg_options().shared_operand) return false;
+  if (kw != 1 || na < 2 || na > 3 || !opt().shared_operand) return false;
   for (int a = 1; a < na; ++a)
     if (plan.arg[a] != plan.arg[0]) return false;
   return true;
@@ -525,10 +527,10 @@ bool AggregateRelation::Impl::shared_operand() const {
 
 Status AggregateRelation::Impl::ensure_partition(int64_t rows, bool nulls_now) {
   const uint64_t S = (uint64_t)T.block_mask + 1;
-  const bool want_shared = narrow && agg_options().narrow_keys != 0 && !nulls_now && shared_operand() &&
-                           ((uint32_t)agg_options().partition_mode & 0x8Fu) == 2u &&
+  const bool want_shared = narrow && opt().narrow_keys != 0 && !nulls_now && shared_operand() &&
+                           ((uint32_t)opt().partition_mode & 0x8Fu) == 2u &&
                            partition_ring_bytes(2, (uint32_t)((T.mask + 1) / S), 16, false, true, 128) <= (size_t)158 * 1024;
-  const bool want_narrow = narrow && kw == 1 && (na == 1 || want_shared) && agg_options().narrow_keys != 0;
+  const bool want_narrow = narrow && kw == 1 && (na == 1 || want_shared) && opt().narrow_keys != 0;
   const uint32_t n_words = want_shared ? 2u : (uint32_t)(kw + na);
   if (pt_layout_valid && rows <= pt_layout_rows && PT.n_parts == (uint32_t)((T.mask + 1) / S) && PT.n_words == n_words &&
       ((PT.flags & PTF_NARROW) != 0) == want_narrow && ((PT.flags & PTF_SHARED) != 0) == want_shared)
@@ -548,7 +550,7 @@ Status AggregateRelation::Impl::ensure_partition(int64_t rows, bool nulls_now) {
   //   2 (default)  lock-free per-partition LDS rings, 128-byte chunks, no barrier in the scan loop
   //   1            workgroup-wide LDS counting sort (also for partition counts whose rings do not fit LDS)
   //   0            one 16-byte store per row straight from registers (very many partitions)
-  const AggOptions& o = agg_options();
+  const AggOptions& o = opt();
   const uint32_t block = o.partition_block == 512 ? 512u : 1024u;
   const size_t budget = block == 512 ? (size_t)79 * 1024 : (size_t)156 * 1024;
   const uint32_t sort_cap = partition_sort_capacity(PT.n_words, PT.n_parts, block, budget);
@@ -748,7 +750,7 @@ Status AggregateRelation::Impl::handle_ctrl(const uint32_t* hc, int64_t n) {
     if (now[CTRL_ERROR]) return error_from_ctrl(now[CTRL_ERROR]);
     uint64_t spilled_now = ((uint64_t)now[CTRL_SPILL_HI] << 32) | now[CTRL_SPILL_LO];
     uint64_t replay_from = 0;
-    if (agg_options().replay_in_place && spilled_now > 0 && !now[CTRL_SATURATED] && now[CTRL_OCCUPIED] <= T.load_limit &&
+    if (opt().replay_in_place && spilled_now > 0 && !now[CTRL_SATURATED] && now[CTRL_OCCUPIED] <= T.load_limit &&
         2 * spilled_now <= spill.capacity) {
       // The table is not full: the rows were spilled by overflowing routing regions (a hot key).  Put them into the
       // table as it is; a row it cannot take is appended to the list BEHIND the rows being replayed (the cursor is not
@@ -882,17 +884,17 @@ Status AggregateRelation::Impl::launch_rows(const DeviceBatch& b, const DevProgr
   }
   if (partition_now) {
     DevFastPlan fpp = fast;
-    if (!agg_options().fast) fpp.valid = 0;
+    if (!opt().fast) fpp.valid = 0;
     DevPartition pt = PT;
     if (pt_pending > 0) pt.flags |= PTF_RESUME;
     // close the window when one more batch could overflow a region (or the batch budget is used up; the calibration
     // slice is aggregated at once: the strategy decision reads the group count)
-    const int max_batches = std::max(1, agg_options().partition_defer_batches);
+    const int max_batches = std::max(1, opt().partition_defer_batches);
     const bool close_window = calibrating || pt_pending + 1 >= max_batches || pt_fill_bound + 2 * (uint64_t)pt_worst > PT.cap_rows;
     // the LAST kernel of this batch publishes the control block itself (examined one batch later, see post_ctrl)
     snap_armed = false;
     uint32_t* snap_to = nullptr;
-    if (agg_options().ctrl_snapshot == 1 && lds_calibrated && !calibrating) {
+    if (opt().ctrl_snapshot == 1 && lds_calibrated && !calibrating) {
       if (!ctrl_host) DFX_RETURN_IF_ERROR(alloc_ctrl_host());
       if (!snap_done) {
         Status st;
@@ -923,16 +925,16 @@ Status AggregateRelation::Impl::launch_rows(const DeviceBatch& b, const DevProgr
     return Status::OK();
   }
   DevFastPlan fp = fast;
-  if (!agg_options().fast) fp.valid = 0;
+  if (!opt().fast) fp.valid = 0;
   // a handful of groups (the calibration slice / earlier batches saw <= 8): register accumulators.  Should more
   // groups turn up later the kernel still handles them (through the table), and the next batch goes back to K7.
-  if (lds_enabled && lds_calibrated && !calibrating && agg_options().strategy != 1 && agg_options().fewgroup &&
+  if (lds_enabled && lds_calibrated && !calibrating && opt().strategy != 1 && opt().fewgroup &&
       occupied_known > 0 && occupied_known <= 8 && fewgroup_supported(prog, fp, T)) {
     DFX_HIP(launch_fewgroup_agg(prog, fp, cols, p, T, spill, n, bytes, s));
     return Status::OK();
   }
-  if (lds_enabled && agg_options().strategy != 1) {
-    const AggOptions& o = agg_options();
+  if (lds_enabled && opt().strategy != 1) {
+    const AggOptions& o = opt();
     int slots = o.lds_slots >= 0 ? o.lds_slots : 4096;
     if (calibrating && o.lds_slots < 0) slots = 512;  // calibration slice: the cache only has to tell few groups from many
     while (slots > 64 && (size_t)slots * ((size_t)(kw + na) * 8 + (kw > 1 ? 4 : 0)) > 64 * 1024) slots >>= 1;
@@ -1029,7 +1031,7 @@ Status AggregateRelation::Impl::consume_batch_chunk(const DeviceBatch& b) {
     double bytes = 0;
     for (int i = 0; i < prog.n_cols; ++i) bytes += (double)n * (prog.col_dtype[i] == T_BOOL ? 0.125 : dtype_width(prog.col_dtype[i]));
     DevFastPlan fp = fast;
-    if (!agg_options().fast) fp.valid = 0;
+    if (!opt().fast) fp.valid = 0;
     DFX_HIP(launch_reduce(prog, fp, cols, plan, T, n, (uint64_t*)partial.get(), (uint32_t*)ctrl.get(), bytes, s));
     DFX_HIP(launch_reduce_fold(T, (const uint8_t*)dev_arg_dtype.get(), (const uint8_t*)dev_func.get(),
                                (uint64_t*)partial.get(), (uint64_t*)state.get(), (uint32_t*)ctrl.get(), s));
@@ -1037,7 +1039,7 @@ Status AggregateRelation::Impl::consume_batch_chunk(const DeviceBatch& b) {
     return Status::OK();
   }
   // grouped: can this batch overflow the table in the worst case (every row a new group)?
-  const AggOptions& oo = agg_options();
+  const AggOptions& oo = opt();
   if (oo.strategy == 3 && kw == 1) {
     if (!use_partition && oo.narrow_keys > 0) narrow = na == 1 || shared_operand();  // forced strategy: no calibration slice -- optimistic (tests)
     use_partition = true;
@@ -1045,11 +1047,11 @@ Status AggregateRelation::Impl::consume_batch_chunk(const DeviceBatch& b) {
   const bool may_spill = use_partition || occupied_known + unconfirmed_rows + (uint64_t)n > T.load_limit;
   // two batches can be in flight unchecked; with a deferred pass 2 every row of the window may still be spilled (by pass 2
   // itself, when its block is full)
-  const int64_t window_rows = use_partition ? (int64_t)std::max(1, agg_options().partition_defer_batches) * std::max(n, pt_layout_rows) : 0;
+  const int64_t window_rows = use_partition ? (int64_t)std::max(1, opt().partition_defer_batches) * std::max(n, pt_layout_rows) : 0;
   if (may_spill) DFX_RETURN_IF_ERROR(ensure_spill(2 * n + window_rows + 65536));
   T.max_probe = may_spill ? 128 : (int)std::min<uint64_t>(T.mask + 1, 1u << 30);
   int64_t row0 = 0;
-  const AggOptions& o = agg_options();
+  const AggOptions& o = opt();
   // (a batch that went through a real FilterRelation is not the table's first rows: its calibration says nothing about them)
   ScanMemo* memo = (o.calibration_memo && !unfused_now) ? input->scan_memo() : nullptr;
   uint64_t remembered = 0;
@@ -1065,7 +1067,7 @@ Status AggregateRelation::Impl::consume_batch_chunk(const DeviceBatch& b) {
     lds_enabled = remembered <= 8192;
     if (!lds_enabled && kw == 1 && remembered >= 16384) {
       use_partition = true;
-      DFX_RETURN_IF_ERROR(ensure_spill(2 * n + (int64_t)std::max(1, agg_options().partition_defer_batches) * n + 65536));
+      DFX_RETURN_IF_ERROR(ensure_spill(2 * n + (int64_t)std::max(1, opt().partition_defer_batches) * n + 65536));
     }
   }
   if (!lds_calibrated && o.strategy == 0 && n > (1 << 21)) {
@@ -1103,7 +1105,7 @@ Status AggregateRelation::Impl::consume_batch_chunk(const DeviceBatch& b) {
     lds_enabled = occupied_known <= 8192;
     if (!lds_enabled && kw == 1 && occupied_known >= 16384) {
       use_partition = true;
-      DFX_RETURN_IF_ERROR(ensure_spill(2 * n + (int64_t)std::max(1, agg_options().partition_defer_batches) * n + 65536));
+      DFX_RETURN_IF_ERROR(ensure_spill(2 * n + (int64_t)std::max(1, opt().partition_defer_batches) * n + 65536));
     }
     row0 = n0;
   } else if (!lds_calibrated) {
@@ -1218,7 +1220,7 @@ Status AggregateRelation::Impl::dict_encode(DictKey& d, const DeviceColumn& src,
   auto ids = device_alloc(sizeof(uint64_t) * (size_t)std::max<int64_t>(n, 1), &st);
   if (!ids) return st;
   if (!d.allocated) {
-    int lg = agg_options().dict_capacity_log2 > 0 ? agg_options().dict_capacity_log2 : 16;
+    int lg = opt().dict_capacity_log2 > 0 ? opt().dict_capacity_log2 : 16;
     lg = std::max(4, std::min(lg, 30));
     DFX_RETURN_IF_ERROR(dict_alloc(d, lg, std::max<uint64_t>((uint64_t)src.data_bytes * 2, 1u << 16), false));
   }
@@ -1339,7 +1341,7 @@ Status AggregateRelation::Impl::drain() {
     }
     DFX_HIP(hipStreamSynchronize(s));
   } else {
-    int cap_log2 = agg_options().capacity_log2 > 0 ? agg_options().capacity_log2 : 21;
+    int cap_log2 = opt().capacity_log2 > 0 ? opt().capacity_log2 : 21;
     cap_log2 = std::max(6, std::min(cap_log2, 31));
     DFX_RETURN_IF_ERROR(alloc_table(cap_log2, &T, &table_owners, true, &accs_full));
     spill.words = nullptr;
@@ -1520,9 +1522,10 @@ Status AggregateRelation::Impl::emit_grouped(DeviceBatch* out, int64_t expected)
 
 // ---- public class -----------------------------------------------------------------------------------
 AggregateRelation::AggregateRelation(SchemaInfo schema, std::unique_ptr<Relation> input,
-                                     std::vector<dfx_runtime_expr> group, std::vector<dfx_runtime_expr> aggr)
+                                     std::vector<dfx_runtime_expr> group, std::vector<dfx_runtime_expr> aggr, OptionOverrides options)
     : schema_(std::move(schema)), impl_(new Impl()) {
   Impl& m = *impl_;
+  m.options.overrides = std::move(options);
   m.group = std::move(group);
   for (const dfx_runtime_expr& e : aggr) {  // AVG(x) -> SUM(x), COUNT(x)
     Impl::OutAgg o;
@@ -1637,7 +1640,7 @@ void AggregateRelation::explain(std::string* out, int depth) const {
     if (!m.dicts.empty()) text += strfmt(", %d Utf8 keys dictionary-encoded on the device", (int)m.dicts.size());
     if (m.built && m.kw > 0)  // after the input was drained: what actually ran
       text += strfmt("; ran %lld rows: %s, %llu of 2^%d table slots occupied", (long long)m.rows_seen,
-                     m.use_partition ? "partitioned" : (m.lds_enabled && m.occupied_known <= 8 && agg_options().fewgroup) ? "few groups (register accumulators or LDS front cache)"
+                     m.use_partition ? "partitioned" : (m.lds_enabled && m.occupied_known <= 8 && m.opt().fewgroup) ? "few groups (register accumulators or LDS front cache)"
                                      : m.lds_enabled ? "LDS front cache + table" : "table (global atomics)",
                      (unsigned long long)m.occupied_known, 64 - m.T.shift);
     else if (m.built)
@@ -1659,7 +1662,7 @@ Status AggregateRelation::next(DeviceBatch* out, bool* has) {
   if (m.kw == 0) DFX_RETURN_IF_ERROR(m.emit_ungrouped(out));
   // (Utf8 keys: dict_emit indexes the dictionary with the compacted ids before the scan's total could contradict the host's
   // count -- the table's own count first, one round trip more)
-  else DFX_RETURN_IF_ERROR(m.emit_grouped(out, (agg_options().emit_async && m.dicts.empty()) ? (int64_t)m.occupied_known : -1));
+  else DFX_RETURN_IF_ERROR(m.emit_grouped(out, (m.opt().emit_async && m.dicts.empty()) ? (int64_t)m.occupied_known : -1));
   *has = true;
   return Status::OK();
 }
@@ -2020,8 +2023,25 @@ int32_t dfx_aggregate_relation_new(const struct ArrowSchema* schema, struct Arro
                                    const dfx_runtime_expr* const* group_exprs, int32_t n_group,
                                    const dfx_runtime_expr* const* aggr_exprs, int32_t n_aggr,
                                    struct ArrowArrayStream* out, char* err, size_t errlen) {
+  return dfx_aggregate_relation_new_with_options(schema, input, group_exprs, n_group, aggr_exprs, n_aggr, nullptr, 0, out, err, errlen);
+}
+
+int32_t dfx_aggregate_relation_new_with_options(const struct ArrowSchema* schema, struct ArrowArrayStream* input,
+                                                const dfx_runtime_expr* const* group_exprs, int32_t n_group,
+                                                const dfx_runtime_expr* const* aggr_exprs, int32_t n_aggr,
+                                                const dfx_option* options, int32_t n_options,
+                                                struct ArrowArrayStream* out, char* err, size_t errlen) {
   return c_abi_guard(err, errlen, [&]() -> int32_t {
-    if (!out) return to_c(Status::Err(DFX_GENERAL, "null argument"), err, errlen);
+    if (!out || (n_options > 0 && !options)) return to_c(Status::Err(DFX_GENERAL, "null argument"), err, errlen);
+    OptionOverrides ov;
+    {
+      AggOptions probe = agg_options();
+      for (int i = 0; i < n_options; ++i) {
+        if (!options[i].key || !set_option_in(probe, options[i].key, options[i].value))
+          return to_c(Status::Err(DFX_GENERAL, std::string("unknown option ") + (options[i].key ? options[i].key : "(null)")), err, errlen);
+        ov.emplace_back(options[i].key, options[i].value);
+      }
+    }
     std::unique_ptr<Relation> in;
     Status st = adopt_input_stream(input, &in);
     if (!st.ok()) return to_c(st, err, errlen);
@@ -2031,7 +2051,7 @@ int32_t dfx_aggregate_relation_new(const struct ArrowSchema* schema, struct Arro
     std::vector<dfx_runtime_expr> g, a;
     for (int i = 0; i < n_group; ++i) g.push_back(*group_exprs[i]);
     for (int i = 0; i < n_aggr; ++i) a.push_back(*aggr_exprs[i]);
-    std::unique_ptr<Relation> rel(new AggregateRelation(si, std::move(in), std::move(g), std::move(a)));
+    std::unique_ptr<Relation> rel(new AggregateRelation(si, std::move(in), std::move(g), std::move(a), std::move(ov)));
     export_relation(std::move(rel), out);
     return DFX_OK;
   });

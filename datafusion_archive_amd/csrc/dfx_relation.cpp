@@ -409,8 +409,9 @@ Status adopt_input_stream(struct ArrowArrayStream* input, std::unique_ptr<Relati
 // =================================================================================================
 // FilterRelation
 // =================================================================================================
-FilterRelation::FilterRelation(std::unique_ptr<Relation> input, const dfx_runtime_expr& expr, SchemaInfo schema)
+FilterRelation::FilterRelation(std::unique_ptr<Relation> input, const dfx_runtime_expr& expr, SchemaInfo schema, OptionOverrides options)
     : input_(std::move(input)), expr_(expr), schema_(std::move(schema)) {
+  opt_.overrides = std::move(options);
   builder_.reset(new ProgramBuilder(input_->schema()));
   int dt = DFX_TYPE_NONE;
   deferred_ = builder_->add(expr_, expr_.root, &pred_operand_, &dt);
@@ -505,7 +506,10 @@ void FilterRelation::explain(std::string* out, int depth) const {
                                                                             : "SSA interpreter";
     int n = 0;
     for (size_t i = 0; i < schema_.fields.size() || i < out_needed_.size(); ++i) n += (out_needed_.empty() || (i < out_needed_.size() && out_needed_[i])) ? 1 : 0;
-    explain_line(out, depth, "Filter: mask + compaction, " + explain_program(P) + ", " + shape +
+    const bool single = more_.empty() && opt_.get().filter_single_pass;
+    explain_line(out, depth, std::string("Filter: ") + (single ? "single pass (predicate, bitmap, look-back over the tiles' kept counts and compaction of the predicate's own columns in one kernel), "
+                                                                 : "mask + scan + compaction (two passes over the predicate's columns), ") +
+                                 explain_program(P) + ", " + shape +
                                  (out_needed_.empty() ? std::string(", every column compacted") : strfmt(", %d columns compacted", n)) +
                                  (more_.empty() ? std::string() : strfmt(", conjunction evaluated by %zu fused programs (masks ANDed)", more_.size() + 1)));
   }
@@ -575,7 +579,7 @@ Status FilterRelation::next(DeviceBatch* out, bool* has) {
   double in_bytes = (double)n / 8.0;
   for (int ci : builder_->columns()) in_bytes += (double)n * (in.columns[ci].dtype == DFX_BOOLEAN ? 0.125 : dtype_width(in.columns[ci].dtype));
   DevFastPlan fp = fast_;
-  if (!agg_options().fast) fp.valid = 0;
+  if (!opt_.get().fast) fp.valid = 0;
   uint64_t kept = 0;
   uint32_t errbits = 0;
   bool single_pass_done = false;
@@ -583,7 +587,7 @@ Status FilterRelation::next(DeviceBatch* out, bool* has) {
   std::vector<std::shared_ptr<void>> fused_vals(in.columns.size());
   bool any_boolean = false;
   for (size_t c = 0; c < in.columns.size(); ++c) any_boolean = any_boolean || in.columns[c].dtype == DFX_BOOLEAN;
-  if (more_.empty() && agg_options().filter_single_pass) {
+  if (more_.empty() && opt_.get().filter_single_pass) {
     // SINGLE PASS: predicate, bitmap, tile offsets (decoupled look-back) and the compaction of up to kFusedOutCols of
     // the predicate's own columns in one kernel -- such a column is read from HBM once (filter.rs:46-110)
     DevFusedOut O;
@@ -639,7 +643,7 @@ Status FilterRelation::next(DeviceBatch* out, bool* has) {
         double bytes2 = (double)n / 8.0;
         for (int ci : p.builder->columns()) bytes2 += (double)n * (in.columns[ci].dtype == DFX_BOOLEAN ? 0.125 : dtype_width(in.columns[ci].dtype));
         DevFastPlan fp2 = p.fast;
-        if (!agg_options().fast) fp2.valid = 0;
+        if (!opt_.get().fast) fp2.valid = 0;
         DFX_HIP(launch_predicate_mask(prog2, fp2, cols2, p.operand, n, (uint64_t*)mask2.get(), nullptr, (uint32_t*)ctrl_.get(), bytes2, s));
         DFX_HIP(launch_mask_and_count((uint64_t*)mask.get(), (const uint64_t*)mask2.get(), (uint32_t*)counts.get(), n, s));
       }
@@ -893,8 +897,23 @@ extern "C" {
 int32_t dfx_filter_relation_new(struct ArrowArrayStream* input, const dfx_runtime_expr* expr,
                                 const struct ArrowSchema* schema, struct ArrowArrayStream* out, char* err,
                                 size_t errlen) {
+  return dfx_filter_relation_new_with_options(input, expr, schema, nullptr, 0, out, err, errlen);
+}
+
+int32_t dfx_filter_relation_new_with_options(struct ArrowArrayStream* input, const dfx_runtime_expr* expr,
+                                             const struct ArrowSchema* schema, const dfx_option* options, int32_t n_options,
+                                             struct ArrowArrayStream* out, char* err, size_t errlen) {
   return c_abi_guard(err, errlen, [&]() -> int32_t {
-    if (!expr || !out) return to_c(Status::Err(DFX_GENERAL, "null argument"), err, errlen);
+    if (!expr || !out || (n_options > 0 && !options)) return to_c(Status::Err(DFX_GENERAL, "null argument"), err, errlen);
+    OptionOverrides ov;
+    {
+      AggOptions probe = agg_options();
+      for (int i = 0; i < n_options; ++i) {
+        if (!options[i].key || !set_option_in(probe, options[i].key, options[i].value))
+          return to_c(Status::Err(DFX_GENERAL, std::string("unknown option ") + (options[i].key ? options[i].key : "(null)")), err, errlen);
+        ov.emplace_back(options[i].key, options[i].value);
+      }
+    }
     std::unique_ptr<Relation> in;
     Status st = adopt_input_stream(input, &in);
     if (!st.ok()) return to_c(st, err, errlen);
@@ -904,7 +923,7 @@ int32_t dfx_filter_relation_new(struct ArrowArrayStream* input, const dfx_runtim
     si = schema_names_over(si, in->schema());
     if (expr->is_aggregate)
       return to_c(Status::Err(DFX_INTERNAL_ERROR, "explicit panic: get_func() on an aggregate expression"), err, errlen);
-    std::unique_ptr<Relation> rel(new FilterRelation(std::move(in), *expr, si));
+    std::unique_ptr<Relation> rel(new FilterRelation(std::move(in), *expr, si, std::move(ov)));
     export_relation(std::move(rel), out);
     return DFX_OK;
   });

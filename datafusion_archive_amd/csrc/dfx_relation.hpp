@@ -44,10 +44,73 @@ class TableScanRelation : public Relation {
   bool emitted_any_ = false;
 };
 
+// ---- option sets ---------------------------------------------------------------------------------
+struct AggOptions {
+  int strategy = 0;         // 0 auto, 1 global table only, 2 LDS front cache
+  int capacity_log2 = 0;    // 0: default
+  int lds_slots = -1;       // -1 auto
+  int lds_copies = -1;      // -1 auto
+  int fast = 1;             // 0: always run the generic interpreter (tests compare both paths)
+  int partition_mode = 2;   // pass 1 of the partitioned strategy: 2 lock-free LDS rings, 1 LDS counting sort, 0 direct routing
+  int dict_capacity_log2 = 0;  // initial slots of a Utf8 key dictionary (0: 2^16); tests use tiny values to force growth
+  int partition_cap_rows = 0;  // rows per (producer, partition) region; 0: sized from the batch
+  int partition_pad = 0;       // bytes of padding between partitions in the routing scratch
+  int partition_block = 1024;  // pass-1 workgroup size in mode 1 (512: two workgroups per CU)
+  int partition_defer = 0;     // routing regions hold this many worst-case batches (1: pass 2 after every batch).  0 (default):
+                               // as many batches as make up ~2^27 rows, at most 8 -- a pass 2 per 2^27 scanned rows is what
+                               // measured best for selective scans whatever the batch size (2^26-row batches: 2 saves 3 %,
+                               // 4 and more lose it again; 2^27-row batches: 1); scans that route most of their rows get 1
+  int partition_split_rows = 1 << 26;  // a batch of a scan that routes most of its rows is routed in launches of at most this
+                               // many rows (0: never split): the regions of a 2^27-row launch cost pass 1 +20 %
+  int partition_defer_batches = 8;  // at most this many pass-1 launches share one pass 2
+  int export_kernel_copy = 1;  // large result columns reach the host by a copy kernel writing pinned memory (0: hipMemcpyAsync / copy engines)
+  int ctrl_snapshot = 1;       // partitioned strategy: 1 the batch's last kernel writes the control-block snapshot to pinned host
+                               // memory itself, 0 asynchronous copy on the side stream (round 1)
+  int narrow_chunk16 = 1;      // narrow rows are written in 16-row chunks (sector-aligned) when no hot-key pairs need the LDS
+  int shared_operand = 1;      // 2..3 aggregates of one null-free operand over narrow keys: 12-byte routed rows {image, raw operand}
+  int narrow_keys = -1;        // 12-byte routed rows when the calibration slice saw only keys below 2^32: -1 auto, 0 never
+  int partition_layout = 1;    // routing scratch: 1 producer-major, 0 partition-major (round 1), 2 windowed (DevPartition::win_stride;
+                               // measured no better for the filtered query and 17 % worse in pass 1 when every row is routed)
+  int partition_producers = 0; // pass-1 workgroups of the ring flavour (0: one per CU)
+  int hot_keys = -1;           // pass 1 hot-key pairs in LDS: -1 when the calibration slice saw skew, 0 never, 1 always
+  int emit_async = 1;          // 1: emit queues its compaction kernels with the host's group count and checks the table's afterwards
+  int calibration_memo = 1;    // 1: a resident table remembers the outcome of an aggregate's calibration slice per program shape
+  int pass2_stream = 1;        // pass 2 of one-aggregate queries: region-streaming kernel (0: the flattened-index kernel)
+  int fewgroup = 1;            // <= 8 groups after calibration: register accumulators (dfx_k_fewgroup.hip); 0: LDS front cache
+  int pass1_ws = 8;            // pass 1 of selective scans over narrow keys: wave-specialised kernel with this many scanner waves of 16
+                               // (0: the ring kernel, every wave scans and routes; the headline's signature also has 6 / 10 / 12
+                               // and, + 100, eight row groups per scanner trip: A/B runs)
+  int filter_single_pass = 1;  // FilterRelation: predicate + bitmap + tile offsets (decoupled look-back) + compaction of the predicate's own
+                               // columns in ONE kernel (0: k_predicate_mask -> scan -> k_compact, the column is read twice)
+  int replay_in_place = 1;     // 1: rows spilled by a table that is NOT full (region overflow of a heavy key) are replayed into the
+                               // table as it is, and only what it cannot take makes it grow (0: every spill quadruples the table)
+};
+AggOptions& agg_options();  // the process-wide defaults (dfx_set_option)
+// one key of dfx_set_option applied to an option set; false: unknown key
+bool set_option_in(AggOptions& o, const char* key, int64_t value);
+typedef std::vector<std::pair<std::string, int64_t>> OptionOverrides;
+// An operator's own option set: the process defaults as they are when the operator first asks, with its overrides on top;
+// frozen from then on (later dfx_set_option calls do not reach a running operator).
+struct OperatorOptions {
+  OptionOverrides overrides;
+  const AggOptions& get() {
+    if (!frozen_) {
+      opt_ = agg_options();
+      for (const auto& kv : overrides) (void)set_option_in(opt_, kv.first.c_str(), kv.second);
+      frozen_ = true;
+    }
+    return opt_;
+  }
+
+ private:
+  AggOptions opt_;
+  bool frozen_ = false;
+};
+
 // ---- FilterRelation (src/execution/filter.rs) ---------------------------------------------------
 class FilterRelation : public Relation {
  public:
-  FilterRelation(std::unique_ptr<Relation> input, const dfx_runtime_expr& expr, SchemaInfo schema);
+  FilterRelation(std::unique_ptr<Relation> input, const dfx_runtime_expr& expr, SchemaInfo schema, OptionOverrides options = OptionOverrides());
   RelationKind kind() const override { return REL_FILTER; }
   Status next(DeviceBatch* out, bool* has) override;
   const SchemaInfo& schema() const override { return schema_; }
@@ -72,6 +135,7 @@ class FilterRelation : public Relation {
   DevFastPlan fast_;
   Status deferred_;  // evaluation-time type errors of the reference surface on next()
   std::shared_ptr<void> ctrl_;
+  mutable OperatorOptions opt_;
   std::shared_ptr<void> ctrl_host_;  // pinned copy of the control block (kept count + error bits of a batch)
   std::vector<char> out_needed_;  // empty: every column is compacted
   bool keep_mask_ = false;
@@ -118,52 +182,10 @@ class ProjectRelation : public Relation {
 };
 
 // ---- AggregateRelation (src/execution/aggregate.rs) ---------------------------------------------
-struct AggOptions {
-  int strategy = 0;         // 0 auto, 1 global table only, 2 LDS front cache
-  int capacity_log2 = 0;    // 0: default
-  int lds_slots = -1;       // -1 auto
-  int lds_copies = -1;      // -1 auto
-  int fast = 1;             // 0: always run the generic interpreter (tests compare both paths)
-  int partition_mode = 2;   // pass 1 of the partitioned strategy: 2 lock-free LDS rings, 1 LDS counting sort, 0 direct routing
-  int dict_capacity_log2 = 0;  // initial slots of a Utf8 key dictionary (0: 2^16); tests use tiny values to force growth
-  int partition_cap_rows = 0;  // rows per (producer, partition) region; 0: sized from the batch
-  int partition_pad = 0;       // bytes of padding between partitions in the routing scratch
-  int partition_block = 1024;  // pass-1 workgroup size in mode 1 (512: two workgroups per CU)
-  int partition_defer = 0;     // routing regions hold this many worst-case batches (1: pass 2 after every batch).  0 (default):
-                               // as many batches as make up ~2^27 rows, at most 8 -- a pass 2 per 2^27 scanned rows is what
-                               // measured best for selective scans whatever the batch size (2^26-row batches: 2 saves 3 %,
-                               // 4 and more lose it again; 2^27-row batches: 1); scans that route most of their rows get 1
-  int partition_split_rows = 1 << 26;  // a batch of a scan that routes most of its rows is routed in launches of at most this
-                               // many rows (0: never split): the regions of a 2^27-row launch cost pass 1 +20 %
-  int partition_defer_batches = 8;  // at most this many pass-1 launches share one pass 2
-  int export_kernel_copy = 1;  // large result columns reach the host by a copy kernel writing pinned memory (0: hipMemcpyAsync / copy engines)
-  int ctrl_snapshot = 1;       // partitioned strategy: 1 the batch's last kernel writes the control-block snapshot to pinned host
-                               // memory itself, 0 asynchronous copy on the side stream (round 1)
-  int narrow_chunk16 = 1;      // narrow rows are written in 16-row chunks (sector-aligned) when no hot-key pairs need the LDS
-  int shared_operand = 1;      // 2..3 aggregates of one null-free operand over narrow keys: 12-byte routed rows {image, raw operand}
-  int narrow_keys = -1;        // 12-byte routed rows when the calibration slice saw only keys below 2^32: -1 auto, 0 never
-  int partition_layout = 1;    // routing scratch: 1 producer-major, 0 partition-major (round 1), 2 windowed (DevPartition::win_stride;
-                               // measured no better for the filtered query and 17 % worse in pass 1 when every row is routed)
-  int partition_producers = 0; // pass-1 workgroups of the ring flavour (0: one per CU)
-  int hot_keys = -1;           // pass 1 hot-key pairs in LDS: -1 when the calibration slice saw skew, 0 never, 1 always
-  int emit_async = 1;          // 1: emit queues its compaction kernels with the host's group count and checks the table's afterwards
-  int calibration_memo = 1;    // 1: a resident table remembers the outcome of an aggregate's calibration slice per program shape
-  int pass2_stream = 1;        // pass 2 of one-aggregate queries: region-streaming kernel (0: the flattened-index kernel)
-  int fewgroup = 1;            // <= 8 groups after calibration: register accumulators (dfx_k_fewgroup.hip); 0: LDS front cache
-  int pass1_ws = 8;            // pass 1 of selective scans over narrow keys: wave-specialised kernel with this many scanner waves of 16
-                               // (0: the ring kernel, every wave scans and routes; the headline's signature also has 6 / 10 / 12
-                               // and, + 100, eight row groups per scanner trip: A/B runs)
-  int filter_single_pass = 1;  // FilterRelation: predicate + bitmap + tile offsets (decoupled look-back) + compaction of the predicate's own
-                               // columns in ONE kernel (0: k_predicate_mask -> scan -> k_compact, the column is read twice)
-  int replay_in_place = 1;     // 1: rows spilled by a table that is NOT full (region overflow of a heavy key) are replayed into the
-                               // table as it is, and only what it cannot take makes it grow (0: every spill quadruples the table)
-};
-AggOptions& agg_options();
-
 class AggregateRelation : public Relation {
  public:
   AggregateRelation(SchemaInfo schema, std::unique_ptr<Relation> input, std::vector<dfx_runtime_expr> group,
-                    std::vector<dfx_runtime_expr> aggr);
+                    std::vector<dfx_runtime_expr> aggr, OptionOverrides options = OptionOverrides());
   ~AggregateRelation() override;
   RelationKind kind() const override { return REL_AGGREGATE; }
   Status next(DeviceBatch* out, bool* has) override;

@@ -224,6 +224,42 @@ Status build_table(Relation* rel, std::shared_ptr<TableData>* out) {
 
 using namespace dfx;
 
+namespace dfx {
+bool set_option_in(AggOptions& o, const char* key, int64_t value) {
+  if (!key) return false;
+  if (!strcmp(key, "agg.strategy")) o.strategy = (int)value;
+  else if (!strcmp(key, "agg.capacity_log2")) o.capacity_log2 = (int)value;
+  else if (!strcmp(key, "agg.lds_slots")) o.lds_slots = (int)value;
+  else if (!strcmp(key, "agg.lds_copies")) o.lds_copies = (int)value;
+  else if (!strcmp(key, "scan.fast")) o.fast = (int)value;
+  else if (!strcmp(key, "agg.partition_mode")) o.partition_mode = (int)value;
+  else if (!strcmp(key, "agg.partition_block")) o.partition_block = (int)value;
+  else if (!strcmp(key, "agg.fewgroup")) o.fewgroup = (int)value;
+  else if (!strcmp(key, "agg.replay_in_place")) o.replay_in_place = (int)value;
+  else if (!strcmp(key, "agg.partition_pad")) o.partition_pad = (int)value;
+  else if (!strcmp(key, "agg.dict_capacity_log2")) o.dict_capacity_log2 = (int)value;
+  else if (!strcmp(key, "agg.partition_cap_rows")) o.partition_cap_rows = (int)value;
+  else if (!strcmp(key, "agg.partition_defer")) o.partition_defer = (int)value;
+  else if (!strcmp(key, "agg.partition_defer_batches")) o.partition_defer_batches = (int)value;
+  else if (!strcmp(key, "agg.partition_split_rows")) o.partition_split_rows = (int)value;
+  else if (!strcmp(key, "agg.pass2_stream")) o.pass2_stream = (int)value;
+  else if (!strcmp(key, "agg.calibration_memo")) o.calibration_memo = (int)value;
+  else if (!strcmp(key, "agg.emit_async")) o.emit_async = (int)value;
+  else if (!strcmp(key, "agg.hot_keys")) o.hot_keys = (int)value;
+  else if (!strcmp(key, "agg.partition_layout")) o.partition_layout = (int)value;
+  else if (!strcmp(key, "agg.narrow_keys")) o.narrow_keys = (int)value;
+  else if (!strcmp(key, "agg.narrow_chunk16")) o.narrow_chunk16 = (int)value;
+  else if (!strcmp(key, "agg.shared_operand")) o.shared_operand = (int)value;
+  else if (!strcmp(key, "agg.ctrl_snapshot")) o.ctrl_snapshot = (int)value;
+  else if (!strcmp(key, "export.kernel_copy")) o.export_kernel_copy = (int)value;
+  else if (!strcmp(key, "agg.partition_producers")) o.partition_producers = (int)value;
+  else if (!strcmp(key, "agg.pass1_ws")) o.pass1_ws = (int)value;
+  else if (!strcmp(key, "filter.single_pass")) o.filter_single_pass = (int)value;
+  else return false;
+  return true;
+}
+}  // namespace dfx
+
 extern "C" {
 
 int32_t dfx_init(int32_t device_ordinal, char* err, size_t errlen) {
@@ -378,38 +414,11 @@ void dfx_counter_reset(void) { counters() = Counters(); }
 
 int32_t dfx_set_option(const char* key, int64_t value) {
   if (!key) return DFX_GENERAL;
-  AggOptions& o = agg_options();
-  if (!strcmp(key, "agg.strategy")) o.strategy = (int)value;
-  else if (!strcmp(key, "agg.capacity_log2")) o.capacity_log2 = (int)value;
-  else if (!strcmp(key, "agg.lds_slots")) o.lds_slots = (int)value;
-  else if (!strcmp(key, "agg.lds_copies")) o.lds_copies = (int)value;
-  else if (!strcmp(key, "scan.fast")) o.fast = (int)value;
-  else if (!strcmp(key, "agg.partition_mode")) o.partition_mode = (int)value;
-  else if (!strcmp(key, "agg.partition_block")) o.partition_block = (int)value;
-  else if (!strcmp(key, "agg.fewgroup")) o.fewgroup = (int)value;
-  else if (!strcmp(key, "agg.replay_in_place")) o.replay_in_place = (int)value;
-  else if (!strcmp(key, "agg.partition_pad")) o.partition_pad = (int)value;
-  else if (!strcmp(key, "agg.dict_capacity_log2")) o.dict_capacity_log2 = (int)value;
-  else if (!strcmp(key, "agg.partition_cap_rows")) o.partition_cap_rows = (int)value;
-  else if (!strcmp(key, "agg.partition_defer")) o.partition_defer = (int)value;
-  else if (!strcmp(key, "agg.partition_defer_batches")) o.partition_defer_batches = (int)value;
-  else if (!strcmp(key, "agg.partition_split_rows")) o.partition_split_rows = (int)value;
-  else if (!strcmp(key, "agg.pass2_stream")) o.pass2_stream = (int)value;
-  else if (!strcmp(key, "agg.calibration_memo")) o.calibration_memo = (int)value;
-  else if (!strcmp(key, "agg.emit_async")) o.emit_async = (int)value;
-  else if (!strcmp(key, "agg.hot_keys")) o.hot_keys = (int)value;
-  else if (!strcmp(key, "agg.partition_layout")) o.partition_layout = (int)value;
-  else if (!strcmp(key, "agg.narrow_keys")) o.narrow_keys = (int)value;
-  else if (!strcmp(key, "agg.narrow_chunk16")) o.narrow_chunk16 = (int)value;
-  else if (!strcmp(key, "agg.shared_operand")) o.shared_operand = (int)value;
-  else if (!strcmp(key, "agg.ctrl_snapshot")) o.ctrl_snapshot = (int)value;
-  else if (!strcmp(key, "export.kernel_copy")) o.export_kernel_copy = (int)value;
-  else if (!strcmp(key, "agg.partition_producers")) o.partition_producers = (int)value;
-  else if (!strcmp(key, "agg.pass1_ws")) o.pass1_ws = (int)value;
-  else if (!strcmp(key, "filter.single_pass")) o.filter_single_pass = (int)value;
-  else if (!strcmp(key, "pool.trim")) pool_trim();
-  else return DFX_GENERAL;
-  return DFX_OK;
+  if (!strcmp(key, "pool.trim")) {
+    pool_trim();
+    return DFX_OK;
+  }
+  return set_option_in(agg_options(), key, value) ? DFX_OK : DFX_GENERAL;
 }
 
 }  // extern "C"

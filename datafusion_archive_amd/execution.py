@@ -59,6 +59,17 @@ def _release_schema(c: "_ffi.ArrowSchema") -> None:
         ctypes.CFUNCTYPE(None, ctypes.POINTER(_ffi.ArrowSchema))(c.release)(ctypes.byref(c))
 
 
+def _options(options: Optional[dict]):
+    """dict -> (dfx_option array or None, count, objects to keep alive during the call)"""
+    if not options:
+        return None, 0, None
+    keys = [k.encode() for k in options]
+    arr = (_ffi.OptionC * len(keys))()
+    for i, (k, v) in enumerate(zip(keys, options.values())):
+        arr[i].key, arr[i].value = k, int(v)
+    return arr, len(keys), keys
+
+
 class RuntimeExpr:
     """expression::RuntimeExpr (expression.rs:42-77)."""
 
@@ -203,14 +214,16 @@ class CsvDataSource(Relation):
 class FilterRelation(Relation):
     """filter::FilterRelation::new(input, expr, schema) (filter.rs:36)."""
 
-    def __init__(self, input: Relation, expr: RuntimeExpr, schema: Optional[pa.Schema] = None):
+    def __init__(self, input: Relation, expr: RuntimeExpr, schema: Optional[pa.Schema] = None, options: Optional[dict] = None):
+        """`options`: per-operator option set (include/dfx.h: dfx_option), e.g. {"filter.single_pass": 0}; not in the reference."""
         super().__init__()
         L = _ffi.lib()
         cs = _export_schema(schema)
         err = _errbuf()
+        opts, n_opts, _keep = _options(options)
         try:
-            code = L.dfx_filter_relation_new(ctypes.byref(input._take_stream()), expr._h, ctypes.byref(cs),
-                                             ctypes.byref(self._stream), err, 1024)
+            code = L.dfx_filter_relation_new_with_options(ctypes.byref(input._take_stream()), expr._h, ctypes.byref(cs), opts, n_opts,
+                                                          ctypes.byref(self._stream), err, 1024)
         finally:
             _release_schema(cs)
         _check(code, err)
@@ -290,17 +303,19 @@ class AggregateRelation(Relation):
     """aggregate::AggregateRelation::new(schema, input, group_expr, aggr_expr) (aggregate.rs:47-52)."""
 
     def __init__(self, schema: Optional[pa.Schema], input: Relation, group_expr: Sequence[RuntimeExpr],
-                 aggr_expr: Sequence[RuntimeExpr]):
+                 aggr_expr: Sequence[RuntimeExpr], options: Optional[dict] = None):
+        """`options`: per-operator option set (include/dfx.h: dfx_option), e.g. {"agg.strategy": 1}; not in the reference."""
         super().__init__()
         L = _ffi.lib()
         cs = _export_schema(schema)
         gs = (ctypes.c_void_p * max(1, len(group_expr)))(*[e._h for e in group_expr])
         as_ = (ctypes.c_void_p * max(1, len(aggr_expr)))(*[e._h for e in aggr_expr])
         err = _errbuf()
+        opts, n_opts, _keep = _options(options)
         try:
-            code = L.dfx_aggregate_relation_new(ctypes.byref(cs), ctypes.byref(input._take_stream()), gs,
-                                                len(group_expr), as_, len(aggr_expr),
-                                                ctypes.byref(self._stream), err, 1024)
+            code = L.dfx_aggregate_relation_new_with_options(ctypes.byref(cs), ctypes.byref(input._take_stream()), gs,
+                                                             len(group_expr), as_, len(aggr_expr), opts, n_opts,
+                                                             ctypes.byref(self._stream), err, 1024)
         finally:
             _release_schema(cs)
         _check(code, err)

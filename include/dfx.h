@@ -229,6 +229,24 @@ int32_t dfx_aggregate_relation_new(const struct ArrowSchema* schema, struct Arro
                                    const dfx_runtime_expr* const* aggr_exprs, int32_t n_aggr,
                                    struct ArrowArrayStream* out, char* err, size_t errlen);
 
+/* Per-operator options.  The reference's operators take no tuning knobs; this library's strategy switches (dfx_set_option
+ * below, process-wide defaults kept for benchmarks and debugging) can also be given to ONE operator: it starts from the
+ * process defaults as they are when it first runs, applies `options` on top, and is not affected by later dfx_set_option
+ * calls.  Keys are the ones dfx_set_option documents ("agg.strategy", "scan.fast", "filter.single_pass", ...); an unknown
+ * key is DFX_GENERAL.  No global mutable state is involved (thread-confined handles). */
+typedef struct dfx_option {
+  const char* key;
+  int64_t value;
+} dfx_option;
+int32_t dfx_filter_relation_new_with_options(struct ArrowArrayStream* input, const dfx_runtime_expr* expr,
+                                             const struct ArrowSchema* schema, const dfx_option* options, int32_t n_options,
+                                             struct ArrowArrayStream* out, char* err, size_t errlen);
+int32_t dfx_aggregate_relation_new_with_options(const struct ArrowSchema* schema, struct ArrowArrayStream* input,
+                                                const dfx_runtime_expr* const* group_exprs, int32_t n_group,
+                                                const dfx_runtime_expr* const* aggr_exprs, int32_t n_aggr,
+                                                const dfx_option* options, int32_t n_options,
+                                                struct ArrowArrayStream* out, char* err, size_t errlen);
+
 /* ------------------------------------------------------------------------------------------
  * HBM-resident tables: the in-memory DataSource (src/execution/datasource.rs:27-30 trait
  * DataSource; relation.rs:34-54 DataSourceRelation).  A table is uploaded (or generated) once

@@ -87,6 +87,13 @@ pub enum DfxTable {}
 pub enum DfxComm {}
 
 #[link(name = "dfx_hip")]
+/// One per-operator option (include/dfx.h: dfx_option): the operator starts from the process defaults and applies these on top.
+#[repr(C)]
+pub struct DfxOption {
+    pub key: *const c_char,
+    pub value: i64,
+}
+
 extern "C" {
     fn dfx_init(device: i32, err: *mut c_char, errlen: usize) -> i32;
     fn dfx_compile_scalar_expr(nodes: *const DfxExprNode, n: i32, root: i32, schema: *const ArrowSchema,
@@ -104,6 +111,14 @@ extern "C" {
                                   group: *const *const DfxRuntimeExpr, n_group: i32,
                                   aggr: *const *const DfxRuntimeExpr, n_aggr: i32,
                                   out: *mut ArrowArrayStream, err: *mut c_char, errlen: usize) -> i32;
+    fn dfx_filter_relation_new_with_options(input: *mut ArrowArrayStream, expr: *const DfxRuntimeExpr, schema: *const ArrowSchema,
+                                            options: *const DfxOption, n_options: i32,
+                                            out: *mut ArrowArrayStream, err: *mut c_char, errlen: usize) -> i32;
+    fn dfx_aggregate_relation_new_with_options(schema: *const ArrowSchema, input: *mut ArrowArrayStream,
+                                               group: *const *const DfxRuntimeExpr, n_group: i32,
+                                               aggr: *const *const DfxRuntimeExpr, n_aggr: i32,
+                                               options: *const DfxOption, n_options: i32,
+                                               out: *mut ArrowArrayStream, err: *mut c_char, errlen: usize) -> i32;
     fn dfx_csv_datasource_new(filename: *const c_char, schema: *const ArrowSchema, batch_size: i64,
                               out: *mut ArrowArrayStream, err: *mut c_char, errlen: usize) -> i32;
     fn dfx_sort_relation_new(input: *mut ArrowArrayStream, exprs: *const *const DfxRuntimeExpr, ascending: *const i32,
@@ -546,9 +561,16 @@ impl GpuRelation {
     }
 
     pub fn filter(input: Rc<RefCell<Relation>>, expr: GpuExpr, schema: Arc<Schema>) -> Result<Self> {
+        Self::filter_with_options(input, expr, schema, &[])
+    }
+    pub fn filter_with_options(input: Rc<RefCell<Relation>>, expr: GpuExpr, schema: Arc<Schema>, options: &[(&str, i64)]) -> Result<Self> {
         let (mut inp, mut out, mut err) = (export_relation(input), Self::new_out(), [0 as c_char; ERRLEN]);
+        let keys: Vec<CString> = options.iter().map(|(k, _)| CString::new(*k).unwrap()).collect();
+        let opts: Vec<DfxOption> = options.iter().zip(keys.iter()).map(|((_, v), k)| DfxOption { key: k.as_ptr(), value: *v }).collect();
         let mut cs = export_schema(&schema);
-        let code = unsafe { dfx_filter_relation_new(&mut inp, expr.0, &cs, &mut *out, err.as_mut_ptr(), ERRLEN) };
+        let code = unsafe {
+            dfx_filter_relation_new_with_options(&mut inp, expr.0, &cs, opts.as_ptr(), opts.len() as i32, &mut *out, err.as_mut_ptr(), ERRLEN)
+        };
         unsafe { release_schema(&mut cs) };
         check(code, &err)?;
         Self::from_stream(out, schema)
@@ -563,13 +585,20 @@ impl GpuRelation {
         Self::from_stream(out, schema)
     }
     pub fn aggregate(schema: Arc<Schema>, input: Rc<RefCell<Relation>>, group: Vec<GpuExpr>, aggr: Vec<GpuExpr>) -> Result<Self> {
+        Self::aggregate_with_options(schema, input, group, aggr, &[])
+    }
+    /// The same with per-operator options, e.g. `&[("agg.strategy", 1)]`: no process-wide state is touched.
+    pub fn aggregate_with_options(schema: Arc<Schema>, input: Rc<RefCell<Relation>>, group: Vec<GpuExpr>, aggr: Vec<GpuExpr>,
+                                  options: &[(&str, i64)]) -> Result<Self> {
         let (mut inp, mut out, mut err) = (export_relation(input), Self::new_out(), [0 as c_char; ERRLEN]);
         let g: Vec<*const DfxRuntimeExpr> = group.iter().map(|e| e.0 as *const DfxRuntimeExpr).collect();
         let a: Vec<*const DfxRuntimeExpr> = aggr.iter().map(|e| e.0 as *const DfxRuntimeExpr).collect();
+        let keys: Vec<CString> = options.iter().map(|(k, _)| CString::new(*k).unwrap()).collect();
+        let opts: Vec<DfxOption> = options.iter().zip(keys.iter()).map(|((_, v), k)| DfxOption { key: k.as_ptr(), value: *v }).collect();
         let mut cs = export_schema(&schema);
         let code = unsafe {
-            dfx_aggregate_relation_new(&cs, &mut inp, g.as_ptr(), g.len() as i32, a.as_ptr(), a.len() as i32, &mut *out,
-                                       err.as_mut_ptr(), ERRLEN)
+            dfx_aggregate_relation_new_with_options(&cs, &mut inp, g.as_ptr(), g.len() as i32, a.as_ptr(), a.len() as i32,
+                                                    opts.as_ptr(), opts.len() as i32, &mut *out, err.as_mut_ptr(), ERRLEN)
         };
         unsafe { release_schema(&mut cs) };
         check(code, &err)?;

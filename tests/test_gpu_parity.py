@@ -268,7 +268,35 @@ def test_filter_single_pass_and_two_pass_agree_with_the_oracle(single_pass, fast
             assert_batches_identical(got[1], oracle.filter_next(pred, b.slice(777, 4096 * 3 + 5)), "sliced")
 
 
-def _wide_conjunction(n_cols, rng, nulls):
+def test_per_operator_options_override_the_process_defaults_for_one_operator_only():
+    """dfx_aggregate_relation_new_with_options / dfx_filter_relation_new_with_options: the option set belongs to the operator.
+    Two aggregates over the same rows in one process, one forced to the global-atomic table, one to the partitioned strategy,
+    while the process default (automatic) stays what it was; both against the oracle.  The Filter's own switch likewise."""
+    rng = np.random.default_rng(99)
+    n = 400000
+    b = pa.RecordBatch.from_arrays([pa.array(rng.integers(0, 50000, n).astype(np.int64)),
+                                    pa.array(rng.integers(0, 1 << 20, n).astype(np.float64) / 1024.0)], names=["k", "v"])
+    aggs = [agg("sum", Column(1), F64), agg("count", Column(1), DataType.UInt64)]
+    want = oracle.aggregate([Column(0)], aggs, [b])
+    plans = {}
+    for name, opts in (("table", {"agg.strategy": 1}), ("partitioned", {"agg.strategy": 3}), ("default", None)):
+        rel = ex.AggregateRelation(None, ex.DataSourceRelation(b.schema, [b]), [ex.compile_scalar_expr(None, Column(0), b.schema)],
+                                   [ex.compile_expr(None, a, b.schema) for a in aggs], options=opts)
+        got = rel.next()
+        assert_groups_identical(got, want, 1, name)
+        plans[name] = ex.explain(rel)
+    assert "ran 400000 rows: table (global atomics)" in plans["table"], plans["table"]
+    assert "ran 400000 rows: partitioned" in plans["partitioned"], plans["partitioned"]
+    assert "partitioned" not in plans["default"].split("; ran")[1]  # 50 000 groups in one 400 000-row batch: no calibration slice, not forced
+    pred = BinaryExpr(Column(1), Operator.Gt, lit(512.0))
+    for sp in (0, 1):
+        rel = ex.FilterRelation(ex.DataSourceRelation(b.schema, [b]), ex.compile_scalar_expr(None, pred, b.schema), b.schema,
+                                options={"filter.single_pass": sp})
+        assert_batches_identical(rel.next(), oracle.filter_next(pred, b), f"filter.single_pass={sp}")
+        assert ("single pass" in ex.explain(rel)) == bool(sp)
+
+
+
     """A batch of n_cols numeric columns and `c0 > a0 AND c0 < b0 AND c1 > a1 AND ...` over all of them."""
     n = 50021
     arrays, names, terms = [], [], []

@@ -267,6 +267,28 @@ def test_explain_baseline_shapes_hit_their_static_signatures():
     assert "SSA interpreter" in _explain_aggregate(kv, pred, [Column(0)], [AggregateFunction("SUM", [BinaryExpr(Column(1), Operator.Plus, Column(1))], f64)])
 
 
+def test_per_operator_options_are_validated_and_do_not_touch_the_process_defaults():
+    """include/dfx.h: dfx_*_relation_new_with_options.  An operator takes its own option set (process defaults + its
+    overrides); an unknown key is General; nothing global changes (no GPU needed: the constructors do no device work)."""
+    schema = pa.schema([("k", pa.int64()), ("v", pa.float64())])
+    b = pa.RecordBatch.from_pydict({"k": [1], "v": [2.0]}, schema=schema)
+    pred = BinaryExpr(Column(1), Operator.Gt, Literal(ScalarValue.Float64(1.0)))
+    sum_v = AggregateFunction("SUM", [Column(1)], DataType.Float64)
+
+    def tree(filter_opts=None, agg_opts=None):
+        rel = ex.FilterRelation(ex.DataSourceRelation(schema, [b]), ex.compile_scalar_expr(None, pred, schema), schema, options=filter_opts)
+        return ex.AggregateRelation(None, rel, [ex.compile_scalar_expr(None, Column(0), schema)], [ex.compile_expr(None, sum_v, schema)], options=agg_opts)
+    tree({"filter.single_pass": 0, "scan.fast": 0}, {"agg.strategy": 1, "agg.pass1_ws": 0})  # accepted
+    with pytest.raises(ex.ExecutionError) as e:
+        tree(agg_opts={"agg.no_such_knob": 1})
+    assert e.value.kind == "General" and "agg.no_such_knob" in e.value.message
+    with pytest.raises(ex.ExecutionError) as e:
+        tree(filter_opts={"bogus": 1})
+    assert e.value.kind == "General"
+    with pytest.raises(ex.ExecutionError):
+        ex.set_option("agg.no_such_knob", 1)  # the process-wide setter knows the same keys
+
+
 def test_explain_operator_tree_and_pushdown():
     schema = pa.schema([("k", pa.int64()), ("v", pa.float64()), ("w", pa.float64())])
     b = pa.RecordBatch.from_pydict({"k": [1], "v": [2.0], "w": [3.0]}, schema=schema)
