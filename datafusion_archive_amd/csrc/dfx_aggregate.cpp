@@ -1347,6 +1347,9 @@ Status AggregateRelation::Impl::drain() {
     spill.words = nullptr;
     spill.capacity = 0;
   }
+  // one slice per routing window from a resident table, whatever batch width its scan was created with (the result of an
+  // aggregate does not depend on it; every slice costs a pass-1 launch)
+  if (opt().merge_scan_batches) input->prefer_batch_rows((int64_t)1 << 27);
   for (;;) {
     DeviceBatch b;
     bool has = false;
@@ -1462,17 +1465,22 @@ Status AggregateRelation::Impl::emit_grouped(DeviceBatch* out, int64_t expected)
     DeviceColumn& c = out->columns[k];
     c.dtype = dt;
     c.length = g;
-    DFX_HIP(launch_compact(plane, 8, (const uint64_t*)mask.get(), (const uint64_t*)offsets.get(), n_slots, dense.get(), 0, s, (uint64_t)g));
     const DictKey* dk = nullptr;
     for (const DictKey& d : dicts)
       if (d.key == k) dk = &d;
+    if (dk || dtype_width(dt) != 8)
+      DFX_HIP(launch_compact(plane, 8, (const uint64_t*)mask.get(), (const uint64_t*)offsets.get(), n_slots, dense.get(), 0, s, (uint64_t)g));
     if (dk) {  // ids -> Arrow Utf8
       DFX_RETURN_IF_ERROR(dict_emit(*dk, (const uint64_t*)dense.get(), g, &c));
       continue;
     }
     auto vals = device_alloc((size_t)std::max<int64_t>(g, 1) * dtype_width(dt), &st);
     if (!vals) return st;
-    DFX_HIP(launch_finalize((const uint64_t*)dense.get(), g, (uint8_t)dt, (uint8_t)VT_RAW, vals.get(), s));
+    if (dtype_width(dt) == 8) {  // the plane's words ARE the column: compact straight into it (one kernel and 16 bytes per group less)
+      DFX_HIP(launch_compact(plane, 8, (const uint64_t*)mask.get(), (const uint64_t*)offsets.get(), n_slots, vals.get(), 0, s, (uint64_t)g));
+    } else {
+      DFX_HIP(launch_finalize((const uint64_t*)dense.get(), g, (uint8_t)dt, (uint8_t)VT_RAW, vals.get(), s));
+    }
     c.values = vals.get();
     c.owners.push_back(vals);
   }
@@ -1484,9 +1492,11 @@ Status AggregateRelation::Impl::emit_grouped(DeviceBatch* out, int64_t expected)
     c.length = g;
     auto vals = device_alloc((size_t)std::max<int64_t>(g, 1) * dtype_width(dt), &st);
     if (!vals) return st;
+    const bool raw8 = !outs[j].avg && dtype_width(dt) == 8 && (val_xform_all[a] == VT_RAW || val_xform_all[a] == VT_COUNT_VALID);  // SUM(f64 / i64), COUNT: no image to undo
     DFX_HIP(launch_compact(accs_full + (size_t)a * T.stride, 8, (const uint64_t*)mask.get(), (const uint64_t*)offsets.get(), n_slots,
-                           dense.get(), 0, s, (uint64_t)g));
-    if (!outs[j].avg) {
+                           raw8 ? vals.get() : dense.get(), 0, s, (uint64_t)g));
+    if (raw8) {
+    } else if (!outs[j].avg) {
       DFX_HIP(launch_finalize((const uint64_t*)dense.get(), g, (uint8_t)dt, val_xform_all[a], vals.get(), s));
     } else {  // SUM plane / COUNT plane (deviation D7); groups that counted nothing are null
       auto dense_cnt = device_alloc(sizeof(uint64_t) * (size_t)std::max<int64_t>(g, 1), &st);

@@ -178,6 +178,10 @@ struct Relation {
   // the number of groups an aggregate's calibration slice produced, keyed by a fingerprint of the fused program, so that
   // the second query of the same shape does not pay for the slice and its synchronous read-back again.
   virtual struct ScanMemo* scan_memo() { return nullptr; }
+  // A consumer whose result does not depend on the batch width (an aggregate) may ask a source that slices RESIDENT data
+  // for batches of at least `rows` rows: a scan of an HBM table then hands out one slice per routing window instead of
+  // many small ones (each costs a launch).  Sources that produce batches (host streams, CSV) ignore it.
+  virtual void prefer_batch_rows(int64_t /*rows*/) {}
 };
 struct ScanMemo {  // shared by every scan of a resident table (a `mutable` member of a const TableData): guarded
   mutable std::mutex mu;

@@ -22,6 +22,17 @@ Status error_from_ctrl(uint32_t bits) {
 // =================================================================================================
 namespace {
 
+// Host Arrow batches -> HBM, PINNED and one batch AHEAD (relation.rs:34-54 is the reference's feed):
+//   * a batch's large buffers are page-locked in place (hipHostRegister: ~2 ms per 256 MB on these hosts, CPU work) and
+//     copied by the DMA engine straight out of the producer's memory on a copy stream of their own (57 GB/s against
+//     53-54 for the staged copy of pageable memory: tools/pin_probe.py);
+//   * batch i + 1 is pulled from the producer, registered and queued for copying BEFORE the host waits for batch i's
+//     copy: registration and the producer's own work overlap the DMA of the batch before, the copy stream never runs dry,
+//     and the consumer's kernels on batch i run while batch i + 1 crosses PCIe;
+//   * the producer's array is released when the copy event of ITS batch has fired -- never earlier (the buffers are
+//     borrowed), and without a synchronisation of the compute stream.
+// A buffer that cannot be registered (already registered by the producer, overlapping pages of a neighbouring buffer,
+// no lockable memory left) and small buffers go through the ordinary hipMemcpyAsync on the same copy stream.
 class HostStreamRelation : public Relation {
  public:
   explicit HostStreamRelation(struct ArrowArrayStream* s) {
@@ -29,6 +40,9 @@ class HostStreamRelation : public Relation {
     memset(s, 0, sizeof(*s));
   }
   ~HostStreamRelation() override {
+    drop(&pending_);
+    if (fence_) (void)hipEventDestroy(fence_);
+    if (copy_stream_) (void)hipStreamDestroy(copy_stream_);
     if (stream_.release) stream_.release(&stream_);
   }
   RelationKind kind() const override { return REL_HOST_STREAM; }
@@ -48,28 +62,96 @@ class HostStreamRelation : public Relation {
   void explain(std::string* out, int depth) const override {
     int n = 0;
     for (size_t i = 0; i < schema_.fields.size(); ++i) n += (needed_.empty() || needed_[i]) ? 1 : 0;
-    explain_line(out, depth, strfmt("HostStream: host Arrow batches, %d of %d columns uploaded per batch", n, (int)schema_.fields.size()));
+    explain_line(out, depth, strfmt("HostStream: host Arrow batches, %d of %d columns uploaded per batch (pinned in place, one batch ahead)", n,
+                                    (int)schema_.fields.size()));
   }
 
   Status next(DeviceBatch* out, bool* has) override {
     *has = false;
     DFX_RETURN_IF_ERROR(ensure_init());
-    struct ArrowArray arr;
-    memset(&arr, 0, sizeof(arr));
-    const int rc = stream_.get_next(&stream_, &arr);
-    if (rc != 0) return stream_error(rc, "get_next");
-    if (arr.release == nullptr) return Status::OK();  // end of stream == Ok(None)
-    Status st = upload(arr, out);
-    {  // host buffers are borrowed until here -- also when upload failed part-way: earlier columns' copies may be queued
-      hipError_t e = hipStreamSynchronize(ctx().stream);
+    if (!copy_stream_) DFX_HIP(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
+    if (!started_) {  // the first batch: nothing to overlap it with yet
+      started_ = true;
+      DFX_RETURN_IF_ERROR(fetch(&pending_));
+    }
+    if (!pending_.valid) {
+      Status st = pending_.error;  // an error met while prefetching surfaces when ITS batch is asked for
+      pending_.error = Status::OK();
+      return st;
+    }
+    InFlight cur;
+    std::swap(cur, pending_);
+    Status ahead = fetch(&pending_);  // queue the NEXT batch's copies behind this one's before waiting
+    if (!ahead.ok()) {
+      drop(&pending_);
+      pending_.error = ahead;
+    }
+    Status st = cur.upload;
+    if (cur.event) {  // the copies of this batch have read the producer's buffers: only now may they be released
+      hipError_t e = hipEventSynchronize(cur.event);
       if (e != hipSuccess && st.ok()) st = Status::Err(DFX_EXECUTION_ERROR, strfmt("HIP error %s after H2D", hipGetErrorString(e)));
     }
-    arr.release(&arr);
-    if (st.ok()) *has = true;
-    return st;
+    DeviceBatch b = std::move(cur.batch);
+    drop(&cur);
+    if (!st.ok()) return st;
+    *out = std::move(b);
+    *has = true;
+    return Status::OK();
   }
 
  private:
+  struct InFlight {
+    bool valid = false;
+    struct ArrowArray arr;        // the producer's batch, borrowed until `event` fires
+    DeviceBatch batch;
+    hipEvent_t event = nullptr;
+    std::vector<void*> registered;  // host ranges page-locked for this batch
+    Status upload, error;
+    InFlight() { memset(&arr, 0, sizeof(arr)); }
+  };
+
+  void drop(InFlight* f) {  // unpin, hand the array back to the producer
+    if (f->event) {
+      (void)hipEventSynchronize(f->event);
+      (void)hipEventDestroy(f->event);
+      f->event = nullptr;
+    }
+    for (void* p : f->registered) (void)hipHostUnregister(p);
+    f->registered.clear();
+    if (f->arr.release) f->arr.release(&f->arr);
+    memset(&f->arr, 0, sizeof(f->arr));
+    f->batch = DeviceBatch();
+    f->valid = false;
+  }
+
+  // pull one batch from the producer and queue its copies (f->valid stays false at the end of the stream)
+  Status fetch(InFlight* f) {
+    if (done_) return Status::OK();
+    const int rc = stream_.get_next(&stream_, &f->arr);
+    if (rc != 0) {
+      memset(&f->arr, 0, sizeof(f->arr));
+      return stream_error(rc, "get_next");
+    }
+    if (f->arr.release == nullptr) {  // end of stream == Ok(None)
+      done_ = true;
+      return Status::OK();
+    }
+    f->valid = true;
+    {  // The device buffers of this batch come from the pool: they may have been handed back by a consumer whose kernels are
+       // still queued on the library's stream.  The copies wait for everything that stream holds right now.
+      if (!fence_) DFX_HIP(hipEventCreateWithFlags(&fence_, hipEventDisableTiming));
+      DFX_HIP(hipEventRecord(fence_, ctx().stream));
+      DFX_HIP(hipStreamWaitEvent(copy_stream_, fence_, 0));
+    }
+    f->upload = upload(f->arr, &f->batch, f);
+    hipError_t e = hipEventCreateWithFlags(&f->event, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventRecord(f->event, copy_stream_);
+    if (e != hipSuccess && f->upload.ok()) f->upload = Status::Err(DFX_EXECUTION_ERROR, strfmt("HIP error %s after H2D", hipGetErrorString(e)));
+    // the consumer's kernels run on the library's stream: they start when the copies have landed
+    if (f->event) (void)hipStreamWaitEvent(ctx().stream, f->event, 0);
+    return Status::OK();
+  }
+
   Status stream_error(int rc, const char* what) {
     const char* m = stream_.get_last_error ? stream_.get_last_error(&stream_) : nullptr;
     // our own streams return a dfx_status; foreign producers an errno
@@ -77,16 +159,21 @@ class HostStreamRelation : public Relation {
     return Status::Err(code, m ? std::string(m) : strfmt("input stream %s failed with code %d", what, rc));
   }
 
-  Status h2d(const void* host, size_t bytes, std::shared_ptr<void>* dev) {
+  Status h2d(const void* host, size_t bytes, std::shared_ptr<void>* dev, InFlight* f) {
     Status st;
     *dev = device_alloc(bytes ? bytes : 8, &st);
     if (!*dev) return st;
-    if (bytes) DFX_HIP(hipMemcpyAsync(dev->get(), host, bytes, hipMemcpyHostToDevice, ctx().stream));
+    if (bytes >= kPinThreshold && hipHostRegister(const_cast<void*>(host), bytes, hipHostRegisterDefault) == hipSuccess) {
+      f->registered.push_back(const_cast<void*>(host));
+    } else if (bytes >= kPinThreshold) {
+      (void)hipGetLastError();  // not lockable (already registered, overlapping pages ...): the staged copy below still works
+    }
+    if (bytes) DFX_HIP(hipMemcpyAsync(dev->get(), host, bytes, hipMemcpyHostToDevice, copy_stream_));
     counters().h2d_bytes += (long long)bytes;
     return Status::OK();
   }
 
-  Status upload(const struct ArrowArray& arr, DeviceBatch* out) {
+  Status upload(const struct ArrowArray& arr, DeviceBatch* out, InFlight* f) {
     if ((size_t)arr.n_children != schema_.fields.size())
       return Status::Err(DFX_ARROW_ERROR, strfmt("batch has %lld columns, schema has %zu", (long long)arr.n_children, schema_.fields.size()));
     out->num_rows = arr.length;
@@ -109,7 +196,7 @@ class HostStreamRelation : public Relation {
       if (validity && c->null_count != 0) {
         std::shared_ptr<void> dv;
         const int64_t b0 = off >> 3, b1 = (off + n + 7) >> 3;
-        DFX_RETURN_IF_ERROR(h2d(validity + b0, (size_t)(b1 - b0), &dv));
+        DFX_RETURN_IF_ERROR(h2d(validity + b0, (size_t)(b1 - b0), &dv, f));
         d.validity = (const uint8_t*)dv.get();
         d.owners.push_back(dv);
         d.null_count = c->null_count < 0 ? -1 : c->null_count;
@@ -123,10 +210,10 @@ class HostStreamRelation : public Relation {
         const int32_t* offs = no_offsets ? kZeroOffset : (const int32_t*)c->buffers[1] + off;
         const uint8_t* data = (const uint8_t*)c->buffers[2];
         std::shared_ptr<void> doff, ddata;
-        DFX_RETURN_IF_ERROR(h2d(offs, sizeof(int32_t) * (size_t)(n + 1), &doff));
+        DFX_RETURN_IF_ERROR(h2d(offs, sizeof(int32_t) * (size_t)(n + 1), &doff, f));
         const int32_t o0 = offs[0], o1 = offs[n];
         if (o1 < o0 || (o1 > o0 && !data)) return Status::Err(DFX_ARROW_ERROR, "Utf8 array with inconsistent offsets");
-        DFX_RETURN_IF_ERROR(h2d(data ? data + o0 : nullptr, (size_t)(o1 - o0), &ddata));
+        DFX_RETURN_IF_ERROR(h2d(data ? data + o0 : nullptr, (size_t)(o1 - o0), &ddata, f));
         d.offsets = (const int32_t*)doff.get();
         d.data = (const uint8_t*)ddata.get() - o0;  // raw offsets index straight into it
         d.data_bytes = o1 - o0;
@@ -136,14 +223,14 @@ class HostStreamRelation : public Relation {
         if (c->n_buffers < 2) return Status::Err(DFX_ARROW_ERROR, "Boolean array without 2 buffers");
         std::shared_ptr<void> dv;
         const int64_t b0 = off >> 3, b1 = (off + n + 7) >> 3;
-        DFX_RETURN_IF_ERROR(h2d((const uint8_t*)c->buffers[1] + b0, (size_t)(b1 - b0), &dv));
+        DFX_RETURN_IF_ERROR(h2d((const uint8_t*)c->buffers[1] + b0, (size_t)(b1 - b0), &dv, f));
         d.values = dv.get();
         d.owners.push_back(dv);
       } else {
         if (c->n_buffers < 2) return Status::Err(DFX_ARROW_ERROR, "primitive array without 2 buffers");
         const int w = dtype_width(dt);
         std::shared_ptr<void> dv;
-        DFX_RETURN_IF_ERROR(h2d((const uint8_t*)c->buffers[1] + (size_t)off * w, (size_t)n * w, &dv));
+        DFX_RETURN_IF_ERROR(h2d((const uint8_t*)c->buffers[1] + (size_t)off * w, (size_t)n * w, &dv, f));
         d.values = dv.get();
         d.owners.push_back(dv);
       }
@@ -151,9 +238,14 @@ class HostStreamRelation : public Relation {
     return Status::OK();
   }
 
+  static constexpr size_t kPinThreshold = (size_t)1 << 20;  // smaller buffers: the staged copy costs less than locking pages
   struct ArrowArrayStream stream_;
   SchemaInfo schema_;
   std::vector<char> needed_;
+  hipStream_t copy_stream_ = nullptr;
+  hipEvent_t fence_ = nullptr;
+  InFlight pending_;  // the batch that is crossing PCIe while the consumer works on the one before
+  bool started_ = false, done_ = false;
 };
 
 // =================================================================================================

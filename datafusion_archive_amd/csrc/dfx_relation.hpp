@@ -36,6 +36,9 @@ class TableScanRelation : public Relation {
   const SchemaInfo& schema() const override { return table_->schema; }
   void explain(std::string* out, int depth) const override;
   ScanMemo* scan_memo() override { return &table_->memo; }  // every scan starts at row 0
+  void prefer_batch_rows(int64_t rows) override {
+    if (!emitted_any_ && rows > batch_rows_) batch_rows_ = rows & ~(int64_t)63;
+  }
 
  private:
   std::shared_ptr<const TableData> table_;
@@ -80,6 +83,8 @@ struct AggOptions {
   int pass1_ws = 8;            // pass 1 of selective scans over narrow keys: wave-specialised kernel with this many scanner waves of 16
                                // (0: the ring kernel, every wave scans and routes; the headline's signature also has 6 / 10 / 12
                                // and, + 100, eight row groups per scanner trip: A/B runs)
+  int merge_scan_batches = 1;  // an aggregate over a scan of a resident table asks for slices of >= 2^27 rows (one per routing window)
+                               // whatever batch width the scan was created with; 0: the caller's batch width is kept
   int filter_single_pass = 1;  // FilterRelation: predicate + bitmap + tile offsets (decoupled look-back) + compaction of the predicate's own
                                // columns in ONE kernel (0: k_predicate_mask -> scan -> k_compact, the column is read twice)
   int replay_in_place = 1;     // 1: rows spilled by a table that is NOT full (region overflow of a heavy key) are replayed into the

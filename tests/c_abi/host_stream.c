@@ -1,0 +1,204 @@
+/* host_stream.c -- a plain C PRODUCER of host Arrow batches (what the reference's DataSourceRelation is to its operators,
+ * relation.rs:34-54) feeding the library through include/dfx.h, with a release callback that POISONS its buffers before
+ * it frees them.  The library borrows a batch's buffers only until it calls release: if a copy to HBM were still reading
+ * them then (or read them later), the aggregate below would see the poison.
+ *
+ *   SELECT k, SUM(v), COUNT(v) FROM batches WHERE v >= 0 GROUP BY k       k = row mod 97, v = (row * 7 mod 1024) / 4
+ *
+ * built as  gcc -std=c11 -I include tests/c_abi/host_stream.c -L datafusion_archive_amd/lib -ldfx_hip -o ...
+ * Prints "OK batches=<b> released=<r> groups=<g> max_outstanding=<m>" after checking every group against the closed form,
+ * or "ERR ...". */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "dfx.h"
+
+#define GROUPS 97
+
+typedef struct {
+  int64_t rows_per_batch;
+  int n_batches, produced, released, outstanding, max_outstanding;
+} producer;
+
+typedef struct {
+  producer* p;
+  int64_t n;
+  int64_t* k;
+  double* v;
+  const void* kbuf[2];
+  const void* vbuf[2];
+  const void* sbuf[1];
+  struct ArrowArray kid[2];
+  struct ArrowArray* kids[2];
+} batch_priv;
+
+static void release_child(struct ArrowArray* a) { a->release = NULL; }
+
+static void release_batch(struct ArrowArray* a) {
+  batch_priv* b = (batch_priv*)a->private_data;
+  /* poison, THEN free: whoever still reads these buffers gets 0xA5 bytes (k = a huge negative key, v = -1.7e-133...) */
+  memset(b->k, 0xA5, sizeof(int64_t) * (size_t)b->n);
+  memset(b->v, 0xA5, sizeof(double) * (size_t)b->n);
+  free(b->k);
+  free(b->v);
+  b->p->released++;
+  b->p->outstanding--;
+  free(b);
+  a->release = NULL;
+}
+
+static int get_schema(struct ArrowArrayStream* s, struct ArrowSchema* out);
+static void release_schema(struct ArrowSchema* s) {
+  if (s->children) {
+    for (int64_t i = 0; i < s->n_children; ++i) {
+      if (s->children[i]->release) s->children[i]->release(s->children[i]);
+      free(s->children[i]);
+    }
+    free(s->children);
+  }
+  s->release = NULL;
+}
+static void fill_schema(struct ArrowSchema* s, const char* format, const char* name, int64_t n_children) {
+  memset(s, 0, sizeof(*s));
+  s->format = format;
+  s->name = name;
+  s->n_children = n_children;
+  s->release = release_schema;
+  if (n_children) {
+    s->children = (struct ArrowSchema**)calloc((size_t)n_children, sizeof(struct ArrowSchema*));
+    for (int64_t i = 0; i < n_children; ++i) s->children[i] = (struct ArrowSchema*)calloc(1, sizeof(struct ArrowSchema));
+  }
+}
+static int get_schema(struct ArrowArrayStream* s, struct ArrowSchema* out) {
+  (void)s;
+  fill_schema(out, "+s", "", 2);
+  fill_schema(out->children[0], "l", "k", 0);
+  fill_schema(out->children[1], "g", "v", 0);
+  return 0;
+}
+
+static int get_next(struct ArrowArrayStream* s, struct ArrowArray* out) {
+  producer* p = (producer*)s->private_data;
+  memset(out, 0, sizeof(*out));
+  if (p->produced >= p->n_batches) return 0; /* released array == end of stream */
+  batch_priv* b = (batch_priv*)calloc(1, sizeof(batch_priv));
+  b->p = p;
+  b->n = p->rows_per_batch;
+  b->k = (int64_t*)malloc(sizeof(int64_t) * (size_t)b->n);
+  b->v = (double*)malloc(sizeof(double) * (size_t)b->n);
+  const int64_t row0 = (int64_t)p->produced * p->rows_per_batch;
+  for (int64_t i = 0; i < b->n; ++i) {
+    b->k[i] = (row0 + i) % GROUPS;
+    b->v[i] = (double)(((row0 + i) * 7) % 1024) / 4.0;
+  }
+  b->kbuf[0] = NULL; b->kbuf[1] = b->k;
+  b->vbuf[0] = NULL; b->vbuf[1] = b->v;
+  b->sbuf[0] = NULL;
+  for (int c = 0; c < 2; ++c) {
+    memset(&b->kid[c], 0, sizeof(struct ArrowArray));
+    b->kid[c].length = b->n;
+    b->kid[c].n_buffers = 2;
+    b->kid[c].buffers = c == 0 ? b->kbuf : b->vbuf;
+    b->kid[c].release = release_child;
+    b->kids[c] = &b->kid[c];
+  }
+  out->length = b->n;
+  out->n_buffers = 1;
+  out->buffers = b->sbuf;
+  out->n_children = 2;
+  out->children = b->kids;
+  out->release = release_batch;
+  out->private_data = b;
+  p->produced++;
+  p->outstanding++;
+  if (p->outstanding > p->max_outstanding) p->max_outstanding = p->outstanding;
+  return 0;
+}
+static const char* get_last_error(struct ArrowArrayStream* s) { (void)s; return NULL; }
+static void release_stream(struct ArrowArrayStream* s) { s->release = NULL; }
+
+#define CHECK(call)                                                     \
+  do {                                                                  \
+    int32_t st_ = (call);                                               \
+    if (st_ != DFX_OK) {                                                \
+      printf("ERR %d %s (%s)\n", (int)st_, err, #call);                 \
+      return 1;                                                         \
+    }                                                                   \
+  } while (0)
+
+static dfx_expr_node node(int kind) {
+  dfx_expr_node n;
+  memset(&n, 0, sizeof(n));
+  n.kind = kind;
+  n.left = n.right = n.column = -1;
+  return n;
+}
+
+int main(int argc, char** argv) {
+  char err[512] = {0};
+  producer p;
+  memset(&p, 0, sizeof(p));
+  p.rows_per_batch = argc > 1 ? atoll(argv[1]) : (1 << 22);
+  p.n_batches = argc > 2 ? atoi(argv[2]) : 6;
+  CHECK(dfx_init(0, err, sizeof(err)));
+  struct ArrowArrayStream src, filtered, agg;
+  memset(&src, 0, sizeof(src));
+  src.get_schema = get_schema;
+  src.get_next = get_next;
+  src.get_last_error = get_last_error;
+  src.release = release_stream;
+  src.private_data = &p;
+  struct ArrowSchema schema;
+  get_schema(&src, &schema);
+
+  dfx_expr_node q[3];
+  q[0] = node(DFX_EXPR_COLUMN);  q[0].column = 1;
+  q[1] = node(DFX_EXPR_LITERAL); q[1].dtype = DFX_FLOAT64; q[1].lit.f64 = 0.0;
+  q[2] = node(DFX_EXPR_BINARY);  q[2].op = DFX_OP_GT_EQ; q[2].left = 0; q[2].right = 1;
+  dfx_runtime_expr *pred = NULL, *key = NULL, *sum = NULL, *cnt = NULL;
+  CHECK(dfx_compile_scalar_expr(q, 3, 2, &schema, &pred, err, sizeof(err)));
+  dfx_expr_node k = node(DFX_EXPR_COLUMN); k.column = 0;
+  CHECK(dfx_compile_scalar_expr(&k, 1, 0, &schema, &key, err, sizeof(err)));
+  dfx_expr_node a[2];
+  a[0] = node(DFX_EXPR_COLUMN); a[0].column = 1;
+  a[1] = node(DFX_EXPR_AGGREGATE_FUNCTION); a[1].dtype = DFX_FLOAT64; a[1].left = 0; a[1].n_args = 1; a[1].name = "SUM";
+  CHECK(dfx_compile_expr(a, 2, 1, &schema, &sum, err, sizeof(err)));
+  a[1].dtype = DFX_UINT64; a[1].name = "COUNT";
+  CHECK(dfx_compile_expr(a, 2, 1, &schema, &cnt, err, sizeof(err)));
+  CHECK(dfx_filter_relation_new(&src, pred, &schema, &filtered, err, sizeof(err)));
+  const dfx_runtime_expr* groups_[1] = {key};
+  const dfx_runtime_expr* aggs_[2] = {sum, cnt};
+  CHECK(dfx_aggregate_relation_new(NULL, &filtered, groups_, 1, aggs_, 2, &agg, err, sizeof(err)));
+
+  struct ArrowArray out;
+  if (agg.get_next(&agg, &out) != 0) { printf("ERR %s\n", agg.get_last_error(&agg)); return 1; }
+  if (out.release == NULL || out.n_children != 3) { printf("ERR no batch\n"); return 1; }
+  if (p.released != p.n_batches || p.outstanding != 0) { printf("ERR %d of %d batches released when the result arrived\n", p.released, p.n_batches); return 1; }
+  /* the closed form, group by group (v is a multiple of 1/4 below 256: every sum is exact) */
+  static double want_sum[GROUPS];
+  static unsigned long long want_cnt[GROUPS];
+  const int64_t total = p.rows_per_batch * p.n_batches;
+  for (int64_t r = 0; r < total; ++r) {
+    want_sum[r % GROUPS] += (double)((r * 7) % 1024) / 4.0;
+    want_cnt[r % GROUPS] += 1;
+  }
+  const int64_t* keys = (const int64_t*)out.children[0]->buffers[1];
+  const double* sums = (const double*)out.children[1]->buffers[1];
+  const uint64_t* counts = (const uint64_t*)out.children[2]->buffers[1];
+  if (out.length != GROUPS) { printf("ERR %lld groups (a poisoned key would add one)\n", (long long)out.length); return 1; }
+  for (int64_t i = 0; i < out.length; ++i) {
+    const int64_t g = keys[i];
+    if (g < 0 || g >= GROUPS || sums[i] != want_sum[g] || counts[i] != want_cnt[g]) {
+      printf("ERR group %lld: sum %.17g count %llu, expected %.17g %llu\n", (long long)g, sums[i], (unsigned long long)counts[i],
+             g >= 0 && g < GROUPS ? want_sum[g] : 0.0, g >= 0 && g < GROUPS ? want_cnt[g] : 0ull);
+      return 1;
+    }
+  }
+  out.release(&out);
+  agg.release(&agg);
+  schema.release(&schema);
+  dfx_runtime_expr_free(pred); dfx_runtime_expr_free(key); dfx_runtime_expr_free(sum); dfx_runtime_expr_free(cnt);
+  printf("OK batches=%d released=%d groups=%d max_outstanding=%d\n", p.n_batches, p.released, GROUPS, p.max_outstanding);
+  return 0;
+}

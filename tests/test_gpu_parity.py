@@ -1187,6 +1187,39 @@ def test_c_abi_consumer_in_plain_c(tmp_path):
     assert int(got["rows_passing"]) == int(np.sum(want.column(2).to_numpy()))
 
 
+def test_aggregate_over_a_table_scan_merges_small_scan_batches():
+    """agg.merge_scan_batches (library default 1; the test suite runs with 0): an aggregate over a scan of a resident table
+    asks the scan for one slice per routing window.  Same groups either way; far fewer batches reach the aggregate."""
+    n = 3000000
+    t = ex.DeviceTable.synth(SYN, 0xDF02, 0, n)
+    schema = pa.schema([("k", pa.int64()), ("v", pa.float64())])
+    aggs = [agg("sum", Column(1), F64), agg("count", Column(1), DataType.UInt64)]
+    res = {}
+    for merge in (0, 1):
+        rel = ex.AggregateRelation(None, t.scan(4096), [ex.compile_scalar_expr(None, Column(0), schema)],
+                                   [ex.compile_expr(None, a, schema) for a in aggs], options={"agg.merge_scan_batches": merge})
+        res[merge] = rel.next()
+    assert_groups_identical(res[1], res[0], 1, "merged scan batches")
+    want = oracle.aggregate([Column(0)], aggs, [oracle.synth_batch(SYN, 0xDF02, 0, n)])
+    assert_groups_identical(res[1], want, 1, "merged scan batches vs oracle")
+
+
+def test_host_batches_are_borrowed_until_their_copy_has_finished(tmp_path):
+    """Row (g) of the round-2 review: host Arrow batches are pinned in place and copied one batch ahead; the producer's
+    release callback must fire only after the copy of ITS batch has read the buffers.  tests/c_abi/host_stream.c is a C
+    producer that poisons and frees its buffers on release and checks every group of the result against the closed form;
+    it also reports how many batches the library held at once (2: the one in use and the one crossing PCIe)."""
+    import subprocess
+    from test_host_logic import _build_c_abi_program
+    exe = _build_c_abi_program(tmp_path, "host_stream")
+    for rows, batches in ((1 << 22, 6), (1000, 5), (1 << 20, 1), (300000, 3)):  # large (pinned in place) and small (staged) buffers
+        r = subprocess.run([exe, str(rows), str(batches)], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and r.stdout.startswith("OK"), r.stdout + r.stderr
+        got = dict(kv.split("=") for kv in r.stdout.split()[1:])
+        assert int(got["released"]) == batches and int(got["groups"]) == 97
+        assert int(got["max_outstanding"]) <= 2, r.stdout
+
+
 def test_large_properties_filter_groupby_sum():
     """2^28 rows (4 GB): sum over groups of SUM(v) == ungrouped SUM(v) bit for bit (exact data),
     sum of COUNTs == rows passing the predicate == ungrouped COUNT."""

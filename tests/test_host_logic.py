@@ -143,6 +143,29 @@ def _build_c_abi_smoke(tmp_path):
     return exe
 
 
+def _build_c_abi_program(tmp_path, name):
+    """gcc-compile tests/c_abi/<name>.c against the built library"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "datafusion_archive_amd", "lib")
+    exe = os.path.join(str(tmp_path), name)
+    subprocess.run(["gcc", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(root, "include"),
+                    os.path.join(root, "tests", "c_abi", name + ".c"), "-L", libdir, "-ldfx_hip",
+                    "-Wl,-rpath," + libdir, "-o", exe], check=True)
+    return exe
+
+
+def test_c_producer_of_host_batches_compiles(tmp_path):
+    """tests/c_abi/host_stream.c (a plain C Arrow stream producer that poisons its buffers on release) builds against the
+    header; without a GPU it fails loudly like every other entry point (its GPU run: test_gpu_parity.py)."""
+    import subprocess
+    import torch
+    exe = _build_c_abi_program(tmp_path, "host_stream")
+    if not torch.cuda.is_available():
+        r = subprocess.run([exe, "1000", "2"], capture_output=True, text=True)
+        assert r.returncode != 0 and r.stdout.startswith("ERR"), r.stdout + r.stderr
+
+
 def test_c_abi_header_compiles_as_c_and_fails_loudly_without_gpu(tmp_path):
     """include/dfx.h is valid C11, a C program links against the library, and on a machine without a GPU the
     very first call reports an error instead of falling back to a CPU path."""
