@@ -725,9 +725,16 @@ hipError_t launch_partition(const DevProgram& P, const DevFastPlan& fast, const 
     return hipGetLastError();
   }
   const bool use_fast = fast.valid && !P.has_nulls;
-  if (P.n_cols <= 2) { if (use_fast) launch_partition_variant2(P, fast, C, plan, T, PT, spill, n, lds_bytes, s); else launch_partition_variant3(P, fast, C, plan, T, PT, spill, n, lds_bytes, s); }
-  else if (P.n_cols <= 4) { if (use_fast) launch_partition_variant4(P, fast, C, plan, T, PT, spill, n, lds_bytes, s); else launch_partition_variant5(P, fast, C, plan, T, PT, spill, n, lds_bytes, s); }
-  else { if (use_fast) launch_partition_variant6(P, fast, C, plan, T, PT, spill, n, lds_bytes, s); else launch_partition_variant7(P, fast, C, plan, T, PT, spill, n, lds_bytes, s); }
+  // The wave-specialised flavour pays when the scan loop is short (compile-time signatures).  The run-time decoded shapes and
+  // the interpreter spend several times as many instructions per row group: eight scanner waves cannot keep up, sixteen
+  // symmetric ones can (measured with PTF_WS on every policy: FastPolicy queries -25 %, the interpreter -28 %).  Same regions,
+  // counts and padding either way, so the choice is made per launch.
+  DevPartition PTg = PT;
+  PTg.flags &= ~PTF_WS;
+  const size_t lds_g = partition_stage_bytes(PTg);
+  if (P.n_cols <= 2) { if (use_fast) launch_partition_variant2(P, fast, C, plan, T, PTg, spill, n, lds_g, s); else launch_partition_variant3(P, fast, C, plan, T, PTg, spill, n, lds_g, s); }
+  else if (P.n_cols <= 4) { if (use_fast) launch_partition_variant4(P, fast, C, plan, T, PTg, spill, n, lds_g, s); else launch_partition_variant5(P, fast, C, plan, T, PTg, spill, n, lds_g, s); }
+  else { if (use_fast) launch_partition_variant6(P, fast, C, plan, T, PTg, spill, n, lds_g, s); else launch_partition_variant7(P, fast, C, plan, T, PTg, spill, n, lds_g, s); }
   return hipGetLastError();
 }
 

@@ -10,7 +10,7 @@
 //     their own single-producer / single-consumer LDS queue: ~30 vector instructions per 64-row group, nothing in their
 //     loop ever waits for a chunk slot or issues a global store;
 //   * 16 - NS ROUTER waves poll the queues of "their" scanners (scanner s belongs to router s mod NR), take 64 rows at a
-//     time at full lane utilisation and run the ring protocol (ring_route, one inlined copy): hash -> partition -> fill
+//     time at full lane utilisation -- two batches side by side when a queue holds 128 -- and run the ring protocol (ring_route2, one inlined copy): hash -> partition -> fill
 //     atomic -> ring -> commit -> cooperative 192-byte flushes.
 // A scanner stalls only when its queue is full (the router then has >= 64 rows to take, so it cannot be a deadlock);
 // a router waits only for rows or for another router's flush of a LOWER chunk -- the argument of the ring kernel.
@@ -207,27 +207,32 @@ __global__ __launch_bounds__(kRingBlock) void k_partition_ws(const DevProgram P,
         const uint32_t head = sc->head;  // (only this wave writes it)
         uint32_t tail = __hip_atomic_load(&sc->tail, __ATOMIC_ACQUIRE, WG_SCOPE);
         uint32_t avail = tail - head;
-        uint32_t take = avail >= 64u ? 64u : 0u;
+        uint32_t take = avail >= 128u ? 128u : avail >= 64u ? 64u : 0u;  // whole batches of 64, two at a time when they are there
         if (take == 0 && __hip_atomic_load(&sc->done, __ATOMIC_ACQUIRE, WG_SCOPE) != 0u) {
           tail = __hip_atomic_load(&sc->tail, __ATOMIC_ACQUIRE, WG_SCOPE);  // the final count was published before `done`
           avail = tail - head;
-          take = avail < 64u ? avail : 64u;
+          take = avail < 128u ? avail : 128u;
           if (avail == 0) fin |= 1u << j;
         }
         if (take == 0) continue;
-        const bool have = (uint32_t)lane < take;
-        const uint32_t at = (head + (uint32_t)lane) & (uint32_t)(kWsQueueRows - 1);
-        uint64_t k2[1];
-        uint64_t v2[kMaxAggs];
+        bool have[2];
+        uint64_t k2[2], v2[2], h2[2];
 #pragma unroll
-        for (int a = 0; a < kMaxAggs; ++a) v2[a] = 0;
-        k2[0] = have ? (uint64_t)qkeys[(size_t)s * kWsQueueRows + at] : 0ull;
-        v2[0] = have ? qvals[(size_t)s * kWsQueueRows + at] : 0ull;
+        for (int b = 0; b < 2; ++b) {  // (both batches' queue reads in flight together)
+          have[b] = (uint32_t)(b * 64 + lane) < take;
+          const uint32_t at = (head + (uint32_t)(b * 64 + lane)) & (uint32_t)(kWsQueueRows - 1);
+          k2[b] = have[b] ? (uint64_t)qkeys[(size_t)s * kWsQueueRows + at] : 0ull;
+          v2[b] = have[b] ? qvals[(size_t)s * kWsQueueRows + at] : 0ull;
+        }
         // the slots are free again as soon as the rows sit in registers
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         if (lane == 0) __hip_atomic_store(&sc->head, head + take, __ATOMIC_RELEASE, WG_SCOPE);
-        const uint64_t h2 = hash_keys<1>(k2);
-        ring_route<1, kWsCH, kWsRP, 1>(T, PT, spill, L, producer, 1, have, k2, v2, h2, err);
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          uint64_t k1[1] = {k2[b]};
+          h2[b] = hash_keys<1>(k1);
+        }
+        ring_route2<kWsCH, kWsRP, 1>(T, PT, spill, L, producer, have, k2, v2, h2, err);
         progress = true;
       }
       if (!progress) {

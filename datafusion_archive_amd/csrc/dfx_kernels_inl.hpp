@@ -375,6 +375,7 @@ DEV bool eval_predicate(const DevProgram& P, ROWSTATE_CPARAMS, uint8_t pred) {
 template <int BANK, int U_>
 struct InterpPolicy {
   static constexpr bool kIsStatic = false;
+  static constexpr int kPredTerms = -1;  // (run-time)
   static constexpr int U = U_;
   static constexpr int kStaticNa = 0;  // aggregates known at compile time (0: run-time)
   typedef typename Bank<BANK>::type COLV;
@@ -451,6 +452,7 @@ DEV bool lane_of_mask(uint64_t mask) { return __builtin_amdgcn_inverse_ballot_w6
 template <int BANK, int U_>
 struct FastPolicy {
   static constexpr bool kIsStatic = false;
+  static constexpr int kPredTerms = -1;  // (run-time)
   static constexpr int U = U_;
   static constexpr int kStaticNa = 0;  // aggregates known at compile time (0: run-time)
   typedef typename Bank<BANK>::type COLV;
@@ -525,6 +527,7 @@ struct FastPolicy1 : FastPolicy<BANK, U_> {
 template <int BANK, int U_, typename SIG>
 struct StaticPolicy {
   static constexpr bool kIsStatic = true;
+  static constexpr int kPredTerms = SIG::NP;  // 0: the signature has no predicate (every in-range row passes)
   static constexpr int U = U_;
   static constexpr int kStaticNa = SIG::NA;
   typedef typename Bank<BANK>::type COLV;

@@ -22,17 +22,15 @@ Status error_from_ctrl(uint32_t bits) {
 // =================================================================================================
 namespace {
 
-// Host Arrow batches -> HBM, PINNED and one batch AHEAD (relation.rs:34-54 is the reference's feed):
-//   * a batch's large buffers are page-locked in place (hipHostRegister: ~2 ms per 256 MB on these hosts, CPU work) and
-//     copied by the DMA engine straight out of the producer's memory on a copy stream of their own (57 GB/s against
-//     53-54 for the staged copy of pageable memory: tools/pin_probe.py);
-//   * batch i + 1 is pulled from the producer, registered and queued for copying BEFORE the host waits for batch i's
-//     copy: registration and the producer's own work overlap the DMA of the batch before, the copy stream never runs dry,
-//     and the consumer's kernels on batch i run while batch i + 1 crosses PCIe;
+// Host Arrow batches -> HBM, one batch AHEAD on a copy stream of its own (relation.rs:34-54 is the reference's
+// feed):
+//   * batch i + 1 is pulled from the producer and its copies are queued BEFORE the host waits for batch i's: the copy
+//     stream never runs dry, and the consumer's kernels on batch i run while batch i + 1 crosses PCIe;
 //   * the producer's array is released when the copy event of ITS batch has fired -- never earlier (the buffers are
-//     borrowed), and without a synchronisation of the compute stream.
-// A buffer that cannot be registered (already registered by the producer, overlapping pages of a neighbouring buffer,
-// no lockable memory left) and small buffers go through the ordinary hipMemcpyAsync on the same copy stream.
+//     borrowed), and without a synchronisation of the compute stream;
+//   * the copies are HIP's staged copies of pageable memory (pinned staging buffers inside the runtime: 53-54 GB/s here).
+//     Page-locking the producer's buffers in place (hipHostRegister, DFX_HOST_PIN=1) lets the DMA engine read them
+//     directly at 57 GB/s, but the locking itself costs half a transfer and was measured slower end to end (see below).
 class HostStreamRelation : public Relation {
  public:
   explicit HostStreamRelation(struct ArrowArrayStream* s) {
@@ -62,7 +60,7 @@ class HostStreamRelation : public Relation {
   void explain(std::string* out, int depth) const override {
     int n = 0;
     for (size_t i = 0; i < schema_.fields.size(); ++i) n += (needed_.empty() || needed_[i]) ? 1 : 0;
-    explain_line(out, depth, strfmt("HostStream: host Arrow batches, %d of %d columns uploaded per batch (pinned in place, one batch ahead)", n,
+    explain_line(out, depth, strfmt("HostStream: host Arrow batches, %d of %d columns uploaded per batch (one batch ahead, own copy stream)", n,
                                     (int)schema_.fields.size()));
   }
 
@@ -163,10 +161,9 @@ class HostStreamRelation : public Relation {
     Status st;
     *dev = device_alloc(bytes ? bytes : 8, &st);
     if (!*dev) return st;
-    if (bytes >= kPinThreshold && hipHostRegister(const_cast<void*>(host), bytes, hipHostRegisterDefault) == hipSuccess) {
-      f->registered.push_back(const_cast<void*>(host));
-    } else if (bytes >= kPinThreshold) {
-      (void)hipGetLastError();  // not lockable (already registered, overlapping pages ...): the staged copy below still works
+    if (pin_in_place_ && bytes >= kPinThreshold) {
+      if (hipHostRegister(const_cast<void*>(host), bytes, hipHostRegisterDefault) == hipSuccess) f->registered.push_back(const_cast<void*>(host));
+      else (void)hipGetLastError();  // not lockable (already registered, overlapping pages ...): the staged copy below still works
     }
     if (bytes) DFX_HIP(hipMemcpyAsync(dev->get(), host, bytes, hipMemcpyHostToDevice, copy_stream_));
     counters().h2d_bytes += (long long)bytes;
@@ -239,6 +236,12 @@ class HostStreamRelation : public Relation {
   }
 
   static constexpr size_t kPinThreshold = (size_t)1 << 20;  // smaller buffers: the staged copy costs less than locking pages
+  // DFX_HOST_PIN=1: page-lock the producer's large buffers in place (hipHostRegister) and let the DMA engine read them
+  // directly.  Off by default: measured end to end it LOSES (bench.py host_streamed_pcie_inclusive: 46 GB/s against 53-54
+  // for HIP's own staged copy of pageable memory) although the copy out of registered memory alone is faster (57 GB/s,
+  // tools/pin_probe.py) -- locking 256 MB costs 2.2 ms of the 4.7 ms its transfer takes, and it does not overlap the
+  // transfer of the batch before.
+  bool pin_in_place_ = getenv("DFX_HOST_PIN") && atoi(getenv("DFX_HOST_PIN")) != 0;
   struct ArrowArrayStream stream_;
   SchemaInfo schema_;
   std::vector<char> needed_;

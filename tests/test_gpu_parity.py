@@ -296,7 +296,7 @@ def test_per_operator_options_override_the_process_defaults_for_one_operator_onl
         assert ("single pass" in ex.explain(rel)) == bool(sp)
 
 
-
+def _wide_conjunction(n_cols, rng, nulls):
     """A batch of n_cols numeric columns and `c0 > a0 AND c0 < b0 AND c1 > a1 AND ...` over all of them."""
     n = 50021
     arrays, names, terms = [], [], []
