@@ -466,6 +466,19 @@ def main():
         dg2, _ = timed(lambda: step(pred, (Column(0),), (sum_2v,)), k3, 1)
         extra["product_argument_query"] = rate(n_rows * k3, dg2, 16, "SELECT k, SUM(v * 2.0) WHERE v > lo AND v < hi GROUP BY k (no static signature: FastPolicy)")
 
+        # two aggregates of DIFFERENT operands over 10^6 groups (generic 24-byte routed rows: no shared operand, no narrow form)
+        try:
+            syn_w = syn + [("w", ex.SYNTH_F64_EXACT, 2, 0.0, 0.0)]
+            schema_w = pa.schema([("k", pa.int64()), ("v", pa.float64()), ("w", pa.float64())])
+            tw = ex.DeviceTable.synth(syn_w, seed, 0, n_rows)
+            min_w = AggregateFunction("MIN", [Column(2)], f64)
+            dgw, _ = timed(lambda: build_on(tw, schema_w, pred, [Column(0)], [sum_v, min_w]).next(), k3, 1)
+            extra["different_operand_sum_min"] = rate(n_rows * k3, dgw, 24, "SELECT k, SUM(v), MIN(w) WHERE v > lo AND v < hi GROUP BY k (two aggregates of "
+                                                      "different operands: 24-byte routed rows {key, two operands}); 24 B/row read")
+            del tw
+        except Exception as e:  # a measurement, not a gate
+            extra["different_operand_sum_min"] = {"error": str(e)[:200]}
+
         # skewed keys (Zipf s = 1.0; the generator is log-uniform, p(k) ~ 1/k), same query
         syn_z = [("k", ex.SYNTH_I64_ZIPF, 0, float(GROUPS), 1.0), ("v", ex.SYNTH_F64_EXACT, 1, 0.0, 0.0)]
         tz = ex.DeviceTable.synth(syn_z, seed, 0, n_rows)

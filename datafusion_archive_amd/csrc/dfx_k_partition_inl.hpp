@@ -858,48 +858,11 @@ __global__ __launch_bounds__(kRingBlock) void k_partition_ring(const DevProgram 
 #ifdef DFX_RING_WAIT_ALL
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
-    // DENSE scans without a predicate (config 3's signature: every row is routed): no compaction queue -- a group IS a full
-    // batch -- and two groups are routed side by side (ring_route2: their LDS round trips overlap; a routed row cost
-    // 3.7 ns x CU with one batch per call, the whole of pass 1 when every row is routed)
-    if constexpr (NV == 1 && !HOT && kRingRP >= 16 && POL::kIsStatic && POL::kPredTerms == 0 && (U % 2) == 0) {
-#pragma unroll
-      for (int u0 = 0; u0 < U; u0 += 2) {
-        bool have[2];
-        uint64_t k2[2], v2[2], h2[2];
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-          const int u = u0 + b;
-          const int64_t row = (w0 + u) * 64 + lane;
-          const bool inb = row < n;
-          u64x16 reg;
-          uint32_t rv = 0;
-          POL::eval(P, F, col[u], cv[u], reg, rv, inb, err);
-          uint64_t v;
-          bool valid;
-          k2[b] = POL::key(P, F, plan.key[0], 0, col[u], cv[u], reg, rv);
-          POL::arg(P, F, plan.arg[0], 0, col[u], cv[u], reg, rv, v, valid);
-          v2[b] = transform_value(shared ? (uint8_t)VT_RAW : POL::xform(T, 0), v, valid);
-          have[b] = inb;
-          passed += inb ? 1 : 0;
-          if (__ballot(inb && k2[b] == kEmptyKey) != 0) {  // the claim-sentinel key lives outside the blocks
-            if (inb && k2[b] == kEmptyKey) {
-              uint64_t sv[kMaxAggs];
-              if (shared) {
-                expand_shared_operand(T, v2[b], sv);
-              } else {
-#pragma unroll
-                for (int a = 0; a < kMaxAggs; ++a) sv[a] = a == 0 ? v2[b] : 0ull;
-              }
-              sentinel_apply(T, sv);
-              have[b] = false;
-            }
-          }
-          uint64_t k1[1] = {k2[b]};
-          h2[b] = hash_keys<1>(k1);
-        }
-        ring_route2<kRingCH, kRingRP, NARROW>(T, PT, spill, L, producer, have, k2, v2, h2, err);
-      }
-    } else
+    // (Routing two full groups side by side straight from registers -- ring_route2, no compaction queue -- was tried for
+    // dense scans without a predicate, config 3's signature: 424-429 us per 2^26-row launch against 373-414 for the queue +
+    // one batch per call below.  128 rows in flight per wave x 16 waves outrun the 32-row rings: lanes wait for chunk
+    // slots and hold BOTH batches up.  The routers of the wave-specialised kernel -- eight waves -- use it: no measurable
+    // difference there, 388-408 us per launch with it, 383-413 without.)
     FOR_U {
       const int64_t row = (w0 + u) * 64 + lane;
       const bool inb = row < n;

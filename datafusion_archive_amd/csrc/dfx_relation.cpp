@@ -22,15 +22,19 @@ Status error_from_ctrl(uint32_t bits) {
 // =================================================================================================
 namespace {
 
-// Host Arrow batches -> HBM, one batch AHEAD on a copy stream of its own (relation.rs:34-54 is the reference's
-// feed):
-//   * batch i + 1 is pulled from the producer and its copies are queued BEFORE the host waits for batch i's: the copy
-//     stream never runs dry, and the consumer's kernels on batch i run while batch i + 1 crosses PCIe;
-//   * the producer's array is released when the copy event of ITS batch has fired -- never earlier (the buffers are
-//     borrowed), and without a synchronisation of the compute stream;
-//   * the copies are HIP's staged copies of pageable memory (pinned staging buffers inside the runtime: 53-54 GB/s here).
-//     Page-locking the producer's buffers in place (hipHostRegister, DFX_HOST_PIN=1) lets the DMA engine read them
-//     directly at 57 GB/s, but the locking itself costs half a transfer and was measured slower end to end (see below).
+// Host Arrow batches -> HBM (relation.rs:34-54 is the reference's feed).  PCIe Gen5 x16 moves ~57 GB/s out of
+// pinned memory here, HBM streams at > 6 TB/s: this relation is bound by the link whatever it does, and the three forms
+// below differ by how close they get to it (tools/pin_probe.py, tools/host_stream_probe.py, bench.py
+// host_streamed_pcie_inclusive; round 3):
+//   * in order (default): copies on the library's stream, one synchronisation per batch, then the producer's array is
+//     released.  HIP moves large pageable buffers by pinning them chunk-wise inside the runtime: 53-54 GB/s = 0.85 of the link;
+//   * DFX_HOST_PREFETCH=1: batch i + 1 pulled and copied on a second stream while the consumer works on batch i, arrays
+//     released on their copy event: 40-43 GB/s -- a pageable copy blocks its caller whichever stream it is queued on;
+//   * + DFX_HOST_PIN=1: the producer's buffers page-locked in place (hipHostRegister) so that the DMA engine reads them
+//     directly (57 GB/s for the copy alone): 40-46 GB/s end to end -- locking 256 MB costs 2.2 ms of the 4.7 ms its transfer
+//     takes and does not overlap the transfer before it.
+// In every form the producer's buffers are only read between get_next and release (tests/c_abi/host_stream.c poisons them on
+// release), and columns nobody reads downstream never cross the link (require_columns).
 class HostStreamRelation : public Relation {
  public:
   explicit HostStreamRelation(struct ArrowArrayStream* s) {
@@ -67,6 +71,7 @@ class HostStreamRelation : public Relation {
   Status next(DeviceBatch* out, bool* has) override {
     *has = false;
     DFX_RETURN_IF_ERROR(ensure_init());
+    if (!prefetch_) return next_in_order(out, has);
     if (!copy_stream_) DFX_HIP(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
     if (!started_) {  // the first batch: nothing to overlap it with yet
       started_ = true;
@@ -91,6 +96,30 @@ class HostStreamRelation : public Relation {
     }
     DeviceBatch b = std::move(cur.batch);
     drop(&cur);
+    if (!st.ok()) return st;
+    *out = std::move(b);
+    *has = true;
+    return Status::OK();
+  }
+
+  // The default: a batch is copied on the library's own stream when it is asked for, the producer's array is released when
+  // the stream has passed the copies.  HIP copies large pageable buffers by pinning them chunk-wise inside the runtime:
+  // 53-54 GB/s here = 0.85 of the link, which is what this path delivers end to end.
+  Status next_in_order(DeviceBatch* out, bool* has) {
+    InFlight f;
+    copy_stream_in_use_ = ctx().stream;
+    Status st = fetch_into(&f, /*fence=*/false);
+    if (!st.ok() || !f.valid) {
+      drop(&f);
+      return st;
+    }
+    st = f.upload;
+    {  // host buffers are borrowed until here -- also when upload failed part-way: earlier columns' copies may be queued
+      hipError_t e = hipStreamSynchronize(ctx().stream);
+      if (e != hipSuccess && st.ok()) st = Status::Err(DFX_EXECUTION_ERROR, strfmt("HIP error %s after H2D", hipGetErrorString(e)));
+    }
+    DeviceBatch b = std::move(f.batch);
+    drop(&f);
     if (!st.ok()) return st;
     *out = std::move(b);
     *has = true;
@@ -122,8 +151,12 @@ class HostStreamRelation : public Relation {
     f->valid = false;
   }
 
-  // pull one batch from the producer and queue its copies (f->valid stays false at the end of the stream)
   Status fetch(InFlight* f) {
+    copy_stream_in_use_ = copy_stream_;
+    return fetch_into(f, /*fence=*/true);
+  }
+  // pull one batch from the producer and queue its copies (f->valid stays false at the end of the stream)
+  Status fetch_into(InFlight* f, bool fence) {
     if (done_) return Status::OK();
     const int rc = stream_.get_next(&stream_, &f->arr);
     if (rc != 0) {
@@ -135,6 +168,10 @@ class HostStreamRelation : public Relation {
       return Status::OK();
     }
     f->valid = true;
+    if (!fence) {  // copies on the library's own stream: in order with everything else, the caller synchronises it
+      f->upload = upload(f->arr, &f->batch, f);
+      return Status::OK();
+    }
     {  // The device buffers of this batch come from the pool: they may have been handed back by a consumer whose kernels are
        // still queued on the library's stream.  The copies wait for everything that stream holds right now.
       if (!fence_) DFX_HIP(hipEventCreateWithFlags(&fence_, hipEventDisableTiming));
@@ -165,7 +202,7 @@ class HostStreamRelation : public Relation {
       if (hipHostRegister(const_cast<void*>(host), bytes, hipHostRegisterDefault) == hipSuccess) f->registered.push_back(const_cast<void*>(host));
       else (void)hipGetLastError();  // not lockable (already registered, overlapping pages ...): the staged copy below still works
     }
-    if (bytes) DFX_HIP(hipMemcpyAsync(dev->get(), host, bytes, hipMemcpyHostToDevice, copy_stream_));
+    if (bytes) DFX_HIP(hipMemcpyAsync(dev->get(), host, bytes, hipMemcpyHostToDevice, copy_stream_in_use_));
     counters().h2d_bytes += (long long)bytes;
     return Status::OK();
   }
@@ -242,6 +279,13 @@ class HostStreamRelation : public Relation {
   // tools/pin_probe.py) -- locking 256 MB costs 2.2 ms of the 4.7 ms its transfer takes, and it does not overlap the
   // transfer of the batch before.
   bool pin_in_place_ = getenv("DFX_HOST_PIN") && atoi(getenv("DFX_HOST_PIN")) != 0;
+  // DFX_HOST_PREFETCH=1: batch i + 1 is pulled from the producer and copied on a stream of its own while the consumer works
+  // on batch i, the producer's array released on the copy's event (no synchronisation of the compute stream).  Off by
+  // default for the same reason: 40-43 GB/s end to end against 53 for the in-order form (tools/host_stream_probe.py) -- a
+  // pageable copy blocks the calling thread whichever stream it is queued on, so nothing overlaps, and the second stream
+  // costs the runtime's pinned-chunk pipeline its rhythm.
+  bool prefetch_ = getenv("DFX_HOST_PREFETCH") && atoi(getenv("DFX_HOST_PREFETCH")) != 0;
+  hipStream_t copy_stream_in_use_ = nullptr;
   struct ArrowArrayStream stream_;
   SchemaInfo schema_;
   std::vector<char> needed_;
