@@ -71,10 +71,7 @@ __global__ __launch_bounds__(kFGBlock) void k_fewgroup_agg(const DevProgram P, c
   for (int64_t w0 = wave_global * U; w0 < n_words; w0 += n_waves * U) {
     COLV col[U];
     uint32_t cv[U];
-    FOR_U {
-      const int64_t row = (w0 + u) * 64 + lane;
-      POL::load(P, C, row, row < n, col[u], cv[u]);
-    }
+    load_trip<POL>(P, C, w0, true, n, lane, col, cv);
 #pragma nounroll
     for (int uu = 0; uu < U; ++uu) {  // ONE copy of the evaluation + accumulation code
       COLV cur;

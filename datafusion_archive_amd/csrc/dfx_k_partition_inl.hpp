@@ -829,10 +829,7 @@ __global__ __launch_bounds__(kRingBlock) void k_partition_ring(const DevProgram 
 #pragma unroll
   for (int d = 0; d < kRingDepth; ++d) {
     const int64_t w0 = wave_global * U + (int64_t)d * n_waves * U;
-    FOR_U {
-      const int64_t row = (w0 + u) * 64 + lane;
-      POL::load(P, C, row, row < n && w0 < n_groups, ncol[d][u], ncv[d][u]);
-    }
+    load_trip<POL>(P, C, w0, w0 < n_groups, n, lane, ncol[d], ncv[d]);  // (static signatures: one scalar base per column, clamped 32-bit lane indices)
   }
   for (int64_t w0 = wave_global * U; w0 < n_groups; w0 += n_waves * U) {
     COLV col[U];
@@ -850,10 +847,7 @@ __global__ __launch_bounds__(kRingBlock) void k_partition_ring(const DevProgram 
     }
     {
       const int64_t w1 = w0 + (int64_t)kRingDepth * n_waves * U;
-      FOR_U {
-        const int64_t row = (w1 + u) * 64 + lane;
-        POL::load(P, C, row, row < n, ncol[kRingDepth - 1][u], ncv[kRingDepth - 1][u]);
-      }
+      load_trip<POL>(P, C, w1, w1 < n_groups, n, lane, ncol[kRingDepth - 1], ncv[kRingDepth - 1]);
     }
 #ifdef DFX_RING_WAIT_ALL
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -1,4 +1,6 @@
 // dfx_k_reduce.hip -- K5 reduce_all (ungrouped aggregates), its own translation unit.
+#include <type_traits>
+
 #include "dfx_kernels_inl.hpp"
 #include "dfx_launch.hpp"
 
@@ -32,19 +34,19 @@ __global__ __launch_bounds__(kBlock) void k_reduce(const DevProgram P, const Dev
   }
   uint32_t err = 0;
   uint64_t passed = 0;
+  // the scan loop once per comparison FORM (StaticPolicy::pass_form: the operators as compile-time constants; 0: run-time masks)
+  auto scan = [&](auto form_tag) {
+  constexpr int FORM = decltype(form_tag)::value;
   for (int64_t w0 = wave_global * U; w0 < n_words; w0 += n_waves * U) {
     COLV col[U];
     uint32_t cv[U];
-    FOR_U {
-      const int64_t row = (w0 + u) * 64 + lane;
-      POL::load(P, C, row, row < n, col[u], cv[u]);
-    }
+    load_trip<POL>(P, C, w0, true, n, lane, col, cv);
     auto body = [&](const COLV& cur, const uint32_t curv, const int64_t row) {
       const bool inb = row < n;
       u64x16 reg;
       uint32_t rv = 0;
       POL::eval(P, F, cur, curv, reg, rv, inb, err);
-      const bool pass = inb && POL::pass(P, F, plan.pred, cur, curv, reg, rv);
+      const bool pass = inb && POL::template pass_form<FORM>(P, F, plan.pred, cur, curv, reg, rv);
       if (pass) {
         ++passed;
 #pragma unroll
@@ -84,6 +86,14 @@ __global__ __launch_bounds__(kBlock) void k_reduce(const DevProgram P, const Dev
         body(cur, curv, (w0 + uu) * 64 + lane);
       }
     }
+  }
+  };
+  switch (POL::form_of(F)) {  // (wave-uniform: the plan sits in the kernarg segment)
+    case 4 | (1 << 3): scan(std::integral_constant<int, (POL::kIsStatic ? (4 | (1 << 3)) : 0)>{}); break;  // x >  a AND x <  b
+    case 6 | (1 << 3): scan(std::integral_constant<int, (POL::kIsStatic ? (6 | (1 << 3)) : 0)>{}); break;  // x >= a AND x <  b
+    case 4 | (3 << 3): scan(std::integral_constant<int, (POL::kIsStatic ? (4 | (3 << 3)) : 0)>{}); break;  // x >  a AND x <= b
+    case 6 | (3 << 3): scan(std::integral_constant<int, (POL::kIsStatic ? (6 | (3 << 3)) : 0)>{}); break;  // x >= a AND x <= b
+    default: scan(std::integral_constant<int, 0>{}); break;
   }
   // wave tree (xor butterfly), then one atomic per workgroup per word
 #pragma unroll
