@@ -156,7 +156,9 @@ def main():
     if world > 1:
         ok = 1
         try:
-            if shared_gpu:
+            if shared_gpu and not os.environ.get("DFX_RCCL_LIB"):
+                # (with DFX_RCCL_LIB = tests/native/librccl_stub.so the library's own exchange runs between the ranks of a
+                # one-GPU dry run, host-staged: plumbing only)
                 raise RuntimeError("dry run: every rank on one GPU (RCCL needs one device per rank)")
             from datafusion_archive_amd.distributed import library_communicator
             comm = library_communicator(world, rank, dist)
