@@ -266,9 +266,29 @@ def main():
              AggregateFunction("sum", [BinaryExpr(dp, Operator.Multiply, BinaryExpr(l64(1.0), Operator.Plus, Column(5)))], f64)]
     pred5 = BinaryExpr(BinaryExpr(Column(6), Operator.LtEq, l64(2436.0)), Operator.And, BinaryExpr(Column(4), Operator.GtEq, l64(0.0)))
     count_qty = AggregateFunction("COUNT", [Column(2)], DataType.UInt64)
+    # the neighbours of the headline query measured as extras (defined here: their oracle runs start before any timing)
+    pred_n = BinaryExpr(BinaryExpr(Column(1), Operator.GtEq, l64(LO)), Operator.And, BinaryExpr(Column(1), Operator.Lt, l64(HI)))
+    min_v = AggregateFunction("MIN", [Column(1)], f64)
+    pred_1 = BinaryExpr(Column(1), Operator.Lt, l64(LO))
+    sum_2v = AggregateFunction("SUM", [BinaryExpr(Column(1), Operator.Multiply, l64(2.0))], f64)
+    pred_3 = BinaryExpr(pred, Operator.And, BinaryExpr(Column(0), Operator.GtEq, Literal(ScalarValue.Int64(0))))
+    syn_w = syn + [("w", ex.SYNTH_F64_EXACT, 2, 0.0, 0.0)]
+    schema_w = pa.schema([("k", pa.int64()), ("v", pa.float64()), ("w", pa.float64())])
+    min_w = AggregateFunction("MIN", [Column(2)], f64)
+    syn_z = [("k", ex.SYNTH_I64_ZIPF, 0, float(GROUPS), 1.0), ("v", ex.SYNTH_F64_EXACT, 1, 0.0, 0.0)]
+    # name -> (generator columns, schema, predicate, aggregates): every one checked on the first verify_rows rows
+    neighbours = {"headline_through_interpreter": (syn, schema, pred, [sum_v]),
+                  "neighbour_query_sum_min": (syn, schema, pred_n, [sum_v, min_v]),
+                  "one_term_predicate_query": (syn, schema, pred_1, [sum_v]),
+                  "product_argument_query": (syn, schema, pred, [sum_2v]),
+                  "three_term_predicate_query": (syn, schema, pred_3, [sum_v]),
+                  "different_operand_sum_min": (syn_w, schema_w, pred, [sum_v, min_w]),
+                  "zipf_keys": (syn_z, schema, pred, [sum_v])}
     bg = {}
     if want_oracle:
         import oracle  # tests/oracle.py: the CPU restatement -- the reported baseline AND the checker of the GPU results
+        for name, (cols_, _sch, filt_, aggs_) in neighbours.items():
+            bg[name] = Background(oracle.run_synth_query, cols_, seed, 0, verify_rows, 1024, filt_, [Column(0)], list(aggs_))
         bg["cfg2"] = Background(oracle.run_synth_filter, syn_lat, seed2, 0, verify_rows, 1024, pred2)
         bg["cfg3"] = Background(oracle.run_synth_query, syn, seed, 0, verify_rows, 1024, None, [Column(0)], [sum_v])
         bg["cfg5"] = Background(oracle.run_synth_query, syn5, seed, 0, verify_rows, 1024, pred5, [Column(0), Column(1)], aggs5 + [count_qty])
@@ -372,6 +392,28 @@ def main():
         except Exception as e:
             return {"rows": verify_rows, "ok": False, "error": f"{name}: {str(e)[:300]}"}
 
+    def verify_neighbour(name, options=()):
+        """the extra `name` over the first verify_rows rows of its table, every group and every aggregate against the CPU
+        oracle bit for bit (exact data: SUMs, MINs and doubled terms have one representable answer)"""
+        def run():
+            cols_, sch_, filt_, aggs_ = neighbours[name]
+            t_s = ex.DeviceTable.synth(cols_, seed, 0, verify_rows)
+            for k_, v_ in options:
+                ex.set_option(k_, v_)
+            try:
+                got = build_on(t_s, sch_, filt_, [Column(0)], list(aggs_)).next()
+            finally:
+                for k_, _v in options:
+                    ex.set_option(k_, 1)
+            _secs, kept, want = bg[name].get()
+            g, w = by_key(got), by_key(want)
+            ok = len(g) == len(w) and len(g[0]) == len(w[0]) and np.array_equal(g[0], w[0])
+            for a_, b_ in zip(g[1:], w[1:]):
+                ok = ok and np.array_equal(np.ascontiguousarray(a_).view(np.uint64), np.ascontiguousarray(b_).view(np.uint64))
+            return {"rows": verify_rows, "groups": int(len(w[0])), "rows_passing": int(kept), "ok": bool(ok),
+                    "what": "every group, every aggregate bit-exact, GPU (same options, same batch width) vs CPU oracle over the same rows"}
+        return checked(name, run)
+
     extra["prewarm_steps"] = args.prewarm_steps
     extra["cold_first_step_ms"] = cold_first_step_ms
     if want_extras:
@@ -444,6 +486,14 @@ def main():
             return {"rows": verify_rows, "rows_passing": int(kept), "ok": ok,
                     "what": "the Arrow bitmap of every batch and the compacted column, GPU vs CPU oracle (orc_filter_next, 1024-row batches), bit for bit"}
         extra["cfg2_filter_mask_and_compact"]["verified_vs_oracle"] = checked("cfg2", verify_cfg2)
+
+        def verify_cfg2_count():
+            t_s = t2 if verify_rows == n_rows else ex.DeviceTable.synth(syn_lat, seed2, 0, verify_rows)
+            got = build_on(t_s, schema2, pred2, [], [count_lat]).next().column(0)[0].as_py() or 0
+            _secs, kept, _c, _m = bg["cfg2"].get()
+            return {"rows": verify_rows, "rows_passing": int(kept), "ok": bool(int(got) == int(kept)),
+                    "what": "COUNT of the fused predicate + reduce, GPU vs the rows the CPU oracle's FilterRelation kept over the same slice"}
+        extra["cfg2_predicate_count"]["verified_vs_oracle"] = checked("cfg2_count", verify_cfg2_count)
         del t2
         extra["cfg3_groupby_sum_no_filter"]["verified_vs_oracle"] = checked("cfg3", verify_cfg3)
 
@@ -455,39 +505,44 @@ def main():
         finally:
             ex.set_option("scan.fast", 1)
         extra["headline_through_interpreter"] = rate(n_rows * k3, dgi, 16, "the headline query with scan.fast = 0 (generic SSA interpreter in every kernel)")
-        pred_n = BinaryExpr(BinaryExpr(Column(1), Operator.GtEq, l64(LO)), Operator.And, BinaryExpr(Column(1), Operator.Lt, l64(HI)))
-        min_v = AggregateFunction("MIN", [Column(1)], f64)
+        extra["headline_through_interpreter"]["verified_vs_oracle"] = verify_neighbour("headline_through_interpreter", (("scan.fast", 0),))
         dgn, _ = timed(lambda: step(pred_n, (Column(0),), (sum_v, min_v)), k3, 1)
         extra["neighbour_query_sum_min"] = rate(n_rows * k3, dgn, 16, "SELECT k, SUM(v), MIN(v) WHERE v >= lo AND v < hi GROUP BY k "
                                                 "(two aggregates of one operand: 12-byte routed rows {image, raw operand})")
+        extra["neighbour_query_sum_min"]["verified_vs_oracle"] = verify_neighbour("neighbour_query_sum_min")
         # shapes without a compile-time signature (FastPolicy: run-time decoded column-op-literal terms)
-        pred_1 = BinaryExpr(Column(1), Operator.Lt, l64(LO))
         dg1, _ = timed(lambda: step(pred_1, (Column(0),), (sum_v,)), k3, 1)
-        extra["one_term_predicate_query"] = rate(n_rows * k3, dg1, 16, "SELECT k, SUM(v) WHERE v < lo GROUP BY k (no static signature: FastPolicy)")
-        sum_2v = AggregateFunction("SUM", [BinaryExpr(Column(1), Operator.Multiply, l64(2.0))], f64)
+        extra["one_term_predicate_query"] = rate(n_rows * k3, dg1, 16, "SELECT k, SUM(v) WHERE v < lo GROUP BY k (one ordered Float64 comparison runs as the "
+                                                 "two-sided range v >= -inf AND v < lo: the headline's compile-time signature; FastPolicy until round 3)")
+        extra["one_term_predicate_query"]["verified_vs_oracle"] = verify_neighbour("one_term_predicate_query")
         dg2, _ = timed(lambda: step(pred, (Column(0),), (sum_2v,)), k3, 1)
-        extra["product_argument_query"] = rate(n_rows * k3, dg2, 16, "SELECT k, SUM(v * 2.0) WHERE v > lo AND v < hi GROUP BY k (no static signature: FastPolicy)")
+        extra["product_argument_query"] = rate(n_rows * k3, dg2, 16, "SELECT k, SUM(v * 2.0) WHERE v > lo AND v < hi GROUP BY k (signature KeyAffSumPred2F64 in pass 1: "
+                                               "argument = column <op> literal, the op read at run time; FastPolicy until round 3)")
+
+        extra["product_argument_query"]["verified_vs_oracle"] = verify_neighbour("product_argument_query")
+        # a shape NO compile-time signature covers (three terms, one of them on the Int64 key): FastPolicy, decoded at run time
+        dg3, _ = timed(lambda: step(pred_3, (Column(0),), (sum_v,)), k3, 1)
+        extra["three_term_predicate_query"] = rate(n_rows * k3, dg3, 16, "SELECT k, SUM(v) WHERE v > lo AND v < hi AND k >= 0 GROUP BY k (no static signature: FastPolicy)")
+        extra["three_term_predicate_query"]["verified_vs_oracle"] = verify_neighbour("three_term_predicate_query")
 
         # two aggregates of DIFFERENT operands over 10^6 groups (generic 24-byte routed rows: no shared operand, no narrow form)
         try:
-            syn_w = syn + [("w", ex.SYNTH_F64_EXACT, 2, 0.0, 0.0)]
-            schema_w = pa.schema([("k", pa.int64()), ("v", pa.float64()), ("w", pa.float64())])
             tw = ex.DeviceTable.synth(syn_w, seed, 0, n_rows)
-            min_w = AggregateFunction("MIN", [Column(2)], f64)
             dgw, _ = timed(lambda: build_on(tw, schema_w, pred, [Column(0)], [sum_v, min_w]).next(), k3, 1)
             extra["different_operand_sum_min"] = rate(n_rows * k3, dgw, 24, "SELECT k, SUM(v), MIN(w) WHERE v > lo AND v < hi GROUP BY k (two aggregates of "
                                                       "different operands: 24-byte routed rows {key, two operands}); 24 B/row read")
             del tw
+            extra["different_operand_sum_min"]["verified_vs_oracle"] = verify_neighbour("different_operand_sum_min")
         except Exception as e:  # a measurement, not a gate
             extra["different_operand_sum_min"] = {"error": str(e)[:200]}
 
         # skewed keys (Zipf s = 1.0; the generator is log-uniform, p(k) ~ 1/k), same query
-        syn_z = [("k", ex.SYNTH_I64_ZIPF, 0, float(GROUPS), 1.0), ("v", ex.SYNTH_F64_EXACT, 1, 0.0, 0.0)]
         tz = ex.DeviceTable.synth(syn_z, seed, 0, n_rows)
         dz, _ = timed(lambda: build_on(tz, schema, pred, [Column(0)], [sum_v]).next(), k3, 1)
         extra["zipf_keys"] = rate(n_rows * k3, dz, 16, "the headline query over Zipf(1.0)-distributed keys (10^6 keys)")
         extra["zipf_rows_per_s"] = n_rows * k3 / dz
         del tz
+        extra["zipf_keys"]["verified_vs_oracle"] = verify_neighbour("zipf_keys")
 
         # PCIe-inclusive rate: the same query over HOST Arrow batches (HostStreamRelation uploads every batch); never `value`
         try:
@@ -505,6 +560,15 @@ def main():
             e["roofline"] = {"bound": "pcie", "achieved": e["roofline"]["achieved"], "peak": 63.0, "unit": "GB/s",
                              "frac": round(e["roofline"]["achieved"] / 63.0, 4)}
             extra["host_streamed_pcie_inclusive"] = e
+
+            def verify_host():
+                got = host_step()
+                want = oracle.aggregate([Column(0)], [sum_v], [oracle.filter_next(pred, b) for b in hb])
+                g, w = by_key(got), by_key(want)
+                ok = len(g[0]) == len(w[0]) and np.array_equal(g[0], w[0]) and np.array_equal(g[1].view(np.uint64), w[1].view(np.uint64))
+                return {"rows": 4 * hb_rows, "groups": int(len(w[0])), "ok": bool(ok),
+                        "what": "SUM bit-exact for every group, GPU over the host batches vs the CPU oracle's FilterRelation + AggregateRelation over the same batches"}
+            extra["host_streamed_pcie_inclusive"]["verified_vs_oracle"] = checked("host_streamed", verify_host)
             del hb
         except Exception as e:  # a measurement, not a gate
             extra["host_streamed_pcie_inclusive"] = {"error": str(e)[:200]}

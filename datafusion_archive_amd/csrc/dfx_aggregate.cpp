@@ -574,7 +574,7 @@ Status AggregateRelation::Impl::ensure_partition(int64_t rows, bool nulls_now) {
     // pass, every wave has rows to route all the time and the ring kernel's symmetric waves are the better fit
     if ((PT.flags & PTF_CHUNK16) && o.pass1_ws > 0 && !dense_seen && !(((uint32_t)o.partition_mode) & ~15u)) {
       PT.ws_scanners = (uint32_t)o.pass1_ws;  // scanner waves (+ 100: eight row groups per trip); unknown values run the default split
-      if (partition_ws_bytes(PT.n_parts, 12) <= (size_t)158 * 1024) PT.flags |= PTF_WS;
+      if (partition_ws_bytes(PT.n_parts, 8) <= (size_t)158 * 1024) PT.flags |= PTF_WS;
     }
     PT.mode = 2u | ((uint32_t)o.partition_mode & ~15u);
     PT.block = 1024;
@@ -1632,6 +1632,7 @@ void AggregateRelation::explain(std::string* out, int depth) const {
       else if (m.fast.valid) shape = "column-op-literal shape (FastPolicy; interpreter when a batch has nulls)";
     } else {
       if (m.kw == 1 && sig_matches<SigKeySumPred2F64>(P, m.fast, 1, m.na, m.acc_kind, m.val_xform)) shape = "static shape KeySumPred2F64";
+      else if (m.kw == 1 && sig_matches<SigKeyAffSumPred2F64>(P, m.fast, 1, m.na, m.acc_kind, m.val_xform)) shape = "static shape KeyAffSumPred2F64 (pass 1 of the partitioned strategy)";
       else if (m.kw == 1 && sig_matches<SigKeySum>(P, m.fast, 1, m.na, m.acc_kind, m.val_xform)) shape = "static shape KeySum";
       else if (m.kw == 2 && sig_matches<SigQ1>(P, m.fast, 2, m.na, m.acc_kind, m.val_xform)) shape = "static shape Q1";
       else if (m.fast.valid) shape = "column-op-literal shape (FastPolicy; interpreter when a batch has nulls)";

@@ -72,7 +72,8 @@ struct DevColumns {
 // code (no bytecode loop, almost no scalar work).  Anything else, and any batch with nulls, runs
 // the generic interpreter.  Both produce identical results (tests compare them).
 enum : uint8_t {
-  FF_NONE = 0, FF_COL = 1, FF_IMM_MINUS_COL = 2, FF_COL_PLUS_IMM = 3, FF_COL_MINUS_IMM = 4, FF_COL_TIMES_IMM = 5
+  FF_NONE = 0, FF_COL = 1, FF_IMM_MINUS_COL = 2, FF_COL_PLUS_IMM = 3, FF_COL_MINUS_IMM = 4, FF_COL_TIMES_IMM = 5,
+  FF_RT = 15  // only in compile-time signatures (dfx_sigs.hpp): "column <op> literal, the op is the plan's" -- never in a DevFastPlan
 };
 struct DevFastTerm {
   uint8_t col;    // column slot

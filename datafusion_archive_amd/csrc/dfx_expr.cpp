@@ -416,6 +416,27 @@ void ProgramBuilder::build_fast(uint8_t pred, const uint8_t* keys, int kw, const
                                 DevFastPlan* F) const {
   memset(F, 0, sizeof(*F));
   if (pred != kNoOperand && !fast_terms(prog_, pred, F)) return;
+  // One ordered Float64 comparison becomes the two-sided range the compile-time signatures are written for (dfx_sigs.hpp:
+  // "WHERE c <op> lit AND c <op> lit"): `v < x` is `v >= -inf AND v < x`, `v > x` is `v > x AND v <= +inf`.  The added term
+  // is true for every value the original term can pass (NaN fails both, as it fails the original), so the rows selected are
+  // the same; lower bound first, so that the pair lands on one of the instantiated comparison forms (GT|GE, LT|LE).
+  if (F->np == 1 && F->term[0].dtype == T_F64 && !F->term[0].inv && F->term[0].m != 2) {
+    const bool upper = F->term[0].m == 1 || F->term[0].m == 3;
+    const double inf = upper ? -__builtin_inf() : __builtin_inf();
+    uint64_t bits;
+    memcpy(&bits, &inf, 8);
+    if (upper) {
+      F->term[1] = F->term[0];
+      F->term_imm[1] = F->term_imm[0];
+      F->term[0].m = 6;  // >= -inf
+      F->term_imm[0] = bits;
+    } else {
+      F->term[1] = F->term[0];
+      F->term[1].m = 3;  // <= +inf
+      F->term_imm[1] = bits;
+    }
+    F->np = 2;
+  }
   for (int k = 0; k < kw; ++k) {
     if ((keys[k] >> 6) != OPK_COL) return;
     F->keycol[k] = (uint8_t)(keys[k] & 63);

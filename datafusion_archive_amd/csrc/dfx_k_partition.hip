@@ -673,7 +673,7 @@ hipError_t launch_probe_wide_keys(const DevTable& T, hipStream_t s) {
 
 size_t partition_stage_bytes(const DevPartition& PT) {
   if ((PT.mode & 15u) == 0) return (size_t)PT.n_parts * 4 + 16;
-  if ((PT.mode & 15u) == 2 && (PT.flags & PTF_WS)) return partition_ws_bytes(PT.n_parts, 12);  // (sized for the most scanner queues any split has)
+  if ((PT.mode & 15u) == 2 && (PT.flags & PTF_WS)) return partition_ws_bytes(PT.n_parts, 8);
   if ((PT.mode & 15u) == 2)
     return partition_ring_bytes(PT.n_words, PT.n_parts, (PT.flags & PTF_CHUNK16) ? 32 : (PT.mode & 0x100u) ? 8 : 16, (PT.flags & PTF_HOT) != 0,
                                 (PT.flags & PTF_NARROW) != 0, (PT.flags & PTF_SHARED) ? 128 : 0);
@@ -699,6 +699,7 @@ void launch_partition_variant4(DFX_PARTITION_VARIANT_ARGS);
 void launch_partition_variant5(DFX_PARTITION_VARIANT_ARGS);
 void launch_partition_variant6(DFX_PARTITION_VARIANT_ARGS);
 void launch_partition_variant7(DFX_PARTITION_VARIANT_ARGS);
+void launch_partition_variant8(DFX_PARTITION_VARIANT_ARGS);
 
 hipError_t launch_partition(const DevProgram& P, const DevFastPlan& fast, const DevColumns& C, const DevAggPlan& plan,
                             const DevTable& T, const DevPartition& PT, const DevRows& spill, int64_t n,
@@ -722,6 +723,10 @@ hipError_t launch_partition(const DevProgram& P, const DevFastPlan& fast, const 
   }
   if (shared ? sig_matches<SigKeySum>(P, fast, 1, 1, raw_kind1, raw_xf) : sig_matches<SigKeySum>(P, fast, 1, T.na, T.acc_kind, T.val_xform)) {
     launch_partition_variant1(P, fast, C, plan, T, PT, spill, n, lds_bytes, s);
+    return hipGetLastError();
+  }
+  if (shared ? sig_matches<SigKeyAffSumPred2F64>(P, fast, 1, 1, raw_kind0, raw_xf) : sig_matches<SigKeyAffSumPred2F64>(P, fast, 1, T.na, T.acc_kind, T.val_xform)) {
+    launch_partition_variant8(P, fast, C, plan, T, PT, spill, n, lds_bytes, s);
     return hipGetLastError();
   }
   const bool use_fast = fast.valid && !P.has_nulls;

@@ -275,28 +275,22 @@ __global__ __launch_bounds__(kRingBlock) void k_partition_ws(const DevProgram P,
   snapshot_ctrl_if_last(T, PT);
 }
 
-// DevPartition::ws_scanners = scanner waves + 100 if the scanners take 8 row groups per trip instead of the policy's own U.
-// WSALL (the headline's variant): every split is instantiated (A/B runs by agg.pass1_ws); the other variants have the default only.
+// DevPartition::ws_scanners: the split asked for (agg.pass1_ws).  One split is instantiated -- eight scanner waves, eight
+// routers, the policy's own U -- chosen from the table in DESIGN.md section 4 (6 / 8 / 10 / 12 scanners and U = 8 measured
+// in round 3); every non-zero value runs it.
 constexpr uint32_t kWsDefault = 8;
-template <typename POLN, typename POLN8, bool WSALL>
+template <typename POLN>
 void launch_partition_ws(const DevProgram& P, const DevFastPlan& fast, const DevColumns& C, const DevAggPlan& plan, const DevTable& T,
                          const DevPartition& PT, const DevRows& spill, int64_t n, size_t lds_bytes, hipStream_t s) {
   const int grid = (int)PT.n_producers;
-#define DFX_WS(POLX, NSX) hipLaunchKernelGGL((k_partition_ws<POLX, NSX>), dim3(grid), dim3(kRingBlock), lds_bytes, s, P, fast, C, plan, T, PT, spill, n)
-  if (WSALL && PT.ws_scanners == 108) DFX_WS(POLN8, WSALL ? 8 : (int)kWsDefault);
-  else if (WSALL && PT.ws_scanners == 106) DFX_WS(POLN8, WSALL ? 6 : (int)kWsDefault);
-  else if (WSALL && PT.ws_scanners == 110) DFX_WS(POLN8, WSALL ? 10 : (int)kWsDefault);
-  else if (WSALL && PT.ws_scanners == 10) DFX_WS(POLN, WSALL ? 10 : (int)kWsDefault);
-  else if (WSALL && PT.ws_scanners == 12) DFX_WS(POLN, WSALL ? 12 : (int)kWsDefault);
-  else DFX_WS(POLN, (int)kWsDefault);
-#undef DFX_WS
+  hipLaunchKernelGGL((k_partition_ws<POLN, (int)kWsDefault>), dim3(grid), dim3(kRingBlock), lds_bytes, s, P, fast, C, plan, T, PT, spill, n);
 }
 
 // one pass-1 variant = one translation unit: the ring / sorted / direct kernels of the policy plus its wave-specialised kernel
-#define DFX_PARTITION_VARIANT_WS(ID, WSALL, POL, POLS, POLN, POLN8)                                                        \
+#define DFX_PARTITION_VARIANT_WS(ID, POL, POLS, POLN)                                                                      \
   void launch_partition_variant##ID(DFX_PARTITION_VARIANT_ARGS) {                                                          \
     if (PT.flags & PTF_WS)                                                                                                 \
-      launch_partition_ws<POLN, POLN8, WSALL>(P, fast, C, plan, T, PT, spill, n, lds_bytes, s);                            \
+      launch_partition_ws<POLN>(P, fast, C, plan, T, PT, spill, n, lds_bytes, s);                                          \
     else                                                                                                                   \
       launch_partition_pol<POL, POLS, POLN>(P, fast, C, plan, T, PT, spill, n, lds_bytes, s);                              \
   }

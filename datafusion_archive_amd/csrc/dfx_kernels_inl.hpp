@@ -639,6 +639,13 @@ struct StaticPolicy {
     const double x = as_f64(cur[SIG::fc(a, j) & (BANK - 1)]);
     const double imm = as_f64(F.arg_imm[a][j]);
     switch (SIG::fk(a, j)) {
+      case FF_RT:  // the operator is the plan's: wave-uniform, read from the kernel arguments
+        switch (F.arg[a].f[j].kind) {
+          case FF_IMM_MINUS_COL: return imm - x;
+          case FF_COL_PLUS_IMM: return x + imm;
+          case FF_COL_MINUS_IMM: return x - imm;
+          default: return x * imm;
+        }
       case FF_IMM_MINUS_COL: return imm - x;
       case FF_COL_PLUS_IMM: return x + imm;
       case FF_COL_MINUS_IMM: return x - imm;

@@ -55,6 +55,16 @@ struct SigKeySumPred2F64 {
   DFX_SIG_FN(arg_dyn, 0) DFX_SIG_FN(arg_col, 0) DFX_SIG_FN(acc, ACC_ADD_F64) DFX_SIG_FN(xf, VT_RAW)
   DFX_SIG_NO_PRODUCTS
 };
+// SELECT c1, SUM(c0 <+ - *> lit) WHERE c0 <op> lit AND c0 <op> lit GROUP BY c1   (the headline with a scaled / shifted
+// argument: the arithmetic operator is the plan's, read once per row group -- FF_RT -- everything else as above)
+struct SigKeyAffSumPred2F64 {
+  static constexpr int NCOL = 2, NP = 2, KW = 1, NA = 1;
+  DFX_SIG_FN(term_cls, T_F64, T_F64) DFX_SIG_FN(term_col, 0, 0) DFX_SIG_FN(key_col, 1)
+  DFX_SIG_FN(arg_dyn, 1) DFX_SIG_FN(arg_col, 0) DFX_SIG_FN(acc, ACC_ADD_F64) DFX_SIG_FN(xf, VT_RAW)
+  static constexpr uint8_t nf(int) { return 1; }
+  static constexpr uint8_t fk(int, int) { return FF_RT; }
+  static constexpr uint8_t fc(int, int) { return 0; }
+};
 // SELECT c0, SUM(c1) GROUP BY c0                                      (config 3)
 struct SigKeySum {
   static constexpr int NCOL = 2, NP = 0, KW = 1, NA = 1;
@@ -99,8 +109,11 @@ inline bool sig_matches(const DevProgram& P, const DevFastPlan& F, int kw, int n
     const bool plain = F.arg[a].nf == 1 && F.arg[a].f[0].kind == FF_COL;
     if (SIG::arg_dyn(a)) {  // a product: the factors (kind + column) are part of the signature
       if (plain || F.arg[a].nf != SIG::nf(a)) return false;
-      for (int j = 0; j < SIG::nf(a); ++j)
-        if (F.arg[a].f[j].kind != SIG::fk(a, j) || F.arg[a].f[j].col != SIG::fc(a, j)) return false;
+      for (int j = 0; j < SIG::nf(a); ++j) {
+        const bool kind_ok = SIG::fk(a, j) == FF_RT ? F.arg[a].f[j].kind != FF_COL && F.arg[a].f[j].kind != FF_NONE
+                                                    : F.arg[a].f[j].kind == SIG::fk(a, j);
+        if (!kind_ok || F.arg[a].f[j].col != SIG::fc(a, j)) return false;
+      }
     } else if (!plain || F.arg[a].f[0].col != SIG::arg_col(a)) {
       return false;
     }

@@ -929,6 +929,55 @@ def test_shared_operand_rows_leave_the_fast_path_correctly():
             ex.set_option(kk, vv)
 
 
+def test_one_sided_predicates_and_scaled_arguments_on_the_static_pass1():
+    """Round 3: `v <op> x` runs as the two-sided range `v >= -inf AND v < x` / `v > x AND v <= +inf` on the headline's
+    compile-time signature, and SUM(v <+ - *> c) has a pass-1 signature of its own.  Both must select and add exactly what
+    the reference does -- filter.rs:79-110 / aggregate.rs:805-874 via the oracle -- also for NaN (never passes), +-inf, -0.0 and
+    subnormals in the compared column, literals on either side, and through every strategy's kernels (the partitioned one
+    with narrow rows, 16-row chunks and specialised waves is the path the signatures exist for)."""
+    rng = np.random.default_rng(77)
+    n, groups = 400000, 60000
+    k = rng.integers(0, groups, n).astype(np.int64)
+    v = rng.integers(0, 1 << 20, n).astype(np.float64) / 1024.0
+    special = np.array([np.nan, np.inf, -np.inf, -0.0, 0.0, 5e-324, -5e-324, 512.0, 512.0 - 2.0 ** -10, 512.0 + 2.0 ** -10])  # (sums stay exact)
+    at = rng.choice(n, 4000, replace=False)
+    v[at] = special[rng.integers(0, len(special), len(at))]
+    # +inf and -inf never share a group (their sum would be a NaN whose payload is nobody's contract): -inf rows get odd keys
+    k[np.isposinf(v)] &= ~np.int64(1)
+    k[np.isneginf(v)] |= 1
+    whole = pa.RecordBatch.from_arrays([pa.array(k), pa.array(v)], names=["k", "v"])
+    batches = [whole.slice(0, 150000), whole.slice(150000, 250000)]
+    x = lit(512.0)
+    preds = [BinaryExpr(Column(1), op, x) for op in (Operator.Lt, Operator.LtEq, Operator.Gt, Operator.GtEq)]
+    preds += [BinaryExpr(x, op, Column(1)) for op in (Operator.Lt, Operator.GtEq)]
+    two_sided = BinaryExpr(BinaryExpr(Column(1), Operator.GtEq, lit(0.0)), Operator.And, BinaryExpr(Column(1), Operator.LtEq, x))
+    args = [Column(1), BinaryExpr(Column(1), Operator.Multiply, lit(2.5)), BinaryExpr(lit(2.5), Operator.Multiply, Column(1)),
+            BinaryExpr(Column(1), Operator.Plus, lit(1.5)), BinaryExpr(Column(1), Operator.Minus, lit(1.5)), BinaryExpr(lit(1.5), Operator.Minus, Column(1))]
+    cases = [(p, args[0]) for p in preds] + [(two_sided, a) for a in args[1:]] + [(preds[0], args[1]), (preds[2], args[5])]
+    ex.set_option("agg.narrow_keys", 1)  # (a forced strategy skips the calibration slice that would find the keys narrow)
+    try:
+        for strategy in (3, 0, 1):
+            ex.set_option("agg.strategy", strategy)
+            for ci, (p, a) in enumerate(cases):
+                aggs = [agg("sum", a, F64)]
+                want = oracle.aggregate([Column(0)], aggs, [oracle.filter_next(p, b) for b in batches])
+                got = gpu_aggregate([Column(0)], aggs, whole.schema, batches, filter_expr=p)
+                assert_groups_identical(got, want, 1, f"strategy {strategy}, case {ci}")
+        # the ungrouped signatures (config 2 through the aggregate) and the FilterRelation's own
+        ex.set_option("agg.strategy", 0)
+        for ci, p in enumerate(preds):
+            aggs = [agg("count", Column(1), DataType.UInt64)]
+            want = oracle.aggregate([], aggs, [oracle.filter_next(p, b) for b in batches])
+            got = gpu_aggregate([], aggs, whole.schema, batches, filter_expr=p)
+            assert_batches_identical(got, want, f"COUNT, predicate {ci}")
+            rel = ex.FilterRelation(ex.DataSourceRelation(whole.schema, batches), ex.compile_scalar_expr(None, p, whole.schema), whole.schema)
+            for b in batches:
+                assert_batches_identical(rel.next(), oracle.filter_next(p, b), f"FilterRelation, predicate {ci}")
+    finally:
+        ex.set_option("agg.strategy", 0)
+        ex.set_option("agg.narrow_keys", -1)
+
+
 def test_large_batches_are_routed_in_several_launches():
     """A batch larger than the routing window is split into pass-1 launches (agg.partition_split_rows; twice that for
     selective scans): one 5.2 M-row batch with the split at 2^20 rows -- dense scan (calibrated: every row routed, 5

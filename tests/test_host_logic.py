@@ -280,6 +280,18 @@ def test_explain_baseline_shapes_hit_their_static_signatures():
     pred5 = BinaryExpr(BinaryExpr(Column(6), Operator.LtEq, l64(2436.0)), Operator.And, BinaryExpr(Column(4), Operator.GtEq, l64(0.0)))
     text = _explain_aggregate(q1, pred5, [Column(0), Column(1)], aggs)
     assert "static shape Q1" in text and "2 keys, 4 accumulators" in text and "7 columns" in text
+    # one ordered Float64 comparison = a two-sided range with an infinite bound (round 3): the same signatures
+    for op in (Operator.Lt, Operator.LtEq, Operator.Gt, Operator.GtEq):
+        one = BinaryExpr(Column(1), op, l64(204.8))
+        assert "static shape KeySumPred2F64" in _explain_aggregate(kv, one, [Column(0)], [sum_v]), op
+        assert "static shape KeySumPred2F64" in _explain_aggregate(kv, BinaryExpr(l64(204.8), op, Column(1)), [Column(0)], [sum_v]), op
+        assert "static shape CountPred2F64" in _explain_aggregate(kv, one, [], [count_v]), op
+    assert "FastPolicy" in _explain_aggregate(kv, BinaryExpr(Column(1), Operator.Eq, l64(204.8)), [Column(0)], [sum_v])
+    assert "FastPolicy" in _explain_aggregate(kv, BinaryExpr(Column(0), Operator.Lt, Literal(ScalarValue.Int64(5))), [Column(0)], [sum_v])
+    # SUM(column <op> literal) under the headline's predicate: its own pass-1 signature (round 3)
+    for arg in (BinaryExpr(Column(1), Operator.Multiply, l64(2.0)), BinaryExpr(l64(2.0), Operator.Multiply, Column(1)),
+                BinaryExpr(Column(1), Operator.Plus, l64(2.0)), BinaryExpr(Column(1), Operator.Minus, l64(2.0)), BinaryExpr(l64(2.0), Operator.Minus, Column(1))):
+        assert "static shape KeyAffSumPred2F64" in _explain_aggregate(kv, pred, [Column(0)], [AggregateFunction("SUM", [arg], f64)])
     # anything else: the run-time decoded shape family, or the interpreter
     assert "FastPolicy" in _explain_aggregate(kv, pred, [Column(0)], [AggregateFunction("MAX", [Column(1)], f64)])
     # AVG = SUM + COUNT of one operand, SUM + MIN + MAX of one column: shared routed value; different operands: not

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Runs one workload a few times (no CPU baseline): the target of rocprofv3 runs.
-usage: prof_query.py <headline|cfg3|cfg2|q1|neighbour|oneterm|threecol|product> [rows] [iters] [option=value ...]
+usage: prof_query.py <headline|cfg3|cfg2|q1|neighbour|oneterm|threecol|diffop|product> [rows] [iters] [option=value ...]
 (neighbour: SELECT k, SUM(v), MIN(v) WHERE v >= lo AND v < hi GROUP BY k -- two aggregates of one operand;
  oneterm: SELECT k, SUM(v) WHERE v < 204.8 GROUP BY k; threecol: SELECT k, SUM(w) WHERE v > lo AND v < hi GROUP BY k;
  product: SELECT k, SUM(v * 2.0) WHERE v > lo AND v < hi GROUP BY k -- shapes without a static signature: FastPolicy)"""
@@ -66,6 +66,11 @@ else:
         syn = syn + [("w", ex.SYNTH_F64_EXACT, 2, 0.0, 0.0)]
         schema = pa.schema([("k", pa.int64()), ("v", pa.float64()), ("w", pa.float64())])
         aggs = [AggregateFunction("SUM", [Column(2)], f64)]
+        bytes_per_row = 24
+    if wl == "diffop":  # two aggregates of DIFFERENT operands: generic 24-byte routed rows
+        syn = syn + [("w", ex.SYNTH_F64_EXACT, 2, 0.0, 0.0)]
+        schema = pa.schema([("k", pa.int64()), ("v", pa.float64()), ("w", pa.float64())])
+        aggs = [AggregateFunction("SUM", [Column(1)], f64), AggregateFunction("MIN", [Column(2)], f64)]
         bytes_per_row = 24
     if wl == "product":
         aggs = [AggregateFunction("SUM", [BinaryExpr(Column(1), Operator.Multiply, lit(2.0))], f64)]
