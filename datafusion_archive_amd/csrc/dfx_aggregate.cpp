@@ -1562,14 +1562,19 @@ AggregateRelation::AggregateRelation(SchemaInfo schema, std::unique_ptr<Relation
     // (or when the Filter itself needed several programs) the Filter stays a relation of its own below the aggregate
     bool fits = f->single_program();
     if (fits && !f->predicate().is_aggregate) {
-      ProgramBuilder trial(f->input()->schema());
-      uint8_t opnd = kNoOperand;
-      int dt = 0;
-      Status tst = trial.add(f->predicate(), f->predicate().root, &opnd, &dt);
-      for (size_t k = 0; k < m.group.size() && tst.ok(); ++k)
-        if (!m.group[k].is_aggregate) tst = trial.add(m.group[k], m.group[k].root, &opnd, &dt);
-      if (tst.ok() && !m.aggr.empty() && m.aggr[0].is_aggregate && m.aggr[0].agg_arg >= 0) tst = trial.add(m.aggr[0], m.aggr[0].agg_arg, &opnd, &dt);
-      if (program_limit_error(tst)) fits = false;
+      // EVERY accumulator must fit beside the predicate and the keys on its own (setup() splits the accumulators into
+      // chunks down to one per program, never below): one that does not would fail the whole query with NotImplemented
+      // where the reference -- which has no such limit -- runs it; un-fused, its program holds keys + argument only
+      for (size_t a = 0; a < std::max<size_t>(m.aggr.size(), 1) && fits; ++a) {
+        ProgramBuilder trial(f->input()->schema());
+        uint8_t opnd = kNoOperand;
+        int dt = 0;
+        Status tst = trial.add(f->predicate(), f->predicate().root, &opnd, &dt);
+        for (size_t k = 0; k < m.group.size() && tst.ok(); ++k)
+          if (!m.group[k].is_aggregate) tst = trial.add(m.group[k], m.group[k].root, &opnd, &dt);
+        if (tst.ok() && a < m.aggr.size() && m.aggr[a].is_aggregate && m.aggr[a].agg_arg >= 0) tst = trial.add(m.aggr[a], m.aggr[a].agg_arg, &opnd, &dt);
+        if (program_limit_error(tst)) fits = false;
+      }
     }
     if (fits && !f->predicate().is_aggregate) {
       m.has_pred = true;

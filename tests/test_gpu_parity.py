@@ -337,6 +337,20 @@ def test_filter_conjunction_wider_than_one_fused_program():
                 assert_groups_identical(g, w, 1, f"aggregate over wide conjunction, nulls {nulls}")
             else:
                 assert_batches_identical(g, w, f"ungrouped aggregate over wide conjunction, nulls {nulls}")
+    # a predicate that fits ONE program (4 columns) and would take the first aggregate beside it, but not a later one whose
+    # argument reads 4 more columns (4 + key + 4 = 9 > 8 columns): the Filter must stay un-fused, not fail the query (the
+    # fusion trial used to look at the first aggregate only)
+    b4, pred4 = _wide_conjunction(4, rng, False)
+    b, _ = _wide_conjunction(12, rng, False)
+    prod = BinaryExpr(BinaryExpr(Column(6), Operator.Plus, Column(7)), Operator.Plus, BinaryExpr(Column(9), Operator.Plus, Column(10)))  # (exact sums)
+    aggs = [agg("sum", Column(0), F64), agg("sum", prod, F64), agg("min", Column(1), F64)]
+    for group in ([], [Column(5)]):
+        g = gpu_aggregate(group, aggs, b.schema, [b], filter_expr=pred4)
+        w = oracle.aggregate(group, aggs, [oracle.filter_next(pred4, b)])
+        if group:
+            assert_groups_identical(g, w, 1, "a later aggregate that does not fit beside the predicate")
+        else:
+            assert_batches_identical(g, w, "ungrouped, a later aggregate that does not fit beside the predicate")
     # a disjunction that does not fit is not split: the limit is still reported
     b, pred = _wide_conjunction(12, rng, False)
     terms = []

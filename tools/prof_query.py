@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Runs one workload a few times (no CPU baseline): the target of rocprofv3 runs.
-usage: prof_query.py <headline|cfg3|cfg2|q1|neighbour|oneterm|threecol|diffop|product> [rows] [iters] [option=value ...]
+usage: prof_query.py <headline|cfg3|cfg2|q1|neighbour|oneterm|threeterm|threecol|diffop|product> [rows] [iters] [option=value ...]
 (neighbour: SELECT k, SUM(v), MIN(v) WHERE v >= lo AND v < hi GROUP BY k -- two aggregates of one operand;
  oneterm: SELECT k, SUM(v) WHERE v < 204.8 GROUP BY k; threecol: SELECT k, SUM(w) WHERE v > lo AND v < hi GROUP BY k;
  product: SELECT k, SUM(v * 2.0) WHERE v > lo AND v < hi GROUP BY k -- shapes without a static signature: FastPolicy)"""
@@ -62,6 +62,8 @@ else:
         aggs = [AggregateFunction("SUM", [Column(1)], f64), AggregateFunction("MIN", [Column(1)], f64)]
     if wl == "oneterm":
         pred = BinaryExpr(Column(1), Operator.Lt, lit(204.8))
+    if wl == "threeterm":  # a third term on the Int64 key: no compile-time signature (FastPolicy)
+        pred = BinaryExpr(pred, Operator.And, BinaryExpr(Column(0), Operator.GtEq, Literal(ScalarValue.Int64(0))))
     if wl == "threecol":
         syn = syn + [("w", ex.SYNTH_F64_EXACT, 2, 0.0, 0.0)]
         schema = pa.schema([("k", pa.int64()), ("v", pa.float64()), ("w", pa.float64())])
