@@ -215,6 +215,7 @@ struct Pool {
   }
   static constexpr size_t kSpareBudget = (size_t)1 << 30;
   size_t spare_bytes = 0;  // (only read / written on the allocation path of the pinned pool)
+  int inject_oom = 0;      // test hook, see take()
   void* take(size_t bytes, hipError_t* e) {
     {
       std::lock_guard<std::mutex> lk(mu);
@@ -226,10 +227,21 @@ struct Pool {
       }
     }
     void* p = nullptr;
-    *e = pinned ? hipHostMalloc(&p, bytes, hipHostMallocDefault) : hipMalloc(&p, bytes);
+    if (!pinned && inject_oom > 0) {  // test hook: a REAL failed hipMalloc (an impossible size), so that HIP's sticky error is set
+      --inject_oom;
+      *e = hipMalloc(&p, (size_t)1 << 50);
+      p = nullptr;
+    } else {
+      *e = pinned ? hipHostMalloc(&p, bytes, hipHostMallocDefault) : hipMalloc(&p, bytes);
+    }
     if (*e != hipSuccess) {  // release cached blocks and retry once
+      // The failed attempt stays in HIP's sticky last-error slot: cleared here, or the next launch_* that returns
+      // hipGetLastError() reports "out of memory" for a kernel that launched correctly (found by tools/soak.py: a long-running
+      // process with many table sizes fills HBM with cached blocks, the first miss after that trims the pool and succeeds).
+      (void)hipGetLastError();
       trim();
       *e = pinned ? hipHostMalloc(&p, bytes, hipHostMallocDefault) : hipMalloc(&p, bytes);
+      if (*e != hipSuccess) (void)hipGetLastError();  // reported through *e, not through somebody else's launch
     }
     // Pinning a large host buffer costs milliseconds (measured: 13-17 ms for the two 8 MB result columns of a 10^6-group
     // aggregate whenever a query found the pool empty because the consumer still held the previous result).  A miss on
@@ -306,5 +318,6 @@ void pool_trim() {
   dev_pool().trim();
   pin_pool().trim();
 }
+void pool_inject_oom(int n) { dev_pool().inject_oom = n; }
 
 }  // namespace dfx

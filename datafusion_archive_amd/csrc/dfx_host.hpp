@@ -136,6 +136,7 @@ std::shared_ptr<void> device_alloc(size_t bytes, Status* st);
 // pooled pinned host memory for H2D / D2H staging
 std::shared_ptr<void> pinned_alloc(size_t bytes, Status* st);
 void pool_trim();
+void pool_inject_oom(int n);  // test hook (dfx_set_option "pool.inject_oom"): the next n device allocations fail their first attempt for real
 
 // ---- device-resident data ---------------------------------------------------------------------
 struct DeviceColumn {

@@ -419,6 +419,10 @@ int32_t dfx_set_option(const char* key, int64_t value) {
     pool_trim();
     return DFX_OK;
   }
+  if (!strcmp(key, "pool.inject_oom")) {  // test hook: the next `value` device allocations that miss the pool fail their first attempt
+    pool_inject_oom((int)value);
+    return DFX_OK;
+  }
   return set_option_in(agg_options(), key, value) ? DFX_OK : DFX_GENERAL;
 }
 

@@ -1044,6 +1044,28 @@ def test_run_time_decoded_terms_at_the_edges_of_their_types():
     ex.set_option("scan.fast", 1)
 
 
+def test_a_failed_allocation_that_the_pool_recovers_from_leaves_no_error_behind():
+    """A device allocation that fails (HBM full of cached blocks) makes the pool release its cache and try again.  The failed
+    attempt used to stay in HIP's sticky last-error slot, and the next kernel launch -- which had worked -- was reported as
+    'out of memory' (found by tools/soak.py after ~800 queries of varying size).  `pool.inject_oom` makes the first attempt of
+    the next allocations fail for real (an impossible size); the queries must neither fail nor change."""
+    rng = np.random.default_rng(3)
+    b = _exact_batch(rng, 200000, 50000)
+    pred = BinaryExpr(Column(1), Operator.Gt, lit(300.0))
+    want = oracle.aggregate([Column(0)], GROUP_AGGS, [oracle.filter_next(pred, b)])
+    try:
+        for strategy in (3, 0):
+            ex.set_option("agg.strategy", strategy)
+            ex.set_option("pool.trim", 1)
+            ex.set_option("pool.inject_oom", 1000)
+            got = gpu_aggregate([Column(0)], GROUP_AGGS, b.schema, [b], filter_expr=pred)
+            assert_groups_identical(got, want, 1, f"strategy {strategy} with failing first allocations")
+            assert_batches_identical(gpu_filter(pred, b.schema, [b])[0], oracle.filter_next(pred, b), "filter with failing first allocations")
+    finally:
+        ex.set_option("pool.inject_oom", 0)
+        ex.set_option("agg.strategy", 0)
+
+
 def test_large_batches_are_routed_in_several_launches():
     """A batch larger than the routing window is split into pass-1 launches (agg.partition_split_rows; twice that for
     selective scans): one 5.2 M-row batch with the split at 2^20 rows -- dense scan (calibrated: every row routed, 5

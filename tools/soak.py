@@ -1,0 +1,113 @@
+#!/usr/bin/env python3
+"""Soak run of the lock-free device protocols (single-pass filter look-back, LDS rings, wave-specialised pass 1, deferred pass 2)
+over random table sizes, batch widths, selectivities and group counts: every iteration checks invariants that hold for the
+EXACT data distribution (every partial sum is representable, so any order of additions gives the same bits):
+
+  rows kept by FilterRelation           == COUNT of the fused predicate + reduce
+  SUM over FilterRelation's output      == SUM of the fused predicate + reduce          (bit for bit)
+  sum over groups of SUM(v)             == that same SUM                                  (bit for bit)
+  sum over groups of COUNT(v)           == rows kept;  number of groups <= the key range
+  a second run of the same query        == the first                                     (every group, bit for bit)
+
+usage: soak.py [seconds] [seed] [first iteration]    exit code 1 on the first violation or error (prints the case that failed)"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import pyarrow as pa  # noqa: E402
+from datafusion_archive_amd import execution as ex  # noqa: E402
+from datafusion_archive_amd.logicalplan import (AggregateFunction, BinaryExpr, Column, DataType, Literal, Operator,  # noqa: E402
+                                                ScalarValue)
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 20260925)
+skip_to = int(sys.argv[3]) if len(sys.argv) > 3 else 0  # replay: draw the same cases, run from this iteration on
+ex.init(0)
+f64 = DataType.Float64
+schema = pa.schema([("k", pa.int64()), ("v", pa.float64())])
+
+
+def lit(v):
+    return Literal(ScalarValue.Float64(float(v)))
+
+
+def by_key(b):
+    k = b.column(0).to_numpy()
+    o = np.argsort(k, kind="stable")
+    return [k[o]] + [b.column(i).to_numpy()[o] for i in range(1, b.num_columns)]
+
+
+sum_v = AggregateFunction("SUM", [Column(1)], f64)
+count_v = AggregateFunction("COUNT", [Column(1)], DataType.UInt64)
+t_end = time.time() + budget
+it = 0
+while time.time() < t_end:
+    it += 1
+    n = int(rng.choice([1, 63, 64, 65, 4097, int(rng.integers(1, 1 << 20)), int(rng.integers(1 << 20, 1 << 26)), int(rng.integers(1 << 26, 3 << 27))]))
+    groups = int(rng.choice([1, 7, 5000, 20000, 100000, 1000000]))
+    kind = ex.SYNTH_I64_ZIPF if rng.random() < 0.25 else ex.SYNTH_I64_UNIFORM
+    batch = int(rng.choice([1 << 27, 1 << 26, 1 << 24, 1 << 22, (int(rng.integers(1, 1 << 18)) * 64)]))
+    a, b = sorted(rng.integers(0, 1 << 20, 2) / 1024.0)
+    mode = rng.integers(0, 5)
+    lo, hi = [(a, b), (-1.0, 2000.0), (5000.0, 6000.0), (a, a), (0.0, b)][mode]  # some / all / none / empty range / prefix
+    ops = [(Operator.Gt, Operator.Lt), (Operator.GtEq, Operator.LtEq), (Operator.GtEq, Operator.Lt), (Operator.Gt, Operator.LtEq)][int(rng.integers(0, 4))]
+    pred = BinaryExpr(BinaryExpr(Column(1), ops[0], lit(lo)), Operator.And, BinaryExpr(Column(1), ops[1], lit(hi)))
+    seed = int(rng.integers(1, 1 << 30))
+    syn = [("k", kind, 0, float(groups), 1.0), ("v", ex.SYNTH_F64_EXACT, 1, 0.0, 0.0)]
+    case = f"iteration {it}: n={n} groups={groups} kind={kind} batch={batch} pred=({ops[0].name} {lo}, {ops[1].name} {hi}) seed={seed}"
+    if it < skip_to:
+        continue
+    table = ex.DeviceTable.synth(syn, seed, 0, n)
+
+    def filt():
+        return ex.FilterRelation(table.scan(batch), ex.compile_scalar_expr(None, pred, schema), schema)
+
+    def agg(group, aggs):
+        rel = ex.AggregateRelation(None, filt(), [ex.compile_scalar_expr(None, g, schema) for g in group], [ex.compile_expr(None, x, schema) for x in aggs])
+        out = rel.next()
+        assert rel.next() is None
+        return out
+
+    def soak_case():
+        ref = agg([], [sum_v, count_v])
+        want_sum = ref.column(0)[0].as_py()
+        want_cnt = ref.column(1)[0].as_py() or 0
+        same = lambda x: want_cnt == 0 or np.float64(x).view(np.uint64) == np.float64(want_sum).view(np.uint64)  # noqa: E731
+        kept = ex.drain_on_device(filt())[0]
+        if kept != want_cnt:
+            return False, f"kept {kept} != COUNT {want_cnt}"
+        if n <= (1 << 26):  # the compacted output itself (downloaded: bounded)
+            got_sum, got_rows = 0.0, 0
+            for rb in filt():
+                v = rb.column(1).to_numpy()
+                got_rows += len(v)
+                got_sum += float(np.sum(v))  # exact data: any order
+            if got_rows != want_cnt or not same(got_sum):
+                return False, f"output rows {got_rows} sum {got_sum!r} != {want_cnt} {want_sum!r}"
+        k1 = by_key(agg([Column(0)], [sum_v, count_v]))
+        tot = float(np.sum(k1[1])) if len(k1[1]) else 0.0
+        if not (int(np.sum(k1[2])) == want_cnt and same(tot) and len(k1[0]) <= groups and len(np.unique(k1[0])) == len(k1[0]) and
+                (len(k1[0]) == 0 or (k1[0].min() >= 0 and k1[0].max() < groups))):
+            return False, f"grouped: {len(k1[0])} groups, count {int(np.sum(k1[2]))} sum {tot!r} against {want_cnt} {want_sum!r}"
+        k3 = by_key(agg([Column(0)], [sum_v]))  # the one-aggregate form (narrow rows, lean pass 2, specialised waves)
+        if not (np.array_equal(k3[0], k1[0]) and np.array_equal(k3[1].view(np.uint64), k1[1].view(np.uint64))):
+            return False, "SUM alone differs from SUM beside COUNT"
+        if it % 3 == 0:
+            k2 = by_key(agg([Column(0)], [sum_v, count_v]))
+            if not all(np.array_equal(x.view(np.uint64) if x.dtype == np.float64 else x, y.view(np.uint64) if y.dtype == np.float64 else y) for x, y in zip(k1, k2)):
+                return False, "a second run of the grouped query differs from the first"
+        return True, ""
+    try:
+        ok, why = soak_case()
+    except Exception as e:  # an error is a failure of the case too
+        ok, why = False, f"{type(e).__name__}: {e}"
+    if not ok:
+        print("SOAK FAILED", case, "--", why, flush=True)
+        sys.exit(1)
+    del table
+    if it % 20 == 0:
+        print(f"  {it} iterations ok ({case})", flush=True)
+print(f"soak ok: {it} iterations in {budget:.0f} s, pass-2 launches {ex.counter_get('agg_pass2_launches')}, table growths {ex.counter_get('agg_growths')}")
