@@ -8,6 +8,9 @@ EXACT data distribution (every partial sum is representable, so any order of add
   sum over groups of SUM(v)             == that same SUM                                  (bit for bit)
   sum over groups of COUNT(v)           == rows kept;  number of groups <= the key range
   a second run of the same query        == the first                                     (every group, bit for bit)
+  the same query under ANOTHER kernel family (interpreter, global table, ring kernel, two-pass filter, wide rows ...) with a
+  random aggregate set (SUM / COUNT / MIN / MAX / AVG of v, of a second column w, of v * c) and predicate shape (two-sided,
+  one-sided, three terms, none)        == under the defaults                            (every group, every aggregate, bit for bit)
 
 usage: soak.py [seconds] [seed] [first iteration]    exit code 1 on the first violation or error (prints the case that failed)"""
 import os
@@ -38,6 +41,31 @@ def by_key(b):
     k = b.column(0).to_numpy()
     o = np.argsort(k, kind="stable")
     return [k[o]] + [b.column(i).to_numpy()[o] for i in range(1, b.num_columns)]
+
+
+schema3 = pa.schema([("k", pa.int64()), ("v", pa.float64()), ("w", pa.float64())])
+ALTERNATIVES = [("scan.fast", 0, 1), ("agg.strategy", 1, 0), ("agg.strategy", 3, 0), ("agg.pass1_ws", 0, 8), ("filter.single_pass", 0, 1),
+                ("agg.narrow_keys", 0, -1), ("agg.shared_operand", 0, 1), ("agg.merge_scan_batches", 0, 1), ("agg.partition_defer", 1, 0)]
+
+
+def aggregate_sets():
+    v, w = Column(1), Column(2)
+    u64 = DataType.UInt64
+    A = AggregateFunction
+    return [[A("SUM", [v], f64)], [A("SUM", [v], f64), A("COUNT", [v], u64)], [A("SUM", [v], f64), A("MIN", [v], f64), A("MAX", [v], f64)],
+            [A("AVG", [v], f64)], [A("SUM", [v], f64), A("MIN", [w], f64)], [A("MAX", [w], f64), A("COUNT", [w], u64), A("SUM", [v], f64)],
+            [A("SUM", [BinaryExpr(v, Operator.Multiply, lit(2.5))], f64)], [A("SUM", [BinaryExpr(v, Operator.Plus, w)], f64)],
+            [A("MIN", [v], f64)], [A("COUNT", [v], u64)]]
+
+
+def same_batches(x, y):
+    if x.num_rows != y.num_rows or x.num_columns != y.num_columns:
+        return False
+    if x.num_rows == 0:
+        return True
+    a, b = by_key(x), by_key(y)
+    return all(np.array_equal(np.ascontiguousarray(p).view(np.uint64) if p.dtype == np.float64 else p,
+                              np.ascontiguousarray(q).view(np.uint64) if q.dtype == np.float64 else q) for p, q in zip(a, b))
 
 
 sum_v = AggregateFunction("SUM", [Column(1)], f64)
@@ -99,6 +127,32 @@ while time.time() < t_end:
             k2 = by_key(agg([Column(0)], [sum_v, count_v]))
             if not all(np.array_equal(x.view(np.uint64) if x.dtype == np.float64 else x, y.view(np.uint64) if y.dtype == np.float64 else y) for x, y in zip(k1, k2)):
                 return False, "a second run of the grouped query differs from the first"
+        # differential: another kernel family must give the same bits (bounded size: the global-atomic table does 24 G rows/s)
+        if n <= (1 << 26):
+            t3 = ex.DeviceTable.synth(syn + [("w", ex.SYNTH_F64_EXACT, 2, 0.0, 0.0)], seed, 0, n)
+            shapes = [pred, BinaryExpr(Column(1), ops[1], lit(hi)), BinaryExpr(pred, Operator.And, BinaryExpr(Column(0), Operator.GtEq, Literal(ScalarValue.Int64(0)))), None,
+                      BinaryExpr(BinaryExpr(Column(2), Operator.GtEq, lit(lo)), Operator.And, BinaryExpr(Column(1), Operator.Lt, lit(hi)))]
+            p3 = shapes[int(rng.integers(0, len(shapes)))]
+            aggs = aggregate_sets()[int(rng.integers(0, 10))]
+            group = [Column(0)] if rng.random() < 0.8 else []
+            key, alt, dflt = ALTERNATIVES[int(rng.integers(0, len(ALTERNATIVES)))]
+
+            def run3():
+                rel = t3.scan(batch)
+                if p3 is not None:
+                    rel = ex.FilterRelation(rel, ex.compile_scalar_expr(None, p3, schema3), schema3)
+                rel = ex.AggregateRelation(None, rel, [ex.compile_scalar_expr(None, g, schema3) for g in group], [ex.compile_expr(None, x, schema3) for x in aggs])
+                return rel.next()
+            base = run3()
+            ex.set_option(key, alt)
+            try:
+                other = run3()
+            finally:
+                ex.set_option(key, dflt)
+            same3 = same_batches(base, other) if group else (base.num_rows == other.num_rows == 1 and all(
+                base.column(c)[0].as_py() == other.column(c)[0].as_py() or (base.column(c)[0].as_py() != base.column(c)[0].as_py()) for c in range(base.num_columns)))
+            if not same3:
+                return False, f"{key}={alt} gives another result than the defaults: predicate {p3!r}, aggregates {aggs!r}, group {bool(group)}"
         return True, ""
     try:
         ok, why = soak_case()
