@@ -44,7 +44,9 @@ def by_key(b):
 
 
 schema3 = pa.schema([("k", pa.int64()), ("v", pa.float64()), ("w", pa.float64())])
-ALTERNATIVES = [("scan.fast", 0, 1), ("agg.strategy", 1, 0), ("agg.strategy", 3, 0), ("agg.pass1_ws", 0, 8), ("filter.single_pass", 0, 1),
+# (option, value of the alternative run, default): kernel families and the rarely taken paths (a table that starts tiny and grows
+#  by rehash + spill replay; regions that overflow into the spill list; hot-key pairs forced on)
+ALTERNATIVES = [("agg.capacity_log2", 9, 0), ("agg.capacity_log2", 14, 0), ("agg.hot_keys", 1, -1), ("scan.fast", 0, 1), ("agg.strategy", 1, 0), ("agg.strategy", 3, 0), ("agg.pass1_ws", 0, 8), ("filter.single_pass", 0, 1),
                 ("agg.narrow_keys", 0, -1), ("agg.shared_operand", 0, 1), ("agg.merge_scan_batches", 0, 1), ("agg.partition_defer", 1, 0)]
 
 
@@ -75,7 +77,7 @@ it = 0
 while time.time() < t_end:
     it += 1
     n = int(rng.choice([1, 63, 64, 65, 4097, int(rng.integers(1, 1 << 20)), int(rng.integers(1 << 20, 1 << 26)), int(rng.integers(1 << 26, 3 << 27))]))
-    groups = int(rng.choice([1, 7, 5000, 20000, 100000, 1000000]))
+    groups = int(rng.choice([1, 7, 5000, 20000, 100000, 1000000, 3000000]))  # (3e6 keys outgrow the default 2^21-slot table)
     kind = ex.SYNTH_I64_ZIPF if rng.random() < 0.25 else ex.SYNTH_I64_UNIFORM
     batch = int(rng.choice([1 << 27, 1 << 26, 1 << 24, 1 << 22, (int(rng.integers(1, 1 << 18)) * 64)]))
     a, b = sorted(rng.integers(0, 1 << 20, 2) / 1024.0)
