@@ -700,8 +700,8 @@ DEV void ring_route2(const DevTable& T, const DevPartition& PT, const DevRows& s
             uint32_t* o32 = region_row12(PT, jb.x, producer, jb.y * kRingCH + rr);
             const uint32_t a = s32[0], b2 = s32[1], c3 = s32[2];
             // one global_store_dwordx3 per lane, 16 adjacent lanes = one 192-byte chunk.  (With the non-temporal hint the launch
-            // took 417-480 us against 394-423 without, three alternating processes on one box: the routed rows are read back
-            // by pass 2 soon enough for the memory-side cache to matter.)
+            // took 417-480 us against 394-423 without, three alternating processes on one box -- probably because
+            // consecutive 192-byte chunks of a region share every other 128-byte line, which L2 merges into whole-line writes.)
             o32[0] = a;
             o32[1] = b2;
             o32[2] = c3;
