@@ -614,10 +614,13 @@ __global__ __launch_bounds__(kABlock) __attribute__((amdgpu_num_vgpr(kP2Vgprs)))
     retry((uint32_t)lane < rqn, (uint32_t)lane);
   }
   p2_drain();  // loads still in flight own v88..v119 until they land
-  __syncthreads();
+  // The key plane goes back only if this block claimed a slot: after a table's first window every key is there already, and
+  // the narrow form's write-back is 8-byte stores into every other slot (load 0.5) -- partial lines, 8 MB per launch at 10^6 groups.
+  const bool claimed = __syncthreads_or(new_keys != 0) != 0;
   for (uint32_t i0 = threadIdx.x * 2; i0 < S; i0 += kABlock * 2) {
     for (uint32_t a = 0; a < NA; ++a)
       *(ulonglong2*)(T.accs + (uint64_t)a * T.stride + slot0 + i0) = *(const ulonglong2*)(laccs + (size_t)a * S + i0);
+    if (!claimed) continue;
     if (NARROW) {
       const uint2 tg = *(const uint2*)(ltags + i0);
       // a tag that is an image is written back as its key (unchanged for slots that held it before, new for claimed
