@@ -573,7 +573,7 @@ Status AggregateRelation::Impl::ensure_partition(int64_t rows, bool nulls_now) {
     // selective scans: the scanning and the routing belong to different waves (dfx_k_partition_ws_inl.hpp).  When most rows
     // pass, every wave has rows to route all the time and the ring kernel's symmetric waves are the better fit
     if ((PT.flags & PTF_CHUNK16) && o.pass1_ws > 0 && !dense_seen && !(((uint32_t)o.partition_mode) & ~15u)) {
-      PT.ws_scanners = (uint32_t)o.pass1_ws;  // scanner waves (+ 100: eight row groups per trip); unknown values run the default split
+      PT.ws_scanners = (uint32_t)o.pass1_ws;  // (one split is built: any non-zero value runs it)
       if (partition_ws_bytes(PT.n_parts, 8) <= (size_t)158 * 1024) PT.flags |= PTF_WS;
     }
     PT.mode = 2u | ((uint32_t)o.partition_mode & ~15u);

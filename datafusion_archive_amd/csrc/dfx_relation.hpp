@@ -80,9 +80,9 @@ struct AggOptions {
   int calibration_memo = 1;    // 1: a resident table remembers the outcome of an aggregate's calibration slice per program shape
   int pass2_stream = 1;        // pass 2 of one-aggregate queries: region-streaming kernel (0: the flattened-index kernel)
   int fewgroup = 1;            // <= 8 groups after calibration: register accumulators (dfx_k_fewgroup.hip); 0: LDS front cache
-  int pass1_ws = 8;            // pass 1 of selective scans over narrow keys: wave-specialised kernel with this many scanner waves of 16
-                               // (0: the ring kernel, every wave scans and routes; the headline's signature also has 6 / 10 / 12
-                               // and, + 100, eight row groups per scanner trip: A/B runs)
+  int pass1_ws = 8;            // pass 1 of selective scans over narrow keys: non-zero = the wave-specialised kernel (8 scanner +
+                               // 8 router waves: the split DESIGN.md section 4 measured best of 6 / 8 / 10 / 12 / 14); 0: the ring
+                               // kernel, every wave scans and routes
   int merge_scan_batches = 1;  // an aggregate over a scan of a resident table asks for slices of >= 2^27 rows (one per routing window)
                                // whatever batch width the scan was created with; 0: the caller's batch width is kept
   int filter_single_pass = 1;  // FilterRelation: predicate + bitmap + tile offsets (decoupled look-back) + compaction of the predicate's own
