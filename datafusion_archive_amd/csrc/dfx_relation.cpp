@@ -64,8 +64,9 @@ class HostStreamRelation : public Relation {
   void explain(std::string* out, int depth) const override {
     int n = 0;
     for (size_t i = 0; i < schema_.fields.size(); ++i) n += (needed_.empty() || needed_[i]) ? 1 : 0;
-    explain_line(out, depth, strfmt("HostStream: host Arrow batches, %d of %d columns uploaded per batch (one batch ahead, own copy stream)", n,
-                                    (int)schema_.fields.size()));
+    explain_line(out, depth, strfmt("HostStream: host Arrow batches, %d of %d columns uploaded per batch (%s%s)", n, (int)schema_.fields.size(),
+                                    prefetch_ ? "one batch ahead, own copy stream" : "in order on the library's stream",
+                                    pin_in_place_ ? ", large buffers page-locked in place" : ""));
   }
 
   Status next(DeviceBatch* out, bool* has) override {
