@@ -420,7 +420,9 @@ void ProgramBuilder::build_fast(uint8_t pred, const uint8_t* keys, int kw, const
   // "WHERE c <op> lit AND c <op> lit"): `v < x` is `v >= -inf AND v < x`, `v > x` is `v > x AND v <= +inf`.  The added term
   // is true for every value the original term can pass (NaN fails both, as it fails the original), so the rows selected are
   // the same; lower bound first, so that the pair lands on one of the instantiated comparison forms (GT|GE, LT|LE).
-  if (F->np == 1 && F->term[0].dtype == T_F64 && !F->term[0].inv && F->term[0].m != 2) {
+  // Only where a signature can match afterwards (they read one or two columns): a run-time decoded plan of three or more
+  // columns would merely pay for a second term.
+  if (F->np == 1 && prog_.n_cols <= 2 && F->term[0].dtype == T_F64 && !F->term[0].inv && F->term[0].m != 2) {
     const bool upper = F->term[0].m == 1 || F->term[0].m == 3;
     const double inf = upper ? -__builtin_inf() : __builtin_inf();
     uint64_t bits;
