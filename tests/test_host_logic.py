@@ -287,6 +287,8 @@ def test_explain_baseline_shapes_hit_their_static_signatures():
         assert "static shape KeySumPred2F64" in _explain_aggregate(kv, BinaryExpr(l64(204.8), op, Column(1)), [Column(0)], [sum_v]), op
         assert "static shape CountPred2F64" in _explain_aggregate(kv, one, [], [count_v]), op
     assert "FastPolicy" in _explain_aggregate(kv, BinaryExpr(Column(1), Operator.Eq, l64(204.8)), [Column(0)], [sum_v])
+    kvw = pa.schema([("k", pa.int64()), ("v", pa.float64()), ("w", pa.float64())])  # three columns: no signature to win, the term stays one term
+    assert "FastPolicy" in _explain_aggregate(kvw, BinaryExpr(Column(1), Operator.Lt, l64(204.8)), [Column(0)], [AggregateFunction("SUM", [Column(2)], f64)])
     assert "FastPolicy" in _explain_aggregate(kv, BinaryExpr(Column(0), Operator.Lt, Literal(ScalarValue.Int64(5))), [Column(0)], [sum_v])
     # SUM(column <op> literal) under the headline's predicate: its own pass-1 signature (round 3)
     for arg in (BinaryExpr(Column(1), Operator.Multiply, l64(2.0)), BinaryExpr(l64(2.0), Operator.Multiply, Column(1)),
