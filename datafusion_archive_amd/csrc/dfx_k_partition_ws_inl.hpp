@@ -157,6 +157,11 @@ __global__ __launch_bounds__(kRingBlock) void k_partition_ws(const DevProgram P,
           if (c != 0) {
             // room for c rows?  (the router publishes its position after every batch of 64 it takes)
             uint32_t spins = 0;
+            // The router only sees the PUBLISHED tail and takes whole batches of 64: rows parked since the last publication
+            // (up to U - 1 groups of this trip) are invisible to it, so a locally dense stretch -- more than ~3/4 of a
+            // 256-row window passing -- could fill the queue with rows nobody may take yet.  Publish before waiting: with
+            // every parked row visible the router leaves fewer than 64 behind, and 64 + c <= 256 always fits.
+            if (tail + c - head_c > (uint32_t)kWsQueueRows && lane == 0) __hip_atomic_store(&my->tail, tail, __ATOMIC_RELEASE, WG_SCOPE);
             while (tail + c - head_c > (uint32_t)kWsQueueRows) {
               head_c = __hip_atomic_load(&my->head, __ATOMIC_ACQUIRE, WG_SCOPE);
               if (tail + c - head_c <= (uint32_t)kWsQueueRows) break;

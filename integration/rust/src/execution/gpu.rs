@@ -86,7 +86,6 @@ pub enum DfxTable {}
 #[repr(C)]
 pub enum DfxComm {}
 
-#[link(name = "dfx_hip")]
 /// One per-operator option (include/dfx.h: dfx_option): the operator starts from the process defaults and applies these on top.
 #[repr(C)]
 pub struct DfxOption {
@@ -94,6 +93,8 @@ pub struct DfxOption {
     pub value: i64,
 }
 
+// (the attribute must sit directly on the extern block: it names the library these symbols come from)
+#[link(name = "dfx_hip")]
 extern "C" {
     fn dfx_init(device: i32, err: *mut c_char, errlen: usize) -> i32;
     fn dfx_compile_scalar_expr(nodes: *const DfxExprNode, n: i32, root: i32, schema: *const ArrowSchema,

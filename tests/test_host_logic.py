@@ -189,6 +189,8 @@ def test_rust_binding_matches_header():
     rust = open(os.path.join(root, "integration", "rust", "src", "execution", "gpu.rs")).read()
     block = rust[rust.index('extern "C" {'):]
     block = block[:block.index("\n}\n")]
+    # the link directive decorates the extern block itself (on anything else the symbols would stay undefined at link time)
+    assert re.search(r'#\[link\(name = "dfx_hip"\)\]\s*\n\s*extern "C" \{', rust), "#[link] must sit directly on the extern block"
 
     def n_params(arglist):
         arglist = arglist.strip()
