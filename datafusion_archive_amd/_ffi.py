@@ -76,7 +76,7 @@ EXPORTED_SYMBOLS = [
     "dfx_comm_unique_id", "dfx_comm_init", "dfx_comm_destroy", "dfx_aggregate_exchange",
     "dfx_profile_enable", "dfx_profile_reset", "dfx_profile_count", "dfx_profile_get", "dfx_set_option",
     "dfx_counter_get", "dfx_counter_reset", "dfx_relation_explain", "dfx_relation_drain_device", "dfx_filter_debug_mask",
-    "dfx_debug_group_hash", "dfx_debug_unhash32",
+    "dfx_debug_group_hash", "dfx_debug_unhash32", "dfx_debug_plan_term",
 ]
 
 _lib = None
@@ -174,6 +174,8 @@ def lib() -> ctypes.CDLL:
     L.dfx_debug_group_hash.restype = ctypes.c_uint64
     L.dfx_debug_unhash32.argtypes = [ctypes.c_uint32]
     L.dfx_debug_unhash32.restype = ctypes.c_uint32
+    L.dfx_debug_plan_term.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int32]
+    L.dfx_debug_plan_term.restype = ctypes.c_int32
     L.dfx_counter_get.argtypes = [ctypes.c_char_p]
     L.dfx_counter_get.restype = ctypes.c_int64
     L.dfx_counter_reset.restype = None

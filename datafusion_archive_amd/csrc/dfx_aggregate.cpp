@@ -102,6 +102,7 @@ struct AggregateRelation::Impl {
   DevAggPlan plan_np;
   DevFastPlan fast_np;
   bool unfused_now = false;
+  bool plan_required = false;  // the batch in hand has nulls under the fused predicate and was left fused for a scan plan
   Status deferred;
   bool done = false;
   bool built = false;
@@ -885,6 +886,7 @@ Status AggregateRelation::Impl::launch_rows(const DeviceBatch& b, const DevProgr
   if (partition_now) {
     DevFastPlan fpp = fast;
     if (!opt().fast) fpp.valid = 0;
+    fpp.plan_mode = opt().plan | (plan_required ? 4 : 0);
     DevPartition pt = PT;
     if (pt_pending > 0) pt.flags |= PTF_RESUME;
     // close the window when one more batch could overflow a region (or the batch budget is used up; the calibration
@@ -926,6 +928,7 @@ Status AggregateRelation::Impl::launch_rows(const DeviceBatch& b, const DevProgr
   }
   DevFastPlan fp = fast;
   if (!opt().fast) fp.valid = 0;
+  fp.plan_mode = opt().plan | (plan_required ? 4 : 0);
   // a handful of groups (the calibration slice / earlier batches saw <= 8): register accumulators.  Should more
   // groups turn up later the kernel still handles them (through the table), and the next batch goes back to K7.
   if (lds_enabled && lds_calibrated && !calibrating && opt().strategy != 1 && opt().fewgroup &&
@@ -973,10 +976,17 @@ struct OneBatchRelation : Relation {
 }  // namespace
 
 Status AggregateRelation::Impl::consume_batch_chunk(const DeviceBatch& b) {
+  plan_required = false;
   if (has_pred && !unfused_now && b.num_rows > 0) {
     bool nulls = false;
     for (int ci : builder->columns())
       if (ci >= 0 && ci < (int)b.columns.size() && b.columns[(size_t)ci].validity && b.columns[(size_t)ci].null_count != 0) nulls = true;
+    // A scan plan evaluates the fused form with exactly those rules -- a null judged by arrow's comparison rule, every
+    // surviving slot valid, value(row) read regardless (DevScanPlan::count_valid) -- in one pass: no materialised filter.
+    if (nulls && opt().plan != 0 && opt().fast != 0 && scan_plan_shape_ok(builder->program(), fast, kw, na, val_xform)) {
+      nulls = false;
+      plan_required = true;  // (this batch's launchers must bind the plan: nothing else evaluates the fused form correctly)
+    }
     if (nulls) {  // FilterRelation for real (its output is all-valid), then the predicate-free program
       std::unique_ptr<OneBatchRelation> one(new OneBatchRelation());
       one->batch = b;
@@ -1032,6 +1042,7 @@ Status AggregateRelation::Impl::consume_batch_chunk(const DeviceBatch& b) {
     for (int i = 0; i < prog.n_cols; ++i) bytes += (double)n * (prog.col_dtype[i] == T_BOOL ? 0.125 : dtype_width(prog.col_dtype[i]));
     DevFastPlan fp = fast;
     if (!opt().fast) fp.valid = 0;
+    fp.plan_mode = opt().plan | (plan_required ? 4 : 0);
     DFX_HIP(launch_reduce(prog, fp, cols, plan, T, n, (uint64_t*)partial.get(), (uint32_t*)ctrl.get(), bytes, s));
     DFX_HIP(launch_reduce_fold(T, (const uint8_t*)dev_arg_dtype.get(), (const uint8_t*)dev_func.get(),
                                (uint64_t*)partial.get(), (uint64_t*)state.get(), (uint32_t*)ctrl.get(), s));
@@ -1634,17 +1645,23 @@ void AggregateRelation::explain(std::string* out, int depth) const {
     if (m.kw == 0) {
       if (sig_matches<SigCountPred2F64>(P, m.fast, 0, m.na, m.acc_kind, m.val_xform)) shape = "static shape CountPred2F64";
       else if (sig_matches<SigSumCountPred2F64>(P, m.fast, 0, m.na, m.acc_kind, m.val_xform)) shape = "static shape SumCountPred2F64";
+      else if (m.opt().plan != 0 && scan_plan_shape_ok(P, m.fast, 0, m.na, m.val_xform)) shape = "scan plan where a batch has nulls or 4-byte columns (PlanPolicy: range tests on value images), else column-op-literal shape (FastPolicy)";
       else if (m.fast.valid) shape = "column-op-literal shape (FastPolicy; interpreter when a batch has nulls)";
     } else {
       if (m.kw == 1 && sig_matches<SigKeySumPred2F64>(P, m.fast, 1, m.na, m.acc_kind, m.val_xform)) shape = "static shape KeySumPred2F64";
       else if (m.kw == 1 && sig_matches<SigKeyAffSumPred2F64>(P, m.fast, 1, m.na, m.acc_kind, m.val_xform)) shape = "static shape KeyAffSumPred2F64 (pass 1 of the partitioned strategy)";
       else if (m.kw == 1 && sig_matches<SigKeySum>(P, m.fast, 1, m.na, m.acc_kind, m.val_xform)) shape = "static shape KeySum";
       else if (m.kw == 2 && sig_matches<SigQ1>(P, m.fast, 2, m.na, m.acc_kind, m.val_xform)) shape = "static shape Q1";
+      else if (m.opt().plan != 0 && scan_plan_shape_ok(P, m.fast, m.kw, m.na, m.val_xform))
+        shape = m.kw == 1 ? "scan plan (PlanPolicy: range tests on value images, 4-byte columns widened, nulls by arrow's rule; every kernel of the partitioned strategy, the other strategies where a batch has nulls or 4-byte columns)"
+                          : "scan plan where a batch has nulls or 4-byte columns (PlanPolicy), else column-op-literal shape (FastPolicy)";
       else if (m.fast.valid) shape = "column-op-literal shape (FastPolicy; interpreter when a batch has nulls)";
     }
     std::string text = strfmt("Aggregate: %d keys, %d accumulators", m.kw, m.na_total);
     if (m.chunks.size() > 1) text += strfmt(" in %d chunks of <= %d (one fused program each, the same table)", (int)m.chunks.size(), kMaxAggs);
-    text += m.has_pred ? ", Filter below fused into the scan (un-fused for batches with nulls in its columns)" : ", no predicate";
+    const bool plan_fuses = m.opt().plan != 0 && m.opt().fast != 0 && scan_plan_shape_ok(P, m.fast, m.kw, m.na, m.val_xform);
+    text += !m.has_pred ? ", no predicate" : plan_fuses ? ", Filter below fused into the scan (batches with nulls too: the scan plan judges a null by arrow's comparison rule and counts every surviving slot as valid)"
+                                                        : ", Filter below fused into the scan (un-fused for batches with nulls in its columns)";
     text += ", " + explain_program(P) + ", " + shape;
     if (m.kw == 0) text += ", ungrouped reduce (64 partial copies + fold)";
     else if (m.kw == 1) text += ", strategy chosen on the first 2^18 rows: register accumulators (<= 8 groups) / LDS front cache (<= 8192) / table / "

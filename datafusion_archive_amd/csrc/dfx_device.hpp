@@ -90,6 +90,55 @@ struct DevFastArg {
   uint8_t pad;
   DevFastFactor f[3];
 };
+// ---- scan plan: the same shape family as DATA, not as control flow ------------------------------
+// The run-time decoded shapes above are bound by the CU's one scalar unit: operator masks chosen with s_cselect, dtype
+// branches, plan words read inside the loop (126 scalar instructions per 64-row group against 43 for
+// a compile-time signature).  A scan plan removes the decisions instead of compiling them in:
+//   * every `column <op> literal` term is an unsigned RANGE test on an order-preserving 64-bit image of the value:
+//       image(x) = x ^ (sign(x) & a) ^ b        f64: a = 0x7FF..F, b = 0x80..0   i64: a = 0, b = 0x80..0   u64: a = b = 0
+//       pass     = ((image(x) - lo) <=u span) != inv
+//     Eq is a one-value range (two for +-0.0: their images are neighbours), NotEq its complement, the ordered operators
+//     half-lines that end at the image of -inf / +inf, so NaN fails every ordered term and Eq and passes NotEq, as IEEE
+//     says; an impossible term (x < -inf, a NaN literal) is the complement of the full range.  One code path for six
+//     operators and six column types;
+//   * 4-byte columns (Int32 / UInt32 / Float32) are read as the ALIGNED 8 bytes that hold the element -- the same
+//     unconditional global_load_dwordx2 as an 8-byte column, so all loads of a trip are in flight together -- and widened
+//     afterwards (sign / zero extension, f32 -> f64 is exact) by lane parity;
+//   * validity bitmaps are read one BYTE per lane (the 64 lanes of a row group share 8 or 9 bytes: one cache line), the bit
+//     is (byte >> ((bit_offset + lane) & 7)) & 1; a column without a bitmap points at a block of 0xFF bytes.  A null value
+//     gives the term arrow 0.12's answer for None (it sorts below every value): DevPlanTerm::if_null;
+//   * the plan words live in VECTOR registers (dfx_kernels_inl.hpp, PlanPolicy): no scalar-register pressure, no selects.
+// Column slots are the plan's own: PlanPolicy1 kernels (one key, one routed value) find the key in slot 0 and the
+// aggregate's argument in slot 1, further predicate columns behind them.
+constexpr int kPlanCols = 4;
+constexpr int kPlanTerms = 4;
+enum : uint32_t { PX_NONE = 0, PX_SEXT32 = 1, PX_ZEXT32 = 2, PX_F32 = 3 };
+// column word (DevScanPlan::col_meta, also DevColumn::bit_offset of a plan-bound column):
+//   bits 0..3 log2(value bytes) (2 / 3), bit 4 element index of row 0 inside its aligned pair (4-byte values),
+//   bits 8..9 PX_*, bits 16..18 bit_offset & 7 of the validity bitmap
+inline constexpr uint32_t plan_col_meta(uint32_t shift, uint32_t delta, uint32_t ext, uint32_t vbit0) {
+  return shift | (delta << 4) | (ext << 8) | (vbit0 << 16);
+}
+struct DevPlanTerm {
+  uint32_t col;      // plan column slot
+  uint32_t inv;      // 1: complement (NotEq, impossible terms)
+  uint32_t if_null;  // the term's value for a null column value
+  uint32_t pad;
+  uint64_t a, b;     // image transform
+  uint64_t lo, span; // range
+};
+struct DevScanPlan {
+  int32_t valid;        // 0: shape not covered (then nothing below is meaningful)
+  int32_t gen;          // 1: needs the general kernels (a 4-byte column or a validity bitmap in this batch)
+  int32_t n_cols;       // plan column slots in use
+  int32_t np;           // terms
+  int32_t count_valid;  // 1: COUNT(x) looks at x's validity (no Filter below: fn filter's output is all-valid, filter.rs:83-92)
+  uint32_t col_meta[kPlanCols];
+  uint8_t keyslot[kMaxKeys];
+  uint8_t argslot[kMaxAggs];
+  DevPlanTerm term[kPlanTerms];
+};
+
 struct DevFastPlan {
   int32_t valid;  // 0: shape not covered
   int32_t np;     // predicate terms (0: no predicate)
@@ -98,6 +147,12 @@ struct DevFastPlan {
   uint8_t keycol[kMaxKeys];
   DevFastArg arg[kMaxAggs];
   uint64_t arg_imm[kMaxAggs][3];
+  int32_t synth;     // bit i: term i was ADDED by build_fast (the open side of a one-sided range): true for every value the query's
+                     // own term passes, so a scan plan leaves it out (and a null value must not be judged by it)
+  int32_t plan_mode; // AggOptions::plan as the launchers see it (scan.plan), bits 0..1: 0 never bind a scan plan, 1 after the
+                     // signatures, 2 before them; bit 2: the host RELIES on the plan (a fused predicate over a batch with nulls, which
+                     // only a plan evaluates by the reference's rules): a launcher that cannot bind one fails instead of falling back
+  DevScanPlan scan;  // filled per launch by bind_scan_plan() (dfx_expr.cpp) when a PlanPolicy kernel runs
 };
 
 // ---- aggregation ----------------------------------------------------------------------------

@@ -14,6 +14,7 @@
 #include <strings.h>
 
 #include "dfx_host.hpp"
+#include "dfx_kernels.hpp"
 
 namespace dfx {
 namespace {
@@ -432,10 +433,12 @@ void ProgramBuilder::build_fast(uint8_t pred, const uint8_t* keys, int kw, const
       F->term_imm[1] = F->term_imm[0];
       F->term[0].m = 6;  // >= -inf
       F->term_imm[0] = bits;
+      F->synth = 1;
     } else {
       F->term[1] = F->term[0];
       F->term[1].m = 3;  // <= +inf
       F->term_imm[1] = bits;
+      F->synth = 2;
     }
     F->np = 2;
   }
@@ -453,6 +456,184 @@ void ProgramBuilder::build_fast(uint8_t pred, const uint8_t* keys, int kw, const
     if (!fast_product(prog_, args[a], &F->arg[a], F->arg_imm[a])) return;
   }
   F->valid = 1;
+}
+
+// -------------------------------------------------------------------------------------------------
+// scan plans (dfx_device.hpp: DevScanPlan): the shape family of DevFastPlan as data
+// -------------------------------------------------------------------------------------------------
+namespace {
+enum PlanClass { PC_NONE = 0, PC_F = 1, PC_I = 2, PC_U = 3 };
+inline PlanClass plan_class(uint8_t t) {
+  switch (t) {
+    case T_F64: case T_F32: return PC_F;
+    case T_I64: case T_I32: return PC_I;
+    case T_U64: case T_U32: return PC_U;
+    default: return PC_NONE;  // 1- and 2-byte columns, Boolean: other kernels
+  }
+}
+inline uint64_t image_of(PlanClass c, uint64_t x) {
+  if (c == PC_F) return (x >> 63) ? ~x : (x | 0x8000000000000000ull);
+  if (c == PC_I) return x ^ 0x8000000000000000ull;
+  return x;
+}
+
+// `value <op> literal` as an inclusive range of images (+ complement flag).  m: three-way mask of the operator (1 less, 2
+// equal, 4 greater), ne: NotEq.  imm: the literal's canonical 64-bit form in the COLUMN's type.
+void plan_term_range(uint8_t dtype, uint8_t m, bool ne, uint64_t imm, DevPlanTerm* T) {
+  const PlanClass c = plan_class(dtype);
+  T->a = c == PC_F ? 0x7FFFFFFFFFFFFFFFull : 0ull;
+  T->b = c == PC_U ? 0ull : 0x8000000000000000ull;
+  uint64_t LO = 0, HI = ~0ull, p, q;
+  bool never = false;  // the comparison is false for every value (an unordered literal)
+  if (c == PC_F) {
+    double d;
+    if (dtype == T_F32) {
+      float f;
+      const uint32_t b32 = (uint32_t)imm;
+      memcpy(&f, &b32, 4);
+      d = (double)f;  // exact: the kernels widen Float32 values the same way
+    } else {
+      memcpy(&d, &imm, 8);
+    }
+    const double ninf = -__builtin_inf(), pinf = __builtin_inf(), nz = -0.0, pz = 0.0;
+    uint64_t bits;
+    memcpy(&bits, &ninf, 8); LO = image_of(PC_F, bits);
+    memcpy(&bits, &pinf, 8); HI = image_of(PC_F, bits);
+    if (d != d) {
+      never = true;
+      p = q = 0;
+    } else if (d == 0.0) {  // -0.0 == +0.0: the two images are neighbours
+      memcpy(&bits, &nz, 8); p = image_of(PC_F, bits);
+      memcpy(&bits, &pz, 8); q = image_of(PC_F, bits);
+    } else {
+      memcpy(&bits, &d, 8);
+      p = q = image_of(PC_F, bits);
+    }
+  } else {
+    p = q = image_of(c, imm);
+  }
+  uint64_t lo = 1, hi = 0;  // (empty)
+  if (!never) {
+    switch (m) {
+      case 1: if (p > LO) { lo = LO; hi = p - 1; } break;        // <
+      case 3: lo = LO; hi = q; break;                            // <=
+      case 4: if (q < HI) { lo = q + 1; hi = HI; } break;        // >
+      case 6: lo = p; hi = HI; break;                            // >=
+      default: lo = p; hi = q; break;                            // == (and != as its complement)
+    }
+  }
+  bool inv = ne;
+  if (lo > hi) {  // no value passes: the complement of everything
+    lo = 0;
+    hi = ~0ull;
+    inv = !inv;
+  }
+  T->lo = lo;
+  T->span = hi - lo;
+  T->inv = inv ? 1u : 0u;
+  // arrow 0.12 bool_op compares Option<T>: None sorts below every value, the result is never null (expression.rs:171-210
+  // -> array_ops; restated in run_program above).  For `null <op> literal`:
+  T->if_null = ne ? 1u : (m == 1 || m == 3) ? 1u : 0u;
+}
+}  // namespace
+
+bool scan_plan_shape_ok(const DevProgram& P, const DevFastPlan& F, int kw, int na, const uint8_t* val_xform) {
+  if (!F.valid || P.n_cols < 1 || P.n_cols > kPlanCols || kw > kMaxKeys || na > kMaxAggs) return false;
+  for (int c = 0; c < P.n_cols; ++c)
+    if (plan_class(P.col_dtype[c]) == PC_NONE) return false;
+  for (int k = 0; k < kw; ++k)
+    if (plan_class(P.col_dtype[F.keycol[k]]) == PC_F) return false;  // (float keys are rejected long before, aggregate.rs:848-850)
+  for (int a = 0; a < na; ++a) {
+    if (F.arg[a].nf != 1 || F.arg[a].f[0].kind != FF_COL) return false;  // products stay with the decoded shapes
+    const uint8_t t = P.col_dtype[F.arg[a].f[0].col];
+    // the accumulators take the argument's own bits: a 4-byte argument is widened by the plan (Int32 as i64, Float32 as f64),
+    // which only COUNT does not mind
+    if (t != T_I64 && t != T_U64 && t != T_F64 && val_xform[a] != VT_COUNT_VALID) return false;
+  }
+  // the one-key kernels bind the key to slot 0 and the first argument to slot 1 even when they are the same column
+  if (kw == 1 && na >= 1 && F.keycol[0] == F.arg[0].f[0].col && P.n_cols >= kPlanCols) return false;
+  return true;
+}
+
+bool bind_scan_plan(const DevProgram& P, const DevFastPlan& F, const DevColumns& C, int kw, int na, const uint8_t* val_xform,
+                    bool fixed, DevFastPlan* Fout, DevColumns* Cout) {
+  if ((F.plan_mode & 3) == 0 || !scan_plan_shape_ok(P, F, kw, na, val_xform)) return false;
+  if (fixed && (kw != 1 || na < 1)) return false;
+  const uint8_t* ones = device_ones_block();
+  if (!ones) return false;
+  *Fout = F;
+  DevScanPlan& S = Fout->scan;
+  memset(&S, 0, sizeof(S));
+  memset(Cout, 0, sizeof(*Cout));
+  // plan slots: FIXED kernels find the key in slot 0 and the routed argument in slot 1; then the program's other columns
+  int slot_of[kMaxCols];
+  for (int c = 0; c < kMaxCols; ++c) slot_of[c] = -1;
+  int src_of[kPlanCols + 2];
+  int n = 0;
+  if (fixed) {
+    src_of[n] = F.keycol[0];
+    slot_of[F.keycol[0]] = n++;
+    const int ac = F.arg[0].f[0].col;
+    src_of[n] = ac;  // (the key column again when the aggregate is over the key: read twice, a cache hit)
+    if (slot_of[ac] < 0) slot_of[ac] = n;
+    ++n;
+  }
+  for (int c = 0; c < P.n_cols; ++c) {
+    if (slot_of[c] >= 0) continue;
+    if (n >= kPlanCols) return false;
+    src_of[n] = c;
+    slot_of[c] = n++;
+  }
+  S.n_cols = n;
+  bool gen = false;
+  for (int sl = 0; sl < kPlanCols; ++sl) {
+    const int c = sl < n ? src_of[sl] : src_of[0];  // unused slots repeat slot 0 (loads are unconditional)
+    const uint8_t t = P.col_dtype[c];
+    const bool w4 = t == T_I32 || t == T_U32 || t == T_F32;
+    const uintptr_t base = (uintptr_t)C.c[c].values;
+    if ((base & (w4 ? 3u : 7u)) != 0) return false;  // (Arrow buffers are at least value-aligned; anything else: other kernels)
+    const uint32_t ext = t == T_I32 ? PX_SEXT32 : t == T_U32 ? PX_ZEXT32 : t == T_F32 ? PX_F32 : PX_NONE;
+    uint32_t vbit0 = 0;
+    const uint8_t* vb = ones;
+    if (C.c[c].validity) {
+      if (C.c[c].bit_offset < 0) return false;
+      vb = C.c[c].validity + (C.c[c].bit_offset >> 3);
+      vbit0 = (uint32_t)(C.c[c].bit_offset & 7);
+      if (sl < n) gen = true;
+    }
+    if (w4 && sl < n) gen = true;
+    const uint32_t meta = plan_col_meta(w4 ? 2u : 3u, w4 ? (uint32_t)((base & 7u) >> 2) : 0u, ext, vbit0);
+    Cout->c[sl].values = (const void*)(base & ~(uintptr_t)7);
+    Cout->c[sl].validity = vb;
+    Cout->c[sl].bit_offset = (int64_t)meta;
+    S.col_meta[sl] = meta;
+  }
+  // terms (the open side build_fast added to a one-sided range is left out: see DevFastPlan::synth)
+  int np = 0;
+  for (int i = 0; i < F.np; ++i) {
+    if ((F.synth >> i) & 1) continue;
+    if (np >= kPlanTerms) return false;
+    DevPlanTerm& T = S.term[np++];
+    T.col = (uint32_t)slot_of[F.term[i].col];
+    plan_term_range(F.term[i].dtype, F.term[i].m, F.term[i].inv != 0, F.term_imm[i], &T);
+  }
+  for (int i = np; i < kPlanTerms; ++i) {  // neutral: every value passes
+    S.term[i].col = 0;
+    S.term[i].lo = 0;
+    S.term[i].span = ~0ull;
+    S.term[i].if_null = 1;
+  }
+  S.np = np;
+  for (int k = 0; k < kw; ++k) S.keyslot[k] = (uint8_t)slot_of[F.keycol[k]];
+  for (int a = 0; a < na; ++a) S.argslot[a] = (uint8_t)slot_of[F.arg[a].f[0].col];
+  if (fixed) S.argslot[0] = 1;
+  // COUNT(x) looks at x's validity only when no Filter sits below: fn filter emits all-valid arrays (filter.rs:83-92), so
+  // under an absorbed predicate every surviving slot counts (and every other aggregate reads value(row) regardless,
+  // aggregate.rs:561-603)
+  S.count_valid = F.np == 0 ? 1 : 0;
+  S.gen = gen ? 1 : 0;
+  S.valid = 1;
+  return true;
 }
 
 Status ProgramBuilder::bind(const DeviceBatch& batch, DevProgram* prog, DevColumns* cols) const {
@@ -551,6 +732,32 @@ int32_t dfx_compile_expr(const dfx_expr_node* nodes, int32_t n_nodes, int32_t ro
     *out = e.release();
     return DFX_OK;
   });
+}
+
+int32_t dfx_debug_plan_term(int32_t dtype, int32_t op, uint64_t literal, uint64_t value, int32_t is_null) {
+  if (op < 0 || op > 5) return -1;
+  const uint8_t t = (uint8_t)dtype;
+  if (t != T_I32 && t != T_U32 && t != T_F32 && t != T_I64 && t != T_U64 && t != T_F64) return -1;
+  static const uint8_t three_way[6] = {2, 2, 1, 3, 4, 6};  // Eq NotEq Lt LtEq Gt GtEq (fast_terms)
+  DevPlanTerm T;
+  memset(&T, 0, sizeof(T));
+  plan_term_range(t, three_way[op], op == DFX_OP_NOT_EQ, literal, &T);
+  if (is_null) return (int32_t)T.if_null;
+  uint64_t x = value;  // what PlanPolicy::eval leaves in the row's register: the value widened to 64 bits
+  if (t == T_F32) {
+    float f;
+    const uint32_t b32 = (uint32_t)value;
+    memcpy(&f, &b32, 4);
+    const double d = (double)f;
+    memcpy(&x, &d, 8);
+  }
+  // PlanPolicy::pass, word for word
+  const uint32_t hi = (uint32_t)(x >> 32);
+  const uint32_t neg = (uint32_t)((int32_t)hi >> 31) & (T.a != 0ull ? 0xFFFFFFFFu : 0u);
+  const uint32_t img_hi = hi ^ (neg & 0x7FFFFFFFu) ^ ((T.b >> 63) ? 0x80000000u : 0u);
+  const uint64_t img = ((uint64_t)img_hi << 32) | ((uint32_t)x ^ neg);
+  const uint64_t nlo = 0ull - T.lo;
+  return (int32_t)(((img + nlo) <= T.span ? 1u : 0u) ^ (T.inv ? 1u : 0u));
 }
 
 const char* dfx_runtime_expr_name(const dfx_runtime_expr* e) { return e ? e->name.c_str() : ""; }

@@ -196,6 +196,23 @@ Status ensure_init() {
   return Status::OK();
 }
 
+const uint8_t* device_ones_block() {
+  static std::once_flag once;
+  static uint8_t* block = nullptr;
+  std::call_once(once, [] {
+    if (!ensure_init().ok()) return;
+    void* p = nullptr;
+    uint8_t ones[256];
+    memset(ones, 0xFF, sizeof(ones));
+    if (hipMalloc(&p, 256) != hipSuccess || hipMemcpy(p, ones, 256, hipMemcpyHostToDevice) != hipSuccess) {  // (synchronous: complete on return)
+      (void)hipGetLastError();
+      return;
+    }
+    block = (uint8_t*)p;  // (lives as long as the process)
+  });
+  return block;
+}
+
 // ---- pools --------------------------------------------------------------------------------------
 namespace {
 struct Pool {

@@ -106,6 +106,9 @@ struct Context {
 };
 Context& ctx();
 Status ensure_init();
+// 256 bytes of 0xFF on the device, allocated once per process: the "validity bitmap" of a column that has none, for the
+// kernels that read every plan column's validity unconditionally (scan plans, dfx_device.hpp).  nullptr without a device.
+const uint8_t* device_ones_block();
 // measurement: bytes of column data copied host -> device by the uploaders (dfx_counter_get("h2d_bytes"))
 struct Counters {
   long long h2d_bytes = 0;

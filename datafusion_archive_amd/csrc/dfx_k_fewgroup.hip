@@ -68,6 +68,8 @@ __global__ __launch_bounds__(kFGBlock) void k_fewgroup_agg(const DevProgram P, c
   const int64_t n_waves = ((int64_t)gridDim.x * kFGBlock) >> 6;
   uint32_t err = 0;
   uint64_t passed = 0;
+  typename POL::PREP prep;  // (PlanPolicy: the plan words in vector registers; empty otherwise)
+  POL::prepare(F, prep);
   for (int64_t w0 = wave_global * U; w0 < n_words; w0 += n_waves * U) {
     COLV col[U];
     uint32_t cv[U];
@@ -82,7 +84,7 @@ __global__ __launch_bounds__(kFGBlock) void k_fewgroup_agg(const DevProgram P, c
       u64x16 reg;
       uint32_t rv = 0;
       POL::eval(P, F, cur, curv, reg, rv, inb, err);
-      const bool pass = inb && POL::pass(P, F, plan.pred, cur, curv, reg, rv);
+      const bool pass = inb && POL::pass(P, F, plan.pred, cur, curv, reg, rv, prep);
       uint64_t key[KW];
       uint64_t val[kMaxAggs];
 #pragma unroll
@@ -263,7 +265,9 @@ static_assert(kFGSlots == 64, "the flush uses one wave");
 
 // host: can the few-group kernel run this scan?
 bool fewgroup_supported(const DevProgram& P, const DevFastPlan& fast, const DevTable& T) {
-  return fast.valid && !P.has_nulls && T.kw >= 1 && T.kw <= 2 && T.na >= 1 && T.na <= 4;
+  if (!(T.kw >= 1 && T.kw <= 2 && T.na >= 1 && T.na <= 4)) return false;
+  if (fast.valid && !P.has_nulls) return true;
+  return (fast.plan_mode & 3) != 0 && scan_plan_shape_ok(P, fast, T.kw, T.na, T.val_xform);  // (validity bitmaps: a scan plan)
 }
 
 hipError_t launch_fewgroup_agg(const DevProgram& P, const DevFastPlan& fast, const DevColumns& C, const DevAggPlan& plan,
@@ -277,6 +281,23 @@ hipError_t launch_fewgroup_agg(const DevProgram& P, const DevFastPlan& fast, con
   if (T.kw == 2 && sig_matches<SigQ1>(P, fast, T.kw, T.na, T.acc_kind, T.val_xform)) {
     DFX_FG(2, DFX_ARG(StaticPolicy<8, 2, SigQ1>));
     return hipGetLastError();
+  }
+  if (P.has_nulls || !P.wide8 || (fast.plan_mode & 3) == 2) {  // validity bitmaps / 4-byte columns: the scan plan (see table_hash_agg)
+    DevFastPlan fp;
+    DevColumns cp;
+    if (bind_scan_plan(P, fast, C, T.kw, T.na, T.val_xform, false, &fp, &cp)) {
+#define DFX_FGP(KW, POL) hipLaunchKernelGGL((k_fewgroup_agg<KW, 4, POL>), dim3(grid), dim3(kFGBlock), 0, s, P, fp, cp, plan, T, spill, n)
+      if (T.kw == 1) {
+        if (fp.scan.n_cols <= 2) DFX_FGP(1, DFX_ARG(PlanPolicyN<2, 4, true>));
+        else DFX_FGP(1, DFX_ARG(PlanPolicyN<4, 2, true>));
+      } else {
+        if (fp.scan.n_cols <= 2) DFX_FGP(2, DFX_ARG(PlanPolicyN<2, 4, true>));
+        else DFX_FGP(2, DFX_ARG(PlanPolicyN<4, 2, true>));
+      }
+#undef DFX_FGP
+      return hipGetLastError();
+    }
+    if (P.has_nulls || (fast.plan_mode & 4)) return hipErrorNotSupported;  // (fewgroup_supported said yes for a plan only)
   }
   if (T.kw == 1) {
     if (P.n_cols <= 2) DFX_FG(1, DFX_ARG(FastPolicy<2, 4>));

@@ -703,6 +703,33 @@ void launch_partition_variant5(DFX_PARTITION_VARIANT_ARGS);
 void launch_partition_variant6(DFX_PARTITION_VARIANT_ARGS);
 void launch_partition_variant7(DFX_PARTITION_VARIANT_ARGS);
 void launch_partition_variant8(DFX_PARTITION_VARIANT_ARGS);
+void launch_partition_variant9(DFX_PARTITION_VARIANT_ARGS);   // PlanPolicy, <= 2 columns, 8-byte null-free
+void launch_partition_variant10(DFX_PARTITION_VARIANT_ARGS);  // ... general (4-byte columns, validity bitmaps)
+void launch_partition_variant11(DFX_PARTITION_VARIANT_ARGS);  // PlanPolicy, <= 4 columns, 8-byte null-free
+void launch_partition_variant12(DFX_PARTITION_VARIANT_ARGS);  // ... general
+
+// The scan plan (DevScanPlan): run-time shapes as data.  Which binding a launch needs follows from the kernel flavour that
+// will run: the one-value flavours (narrow rows, the wave-specialised kernel) find the key in slot 0 and the routed value in
+// slot 1 (PlanPolicy1), the others look their slots up.
+static bool launch_partition_plan(const DevProgram& P, const DevFastPlan& fast, const DevColumns& C, const DevAggPlan& plan,
+                                  const DevTable& T, const DevPartition& PT, const DevRows& spill, int64_t n, size_t lds_bytes,
+                                  hipStream_t s) {
+  const bool shared = (PT.flags & PTF_SHARED) != 0;
+  const bool one_value = (PT.flags & PTF_WS) || ((PT.mode & 15u) == 2 && (PT.flags & PTF_NARROW));
+  if (one_value && !shared && T.na != 1) return false;
+  const uint8_t raw_xf[kMaxAggs] = {VT_RAW};
+  DevFastPlan fp;
+  DevColumns cp;
+  if (!bind_scan_plan(P, fast, C, 1, shared ? 1 : T.na, shared ? raw_xf : T.val_xform, one_value, &fp, &cp)) return false;
+  if (fp.scan.n_cols <= 2) {
+    if (fp.scan.gen) launch_partition_variant10(P, fp, cp, plan, T, PT, spill, n, lds_bytes, s);
+    else launch_partition_variant9(P, fp, cp, plan, T, PT, spill, n, lds_bytes, s);
+  } else {
+    if (fp.scan.gen) launch_partition_variant12(P, fp, cp, plan, T, PT, spill, n, lds_bytes, s);
+    else launch_partition_variant11(P, fp, cp, plan, T, PT, spill, n, lds_bytes, s);
+  }
+  return true;
+}
 
 hipError_t launch_partition(const DevProgram& P, const DevFastPlan& fast, const DevColumns& C, const DevAggPlan& plan,
                             const DevTable& T, const DevPartition& PT, const DevRows& spill, int64_t n,
@@ -720,6 +747,7 @@ hipError_t launch_partition(const DevProgram& P, const DevFastPlan& fast, const 
   const bool shared = (PT.flags & PTF_SHARED) != 0;
   const uint8_t raw_kind0[1] = {SigKeySumPred2F64::acc(0)}, raw_kind1[1] = {SigKeySum::acc(0)}, raw_xf[1] = {VT_RAW};
   static_assert(SigKeySumPred2F64::xf(0) == VT_RAW && SigKeySum::xf(0) == VT_RAW, "the one-aggregate signatures route the raw operand");
+  if ((fast.plan_mode & 3) == 2 && launch_partition_plan(P, fast, C, plan, T, PT, spill, n, lds_bytes, s)) return hipGetLastError();  // (A/B: scan.plan = 2)
   if (shared ? sig_matches<SigKeySumPred2F64>(P, fast, 1, 1, raw_kind0, raw_xf) : sig_matches<SigKeySumPred2F64>(P, fast, 1, T.na, T.acc_kind, T.val_xform)) {
     launch_partition_variant0(P, fast, C, plan, T, PT, spill, n, lds_bytes, s);
     return hipGetLastError();
@@ -732,6 +760,10 @@ hipError_t launch_partition(const DevProgram& P, const DevFastPlan& fast, const 
     launch_partition_variant8(P, fast, C, plan, T, PT, spill, n, lds_bytes, s);
     return hipGetLastError();
   }
+  // everything else the plan covers: any single MIN / MAX / COUNT / SUM, one to four terms over Int32 ... Float64 columns,
+  // nullable columns -- same kernels, the query is data (the wave-specialised flavour included: its scan loop stays short)
+  if (launch_partition_plan(P, fast, C, plan, T, PT, spill, n, lds_bytes, s)) return hipGetLastError();
+  if (fast.plan_mode & 4) return hipErrorNotSupported;  // (the host fused a predicate over nulls counting on a plan)
   const bool use_fast = fast.valid && !P.has_nulls;
   // The wave-specialised flavour pays when the scan loop is short (compile-time signatures).  The run-time decoded shapes and
   // the interpreter spend several times as many instructions per row group: eight scanner waves cannot keep up, sixteen

@@ -107,6 +107,8 @@ __global__ __launch_bounds__(kPBlock) void k_partition(const DevProgram P, const
   const int64_t n_waves = (int64_t)gridDim.x * (kPBlock / 64);
   uint32_t err = 0;
   uint64_t passed = 0;
+  typename POL::PREP prep;  // (PlanPolicy: the plan words in vector registers; empty otherwise)
+  POL::prepare(F, prep);
   for (int64_t w0 = wave_global * U; w0 < n_groups; w0 += n_waves * U) {
     COLV col[U];
     uint32_t cv[U];
@@ -124,7 +126,7 @@ __global__ __launch_bounds__(kPBlock) void k_partition(const DevProgram P, const
       u64x16 reg;
       uint32_t rv = 0;
       POL::eval(P, F, col[u], cv[u], reg, rv, inb, err);
-      bool pass = inb && POL::pass(P, F, plan.pred, col[u], cv[u], reg, rv);
+      bool pass = inb && POL::pass(P, F, plan.pred, col[u], cv[u], reg, rv, prep);
       key[u][0] = POL::key(P, F, plan.key[0], 0, col[u], cv[u], reg, rv);
 #pragma unroll
       for (int a = 0; a < kMaxAggs; ++a) {
@@ -346,6 +348,8 @@ __global__ __launch_bounds__(BLOCK) void k_partition_sorted(const DevProgram P, 
   const int64_t n_waves = (int64_t)gridDim.x * NWAVES;
   uint32_t err = 0;
   uint64_t passed = 0;
+  typename POL::PREP prep;  // (PlanPolicy: the plan words in vector registers; empty otherwise)
+  POL::prepare(F, prep);
   for (int64_t w0 = wave_global * U; w0 < n_groups; w0 += n_waves * U) {
     COLV col[U];
     uint32_t cv[U];
@@ -362,7 +366,7 @@ __global__ __launch_bounds__(BLOCK) void k_partition_sorted(const DevProgram P, 
       u64x16 reg;
       uint32_t rv = 0;
       POL::eval(P, F, col[u], cv[u], reg, rv, inb, err);
-      bool pass = inb && POL::pass(P, F, plan.pred, col[u], cv[u], reg, rv);
+      bool pass = inb && POL::pass(P, F, plan.pred, col[u], cv[u], reg, rv, prep);
       key[u][0] = POL::key(P, F, plan.key[0], 0, col[u], cv[u], reg, rv);
 #pragma unroll
       for (int a = 0; a < kMaxAggs; ++a) {
@@ -827,6 +831,8 @@ __global__ __launch_bounds__(kRingBlock) void k_partition_ring(const DevProgram 
   // VGPRs, -DDFX_RING_DEPTH) were measured: 3.46-3.66 ms per 1e9 rows against 3.24-3.62 ms at depth 1 -- no gain, the
   // kernel is not short of bytes in flight; the run-to-run spread (+-6 % on one box) is larger than any difference.
   constexpr int kRingDepth = DFX_RING_DEPTH;
+  typename POL::PREP prep;  // (PlanPolicy: the plan words in vector registers; empty otherwise)
+  POL::prepare(F, prep);
   COLV ncol[kRingDepth][U];
   uint32_t ncv[kRingDepth][U];
 #pragma unroll
@@ -866,7 +872,7 @@ __global__ __launch_bounds__(kRingBlock) void k_partition_ring(const DevProgram 
       u64x16 reg;
       uint32_t rv = 0;
       POL::eval(P, F, col[u], cv[u], reg, rv, inb, err);
-      bool pass = inb && POL::pass(P, F, plan.pred, col[u], cv[u], reg, rv);
+      bool pass = inb && POL::pass(P, F, plan.pred, col[u], cv[u], reg, rv, prep);
       uint64_t key[1];
       uint64_t val[kMaxAggs];
       key[0] = POL::key(P, F, plan.key[0], 0, col[u], cv[u], reg, rv);

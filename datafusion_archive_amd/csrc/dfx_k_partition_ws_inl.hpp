@@ -44,23 +44,28 @@ size_t partition_ws_bytes(uint32_t n_parts, int ns);
 #endif
 
 // rows the narrow routed form cannot carry: a key >= 2^32 (the claim sentinel i64::MIN among them).  No row of a stream whose
-// calibration slice saw narrow keys only takes this path unless the data changes under it.
+// calibration slice saw narrow keys only takes this path unless the data changes under it.  They go to the spill list and
+// nowhere else: the replay (launch_merge_rows -> table_apply) knows the sentinel key's slot, CTRL_WIDE_KEYS makes the host
+// leave narrow mode, and the scan loop carries a few dozen instructions for them instead of the accumulator algebra
+// (sentinel_apply inlined four times per loop was 600 instructions and most of this kernel's scalar-register pressure).
 DEV void ws_slow_rows(const DevTable& T, const DevRows& spill, bool slow, uint64_t key0, uint64_t val0) {
-  uint64_t key[1] = {key0};
-  uint64_t val[kMaxAggs];
-#pragma unroll
-  for (int a = 0; a < kMaxAggs; ++a) val[a] = a == 0 ? val0 : 0ull;
-  if (__ballot(slow && key0 == kEmptyKey) != 0) {
-    if (slow && key0 == kEmptyKey) {
-      sentinel_apply(T, val);
-      slow = false;
+  if (__hip_atomic_load(&T.ctrl[CTRL_WIDE_KEYS], RLX_AGENT) == 0u) __hip_atomic_store(&T.ctrl[CTRL_WIDE_KEYS], 1u, RLX_AGENT);
+  const uint64_t m = __ballot(slow);
+  const int lane = lane_id();
+  const int leader = __ffsll((unsigned long long)m) - 1;
+  uint64_t base = 0;
+  if (lane == leader) base = atomicAdd((unsigned long long*)&T.ctrl[CTRL_SPILL_LO], (unsigned long long)__popcll(m));
+  base = __shfl(base, leader, 64);
+  if (slow) {
+    const uint64_t pos = base + (uint64_t)__popcll(m & ((1ull << lane) - 1ull));
+    if (pos < spill.capacity) {  // (one key word, one value: the only rows this kernel routes)
+      spill.words[pos] = key0;
+      spill.words[spill.capacity + pos] = val0;
     }
   }
-  if (slow && __hip_atomic_load(&T.ctrl[CTRL_WIDE_KEYS], RLX_AGENT) == 0u) __hip_atomic_store(&T.ctrl[CTRL_WIDE_KEYS], 1u, RLX_AGENT);
-  spill_row<1>(T, spill, slow, key, val);
 }
 
-template <typename POL, int NS>
+template <typename POL, int NS, int FORM>
 __global__ __launch_bounds__(kRingBlock) void k_partition_ws(const DevProgram P, const DevFastPlan F, const DevColumns C,
                                                             const DevAggPlan plan, const DevTable T,
                                                             const DevPartition PT, const DevRows spill, const int64_t n) {
@@ -116,11 +121,14 @@ __global__ __launch_bounds__(kRingBlock) void k_partition_ws(const DevProgram P,
     const int64_t n_groups = (n + 63) >> 6;
     const int64_t wave_global = (int64_t)blockIdx.x * NS + wave;
     const int64_t n_waves = (int64_t)gridDim.x * NS;
-    // The scan loop, once per comparison FORM (StaticPolicy::pass_form: the operators as compile-time constants -- one v_cmp
-    // per term instead of three and no scalar selects; 0: run-time masks).  Software pipeline, one trip deep (as in
-    // k_partition_ring: deeper was measured no faster).
-    auto scan = [&](auto form_tag) {
-      constexpr int FORM = decltype(form_tag)::value;
+    // The scan loop.  FORM (StaticPolicy::pass_form) makes the comparison operators compile-time constants -- one v_cmp per term
+    // instead of three and no scalar selects; 0: the policy's run-time form.  It is a template parameter of the KERNEL, chosen
+    // by the host (launch_partition_ws): round 3 switched between five inlined copies of this loop inside one kernel -- 26 000
+    // instructions, 212 spilled scalar registers -- for a decision that is the same for every wave of every launch of a query.
+    // Software pipeline, one trip deep (as in k_partition_ring: deeper was measured no faster).
+    {
+      typename POL::PREP prep;  // (PlanPolicy: the plan words in vector registers; empty otherwise)
+      POL::prepare(F, prep);
       COLV ncol[U];
       uint32_t ncv[U];
       load_trip<POL>(P, C, wave_global * U, wave_global * U < n_groups, n, lane, ncol, ncv);
@@ -140,7 +148,8 @@ __global__ __launch_bounds__(kRingBlock) void k_partition_ws(const DevProgram P,
           u64x16 reg;
           uint32_t rv = 0;
           POL::eval(P, F, cur, curv, reg, rv, inb, err);
-          bool pass = inb && POL::template pass_form<FORM>(P, F, plan.pred, cur, curv, reg, rv);
+          bool pass = POL::template pass_form<FORM>(P, F, plan.pred, cur, curv, reg, rv, prep);
+          pass = pass && inb;  // (evaluated for every lane: no branch around the predicate)
           const uint64_t key = POL::key(P, F, plan.key[0], 0, cur, curv, reg, rv);
           uint64_t v;
           bool valid;
@@ -181,13 +190,6 @@ __global__ __launch_bounds__(kRingBlock) void k_partition_ws(const DevProgram P,
         }
         if (lane == 0) __hip_atomic_store(&my->tail, tail, __ATOMIC_RELEASE, WG_SCOPE);  // once per trip: the rows above are visible first
       }
-    };
-    switch (POL::form_of(F)) {  // (wave-uniform: the plan sits in the kernarg segment)
-      case 4 | (1 << 3): scan(std::integral_constant<int, (POL::kIsStatic ? (4 | (1 << 3)) : 0)>{}); break;  // x >  a AND x <  b
-      case 6 | (1 << 3): scan(std::integral_constant<int, (POL::kIsStatic ? (6 | (1 << 3)) : 0)>{}); break;  // x >= a AND x <  b
-      case 4 | (3 << 3): scan(std::integral_constant<int, (POL::kIsStatic ? (4 | (3 << 3)) : 0)>{}); break;  // x >  a AND x <= b
-      case 6 | (3 << 3): scan(std::integral_constant<int, (POL::kIsStatic ? (6 | (3 << 3)) : 0)>{}); break;  // x >= a AND x <= b
-      default: scan(std::integral_constant<int, 0>{}); break;
     }
     if (lane == 0) {
       __hip_atomic_store(&my->tail, tail, __ATOMIC_RELEASE, WG_SCOPE);
@@ -282,20 +284,35 @@ __global__ __launch_bounds__(kRingBlock) void k_partition_ws(const DevProgram P,
 
 // DevPartition::ws_scanners: the split asked for (agg.pass1_ws).  One split is instantiated -- eight scanner waves, eight
 // routers, the policy's own U -- chosen from the table in DESIGN.md section 4 (6 / 8 / 10 / 12 scanners and U = 8 measured
-// in round 3); every non-zero value runs it.
+// in round 3); every non-zero value runs it.  The comparison form is the host's choice: one kernel per form the signature's
+// two-term predicates can take (lower bound > / >=, upper bound < / <=), the run-time form for everything else.
 constexpr uint32_t kWsDefault = 8;
 template <typename POLN>
 void launch_partition_ws(const DevProgram& P, const DevFastPlan& fast, const DevColumns& C, const DevAggPlan& plan, const DevTable& T,
                          const DevPartition& PT, const DevRows& spill, int64_t n, size_t lds_bytes, hipStream_t s) {
   const int grid = (int)PT.n_producers;
-  hipLaunchKernelGGL((k_partition_ws<POLN, (int)kWsDefault>), dim3(grid), dim3(kRingBlock), lds_bytes, s, P, fast, C, plan, T, PT, spill, n);
+#define DFX_WS_LAUNCH(FORM_) \
+  hipLaunchKernelGGL((k_partition_ws<POLN, (int)kWsDefault, FORM_>), dim3(grid), dim3(kRingBlock), lds_bytes, s, P, fast, C, plan, T, PT, spill, n)
+  if constexpr (POLN::kIsStatic && POLN::kPredTerms == 2) {
+    switch (POLN::form_of(fast)) {
+      case 4 | (1 << 3): DFX_WS_LAUNCH(4 | (1 << 3)); return;  // x >  a AND x <  b
+      case 6 | (1 << 3): DFX_WS_LAUNCH(6 | (1 << 3)); return;  // x >= a AND x <  b
+      case 4 | (3 << 3): DFX_WS_LAUNCH(4 | (3 << 3)); return;  // x >  a AND x <= b
+      case 6 | (3 << 3): DFX_WS_LAUNCH(6 | (3 << 3)); return;  // x >= a AND x <= b
+      default: break;
+    }
+  }
+  DFX_WS_LAUNCH(0);
+#undef DFX_WS_LAUNCH
 }
 
 // one pass-1 variant = one translation unit: the ring / sorted / direct kernels of the policy plus its wave-specialised kernel
-#define DFX_PARTITION_VARIANT_WS(ID, POL, POLS, POLN)                                                                      \
+// (POLW: the one-value policy of the wave-specialised kernel -- the scanners can afford more row groups per trip than the
+// ring kernels, whose routing state competes for the same 128 registers)
+#define DFX_PARTITION_VARIANT_WS(ID, POL, POLS, POLN, POLW)                                                                \
   void launch_partition_variant##ID(DFX_PARTITION_VARIANT_ARGS) {                                                          \
     if (PT.flags & PTF_WS)                                                                                                 \
-      launch_partition_ws<POLN>(P, fast, C, plan, T, PT, spill, n, lds_bytes, s);                                          \
+      launch_partition_ws<POLW>(P, fast, C, plan, T, PT, spill, n, lds_bytes, s);                                          \
     else                                                                                                                   \
       launch_partition_pol<POL, POLS, POLN>(P, fast, C, plan, T, PT, spill, n, lds_bytes, s);                              \
   }

@@ -34,6 +34,8 @@ __global__ __launch_bounds__(kBlock) void k_reduce(const DevProgram P, const Dev
   }
   uint32_t err = 0;
   uint64_t passed = 0;
+  typename POL::PREP prep;  // (PlanPolicy: the plan words in vector registers; empty otherwise)
+  POL::prepare(F, prep);
   // the scan loop once per comparison FORM (StaticPolicy::pass_form: the operators as compile-time constants; 0: run-time masks)
   auto scan = [&](auto form_tag) {
   constexpr int FORM = decltype(form_tag)::value;
@@ -46,7 +48,7 @@ __global__ __launch_bounds__(kBlock) void k_reduce(const DevProgram P, const Dev
       u64x16 reg;
       uint32_t rv = 0;
       POL::eval(P, F, cur, curv, reg, rv, inb, err);
-      const bool pass = inb && POL::template pass_form<FORM>(P, F, plan.pred, cur, curv, reg, rv);
+      const bool pass = inb && POL::template pass_form<FORM>(P, F, plan.pred, cur, curv, reg, rv, prep);
       if (pass) {
         ++passed;
 #pragma unroll
@@ -154,6 +156,18 @@ hipError_t launch_reduce(const DevProgram& P, const DevFastPlan& fast, const Dev
     DFX_REDUCE(DFX_ARG(StaticPolicy<2, 8, SigSumCountPred2F64>), 2);
     return hipGetLastError();
   }
+  if (P.has_nulls || !P.wide8 || (fast.plan_mode & 3) == 2) {  // validity bitmaps / 4-byte columns: the scan plan (see table_hash_agg)
+    DevFastPlan fp;
+    DevColumns cp;
+    if (bind_scan_plan(P, fast, C, 0, T.na, T.val_xform, false, &fp, &cp)) {
+#define DFX_REDUCE_P(POL, NM) hipLaunchKernelGGL((k_reduce<POL, NM>), dim3(grid), dim3(kBlock), 0, s, P, fp, cp, plan, T, n, partial, ctrl)
+      if (fp.scan.n_cols <= 2) { if (T.na <= 2) DFX_REDUCE_P(DFX_ARG(PlanPolicyN<2, 4, true>), 2); else DFX_REDUCE_P(DFX_ARG(PlanPolicyN<2, 4, true>), 8); }
+      else { if (T.na <= 2) DFX_REDUCE_P(DFX_ARG(PlanPolicyN<4, 2, true>), 2); else DFX_REDUCE_P(DFX_ARG(PlanPolicyN<4, 2, true>), 8); }
+#undef DFX_REDUCE_P
+      return hipGetLastError();
+    }
+  }
+  if (fast.plan_mode & 4) return hipErrorNotSupported;  // (the host fused a predicate over nulls counting on a plan)
   const bool use_fast = fast.valid && !P.has_nulls;
   if (P.n_cols <= 2) { if (use_fast) DFX_REDUCE_NA(DFX_ARG(FastPolicy<2, 8>)); else DFX_REDUCE_NA(DFX_ARG(InterpPolicy<2, 8>)); }
   else if (P.n_cols <= 4) { if (use_fast) DFX_REDUCE_NA(DFX_ARG(FastPolicy<4, 4>)); else DFX_REDUCE_NA(DFX_ARG(InterpPolicy<4, 4>)); }

@@ -43,6 +43,8 @@ __global__ __launch_bounds__(kBlock) void k_hash_agg(const DevProgram P, const D
   uint64_t passed = 0;
   int iter = 0;
   bool saturated = false;
+  typename POL::PREP prep;  // (PlanPolicy: the plan words in vector registers; empty otherwise)
+  POL::prepare(F, prep);
   for (int64_t w0 = wave_global * U; w0 < n_words; w0 += n_waves * U, ++iter) {
     if ((iter & 7) == 0) {  // wave-uniform, one request: has the table passed its load limit?
       saturated = __hip_atomic_load(&T.ctrl[CTRL_SATURATED], RLX_AGENT) != 0u;
@@ -68,7 +70,7 @@ __global__ __launch_bounds__(kBlock) void k_hash_agg(const DevProgram P, const D
       u64x16 reg;
       uint32_t rv = 0;
       POL::eval(P, F, cur, curv, reg, rv, inb, err);
-      const bool pass = inb && POL::pass(P, F, plan.pred, cur, curv, reg, rv);
+      const bool pass = inb && POL::pass(P, F, plan.pred, cur, curv, reg, rv, prep);
       uint64_t key[KW];
       uint64_t val[kMaxAggs];
 #pragma unroll
@@ -385,6 +387,19 @@ hipError_t table_hash_agg(const DevProgram& P, const DevFastPlan& fast, const De
     DFX_HA(DFX_ARG(StaticPolicy<8, 2, SigQ1>));
     return hipGetLastError();
   }
+  // A scan plan where the decoded shapes would not run (validity bitmaps) or would run their slow loader (4-byte columns):
+  // the same shape family with nulls by arrow's rules and widening loads.  (8-byte null-free scans keep FastPolicy here: it
+  // also takes product arguments; the partitioned strategy is where the rows are, and it runs plans for everything.)
+  if (P.has_nulls || !P.wide8 || (fast.plan_mode & 3) == 2) {
+    DevFastPlan fp;
+    DevColumns cp;
+    if (bind_scan_plan(P, fast, C, KW, T.na, T.val_xform, false, &fp, &cp)) {
+      if (fp.scan.n_cols <= 2) hipLaunchKernelGGL((k_hash_agg<KW, PlanPolicyN<2, 4, true>>), dim3(grid), dim3(kBlock), lds_bytes, s, P, fp, cp, plan, T, spill, n);
+      else hipLaunchKernelGGL((k_hash_agg<KW, PlanPolicyN<4, 2, true>>), dim3(grid), dim3(kBlock), lds_bytes, s, P, fp, cp, plan, T, spill, n);
+      return hipGetLastError();
+    }
+  }
+  if (fast.plan_mode & 4) return hipErrorNotSupported;  // (the host fused a predicate over nulls counting on a plan)
   const bool use_fast = fast.valid && !P.has_nulls;
   if (P.n_cols <= 2) { if (use_fast) DFX_HA(DFX_ARG(FastPolicy<2, 4>)); else DFX_HA(DFX_ARG(InterpPolicy<2, 4>)); }
   else if (P.n_cols <= 4) { if (use_fast) DFX_HA(DFX_ARG(FastPolicy<4, 4>)); else DFX_HA(DFX_ARG(InterpPolicy<4, 4>)); }

@@ -42,6 +42,15 @@ bool profile_get(int index, const char** name, int64_t* launches, double* total_
 
 int device_cu_count();
 
+// ---- scan plans (DevScanPlan, dfx_device.hpp; built in dfx_expr.cpp) -------------------------------------------------
+// Shape check at operator-creation time (no batch needed): <= 4 columns of 4 / 8-byte numeric types, a conjunction of
+// `column <op> literal` terms, plain-column keys, plain-column arguments.
+bool scan_plan_shape_ok(const DevProgram& P, const DevFastPlan& F, int kw, int na, const uint8_t* val_xform);
+// Per launch: the plan-order column binding (Cout) and the plan itself (Fout->scan) for the bound batch.  fixed: one key in
+// slot 0 and the (first) argument in slot 1 (PlanPolicy1).  False: the shape or this batch's buffers are not covered.
+bool bind_scan_plan(const DevProgram& P, const DevFastPlan& F, const DevColumns& C, int kw, int na, const uint8_t* val_xform,
+                    bool fixed, DevFastPlan* Fout, DevColumns* Cout);
+
 // K1 predicate_mask: fused compare/AND/OR expression -> Arrow LSB bitmap (one __ballot per 64 rows)
 //   replaces comparison_ops!/boolean_ops!/literal_array! closures (expression.rs:171-243, :410-465)
 // tile_counts (may be null): popcount per 4096-row tile, for the compaction offsets.

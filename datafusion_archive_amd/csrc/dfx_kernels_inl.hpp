@@ -375,6 +375,9 @@ DEV bool eval_predicate(const DevProgram& P, ROWSTATE_CPARAMS, uint8_t pred) {
 template <int BANK, int U_>
 struct InterpPolicy {
   static constexpr bool kIsStatic = false;
+  static constexpr bool kHasTripLoad = false;
+  struct PREP {};  // per-wave state prepared before the scan loop (PlanPolicy: the plan words in vector registers)
+  static DEV void prepare(const DevFastPlan&, PREP&) {}
   static constexpr int kPredTerms = -1;  // (run-time)
   static constexpr int U = U_;
   static constexpr int kStaticNa = 0;  // aggregates known at compile time (0: run-time)
@@ -393,13 +396,13 @@ struct InterpPolicy {
     run_program(P, c, reg, cvv, rv, inb, err);
   }
   static DEV bool pass(const DevProgram& P, const DevFastPlan&, uint8_t pred, const COLV& cur, uint32_t curv,
-                       const u64x16& reg, uint32_t rv) {
+                       const u64x16& reg, uint32_t rv, const PREP& = PREP()) {
     return eval_predicate(P, cur, reg, curv, rv, pred);
   }
   static DEV int form_of(const DevFastPlan&) { return 0; }
   template <int FORM>
-  static DEV bool pass_form(const DevProgram& P, const DevFastPlan& F, uint8_t pred, const COLV& cur, uint32_t cv, const u64x16& reg, uint32_t rv) {
-    return pass(P, F, pred, cur, cv, reg, rv);
+  static DEV bool pass_form(const DevProgram& P, const DevFastPlan& F, uint8_t pred, const COLV& cur, uint32_t cv, const u64x16& reg, uint32_t rv, const PREP& prep = PREP()) {
+    return pass(P, F, pred, cur, cv, reg, rv, prep);
   }
   static DEV void load_trip(const DevColumns&, int64_t, bool, int64_t, int, COLV (&)[U_], uint32_t (&)[U_]) {}  // (kIsStatic only)
   static DEV uint64_t key(const DevProgram& P, const DevFastPlan&, uint8_t opnd, int, const COLV& cur, uint32_t curv,
@@ -452,6 +455,9 @@ DEV bool lane_of_mask(uint64_t mask) { return __builtin_amdgcn_inverse_ballot_w6
 template <int BANK, int U_>
 struct FastPolicy {
   static constexpr bool kIsStatic = false;
+  static constexpr bool kHasTripLoad = false;
+  struct PREP {};
+  static DEV void prepare(const DevFastPlan&, PREP&) {}
   static constexpr int kPredTerms = -1;  // (run-time)
   static constexpr int U = U_;
   static constexpr int kStaticNa = 0;  // aggregates known at compile time (0: run-time)
@@ -465,7 +471,7 @@ struct FastPolicy {
   static DEV void eval(const DevProgram&, const DevFastPlan&, const COLV&, uint32_t, u64x16&, uint32_t&, bool,
                        uint32_t&) {}
   static DEV bool pass(const DevProgram&, const DevFastPlan& F, uint8_t, const COLV& cur, uint32_t, const u64x16&,
-                       uint32_t) {
+                       uint32_t, const PREP& = PREP()) {
     uint64_t ok = ~0ull;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -478,8 +484,8 @@ struct FastPolicy {
   }
   static DEV int form_of(const DevFastPlan&) { return 0; }
   template <int FORM>
-  static DEV bool pass_form(const DevProgram& P, const DevFastPlan& F, uint8_t pred, const COLV& cur, uint32_t cv, const u64x16& reg, uint32_t rv) {
-    return pass(P, F, pred, cur, cv, reg, rv);
+  static DEV bool pass_form(const DevProgram& P, const DevFastPlan& F, uint8_t pred, const COLV& cur, uint32_t cv, const u64x16& reg, uint32_t rv, const PREP& prep = PREP()) {
+    return pass(P, F, pred, cur, cv, reg, rv, prep);
   }
   static DEV void load_trip(const DevColumns&, int64_t, bool, int64_t, int, COLV (&)[U_], uint32_t (&)[U_]) {}  // (kIsStatic only)
   static DEV uint64_t key(const DevProgram&, const DevFastPlan& F, uint8_t, int k, const COLV& cur, uint32_t,
@@ -527,6 +533,9 @@ struct FastPolicy1 : FastPolicy<BANK, U_> {
 template <int BANK, int U_, typename SIG>
 struct StaticPolicy {
   static constexpr bool kIsStatic = true;
+  static constexpr bool kHasTripLoad = true;
+  struct PREP {};
+  static DEV void prepare(const DevFastPlan&, PREP&) {}
   static constexpr int kPredTerms = SIG::NP;  // 0: the signature has no predicate (every in-range row passes)
   static constexpr int U = U_;
   static constexpr int kStaticNa = SIG::NA;
@@ -573,7 +582,7 @@ struct StaticPolicy {
   static DEV void eval(const DevProgram&, const DevFastPlan&, const COLV&, uint32_t, u64x16&, uint32_t&, bool,
                        uint32_t&) {}
   static DEV bool pass(const DevProgram&, const DevFastPlan& F, uint8_t, const COLV& cur, uint32_t, const u64x16&,
-                       uint32_t) {
+                       uint32_t, const PREP& = PREP()) {
     uint64_t ok = ~0ull;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -587,7 +596,7 @@ struct StaticPolicy {
   // and a dozen scalar selects per row group; the operators of a query do not change while it runs, so the scan kernels
   // pick one of a few loop bodies once per wave: FORM = m0 | m1 << 3 | ... (three-way masks of the terms, none inverted),
   // 0 = the run-time form above.  form_of() names the FORM a plan matches (0 if none is instantiated).
-  static DEV int form_of(const DevFastPlan& F) {
+  static __host__ __device__ inline int form_of(const DevFastPlan& F) {
     int form = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -614,7 +623,7 @@ struct StaticPolicy {
     return cmp_ct<M, int64_t>((int64_t)x, (int64_t)y);
   }
   template <int FORM>
-  static DEV bool pass_form(const DevProgram& P, const DevFastPlan& F, uint8_t pred, const COLV& cur, uint32_t cv, const u64x16& reg, uint32_t rv) {
+  static DEV bool pass_form(const DevProgram& P, const DevFastPlan& F, uint8_t pred, const COLV& cur, uint32_t cv, const u64x16& reg, uint32_t rv, const PREP& = PREP()) {
     if constexpr (FORM == 0) {
       return pass(P, F, pred, cur, cv, reg, rv);
     } else {
@@ -673,12 +682,228 @@ struct StaticPolicy {
   }
 };
 
+// ---------------------------------------------------------------------------------------------
+// scan plan (DevScanPlan): the run-time shape family evaluated as DATA -- see dfx_device.hpp
+// ---------------------------------------------------------------------------------------------
+// A wave-uniform plan word in a VECTOR register.  Plan words read from the kernel arguments are scalar values, and a
+// loop that keeps thirty of them alive runs out of scalar registers (the run-time decoded kernels carried 230-300 SGPR
+// spills: a v_readlane per use); the vector file has room (128 registers per lane at sixteen waves per CU, the scan
+// loops use ~60).  volatile: the copy stays where PlanPolicy::prepare puts it, before the scan loop (a pure asm was
+// re-executed inside the loop, with its scalar sources alive across it: nothing gained).
+DEV uint32_t plan_word(uint32_t s) {
+  uint32_t v;
+  asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(s));
+  return v;
+}
+DEV uint64_t plan_word64(uint64_t s) { return (uint64_t)plan_word((uint32_t)s) | ((uint64_t)plan_word((uint32_t)(s >> 32)) << 32); }
+
+template <int NCOL, bool GEN>
+struct PlanBank {
+  uint64_t v[NCOL];             // the aligned 8 bytes that hold the row's element of every plan column
+  uint32_t vb[GEN ? NCOL : 1];  // GEN: the validity byte that holds the row's bit
+  DEV uint64_t operator[](int c) const { return v[c]; }
+};
+
+template <int NCOL>
+DEV uint64_t plan_sel(const u64x16& reg, uint32_t slot) {  // slot is wave-uniform: compare-and-select, no indexing
+  uint64_t x = reg[0];
+  if (NCOL > 1) x = slot == 1u ? reg[1] : x;
+  if (NCOL > 2) x = slot == 2u ? reg[2] : x;
+  if (NCOL > 3) x = slot == 3u ? reg[3] : x;
+  return x;
+}
+
+// NCOL: plan column slots loaded per row (slots past the plan's n_cols repeat slot 0: a cache hit, no branch around a load);
+// GEN: 4-byte columns and validity bitmaps (without it every column is 8 bytes wide and null-free: no widening, no validity
+// loads); FIXED: one key in slot 0, one routed argument in slot 1 (the partitioned GROUP BY's one-value kernels).
+template <int NCOL, int U_, bool GEN, bool FIXED>
+struct PlanPolicy {
+  static constexpr bool kIsStatic = false;
+  static constexpr bool kHasTripLoad = true;
+  static constexpr int kPredTerms = -1;
+  static constexpr int U = U_;
+  static constexpr int kStaticNa = FIXED ? 1 : 0;
+  typedef PlanBank<NCOL, GEN> COLV;
+  // The terms' plan words, one copy per lane (see plan_word): everything a term needs is a vector operand, the predicate is
+  // evaluated without one scalar instruction besides the `t < np` guards.  Five registers per term: the range, and one word
+  // of flags that v_bfe takes apart per use (a register per flag cost the ring kernels their 128-register budget):
+  //   bit 0  image: negative values are complemented (f64)       bit 1  image: the sign bit is flipped (f64, i64)
+  //   bit 2  complement the range test (NotEq, impossible terms) bit 3, 4  the term's column slot
+  //   bit 5  the term's value for a null column value
+  struct PREP {
+    uint64_t nlo[kPlanTerms];   // -lo
+    uint64_t span[kPlanTerms];
+    uint32_t flags[kPlanTerms];
+  };
+  static DEV void prepare(const DevFastPlan& F, PREP& W) {
+#pragma unroll
+    for (int t = 0; t < kPlanTerms; ++t) {
+      const DevPlanTerm& T = F.scan.term[t];
+      W.nlo[t] = plan_word64(0ull - T.lo);
+      W.span[t] = plan_word64(T.span);
+      W.flags[t] = plan_word((T.a != 0ull ? 1u : 0u) | ((T.b >> 63) ? 2u : 0u) | (T.inv ? 4u : 0u) | ((T.col & 3u) << 3) | (T.if_null ? 32u : 0u));
+    }
+  }
+  static DEV int na(const DevTable& T) { return FIXED ? 1 : T.na; }
+  static DEV uint8_t acc_kind(const DevTable& T, int a) { return T.acc_kind[a]; }
+  static DEV uint8_t xform(const DevTable& T, int a) { return T.val_xform[a]; }
+
+  // C is the plan's own binding (bind_scan_plan): values = the column base rounded down to 8 bytes, validity = the byte
+  // that holds row 0's bit (or the block of 0xFF bytes), bit_offset = the column word (plan_col_meta)
+  static DEV void load(const DevProgram&, const DevColumns& C, int64_t row, bool inb, COLV& col, uint32_t& cv) {
+    cv = 0xFFFFFFFFu;
+    const uint64_t r = inb ? (uint64_t)row : 0ull;
+#pragma unroll
+    for (int c = 0; c < NCOL; ++c) {
+      if constexpr (GEN) {
+        const uint32_t meta = (uint32_t)C.c[c].bit_offset;
+        const uint64_t off = ((r + ((meta >> 4) & 1u)) << (meta & 15u)) & ~7ull;
+        col.v[c] = __builtin_nontemporal_load((const uint64_t*)((const uint8_t*)C.c[c].values + off));
+        col.vb[c] = (uint32_t)C.c[c].validity[(r + ((meta >> 16) & 7u)) >> 3];
+      } else {
+        col.v[c] = __builtin_nontemporal_load((const uint64_t*)C.c[c].values + r);
+      }
+    }
+    if constexpr (!GEN) col.vb[0] = 0;
+  }
+  // one trip of U row groups from group w0: a scalar base per column, 32-bit lane offsets clamped to the batch's last row
+  // (StaticPolicy::load_trip), every load unconditional
+  static DEV void load_trip(const DevColumns& C, int64_t w0, bool active, int64_t n, int lane, COLV (&col)[U], uint32_t (&cv)[U]) {
+    const int64_t r0 = active ? w0 * 64 : 0;
+    const int64_t left = n - r0;
+    const bool none = !active || left <= 0;
+    const uint32_t last = none ? 0u : (uint32_t)((left < (int64_t)U * 64 ? left : (int64_t)U * 64) - 1);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      cv[u] = 0xFFFFFFFFu;
+      if constexpr (!GEN) col[u].vb[0] = 0;
+    }
+#pragma unroll
+    for (int c = 0; c < NCOL; ++c) {
+      if constexpr (GEN) {
+        const uint32_t meta = (uint32_t)C.c[c].bit_offset;
+        const uint32_t shift = meta & 15u, delta = (meta >> 4) & 1u, vbit0 = (meta >> 16) & 7u;
+        const uint8_t* p = (const uint8_t*)C.c[c].values + (none ? 0ull : ((uint64_t)r0 << shift));  // r0 is a multiple of 64: still 8-byte aligned
+        const uint8_t* pv = C.c[c].validity + (none ? 0ull : ((uint64_t)r0 >> 3));
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const uint32_t i = (uint32_t)(u * 64 + lane);
+          const uint32_t ic = i < last ? i : last;
+          col[u].v[c] = __builtin_nontemporal_load((const uint64_t*)(p + (((ic + delta) << shift) & ~7u)));
+          col[u].vb[c] = (uint32_t)pv[(ic + vbit0) >> 3];
+        }
+      } else {
+        const uint64_t* p = (const uint64_t*)C.c[c].values + (none ? 0 : r0);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const uint32_t i = (uint32_t)(u * 64 + lane);
+          col[u].v[c] = __builtin_nontemporal_load(p + (i < last ? i : last));
+        }
+      }
+    }
+  }
+  // widened values into reg[0 .. NCOL), validity bits into rv (bit c = slot c)
+  static DEV void eval(const DevProgram&, const DevFastPlan& F, const COLV& cur, uint32_t, u64x16& reg, uint32_t& rv, bool,
+                       uint32_t&) {
+    rv = 0xFFFFFFFFu;
+    if constexpr (!GEN) {
+#pragma unroll
+      for (int c = 0; c < NCOL; ++c) reg[c] = cur.v[c];
+    } else {
+      const uint32_t lane = (uint32_t)lane_id();
+      uint32_t valid = 0;
+#pragma unroll
+      for (int c = 0; c < NCOL; ++c) {
+        const uint32_t meta = F.scan.col_meta[c];  // (wave-uniform)
+        uint64_t x = cur.v[c];
+        if ((meta & 15u) == 2u) {  // a 4-byte value: the half of the aligned pair this lane's row lives in
+          const bool odd = ((lane + ((meta >> 4) & 1u)) & 1u) != 0u;
+          const uint32_t w = odd ? (uint32_t)(x >> 32) : (uint32_t)x;
+          const uint32_t ext = (meta >> 8) & 3u;
+          if (ext == PX_F32) x = f64_bits((double)__uint_as_float(w));  // exact
+          else if (ext == PX_SEXT32) x = (uint64_t)(int64_t)(int32_t)w;
+          else x = (uint64_t)w;
+        }
+        reg[c] = x;
+        valid |= ((cur.vb[c] >> ((lane + ((meta >> 16) & 7u)) & 7u)) & 1u) << c;
+      }
+      rv = valid;
+    }
+  }
+  // value of the term's column: a bitwise select by the slot's bits (vector masks: no scalar compare, no SGPR pair per term)
+  static DEV uint64_t term_value(const u64x16& reg, uint32_t flags) {
+    const uint32_t m0 = (uint32_t)__builtin_amdgcn_sbfe((int)flags, 3, 1);  // all ones: slot bit 0
+    const uint64_t M0 = ((uint64_t)m0 << 32) | m0;
+    if constexpr (NCOL <= 2) {
+      return reg[0] ^ ((reg[0] ^ reg[NCOL > 1 ? 1 : 0]) & M0);
+    } else {
+      const uint32_t m1 = (uint32_t)__builtin_amdgcn_sbfe((int)flags, 4, 1);
+      const uint64_t M1 = ((uint64_t)m1 << 32) | m1;
+      const uint64_t y0 = reg[0] ^ ((reg[0] ^ reg[1]) & M0);
+      const uint64_t y1 = reg[2] ^ ((reg[2] ^ reg[NCOL > 3 ? 3 : 2]) & M0);
+      return y0 ^ ((y0 ^ y1) & M1);
+    }
+  }
+  static DEV bool pass(const DevProgram&, const DevFastPlan& F, uint8_t, const COLV&, uint32_t, const u64x16& reg, uint32_t rv,
+                       const PREP& W) {
+    uint32_t ok = 1u;
+#pragma unroll
+    for (int t = 0; t < kPlanTerms; ++t) {
+      if (t < F.scan.np) {  // (wave-uniform; nothing but vector arithmetic inside)
+        const uint32_t f = W.flags[t];
+        const uint64_t x = term_value(reg, f);
+        const uint32_t hi = (uint32_t)(x >> 32);
+        const uint32_t neg = (uint32_t)((int32_t)hi >> 31) & (uint32_t)__builtin_amdgcn_sbfe((int)f, 0, 1);  // all ones: a negative f64
+        const uint32_t img_hi = hi ^ (neg & 0x7FFFFFFFu) ^ ((f << 30) & 0x80000000u);
+        const uint64_t img = ((uint64_t)img_hi << 32) | ((uint32_t)x ^ neg);
+        uint32_t r = ((img + W.nlo[t]) <= W.span[t] ? 1u : 0u) ^ ((f >> 2) & 1u);
+        if constexpr (GEN) r = ((rv >> ((f >> 3) & 3u)) & 1u) ? r : ((f >> 5) & 1u);
+        ok &= r;
+      }
+    }
+    return ok != 0u;
+  }
+  static DEV int form_of(const DevFastPlan&) { return 0; }
+  template <int FORM>
+  static DEV bool pass_form(const DevProgram& P, const DevFastPlan& F, uint8_t pred, const COLV& cur, uint32_t cv, const u64x16& reg, uint32_t rv, const PREP& W) {
+    return pass(P, F, pred, cur, cv, reg, rv, W);
+  }
+  static DEV uint64_t key(const DevProgram&, const DevFastPlan& F, uint8_t, int k, const COLV&, uint32_t, const u64x16& reg, uint32_t) {
+    if constexpr (FIXED) return reg[0];
+    uint64_t v = 0;
+#pragma unroll
+    for (int j = 0; j < kMaxKeys; ++j)  // k is a compile-time constant after unrolling at the call site
+      if (j == k) v = plan_sel<NCOL>(reg, F.scan.keyslot[j]);
+    return v;
+  }
+  static DEV void arg(const DevProgram&, const DevFastPlan& F, uint8_t, int a, const COLV&, uint32_t, const u64x16& reg, uint32_t rv,
+                      uint64_t& v, bool& valid) {
+    if constexpr (FIXED) {
+      v = reg[NCOL > 1 ? 1 : 0];
+      valid = (GEN && F.scan.count_valid) ? ((rv >> 1) & 1u) != 0u : true;
+    } else {
+      v = 0;
+      valid = true;
+#pragma unroll
+      for (int j = 0; j < kMaxAggs; ++j) {
+        if (j == a) {
+          const uint32_t slot = F.scan.argslot[j];
+          v = plan_sel<NCOL>(reg, slot);
+          if (GEN && F.scan.count_valid) valid = ((rv >> slot) & 1u) != 0u;
+        }
+      }
+    }
+  }
+};
+template <int NCOL, int U, bool GEN> using PlanPolicyN = PlanPolicy<NCOL, U, GEN, false>;  // any keys / arguments
+template <int NCOL, int U, bool GEN> using PlanPolicy1 = PlanPolicy<NCOL, U, GEN, true>;   // key in slot 0, one routed value in slot 1
+
 // the column loads of one trip of U row groups starting at group w0 (wave-uniform); `active` false: nothing is needed (the
 // software pipeline's prefetch past the end), the loads still happen (row 0) so that their count stays fixed
 template <typename POL>
 DEV void load_trip(const DevProgram& P, const DevColumns& C, int64_t w0, bool active, int64_t n, int lane,
                    typename POL::COLV (&col)[POL::U], uint32_t (&cv)[POL::U]) {
-  if constexpr (POL::kIsStatic) {
+  if constexpr (POL::kHasTripLoad) {
     POL::load_trip(C, w0, active, n, lane, col, cv);
   } else {
 #pragma unroll

@@ -54,6 +54,9 @@ struct AggOptions {
   int lds_slots = -1;       // -1 auto
   int lds_copies = -1;      // -1 auto
   int fast = 1;             // 0: always run the generic interpreter (tests compare both paths)
+  int plan = 1;             // scan plans (DevScanPlan: range tests on value images, 4-byte columns and validity bitmaps without the
+                            // interpreter): 1 wherever the shape is covered and no compile-time signature matches, 0 never (round 3's
+                            // dispatch: run-time decoded shapes / interpreter), 2 also INSTEAD of the compile-time signatures (A/B)
   int partition_mode = 2;   // pass 1 of the partitioned strategy: 2 lock-free LDS rings, 1 LDS counting sort, 0 direct routing
   int dict_capacity_log2 = 0;  // initial slots of a Utf8 key dictionary (0: 2^16); tests use tiny values to force growth
   int partition_cap_rows = 0;  // rows per (producer, partition) region; 0: sized from the batch

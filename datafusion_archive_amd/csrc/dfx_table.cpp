@@ -232,6 +232,7 @@ bool set_option_in(AggOptions& o, const char* key, int64_t value) {
   else if (!strcmp(key, "agg.lds_slots")) o.lds_slots = (int)value;
   else if (!strcmp(key, "agg.lds_copies")) o.lds_copies = (int)value;
   else if (!strcmp(key, "scan.fast")) o.fast = (int)value;
+  else if (!strcmp(key, "scan.plan")) o.plan = (int)value;
   else if (!strcmp(key, "agg.partition_mode")) o.partition_mode = (int)value;
   else if (!strcmp(key, "agg.partition_block")) o.partition_block = (int)value;
   else if (!strcmp(key, "agg.fewgroup")) o.fewgroup = (int)value;

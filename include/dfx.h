@@ -367,6 +367,13 @@ int32_t dfx_aggregate_exchange(struct ArrowArrayStream* agg, dfx_comm* comm, int
  * no GPU needed; used by the CPU tests. */
 uint64_t dfx_debug_group_hash(uint64_t key);
 uint32_t dfx_debug_unhash32(uint32_t image);
+/* One `column <op> literal` term of a scan plan (csrc/dfx_device.hpp: DevScanPlan) evaluated on the host with the arithmetic
+ * the kernels use: the range test on the order-preserving image of `value`.  dtype: the column's dfx_dtype (Int32, UInt32,
+ * Float32, Int64, UInt64, Float64); op: dfx_operator 0..5 (Eq NotEq Lt LtEq Gt GtEq); literal / value: canonical 64-bit
+ * forms (signed ints sign-extended, unsigned zero-extended, Float32 bits in the low word, Float64 bits); is_null: the value
+ * is null (arrow 0.12's rule for None decides).  Returns 0 / 1, or -1 for a type the plans do not cover.  Host code, no
+ * GPU needed: the CPU tests compare it with the comparison it restates over NaN, +-0.0, +-inf and the integer extremes. */
+int32_t dfx_debug_plan_term(int32_t dtype, int32_t op, uint64_t literal, uint64_t value, int32_t is_null);
 /* Pulls every batch of a library stream and drops it on the device: no host RecordBatch, no D2H copy (what a stacked
  * operator would see).  rows / batches (may be NULL): what came out. */
 int32_t dfx_relation_drain_device(struct ArrowArrayStream* stream, int64_t* rows, int64_t* batches, char* err, size_t errlen);

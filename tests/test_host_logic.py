@@ -288,16 +288,31 @@ def test_explain_baseline_shapes_hit_their_static_signatures():
         assert "static shape KeySumPred2F64" in _explain_aggregate(kv, one, [Column(0)], [sum_v]), op
         assert "static shape KeySumPred2F64" in _explain_aggregate(kv, BinaryExpr(l64(204.8), op, Column(1)), [Column(0)], [sum_v]), op
         assert "static shape CountPred2F64" in _explain_aggregate(kv, one, [], [count_v]), op
-    assert "FastPolicy" in _explain_aggregate(kv, BinaryExpr(Column(1), Operator.Eq, l64(204.8)), [Column(0)], [sum_v])
+    # round 4: what the signatures do not name is a SCAN PLAN (the query as data: range tests on value images), not a decoded shape
+    assert "scan plan (PlanPolicy" in _explain_aggregate(kv, BinaryExpr(Column(1), Operator.Eq, l64(204.8)), [Column(0)], [sum_v])
     kvw = pa.schema([("k", pa.int64()), ("v", pa.float64()), ("w", pa.float64())])  # three columns: no signature to win, the term stays one term
-    assert "FastPolicy" in _explain_aggregate(kvw, BinaryExpr(Column(1), Operator.Lt, l64(204.8)), [Column(0)], [AggregateFunction("SUM", [Column(2)], f64)])
-    assert "FastPolicy" in _explain_aggregate(kv, BinaryExpr(Column(0), Operator.Lt, Literal(ScalarValue.Int64(5))), [Column(0)], [sum_v])
+    assert "scan plan (PlanPolicy" in _explain_aggregate(kvw, BinaryExpr(Column(1), Operator.Lt, l64(204.8)), [Column(0)], [AggregateFunction("SUM", [Column(2)], f64)])
+    assert "scan plan (PlanPolicy" in _explain_aggregate(kv, BinaryExpr(Column(0), Operator.Lt, Literal(ScalarValue.Int64(5))), [Column(0)], [sum_v])
+    # ... any single MIN / MAX / COUNT / SUM, an Int32 key, a Float32 / Int32 predicate column, a third term, nulls in any of them
+    k32 = pa.schema([("k", pa.int32()), ("v", pa.float64()), ("w", pa.float32())])
+    three = BinaryExpr(pred, Operator.And, BinaryExpr(Column(0), Operator.GtEq, Literal(ScalarValue.Int32(0))))
+    for agg in (AggregateFunction("MIN", [Column(1)], f64), AggregateFunction("MAX", [Column(1)], f64), AggregateFunction("COUNT", [Column(1)], DataType.UInt64), sum_v):
+        text = _explain_aggregate(k32, three, [Column(0)], [agg])
+        assert "scan plan (PlanPolicy" in text and "batches with nulls too" in text, text
+    wpred = BinaryExpr(Column(2), Operator.Lt, Literal(ScalarValue.Float32(0.5)))
+    assert "scan plan (PlanPolicy" in _explain_aggregate(k32, wpred, [Column(0)], [sum_v])
+    # not a plan: a Float32 argument of SUM (the accumulators take the argument's own bits), a product argument, an Int16 column
+    assert "scan plan" not in _explain_aggregate(k32, wpred, [Column(0)], [AggregateFunction("SUM", [Column(2)], DataType.Float32)])
+    k16 = pa.schema([("k", pa.int16()), ("v", pa.float64())])
+    assert "scan plan" not in _explain_aggregate(k16, None, [Column(0)], [sum_v])
     # SUM(column <op> literal) under the headline's predicate: its own pass-1 signature (round 3)
     for arg in (BinaryExpr(Column(1), Operator.Multiply, l64(2.0)), BinaryExpr(l64(2.0), Operator.Multiply, Column(1)),
                 BinaryExpr(Column(1), Operator.Plus, l64(2.0)), BinaryExpr(Column(1), Operator.Minus, l64(2.0)), BinaryExpr(l64(2.0), Operator.Minus, Column(1))):
         assert "static shape KeyAffSumPred2F64" in _explain_aggregate(kv, pred, [Column(0)], [AggregateFunction("SUM", [arg], f64)])
     # anything else: the run-time decoded shape family, or the interpreter
-    assert "FastPolicy" in _explain_aggregate(kv, pred, [Column(0)], [AggregateFunction("MAX", [Column(1)], f64)])
+    assert "scan plan (PlanPolicy" in _explain_aggregate(kv, pred, [Column(0)], [AggregateFunction("MAX", [Column(1)], f64)])
+    prod = BinaryExpr(BinaryExpr(Column(1), Operator.Multiply, l64(2.0)), Operator.Multiply, BinaryExpr(Column(1), Operator.Plus, l64(1.0)))
+    assert "FastPolicy" in _explain_aggregate(kv, BinaryExpr(Column(1), Operator.Eq, l64(204.8)), [Column(0)], [AggregateFunction("SUM", [prod], f64)])
     # AVG = SUM + COUNT of one operand, SUM + MIN + MAX of one column: shared routed value; different operands: not
     assert "2 aggregates of ONE operand" in _explain_aggregate(kv, pred, [Column(0)], [AggregateFunction("AVG", [Column(1)], f64)])
     assert "3 aggregates of ONE operand" in _explain_aggregate(kv, None, [Column(0)], [sum_v, AggregateFunction("MIN", [Column(1)], f64), AggregateFunction("MAX", [Column(1)], f64)])
