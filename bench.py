@@ -284,6 +284,21 @@ def main():
                   "three_term_predicate_query": (syn, schema, pred_3, [sum_v]),
                   "different_operand_sum_min": (syn_w, schema_w, pred, [sum_v, min_w]),
                   "zipf_keys": (syn_z, schema, pred, [sum_v])}
+    # round 4: the run-time shape FAMILY (scan plans: the query is data, csrc/dfx_device.hpp DevScanPlan) -- what round 3 ran through
+    # FastPolicy (0.29) or the interpreter (0.16)
+    i64lit = lambda v: Literal(ScalarValue.Int64(v))
+    pred_k = BinaryExpr(BinaryExpr(Column(0), Operator.GtEq, i64lit(200000)), Operator.And, BinaryExpr(Column(0), Operator.Lt, i64lit(400000)))
+    syn_nv = [syn[0], ("v", ex.synth_nulls(ex.SYNTH_F64_EXACT, 100), 1, 0.0, 0.0)]
+    syn_k32 = [("k", ex.SYNTH_I32_UNIFORM, 0, float(GROUPS), 0.0), syn[1]]
+    schema_k32 = pa.schema([("k", pa.int32()), ("v", pa.float64())])
+    family = {"min_only": (syn, schema, pred, [min_v], 16, "SELECT k, MIN(v) WHERE v > lo AND v < hi GROUP BY k (the headline's scan, another accumulator: pass 1 routes the ordered image)"),
+              "int64_predicate": (syn, schema, pred_k, [sum_v], 16, "SELECT k, SUM(v) WHERE k >= 200000 AND k < 400000 GROUP BY k (a two-term range on the Int64 key column, 20 % of the rows)"),
+              "nullable_v_10pct": (syn_nv, schema, pred, [sum_v], 16.125, "the headline query over a v column with a validity bitmap, 10 % nulls (16 B + 1 validity bit per row; round 3: a "
+                                   "materialised FilterRelation + the interpreter)"),
+              "int32_key": (syn_k32, schema_k32, pred, [sum_v], 12, "the headline query with an Int32 key column (12 B/row: the reference's own fixtures group by Int32, aggregate.rs:1033-1127)"),
+              "headline_through_scan_plan": (syn, schema, pred, [sum_v], 16, "the headline query with scan.plan = 2: the plan kernels INSTEAD of its compile-time signature (what the signature still buys)")}
+    for name_, (cols_, sch_, filt_, aggs_, _b, _w) in family.items():
+        neighbours[name_] = (cols_, sch_, filt_, aggs_)
     bg = {}
     if want_oracle:
         import oracle  # tests/oracle.py: the CPU restatement -- the reported baseline AND the checker of the GPU results
@@ -522,8 +537,27 @@ def main():
         extra["product_argument_query"]["verified_vs_oracle"] = verify_neighbour("product_argument_query")
         # a shape NO compile-time signature covers (three terms, one of them on the Int64 key): FastPolicy, decoded at run time
         dg3, _ = timed(lambda: step(pred_3, (Column(0),), (sum_v,)), k3, 1)
-        extra["three_term_predicate_query"] = rate(n_rows * k3, dg3, 16, "SELECT k, SUM(v) WHERE v > lo AND v < hi AND k >= 0 GROUP BY k (no static signature: FastPolicy)")
+        extra["three_term_predicate_query"] = rate(n_rows * k3, dg3, 16, "SELECT k, SUM(v) WHERE v > lo AND v < hi AND k >= 0 GROUP BY k (no compile-time signature: a scan plan; FastPolicy until round 4)")
         extra["three_term_predicate_query"]["verified_vs_oracle"] = verify_neighbour("three_term_predicate_query")
+
+        # the shape family (scan plans): one more accumulator kind, an Int64 predicate column, a validity bitmap, a 4-byte key,
+        # and the headline itself through the plan kernels
+        for name_, (cols_, sch_, filt_, aggs_, bytes_, what_) in family.items():
+            opts_ = (("scan.plan", 2),) if name_ == "headline_through_scan_plan" else ()
+            try:
+                tf = table if cols_ is syn else ex.DeviceTable.synth(cols_, seed, 0, n_rows)
+                for k_, v_ in opts_:
+                    ex.set_option(k_, v_)
+                try:
+                    dfm, _ = timed(lambda: build_on(tf, sch_, filt_, [Column(0)], list(aggs_)).next(), k3, 1)
+                finally:
+                    for k_, _v in opts_:
+                        ex.set_option(k_, 1)
+                del tf
+                extra[name_] = rate(n_rows * k3, dfm, bytes_, what_)
+                extra[name_]["verified_vs_oracle"] = verify_neighbour(name_, opts_)
+            except Exception as e:  # a measurement, not a gate
+                extra[name_] = {"error": str(e)[:200]}
 
         # two aggregates of DIFFERENT operands over 10^6 groups (generic 24-byte routed rows: no shared operand, no narrow form)
         try:

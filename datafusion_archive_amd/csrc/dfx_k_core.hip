@@ -728,6 +728,8 @@ __global__ __launch_bounds__(kBlock) void k_synth(int kind, int column_id, doubl
       ((double*)out)[i] = (double)(r >> exact_shift) * exact_scale;
     } else if (kind == 2) {
       ((int64_t*)out)[i] = (int64_t)__umul64hi(r, G);
+    } else if (kind == 4) {
+      ((int32_t*)out)[i] = (int32_t)__umul64hi(r, G);
     } else {
       const uint64_t b = __umul64hi(r, (uint64_t)zipf_bits + 1ull);
       const uint64_t r2 = mix64(r ^ 0xD6E8FEB86659FD93ull);
@@ -736,6 +738,27 @@ __global__ __launch_bounds__(kBlock) void k_synth(int kind, int column_id, doubl
       ((int64_t*)out)[i] = (int64_t)k;
     }
   }
+}
+
+// validity bitmap of a synthetic column: row NULL with probability permille / 1000 (include/dfx.h: DFX_SYNTH_NULL_PERMILLE;
+// same draw as orc_synth_validity).  One ballot word per 64 rows; nulls += the number of null rows.
+__global__ __launch_bounds__(kBlock) void k_synth_validity(int column_id, uint32_t permille, uint64_t seed, int64_t row_begin,
+                                                           int64_t n, uint64_t* __restrict__ words, unsigned long long* nulls) {
+  const int64_t n_words = (n + 63) >> 6;
+  const int lane = lane_id();
+  unsigned long long mine = 0;
+  for (int64_t w = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6; w < n_words; w += ((int64_t)gridDim.x * kBlock) >> 6) {
+    const int64_t i = w * 64 + lane;
+    const bool inb = i < n;
+    const bool valid = inb && __umul64hi(synth_u64(seed, column_id ^ DFX_SYNTH_NULL_STREAM, row_begin + i), 1000ull) >= (uint64_t)permille;
+    const uint64_t m = __ballot(valid);
+    if (lane == 0) {
+      words[w] = m;
+      const int64_t rows = n - w * 64 < 64 ? n - w * 64 : 64;
+      mine += (unsigned long long)(rows - __popcll(m));
+    }
+  }
+  if (lane == 0 && mine) atomicAdd(nulls, mine);
 }
 
 // =============================================================================================
@@ -1128,6 +1151,15 @@ hipError_t launch_finalize_avg(const uint64_t* sum, const uint64_t* cnt, int64_t
   Scope sc(KID_FINALIZE, s, 0);
   hipLaunchKernelGGL(k_finalize_avg, dim3(stream_grid((n + kBlock - 1) / kBlock, 8)), dim3(kBlock), 0, s, sum, cnt, n, out_dtype, out,
                      validity, null_count);
+  return hipGetLastError();
+}
+
+hipError_t launch_synth_validity(int column_id, uint32_t permille, uint64_t seed, int64_t row_begin, int64_t n, uint64_t* words,
+                                 uint64_t* nulls, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  Scope sc(KID_SYNTH, s, 0);
+  hipLaunchKernelGGL(k_synth_validity, dim3(stream_grid((n + kBlock - 1) / kBlock, 16)), dim3(kBlock), 0, s, column_id, permille, seed, row_begin, n,
+                     words, (unsigned long long*)nulls);
   return hipGetLastError();
 }
 

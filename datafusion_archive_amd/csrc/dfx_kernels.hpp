@@ -210,6 +210,9 @@ hipError_t launch_gather_utf8_copy(const int32_t* const* offsets, const uint8_t*
 // synthetic columns (definition shared with oracle/dfx_oracle.c: orc_synth_fill)
 hipError_t launch_synth(int kind, int column_id, double p0, double p1, uint64_t seed, int64_t row_begin,
                         int64_t n, void* out, hipStream_t s);
+// validity bitmap of a synthetic column with nulls (DFX_SYNTH_NULL_PERMILLE): (n + 63) / 64 words; *nulls += null rows
+hipError_t launch_synth_validity(int column_id, uint32_t permille, uint64_t seed, int64_t row_begin, int64_t n, uint64_t* words,
+                                 uint64_t* nulls, hipStream_t s);
 
 // host mirror of the device hash (rank ownership in tests)
 uint64_t host_hash_keys(const uint64_t* key, int kw);

@@ -330,20 +330,37 @@ int32_t dfx_table_synth(const dfx_synth_column* cols, int32_t n_cols, uint64_t s
     for (int c = 0; c < n_cols; ++c) {
       Field f;
       f.name = cols[c].name ? cols[c].name : strfmt("c%d", c);
-      f.dtype = (cols[c].kind == DFX_SYNTH_I64_UNIFORM || cols[c].kind == DFX_SYNTH_I64_ZIPF) ? DFX_INT64 : DFX_FLOAT64;
-      f.nullable = false;
-      if (cols[c].kind < 0 || cols[c].kind > DFX_SYNTH_I64_ZIPF)
+      const int kind = DFX_SYNTH_KIND(cols[c].kind);
+      const uint32_t permille = (uint32_t)DFX_SYNTH_NULL_PERMILLE(cols[c].kind);
+      f.dtype = (kind == DFX_SYNTH_I64_UNIFORM || kind == DFX_SYNTH_I64_ZIPF) ? DFX_INT64 : kind == DFX_SYNTH_I32_UNIFORM ? DFX_INT32 : DFX_FLOAT64;
+      f.nullable = permille != 0;
+      if (cols[c].kind < 0 || kind > DFX_SYNTH_I32_UNIFORM || permille > 1000 || (cols[c].kind >> 18) != 0)
         return to_c(Status::Err(DFX_NOT_IMPLEMENTED, "unknown synthetic column kind"), err, errlen);
       t->schema.fields.push_back(f);
       DeviceColumn col;
       col.dtype = f.dtype;
       col.length = n_rows;
-      auto vals = device_alloc((size_t)std::max<int64_t>(n_rows, 1) * 8, &st);
+      auto vals = device_alloc((size_t)std::max<int64_t>(n_rows, 1) * 8, &st);  // (4-byte kinds: half used)
       if (!vals) return to_c(st, err, errlen);
-      hipError_t e = launch_synth(cols[c].kind, cols[c].column_id, cols[c].p0, cols[c].p1, seed, row_begin, n_rows, vals.get(), s);
+      hipError_t e = launch_synth(kind, cols[c].column_id, cols[c].p0, cols[c].p1, seed, row_begin, n_rows, vals.get(), s);
       if (e != hipSuccess) return to_c(Status::Err(DFX_EXECUTION_ERROR, hipGetErrorString(e)), err, errlen);
       col.values = vals.get();
       col.owners.push_back(vals);
+      if (permille != 0 && n_rows > 0) {
+        auto bits = device_alloc((size_t)((n_rows + 63) / 64) * 8 + 8, &st);
+        if (!bits) return to_c(st, err, errlen);
+        uint64_t* count = (uint64_t*)bits.get() + (n_rows + 63) / 64;  // (the word behind the bitmap)
+        e = hipMemsetAsync(count, 0, 8, s);
+        if (e == hipSuccess) e = launch_synth_validity(cols[c].column_id, permille, seed, row_begin, n_rows, (uint64_t*)bits.get(), count, s);
+        uint64_t nulls = 0;
+        if (e == hipSuccess) e = hipMemcpyAsync(&nulls, count, 8, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) return to_c(Status::Err(DFX_EXECUTION_ERROR, hipGetErrorString(e)), err, errlen);
+        col.validity = (const uint8_t*)bits.get();
+        col.bit_offset = 0;
+        col.null_count = (int64_t)nulls;
+        col.owners.push_back(bits);
+      }
       t->columns.push_back(std::move(col));
     }
     hipError_t e = hipStreamSynchronize(s);

@@ -392,7 +392,12 @@ class Communicator:
 # ---------------------------------------------------------------------------------------------------
 # HBM-resident tables (the in-memory DataSource)
 # ---------------------------------------------------------------------------------------------------
-SYNTH_F64_UNIFORM, SYNTH_F64_EXACT, SYNTH_I64_UNIFORM, SYNTH_I64_ZIPF = 0, 1, 2, 3
+SYNTH_F64_UNIFORM, SYNTH_F64_EXACT, SYNTH_I64_UNIFORM, SYNTH_I64_ZIPF, SYNTH_I32_UNIFORM = 0, 1, 2, 3, 4
+
+
+def synth_nulls(kind: int, permille: int) -> int:
+    """include/dfx.h: `kind | (permille << 8)` -- the column gets a validity bitmap, a row is NULL with probability permille / 1000"""
+    return kind | (int(permille) << 8)
 
 
 class _TableScan(Relation):

@@ -265,11 +265,18 @@ typedef enum dfx_synth_kind {
   DFX_SYNTH_F64_UNIFORM = 0, /* p0 + p1 * u,  u in [0,1) 53-bit          (dtype Float64) */
   DFX_SYNTH_F64_EXACT = 1,   /* m * 2^-S, m uniform integer in [0,2^B): B = p0 (0: 20), S = p1 (0: 10)  (dtype Float64) */
   DFX_SYNTH_I64_UNIFORM = 2, /* uniform integer in [0, (int64)p0)          (dtype Int64)   */
-  DFX_SYNTH_I64_ZIPF = 3     /* floor(p0 ^ u) - 1 clipped to [0,p0): log-uniform skew (dtype Int64) */
+  DFX_SYNTH_I64_ZIPF = 3,    /* floor(p0 ^ u) - 1 clipped to [0,p0): log-uniform skew (dtype Int64) */
+  DFX_SYNTH_I32_UNIFORM = 4  /* uniform integer in [0, (int32)p0): the same draw as I64_UNIFORM, stored in 4 bytes (dtype Int32) */
 } dfx_synth_kind;
+/* Nulls: `kind | (permille << 8)` gives the column a validity bitmap in which a row is NULL with probability permille / 1000
+ * (1 .. 1000), decided by a draw of its own -- DFX_SYNTH_NULL_STREAM mixed into the column id -- so the values under the null
+ * slots are ordinary values: grouped aggregates read value(row) without a null check (aggregate.rs:561-603). */
+#define DFX_SYNTH_KIND(k) ((k) & 0xFF)
+#define DFX_SYNTH_NULL_PERMILLE(k) (((k) >> 8) & 0x3FF)
+#define DFX_SYNTH_NULL_STREAM 0x4E554C4C
 typedef struct dfx_synth_column {
   const char* name;
-  int32_t kind;      /* dfx_synth_kind */
+  int32_t kind;      /* dfx_synth_kind, optionally | (null permille << 8) */
   int32_t column_id; /* stream id mixed into the generator */
   double p0, p1;
 } dfx_synth_column;

@@ -993,6 +993,7 @@ int32_t orc_synth_fill(int32_t kind, int32_t column_id, double p0, double p1, ui
         break;
       }
       case DFX_SYNTH_I64_UNIFORM: ((int64_t*)out)[i] = (int64_t)mulhi64(r, (uint64_t)(int64_t)p0); break;
+      case DFX_SYNTH_I32_UNIFORM: ((int32_t*)out)[i] = (int32_t)mulhi64(r, (uint64_t)(int64_t)p0); break;
       case DFX_SYNTH_I64_ZIPF: {
         /* log-uniform skew: k = floor(2^(u * log2(G))) - 1, computed in integers:
          * pick a bit-length b uniformly in [0, ceil(log2 G)], then a uniform value below 2^b. */
@@ -1010,6 +1011,22 @@ int32_t orc_synth_fill(int32_t kind, int32_t column_id, double p0, double p1, ui
     }
   }
   return DFX_OK;
+}
+
+/* validity bitmap of a synthetic column with nulls (include/dfx.h: DFX_SYNTH_NULL_PERMILLE): LSB first, (n + 7) / 8 bytes
+ * (zeroed here); returns the number of null rows */
+int64_t orc_synth_validity(int32_t column_id, int32_t permille, uint64_t seed, int64_t row_begin, int64_t n, uint8_t* bits) {
+  int64_t nulls = 0;
+  memset(bits, 0, (size_t)((n + 7) / 8));
+  for (int64_t i = 0; i < n; ++i) {
+    if (mulhi64(orc_synth_u64(seed, column_id ^ DFX_SYNTH_NULL_STREAM, row_begin + i), 1000ull) >= (uint64_t)permille) bits[i >> 3] |= (uint8_t)(1u << (i & 7));
+    else ++nulls;
+  }
+  return nulls;
+}
+static int synth_dtype(int32_t kind) {
+  const int k = DFX_SYNTH_KIND(kind);
+  return (k == DFX_SYNTH_I64_UNIFORM || k == DFX_SYNTH_I64_ZIPF) ? DFX_INT64 : k == DFX_SYNTH_I32_UNIFORM ? DFX_INT32 : DFX_FLOAT64;
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -1039,8 +1056,7 @@ int32_t orc_run_synth_query(const dfx_synth_column* cols, int32_t n_cols, uint64
   b.num_columns = n_cols;
   b.columns = (orc_array**)calloc((size_t)n_cols, sizeof(orc_array*));
   for (int c = 0; c < n_cols; ++c) {
-    int dt = (cols[c].kind == DFX_SYNTH_I64_UNIFORM || cols[c].kind == DFX_SYNTH_I64_ZIPF) ? DFX_INT64 : DFX_FLOAT64;
-    b.columns[c] = arr_new(dt, batch_rows, 0);
+    b.columns[c] = arr_new(synth_dtype(cols[c].kind), batch_rows, DFX_SYNTH_NULL_PERMILLE(cols[c].kind) != 0);
   }
   double t = 0.0;
   int64_t kept = 0;
@@ -1048,7 +1064,8 @@ int32_t orc_run_synth_query(const dfx_synth_column* cols, int32_t n_cols, uint64
     int64_t n = n_rows - r0 < batch_rows ? n_rows - r0 : batch_rows;
     for (int c = 0; c < n_cols; ++c) {
       b.columns[c]->length = n;
-      orc_synth_fill(cols[c].kind, cols[c].column_id, cols[c].p0, cols[c].p1, seed, row_begin + r0, n, b.columns[c]->values);
+      orc_synth_fill(DFX_SYNTH_KIND(cols[c].kind), cols[c].column_id, cols[c].p0, cols[c].p1, seed, row_begin + r0, n, b.columns[c]->values);
+      if (b.columns[c]->validity) (void)orc_synth_validity(cols[c].column_id, DFX_SYNTH_NULL_PERMILLE(cols[c].kind), seed, row_begin + r0, n, b.columns[c]->validity);
     }
     b.num_rows = n;
     double t0 = now_s();
@@ -1105,8 +1122,7 @@ int32_t orc_run_synth_filter(const dfx_synth_column* cols, int32_t n_cols, uint6
   b.num_columns = n_cols;
   b.columns = (orc_array**)calloc((size_t)n_cols, sizeof(orc_array*));
   for (int c = 0; c < n_cols; ++c) {
-    int dt = (cols[c].kind == DFX_SYNTH_I64_UNIFORM || cols[c].kind == DFX_SYNTH_I64_ZIPF) ? DFX_INT64 : DFX_FLOAT64;
-    b.columns[c] = arr_new(dt, batch_rows, 0);
+    b.columns[c] = arr_new(synth_dtype(cols[c].kind), batch_rows, DFX_SYNTH_NULL_PERMILLE(cols[c].kind) != 0);
   }
   if (mask_bits) memset(mask_bits, 0, (size_t)((n_rows + 7) / 8));
   double t = 0.0;
@@ -1115,7 +1131,8 @@ int32_t orc_run_synth_filter(const dfx_synth_column* cols, int32_t n_cols, uint6
     int64_t n = n_rows - r0 < batch_rows ? n_rows - r0 : batch_rows;
     for (int c = 0; c < n_cols; ++c) {
       b.columns[c]->length = n;
-      orc_synth_fill(cols[c].kind, cols[c].column_id, cols[c].p0, cols[c].p1, seed, row_begin + r0, n, b.columns[c]->values);
+      orc_synth_fill(DFX_SYNTH_KIND(cols[c].kind), cols[c].column_id, cols[c].p0, cols[c].p1, seed, row_begin + r0, n, b.columns[c]->values);
+      if (b.columns[c]->validity) (void)orc_synth_validity(cols[c].column_id, DFX_SYNTH_NULL_PERMILLE(cols[c].kind), seed, row_begin + r0, n, b.columns[c]->validity);
     }
     b.num_rows = n;
     double t0 = now_s();

@@ -75,6 +75,8 @@ void orc_agg_free(orc_agg* agg);
 uint64_t orc_synth_u64(uint64_t seed, int32_t column_id, int64_t row);
 int32_t orc_synth_fill(int32_t kind, int32_t column_id, double p0, double p1, uint64_t seed,
                        int64_t row_begin, int64_t n, void* out);
+/* validity bitmap of a synthetic column with nulls (include/dfx.h: DFX_SYNTH_NULL_PERMILLE); returns the null count */
+int64_t orc_synth_validity(int32_t column_id, int32_t permille, uint64_t seed, int64_t row_begin, int64_t n, uint8_t* bits);
 
 /* CPU baseline: run `[filter ->] aggregate` reference-shaped (1024-row batches, materialised
  * literal arrays, per-row hash map) over synthetic columns; returns wall seconds via *seconds and

@@ -254,20 +254,38 @@ def aggregate(group_exprs: Sequence[Expr], aggr_exprs: Sequence[Expr],
 # ---------------------------------------------------------------------------------------------
 # synthetic data (definition shared with the device generator)
 # ---------------------------------------------------------------------------------------------
-SYNTH_F64_UNIFORM, SYNTH_F64_EXACT, SYNTH_I64_UNIFORM, SYNTH_I64_ZIPF = 0, 1, 2, 3
+SYNTH_F64_UNIFORM, SYNTH_F64_EXACT, SYNTH_I64_UNIFORM, SYNTH_I64_ZIPF, SYNTH_I32_UNIFORM = 0, 1, 2, 3, 4
 
 
 def synth_column(kind: int, column_id: int, p0: float, p1: float, seed: int, row_begin: int, n: int) -> np.ndarray:
-    out = np.empty(n, dtype=np.int64 if kind in (SYNTH_I64_UNIFORM, SYNTH_I64_ZIPF) else np.float64)
+    kind &= 0xFF
+    out = np.empty(n, dtype=np.int64 if kind in (SYNTH_I64_UNIFORM, SYNTH_I64_ZIPF) else np.int32 if kind == SYNTH_I32_UNIFORM else np.float64)
     code = lib().orc_synth_fill(kind, column_id, p0, p1, seed, row_begin, n, out.ctypes.data_as(ctypes.c_void_p))
     if code != 0:
         raise OracleError(code, "orc_synth_fill")
     return out
 
 
+def synth_validity(kind: int, column_id: int, seed: int, row_begin: int, n: int):
+    """Boolean numpy array (True = valid) of a synthetic column with nulls (kind | permille << 8), or None"""
+    permille = (kind >> 8) & 0x3FF
+    if permille == 0:
+        return None
+    bits = np.zeros((n + 7) // 8, dtype=np.uint8)
+    L = lib()
+    L.orc_synth_validity.restype = ctypes.c_int64
+    L.orc_synth_validity.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_uint64, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]
+    L.orc_synth_validity(column_id, permille, seed, row_begin, n, bits.ctypes.data_as(ctypes.c_void_p))
+    return np.unpackbits(bits, bitorder="little")[:n].astype(bool)
+
+
 def synth_batch(cols: Sequence[tuple], seed: int, row_begin: int, n: int) -> pa.RecordBatch:
     """cols: (name, kind, column_id, p0, p1)."""
-    arrays = [pa.array(synth_column(k, cid, p0, p1, seed, row_begin, n)) for (_, k, cid, p0, p1) in cols]
+    arrays = []
+    for (_, k, cid, p0, p1) in cols:
+        v = synth_column(k, cid, p0, p1, seed, row_begin, n)
+        valid = synth_validity(k, cid, seed, row_begin, n)
+        arrays.append(pa.array(v) if valid is None else pa.array(v, mask=~valid))
     return pa.RecordBatch.from_arrays(arrays, names=[c[0] for c in cols])
 
 
