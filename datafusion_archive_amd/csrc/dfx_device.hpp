@@ -115,9 +115,10 @@ constexpr int kPlanTerms = 4;
 enum : uint32_t { PX_NONE = 0, PX_SEXT32 = 1, PX_ZEXT32 = 2, PX_F32 = 3 };
 // column word (DevScanPlan::col_meta, also DevColumn::bit_offset of a plan-bound column):
 //   bits 0..3 log2(value bytes) (2 / 3), bit 4 element index of row 0 inside its aligned pair (4-byte values),
-//   bits 8..9 PX_*, bits 16..18 bit_offset & 7 of the validity bitmap
-inline constexpr uint32_t plan_col_meta(uint32_t shift, uint32_t delta, uint32_t ext, uint32_t vbit0) {
-  return shift | (delta << 4) | (ext << 8) | (vbit0 << 16);
+//   bits 8..9 PX_*, bits 16..18 bit_offset & 7 of the validity bitmap, bit 20 the column HAS a bitmap (without one every lane
+//   reads byte 0 of the block of 0xFF bytes, whatever its row)
+inline constexpr uint32_t plan_col_meta(uint32_t shift, uint32_t delta, uint32_t ext, uint32_t vbit0, bool bitmap) {
+  return shift | (delta << 4) | (ext << 8) | (vbit0 << 16) | (bitmap ? 1u << 20 : 0u);
 }
 struct DevPlanTerm {
   uint32_t col;      // plan column slot
@@ -129,7 +130,7 @@ struct DevPlanTerm {
 };
 struct DevScanPlan {
   int32_t valid;        // 0: shape not covered (then nothing below is meaningful)
-  int32_t gen;          // 1: needs the general kernels (a 4-byte column or a validity bitmap in this batch)
+  int32_t gen;          // what this batch needs of the kernels: bit 0 a 4-byte column (widening loads), bit 1 a validity bitmap
   int32_t n_cols;       // plan column slots in use
   int32_t np;           // terms
   int32_t count_valid;  // 1: COUNT(x) looks at x's validity (no Filter below: fn filter's output is all-valid, filter.rs:83-92)
@@ -176,6 +177,7 @@ enum : uint8_t {
   VT_COUNT_VALID = 5    // 1 if the argument is valid else 0
 };
 
+constexpr int kSynthNullStream = 0x4E554C4C;  // == DFX_SYNTH_NULL_STREAM (include/dfx.h): the draw that decides a synthetic row's validity
 constexpr uint64_t kEmptyKey = 0x8000000000000000ull;  // single-word key claim sentinel
 // PTF_NARROW: 32-bit hash images stand for keys; two images are reserved (keys that hash to them are not "narrow")
 constexpr uint32_t kTagEmpty = 0xFFFFFFFFu;    // empty slot of the LDS tag plane / padding row of a region

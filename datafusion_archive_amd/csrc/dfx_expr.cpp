@@ -585,7 +585,7 @@ bool bind_scan_plan(const DevProgram& P, const DevFastPlan& F, const DevColumns&
     slot_of[c] = n++;
   }
   S.n_cols = n;
-  bool gen = false;
+  int gen = 0;
   for (int sl = 0; sl < kPlanCols; ++sl) {
     const int c = sl < n ? src_of[sl] : src_of[0];  // unused slots repeat slot 0 (loads are unconditional)
     const uint8_t t = P.col_dtype[c];
@@ -599,10 +599,10 @@ bool bind_scan_plan(const DevProgram& P, const DevFastPlan& F, const DevColumns&
       if (C.c[c].bit_offset < 0) return false;
       vb = C.c[c].validity + (C.c[c].bit_offset >> 3);
       vbit0 = (uint32_t)(C.c[c].bit_offset & 7);
-      if (sl < n) gen = true;
+      if (sl < n) gen |= 2;
     }
-    if (w4 && sl < n) gen = true;
-    const uint32_t meta = plan_col_meta(w4 ? 2u : 3u, w4 ? (uint32_t)((base & 7u) >> 2) : 0u, ext, vbit0);
+    if (w4 && sl < n) gen |= 1;
+    const uint32_t meta = plan_col_meta(w4 ? 2u : 3u, w4 ? (uint32_t)((base & 7u) >> 2) : 0u, ext, vbit0, C.c[c].validity != nullptr);
     Cout->c[sl].values = (const void*)(base & ~(uintptr_t)7);
     Cout->c[sl].validity = vb;
     Cout->c[sl].bit_offset = (int64_t)meta;
@@ -631,7 +631,7 @@ bool bind_scan_plan(const DevProgram& P, const DevFastPlan& F, const DevColumns&
   // under an absorbed predicate every surviving slot counts (and every other aggregate reads value(row) regardless,
   // aggregate.rs:561-603)
   S.count_valid = F.np == 0 ? 1 : 0;
-  S.gen = gen ? 1 : 0;
+  S.gen = gen;
   S.valid = 1;
   return true;
 }

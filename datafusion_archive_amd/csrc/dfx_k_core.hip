@@ -750,7 +750,7 @@ __global__ __launch_bounds__(kBlock) void k_synth_validity(int column_id, uint32
   for (int64_t w = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6; w < n_words; w += ((int64_t)gridDim.x * kBlock) >> 6) {
     const int64_t i = w * 64 + lane;
     const bool inb = i < n;
-    const bool valid = inb && __umul64hi(synth_u64(seed, column_id ^ DFX_SYNTH_NULL_STREAM, row_begin + i), 1000ull) >= (uint64_t)permille;
+    const bool valid = inb && __umul64hi(synth_u64(seed, column_id ^ kSynthNullStream, row_begin + i), 1000ull) >= (uint64_t)permille;
     const uint64_t m = __ballot(valid);
     if (lane == 0) {
       words[w] = m;

@@ -83,7 +83,7 @@ __global__ __launch_bounds__(kFGBlock) void k_fewgroup_agg(const DevProgram P, c
       const bool inb = row < n;
       u64x16 reg;
       uint32_t rv = 0;
-      POL::eval(P, F, cur, curv, reg, rv, inb, err);
+      POL::eval(P, F, cur, curv, reg, rv, inb, err, prep);
       const bool pass = inb && POL::pass(P, F, plan.pred, cur, curv, reg, rv, prep);
       uint64_t key[KW];
       uint64_t val[kMaxAggs];
@@ -288,11 +288,11 @@ hipError_t launch_fewgroup_agg(const DevProgram& P, const DevFastPlan& fast, con
     if (bind_scan_plan(P, fast, C, T.kw, T.na, T.val_xform, false, &fp, &cp)) {
 #define DFX_FGP(KW, POL) hipLaunchKernelGGL((k_fewgroup_agg<KW, 4, POL>), dim3(grid), dim3(kFGBlock), 0, s, P, fp, cp, plan, T, spill, n)
       if (T.kw == 1) {
-        if (fp.scan.n_cols <= 2) DFX_FGP(1, DFX_ARG(PlanPolicyN<2, 4, true>));
-        else DFX_FGP(1, DFX_ARG(PlanPolicyN<4, 2, true>));
+        if (fp.scan.n_cols <= 2) DFX_FGP(1, DFX_ARG(PlanPolicyN<2, 4, kPlanW4 | kPlanNulls>));
+        else DFX_FGP(1, DFX_ARG(PlanPolicyN<4, 2, kPlanW4 | kPlanNulls>));
       } else {
-        if (fp.scan.n_cols <= 2) DFX_FGP(2, DFX_ARG(PlanPolicyN<2, 4, true>));
-        else DFX_FGP(2, DFX_ARG(PlanPolicyN<4, 2, true>));
+        if (fp.scan.n_cols <= 2) DFX_FGP(2, DFX_ARG(PlanPolicyN<2, 4, kPlanW4 | kPlanNulls>));
+        else DFX_FGP(2, DFX_ARG(PlanPolicyN<4, 2, kPlanW4 | kPlanNulls>));
       }
 #undef DFX_FGP
       return hipGetLastError();

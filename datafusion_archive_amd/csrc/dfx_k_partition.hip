@@ -704,9 +704,13 @@ void launch_partition_variant6(DFX_PARTITION_VARIANT_ARGS);
 void launch_partition_variant7(DFX_PARTITION_VARIANT_ARGS);
 void launch_partition_variant8(DFX_PARTITION_VARIANT_ARGS);
 void launch_partition_variant9(DFX_PARTITION_VARIANT_ARGS);   // PlanPolicy, <= 2 columns, 8-byte null-free
-void launch_partition_variant10(DFX_PARTITION_VARIANT_ARGS);  // ... general (4-byte columns, validity bitmaps)
+void launch_partition_variant10(DFX_PARTITION_VARIANT_ARGS);  // ... 4-byte columns AND validity bitmaps
 void launch_partition_variant11(DFX_PARTITION_VARIANT_ARGS);  // PlanPolicy, <= 4 columns, 8-byte null-free
-void launch_partition_variant12(DFX_PARTITION_VARIANT_ARGS);  // ... general
+void launch_partition_variant12(DFX_PARTITION_VARIANT_ARGS);  // ... 4-byte columns AND validity bitmaps
+void launch_partition_variant13(DFX_PARTITION_VARIANT_ARGS);  // <= 2 columns, 4-byte columns (no bitmap in the batch)
+void launch_partition_variant14(DFX_PARTITION_VARIANT_ARGS);  // <= 2 columns, validity bitmaps (8-byte columns)
+void launch_partition_variant15(DFX_PARTITION_VARIANT_ARGS);  // <= 4 columns, 4-byte columns
+void launch_partition_variant16(DFX_PARTITION_VARIANT_ARGS);  // <= 4 columns, validity bitmaps
 
 // The scan plan (DevScanPlan): run-time shapes as data.  Which binding a launch needs follows from the kernel flavour that
 // will run: the one-value flavours (narrow rows, the wave-specialised kernel) find the key in slot 0 and the routed value in
@@ -721,13 +725,11 @@ static bool launch_partition_plan(const DevProgram& P, const DevFastPlan& fast, 
   DevFastPlan fp;
   DevColumns cp;
   if (!bind_scan_plan(P, fast, C, 1, shared ? 1 : T.na, shared ? raw_xf : T.val_xform, one_value, &fp, &cp)) return false;
-  if (fp.scan.n_cols <= 2) {
-    if (fp.scan.gen) launch_partition_variant10(P, fp, cp, plan, T, PT, spill, n, lds_bytes, s);
-    else launch_partition_variant9(P, fp, cp, plan, T, PT, spill, n, lds_bytes, s);
-  } else {
-    if (fp.scan.gen) launch_partition_variant12(P, fp, cp, plan, T, PT, spill, n, lds_bytes, s);
-    else launch_partition_variant11(P, fp, cp, plan, T, PT, spill, n, lds_bytes, s);
-  }
+  typedef void (*Variant)(DFX_PARTITION_VARIANT_ARGS);
+  static const Variant by_need[2][4] = {  // [> 2 columns][DevScanPlan::gen: bit 0 4-byte columns, bit 1 validity bitmaps]
+      {launch_partition_variant9, launch_partition_variant13, launch_partition_variant14, launch_partition_variant10},
+      {launch_partition_variant11, launch_partition_variant15, launch_partition_variant16, launch_partition_variant12}};
+  by_need[fp.scan.n_cols <= 2 ? 0 : 1][fp.scan.gen & 3](P, fp, cp, plan, T, PT, spill, n, lds_bytes, s);
   return true;
 }
 

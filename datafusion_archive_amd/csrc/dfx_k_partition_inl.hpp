@@ -125,7 +125,7 @@ __global__ __launch_bounds__(kPBlock) void k_partition(const DevProgram P, const
       const bool inb = row < n;
       u64x16 reg;
       uint32_t rv = 0;
-      POL::eval(P, F, col[u], cv[u], reg, rv, inb, err);
+      POL::eval(P, F, col[u], cv[u], reg, rv, inb, err, prep);
       bool pass = inb && POL::pass(P, F, plan.pred, col[u], cv[u], reg, rv, prep);
       key[u][0] = POL::key(P, F, plan.key[0], 0, col[u], cv[u], reg, rv);
 #pragma unroll
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(BLOCK) void k_partition_sorted(const DevProgram P, 
       const bool inb = row < n;
       u64x16 reg;
       uint32_t rv = 0;
-      POL::eval(P, F, col[u], cv[u], reg, rv, inb, err);
+      POL::eval(P, F, col[u], cv[u], reg, rv, inb, err, prep);
       bool pass = inb && POL::pass(P, F, plan.pred, col[u], cv[u], reg, rv, prep);
       key[u][0] = POL::key(P, F, plan.key[0], 0, col[u], cv[u], reg, rv);
 #pragma unroll
@@ -871,7 +871,7 @@ __global__ __launch_bounds__(kRingBlock) void k_partition_ring(const DevProgram 
       const bool inb = row < n;
       u64x16 reg;
       uint32_t rv = 0;
-      POL::eval(P, F, col[u], cv[u], reg, rv, inb, err);
+      POL::eval(P, F, col[u], cv[u], reg, rv, inb, err, prep);
       bool pass = inb && POL::pass(P, F, plan.pred, col[u], cv[u], reg, rv, prep);
       uint64_t key[1];
       uint64_t val[kMaxAggs];

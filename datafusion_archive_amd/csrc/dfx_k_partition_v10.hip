@@ -1,5 +1,6 @@
-// dfx_k_partition_v10.hip -- pass 1 of the partitioned GROUP BY for one row-source policy: PlanPolicy (the scan plan: range tests on value images, plan words in vector registers), <= 2 columns, general form (4-byte columns, validity bitmaps).
+// dfx_k_partition_v10.hip -- pass 1 of the partitioned GROUP BY for one row-source policy: PlanPolicy (the scan plan: range tests on
+// value images, plan words in vector registers), <= 2 columns, GENK = 3 (4-byte+bitmaps: bit 0 4-byte columns widened, bit 1 validity bitmaps).
 #include "dfx_k_partition_ws_inl.hpp"
 namespace dfx {
-DFX_PARTITION_VARIANT_WS(10, DFX_ARG(PlanPolicyN<2, 2, true>), DFX_ARG(PlanPolicyN<2, 2, true>), DFX_ARG(PlanPolicy1<2, 2, true>), DFX_ARG(PlanPolicy1<2, 4, true>))
+DFX_PARTITION_VARIANT_WS(10, DFX_ARG(PlanPolicyN<2, 2, 3>), DFX_ARG(PlanPolicyN<2, 2, 3>), DFX_ARG(PlanPolicy1<2, 2, 3>), DFX_ARG(PlanPolicy1<2, 4, 3>))
 }  // namespace dfx

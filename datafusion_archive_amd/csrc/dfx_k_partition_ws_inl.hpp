@@ -147,7 +147,7 @@ __global__ __launch_bounds__(kRingBlock) void k_partition_ws(const DevProgram P,
           const bool inb = row < n;
           u64x16 reg;
           uint32_t rv = 0;
-          POL::eval(P, F, cur, curv, reg, rv, inb, err);
+          POL::eval(P, F, cur, curv, reg, rv, inb, err, prep);
           bool pass = POL::template pass_form<FORM>(P, F, plan.pred, cur, curv, reg, rv, prep);
           pass = pass && inb;  // (evaluated for every lane: no branch around the predicate)
           const uint64_t key = POL::key(P, F, plan.key[0], 0, cur, curv, reg, rv);

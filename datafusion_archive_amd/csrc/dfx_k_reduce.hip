@@ -47,7 +47,7 @@ __global__ __launch_bounds__(kBlock) void k_reduce(const DevProgram P, const Dev
       const bool inb = row < n;
       u64x16 reg;
       uint32_t rv = 0;
-      POL::eval(P, F, cur, curv, reg, rv, inb, err);
+      POL::eval(P, F, cur, curv, reg, rv, inb, err, prep);
       const bool pass = inb && POL::template pass_form<FORM>(P, F, plan.pred, cur, curv, reg, rv, prep);
       if (pass) {
         ++passed;
@@ -161,8 +161,8 @@ hipError_t launch_reduce(const DevProgram& P, const DevFastPlan& fast, const Dev
     DevColumns cp;
     if (bind_scan_plan(P, fast, C, 0, T.na, T.val_xform, false, &fp, &cp)) {
 #define DFX_REDUCE_P(POL, NM) hipLaunchKernelGGL((k_reduce<POL, NM>), dim3(grid), dim3(kBlock), 0, s, P, fp, cp, plan, T, n, partial, ctrl)
-      if (fp.scan.n_cols <= 2) { if (T.na <= 2) DFX_REDUCE_P(DFX_ARG(PlanPolicyN<2, 4, true>), 2); else DFX_REDUCE_P(DFX_ARG(PlanPolicyN<2, 4, true>), 8); }
-      else { if (T.na <= 2) DFX_REDUCE_P(DFX_ARG(PlanPolicyN<4, 2, true>), 2); else DFX_REDUCE_P(DFX_ARG(PlanPolicyN<4, 2, true>), 8); }
+      if (fp.scan.n_cols <= 2) { if (T.na <= 2) DFX_REDUCE_P(DFX_ARG(PlanPolicyN<2, 4, kPlanW4 | kPlanNulls>), 2); else DFX_REDUCE_P(DFX_ARG(PlanPolicyN<2, 4, kPlanW4 | kPlanNulls>), 8); }
+      else { if (T.na <= 2) DFX_REDUCE_P(DFX_ARG(PlanPolicyN<4, 2, kPlanW4 | kPlanNulls>), 2); else DFX_REDUCE_P(DFX_ARG(PlanPolicyN<4, 2, kPlanW4 | kPlanNulls>), 8); }
 #undef DFX_REDUCE_P
       return hipGetLastError();
     }

@@ -69,7 +69,7 @@ __global__ __launch_bounds__(kBlock) void k_hash_agg(const DevProgram P, const D
       const bool inb = row < n;
       u64x16 reg;
       uint32_t rv = 0;
-      POL::eval(P, F, cur, curv, reg, rv, inb, err);
+      POL::eval(P, F, cur, curv, reg, rv, inb, err, prep);
       const bool pass = inb && POL::pass(P, F, plan.pred, cur, curv, reg, rv, prep);
       uint64_t key[KW];
       uint64_t val[kMaxAggs];
@@ -394,8 +394,8 @@ hipError_t table_hash_agg(const DevProgram& P, const DevFastPlan& fast, const De
     DevFastPlan fp;
     DevColumns cp;
     if (bind_scan_plan(P, fast, C, KW, T.na, T.val_xform, false, &fp, &cp)) {
-      if (fp.scan.n_cols <= 2) hipLaunchKernelGGL((k_hash_agg<KW, PlanPolicyN<2, 4, true>>), dim3(grid), dim3(kBlock), lds_bytes, s, P, fp, cp, plan, T, spill, n);
-      else hipLaunchKernelGGL((k_hash_agg<KW, PlanPolicyN<4, 2, true>>), dim3(grid), dim3(kBlock), lds_bytes, s, P, fp, cp, plan, T, spill, n);
+      if (fp.scan.n_cols <= 2) hipLaunchKernelGGL((k_hash_agg<KW, PlanPolicyN<2, 4, kPlanW4 | kPlanNulls>>), dim3(grid), dim3(kBlock), lds_bytes, s, P, fp, cp, plan, T, spill, n);
+      else hipLaunchKernelGGL((k_hash_agg<KW, PlanPolicyN<4, 2, kPlanW4 | kPlanNulls>>), dim3(grid), dim3(kBlock), lds_bytes, s, P, fp, cp, plan, T, spill, n);
       return hipGetLastError();
     }
   }

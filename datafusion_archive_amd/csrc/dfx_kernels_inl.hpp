@@ -390,7 +390,7 @@ struct InterpPolicy {
   static DEV uint8_t acc_kind(const DevTable& T, int a) { return T.acc_kind[a]; }
   static DEV uint8_t xform(const DevTable& T, int a) { return T.val_xform[a]; }
   static DEV void eval(const DevProgram& P, const DevFastPlan&, const COLV& cur, uint32_t curv, u64x16& reg,
-                       uint32_t& rv, bool inb, uint32_t& err) {
+                       uint32_t& rv, bool inb, uint32_t& err, const PREP& = PREP()) {
     COLV c = cur;
     uint32_t cvv = curv;
     run_program(P, c, reg, cvv, rv, inb, err);
@@ -469,7 +469,7 @@ struct FastPolicy {
   static DEV uint8_t acc_kind(const DevTable& T, int a) { return T.acc_kind[a]; }
   static DEV uint8_t xform(const DevTable& T, int a) { return T.val_xform[a]; }
   static DEV void eval(const DevProgram&, const DevFastPlan&, const COLV&, uint32_t, u64x16&, uint32_t&, bool,
-                       uint32_t&) {}
+                       uint32_t&, const PREP& = PREP()) {}
   static DEV bool pass(const DevProgram&, const DevFastPlan& F, uint8_t, const COLV& cur, uint32_t, const u64x16&,
                        uint32_t, const PREP& = PREP()) {
     uint64_t ok = ~0ull;
@@ -580,7 +580,7 @@ struct StaticPolicy {
   static DEV uint8_t acc_kind(const DevTable&, int a) { return SIG::acc(a); }
   static DEV uint8_t xform(const DevTable&, int a) { return SIG::xf(a); }
   static DEV void eval(const DevProgram&, const DevFastPlan&, const COLV&, uint32_t, u64x16&, uint32_t&, bool,
-                       uint32_t&) {}
+                       uint32_t&, const PREP& = PREP()) {}
   static DEV bool pass(const DevProgram&, const DevFastPlan& F, uint8_t, const COLV& cur, uint32_t, const u64x16&,
                        uint32_t, const PREP& = PREP()) {
     uint64_t ok = ~0ull;
@@ -697,10 +697,12 @@ DEV uint32_t plan_word(uint32_t s) {
 }
 DEV uint64_t plan_word64(uint64_t s) { return (uint64_t)plan_word((uint32_t)s) | ((uint64_t)plan_word((uint32_t)(s >> 32)) << 32); }
 
-template <int NCOL, bool GEN>
+template <int NCOL, bool NULLS>
 struct PlanBank {
-  uint64_t v[NCOL];             // the aligned 8 bytes that hold the row's element of every plan column
-  uint32_t vb[GEN ? NCOL : 1];  // GEN: the validity byte that holds the row's bit
+  uint64_t v[NCOL];               // the aligned 8 bytes that hold the row's element of every plan column
+  uint32_t vb[NULLS ? NCOL : 1];  // NULLS: validity bytes -- the row's own byte (per-row loads), or lane j = byte j of the TRIP's
+                                  // bitmap slice (trip loads: one load per column and trip, every row group picks its byte
+                                  // with ds_bpermute)
   DEV uint64_t operator[](int c) const { return v[c]; }
 };
 
@@ -714,26 +716,38 @@ DEV uint64_t plan_sel(const u64x16& reg, uint32_t slot) {  // slot is wave-unifo
 }
 
 // NCOL: plan column slots loaded per row (slots past the plan's n_cols repeat slot 0: a cache hit, no branch around a load);
-// GEN: 4-byte columns and validity bitmaps (without it every column is 8 bytes wide and null-free: no widening, no validity
-// loads); FIXED: one key in slot 0, one routed argument in slot 1 (the partitioned GROUP BY's one-value kernels).
-template <int NCOL, int U_, bool GEN, bool FIXED>
+// GENK bit 0 (W4): 4-byte columns (read as the aligned 8 bytes that hold the element, widened afterwards), bit 1 (NULLS):
+// validity bitmaps (without either every column is 8 bytes wide and null-free: no widening, no validity loads);
+// FIXED: one key in slot 0, one routed argument in slot 1 (the partitioned GROUP BY's one-value kernels).
+constexpr int kPlanW4 = 1, kPlanNulls = 2;
+template <int NCOL, int U_, int GENK, bool FIXED>
 struct PlanPolicy {
+  static constexpr bool W4 = (GENK & kPlanW4) != 0, NULLS = (GENK & kPlanNulls) != 0;
   static constexpr bool kIsStatic = false;
   static constexpr bool kHasTripLoad = true;
   static constexpr int kPredTerms = -1;
   static constexpr int U = U_;
   static constexpr int kStaticNa = FIXED ? 1 : 0;
-  typedef PlanBank<NCOL, GEN> COLV;
+  static_assert(U_ * 8 + 1 <= 64, "one lane per validity byte of a trip");
+  typedef PlanBank<NCOL, NULLS> COLV;
   // The terms' plan words, one copy per lane (see plan_word): everything a term needs is a vector operand, the predicate is
   // evaluated without one scalar instruction besides the `t < np` guards.  Five registers per term: the range, and one word
   // of flags that v_bfe takes apart per use (a register per flag cost the ring kernels their 128-register budget):
   //   bit 0  image: negative values are complemented (f64)       bit 1  image: the sign bit is flipped (f64, i64)
   //   bit 2  complement the range test (NotEq, impossible terms) bit 3, 4  the term's column slot
   //   bit 5  the term's value for a null column value
+  // ... and what the columns need, as per-LANE constants (the row groups of a trip start at multiples of 64 rows, so a lane's
+  // half of an aligned pair, its validity bit and its byte of the trip's bitmap slice never change): widening and validity are
+  // vector selects, no column word is decoded inside the loop.
   struct PREP {
     uint64_t nlo[kPlanTerms];   // -lo
     uint64_t span[kPlanTerms];
     uint32_t flags[kPlanTerms];
+    uint32_t hi_half[W4 ? NCOL : 1];  // W4: all ones where this lane's 4-byte element is the HIGH word of its aligned pair
+    uint32_t is4[W4 ? NCOL : 1];      //     all ones: a 4-byte column
+    uint32_t sext[W4 ? NCOL : 1];     //     all ones: ... of signed integers
+    uint32_t vshift[NULLS ? NCOL : 1];  // NULLS: (lane + bit_offset) & 7: the row's bit inside its validity byte
+    uint32_t vlane[NULLS ? NCOL : 1];   //        ((lane + bit_offset) >> 3) * 4: ds_bpermute address of the row's byte in group 0 of a trip
   };
   static DEV void prepare(const DevFastPlan& F, PREP& W) {
 #pragma unroll
@@ -743,6 +757,24 @@ struct PlanPolicy {
       W.span[t] = plan_word64(T.span);
       W.flags[t] = plan_word((T.a != 0ull ? 1u : 0u) | ((T.b >> 63) ? 2u : 0u) | (T.inv ? 4u : 0u) | ((T.col & 3u) << 3) | (T.if_null ? 32u : 0u));
     }
+    const uint32_t lane = (uint32_t)lane_id();
+#pragma unroll
+    for (int c = 0; c < NCOL; ++c) {
+      const uint32_t meta = F.scan.col_meta[c];
+      if constexpr (W4) {
+        const bool four = (meta & 15u) == 2u;
+        W.is4[c] = plan_word(four ? 0xFFFFFFFFu : 0u);
+        W.sext[c] = plan_word((four && ((meta >> 8) & 3u) == PX_SEXT32) ? 0xFFFFFFFFu : 0u);
+        W.hi_half[c] = (four && ((lane + ((meta >> 4) & 1u)) & 1u)) ? 0xFFFFFFFFu : 0u;
+      }
+      if constexpr (NULLS) {
+        const uint32_t at = lane + ((meta >> 16) & 7u);
+        W.vshift[c] = at & 7u;
+        W.vlane[c] = (at >> 3) << 2;
+      }
+    }
+    if constexpr (!W4) W.hi_half[0] = W.is4[0] = W.sext[0] = 0;
+    if constexpr (!NULLS) W.vshift[0] = W.vlane[0] = 0;
   }
   static DEV int na(const DevTable& T) { return FIXED ? 1 : T.na; }
   static DEV uint8_t acc_kind(const DevTable& T, int a) { return T.acc_kind[a]; }
@@ -751,23 +783,25 @@ struct PlanPolicy {
   // C is the plan's own binding (bind_scan_plan): values = the column base rounded down to 8 bytes, validity = the byte
   // that holds row 0's bit (or the block of 0xFF bytes), bit_offset = the column word (plan_col_meta)
   static DEV void load(const DevProgram&, const DevColumns& C, int64_t row, bool inb, COLV& col, uint32_t& cv) {
-    cv = 0xFFFFFFFFu;
+    cv = 0xFFFFFFFFu;  // (vb holds every row's own byte)
     const uint64_t r = inb ? (uint64_t)row : 0ull;
+    if constexpr (!NULLS) col.vb[0] = 0;
 #pragma unroll
     for (int c = 0; c < NCOL; ++c) {
-      if constexpr (GEN) {
-        const uint32_t meta = (uint32_t)C.c[c].bit_offset;
+      const uint32_t meta = (uint32_t)C.c[c].bit_offset;
+      if constexpr (W4) {
         const uint64_t off = ((r + ((meta >> 4) & 1u)) << (meta & 15u)) & ~7ull;
         col.v[c] = __builtin_nontemporal_load((const uint64_t*)((const uint8_t*)C.c[c].values + off));
-        col.vb[c] = (uint32_t)C.c[c].validity[(r + ((meta >> 16) & 7u)) >> 3];
       } else {
         col.v[c] = __builtin_nontemporal_load((const uint64_t*)C.c[c].values + r);
       }
+      if constexpr (NULLS) col.vb[c] = (uint32_t)C.c[c].validity[((r + ((meta >> 16) & 7u)) >> 3) & (0ull - (uint64_t)((meta >> 20) & 1u))];
     }
-    if constexpr (!GEN) col.vb[0] = 0;
   }
   // one trip of U row groups from group w0: a scalar base per column, 32-bit lane offsets clamped to the batch's last row
-  // (StaticPolicy::load_trip), every load unconditional
+  // (StaticPolicy::load_trip), every load unconditional.  Validity: ONE byte load per column and trip -- lane j takes byte j
+  // of the trip's slice of the bitmap (U x 8 + 1 bytes at most) -- instead of one per row group: vector-memory instructions,
+  // not bytes, are what a second load per group costs.  cv[u] = u tells eval which rows of the slice are its own.
   static DEV void load_trip(const DevColumns& C, int64_t w0, bool active, int64_t n, int lane, COLV (&col)[U], uint32_t (&cv)[U]) {
     const int64_t r0 = active ? w0 * 64 : 0;
     const int64_t left = n - r0;
@@ -775,22 +809,20 @@ struct PlanPolicy {
     const uint32_t last = none ? 0u : (uint32_t)((left < (int64_t)U * 64 ? left : (int64_t)U * 64) - 1);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      cv[u] = 0xFFFFFFFFu;
-      if constexpr (!GEN) col[u].vb[0] = 0;
+      cv[u] = (uint32_t)u;
+      if constexpr (!NULLS) col[u].vb[0] = 0;
     }
 #pragma unroll
     for (int c = 0; c < NCOL; ++c) {
-      if constexpr (GEN) {
-        const uint32_t meta = (uint32_t)C.c[c].bit_offset;
-        const uint32_t shift = meta & 15u, delta = (meta >> 4) & 1u, vbit0 = (meta >> 16) & 7u;
+      const uint32_t meta = (uint32_t)C.c[c].bit_offset;
+      if constexpr (W4) {
+        const uint32_t shift = meta & 15u, delta = (meta >> 4) & 1u;
         const uint8_t* p = (const uint8_t*)C.c[c].values + (none ? 0ull : ((uint64_t)r0 << shift));  // r0 is a multiple of 64: still 8-byte aligned
-        const uint8_t* pv = C.c[c].validity + (none ? 0ull : ((uint64_t)r0 >> 3));
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           const uint32_t i = (uint32_t)(u * 64 + lane);
           const uint32_t ic = i < last ? i : last;
           col[u].v[c] = __builtin_nontemporal_load((const uint64_t*)(p + (((ic + delta) << shift) & ~7u)));
-          col[u].vb[c] = (uint32_t)pv[(ic + vbit0) >> 3];
         }
       } else {
         const uint64_t* p = (const uint64_t*)C.c[c].values + (none ? 0 : r0);
@@ -800,35 +832,50 @@ struct PlanPolicy {
           col[u].v[c] = __builtin_nontemporal_load(p + (i < last ? i : last));
         }
       }
+      if constexpr (NULLS) {
+        const uint32_t vbit0 = (meta >> 16) & 7u;
+        const uint32_t vmask = 0u - ((meta >> 20) & 1u);  // no bitmap: byte 0 of the ones block for every lane
+        const uint8_t* pv = C.c[c].validity + ((none || vmask == 0u) ? 0ull : ((uint64_t)r0 >> 3));
+        const uint32_t last_byte = (last + vbit0) >> 3;
+        const uint32_t j = (uint32_t)lane < last_byte ? (uint32_t)lane : last_byte;
+        const uint32_t bytes = (uint32_t)pv[j & vmask];
+#pragma unroll
+        for (int u = 0; u < U; ++u) col[u].vb[c] = bytes;
+      }
     }
   }
-  // widened values into reg[0 .. NCOL), validity bits into rv (bit c = slot c)
-  static DEV void eval(const DevProgram&, const DevFastPlan& F, const COLV& cur, uint32_t, u64x16& reg, uint32_t& rv, bool,
-                       uint32_t&) {
+  // widened values into reg[0 .. NCOL), validity bits into rv (bit c = slot c).  curv: the row group's index inside its trip
+  // (load_trip), or ~0 (per-row loads).  Kernels that prepare() pass W; without it (never in the scan loops) the column words
+  // are decoded here.
+  static DEV void eval(const DevProgram& P, const DevFastPlan& F, const COLV& cur, uint32_t curv, u64x16& reg, uint32_t& rv, bool inb,
+                       uint32_t& err) {
+    PREP W;
+    prepare(F, W);
+    eval(P, F, cur, curv, reg, rv, inb, err, W);
+  }
+  static DEV void eval(const DevProgram&, const DevFastPlan& F, const COLV& cur, uint32_t curv, u64x16& reg, uint32_t& rv, bool,
+                       uint32_t&, const PREP& W) {
     rv = 0xFFFFFFFFu;
-    if constexpr (!GEN) {
+    uint32_t valid = 0;
 #pragma unroll
-      for (int c = 0; c < NCOL; ++c) reg[c] = cur.v[c];
-    } else {
-      const uint32_t lane = (uint32_t)lane_id();
-      uint32_t valid = 0;
-#pragma unroll
-      for (int c = 0; c < NCOL; ++c) {
-        const uint32_t meta = F.scan.col_meta[c];  // (wave-uniform)
-        uint64_t x = cur.v[c];
-        if ((meta & 15u) == 2u) {  // a 4-byte value: the half of the aligned pair this lane's row lives in
-          const bool odd = ((lane + ((meta >> 4) & 1u)) & 1u) != 0u;
-          const uint32_t w = odd ? (uint32_t)(x >> 32) : (uint32_t)x;
-          const uint32_t ext = (meta >> 8) & 3u;
-          if (ext == PX_F32) x = f64_bits((double)__uint_as_float(w));  // exact
-          else if (ext == PX_SEXT32) x = (uint64_t)(int64_t)(int32_t)w;
-          else x = (uint64_t)w;
-        }
-        reg[c] = x;
-        valid |= ((cur.vb[c] >> ((lane + ((meta >> 16) & 7u)) & 7u)) & 1u) << c;
+    for (int c = 0; c < NCOL; ++c) {
+      uint64_t x = cur.v[c];
+      if constexpr (W4) {
+        const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+        const uint32_t w = (hi & W.hi_half[c]) | (lo & ~W.hi_half[c]);  // (an 8-byte column: hi_half = 0, w = lo)
+        const uint32_t xh = (hi & ~W.is4[c]) | ((uint32_t)((int32_t)w >> 31) & W.sext[c]);
+        x = ((uint64_t)xh << 32) | w;
+        if (((F.scan.col_meta[c] >> 8) & 3u) == PX_F32) x = f64_bits((double)__uint_as_float(w));  // (wave-uniform, rare; exact)
       }
-      rv = valid;
+      if constexpr (NULLS) {
+        uint32_t byte = cur.vb[c];
+        if (curv != 0xFFFFFFFFu)  // the trip's slice: this row's byte sits in lane (group x 64 + lane + bit_offset) / 8
+          byte = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(W.vlane[c] + (curv << 5)), (int)byte);
+        valid |= ((byte >> W.vshift[c]) & 1u) << c;
+      }
+      reg[c] = x;
     }
+    if constexpr (NULLS) rv = valid;
   }
   // value of the term's column: a bitwise select by the slot's bits (vector masks: no scalar compare, no SGPR pair per term)
   static DEV uint64_t term_value(const u64x16& reg, uint32_t flags) {
@@ -857,7 +904,7 @@ struct PlanPolicy {
         const uint32_t img_hi = hi ^ (neg & 0x7FFFFFFFu) ^ ((f << 30) & 0x80000000u);
         const uint64_t img = ((uint64_t)img_hi << 32) | ((uint32_t)x ^ neg);
         uint32_t r = ((img + W.nlo[t]) <= W.span[t] ? 1u : 0u) ^ ((f >> 2) & 1u);
-        if constexpr (GEN) r = ((rv >> ((f >> 3) & 3u)) & 1u) ? r : ((f >> 5) & 1u);
+        if constexpr (NULLS) r = ((rv >> ((f >> 3) & 3u)) & 1u) ? r : ((f >> 5) & 1u);
         ok &= r;
       }
     }
@@ -880,7 +927,7 @@ struct PlanPolicy {
                       uint64_t& v, bool& valid) {
     if constexpr (FIXED) {
       v = reg[NCOL > 1 ? 1 : 0];
-      valid = (GEN && F.scan.count_valid) ? ((rv >> 1) & 1u) != 0u : true;
+      valid = (NULLS && F.scan.count_valid) ? ((rv >> 1) & 1u) != 0u : true;
     } else {
       v = 0;
       valid = true;
@@ -889,14 +936,14 @@ struct PlanPolicy {
         if (j == a) {
           const uint32_t slot = F.scan.argslot[j];
           v = plan_sel<NCOL>(reg, slot);
-          if (GEN && F.scan.count_valid) valid = ((rv >> slot) & 1u) != 0u;
+          if (NULLS && F.scan.count_valid) valid = ((rv >> slot) & 1u) != 0u;
         }
       }
     }
   }
 };
-template <int NCOL, int U, bool GEN> using PlanPolicyN = PlanPolicy<NCOL, U, GEN, false>;  // any keys / arguments
-template <int NCOL, int U, bool GEN> using PlanPolicy1 = PlanPolicy<NCOL, U, GEN, true>;   // key in slot 0, one routed value in slot 1
+template <int NCOL, int U, int GENK> using PlanPolicyN = PlanPolicy<NCOL, U, GENK, false>;  // any keys / arguments
+template <int NCOL, int U, int GENK> using PlanPolicy1 = PlanPolicy<NCOL, U, GENK, true>;   // key in slot 0, one routed value in slot 1
 
 // the column loads of one trip of U row groups starting at group w0 (wave-uniform); `active` false: nothing is needed (the
 // software pipeline's prefetch past the end), the loads still happen (row 0) so that their count stays fixed

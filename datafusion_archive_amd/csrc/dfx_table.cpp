@@ -317,6 +317,7 @@ int32_t dfx_table_from_stream(struct ArrowArrayStream* input, dfx_table** out, c
   });
 }
 
+static_assert(dfx::kSynthNullStream == DFX_SYNTH_NULL_STREAM, "device and header agree on the validity stream");
 int32_t dfx_table_synth(const dfx_synth_column* cols, int32_t n_cols, uint64_t seed, int64_t row_begin, int64_t n_rows,
                         dfx_table** out, char* err, size_t errlen) {
   return c_abi_guard(err, errlen, [&]() -> int32_t {

@@ -413,3 +413,87 @@ def limit_batches(batches: Sequence[pa.RecordBatch], limit: int) -> List[pa.Reco
         out.append(b.slice(0, min(left, b.num_rows)))
         left -= out[-1].num_rows
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# exact ("truth") group sums of doubles, and the tolerance every Float64 SUM is held to
+# ---------------------------------------------------------------------------------------------
+class ExactGroupSums:
+    """Correctly rounded EXACT per-group sums of non-negative doubles, accumulated slice by slice in integer arithmetic.
+
+    Every value must be a multiple of 2^-scale and below 2^(78 - scale) (the synthetic columns are: uniform doubles on a
+    2^-53 grid, products of bounded factors).  v * 2^scale is split into four 26-bit limbs; numpy.bincount adds a limb of
+    every row to its group in float64 -- exact while a sum stays below 2^53, i.e. for fewer than 2^27 rows per group --
+    and the limbs are recombined as Python integers at the end: truth = round_to_nearest(sum / 2^scale), one rounding."""
+
+    def __init__(self, n_groups: int, scale: int = 53):
+        self.n_groups, self.scale = int(n_groups), int(scale)
+        self.limbs = [np.zeros(self.n_groups, dtype=np.float64) for _ in range(4)]
+        self.count = np.zeros(self.n_groups, dtype=np.int64)
+
+    def add(self, group_ids: np.ndarray, values: np.ndarray) -> None:
+        g = np.asarray(group_ids, dtype=np.int64)
+        v = np.asarray(values, dtype=np.float64)
+        if v.size == 0:
+            return
+        assert np.all(v >= 0.0) and np.all(np.isfinite(v)), "ExactGroupSums: non-negative finite values only"
+        m, e = np.frexp(v)                      # v = m * 2^e, m in [0.5, 1) (0 for v == 0)
+        big = (m * 9007199254740992.0).astype(np.int64)   # 53-bit integer mantissa, exact
+        shift = e.astype(np.int64) - 53 + self.scale        # v * 2^scale = big << shift
+        shift = np.where(big == 0, 0, shift)
+        assert shift.max() <= 25, f"ExactGroupSums: value above the fixed-point window (shift {shift.max()})"
+        down = np.maximum(-shift, 0)             # small values: the mantissa's low bits must be zeros (a multiple of 2^-scale)
+        assert down.max() <= 62 and np.all((big & ((np.int64(1) << down) - 1)) == 0), "ExactGroupSums: a value is not a multiple of 2^-scale"
+        big = big >> down
+        up = np.maximum(shift, 0)
+        hi, lo = big >> 26, big & ((1 << 26) - 1)
+        a, b = hi << up, lo << up                # value * 2^scale = a * 2^26 + b, both below 2^52
+        for k, part in enumerate((b & ((1 << 26) - 1), b >> 26, a & ((1 << 26) - 1), a >> 26)):
+            self.limbs[k] += np.bincount(g, weights=part.astype(np.float64), minlength=self.n_groups)
+        self.count += np.bincount(g, minlength=self.n_groups)
+        assert self.count.max() < (1 << 27), "ExactGroupSums: too many rows in one group for exact float64 limb sums"
+
+    def result(self) -> np.ndarray:
+        """float64 array: the correctly rounded exact sum of every group"""
+        l0, l1, l2, l3 = (x.astype(np.int64) for x in self.limbs)
+        out = np.empty(self.n_groups, dtype=np.float64)
+        den = 1 << self.scale
+        for i in range(self.n_groups):
+            total = int(l0[i]) + (int(l1[i]) << 26) + (int(l2[i]) << 26) + (int(l3[i]) << 52)
+            out[i] = total / den  # int / int true division: correctly rounded
+        return out
+
+
+def check_float_sums(got: np.ndarray, ref: np.ndarray, n: np.ndarray, abs_sum: np.ndarray, truth: Optional[np.ndarray] = None, what: str = "") -> dict:
+    """The tolerance a Float64 SUM of the product is held to, per group of n rows:
+      proven     |got - ref| <= n * eps * sum|v|      both are sums of the same n terms in different orders (eps = 2^-52);
+      empirical  |got - ref| <= 64 * sqrt(n) ULP(ref) rounding errors of a sequential sum behave like a random walk: the
+                 reference's own distance from the exact sum is ~0.3 sqrt(n) ULP, the product's (tree / per-lane partial
+                 sums) far smaller.  64 sqrt(n) is 150 x what is observed and n / (64 sqrt(n)) tighter than the proven bound;
+      vs truth   |got - truth| <= (sqrt(n) + 8) ULP   when the exact sums are known (ExactGroupSums): the product must not be
+                 further from the exact sum than a sequential sum typically is.
+    Raises AssertionError naming the first offending group; returns the observed maxima (in ULP and in sqrt(n) units)."""
+    got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    n = np.asarray(n, dtype=np.float64)
+    eps = 2.0 ** -52
+    err = np.abs(got - ref)
+    ulp = np.spacing(np.abs(ref))
+    proven = n * eps * np.asarray(abs_sum, dtype=np.float64)
+    bad = np.nonzero(err > proven)[0]
+    assert bad.size == 0, f"{what}: {bad.size} groups outside n * eps * sum|v|, e.g. group {bad[0]}: got {got[bad[0]]!r} reference {ref[bad[0]]!r}"
+    emp = 64.0 * np.sqrt(n) * ulp
+    bad = np.nonzero(err > emp)[0]
+    assert bad.size == 0, (f"{what}: {bad.size} groups further than 64 sqrt(n) ULP from the reference's sum, e.g. group {bad[0]} ({int(n[bad[0]])} rows): "
+                           f"got {got[bad[0]]!r} reference {ref[bad[0]]!r} = {err[bad[0]] / ulp[bad[0]]:.0f} ULP")
+    out = {"max_ulp_vs_reference": float((err / ulp).max()) if err.size else 0.0,
+           "max_over_sqrt_n": float((err / ulp / np.sqrt(np.maximum(n, 1.0))).max()) if err.size else 0.0}
+    if truth is not None:
+        truth = np.asarray(truth, dtype=np.float64)
+        tulp = np.spacing(np.abs(truth))
+        terr = np.abs(got - truth)
+        bad = np.nonzero(terr > (np.sqrt(n) + 8.0) * tulp)[0]
+        assert bad.size == 0, (f"{what}: {bad.size} groups further than (sqrt(n) + 8) ULP from the EXACT sum, e.g. group {bad[0]} ({int(n[bad[0]])} rows): "
+                               f"got {got[bad[0]]!r} exact {truth[bad[0]]!r} = {terr[bad[0]] / tulp[bad[0]]:.0f} ULP")
+        out["max_ulp_vs_exact"] = float((terr / tulp).max()) if terr.size else 0.0
+        out["reference_max_ulp_vs_exact"] = float((np.abs(ref - truth) / tulp).max()) if terr.size else 0.0
+    return out
