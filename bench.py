@@ -724,7 +724,10 @@ def main():
                                    + ("" if world == 1 else f" (BASELINE config 4: {total_rows} rows over {world} GPUs)"),
                        "rows_per_gpu": n_rows, "rows_total": total_rows, "batch_rows": args.batch_rows,
                        "algorithmic_bytes_per_row": 16, "parallelism": f"rows range-partitioned x{world}, "
-                       "group partials all-to-all" if world > 1 else "single GPU", "exchange": exchange_mode},
+                       "group partials all-to-all" if world > 1 else "single GPU", "exchange": exchange_mode,
+                       # the ranks RCCL itself reports for the library's communicator (ncclCommCount): N means the exchange ran
+                       # over RCCL between N ranks; null: no library communicator (one GPU, or the host-driven fallback)
+                       "rccl_ranks": (comm.ranks() if comm is not None else None)},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "extra": extra,
         }
         print(json.dumps(line), flush=True)

@@ -73,7 +73,7 @@ EXPORTED_SYMBOLS = [
     "dfx_table_column_device_ptr", "dfx_table_scan_new", "dfx_table_free", "dfx_csv_datasource_new",
     "dfx_sort_relation_new", "dfx_limit_relation_new",
     "dfx_aggregate_partial_build", "dfx_aggregate_partial_export", "dfx_aggregate_partial_import",
-    "dfx_comm_unique_id", "dfx_comm_init", "dfx_comm_destroy", "dfx_aggregate_exchange",
+    "dfx_comm_unique_id", "dfx_comm_init", "dfx_comm_destroy", "dfx_comm_ranks", "dfx_aggregate_exchange",
     "dfx_profile_enable", "dfx_profile_reset", "dfx_profile_count", "dfx_profile_get", "dfx_set_option",
     "dfx_counter_get", "dfx_counter_reset", "dfx_relation_explain", "dfx_relation_drain_device", "dfx_filter_debug_mask",
     "dfx_debug_group_hash", "dfx_debug_unhash32", "dfx_debug_plan_term",
@@ -161,6 +161,8 @@ def lib() -> ctypes.CDLL:
     L.dfx_comm_init.argtypes = [ctypes.c_char_p, ctypes.c_int32, ctypes.c_int32, P(ctypes.c_void_p)] + c_err
     L.dfx_comm_destroy.argtypes = [ctypes.c_void_p]
     L.dfx_comm_destroy.restype = None
+    L.dfx_comm_ranks.argtypes = [ctypes.c_void_p]
+    L.dfx_comm_ranks.restype = ctypes.c_int32
     L.dfx_aggregate_exchange.argtypes = [P(ArrowArrayStream), ctypes.c_void_p, P(ctypes.c_int64)] + c_err
     L.dfx_profile_enable.argtypes = [ctypes.c_int32]
     L.dfx_profile_get.argtypes = [ctypes.c_int32, ctypes.c_char_p, ctypes.c_size_t, P(ctypes.c_int64),

@@ -33,6 +33,7 @@ struct Rccl {
   decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
   decltype(&ncclCommInitRank) CommInitRank = nullptr;
   decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclCommCount) CommCount = nullptr;
   decltype(&ncclGroupStart) GroupStart = nullptr;
   decltype(&ncclGroupEnd) GroupEnd = nullptr;
   decltype(&ncclSend) Send = nullptr;
@@ -66,6 +67,7 @@ Rccl& rccl() {
     DFX_SYM(GetUniqueId, "ncclGetUniqueId")
     DFX_SYM(CommInitRank, "ncclCommInitRank")
     DFX_SYM(CommDestroy, "ncclCommDestroy")
+    DFX_SYM(CommCount, "ncclCommCount")
     DFX_SYM(GroupStart, "ncclGroupStart")
     DFX_SYM(GroupEnd, "ncclGroupEnd")
     DFX_SYM(Send, "ncclSend")
@@ -95,9 +97,22 @@ struct dfx_comm {
   ncclComm_t comm = nullptr;
   int world = 1;
   int rank = 0;
+  // Device words reserved when the communicator is created: everything the ranks use to tell each other how they are --
+  // counts, failure marks, ready flags, the ungrouped state blocks -- lives here, so that no allocation can fail between a
+  // rank's decision to take part in a collective and the collective itself.
+  std::shared_ptr<void> slab;
+  uint64_t* words = nullptr;
 };
 
 namespace dfx {
+
+// slab layout (64-bit words; W = world)
+static size_t slab_flags(int) { return 0; }                                   // [2 W]  send | received: counts, marks, flags
+static size_t slab_dict_mine(int W) { return 2 * (size_t)W; }                  // [3]
+static size_t slab_dict_all(int W) { return 2 * (size_t)W + 4; }               // [3 W]
+static size_t slab_state_mine(int W) { return 5 * (size_t)W + 8; }             // [2 kMaxAggs]  (ungrouped)
+static size_t slab_state_all(int W) { return 5 * (size_t)W + 8 + 2 * kMaxAggs; }  // [2 kMaxAggs x W]
+static size_t slab_words(int W) { return slab_state_all(W) + (size_t)2 * kMaxAggs * (size_t)W + 8; }
 
 // all-to-all of `count_of(peer)` 64-bit words per peer; peer == rank is a device-to-device copy
 template <typename SendAt, typename RecvAt>
@@ -139,27 +154,70 @@ static Status all_gather_v_words(dfx_comm* c, const uint64_t* mine, const std::v
       [&](int peer, void** p, size_t* n) { *p = all + base[(size_t)peer]; *n = (size_t)sizes[(size_t)peer]; }, s);
 }
 
-constexpr uint64_t kPeerFailed = ~0ull;  // travels instead of a count: the sender hit an error, every rank gives up together
+constexpr uint64_t kPeerFailed = ~0ull;  // travels instead of a count / a flag: the sender hit an error, every rank gives up together
+
+// test hook (tests/test_gpu_exchange_world2.py): DFX_EXCHANGE_FAIL = "<rank>:<stage>" makes that rank fail locally at that stage
+static bool inject_failure(const dfx_comm* c, const char* stage) {
+  const char* e = getenv("DFX_EXCHANGE_FAIL");
+  if (!e) return false;
+  const char* colon = strchr(e, ':');
+  return colon && atoi(e) == c->rank && !strcmp(colon + 1, stage);
+}
+static Status injected(const dfx_comm* c, const char* stage) {
+  return inject_failure(c, stage) ? Status::Err(DFX_EXECUTION_ERROR, strfmt("injected failure at stage '%s' (DFX_EXCHANGE_FAIL)", stage)) : Status::OK();
+}
+
+// THE rule of this file: between its first and its last collective a rank never returns on a LOCAL failure.  It folds the
+// failure into `local`, goes on taking part in every collective with well-formed (if meaningless) messages, and all ranks
+// leave together at the next agree(): every rank tells every rank whether it is still well -- one word per peer over the
+// reserved slab -- plus a word describing what it is about to exchange (`shape`: keys, chunks, dictionaries ...), so ranks
+// whose queries differ (one of them carries a deferred set-up error, say) find out instead of waiting for each other.
+// Returns the rank's own error if it has one, else "rank r failed <what>" / "ranks disagree", else OK -- the same verdict
+// (ok or not) on every rank.  (A collective that itself fails inside RCCL is RCCL's to report: nothing to agree over.)
+static Status agree(dfx_comm* c, const Status& local, uint64_t shape, const char* what, int64_t* host_syncs, hipStream_t s) {
+  if (c->world <= 1) return local;
+  const int W = c->world;
+  const uint64_t word = local.ok() ? (1ull | (shape << 8)) : kPeerFailed;
+  std::vector<uint64_t> hf((size_t)W * 2, 0);
+  for (int r = 0; r < W; ++r) hf[(size_t)r] = word;
+  uint64_t* d = c->words + slab_flags(W);
+  DFX_HIP(hipMemcpyAsync(d, hf.data(), sizeof(uint64_t) * hf.size(), hipMemcpyHostToDevice, s));
+  DFX_RETURN_IF_ERROR(all_to_all_words(
+      c, [&](int peer, const void** p, size_t* n) { *p = d + peer; *n = 1; },
+      [&](int peer, void** p, size_t* n) { *p = d + W + peer; *n = 1; }, s));
+  DFX_HIP(hipMemcpyAsync(hf.data(), d, sizeof(uint64_t) * hf.size(), hipMemcpyDeviceToHost, s));
+  DFX_HIP(hipStreamSynchronize(s));
+  ++*host_syncs;
+  if (!local.ok()) return local;
+  for (int r = 0; r < W; ++r)
+    if (hf[(size_t)W + r] == kPeerFailed) return Status::Err(DFX_EXECUTION_ERROR, strfmt("multi-GPU exchange: rank %d failed %s", r, what));
+  for (int r = 0; r < W; ++r)
+    if (hf[(size_t)W + r] != word)
+      return Status::Err(DFX_EXECUTION_ERROR, strfmt("multi-GPU exchange: rank %d is exchanging a different query (keys / accumulator chunks / dictionaries)", r));
+  return Status::OK();
+}
 
 // Utf8 GROUP BY keys: dictionary ids are rank-local.  Every rank learns every rank's strings (sizes first, then lengths +
 // bytes), builds the SAME global dictionary on the host (rank 0's strings in id order, then rank 1's new ones, ...), rewrites
 // its key plane to global ids and installs the global dictionary for the emit.  O(distinct strings of all ranks) on the host.
-static Status globalise_dictionaries(AggregateRelation* a, dfx_comm* c, Status local, int64_t* host_syncs) {
+// Aligned on every rank: per dictionary a sizes round (carrying the failure mark), an agree() after the blob buffers were
+// allocated, the blob round, an agree() after the host-side build.  Returns the same verdict on every rank.
+static Status globalise_dictionaries(AggregateRelation* a, dfx_comm* c, int64_t* host_syncs) {
   const int world = c->world;
   hipStream_t s = ctx().stream;
+  Status local = Status::OK();
   for (int d = 0; d < a->exchange_dicts(); ++d) {
     std::vector<uint32_t> lens;
     std::vector<uint8_t> pool;
     if (local.ok()) local = a->exchange_dict_local(d, &lens, &pool);
+    if (local.ok()) local = injected(c, "dict_local");
+    if (!local.ok()) { lens.clear(); pool.clear(); }
     // blob = lens (u32, padded to words) + bytes (padded to words)
     const uint64_t len_words = ((uint64_t)lens.size() + 1) / 2, pool_words = ((uint64_t)pool.size() + 7) / 8;
-    Status st;
-    auto dsz = device_alloc(sizeof(uint64_t) * (size_t)world * 3 * 2, &st);  // mine [3], all [3 * world]
-    if (!dsz) return st;
     uint64_t hmine[3] = {local.ok() ? (uint64_t)lens.size() : kPeerFailed, (uint64_t)pool.size(), 0};
-    uint64_t* dmine = (uint64_t*)dsz.get();
-    uint64_t* dall = dmine + 3;
-    DFX_HIP(hipMemcpy(dmine, hmine, sizeof(hmine), hipMemcpyHostToDevice));
+    uint64_t* dmine = c->words + slab_dict_mine(world);
+    uint64_t* dall = c->words + slab_dict_all(world);
+    DFX_HIP(hipMemcpyAsync(dmine, hmine, sizeof(hmine), hipMemcpyHostToDevice, s));
     std::vector<uint64_t> three((size_t)world, 3);
     DFX_RETURN_IF_ERROR(all_gather_v_words(c, dmine, three, dall, s));
     std::vector<uint64_t> hall((size_t)world * 3, 0);
@@ -179,11 +237,18 @@ static Status globalise_dictionaries(AggregateRelation* a, dfx_comm* c, Status l
     std::vector<uint64_t> blob((size_t)std::max<uint64_t>(1, len_words + pool_words), 0);
     if (!lens.empty()) memcpy(blob.data(), lens.data(), sizeof(uint32_t) * lens.size());
     if (!pool.empty()) memcpy(blob.data() + len_words, pool.data(), pool.size());
+    // the blob buffers: allocated before the ranks commit themselves to the blob round
+    Status st;
     auto dblob = device_alloc(sizeof(uint64_t) * blob.size(), &st);
-    if (!dblob) return st;
-    auto dblobs = device_alloc(sizeof(uint64_t) * (size_t)std::max<uint64_t>(1, base[(size_t)world]), &st);
-    if (!dblobs) return st;
-    DFX_HIP(hipMemcpy(dblob.get(), blob.data(), sizeof(uint64_t) * blob.size(), hipMemcpyHostToDevice));
+    std::shared_ptr<void> dblobs;
+    if (dblob) dblobs = device_alloc(sizeof(uint64_t) * (size_t)std::max<uint64_t>(1, base[(size_t)world]), &st);
+    if (!dblob || !dblobs) local = st;
+    if (local.ok()) local = injected(c, "dict_blob_alloc");
+    if (local.ok()) {
+      hipError_t e = hipMemcpyAsync(dblob.get(), blob.data(), sizeof(uint64_t) * blob.size(), hipMemcpyHostToDevice, s);
+      if (e != hipSuccess) local = Status::Err(DFX_EXECUTION_ERROR, strfmt("HIP error %s in the exchange", hipGetErrorString(e)));
+    }
+    DFX_RETURN_IF_ERROR(agree(c, local, (uint64_t)d, "while it prepared its dictionary", host_syncs, s));
     DFX_RETURN_IF_ERROR(all_gather_v_words(c, (const uint64_t*)dblob.get(), sizes, (uint64_t*)dblobs.get(), s));
     std::vector<uint64_t> blobs((size_t)std::max<uint64_t>(1, base[(size_t)world]), 0);
     DFX_HIP(hipMemcpyAsync(blobs.data(), dblobs.get(), sizeof(uint64_t) * blobs.size(), hipMemcpyDeviceToHost, s));
@@ -194,13 +259,16 @@ static Status globalise_dictionaries(AggregateRelation* a, dfx_comm* c, Status l
     std::vector<uint32_t> glens;
     std::vector<uint8_t> gpool;
     std::vector<uint64_t> remap;
-    for (int r = 0; r < world; ++r) {
+    for (int r = 0; r < world && local.ok(); ++r) {
       const uint64_t n_ids = hall[(size_t)r * 3], n_bytes = hall[(size_t)r * 3 + 1];
       const uint32_t* rl = r == c->rank ? lens.data() : (const uint32_t*)(blobs.data() + base[(size_t)r]);
       const uint8_t* rp = r == c->rank ? pool.data() : (const uint8_t*)(blobs.data() + base[(size_t)r] + (n_ids + 1) / 2);
       uint64_t at = 0;
       for (uint64_t i = 0; i < n_ids; ++i) {
-        if (at + rl[i] > n_bytes) return Status::Err(DFX_INTERNAL_ERROR, "multi-GPU exchange: malformed dictionary blob");
+        if (at + rl[i] > n_bytes) {
+          local = Status::Err(DFX_INTERNAL_ERROR, "multi-GPU exchange: malformed dictionary blob");
+          break;
+        }
         std::string str((const char*)rp + at, (size_t)rl[i]);
         at += rl[i];
         auto ins = ids.emplace(std::move(str), (uint64_t)glens.size());
@@ -211,9 +279,10 @@ static Status globalise_dictionaries(AggregateRelation* a, dfx_comm* c, Status l
         if (r == c->rank) remap.push_back(ins.first->second);
       }
     }
-    DFX_RETURN_IF_ERROR(a->exchange_dict_globalise(d, glens, gpool, remap));
+    if (local.ok()) local = a->exchange_dict_globalise(d, glens, gpool, remap);
+    DFX_RETURN_IF_ERROR(agree(c, local, (uint64_t)d, "while it installed the global dictionary", host_syncs, s));
   }
-  return local;
+  return Status::OK();
 }
 
 Status AggregateRelation::exchange(dfx_comm* c, int64_t* stats) {
@@ -223,47 +292,65 @@ Status AggregateRelation::exchange(dfx_comm* c, int64_t* stats) {
   int64_t host_syncs = 0;
   if (stats) stats[0] = stats[1] = stats[2] = stats[3] = 0;
   if (is_ungrouped()) {  // one row per rank: all-gather the accumulator states, fold them with the aggregates' algebra
-    DFX_RETURN_IF_ERROR(ungrouped_state_begin());
+    Status local = ungrouped_state_begin();  // (drains the input: DivideByZero, out of memory ...)
+    if (local.ok()) local = injected(c, "drain");
     const int nw = ungrouped_state_words();
-    Status st;
-    auto all = device_alloc(sizeof(uint64_t) * (size_t)nw * (size_t)world, &st);
-    if (!all) return st;
-    for (int ch = 0; ch < exchange_chunks(); ++ch) {  // more than kMaxAggs accumulators: one state block per chunk
-      DFX_RETURN_IF_ERROR(ungrouped_select_chunk(ch));
+    const int n_chunks = exchange_chunks();
+    DFX_RETURN_IF_ERROR(agree(c, local, 0x100ull | ((uint64_t)n_chunks << 16) | ((uint64_t)nw << 24), "before the exchange", &host_syncs, s));
+    if (nw > 2 * kMaxAggs) return Status::Err(DFX_INTERNAL_ERROR, "exchange: ungrouped state wider than the communicator's slab");
+    uint64_t* all = c->words + slab_state_all(world);
+    for (int ch = 0; ch < n_chunks; ++ch) {  // more than kMaxAggs accumulators: one state block per chunk
+      if (local.ok()) local = ungrouped_select_chunk(ch);
+      if (local.ok() && ch == n_chunks - 1) local = injected(c, "merge");
+      const void* mine = ungrouped_state_device();
+      if (!local.ok() || !mine) mine = c->words + slab_state_mine(world);  // (something well-formed to send: every rank gives up at the agree() below)
       if (world > 1) {
-        DFX_NCCL(rccl().AllGather(ungrouped_state_device(), all.get(), (size_t)nw, ncclUint64, c->comm, s), "ncclAllGather");
+        DFX_NCCL(rccl().AllGather(mine, all, (size_t)nw, ncclUint64, c->comm, s), "ncclAllGather");
       } else {
-        DFX_HIP(hipMemcpyAsync(all.get(), ungrouped_state_device(), sizeof(uint64_t) * (size_t)nw, hipMemcpyDeviceToDevice, s));
+        DFX_HIP(hipMemcpyAsync(all, mine, sizeof(uint64_t) * (size_t)nw, hipMemcpyDeviceToDevice, s));
       }
       std::vector<uint64_t> host((size_t)nw * (size_t)world);
-      DFX_HIP(hipMemcpyAsync(host.data(), all.get(), sizeof(uint64_t) * host.size(), hipMemcpyDeviceToHost, s));
+      DFX_HIP(hipMemcpyAsync(host.data(), all, sizeof(uint64_t) * host.size(), hipMemcpyDeviceToHost, s));
       DFX_HIP(hipStreamSynchronize(s));
       ++host_syncs;
-      DFX_RETURN_IF_ERROR(ungrouped_state_merge(host.data(), world, c->rank));
+      if (local.ok()) local = ungrouped_state_merge(host.data(), world, c->rank);
     }
-    DFX_RETURN_IF_ERROR(ungrouped_select_chunk(0));
+    if (local.ok()) local = ungrouped_select_chunk(0);
+    DFX_RETURN_IF_ERROR(agree(c, local, 0x101ull, "while it merged the ranks' states", &host_syncs, s));
     if (stats) {
       stats[0] = stats[1] = 1;
-      stats[2] = (int64_t)(sizeof(uint64_t) * (size_t)nw * (size_t)exchange_chunks());
+      stats[2] = (int64_t)(sizeof(uint64_t) * (size_t)nw * (size_t)n_chunks);
       stats[3] = host_syncs;
     }
     return Status::OK();
   }
   // ---- grouped ----
-  // A rank that fails locally (drain error, out of memory ...) still takes part in the first all-to-all and sends
-  // kPeerFailed instead of its counts: every rank then returns an error instead of waiting for buckets that never come.
-  Status st;
-  auto counts_owner = device_alloc(sizeof(uint64_t) * (size_t)world * 2, &st);  // [0, world): send counts, [world, 2 world): received ones
-  if (!counts_owner) return st;
-  uint64_t* d_counts = (uint64_t*)counts_owner.get();
+  uint64_t* d_counts = c->words + slab_flags(world);  // [0, world): send counts, [world, 2 world): received ones
   Status local = exchange_drain();
-  if (exchange_dicts() > 0) local = globalise_dictionaries(this, c, local, &host_syncs);
-  if (local.ok()) local = exchange_count(world, d_counts);
-  if (!local.ok()) DFX_HIP(hipMemsetAsync(d_counts, 0xFF, sizeof(uint64_t) * (size_t)world, s));
-  DFX_HIP(hipMemsetAsync(d_counts + world, 0, sizeof(uint64_t) * (size_t)world, s));
-  DFX_RETURN_IF_ERROR(all_to_all_words(
-      c, [&](int peer, const void** p, size_t* n) { *p = d_counts + peer; *n = 1; },
-      [&](int peer, void** p, size_t* n) { *p = d_counts + world + peer; *n = 1; }, s));
+  if (local.ok()) local = injected(c, "drain");
+  const int n_chunks = exchange_chunks();
+  int widest = 0;
+  uint64_t shape = 0x200ull | ((uint64_t)n_chunks << 12) | ((uint64_t)exchange_dicts() << 20);
+  for (int ch = 0; ch < n_chunks; ++ch) {
+    widest = std::max(widest, exchange_chunk_words(ch));
+    shape = shape * 31 + (uint64_t)exchange_chunk_words(ch);
+  }
+  DFX_RETURN_IF_ERROR(agree(c, local, shape & 0xFFFFFFFFFFFFull, "before the exchange", &host_syncs, s));
+  if (exchange_dicts() > 0) DFX_RETURN_IF_ERROR(globalise_dictionaries(this, c, &host_syncs));
+  // counts: a rank whose count kernel cannot run sends the failure mark instead
+  local = exchange_count(world, d_counts);
+  if (local.ok()) local = injected(c, "count");
+  {
+    std::vector<uint64_t> init((size_t)world, kPeerFailed);
+    hipError_t e = hipSuccess;
+    if (!local.ok()) e = hipMemcpyAsync(d_counts, init.data(), sizeof(uint64_t) * (size_t)world, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemsetAsync(d_counts + world, 0, sizeof(uint64_t) * (size_t)world, s);
+    if (e != hipSuccess && local.ok()) local = Status::Err(DFX_EXECUTION_ERROR, strfmt("HIP error %s in the exchange", hipGetErrorString(e)));
+    if (e != hipSuccess) (void)hipStreamSynchronize(s);  // (`init` is a stack vector)
+    DFX_RETURN_IF_ERROR(all_to_all_words(
+        c, [&](int peer, const void** p, size_t* n) { *p = d_counts + peer; *n = 1; },
+        [&](int peer, void** p, size_t* n) { *p = d_counts + world + peer; *n = 1; }, s));
+  }
   std::vector<uint64_t> hc((size_t)world * 2);
   DFX_HIP(hipMemcpyAsync(hc.data(), d_counts, sizeof(uint64_t) * hc.size(), hipMemcpyDeviceToHost, s));
   DFX_HIP(hipStreamSynchronize(s));  // the ONE read-back of the exchange proper: buffer sizes
@@ -279,46 +366,35 @@ Status AggregateRelation::exchange(dfx_comm* c, int64_t* stats) {
     sbase[r + 1] = sbase[r] + hc[r];
     rbase[r + 1] = rbase[r] + hc[(size_t)world + r];
   }
-  const int n_chunks = exchange_chunks();
-  int widest = 0;
-  for (int ch = 0; ch < n_chunks; ++ch) widest = std::max(widest, exchange_chunk_words(ch));
   // every allocation of the payload rounds happens BEFORE them, and the ranks tell each other whether it worked
+  Status st;
   auto send = device_alloc(sizeof(uint64_t) * (size_t)std::max<uint64_t>(1, sbase[world] * (uint64_t)widest), &st);
   std::shared_ptr<void> recv;
-  Status ready = st;
-  if (send) recv = device_alloc(sizeof(uint64_t) * (size_t)std::max<uint64_t>(1, rbase[world] * (uint64_t)widest), &ready);
-  if (ready.ok() && send && recv) ready = exchange_import_begin(rbase[world]);
-  if (world > 1) {
-    const uint64_t flag = (ready.ok() && send && recv) ? 1ull : kPeerFailed;
-    std::vector<uint64_t> hf((size_t)world * 2, flag);
-    DFX_HIP(hipMemcpy(d_counts, hf.data(), sizeof(uint64_t) * hf.size(), hipMemcpyHostToDevice));
-    DFX_RETURN_IF_ERROR(all_to_all_words(
-        c, [&](int peer, const void** p, size_t* n) { *p = d_counts + peer; *n = 1; },
-        [&](int peer, void** p, size_t* n) { *p = d_counts + world + peer; *n = 1; }, s));
-    DFX_HIP(hipMemcpyAsync(hf.data(), d_counts, sizeof(uint64_t) * hf.size(), hipMemcpyDeviceToHost, s));
-    DFX_HIP(hipStreamSynchronize(s));
-    ++host_syncs;
-    if (!ready.ok() || !send || !recv) return ready.ok() ? Status::Err(DFX_EXECUTION_ERROR, "multi-GPU exchange: out of device memory") : ready;
-    for (int r = 0; r < world; ++r)
-      if (r != c->rank && hf[(size_t)world + r] == kPeerFailed)
-        return Status::Err(DFX_EXECUTION_ERROR, strfmt("multi-GPU exchange: rank %d could not allocate its buffers", r));
-  } else if (!ready.ok() || !send || !recv) {
-    return ready.ok() ? Status::Err(DFX_EXECUTION_ERROR, "multi-GPU exchange: out of device memory") : ready;
-  }
+  if (send) recv = device_alloc(sizeof(uint64_t) * (size_t)std::max<uint64_t>(1, rbase[world] * (uint64_t)widest), &st);
+  local = (send && recv) ? Status::OK() : st;
+  if (local.ok()) local = injected(c, "payload_alloc");
+  if (local.ok()) local = exchange_import_begin(rbase[world]);
+  DFX_RETURN_IF_ERROR(agree(c, local, 0x201ull, "while it allocated its exchange buffers", &host_syncs, s));
+  if (!local.ok()) return local;  // (world == 1: agree() is the identity)
   uint64_t* sw = (uint64_t*)send.get();
   uint64_t* rw = (uint64_t*)recv.get();
   int64_t sent_words = 0;
   for (int ch = 0; ch < n_chunks; ++ch) {  // accumulators beyond kMaxAggs: one round per chunk of planes, the same keys every time
     const uint64_t nw = (uint64_t)exchange_chunk_words(ch);
-    DFX_RETURN_IF_ERROR(exchange_export_chunk(ch, send_counts, send.get(), (int64_t)(sbase[world] * nw)));
+    // a rank whose scatter / merge kernels fail keeps sending and receiving what was agreed (its peers merge rows they will
+    // throw away): the agree() behind the rounds ends the exchange on every rank
+    if (local.ok()) local = exchange_export_chunk(ch, send_counts, send.get(), (int64_t)(sbase[world] * nw));
+    if (local.ok() && ch == n_chunks - 1) local = injected(c, "export");
     DFX_RETURN_IF_ERROR(all_to_all_words(
         c, [&](int peer, const void** p, size_t* n) { *p = sw + sbase[peer] * nw; *n = (size_t)(hc[peer] * nw); },
         [&](int peer, void** p, size_t* n) { *p = rw + rbase[peer] * nw; *n = (size_t)(hc[(size_t)world + peer] * nw); }, s));
-    DFX_RETURN_IF_ERROR(exchange_import_chunk(ch, recv.get(), recv_counts.data(), world));  // merges on the same stream
+    if (local.ok()) local = exchange_import_chunk(ch, recv.get(), recv_counts.data(), world);  // merges on the same stream
     sent_words += (int64_t)(sbase[world] * nw);
   }
-  DFX_RETURN_IF_ERROR(exchange_import_finish());  // the one synchronisation of the payload rounds
+  if (local.ok()) local = exchange_import_finish();  // the one synchronisation of the payload rounds
   ++host_syncs;
+  DFX_RETURN_IF_ERROR(agree(c, local, 0x202ull, "during the payload rounds", &host_syncs, s));
+  if (!local.ok()) return local;
   if (stats) {
     stats[0] = (int64_t)sbase[world];
     stats[1] = (int64_t)rbase[world];
@@ -364,11 +440,25 @@ int32_t dfx_comm_init(const uint8_t* id, int32_t world, int32_t rank, dfx_comm**
       hipError_t e = hipSetDevice(ctx().device);
       if (e != hipSuccess) return to_c(Status::Err(DFX_EXECUTION_ERROR, strfmt("hipSetDevice(%d): %s", ctx().device, hipGetErrorString(e))), err, errlen);
     }
+    // the slab first: a rank that cannot have it must not enter the collective communicator set-up half-way
+    c->slab = device_alloc(sizeof(uint64_t) * slab_words(world), &st);
+    if (!c->slab) return to_c(st, err, errlen);
+    c->words = (uint64_t*)c->slab.get();
+    {
+      hipError_t e = hipMemset(c->words, 0, sizeof(uint64_t) * slab_words(world));
+      if (e != hipSuccess) return to_c(Status::Err(DFX_EXECUTION_ERROR, strfmt("hipMemset: %s", hipGetErrorString(e))), err, errlen);
+    }
     st = nccl_status(r.CommInitRank(&c->comm, world, u, rank), "ncclCommInitRank");
     if (!st.ok()) return to_c(st, err, errlen);
     *out = c.release();
     return DFX_OK;
   });
+}
+
+int32_t dfx_comm_ranks(const dfx_comm* c) {
+  if (!c || !c->comm || !rccl().CommCount) return -1;
+  int n = -1;
+  return rccl().CommCount(c->comm, &n) == ncclSuccess ? (int32_t)n : -1;
 }
 
 void dfx_comm_destroy(dfx_comm* c) {

@@ -377,6 +377,10 @@ class Communicator:
         _check(L.dfx_aggregate_exchange(ctypes.byref(agg._live_stream()), self._h, stats, err, 1024), err)
         return {"sent_groups": stats[0], "received_groups": stats[1], "sent_bytes": stats[2], "host_syncs": stats[3]}
 
+    def ranks(self) -> int:
+        """ncclCommCount of the library's communicator: the ranks RCCL itself sees"""
+        return int(_ffi.lib().dfx_comm_ranks(self._h))
+
     def close(self) -> None:
         if getattr(self, "_h", None) and self._h.value:
             _ffi.lib().dfx_comm_destroy(self._h)

@@ -363,6 +363,9 @@ typedef struct dfx_comm dfx_comm;
 int32_t dfx_comm_unique_id(uint8_t* id /* [DFX_COMM_ID_BYTES] */, char* err, size_t errlen);
 int32_t dfx_comm_init(const uint8_t* id, int32_t world, int32_t rank, dfx_comm** out, char* err, size_t errlen);
 void dfx_comm_destroy(dfx_comm* comm);
+/* The number of ranks the communicator ITSELF reports (ncclCommCount): what RCCL saw, not what the host asked for.
+ * -1: not a communicator, or RCCL refused.  (bench.py puts it into the line's config.rccl_ranks.) */
+int32_t dfx_comm_ranks(const dfx_comm* comm);
 int32_t dfx_aggregate_exchange(struct ArrowArrayStream* agg, dfx_comm* comm, int64_t* stats, char* err, size_t errlen);
 
 /* ------------------------------------------------------------------------------------------

@@ -144,6 +144,7 @@ extern "C" {
     fn dfx_comm_unique_id(id: *mut u8, err: *mut c_char, errlen: usize) -> i32;
     fn dfx_comm_init(id: *const u8, world: i32, rank: i32, out: *mut *mut DfxComm, err: *mut c_char, errlen: usize) -> i32;
     fn dfx_comm_destroy(comm: *mut DfxComm);
+    fn dfx_comm_ranks(comm: *const DfxComm) -> i32;
     fn dfx_aggregate_exchange(agg: *mut ArrowArrayStream, comm: *mut DfxComm, stats: *mut i64, err: *mut c_char, errlen: usize) -> i32;
 }
 

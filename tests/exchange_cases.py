@@ -56,10 +56,23 @@ CASES = {
 CASES["peer_failure"] = (1000, None, [Column(0)], [agg("sum", BinaryExpr(Column(1), Operator.Divide, Column(2)))], {})
 
 
+# ... the same for ungrouped aggregates: round 3 returned before the all-gather, the peers waited for ever
+CASES["ungrouped_peer_failure"] = (1000, None, [], [agg("sum", BinaryExpr(Column(1), Operator.Divide, Column(2))), agg("count", Column(1), U64)], {})
+# local failures INJECTED at the later stages (DFX_EXCHANGE_FAIL = "1:<stage>", csrc/dfx_exchange.cpp: inject_failure): the
+# count kernel, the payload buffers, the last export, a dictionary's blob buffers, the ungrouped merge -- the query and the
+# data are those of a passing case
+FAILURE_STAGES = {"alloc_failure_before_counts": ("int_keys_4_aggs", "count"), "payload_alloc_failure": ("int_keys_4_aggs", "payload_alloc"),
+                  "export_failure": ("eleven_accumulators", "export"), "dict_blob_alloc_failure": ("utf8_key", "dict_blob_alloc"),
+                  "ungrouped_merge_failure": ("eleven_accumulators_ungrouped", "merge")}
+for _name, (_base, _stage) in FAILURE_STAGES.items():
+    CASES[_name] = CASES[_base]
+FAILURE_CASES = ["peer_failure", "ungrouped_peer_failure"] + list(FAILURE_STAGES)
+
+
 def batches_of_rank(case, rank):
     n_keys = CASES[case][0]
     b = _table(rank, n_keys)
-    if case == "peer_failure":
+    if case in ("peer_failure", "ungrouped_peer_failure"):
         w = np.ones(ROWS)
         if rank == 1:
             w[7] = 0.0

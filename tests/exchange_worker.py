@@ -36,7 +36,7 @@ if pred is not None:
     rel = ex.FilterRelation(rel, ex.compile_scalar_expr(None, pred, xc.SCHEMA), xc.SCHEMA)
 rel = ex.AggregateRelation(None, rel, [ex.compile_scalar_expr(None, g, xc.SCHEMA) for g in group],
                            [ex.compile_expr(None, a, xc.SCHEMA) for a in aggs])
-if case == "peer_failure":
+if case in xc.FAILURE_CASES:
     try:
         comm.exchange(rel)
         print(f"rank {rank}: NO ERROR")

@@ -129,6 +129,12 @@ ncclResult_t ncclCommDestroy(ncclComm_t comm) {
   return ncclSuccess;
 }
 
+ncclResult_t ncclCommCount(const ncclComm_t comm, int* count) {
+  if (!comm || !count) return ncclInvalidArgument;
+  *count = comm->world;
+  return ncclSuccess;
+}
+
 const char* ncclGetErrorString(ncclResult_t rc) { return rc == ncclSuccess ? "no error" : "rccl_stub: transfer failed"; }
 
 ncclResult_t ncclGroupStart() {

@@ -32,8 +32,9 @@ def _build_stub():
     return STUB_SO
 
 
-def _run_ranks(case, world, tmp_path, read_results=True):
+def _run_ranks(case, world, tmp_path, read_results=True, extra_env=None):
     env = dict(os.environ, DFX_RCCL_LIB=_build_stub(), DFX_NO_TORCH="1")
+    env.update(extra_env or {})
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "exchange_worker.py"), case, str(r), str(world), str(tmp_path)],
                               env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     outs = []
@@ -63,8 +64,32 @@ def test_a_failing_rank_ends_the_exchange_on_every_rank(tmp_path):
     assert "rank 0: error: ExecutionError" in logs[0] and "rank 1 failed before the exchange" in logs[0], logs[0]
 
 
+def test_a_failing_rank_ends_the_ungrouped_exchange_on_every_rank(tmp_path):
+    """The ungrouped form: rank 1's drain fails (DivideByZero).  Round 3 returned before the all-gather and rank 0 waited for
+    ever; now every rank first tells every rank how it is (agree(), one word per peer over the communicator's reserved slab)."""
+    _res, logs = _run_ranks("ungrouped_peer_failure", 2, tmp_path, read_results=False)
+    assert "rank 1: error: ArrowError: DivideByZero" in logs[1], logs[1]
+    assert "rank 0: error: ExecutionError" in logs[0] and "rank 1 failed before the exchange" in logs[0], logs[0]
+
+
 @pytest.mark.parametrize("world", [2, 3])
-@pytest.mark.parametrize("case", [c for c in xc.CASES if c != "peer_failure"])
+@pytest.mark.parametrize("case", list(xc.FAILURE_STAGES))
+def test_a_local_failure_at_any_stage_ends_the_exchange_on_every_rank(case, world, tmp_path):
+    """Rank 1 fails locally at a LATER stage (injected: the count kernel, the payload buffers, the last chunk's export, a
+    dictionary's blob buffers, the ungrouped merge).  It keeps taking part in every collective with well-formed messages and
+    all ranks leave together at the next agree(): nobody hangs (the run would time out), the failing rank reports its own
+    error, the others name it."""
+    if world == 3 and case not in ("alloc_failure_before_counts", "dict_blob_alloc_failure"):
+        pytest.skip("three ranks: one integer-key and one Utf8-key stage")
+    _base, stage = xc.FAILURE_STAGES[case]
+    _res, logs = _run_ranks(case, world, tmp_path, read_results=False, extra_env={"DFX_EXCHANGE_FAIL": f"1:{stage}"})
+    assert f"rank 1: error: ExecutionError" in logs[1] and f"injected failure at stage '{stage}'" in logs[1], logs[1]
+    for r in [x for x in range(world) if x != 1]:
+        assert f"rank {r}: error: ExecutionError" in logs[r] and "rank 1 failed" in logs[r], logs[r]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("case", [c for c in xc.CASES if c not in xc.FAILURE_CASES])
 def test_library_exchange_between_processes(case, world, tmp_path):
     if world == 3 and case not in ("int_keys_4_aggs", "utf8_key"):
         pytest.skip("three ranks: one integer-key and one Utf8-key case")
