@@ -70,6 +70,71 @@ def _recorded_flags(obj: str) -> str:
         return ""
 
 
+# ---- build-time guard: hand-scheduled registers of pass 2 ------------------------------------------------------------------
+# k_partition_agg_lean (csrc/dfx_k_partition.hip) issues its row loads by inline assembly into VGPRs v88..v119, which the kernel
+# withholds from the register allocator (amdgpu_num_vgpr(88)).  That is only sound while (a) the code object ALLOCATES those
+# registers (its .vgpr_count covers them: a wave that was given fewer would have its loads land in another wave's registers) and
+# (b) nothing the compiler generates touches them.  Round 2 found a silent-corruption bug of exactly this kind on the GPU;
+# build() refuses to produce a library that has the next one (tests/test_build_guards.py runs the same check).
+GUARD_SRC = "dfx_k_partition.hip"
+RESERVED_VGPRS = range(88, 120)
+
+
+def _asm_registers(operand_text: str):
+    import re
+    regs = set()
+    for m in re.finditer(r"\bv\[(\d+):(\d+)\]", operand_text):
+        regs.update(range(int(m.group(1)), int(m.group(2)) + 1))
+    for m in re.finditer(r"\bv(\d+)\b", operand_text):
+        regs.add(int(m.group(1)))
+    return regs
+
+
+def check_pass2_reserved_registers(asm: str) -> int:
+    """Raises RuntimeError naming the kernel and the instruction; returns the number of instantiations checked."""
+    import re
+    kernels = {m.group(1): m.group(2) for m in re.finditer(r"^(_ZN3dfx\d+k_partition_agg_lean\w*):.*?\n(.*?)\n\s*s_endpgm", asm, re.S | re.M)}
+    if len(kernels) < 8:
+        raise RuntimeError(f"build guard: expected every k_partition_agg_lean instantiation, found {len(kernels)}")
+    meta = {m.group(1): int(m.group(2)) for m in re.finditer(r"\.name:\s+(\S+)\n(?:(?!\.name:).*\n)*?\s+\.vgpr_count:\s+(\d+)", asm)}
+    reserved = set(RESERVED_VGPRS)
+    for k, body in kernels.items():
+        if k not in meta:
+            raise RuntimeError(f"build guard: no metadata for {k}")
+        used = max(_asm_registers(body) & reserved, default=0)  # v118 with 12-byte rows (dwordx3 loads), v119 with 16-byte rows
+        if used < 118:
+            raise RuntimeError(f"build guard: {k}: the in-flight row registers v88..v119 are gone")
+        if meta[k] <= used:
+            raise RuntimeError(f"build guard: {k}: .vgpr_count = {meta[k]} does not cover v{used} (the in-flight row registers v88..v{used}): "
+                               "a wave would be allocated fewer registers than the hand-written loads write")
+        for line in body.split("\n"):
+            ins = line.split(";")[0].strip()
+            if not ins or ins.endswith(":") or ins.startswith("."):
+                continue
+            op, _, rest = ins.partition(" ")
+            ops = [o.strip() for o in rest.split(",")]
+            if not (_asm_registers(rest) & reserved):
+                continue
+            if op in ("global_load_dwordx3", "global_load_dwordx4"):
+                ok = _asm_registers(ops[0]) <= reserved and not (_asm_registers(",".join(ops[1:])) & reserved)
+            elif op in ("v_mov_b32", "v_mov_b32_e32"):
+                ok = not (_asm_registers(ops[0]) & reserved) and _asm_registers(ops[1]) <= reserved
+            else:
+                ok = False
+            if not ok:
+                raise RuntimeError(f"build guard: {k}: compiler-generated instruction touches a reserved register: {ins}")
+    return len(kernels)
+
+
+def pass2_guard_asm(hipcc: str, out_path: str) -> str:
+    """device assembly of the pass-2 translation unit, with the flags the library is built with"""
+    flags = [f for f in CXXFLAGS if f not in ("-fPIC",)]
+    r = subprocess.run([hipcc] + flags + ["--cuda-device-only", "-S", "-o", out_path, os.path.join(CSRC, GUARD_SRC)], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("build guard: hipcc -S failed:\n" + r.stderr[-2000:])
+    return open(out_path).read()
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     os.makedirs(OBJDIR, exist_ok=True)
@@ -99,9 +164,25 @@ def build(force: bool = False, verbose: bool = False) -> str:
                 fh.write(os.environ.get("DFX_EXTRA_CXXFLAGS", ""))
         return r
 
-    if jobs:
-        with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
+    guard_obj = os.path.join(OBJDIR, os.path.splitext(GUARD_SRC)[0] + ".o")
+    guard_stamp = guard_obj + ".guard"
+    guard_due = any(cmd[-1] == guard_obj for cmd in jobs) or not os.path.exists(guard_stamp) or \
+        (os.path.exists(guard_obj) and os.path.getmtime(guard_stamp) < os.path.getmtime(guard_obj))
+
+    def guard(_unused=None):
+        n = check_pass2_reserved_registers(pass2_guard_asm(hipcc, os.path.join(OBJDIR, "dfx_k_partition.guard.s")))
+        if verbose:
+            print(f"build guard: {n} instantiations of k_partition_agg_lean keep v88..v119 to the hand-written loads", flush=True)
+
+    if jobs or guard_due:
+        with ThreadPoolExecutor(max_workers=min(8, len(jobs) + 1)) as ex:
+            guard_future = ex.submit(guard) if guard_due else None  # (beside the compile jobs: ~15 s of its own)
             list(ex.map(run, jobs))
+            if guard_future is not None:
+                guard_future.result()  # raises: no library from a translation unit that fails the guard
+        if guard_due:
+            with open(guard_stamp, "w") as fh:
+                fh.write("ok\n")
     if jobs or force or _stale(LIB, objs):
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
     return LIB

@@ -14,18 +14,6 @@ import subprocess
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "datafusion_archive_amd", "csrc", "dfx_k_partition.hip")
-RESERVED = range(88, 120)
-
-
-def _registers(operand_text):
-    """VGPR numbers an operand string mentions: v93, v[92:94] ..."""
-    regs = set()
-    for m in re.finditer(r"\bv\[(\d+):(\d+)\]", operand_text):
-        regs.update(range(int(m.group(1)), int(m.group(2)) + 1))
-    for m in re.finditer(r"\bv(\d+)\b", operand_text):
-        regs.add(int(m.group(1)))
-    return regs
 
 
 @pytest.fixture(scope="module")
@@ -34,45 +22,22 @@ def pass2_asm(tmp_path_factory):
     if not os.path.exists(hipcc):
         pytest.skip("no hipcc")
     from datafusion_archive_amd import build as b
-    out = str(tmp_path_factory.mktemp("asm") / "partition.s")
-    flags = [f for f in b.CXXFLAGS if f not in ("-fPIC",)]
-    subprocess.check_call([hipcc] + flags + ["--cuda-device-only", "-S", "-o", out, SRC], stderr=subprocess.DEVNULL)
-    return open(out).read()
-
-
-def _kernels(asm, name):
-    """{mangled name: body} of every instantiation of `name`"""
-    out = {}
-    for m in re.finditer(r"^(_ZN3dfx\d+" + name + r"\w*):.*?\n(.*?)\n\s*s_endpgm", asm, re.S | re.M):
-        out[m.group(1)] = m.group(2)
-    return out
+    return b.pass2_guard_asm(hipcc, str(tmp_path_factory.mktemp("asm") / "partition.s"))
 
 
 def test_pass2_reserved_registers_are_allocated_and_untouched(pass2_asm):
-    kernels = _kernels(pass2_asm, "k_partition_agg_lean")
-    assert len(kernels) >= 8, f"expected every k_partition_agg_lean instantiation, found {len(kernels)}"
-    # (a) the code object's register allocation covers v119
-    meta = {m.group(1): int(m.group(2)) for m in
-            re.finditer(r"\.name:\s+(\S+)\n(?:(?!\.name:).*\n)*?\s+\.vgpr_count:\s+(\d+)", pass2_asm)}
-    for k, body in kernels.items():
-        assert k in meta, f"no metadata for {k}"
-        used = max(_registers(body) & set(RESERVED))  # v118 with 12-byte rows (dwordx3 loads), v119 with 16-byte rows
-        assert used >= 118, f"{k}: the in-flight row registers are gone?"
-        assert meta[k] > used, f"{k}: .vgpr_count = {meta[k]} does not cover v{used} (the in-flight row registers v88..v{used})"
-    # (b) only the hand-written instructions name v88..v119: loads INTO them, v_mov_b32 OUT of them
-    for k, body in kernels.items():
-        for line in body.split("\n"):
-            ins = line.split(";")[0].strip()
-            if not ins or ins.endswith(":") or ins.startswith("."):
-                continue
-            op, _, rest = ins.partition(" ")
-            ops = [o.strip() for o in rest.split(",")]
-            touched = _registers(rest) & set(RESERVED)
-            if not touched:
-                continue
-            if op in ("global_load_dwordx3", "global_load_dwordx4"):
-                assert _registers(ops[0]) <= set(RESERVED) and not (_registers(",".join(ops[1:])) & set(RESERVED)), f"{k}: {ins}"
-            elif op in ("v_mov_b32", "v_mov_b32_e32"):
-                assert not (_registers(ops[0]) & set(RESERVED)) and _registers(ops[1]) <= set(RESERVED), f"{k}: {ins}"
-            else:
-                raise AssertionError(f"{k}: compiler-generated instruction touches a reserved register: {ins}")
+    """the check build() itself runs whenever dfx_k_partition.o is rebuilt (datafusion_archive_amd/build.py)"""
+    from datafusion_archive_amd import build as b
+    assert b.check_pass2_reserved_registers(pass2_asm) >= 8
+
+
+def test_the_guard_refuses_a_build_that_breaks_the_register_window(pass2_asm):
+    """(a) a code object whose .vgpr_count stops short of the window, (b) a compiler-generated instruction inside it"""
+    from datafusion_archive_amd import build as b
+    short = re.sub(r"(\.vgpr_count:\s+)\d+", r"\g<1>96", pass2_asm)
+    with pytest.raises(RuntimeError, match="does not cover"):
+        b.check_pass2_reserved_registers(short)
+    m = re.search(r"^(_ZN3dfx\d+k_partition_agg_lean\w*):.*?\n", pass2_asm, re.M)
+    poisoned = pass2_asm[:m.end()] + "\tv_add_u32_e32 v90, v1, v2\n" + pass2_asm[m.end():]
+    with pytest.raises(RuntimeError, match="touches a reserved register"):
+        b.check_pass2_reserved_registers(poisoned)
