@@ -1308,6 +1308,7 @@ Status AggregateRelation::Impl::drain() {
   if (built) return Status::OK();
   ScopedUs t_drain(&counters().agg_drain_us);
   DFX_RETURN_IF_ERROR(ensure_init());
+  if (!options.overrides.empty() && input) input->host_stream_options(host_stream_options_of(opt()));  // (its own option set: how a host source below moves batches)
   hipStream_t s = ctx().stream;
   Status st;
   if (kw == 0) {

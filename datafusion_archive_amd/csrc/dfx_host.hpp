@@ -112,6 +112,7 @@ const uint8_t* device_ones_block();
 // measurement: bytes of column data copied host -> device by the uploaders (dfx_counter_get("h2d_bytes"))
 struct Counters {
   long long h2d_bytes = 0;
+  long long h2d_staged_bytes = 0;  // ... of which through the pinned staging ring (HostStreamOptions::mode 1)
   long long csv_cells = 0;  // cells converted by the CSV source
   // host-side time accounting of the aggregate (microseconds; tools/kprobe.py): where a query's wall time goes beyond its kernels
   long long agg_ctrl_wait_us = 0;   // blocked on control-block snapshots (one batch behind the launches)
@@ -161,6 +162,19 @@ struct DeviceBatch {
   std::vector<DeviceColumn> columns;
 };
 
+// How a source of HOST Arrow batches moves them to HBM (AggOptions::host_*: "host.stream", "host.stage_threads",
+// "host.stage_mb", "host.stage_slots"; an operator's own option set reaches its source through Relation::host_stream_options)
+struct HostStreamOptions {
+  int mode = 1;      // 1 (default) staged: library threads copy the producer's buffers into a ring of pinned slots while the DMA
+                     //   engine drains the slots filled before -- the engine reads pinned memory at 57 GB/s, one CPU thread fills
+                     //   it at 29; 0 in order: hipMemcpyAsync of the pageable buffers on the library's stream (HIP pins chunk-wise
+                     //   inside the runtime: 53-54 GB/s) and one stream synchronisation per batch; 2 one batch ahead on a copy stream;
+                     //   3 = 2 + the producer's large buffers page-locked in place (hipHostRegister)
+  int threads = 4;   // staged: threads filling slots
+  int piece_mb = 8;  // staged: bytes per slot (a column buffer travels in pieces of this size)
+  int slots = 8;     // staged: pinned slots (slots x piece_mb of pinned memory per source)
+};
+
 enum RelationKind { REL_HOST_STREAM, REL_TABLE_SCAN, REL_FILTER, REL_PROJECT, REL_AGGREGATE, REL_CSV, REL_SORT, REL_LIMIT };
 
 // trait Relation (src/execution/relation.rs:27-32)
@@ -186,6 +200,9 @@ struct Relation {
   // for batches of at least `rows` rows: a scan of an HBM table then hands out one slice per routing window instead of
   // many small ones (each costs a launch).  Sources that produce batches (host streams, CSV) ignore it.
   virtual void prefer_batch_rows(int64_t /*rows*/) {}
+  // An operator with its own option set tells the host source below it how to move batches (before its first next());
+  // operators forward it, device sources ignore it.  Without it a host source uses the process defaults.
+  virtual void host_stream_options(const HostStreamOptions& /*o*/) {}
 };
 struct ScanMemo {  // shared by every scan of a resident table (a `mutable` member of a const TableData): guarded
   mutable std::mutex mu;

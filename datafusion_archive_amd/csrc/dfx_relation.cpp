@@ -4,6 +4,11 @@
 #include "dfx_sigs.hpp"
 
 #include <errno.h>
+
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <stdlib.h>
 #include <string.h>
 
@@ -43,11 +48,20 @@ class HostStreamRelation : public Relation {
   }
   ~HostStreamRelation() override {
     drop(&pending_);
+    if (copy_stream_) (void)hipStreamSynchronize(copy_stream_);  // (staged pieces still crossing the link read the pinned slots)
+    for (hipEvent_t e : slot_event_)
+      if (e) (void)hipEventDestroy(e);
+    if (batch_event_) (void)hipEventDestroy(batch_event_);
     if (fence_) (void)hipEventDestroy(fence_);
     if (copy_stream_) (void)hipStreamDestroy(copy_stream_);
     if (stream_.release) stream_.release(&stream_);
   }
   RelationKind kind() const override { return REL_HOST_STREAM; }
+  void host_stream_options(const HostStreamOptions& o) override {
+    if (started_ || opts_set_) return;  // the first operator above decides, before the first batch
+    hopt_ = o;
+    opts_set_ = true;
+  }
 
   Status init() {
     struct ArrowSchema as;
@@ -65,14 +79,32 @@ class HostStreamRelation : public Relation {
     int n = 0;
     for (size_t i = 0; i < schema_.fields.size(); ++i) n += (needed_.empty() || needed_[i]) ? 1 : 0;
     explain_line(out, depth, strfmt("HostStream: host Arrow batches, %d of %d columns uploaded per batch (%s%s)", n, (int)schema_.fields.size(),
-                                    prefetch_ ? "one batch ahead, own copy stream" : "in order on the library's stream",
-                                    pin_in_place_ ? ", large buffers page-locked in place" : ""));
+                                    mode() == 1 ? "pinned staging ring filled by library threads, DMA on a copy stream" :
+                                    mode() >= 2 ? "one batch ahead, own copy stream" : "in order on the library's stream",
+                                    mode() == 3 ? ", large buffers page-locked in place" : ""));
   }
 
   Status next(DeviceBatch* out, bool* has) override {
     *has = false;
     DFX_RETURN_IF_ERROR(ensure_init());
-    if (!prefetch_) return next_in_order(out, has);
+    if (!opts_set_) {  // no operator above brought its own option set: the process defaults
+      const AggOptions& d = agg_options();
+      hopt_.mode = d.host_stream;
+      hopt_.threads = d.host_stage_threads;
+      hopt_.piece_mb = d.host_stage_mb;
+      hopt_.slots = d.host_stage_slots;
+      opts_set_ = true;
+    }
+    prefetch_ = mode() >= 2;
+    pin_in_place_ = mode() == 3;
+    if (mode() == 1) {
+      started_ = true;
+      return next_staged(out, has);
+    }
+    if (!prefetch_) {
+      started_ = true;
+      return next_in_order(out, has);
+    }
     if (!copy_stream_) DFX_HIP(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
     if (!started_) {  // the first batch: nothing to overlap it with yet
       started_ = true;
@@ -127,7 +159,14 @@ class HostStreamRelation : public Relation {
     return Status::OK();
   }
 
- private:
+  // The staged form (default).  The DMA engine reads PINNED host memory at 57 GB/s and pageable memory not at all: HIP's own
+  // copy of a pageable buffer pins it chunk-wise inside the runtime (53-54 GB/s, the calling thread blocked throughout), locking
+  // the producer's pages in place costs half the transfer's time (tools/pin_probe.py).  Here the library owns a ring of pinned
+  // slots; `threads` library threads copy the producer's buffers into slots piece by piece (one thread fills at ~29 GB/s: it
+  // takes two to four to outrun the engine) and queue each slot's DMA on a copy stream as soon as it is full, so the engine
+  // drains slot i while slots i + 1 ... are being filled.  The producer's buffers are read by those memcpys only: the array
+  // is released when the threads have joined, with the last slots still crossing the link; the consumer's kernels wait for
+  // the batch's copy event on the library's stream -- no host synchronisation at all.
   struct InFlight {
     bool valid = false;
     struct ArrowArray arr;        // the producer's batch, borrowed until `event` fires
@@ -137,6 +176,127 @@ class HostStreamRelation : public Relation {
     Status upload, error;
     InFlight() { memset(&arr, 0, sizeof(arr)); }
   };
+  struct Piece {
+    const uint8_t* host;
+    uint8_t* dev;
+    size_t bytes;
+  };
+  Status next_staged(DeviceBatch* out, bool* has) {
+    if (!copy_stream_) DFX_HIP(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
+    InFlight f;
+    copy_stream_in_use_ = copy_stream_;
+    pieces_.clear();
+    staging_ = true;
+    Status st = fetch_staged(&f);
+    staging_ = false;
+    if (!st.ok() || !f.valid) {
+      drop(&f);
+      return st;
+    }
+    st = f.upload;
+    if (st.ok()) st = run_pieces();
+    hipError_t e = hipSuccess;
+    if (st.ok()) {  // the consumer's kernels (library stream) start when this batch's last piece has landed
+      if (!batch_event_) e = hipEventCreateWithFlags(&batch_event_, hipEventDisableTiming);
+      if (e == hipSuccess) e = hipEventRecord(batch_event_, copy_stream_);
+      if (e == hipSuccess) e = hipStreamWaitEvent(ctx().stream, batch_event_, 0);
+      if (e != hipSuccess) st = Status::Err(DFX_EXECUTION_ERROR, strfmt("HIP error %s after H2D", hipGetErrorString(e)));
+    } else {
+      (void)hipStreamSynchronize(copy_stream_);  // pieces already queued read pinned slots, not the producer: nothing else to wait for
+    }
+    DeviceBatch b = std::move(f.batch);
+    drop(&f);  // every byte of the producer's buffers has been copied out by now
+    if (!st.ok()) return st;
+    *out = std::move(b);
+    *has = true;
+    return Status::OK();
+  }
+  Status fetch_staged(InFlight* f) {
+    if (done_) return Status::OK();
+    const int rc = stream_.get_next(&stream_, &f->arr);
+    if (rc != 0) {
+      memset(&f->arr, 0, sizeof(f->arr));
+      return stream_error(rc, "get_next");
+    }
+    if (f->arr.release == nullptr) {
+      done_ = true;
+      return Status::OK();
+    }
+    f->valid = true;
+    // device buffers come from the pool: a consumer's kernels that still use them may be queued on the library's stream
+    if (!fence_) DFX_HIP(hipEventCreateWithFlags(&fence_, hipEventDisableTiming));
+    DFX_HIP(hipEventRecord(fence_, ctx().stream));
+    DFX_HIP(hipStreamWaitEvent(copy_stream_, fence_, 0));
+    f->upload = upload(f->arr, &f->batch, f);  // (h2d only lists the pieces while staging_)
+    return Status::OK();
+  }
+  Status ensure_ring() {
+    const size_t piece = (size_t)std::max(1, hopt_.piece_mb) << 20;
+    const int slots = std::max(2, std::min(64, hopt_.slots));
+    if (ring_ && ring_piece_ == piece && (int)slot_event_.size() == slots) return Status::OK();
+    if (copy_stream_) (void)hipStreamSynchronize(copy_stream_);
+    Status st;
+    ring_ = pinned_alloc(piece * (size_t)slots, &st);
+    if (!ring_) return st;
+    ring_piece_ = piece;
+    for (hipEvent_t e : slot_event_)
+      if (e) (void)hipEventDestroy(e);
+    slot_event_.assign((size_t)slots, nullptr);
+    for (auto& e : slot_event_) DFX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    slot_gen_.assign((size_t)slots, 0);
+    return Status::OK();
+  }
+  Status run_pieces() {
+    if (pieces_.empty()) return Status::OK();
+    DFX_RETURN_IF_ERROR(ensure_ring());
+    const size_t n = pieces_.size(), R = slot_event_.size();
+    size_t total = 0;
+    for (const Piece& p : pieces_) total += p.bytes;
+    std::fill(slot_gen_.begin(), slot_gen_.end(), 0);
+    std::atomic<size_t> next{0};
+    std::mutex mu;
+    std::condition_variable cv;
+    Status first_error = Status::OK();
+    const int device = ctx().device;
+    uint8_t* const ring = (uint8_t*)ring_.get();
+    auto worker = [&]() {
+      (void)hipSetDevice(device);  // (the current device is a per-thread setting)
+      for (;;) {
+        const size_t i = next.fetch_add(1);
+        if (i >= n) break;
+        const size_t sl = i % R, turn = i / R;
+        {  // my slot's previous occupant (piece i - R, taken earlier by some thread) has been queued ...
+          std::unique_lock<std::mutex> lk(mu);
+          cv.wait(lk, [&] { return slot_gen_[sl] == turn; });
+        }
+        hipError_t e = hipSuccess;
+        if (slot_used_ || turn > 0) e = hipEventSynchronize(slot_event_[sl]);  // ... and has left the slot
+        const Piece& p = pieces_[i];
+        if (e == hipSuccess) {
+          memcpy(ring + sl * ring_piece_, p.host, p.bytes);
+          e = hipMemcpyAsync(p.dev, ring + sl * ring_piece_, p.bytes, hipMemcpyHostToDevice, copy_stream_);
+        }
+        if (e == hipSuccess) e = hipEventRecord(slot_event_[sl], copy_stream_);
+        {
+          std::lock_guard<std::mutex> lk(mu);
+          if (e != hipSuccess && first_error.ok()) first_error = Status::Err(DFX_EXECUTION_ERROR, strfmt("HIP error %s in the staged H2D copy", hipGetErrorString(e)));
+          slot_gen_[sl] = turn + 1;
+        }
+        cv.notify_all();
+      }
+    };
+    // small batches (the reference's 1024-row batches): the calling thread alone -- starting threads costs more than the copy
+    const int threads = total < ((size_t)4 << 20) ? 1 : std::max(1, std::min(16, hopt_.threads));
+    std::vector<std::thread> pool;
+    for (int t = 1; t < threads; ++t) pool.emplace_back(worker);
+    worker();
+    for (std::thread& t : pool) t.join();
+    slot_used_ = true;
+    counters().h2d_staged_bytes += (long long)total;
+    return first_error;
+  }
+
+ private:
 
   void drop(InFlight* f) {  // unpin, hand the array back to the producer
     if (f->event) {
@@ -199,6 +359,17 @@ class HostStreamRelation : public Relation {
     Status st;
     *dev = device_alloc(bytes ? bytes : 8, &st);
     if (!*dev) return st;
+    if (staging_) {  // staged form: only list what has to travel (run_pieces moves it)
+      for (size_t at = 0; at < bytes; at += ring_piece_bytes()) {
+        Piece p;
+        p.host = (const uint8_t*)host + at;
+        p.dev = (uint8_t*)dev->get() + at;
+        p.bytes = std::min(ring_piece_bytes(), bytes - at);
+        pieces_.push_back(p);
+      }
+      counters().h2d_bytes += (long long)bytes;
+      return Status::OK();
+    }
     if (pin_in_place_ && bytes >= kPinThreshold) {
       if (hipHostRegister(const_cast<void*>(host), bytes, hipHostRegisterDefault) == hipSuccess) f->registered.push_back(const_cast<void*>(host));
       else (void)hipGetLastError();  // not lockable (already registered, overlapping pages ...): the staged copy below still works
@@ -279,13 +450,26 @@ class HostStreamRelation : public Relation {
   // for HIP's own staged copy of pageable memory) although the copy out of registered memory alone is faster (57 GB/s,
   // tools/pin_probe.py) -- locking 256 MB costs 2.2 ms of the 4.7 ms its transfer takes, and it does not overlap the
   // transfer of the batch before.
-  bool pin_in_place_ = getenv("DFX_HOST_PIN") && atoi(getenv("DFX_HOST_PIN")) != 0;
+  bool pin_in_place_ = false;  // HostStreamOptions::mode == 3 ("host.stream"; the DFX_HOST_PIN environment switch of round 3 is gone)
   // DFX_HOST_PREFETCH=1: batch i + 1 is pulled from the producer and copied on a stream of its own while the consumer works
   // on batch i, the producer's array released on the copy's event (no synchronisation of the compute stream).  Off by
   // default for the same reason: 40-43 GB/s end to end against 53 for the in-order form (tools/host_stream_probe.py) -- a
   // pageable copy blocks the calling thread whichever stream it is queued on, so nothing overlaps, and the second stream
   // costs the runtime's pinned-chunk pipeline its rhythm.
-  bool prefetch_ = getenv("DFX_HOST_PREFETCH") && atoi(getenv("DFX_HOST_PREFETCH")) != 0;
+  bool prefetch_ = false;  // HostStreamOptions::mode >= 2 (was DFX_HOST_PREFETCH)
+  HostStreamOptions hopt_;
+  bool opts_set_ = false;
+  int mode() const { return hopt_.mode < 0 || hopt_.mode > 3 ? 1 : hopt_.mode; }
+  size_t ring_piece_bytes() const { return (size_t)std::max(1, hopt_.piece_mb) << 20; }
+  // staged form
+  bool staging_ = false;
+  std::vector<Piece> pieces_;
+  std::shared_ptr<void> ring_;
+  size_t ring_piece_ = 0;
+  std::vector<hipEvent_t> slot_event_;
+  std::vector<size_t> slot_gen_;
+  bool slot_used_ = false;
+  hipEvent_t batch_event_ = nullptr;
   hipStream_t copy_stream_in_use_ = nullptr;
   struct ArrowArrayStream stream_;
   SchemaInfo schema_;
@@ -680,6 +864,10 @@ static Status alloc_zeroed_ctrl(std::shared_ptr<void>* ctrl) {
 
 Status FilterRelation::next(DeviceBatch* out, bool* has) {
   *has = false;
+  if (!source_told_) {  // this operator's own option set decides how a host source below moves its batches
+    source_told_ = true;
+    if (!opt_.overrides.empty()) input_->host_stream_options(host_stream_options_of(opt_.get()));
+  }
   DeviceBatch in;
   bool got = false;
   DFX_RETURN_IF_ERROR(input_->next(&in, &got));

@@ -88,12 +88,25 @@ struct AggOptions {
                                // kernel, every wave scans and routes
   int merge_scan_batches = 1;  // an aggregate over a scan of a resident table asks for slices of >= 2^27 rows (one per routing window)
                                // whatever batch width the scan was created with; 0: the caller's batch width is kept
+  int host_stream = 1;         // host Arrow batches -> HBM (HostStreamOptions::mode): 1 pinned staging ring filled by library threads,
+                               // 0 in-order pageable copies, 2 one batch ahead on a copy stream, 3 = 2 + page-locking in place
+  int host_stage_threads = 4;  // ... threads that fill the ring
+  int host_stage_mb = 8;       // ... bytes per slot
+  int host_stage_slots = 8;    // ... slots
   int filter_single_pass = 1;  // FilterRelation: predicate + bitmap + tile offsets (decoupled look-back) + compaction of the predicate's own
                                // columns in ONE kernel (0: k_predicate_mask -> scan -> k_compact, the column is read twice)
   int replay_in_place = 1;     // 1: rows spilled by a table that is NOT full (region overflow of a heavy key) are replayed into the
                                // table as it is, and only what it cannot take makes it grow (0: every spill quadruples the table)
 };
 AggOptions& agg_options();  // the process-wide defaults (dfx_set_option)
+inline HostStreamOptions host_stream_options_of(const AggOptions& o) {
+  HostStreamOptions h;
+  h.mode = o.host_stream;
+  h.threads = o.host_stage_threads;
+  h.piece_mb = o.host_stage_mb;
+  h.slots = o.host_stage_slots;
+  return h;
+}
 // one key of dfx_set_option applied to an option set; false: unknown key
 bool set_option_in(AggOptions& o, const char* key, int64_t value);
 typedef std::vector<std::pair<std::string, int64_t>> OptionOverrides;
@@ -123,6 +136,7 @@ class FilterRelation : public Relation {
   Status next(DeviceBatch* out, bool* has) override;
   const SchemaInfo& schema() const override { return schema_; }
   void require_columns(const std::vector<char>& needed) override;
+  void host_stream_options(const HostStreamOptions& o) override { if (input_) input_->host_stream_options(o); }
   void explain(std::string* out, int depth) const override;
   // for Filter -> Aggregate fusion
   std::unique_ptr<Relation> release_input() { return std::move(input_); }
@@ -144,6 +158,7 @@ class FilterRelation : public Relation {
   Status deferred_;  // evaluation-time type errors of the reference surface on next()
   std::shared_ptr<void> ctrl_;
   mutable OperatorOptions opt_;
+  bool source_told_ = false;  // this operator's option set has reached the host source below (before the first batch is pulled)
   std::shared_ptr<void> ctrl_host_;  // pinned copy of the control block (kept count + error bits of a batch)
   std::vector<char> out_needed_;  // empty: every column is compacted
   bool keep_mask_ = false;
@@ -169,6 +184,7 @@ class ProjectRelation : public Relation {
   RelationKind kind() const override { return REL_PROJECT; }
   Status next(DeviceBatch* out, bool* has) override;
   const SchemaInfo& schema() const override { return schema_; }
+  void host_stream_options(const HostStreamOptions& o) override { if (input_) input_->host_stream_options(o); }
   void explain(std::string* out, int depth) const override;
 
  private:

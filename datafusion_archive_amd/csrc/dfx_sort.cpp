@@ -411,6 +411,7 @@ class LimitRelation : public Relation {
   RelationKind kind() const override { return REL_LIMIT; }
   const SchemaInfo& schema() const override { return schema_; }
   void require_columns(const std::vector<char>& needed) override { input_->require_columns(needed); }
+  void host_stream_options(const HostStreamOptions& o) override { input_->host_stream_options(o); }
   void explain(std::string* out, int depth) const override {
     explain_line(out, depth, strfmt("Limit: %lld rows left", (long long)left_));
     input_->explain(out, depth + 1);

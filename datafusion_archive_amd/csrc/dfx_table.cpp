@@ -257,6 +257,10 @@ bool set_option_in(AggOptions& o, const char* key, int64_t value) {
   else if (!strcmp(key, "agg.pass1_ws")) o.pass1_ws = (int)value;
   else if (!strcmp(key, "agg.merge_scan_batches")) o.merge_scan_batches = (int)value;
   else if (!strcmp(key, "filter.single_pass")) o.filter_single_pass = (int)value;
+  else if (!strcmp(key, "host.stream")) o.host_stream = (int)value;
+  else if (!strcmp(key, "host.stage_threads")) o.host_stage_threads = (int)value;
+  else if (!strcmp(key, "host.stage_mb")) o.host_stage_mb = (int)value;
+  else if (!strcmp(key, "host.stage_slots")) o.host_stage_slots = (int)value;
   else return false;
   return true;
 }
@@ -417,6 +421,7 @@ uint32_t dfx_debug_unhash32(uint32_t image) { return host_unhash_word32(image); 
 int64_t dfx_counter_get(const char* name) {
   if (!name) return -1;
   if (!strcmp(name, "h2d_bytes")) return counters().h2d_bytes;
+  if (!strcmp(name, "h2d_staged_bytes")) return counters().h2d_staged_bytes;
   if (!strcmp(name, "csv_cells")) return counters().csv_cells;
   if (!strcmp(name, "agg_ctrl_wait_us")) return counters().agg_ctrl_wait_us;
   if (!strcmp(name, "agg_sync_us")) return counters().agg_sync_us;

@@ -420,10 +420,19 @@ int64_t dfx_relation_explain(struct ArrowArrayStream* stream, char* buf, size_t 
  *   "agg.replay_in_place"    experimental, default 0
  *   "agg.dict_capacity_log2" initial slots of a Utf8 key dictionary (0: 2^16)
  *   "scan.fast"              0: always the generic SSA interpreter instead of the shape-specialised kernels
+ *   "scan.plan"              scan plans (run-time query shapes evaluated as data: range tests on value images, 4-byte columns
+ *                            widened, nulls by arrow's comparison rule): 1 wherever the shape is covered and no compile-time
+ *                            signature matches (default), 0 never (round 3's dispatch), 2 also instead of the signatures
+ *   "host.stream"            how HOST Arrow batches reach HBM (also a per-operator option: the first operator above a host
+ *                            source decides): 1 pinned staging ring filled by library threads, DMA on a copy stream, the
+ *                            producer's array released when its bytes have been copied out (default); 0 pageable copies in
+ *                            order on the library's stream; 2 one batch ahead on a copy stream; 3 = 2 + large buffers
+ *                            page-locked in place.  "host.stage_threads" (4), "host.stage_mb" (8: bytes per pinned slot),
+ *                            "host.stage_slots" (8) size the ring
  *   "pool.trim"              (any value) return the cached device buffers to the driver */
 int32_t dfx_set_option(const char* key, int64_t value);
-/* Measurement counters: "h2d_bytes" (column bytes the uploaders copied host -> device), "csv_cells" (cells the CSV
- * source converted) -- what projection push-down saves.  -1: unknown name. */
+/* Measurement counters: "h2d_bytes" (column bytes the uploaders copied host -> device), "h2d_staged_bytes" (of which through
+ * the pinned staging ring), "csv_cells" (cells the CSV source converted) -- what projection push-down saves.  -1: unknown name. */
 int64_t dfx_counter_get(const char* name);
 void dfx_counter_reset(void);
 

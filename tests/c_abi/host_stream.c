@@ -141,7 +141,12 @@ int main(int argc, char** argv) {
   memset(&p, 0, sizeof(p));
   p.rows_per_batch = argc > 1 ? atoll(argv[1]) : (1 << 22);
   p.n_batches = argc > 2 ? atoi(argv[2]) : 6;
+  /* argv[3]: how the host batches travel (dfx option "host.stream": 1 pinned staging ring, 0 in order, 2 one batch ahead,
+   * 3 = 2 + page-locked in place); argv[4] = "operator": handed to the aggregate as ITS option instead of the process default */
+  const int mode = argc > 3 ? atoi(argv[3]) : -1;
+  const int per_operator = argc > 4 && !strcmp(argv[4], "operator");
   CHECK(dfx_init(0, err, sizeof(err)));
+  if (mode >= 0 && !per_operator) CHECK(dfx_set_option("host.stream", mode));
   struct ArrowArrayStream src, filtered, agg;
   memset(&src, 0, sizeof(src));
   src.get_schema = get_schema;
@@ -169,7 +174,14 @@ int main(int argc, char** argv) {
   CHECK(dfx_filter_relation_new(&src, pred, &schema, &filtered, err, sizeof(err)));
   const dfx_runtime_expr* groups_[1] = {key};
   const dfx_runtime_expr* aggs_[2] = {sum, cnt};
-  CHECK(dfx_aggregate_relation_new(NULL, &filtered, groups_, 1, aggs_, 2, &agg, err, sizeof(err)));
+  if (mode >= 0 && per_operator) {
+    dfx_option o[2];
+    o[0].key = "host.stream"; o[0].value = mode;
+    o[1].key = "host.stage_mb"; o[1].value = 1;  /* small slots: a 2^22-row column travels in 32 pieces through 8 slots */
+    CHECK(dfx_aggregate_relation_new_with_options(NULL, &filtered, groups_, 1, aggs_, 2, o, 2, &agg, err, sizeof(err)));
+  } else {
+    CHECK(dfx_aggregate_relation_new(NULL, &filtered, groups_, 1, aggs_, 2, &agg, err, sizeof(err)));
+  }
 
   struct ArrowArray out;
   if (agg.get_next(&agg, &out) != 0) { printf("ERR %s\n", agg.get_last_error(&agg)); return 1; }

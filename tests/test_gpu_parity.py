@@ -1341,28 +1341,26 @@ def test_aggregate_over_a_table_scan_merges_small_scan_batches():
     assert_groups_identical(res[1], want, 1, "merged scan batches vs oracle")
 
 
-@pytest.mark.parametrize("mode", ["in order", "in order + pinned in place", "prefetch", "prefetch + pinned in place"])
+@pytest.mark.parametrize("mode", ["staged ring (default)", "staged ring as the operator's own option", "in order", "one batch ahead", "one batch ahead + pinned in place"])
 def test_host_batches_are_borrowed_until_their_copy_has_finished(tmp_path, mode):
     """Row (g) of the round-2 review: the producer's release callback must fire only after the copy of ITS batch has read the
-    buffers -- in every form of the host stream (csrc/dfx_relation.cpp): in order (the default: copies on the library's
-    stream, release after the synchronisation), one batch ahead on a copy stream (DFX_HOST_PREFETCH=1: release on the copy's
-    event) and with the producer's buffers page-locked in place on top of that (DFX_HOST_PIN=1).  tests/c_abi/host_stream.c
-    is a C producer that poisons and frees its buffers on release and checks every group of the result against the closed
-    form; it also reports how many batches the library held at once (1 in order, 2 when it copies ahead)."""
+    buffers -- in every form of the host stream (csrc/dfx_relation.cpp; option "host.stream"): the pinned staging ring (1, the
+    default since round 4: library threads copy the producer's buffers into pinned slots, the array is released when they have
+    joined), in order (0: copies on the library's stream, release after the synchronisation), one batch ahead on a copy stream
+    (2: release on the copy's event) and with the producer's buffers page-locked in place on top of that (3).
+    tests/c_abi/host_stream.c is a C producer that poisons and frees its buffers on release and checks every group of the result
+    against the closed form; it also reports how many batches the library held at once (2 when it copies ahead, else 1)."""
     import subprocess
     from test_host_logic import _build_c_abi_program
     exe = _build_c_abi_program(tmp_path, "host_stream")
-    env = dict(os.environ)
-    if mode.startswith("prefetch"):
-        env["DFX_HOST_PREFETCH"] = "1"
-    if mode.endswith("pinned in place"):
-        env["DFX_HOST_PIN"] = "1"
+    args = {"staged ring (default)": [], "staged ring as the operator's own option": ["1", "operator"], "in order": ["0"],
+            "one batch ahead": ["2"], "one batch ahead + pinned in place": ["3"]}[mode]
     for rows, batches in ((1 << 22, 6), (1000, 5), (1 << 20, 1), (300000, 3)):  # large (page-locked when asked for) and small buffers
-        r = subprocess.run([exe, str(rows), str(batches)], capture_output=True, text=True, timeout=300, env=env)
+        r = subprocess.run([exe, str(rows), str(batches)] + args, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0 and r.stdout.startswith("OK"), r.stdout + r.stderr
         got = dict(kv.split("=") for kv in r.stdout.split()[1:])
         assert int(got["released"]) == batches and int(got["groups"]) == 97
-        assert int(got["max_outstanding"]) <= (2 if mode.startswith("prefetch") else 1), r.stdout
+        assert int(got["max_outstanding"]) <= (2 if mode.startswith("one batch ahead") else 1), r.stdout
 
 
 def test_large_properties_filter_groupby_sum():
