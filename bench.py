@@ -480,6 +480,43 @@ def main():
         extra["cfg2_filter_two_pass"] = rate(n_rows * k3, dfw2, 8.125 + 8 * sel2, "the same with filter.single_pass = 0 (k_predicate_mask -> scan -> k_compact: "
                                              "round 2's path, the column is read twice)")
 
+        # ... and when the filter is NOT selective: a wave parks at most a quarter of its 4096-row tile in LDS, denser tiles re-read
+        # their passing rows after the look-back (two reads of those tiles) -- what that costs, at selectivity 0.5 and 0.9
+        dense_preds = {"cfg2_filter_dense_sel50": (51.0, 56.0), "cfg2_filter_dense_sel90": (49.5, 58.5)}
+        for name_, (lo_, hi_) in dense_preds.items():
+            pd_ = BinaryExpr(BinaryExpr(Column(0), Operator.Gt, l64(lo_)), Operator.And, BinaryExpr(Column(0), Operator.Lt, l64(hi_)))
+            keptd = [0]
+
+            def filter_dense():
+                rel = ex.FilterRelation(t2.scan(args.batch_rows), ex.compile_scalar_expr(None, pd_, schema2), schema2)
+                keptd[0] = ex.drain_on_device(rel)[0]
+            try:
+                dfd, _ = timed(filter_dense, k3, 1)
+                seld = keptd[0] / n_rows
+                extra[name_] = rate(n_rows * k3, dfd, 8.125 + 8 * seld, f"FilterRelation over lat = 49 + 10 u WHERE lat > {lo_} AND lat < {hi_}: selectivity {seld:.3f} "
+                                    "(8.125 + 8 sel B/row), bitmap + compacted output on the device")
+                if want_oracle:
+                    bg[name_] = Background(oracle.run_synth_filter, syn_lat, seed2, 0, min(verify_rows, 30000000), 1024, pd_)
+            except Exception as e:
+                extra[name_] = {"error": str(e)[:200]}
+
+        def verify_dense(name_):
+            lo_, hi_ = dense_preds[name_]
+            pd_ = BinaryExpr(BinaryExpr(Column(0), Operator.Gt, l64(lo_)), Operator.And, BinaryExpr(Column(0), Operator.Lt, l64(hi_)))
+            rows_ = min(verify_rows, 30000000)
+            t_s = ex.DeviceTable.synth(syn_lat, seed2, 0, rows_)
+            rel = ex.FilterRelation(t_s.scan(args.batch_rows), ex.compile_scalar_expr(None, pd_, schema2), schema2)
+            _secs, kept, want_cols, _m = bg[name_].get()
+            parts = []
+            while True:
+                b = rel.next()
+                if b is None:
+                    break
+                parts.append(b.column(0).to_numpy())
+            got = np.concatenate(parts) if parts else np.empty(0)
+            ok = bool(len(got) == kept and np.array_equal(got.view(np.uint64), want_cols[0][:kept].view(np.uint64)))
+            return {"rows": rows_, "rows_passing": int(kept), "ok": ok, "what": "the compacted column, GPU vs CPU oracle (orc_filter_next, 1024-row batches), bit for bit"}
+
         def verify_cfg2():
             t_s = t2 if verify_rows == n_rows else ex.DeviceTable.synth(syn_lat, seed2, 0, verify_rows)
             rel = ex.FilterRelation(t_s.scan(args.batch_rows), ex.compile_scalar_expr(None, pred2, schema2), schema2)
@@ -501,6 +538,9 @@ def main():
             return {"rows": verify_rows, "rows_passing": int(kept), "ok": ok,
                     "what": "the Arrow bitmap of every batch and the compacted column, GPU vs CPU oracle (orc_filter_next, 1024-row batches), bit for bit"}
         extra["cfg2_filter_mask_and_compact"]["verified_vs_oracle"] = checked("cfg2", verify_cfg2)
+        for name_ in dense_preds:
+            if "roofline" in extra.get(name_, {}):
+                extra[name_]["verified_vs_oracle"] = checked(name_, lambda n_=name_: verify_dense(n_))
 
         def verify_cfg2_count():
             t_s = t2 if verify_rows == n_rows else ex.DeviceTable.synth(syn_lat, seed2, 0, verify_rows)

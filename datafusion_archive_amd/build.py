@@ -19,7 +19,7 @@ OBJDIR = os.path.join(HERE, "build")
 LIB = os.path.join(LIBDIR, "libdfx_hip.so")
 
 # kernel translation units first (slowest): they compile in parallel
-SOURCES = ["dfx_k_table1.hip", "dfx_k_table2.hip", "dfx_k_table3.hip", "dfx_k_table4.hip", "dfx_k_core.hip",
+SOURCES = ["dfx_k_table1.hip", "dfx_k_table2.hip", "dfx_k_table3.hip", "dfx_k_table4.hip", "dfx_k_table8.hip", "dfx_k_core.hip",
            "dfx_k_reduce.hip", "dfx_k_partition.hip", "dfx_k_partition_v0.hip", "dfx_k_partition_v1.hip", "dfx_k_partition_v2.hip",
            "dfx_k_partition_v3.hip", "dfx_k_partition_v4.hip", "dfx_k_partition_v5.hip", "dfx_k_partition_v6.hip", "dfx_k_partition_v7.hip", "dfx_k_partition_v8.hip",
            "dfx_k_partition_v9.hip", "dfx_k_partition_v10.hip", "dfx_k_partition_v11.hip", "dfx_k_partition_v12.hip",

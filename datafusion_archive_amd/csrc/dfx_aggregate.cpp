@@ -107,6 +107,8 @@ struct AggregateRelation::Impl {
   bool done = false;
   bool built = false;
   int kw = 0, na = 0;
+  int kw_out = 0;  // GROUP BY expressions of the query = key columns of the result (kw: key WORDS the kernels see -- five to
+                   // seven keys are padded to eight with constant zero words, the table kernels being built for 1, 2, 3, 4, 8)
   std::vector<int> key_dtype, arg_dtype, out_dtype, func;
   uint8_t acc_kind[kMaxAggs], val_xform[kMaxAggs];
   uint64_t acc_init[kMaxAggs];
@@ -220,9 +222,30 @@ Status AggregateRelation::Impl::setup(const SchemaInfo& input_schema) {
     key_out_dtype[k] = DFX_UTF8;
     dicts.push_back(std::move(d));
   }
-  kw = (int)group.size();
+  kw_out = (int)group.size();
   na_total = (int)aggr.size();
-  if (kw > kMaxKeys) return Status::Err(DFX_NOT_IMPLEMENTED, strfmt("more than %d GROUP BY expressions", kMaxKeys));
+  if (kw_out > kMaxKeys) return Status::Err(DFX_NOT_IMPLEMENTED, strfmt("more than %d GROUP BY expressions", kMaxKeys));
+  kw = kw_out;
+  if (kw_out > 4) {  // (the reference builds a Vec<GroupByScalar> of any length, aggregate.rs:807-852)
+    dfx_runtime_expr zero;
+    dfx_expr_node n;
+    memset(&n, 0, sizeof(n));
+    n.kind = DFX_EXPR_LITERAL;
+    n.dtype = DFX_INT64;
+    n.left = n.right = n.column = -1;
+    n.lit.i64 = 0;
+    zero.nodes.push_back(n);
+    zero.strings.emplace_back();
+    zero.has_name.push_back(0);
+    zero.root = 0;
+    zero.dtype = DFX_INT64;
+    zero.name = "0";
+    while ((int)group_rw.size() < kMaxKeys) {
+      group_rw.push_back(zero);
+      key_out_dtype.push_back(DFX_INT64);
+    }
+    kw = kMaxKeys;
+  }
   if (na_total > kMaxAccsTotal) return Status::Err(DFX_NOT_IMPLEMENTED, strfmt("more than %d accumulators", kMaxAccsTotal));
   key_dtype.assign(kw, 0);
   arg_dtype.assign(na_total, 0);
@@ -280,7 +303,7 @@ Status AggregateRelation::Impl::build_chunk_programs(Chunk& ch) {
     if (dt != DFX_BOOLEAN) return Status::Err(DFX_EXECUTION_ERROR, "Filter expression did not evaluate to boolean");
   }
   for (int k = 0; k < kw; ++k) {
-    if (group[k].is_aggregate) return Status::Err(DFX_INTERNAL_ERROR, "explicit panic: get_func() on an aggregate expression");
+    if (k < kw_out && group[k].is_aggregate) return Status::Err(DFX_INTERNAL_ERROR, "explicit panic: get_func() on an aggregate expression");
     int dt = 0;
     DFX_RETURN_IF_ERROR(builder->add(group_rw[k], group_rw[k].root, &plan.key[k], &dt));
     if (!dtype_is_int(dt))  // aggregate.rs:848-850 (floats and booleans are rejected)
@@ -1466,12 +1489,12 @@ Status AggregateRelation::Impl::emit_grouped(DeviceBatch* out, int64_t expected)
   const int64_t g = expected < 0 ? (int64_t)*total : expected;
   out->num_rows = g;
   out->columns.clear();
-  out->columns.resize((size_t)kw + outs.size());
+  out->columns.resize((size_t)kw_out + outs.size());
   auto dense = device_alloc(sizeof(uint64_t) * (size_t)std::max<int64_t>(g, 1), &st);
   if (!dense) return st;
   // the sentinel group's key word is not stored in the table: patch slot `cap` before compaction
   if (kw == 1) DFX_HIP(launch_fill_u64(T.keys + T.mask + 1, kEmptyKey, 1, s));
-  for (int k = 0; k < kw; ++k) {
+  for (int k = 0; k < kw_out; ++k) {  // (padding words beyond kw_out are constants: not part of the result)
     const uint64_t* plane = T.keys + (size_t)k * T.stride;
     const int dt = key_dtype[k];
     DeviceColumn& c = out->columns[k];
@@ -1499,7 +1522,7 @@ Status AggregateRelation::Impl::emit_grouped(DeviceBatch* out, int64_t expected)
   for (size_t j = 0; j < outs.size(); ++j) {
     const int a = outs[j].acc;
     const int dt = outs[j].avg ? outs[j].dtype : out_dtype[a];
-    DeviceColumn& c = out->columns[(size_t)kw + j];
+    DeviceColumn& c = out->columns[(size_t)kw_out + j];
     c.dtype = dt;
     c.length = g;
     auto vals = device_alloc((size_t)std::max<int64_t>(g, 1) * dtype_width(dt), &st);
@@ -1658,7 +1681,7 @@ void AggregateRelation::explain(std::string* out, int depth) const {
                           : "scan plan where a batch has nulls or 4-byte columns (PlanPolicy), else column-op-literal shape (FastPolicy)";
       else if (m.fast.valid) shape = "column-op-literal shape (FastPolicy; interpreter when a batch has nulls)";
     }
-    std::string text = strfmt("Aggregate: %d keys, %d accumulators", m.kw, m.na_total);
+    std::string text = strfmt("Aggregate: %d keys%s, %d accumulators", m.kw_out, m.kw != m.kw_out ? " (as 8 key words)" : "", m.na_total);
     if (m.chunks.size() > 1) text += strfmt(" in %d chunks of <= %d (one fused program each, the same table)", (int)m.chunks.size(), kMaxAggs);
     const bool plan_fuses = m.opt().plan != 0 && m.opt().fast != 0 && scan_plan_shape_ok(P, m.fast, m.kw, m.na, m.val_xform);
     text += !m.has_pred ? ", no predicate" : plan_fuses ? ", Filter below fused into the scan (batches with nulls too: the scan plan judges a null by arrow's comparison rule and counts every surviving slot as valid)"

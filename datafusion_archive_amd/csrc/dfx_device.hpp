@@ -15,7 +15,7 @@ namespace dfx {
 constexpr int kMaxRegs = 16;  // computed values per fused program
 constexpr int kMaxCols = 8;   // distinct input columns per fused program
 constexpr int kMaxImm = 16;   // distinct literals per fused program
-constexpr int kMaxKeys = 4;   // GROUP BY key words
+constexpr int kMaxKeys = 8;   // GROUP BY key words (the table kernels are built for 1, 2, 3, 4 and 8: five to seven keys run as eight, padded with constant words)
 constexpr int kMaxAggs = 8;   // aggregates per AggregateRelation
 constexpr int kMaxOut = 8;    // projection outputs per launch
 
@@ -336,7 +336,9 @@ struct DevFusedOut {
   int32_t n;                     // 0..kFusedOutCols
   uint8_t slot[kFusedOutCols];   // column slot of the fused program
   uint8_t dtype[kFusedOutCols];
-  void* out[kFusedOutCols];      // room for every row of the batch (the kept count is known when the kernel ends)
+  void* out[kFusedOutCols];      // room for cap_rows rows
+  uint64_t cap_rows;             // rows past it are not stored (the host sized the buffers from the selectivity it has seen; when
+                                 // a batch keeps more, it compacts those columns again from the bitmap: k_compact)
 };
 
 struct DevProjectPlan {

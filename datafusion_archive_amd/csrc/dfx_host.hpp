@@ -112,7 +112,9 @@ const uint8_t* device_ones_block();
 // measurement: bytes of column data copied host -> device by the uploaders (dfx_counter_get("h2d_bytes"))
 struct Counters {
   long long h2d_bytes = 0;
-  long long h2d_staged_bytes = 0;  // ... of which through the pinned staging ring (HostStreamOptions::mode 1)
+  long long h2d_staged_bytes = 0;
+  long long filter_output_regrows = 0;      // single-pass FilterRelation: batches that kept more rows than their output buffers were sized for
+  long long filter_lookback_fallbacks = 0;  // ... batches redone in two passes because the look-back gave up waiting (a shared GPU)  // ... of which through the pinned staging ring (HostStreamOptions::mode 1)
   long long csv_cells = 0;  // cells converted by the CSV source
   // host-side time accounting of the aggregate (microseconds; tools/kprobe.py): where a query's wall time goes beyond its kernels
   long long agg_ctrl_wait_us = 0;   // blocked on control-block snapshots (one batch behind the launches)

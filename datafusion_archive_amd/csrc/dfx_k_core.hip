@@ -21,6 +21,8 @@
 
 #include <algorithm>
 
+#include <atomic>
+
 #include "dfx_kernels_inl.hpp"
 #include "dfx_launch.hpp"
 
@@ -32,7 +34,8 @@ uint64_t host_hash_keys(const uint64_t* key, int kw) {
     case 1: return hash_keys<1>(key);
     case 2: return hash_keys<2>(key);
     case 3: return hash_keys<3>(key);
-    default: return hash_keys<4>(key);
+    case 4: return hash_keys<4>(key);
+    default: return hash_keys<8>(key);
   }
 }
 
@@ -311,13 +314,15 @@ __global__ __launch_bounds__(kBlock, (POL::kStaticNa == 0 && sizeof(typename POL
     for (int o = 0; o < kFusedOutCols; ++o) {
       if (o < O.n) {
         const uint8_t t = O.dtype[o];
+        // (the output buffers hold O.cap_rows rows: what lies beyond is the host's to compact again)
+        const uint32_t room = my_base >= O.cap_rows ? 0u : (O.cap_rows - my_base < (uint64_t)cnt ? (uint32_t)(O.cap_rows - my_base) : cnt);
         if (cnt <= (uint32_t)kFusedStage) {  // (wave-uniform) everything this wave kept is parked in LDS
           const uint64_t* src = stage + (size_t)(o * NW + wave) * kFusedStage;
           if (t == T_F64 || t == T_I64 || t == T_U64) {
             uint64_t* dst = (uint64_t*)O.out[o] + my_base;
-            for (uint32_t j = (uint32_t)lane; j < cnt; j += 64) dst[j] = src[j];
+            for (uint32_t j = (uint32_t)lane; j < room; j += 64) dst[j] = src[j];
           } else {
-            for (uint32_t j = (uint32_t)lane; j < cnt; j += 64) store_typed(t, O.out[o], (int64_t)(my_base + j), src[j]);
+            for (uint32_t j = (uint32_t)lane; j < room; j += 64) store_typed(t, O.out[o], (int64_t)(my_base + j), src[j]);
           }
         } else {  // a dense tile: its passing rows are read again (bitmap words from LDS), as k_compact would
           const int slot = O.slot[o];
@@ -327,7 +332,8 @@ __global__ __launch_bounds__(kBlock, (POL::kStaticNa == 0 && sizeof(typename POL
             if ((word >> lane) & 1ull) {
               const int64_t row = (tile * kTileWords + i) * 64 + lane;
               const uint64_t v = load_canonical(t, C.c[slot].values, row, C.c[slot].bit_offset);
-              store_typed(t, O.out[o], (int64_t)(my_base + run + mbcnt_u64(word)), v);
+              const uint32_t at = run + mbcnt_u64(word);
+              if (at < room) store_typed(t, O.out[o], (int64_t)(my_base + at), v);
             }
             run += (uint32_t)__popcll(word);
           }
@@ -897,16 +903,19 @@ static hipError_t filter_fused_launch(const DevProgram& P, const DevFastPlan& fa
   const size_t lds = (size_t)O.n * kFusedTiles * kFusedStage * sizeof(uint64_t);
   // the grid must be co-resident (the look-back waits for other workgroups): workgroups per CU from the occupancy API,
   // asked once per (policy, LDS size)
-  static int per_cu[kFusedOutCols + 1] = {0, 0, 0};
-  if (per_cu[O.n] == 0) {
+  // (one device per process -- ctx().device --; the cache is atomic: two threads that both miss compute the same answer)
+  static std::atomic<int> per_cu[kFusedOutCols + 1];
+  int wg_per_cu = per_cu[O.n].load(std::memory_order_relaxed);
+  if (wg_per_cu == 0) {
     int nb = 0;
     hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_filter_fused<POL>, kBlock, lds);
     if (e != hipSuccess) return e;
-    per_cu[O.n] = nb > 0 ? nb : 1;
+    wg_per_cu = nb > 0 ? nb : 1;
+    per_cu[O.n].store(wg_per_cu, std::memory_order_relaxed);
   }
   const int64_t tiles = (n + kTileRows - 1) / kTileRows;
   const int64_t units = (tiles + kFusedTiles - 1) / kFusedTiles;
-  const int64_t cap = (int64_t)device_cu_count() * per_cu[O.n];
+  const int64_t cap = (int64_t)device_cu_count() * wg_per_cu;
   const int grid = (int)(units < cap ? units : cap);
   hipLaunchKernelGGL((k_filter_fused<POL>), dim3(grid), dim3(kBlock), lds, s, P, fast, C, pred, n, mask_words, tile_offsets, sync, O, ctrl);
   return hipGetLastError();
@@ -1029,6 +1038,7 @@ DFX_DECLARE_TABLE_KW(1)
 DFX_DECLARE_TABLE_KW(2)
 DFX_DECLARE_TABLE_KW(3)
 DFX_DECLARE_TABLE_KW(4)
+DFX_DECLARE_TABLE_KW(8)
 
 #define DFX_KW_DISPATCH(kw, CALL)            \
   switch (kw) {                              \
@@ -1036,6 +1046,7 @@ DFX_DECLARE_TABLE_KW(4)
     case 2: return CALL(2);                  \
     case 3: return CALL(3);                  \
     case 4: return CALL(4);                  \
+    case 8: return CALL(8);                  \
     default: return hipErrorInvalidValue;    \
   }
 

@@ -921,6 +921,12 @@ Status FilterRelation::next(DeviceBatch* out, bool* has) {
     DevFusedOut O;
     memset(&O, 0, sizeof(O));
     double out_bytes = 0;
+    // Output buffers sized from the selectivity this stream has shown so far (the first batch: every row): a 2^27-row batch of
+    // two Float64 predicate columns pinned 2 GB of HBM however few rows it kept.  A batch that keeps more than its buffers hold
+    // has those columns compacted again from the bitmap below (k_compact): a second read of the column, paid only then.
+    const uint64_t fused_cap = sel_seen_ < 0.0 ? (uint64_t)n
+                                               : std::min<uint64_t>((uint64_t)n, (uint64_t)((double)n * std::min(1.0, 1.5 * sel_seen_ + 0.02)) + 4096);
+    O.cap_rows = fused_cap;
     const std::vector<int>& pcols = builder_->columns();
     for (size_t slot = 0; slot < pcols.size() && O.n < kFusedOutCols && !any_boolean; ++slot) {
       const int ci = pcols[slot];
@@ -930,7 +936,7 @@ Status FilterRelation::next(DeviceBatch* out, bool* has) {
       if ((size_t)ci < out_needed_.size() && !out_needed_[ci]) continue;  // projection push-down: nobody reads it
       if (fused_vals[ci]) continue;
       const int w = dtype_width(ic.dtype);
-      auto vals = device_alloc((size_t)n * w, &st);  // worst case: every row kept (the count is known when the kernel ends)
+      auto vals = device_alloc((size_t)std::max<uint64_t>(fused_cap, 1) * w, &st);
       if (!vals) return st;
       fused_vals[ci] = vals;
       O.slot[O.n] = (uint8_t)slot;
@@ -958,7 +964,25 @@ Status FilterRelation::next(DeviceBatch* out, bool* has) {
     kept = (uint64_t)hc[CTRL_PASSED_LO] | ((uint64_t)hc[CTRL_PASSED_HI] << 32);
     errbits = hc[CTRL_ERROR];
     single_pass_done = true;
-  } else {
+    if (errbits == 8u) {
+      // The look-back gave up waiting (its grid is sized for an EMPTY device: other work on the GPU -- another process, a
+      // multi-rank dry run -- can keep a workgroup from becoming resident).  Not an error of the query: this batch takes the
+      // two-pass form, which has no inter-workgroup waits.
+      DFX_HIP(hipMemsetAsync(ctrl_.get(), 0, sizeof(uint32_t) * CTRL_WORDS, s));
+      for (auto& v : fused_vals) v.reset();
+      errbits = 0;
+      kept = 0;
+      single_pass_done = false;
+      ++counters().filter_lookback_fallbacks;
+    } else if (errbits == 0) {
+      sel_seen_ = std::max(sel_seen_, n > 0 ? (double)kept / (double)n : 0.0);
+      if (kept > fused_cap) {  // denser than the stream had been: the kernel stored what fitted; these columns are compacted again below
+        for (auto& v : fused_vals) v.reset();
+        ++counters().filter_output_regrows;
+      }
+    }
+  }
+  if (!single_pass_done) {
     DFX_HIP(launch_predicate_mask(prog, fp, cols, pred_operand_, n, (uint64_t*)mask.get(), (uint32_t*)counts.get(),
                                   (uint32_t*)ctrl_.get(), in_bytes, s));
     if (!more_.empty()) {  // the other conjuncts: their masks are ANDed into the first, the tile counts redone
@@ -978,8 +1002,6 @@ Status FilterRelation::next(DeviceBatch* out, bool* has) {
     }
     DFX_HIP(launch_scan_u32((const uint32_t*)counts.get(), (uint64_t*)offsets.get(), n_tiles, (uint64_t*)tmp.get(), s));
     DFX_HIP(hipMemcpyAsync(&kept, (uint64_t*)offsets.get() + n_tiles, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
-  }
-  if (!single_pass_done) {
     DFX_HIP(hipMemcpyAsync(&errbits, (uint32_t*)ctrl_.get() + CTRL_ERROR, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     DFX_HIP(hipStreamSynchronize(s));
   }

@@ -158,6 +158,7 @@ class FilterRelation : public Relation {
   Status deferred_;  // evaluation-time type errors of the reference surface on next()
   std::shared_ptr<void> ctrl_;
   mutable OperatorOptions opt_;
+  double sel_seen_ = -1.0;    // largest kept / rows of a batch so far (-1: none yet): sizes the single-pass kernel's output buffers
   bool source_told_ = false;  // this operator's option set has reached the host source below (before the first batch is pulled)
   std::shared_ptr<void> ctrl_host_;  // pinned copy of the control block (kept count + error bits of a batch)
   std::vector<char> out_needed_;  // empty: every column is compacted

@@ -422,6 +422,8 @@ int64_t dfx_counter_get(const char* name) {
   if (!name) return -1;
   if (!strcmp(name, "h2d_bytes")) return counters().h2d_bytes;
   if (!strcmp(name, "h2d_staged_bytes")) return counters().h2d_staged_bytes;
+  if (!strcmp(name, "filter_output_regrows")) return counters().filter_output_regrows;
+  if (!strcmp(name, "filter_lookback_fallbacks")) return counters().filter_lookback_fallbacks;
   if (!strcmp(name, "csv_cells")) return counters().csv_cells;
   if (!strcmp(name, "agg_ctrl_wait_us")) return counters().agg_ctrl_wait_us;
   if (!strcmp(name, "agg_sync_us")) return counters().agg_sync_us;

@@ -268,6 +268,25 @@ def test_filter_single_pass_and_two_pass_agree_with_the_oracle(single_pass, fast
             assert_batches_identical(got[1], oracle.filter_next(pred, b.slice(777, 4096 * 3 + 5)), "sliced")
 
 
+def test_filter_single_pass_output_buffers_follow_the_selectivity():
+    """The single-pass kernel's output buffers are sized from the selectivity the stream has shown so far (round 3 allocated
+    rows x width per predicate column and batch whatever was kept: 2 GB per 2^27-row batch of two Float64 columns).  A batch
+    that keeps MORE than its buffers hold must still be right: the kernel stores what fits, the columns are compacted again
+    from the bitmap.  Batches: selective, selective, dense (every row), selective, empty selection -- against fn filter."""
+    rng = np.random.default_rng(99)
+    n = 64 * 4096 + 77
+    def batch(lo, hi):
+        return pa.RecordBatch.from_arrays([pa.array(lo + (hi - lo) * rng.random(n)), pa.array(rng.integers(0, 1000, n).astype(np.int64))], names=["lat", "k"])
+    pred = BinaryExpr(BinaryExpr(Column(0), Operator.Gt, lit(51.0)), Operator.And, BinaryExpr(Column(1), Operator.Lt, ilit(900)))
+    batches = [batch(40.0, 51.2), batch(40.0, 51.2), batch(52.0, 59.0), batch(40.0, 51.1), batch(10.0, 20.0), batch(49.0, 59.0)]
+    ex.counter_reset()
+    got = gpu_filter(pred, batches[0].schema, batches)
+    assert len(got) == len(batches)
+    for i, (g, b) in enumerate(zip(got, batches)):
+        assert_batches_identical(g, oracle.filter_next(pred, b), f"batch {i}")
+    assert ex.counter_get("filter_output_regrows") >= 1, "the dense batch after the selective ones must have outgrown its buffers"
+
+
 def test_per_operator_options_override_the_process_defaults_for_one_operator_only():
     """dfx_aggregate_relation_new_with_options / dfx_filter_relation_new_with_options: the option set belongs to the operator.
     Two aggregates over the same rows in one process, one forced to the global-atomic table, one to the partitioned strategy,
@@ -547,6 +566,35 @@ def test_grouped_multi_column_keys(strategy):
     for keys in ([Column(0), Column(1)], [Column(0), Column(1), Column(2)]):
         got = gpu_aggregate(keys, aggs, b.schema, [b])
         assert_groups_identical(got, oracle.aggregate(keys, aggs, [b]), len(keys), f"{len(keys)} keys")
+
+
+@pytest.mark.parametrize("strategy", [0, 1, 2])
+def test_grouped_five_to_eight_key_columns(strategy):
+    """The reference's key is a Vec<GroupByScalar> of any length (aggregate.rs:807-852); round 3 stopped at four key words.
+    Five to eight key columns run as EIGHT key words (the table kernels are built for 1, 2, 3, 4 and 8 words; fewer than
+    eight are padded with constant zero words that never reach the result): Int8 ... UInt64 and Utf8 keys mixed, nulls in
+    the argument, a predicate, two batches; nine keys are NotImplemented, reported before any row is read."""
+    ex.set_option("agg.strategy", strategy)
+    rng = np.random.default_rng(88)
+    n = 60000
+    cols = [pa.array(rng.integers(0, 3, n).astype(np.int64)), pa.array(rng.integers(-2, 2, n).astype(np.int32)),
+            pa.array(rng.integers(0, 4, n).astype(np.uint8)), pa.array(rng.integers(-1, 2, n).astype(np.int16)),
+            pa.array(rng.integers(0, 2, n).astype(np.uint64)), pa.array(["s%d" % x for x in rng.integers(0, 3, n)]),
+            pa.array(rng.integers(0, 2, n).astype(np.int8)), pa.array(rng.integers(5, 7, n).astype(np.uint32)),
+            pa.array(rng.integers(0, 2, n).astype(np.int64)),
+            pa.array(rng.integers(0, 2**20, n).astype(np.float64) * 2.0 ** -10, mask=rng.random(n) < 0.05)]
+    b = pa.RecordBatch.from_arrays(cols, names=["a", "b", "c", "d", "e", "f", "g", "h", "i", "v"])
+    aggs = [agg("sum", Column(9), F64), agg("count", Column(9), DataType.UInt64), agg("max", Column(9), F64)]
+    pred = BinaryExpr(Column(0), Operator.LtEq, ilit(1))
+    for nk in (5, 6, 8):
+        keys = [Column(i) for i in range(nk)]
+        for filt in (None, pred):
+            got = gpu_aggregate(keys, aggs, b.schema, [b.slice(0, 40000), b.slice(40000)], filter_expr=filt)
+            want_in = [b] if filt is None else [oracle.filter_next(filt, b)]
+            assert_groups_identical(got, oracle.aggregate(keys, aggs, want_in), nk, f"{nk} keys, strategy {strategy}, filter {filt is not None}")
+    with pytest.raises(ex.ExecutionError) as ei:
+        gpu_aggregate([Column(i) for i in range(9)], aggs, b.schema, [b])
+    assert ei.value.kind == "NotImplemented" and "more than 8 GROUP BY expressions" in ei.value.message
 
 
 @pytest.mark.parametrize("fast", [1, 0])
