@@ -324,18 +324,48 @@ __global__ __launch_bounds__(kBlock, (POL::kStaticNa == 0 && sizeof(typename POL
           } else {
             for (uint32_t j = (uint32_t)lane; j < room; j += 64) store_typed(t, O.out[o], (int64_t)(my_base + j), src[j]);
           }
-        } else {  // a dense tile: its passing rows are read again (bitmap words from LDS), as k_compact would
+        } else {  // a dense tile: its passing rows are read again (bitmap words from LDS), as k_compact would -- the tile was
+                  // streamed through this CU microseconds ago, so the second read is an L2 / Infinity Cache hit, not HBM traffic.
+                  // Eight row groups per step, their loads issued together: one dependent load -> store round trip per row group
+                  // (64 per tile) made selectivities above a quarter cost 2.5 x the selective case (cfg2_filter_dense_sel50: 0.29).
           const int slot = O.slot[o];
+          constexpr int kStep = 8;
+          static_assert(kTileWords % kStep == 0, "whole steps");
           uint32_t run = 0;
-          for (int i = 0; i < kTileWords; ++i) {
-            const uint64_t word = s_words[wave * kTileWords + i];
-            if ((word >> lane) & 1ull) {
-              const int64_t row = (tile * kTileWords + i) * 64 + lane;
-              const uint64_t v = load_canonical(t, C.c[slot].values, row, C.c[slot].bit_offset);
-              const uint32_t at = run + mbcnt_u64(word);
-              if (at < room) store_typed(t, O.out[o], (int64_t)(my_base + at), v);
+          const int64_t n_rows_m1 = n - 1;
+          // (the width is decided once per tile, outside the steps: a dtype switch around every load would put a join --
+          // and a conservative wait -- between them)
+          auto steps = [&](auto load_one, auto store_one) {
+            for (int i0 = 0; i0 < kTileWords; i0 += kStep) {
+              uint64_t word[kStep], v[kStep];
+#pragma unroll
+              for (int j = 0; j < kStep; ++j) {
+                word[j] = s_words[wave * kTileWords + i0 + j];
+                int64_t row = (tile * kTileWords + i0 + j) * 64 + lane;
+                row = row < n_rows_m1 ? row : n_rows_m1;  // (unconditional loads: rows past the end are never selected)
+                v[j] = load_one(row);
+              }
+#pragma unroll
+              for (int j = 0; j < kStep; ++j) {
+                if ((word[j] >> lane) & 1ull) {
+                  const uint32_t at = run + mbcnt_u64(word[j]);
+                  if (at < room) store_one(my_base + at, v[j]);
+                }
+                run += (uint32_t)__popcll(word[j]);
+              }
             }
-            run += (uint32_t)__popcll(word);
+          };
+          if (t == T_F64 || t == T_I64 || t == T_U64) {
+            const uint64_t* in8 = (const uint64_t*)C.c[slot].values;
+            uint64_t* out8 = (uint64_t*)O.out[o];
+            steps([&](int64_t row) { return in8[row]; }, [&](uint64_t at, uint64_t v) { out8[at] = v; });
+          } else if (t == T_I32 || t == T_U32 || t == T_F32) {
+            const uint32_t* in4 = (const uint32_t*)C.c[slot].values;
+            uint32_t* out4 = (uint32_t*)O.out[o];
+            steps([&](int64_t row) { return (uint64_t)in4[row]; }, [&](uint64_t at, uint64_t v) { out4[at] = (uint32_t)v; });
+          } else {
+            steps([&](int64_t row) { return load_canonical(t, C.c[slot].values, row, C.c[slot].bit_offset); },
+                  [&](uint64_t at, uint64_t v) { store_typed(t, O.out[o], (int64_t)at, v); });
           }
         }
       }
