@@ -634,19 +634,20 @@ def main():
             for b_ in bg.values():
                 b_.t.join()
             dh, _ = timed(host_step, 4, 1)
-            e = rate(4 * hb_rows * 4, dh, 16, "the headline query over host Arrow batches (4 x 2^24 rows), H2D inside the timed region: pinned staging ring filled "
-                     "by 4 library threads, DMA on a copy stream (host.stream = 1, the default)")
+            e = rate(4 * hb_rows * 4, dh, 16, "the headline query over host Arrow batches (4 x 2^24 rows), H2D inside the timed region: pageable copies in order "
+                     "on the library's stream (host.stream = 0, the default: the fastest of the four forms measured, profiles/r04_host_stream_matrix.txt)")
             e["roofline"] = {"bound": "pcie", "achieved": e["roofline"]["achieved"], "peak": 63.0, "unit": "GB/s",
                              "frac": round(e["roofline"]["achieved"] / 63.0, 4)}
             extra["host_streamed_pcie_inclusive"] = e
-            ex.set_option("host.stream", 0)  # round 3's default for comparison: pageable copies in order on the library's stream
+            ex.set_option("host.stream", 1)  # round 4's pinned staging ring (8 library threads, 6 x 16 MB slots)
             try:
-                dh0, _ = timed(host_step, 2, 1)
+                dh1, _ = timed(host_step, 2, 1)
             finally:
-                ex.set_option("host.stream", 1)
-            e0 = rate(4 * hb_rows * 2, dh0, 16, "the same with host.stream = 0 (hipMemcpyAsync of the pageable buffers, one stream synchronisation per batch)")
-            e0["roofline"] = {"bound": "pcie", "achieved": e0["roofline"]["achieved"], "peak": 63.0, "unit": "GB/s", "frac": round(e0["roofline"]["achieved"] / 63.0, 4)}
-            extra["host_streamed_in_order_pageable"] = e0
+                ex.set_option("host.stream", 0)
+            e1 = rate(4 * hb_rows * 2, dh1, 16, "the same with host.stream = 1: a ring of pinned slots filled by 8 library threads, DMA on a copy stream (slower: the staging "
+                      "copy triples the host-memory traffic per byte moved)")
+            e1["roofline"] = {"bound": "pcie", "achieved": e1["roofline"]["achieved"], "peak": 63.0, "unit": "GB/s", "frac": round(e1["roofline"]["achieved"] / 63.0, 4)}
+            extra["host_streamed_staged_ring"] = e1
 
             def verify_host():
                 got = host_step()

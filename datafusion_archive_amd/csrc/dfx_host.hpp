@@ -167,14 +167,17 @@ struct DeviceBatch {
 // How a source of HOST Arrow batches moves them to HBM (AggOptions::host_*: "host.stream", "host.stage_threads",
 // "host.stage_mb", "host.stage_slots"; an operator's own option set reaches its source through Relation::host_stream_options)
 struct HostStreamOptions {
-  int mode = 1;      // 1 (default) staged: library threads copy the producer's buffers into a ring of pinned slots while the DMA
-                     //   engine drains the slots filled before -- the engine reads pinned memory at 57 GB/s, one CPU thread fills
-                     //   it at 29; 0 in order: hipMemcpyAsync of the pageable buffers on the library's stream (HIP pins chunk-wise
-                     //   inside the runtime: 53-54 GB/s) and one stream synchronisation per batch; 2 one batch ahead on a copy stream;
-                     //   3 = 2 + the producer's large buffers page-locked in place (hipHostRegister)
-  int threads = 4;   // staged: threads filling slots
-  int piece_mb = 8;  // staged: bytes per slot (a column buffer travels in pieces of this size)
-  int slots = 8;     // staged: pinned slots (slots x piece_mb of pinned memory per source)
+  int mode = 0;      // 0 (default) in order: hipMemcpyAsync of the pageable buffers on the library's stream (HIP pins chunk-wise
+                     //   inside the runtime) and one stream synchronisation per batch: 53.6 GB/s = 0.85 of the link, the best of the
+                     //   four forms on this platform (profiles/r04_host_stream_matrix.txt);
+                     //   1 staged: library threads copy the producer's buffers into a ring of pinned slots while the DMA engine
+                     //   drains the slots filled before, the producer's array released when its bytes have been copied out -- built in
+                     //   round 4 to reach the engine's 57 GB/s from pinned memory; measured 38-46 GB/s whatever the thread count (2-16),
+                     //   slot size (2-32 MB) or ring depth: the staging copy triples the host-memory traffic per byte moved;
+                     //   2 one batch ahead on a copy stream (51.6 GB/s); 3 = 2 + the producer's large buffers page-locked in place
+  int threads = 8;   // staged: threads filling slots
+  int piece_mb = 16; // staged: bytes per slot (a column buffer travels in pieces of this size)
+  int slots = 6;     // staged: pinned slots (slots x piece_mb of pinned memory per source)
 };
 
 enum RelationKind { REL_HOST_STREAM, REL_TABLE_SCAN, REL_FILTER, REL_PROJECT, REL_AGGREGATE, REL_CSV, REL_SORT, REL_LIMIT };

@@ -159,7 +159,8 @@ class HostStreamRelation : public Relation {
     return Status::OK();
   }
 
-  // The staged form (default).  The DMA engine reads PINNED host memory at 57 GB/s and pageable memory not at all: HIP's own
+  // The staged form (host.stream = 1; NOT the default: measured slower than HIP's own pageable copy on this platform, see
+  // HostStreamOptions).  The DMA engine reads PINNED host memory at 57 GB/s and pageable memory not at all: HIP's own
   // copy of a pageable buffer pins it chunk-wise inside the runtime (53-54 GB/s, the calling thread blocked throughout), locking
   // the producer's pages in place costs half the transfer's time (tools/pin_probe.py).  Here the library owns a ring of pinned
   // slots; `threads` library threads copy the producer's buffers into slots piece by piece (one thread fills at ~29 GB/s: it
@@ -459,7 +460,7 @@ class HostStreamRelation : public Relation {
   bool prefetch_ = false;  // HostStreamOptions::mode >= 2 (was DFX_HOST_PREFETCH)
   HostStreamOptions hopt_;
   bool opts_set_ = false;
-  int mode() const { return hopt_.mode < 0 || hopt_.mode > 3 ? 1 : hopt_.mode; }
+  int mode() const { return hopt_.mode < 0 || hopt_.mode > 3 ? 0 : hopt_.mode; }
   size_t ring_piece_bytes() const { return (size_t)std::max(1, hopt_.piece_mb) << 20; }
   // staged form
   bool staging_ = false;

@@ -88,11 +88,11 @@ struct AggOptions {
                                // kernel, every wave scans and routes
   int merge_scan_batches = 1;  // an aggregate over a scan of a resident table asks for slices of >= 2^27 rows (one per routing window)
                                // whatever batch width the scan was created with; 0: the caller's batch width is kept
-  int host_stream = 1;         // host Arrow batches -> HBM (HostStreamOptions::mode): 1 pinned staging ring filled by library threads,
-                               // 0 in-order pageable copies, 2 one batch ahead on a copy stream, 3 = 2 + page-locking in place
-  int host_stage_threads = 4;  // ... threads that fill the ring
-  int host_stage_mb = 8;       // ... bytes per slot
-  int host_stage_slots = 8;    // ... slots
+  int host_stream = 0;         // host Arrow batches -> HBM (HostStreamOptions::mode): 0 in-order pageable copies (default: measured fastest),
+                               // 1 pinned staging ring filled by library threads, 2 one batch ahead on a copy stream, 3 = 2 + page-locking in place
+  int host_stage_threads = 8;  // ... threads that fill the ring
+  int host_stage_mb = 16;      // ... bytes per slot
+  int host_stage_slots = 6;    // ... slots
   int filter_single_pass = 1;  // FilterRelation: predicate + bitmap + tile offsets (decoupled look-back) + compaction of the predicate's own
                                // columns in ONE kernel (0: k_predicate_mask -> scan -> k_compact, the column is read twice)
   int replay_in_place = 1;     // 1: rows spilled by a table that is NOT full (region overflow of a heavy key) are replayed into the

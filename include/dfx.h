@@ -424,11 +424,12 @@ int64_t dfx_relation_explain(struct ArrowArrayStream* stream, char* buf, size_t 
  *                            widened, nulls by arrow's comparison rule): 1 wherever the shape is covered and no compile-time
  *                            signature matches (default), 0 never (round 3's dispatch), 2 also instead of the signatures
  *   "host.stream"            how HOST Arrow batches reach HBM (also a per-operator option: the first operator above a host
- *                            source decides): 1 pinned staging ring filled by library threads, DMA on a copy stream, the
- *                            producer's array released when its bytes have been copied out (default); 0 pageable copies in
- *                            order on the library's stream; 2 one batch ahead on a copy stream; 3 = 2 + large buffers
- *                            page-locked in place.  "host.stage_threads" (4), "host.stage_mb" (8: bytes per pinned slot),
- *                            "host.stage_slots" (8) size the ring
+ *                            source decides): 0 pageable copies in order on the library's stream, the producer's array
+ *                            released after the stream has passed them (default: 0.85 of the link, the fastest form measured);
+ *                            1 pinned staging ring filled by library threads, DMA on a copy stream, the array released when its
+ *                            bytes have been copied out; 2 one batch ahead on a copy stream; 3 = 2 + large buffers page-locked
+ *                            in place.  "host.stage_threads" (8), "host.stage_mb" (16: bytes per pinned slot),
+ *                            "host.stage_slots" (6) size the ring of form 1
  *   "pool.trim"              (any value) return the cached device buffers to the driver */
 int32_t dfx_set_option(const char* key, int64_t value);
 /* Measurement counters: "h2d_bytes" (column bytes the uploaders copied host -> device), "h2d_staged_bytes" (of which through

@@ -586,12 +586,14 @@ def test_grouped_five_to_eight_key_columns(strategy):
     b = pa.RecordBatch.from_arrays(cols, names=["a", "b", "c", "d", "e", "f", "g", "h", "i", "v"])
     aggs = [agg("sum", Column(9), F64), agg("count", Column(9), DataType.UInt64), agg("max", Column(9), F64)]
     pred = BinaryExpr(Column(0), Operator.LtEq, ilit(1))
-    for nk in (5, 6, 8):
+    # (a fused program reads at most 8 distinct columns: eight keys leave room for aggregates of the keys themselves only)
+    aggs8 = [agg("count", Column(0), DataType.UInt64), agg("max", Column(1), DataType.Int32), agg("sum", Column(4), DataType.UInt64)]
+    for nk, these in ((5, aggs), (6, aggs), (7, aggs), (8, aggs8)):
         keys = [Column(i) for i in range(nk)]
         for filt in (None, pred):
-            got = gpu_aggregate(keys, aggs, b.schema, [b.slice(0, 40000), b.slice(40000)], filter_expr=filt)
+            got = gpu_aggregate(keys, these, b.schema, [b.slice(0, 40000), b.slice(40000)], filter_expr=filt)
             want_in = [b] if filt is None else [oracle.filter_next(filt, b)]
-            assert_groups_identical(got, oracle.aggregate(keys, aggs, want_in), nk, f"{nk} keys, strategy {strategy}, filter {filt is not None}")
+            assert_groups_identical(got, oracle.aggregate(keys, these, want_in), nk, f"{nk} keys, strategy {strategy}, filter {filt is not None}")
     with pytest.raises(ex.ExecutionError) as ei:
         gpu_aggregate([Column(i) for i in range(9)], aggs, b.schema, [b])
     assert ei.value.kind == "NotImplemented" and "more than 8 GROUP BY expressions" in ei.value.message
@@ -1389,19 +1391,19 @@ def test_aggregate_over_a_table_scan_merges_small_scan_batches():
     assert_groups_identical(res[1], want, 1, "merged scan batches vs oracle")
 
 
-@pytest.mark.parametrize("mode", ["staged ring (default)", "staged ring as the operator's own option", "in order", "one batch ahead", "one batch ahead + pinned in place"])
+@pytest.mark.parametrize("mode", ["in order (default)", "staged ring", "staged ring as the operator's own option", "one batch ahead", "one batch ahead + pinned in place"])
 def test_host_batches_are_borrowed_until_their_copy_has_finished(tmp_path, mode):
     """Row (g) of the round-2 review: the producer's release callback must fire only after the copy of ITS batch has read the
-    buffers -- in every form of the host stream (csrc/dfx_relation.cpp; option "host.stream"): the pinned staging ring (1, the
-    default since round 4: library threads copy the producer's buffers into pinned slots, the array is released when they have
-    joined), in order (0: copies on the library's stream, release after the synchronisation), one batch ahead on a copy stream
+    buffers -- in every form of the host stream (csrc/dfx_relation.cpp; option "host.stream"): in order (0, the default: copies
+    on the library's stream, release after the synchronisation), the pinned staging ring (1, round 4: library threads copy the
+    producer's buffers into pinned slots, the array is released when they have joined), one batch ahead on a copy stream
     (2: release on the copy's event) and with the producer's buffers page-locked in place on top of that (3).
     tests/c_abi/host_stream.c is a C producer that poisons and frees its buffers on release and checks every group of the result
     against the closed form; it also reports how many batches the library held at once (2 when it copies ahead, else 1)."""
     import subprocess
     from test_host_logic import _build_c_abi_program
     exe = _build_c_abi_program(tmp_path, "host_stream")
-    args = {"staged ring (default)": [], "staged ring as the operator's own option": ["1", "operator"], "in order": ["0"],
+    args = {"in order (default)": [], "staged ring": ["1"], "staged ring as the operator's own option": ["1", "operator"],
             "one batch ahead": ["2"], "one batch ahead + pinned in place": ["3"]}[mode]
     for rows, batches in ((1 << 22, 6), (1000, 5), (1 << 20, 1), (300000, 3)):  # large (page-locked when asked for) and small buffers
         r = subprocess.run([exe, str(rows), str(batches)] + args, capture_output=True, text=True, timeout=300)
