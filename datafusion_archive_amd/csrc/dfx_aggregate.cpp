@@ -80,6 +80,18 @@ struct AggregateRelation::Impl {
   };
   std::vector<Chunk> chunks;
   int cur_chunk = 0;
+  // ONE key, several aggregates of DIFFERENT operands (SUM(v), MIN(w) ...): under the partitioned strategy a scan per aggregate --
+  // each through the one-value kernels (12-byte routed rows, 256 partitions, the wave-specialised pass 1, the lean pass 2) -- beats
+  // one scan that routes a row per key with every operand (24-byte rows: 512 partitions, 4-row chunks: pass 1 alone 1.42 ms per 2^27
+  // rows against 2 x 0.43).  `single_chunks` holds that chunking, built at set-up; it replaces `chunks` when the strategy decision
+  // (calibration slice or the resident table's memo) says "partitioned" -- few groups keep the one scan for all aggregates.
+  std::vector<Chunk> single_chunks;
+  bool split_ready = false;     // single_chunks is built (used if agg.split_aggregates allows it when the operator runs)
+  bool split_done = false;      // ... and installed
+  bool split_decided = false;   // the strategy decision has been taken (whichever way)
+  bool stop_after_decision = false;  // consume_batch_chunk returns as soon as the strategy is decided (rows before `decided_rows` are done)
+  int64_t decided_rows = 0;
+  void install_chunks(std::vector<Chunk>&& next);
   int na_total = 0;
   uint8_t acc_kind_all[kMaxAccsTotal], val_xform_all[kMaxAccsTotal];
   uint64_t acc_init_all[kMaxAccsTotal];
@@ -285,6 +297,23 @@ Status AggregateRelation::Impl::setup(const SchemaInfo& input_schema) {
     val_xform[a] = val_xform_all[a];
     acc_init[a] = acc_init_all[a];
   }
+  // one key, two or more aggregates that do not all take the same operand: the per-aggregate chunking for the partitioned
+  // strategy (see single_chunks).  Built now so that a shape the one-aggregate programs cannot take shows up here, not mid-stream.
+  if (kw == 1 && kw_out == 1 && na_total >= 2 && chunks.size() == 1 && !shared_operand()) {  // (agg.split_aggregates is read when the operator runs: options freeze at first use)
+    std::vector<Chunk> singles;
+    bool ok = true;
+    for (int a = 0; a < na_total && ok; ++a) {
+      Chunk ch;
+      ch.a0 = a;
+      ch.n = 1;
+      ok = build_chunk_programs(ch).ok();
+      if (ok) singles.push_back(std::move(ch));
+    }
+    if (ok) {
+      single_chunks = std::move(singles);
+      split_ready = true;
+    }
+  }
   return Status::OK();
 }
 
@@ -386,6 +415,32 @@ Status AggregateRelation::Impl::build_chunk_programs(Chunk& ch) {
   return Status::OK();
 }
 
+// Replace the chunking (grouped aggregates only): the active chunk's members go back to their chunk, `next` becomes the
+// chunk list, its first chunk the active one.  The accumulator planes are per ACCUMULATOR, not per chunk: nothing moves.
+void AggregateRelation::Impl::install_chunks(std::vector<Chunk>&& next) {
+  auto swap_with = [&](Chunk& ch) {
+    std::swap(builder, ch.builder);
+    std::swap(builder_np, ch.builder_np);
+    std::swap(plan, ch.plan);
+    std::swap(plan_np, ch.plan_np);
+    std::swap(fast, ch.fast);
+    std::swap(fast_np, ch.fast_np);
+  };
+  swap_with(chunks[(size_t)cur_chunk]);
+  chunks = std::move(next);
+  cur_chunk = 0;
+  swap_with(chunks[0]);
+  const Chunk& ch = chunks[0];
+  na = ch.n;
+  for (int a = 0; a < na; ++a) {
+    acc_kind[a] = acc_kind_all[ch.a0 + a];
+    val_xform[a] = val_xform_all[ch.a0 + a];
+    acc_init[a] = acc_init_all[ch.a0 + a];
+  }
+  if (kw > 0 && accs_full) T = view_of(T, accs_full, 0);
+  pt_layout_valid = false;  // (routed rows change width)
+}
+
 // Make chunk c the active one: programs, accumulator algebra, ungrouped buffers and the table view.
 void AggregateRelation::Impl::activate(int c) {
   if (c == cur_chunk) return;
@@ -476,6 +531,7 @@ Status AggregateRelation::Impl::alloc_table(int cap_log2, DevTable* Tn, std::vec
   {  // probing block = what one workgroup can hold in 128 KB of LDS (keys + the accumulators of the widest chunk)
     int widest = 1;
     for (const Chunk& ch : chunks) widest = std::max(widest, ch.n);
+    if (split_ready && opt().split_aggregates) widest = 1;  // (the partitioned strategy will run one accumulator per scan: blocks of 8192 slots, 256 partitions)
     uint64_t blk = 16384 / (uint64_t)(std::max(kw, 1) + widest);  // 128 KB of LDS per block (pass 2: one workgroup per CU)
     uint64_t p2 = 64;
     while (p2 * 2 <= blk) p2 *= 2;
@@ -1145,6 +1201,11 @@ Status AggregateRelation::Impl::consume_batch_chunk(const DeviceBatch& b) {
   } else if (!lds_calibrated) {
     if (o.strategy == 1) lds_enabled = false;
   }
+  if (stop_after_decision && lds_calibrated) {  // (consume_batch: the decision is what was asked for; rows [0, row0) are done)
+    decided_rows = row0;
+    rows_seen += row0;
+    return Status::OK();
+  }
   {  // a scan that routes most of its rows: launches of at most partition_split_rows rows (regions sized for that many)
     // (selective scans: twice that -- 2^27-row launches measured best, 2^28-row ones 7 % slower)
     const int64_t split = (use_partition && o.partition_split_rows >= (1 << 20)) ? (((int64_t)o.partition_split_rows * (dense_seen ? 1 : 2)) & ~(int64_t)63) : 0;
@@ -1170,13 +1231,63 @@ Status AggregateRelation::Impl::consume_batch_chunk(const DeviceBatch& b) {
     DFX_RETURN_IF_ERROR(examine_ctrl(prev)); // the previous batch's snapshot (normally complete by now)
   }
   rows_seen += n;
+  if (stop_after_decision) decided_rows = n;  // (a batch too small for a calibration slice: it ran whole, decided afterwards)
   return Status::OK();
 }
 
 // One input batch through every chunk of accumulators.  With several chunks each chunk's kernels are checked
 // synchronously (errors, spilled rows, growth) before the next chunk runs: the spill list and the routing scratch carry
 // rows of ONE chunk's width at a time.
+static DeviceBatch rows_from(const DeviceBatch& b, int64_t row0) {  // rows [row0, end) of a batch, zero copy (row0: a multiple of 64)
+  DeviceBatch r;
+  r.num_rows = b.num_rows - row0;
+  r.columns.reserve(b.columns.size());
+  for (const DeviceColumn& c : b.columns) {
+    DeviceColumn s = c;
+    s.length = r.num_rows;
+    if (!c.absent) {
+      if (c.dtype == DFX_UTF8) {
+        if (c.offsets) s.offsets = c.offsets + row0;
+        s.data_bytes = 0;
+      } else if (c.dtype == DFX_BOOLEAN) {
+        if (c.values) s.values = (const uint8_t*)c.values + (row0 >> 3);
+      } else if (c.values) {
+        s.values = (const uint8_t*)c.values + (size_t)row0 * dtype_width(c.dtype);
+      }
+      if (c.validity) s.validity = c.validity + (row0 >> 3);
+      if (c.null_count != 0) s.null_count = -1;
+    }
+    r.columns.push_back(std::move(s));
+  }
+  return r;
+}
+
 Status AggregateRelation::Impl::consume_batch(const DeviceBatch& b) {
+  if (split_ready && !split_done && !split_decided && opt().split_aggregates) {
+    // The strategy decision first (calibration slice, the resident table's memo, a forced strategy), with the all-aggregates
+    // program and nothing else of the batch; if it says "partitioned", the per-aggregate chunking takes over from there.
+    const bool forced = opt().strategy == 3;  // (no decision to wait for: the chunk loop below turns the strategy on itself)
+    if (forced) {
+      decided_rows = 0;
+    } else {
+      stop_after_decision = true;
+      decided_rows = 0;
+      Status st = consume_batch_chunk(b);
+      stop_after_decision = false;
+      DFX_RETURN_IF_ERROR(st);
+    }
+    split_decided = true;
+    if (use_partition || forced) {
+      DFX_RETURN_IF_ERROR(flush_pass2());
+      DFX_RETURN_IF_ERROR(settle_ctrl());
+      install_chunks(std::move(single_chunks));
+      single_chunks.clear();
+      split_done = true;
+    }
+    if (decided_rows >= b.num_rows) return Status::OK();
+    if (decided_rows == 0) return consume_batch(b);
+    return consume_batch(rows_from(b, decided_rows));
+  }
   if (chunks.size() <= 1) return consume_batch_chunk(b);
   for (int c = 0; c < (int)chunks.size(); ++c) {
     activate(c);

@@ -93,6 +93,8 @@ struct AggOptions {
   int host_stage_threads = 8;  // ... threads that fill the ring
   int host_stage_mb = 16;      // ... bytes per slot
   int host_stage_slots = 6;    // ... slots
+  int split_aggregates = 1;    // one key, several aggregates of different operands, many groups: a scan per aggregate through the one-value
+                               // kernels of the partitioned strategy (0: one scan that routes a row with every operand)
   int filter_single_pass = 1;  // FilterRelation: predicate + bitmap + tile offsets (decoupled look-back) + compaction of the predicate's own
                                // columns in ONE kernel (0: k_predicate_mask -> scan -> k_compact, the column is read twice)
   int replay_in_place = 1;     // 1: rows spilled by a table that is NOT full (region overflow of a heavy key) are replayed into the

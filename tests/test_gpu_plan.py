@@ -152,7 +152,12 @@ def test_plan_two_aggregates_of_different_operands_and_several_keys():
     """several accumulators / two keys (no one-value kernels): the plan looks its slots up (PlanPolicyN)"""
     syn = _syn(v_nulls=100, w_nulls=100)
     pred = AND(HEAD, BinaryExpr(Column(2), Operator.Lt, i64(900)))
-    _check("sum_v_max_w", syn, pred, [SUM_V, MAX_W, COUNT_V])
+    _check("sum_v_max_w", syn, pred, [SUM_V, MAX_W, COUNT_V])  # many groups: a scan per aggregate (agg.split_aggregates, the default)
+    _check("sum_v_max_w, one scan", syn, pred, [SUM_V, MAX_W, COUNT_V], opts=(("agg.split_aggregates", 0),))
+    ex.set_option("agg.split_aggregates", 1)
+    _check("sum_v_max_w, forced partitioned", syn, pred, [SUM_V, MAX_W, COUNT_V], opts=(("agg.strategy", 3),))
+    ex.set_option("agg.strategy", 0)
+    _check("sum_v_max_w, no predicate", _syn(), None, [SUM_V, MAX_W])
     # two keys: (k mod-free) k and w
     schema = _schema(syn)
     _s, _kept, want = oracle.run_synth_query(syn, SEED, 0, 1 << 20, 1024, pred, [Column(2)], [SUM_V, COUNT_V])
