@@ -604,7 +604,8 @@ def main():
             tw = ex.DeviceTable.synth(syn_w, seed, 0, n_rows)
             dgw, _ = timed(lambda: build_on(tw, schema_w, pred, [Column(0)], [sum_v, min_w]).next(), k3, 1)
             extra["different_operand_sum_min"] = rate(n_rows * k3, dgw, 24, "SELECT k, SUM(v), MIN(w) WHERE v > lo AND v < hi GROUP BY k (two aggregates of "
-                                                      "different operands: 24-byte routed rows {key, two operands}); 24 B/row read")
+                                                      "different operands over 10^6 groups: one scan per aggregate through the one-value kernels, agg.split_aggregates; "
+                                                      "round 3: one scan routing 24-byte rows {key, two operands}); 24 B/row of algorithmic bytes")
             del tw
             extra["different_operand_sum_min"]["verified_vs_oracle"] = verify_neighbour("different_operand_sum_min")
         except Exception as e:  # a measurement, not a gate
