@@ -956,7 +956,9 @@ Status AggregateRelation::Impl::launch_rows(const DeviceBatch& b, const DevProgr
     bytes += (double)n * (w ? w : 0.125);
   }
   DevAggPlan p = plan;
-  bool partition_now = use_partition;
+  // (while the per-aggregate chunking is pending -- the table's blocks are sized for one accumulator per scan -- the all-aggregates
+  // program never takes the partitioned strategy: its pass 2 would not fit a block into LDS)
+  bool partition_now = use_partition && !(split_ready && !split_done && opt().split_aggregates);
   if (partition_now) {
     Status pst = ensure_partition(launch_rows_hint > 0 ? std::max<int64_t>(n, std::min<int64_t>(launch_rows_hint, b.num_rows)) : std::max<int64_t>(n, b.num_rows), prog.has_nulls != 0);  // (the slice after the calibration rows: size for the whole batch)
     if (!pst.ok() && pst.code == DFX_NOT_IMPLEMENTED) partition_now = false;  // global-atomic path instead
@@ -1085,7 +1087,11 @@ Status AggregateRelation::Impl::consume_batch_chunk(const DeviceBatch& b) {
       std::swap(plan, plan_np);
       std::swap(fast, fast_np);
       unfused_now = true;
+      const bool stop = stop_after_decision;  // (the filtered batch is this call's own: it is consumed whole, whatever is decided on the way)
+      stop_after_decision = false;
       Status st = consume_batch_chunk(fb);
+      stop_after_decision = stop;
+      if (stop) decided_rows = b.num_rows;
       unfused_now = false;
       std::swap(builder, builder_np);
       std::swap(plan, plan_np);

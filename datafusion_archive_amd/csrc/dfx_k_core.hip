@@ -326,10 +326,10 @@ __global__ __launch_bounds__(kBlock, (POL::kStaticNa == 0 && sizeof(typename POL
           }
         } else {  // a dense tile: its passing rows are read again (bitmap words from LDS), as k_compact would -- the tile was
                   // streamed through this CU microseconds ago, so the second read is an L2 / Infinity Cache hit, not HBM traffic.
-                  // Sixteen row groups per step, their loads issued together: one dependent load -> store round trip per row group
+                  // Eight row groups per step, their loads issued together: one dependent load -> store round trip per row group
                   // (64 per tile) made selectivities above a quarter cost 2.5 x the selective case (cfg2_filter_dense_sel50: 0.29).
           const int slot = O.slot[o];
-          constexpr int kStep = 16;
+          constexpr int kStep = 8;  // (16 was measured: the selective path lost 13 % -- 0.588 -> 0.510 -- to the registers the dense path asked for)
           static_assert(kTileWords % kStep == 0, "whole steps");
           uint32_t run = 0;
           const int64_t n_rows_m1 = n - 1;
