@@ -130,7 +130,8 @@ struct DevPlanTerm {
 };
 struct DevScanPlan {
   int32_t valid;        // 0: shape not covered (then nothing below is meaningful)
-  int32_t gen;          // what this batch needs of the kernels: bit 0 a 4-byte column (widening loads), bit 1 a validity bitmap
+  int32_t gen;          // what this batch needs of the kernels: bit 0 a 4-byte column (widening loads), bit 1 a validity bitmap,
+                        // bit 2 (instead of bit 0; one-key kernels) the key is the ONLY 4-byte column: a real 4-byte load
   int32_t n_cols;       // plan column slots in use
   int32_t np;           // terms
   int32_t count_valid;  // 1: COUNT(x) looks at x's validity (no Filter below: fn filter's output is all-valid, filter.rs:83-92)

@@ -631,6 +631,21 @@ bool bind_scan_plan(const DevProgram& P, const DevFastPlan& F, const DevColumns&
   // under an absorbed predicate every surviving slot counts (and every other aggregate reads value(row) regardless,
   // aggregate.rs:561-603)
   S.count_valid = F.np == 0 ? 1 : 0;
+  // the Int32 / UInt32 key of a one-key kernel with nothing else to widen: its own flavour (a real 4-byte load of the key)
+  if (fixed && (gen & 1)) {
+    bool only_key = plan_class(P.col_dtype[src_of[0]]) != PC_F && (P.col_dtype[src_of[0]] == T_I32 || P.col_dtype[src_of[0]] == T_U32);
+    for (int sl = 1; sl < n && only_key; ++sl) {
+      const uint8_t t = P.col_dtype[src_of[sl]];
+      if (t == T_I32 || t == T_U32 || t == T_F32) only_key = false;
+    }
+    if (only_key) {
+      gen = (gen & ~1) | 4;
+      for (int sl = n; sl < kPlanCols; ++sl) {  // unused slots are read 8 bytes wide here: repeat slot 1, never the 4-byte key
+        Cout->c[sl] = Cout->c[1];
+        S.col_meta[sl] = S.col_meta[1];
+      }
+    }
+  }
   S.gen = gen;
   S.valid = 1;
   return true;

@@ -719,10 +719,14 @@ DEV uint64_t plan_sel(const u64x16& reg, uint32_t slot) {  // slot is wave-unifo
 // GENK bit 0 (W4): 4-byte columns (read as the aligned 8 bytes that hold the element, widened afterwards), bit 1 (NULLS):
 // validity bitmaps (without either every column is 8 bytes wide and null-free: no widening, no validity loads);
 // FIXED: one key in slot 0, one routed argument in slot 1 (the partitioned GROUP BY's one-value kernels).
-constexpr int kPlanW4 = 1, kPlanNulls = 2;
+// bit 2 (KEY4, FIXED kernels only): slot 0 -- the key -- is a 4-byte integer column and every other slot is 8 bytes wide: the
+// key is read with a real 4-byte load (half the bytes of the aligned-pair form, no lane select) and extended in one operation.
+// The reference's own GROUP BY fixtures have Int32 keys (aggregate.rs:1033-1127).
+constexpr int kPlanW4 = 1, kPlanNulls = 2, kPlanKey4 = 4;
 template <int NCOL, int U_, int GENK, bool FIXED>
 struct PlanPolicy {
-  static constexpr bool W4 = (GENK & kPlanW4) != 0, NULLS = (GENK & kPlanNulls) != 0;
+  static constexpr bool W4 = (GENK & kPlanW4) != 0, NULLS = (GENK & kPlanNulls) != 0, KEY4 = (GENK & kPlanKey4) != 0;
+  static_assert(!(W4 && KEY4), "KEY4 is the special case of W4");
   static constexpr bool kIsStatic = false;
   static constexpr bool kHasTripLoad = true;
   static constexpr int kPredTerms = -1;
@@ -743,6 +747,7 @@ struct PlanPolicy {
     uint64_t nlo[kPlanTerms];   // -lo
     uint64_t span[kPlanTerms];
     uint32_t flags[kPlanTerms];
+    uint32_t key_sext;                // KEY4: all ones: the key is a signed integer (sign-extended), else zero-extended
     uint32_t hi_half[W4 ? NCOL : 1];  // W4: all ones where this lane's 4-byte element is the HIGH word of its aligned pair
     uint32_t is4[W4 ? NCOL : 1];      //     all ones: a 4-byte column
     uint32_t sext[W4 ? NCOL : 1];     //     all ones: ... of signed integers
@@ -773,6 +778,7 @@ struct PlanPolicy {
         W.vlane[c] = (at >> 3) << 2;
       }
     }
+    W.key_sext = KEY4 ? plan_word(((F.scan.col_meta[0] >> 8) & 3u) == PX_SEXT32 ? 0xFFFFFFFFu : 0u) : 0u;
     if constexpr (!W4) W.hi_half[0] = W.is4[0] = W.sext[0] = 0;
     if constexpr (!NULLS) W.vshift[0] = W.vlane[0] = 0;
   }
@@ -792,6 +798,11 @@ struct PlanPolicy {
       if constexpr (W4) {
         const uint64_t off = ((r + ((meta >> 4) & 1u)) << (meta & 15u)) & ~7ull;
         col.v[c] = __builtin_nontemporal_load((const uint64_t*)((const uint8_t*)C.c[c].values + off));
+      } else if constexpr (KEY4) {
+        if (c == 0)  // (values = the column base rounded down to 8 bytes; bit 4 of the column word: row 0 is the pair's second element)
+          col.v[c] = (uint64_t)__builtin_nontemporal_load((const uint32_t*)C.c[c].values + ((meta >> 4) & 1u) + r);
+        else
+          col.v[c] = __builtin_nontemporal_load((const uint64_t*)C.c[c].values + r);
       } else {
         col.v[c] = __builtin_nontemporal_load((const uint64_t*)C.c[c].values + r);
       }
@@ -823,6 +834,13 @@ struct PlanPolicy {
           const uint32_t i = (uint32_t)(u * 64 + lane);
           const uint32_t ic = i < last ? i : last;
           col[u].v[c] = __builtin_nontemporal_load((const uint64_t*)(p + (((ic + delta) << shift) & ~7u)));
+        }
+      } else if (KEY4 && c == 0) {
+        const uint32_t* p = (const uint32_t*)C.c[c].values + ((meta >> 4) & 1u) + (none ? 0 : r0);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const uint32_t i = (uint32_t)(u * 64 + lane);
+          col[u].v[c] = (uint64_t)__builtin_nontemporal_load(p + (i < last ? i : last));
         }
       } else {
         const uint64_t* p = (const uint64_t*)C.c[c].values + (none ? 0 : r0);
@@ -866,6 +884,9 @@ struct PlanPolicy {
         const uint32_t xh = (hi & ~W.is4[c]) | ((uint32_t)((int32_t)w >> 31) & W.sext[c]);
         x = ((uint64_t)xh << 32) | w;
         if (((F.scan.col_meta[c] >> 8) & 3u) == PX_F32) x = f64_bits((double)__uint_as_float(w));  // (wave-uniform, rare; exact)
+      }
+      if constexpr (KEY4) {
+        if (c == 0) x = ((uint64_t)((uint32_t)((int32_t)(uint32_t)x >> 31) & W.key_sext) << 32) | (uint32_t)x;
       }
       if constexpr (NULLS) {
         uint32_t byte = cur.vb[c];
