@@ -25,6 +25,7 @@ SOURCES = ["dfx_k_table1.hip", "dfx_k_table2.hip", "dfx_k_table3.hip", "dfx_k_ta
            "dfx_k_partition_v9.hip", "dfx_k_partition_v10.hip", "dfx_k_partition_v11.hip", "dfx_k_partition_v12.hip",
            "dfx_k_partition_v13.hip", "dfx_k_partition_v14.hip", "dfx_k_partition_v15.hip", "dfx_k_partition_v16.hip",
            "dfx_k_partition_v17.hip", "dfx_k_partition_v18.hip", "dfx_k_partition_v19.hip", "dfx_k_partition_v20.hip",
+           "dfx_k_partition_v21.hip", "dfx_k_partition_v22.hip", "dfx_k_partition_v23.hip", "dfx_k_partition_v24.hip",
            "dfx_k_fewgroup.hip", "dfx_k_csv.hip", "dfx_k_sort.hip", "dfx_k_dict.hip", "dfx_host.cpp", "dfx_expr.cpp", "dfx_relation.cpp", "dfx_aggregate.cpp",
            "dfx_table.cpp", "dfx_csv.cpp", "dfx_sort.cpp", "dfx_exchange.cpp"]
 HEADERS = ["dfx_device.hpp", "dfx_sigs.hpp", "dfx_numparse.hpp", "dfx_pow5_table.hpp", "dfx_csv_walk.hpp", "dfx_kernels.hpp", "dfx_kernels_inl.hpp", "dfx_k_table_inl.hpp", "dfx_k_partition_inl.hpp", "dfx_k_partition_ws_inl.hpp", "dfx_launch.hpp",

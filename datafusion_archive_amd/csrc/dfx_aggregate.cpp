@@ -1137,7 +1137,7 @@ Status AggregateRelation::Impl::consume_batch_chunk(const DeviceBatch& b) {
   // grouped: can this batch overflow the table in the worst case (every row a new group)?
   const AggOptions& oo = opt();
   if (oo.strategy == 3 && kw == 1) {
-    if (!use_partition && oo.narrow_keys > 0) narrow = na == 1 || shared_operand();  // forced strategy: no calibration slice -- optimistic (tests)
+    if (!use_partition && oo.narrow_keys > 0) narrow = true;  // forced strategy: no calibration slice -- optimistic (tests); ensure_partition looks at the shape
     use_partition = true;
   }
   const bool may_spill = use_partition || occupied_known + unconfirmed_rows + (uint64_t)n > T.load_limit;
@@ -1177,7 +1177,9 @@ Status AggregateRelation::Impl::consume_batch_chunk(const DeviceBatch& b) {
     if (kw == 1) DFX_HIP(launch_probe_wide_keys(T, ctx().stream));  // does any key of the slice lack a 32-bit image?
     uint32_t hc[CTRL_WORDS];
     DFX_RETURN_IF_ERROR(read_ctrl(hc));
-    narrow = kw == 1 && (na == 1 || shared_operand()) && hc[CTRL_WIDE_KEYS] == 0;
+    // (a property of the KEYS: whether a launch routes 12-byte rows also depends on the aggregates of the chunk it serves --
+    // ensure_partition -- and a query that is split into one scan per aggregate has one-aggregate chunks after this point)
+    narrow = kw == 1 && hc[CTRL_WIDE_KEYS] == 0;
     // strategy from the number of groups the calibration slice produced: the LDS front cache pays
     // when the groups fit it (every later row is an LDS atomic); for many groups per-row global
     // atomics would cap the query near 24 G rows/s, so rows are routed to their table blocks

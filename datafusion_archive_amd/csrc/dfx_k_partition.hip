@@ -715,6 +715,10 @@ void launch_partition_variant17(DFX_PARTITION_VARIANT_ARGS);  // <= 2 columns, a
 void launch_partition_variant18(DFX_PARTITION_VARIANT_ARGS);  // <= 2 columns, a 4-byte key + validity bitmaps
 void launch_partition_variant19(DFX_PARTITION_VARIANT_ARGS);  // <= 4 columns, a 4-byte key
 void launch_partition_variant20(DFX_PARTITION_VARIANT_ARGS);  // <= 4 columns, a 4-byte key + validity bitmaps
+void launch_partition_variant21(DFX_PARTITION_VARIANT_ARGS);  // 3 columns
+void launch_partition_variant22(DFX_PARTITION_VARIANT_ARGS);  // 3 columns, 4-byte columns
+void launch_partition_variant23(DFX_PARTITION_VARIANT_ARGS);  // 3 columns, validity bitmaps
+void launch_partition_variant24(DFX_PARTITION_VARIANT_ARGS);  // 3 columns, both
 
 // The scan plan (DevScanPlan): run-time shapes as data.  Which binding a launch needs follows from the kernel flavour that
 // will run: the one-value flavours (narrow rows, the wave-specialised kernel) find the key in slot 0 and the routed value in
@@ -731,13 +735,15 @@ static bool launch_partition_plan(const DevProgram& P, const DevFastPlan& fast, 
   if (!bind_scan_plan(P, fast, C, 1, shared ? 1 : T.na, shared ? raw_xf : T.val_xform, one_value, &fp, &cp)) return false;
   typedef void (*Variant)(DFX_PARTITION_VARIANT_ARGS);
   // [> 2 columns][DevScanPlan::gen: bit 0 4-byte columns, bit 1 validity bitmaps, bit 2 (instead of bit 0) a 4-byte key only]
-  static const Variant by_need[2][8] = {
+  static const Variant by_need[3][8] = {
       {launch_partition_variant9, launch_partition_variant13, launch_partition_variant14, launch_partition_variant10,
        launch_partition_variant17, launch_partition_variant13, launch_partition_variant18, launch_partition_variant10},
+      {launch_partition_variant21, launch_partition_variant22, launch_partition_variant23, launch_partition_variant24,
+       launch_partition_variant19, launch_partition_variant22, launch_partition_variant20, launch_partition_variant24},
       {launch_partition_variant11, launch_partition_variant15, launch_partition_variant16, launch_partition_variant12,
        launch_partition_variant19, launch_partition_variant15, launch_partition_variant20, launch_partition_variant12}};
   if (!one_value && (fp.scan.gen & 4)) return false;  // (cannot happen: bind_scan_plan gives bit 2 to fixed-slot bindings only)
-  by_need[fp.scan.n_cols <= 2 ? 0 : 1][fp.scan.gen & 7](P, fp, cp, plan, T, PT, spill, n, lds_bytes, s);
+  by_need[fp.scan.n_cols <= 2 ? 0 : fp.scan.n_cols == 3 ? 1 : 2][fp.scan.gen & 7](P, fp, cp, plan, T, PT, spill, n, lds_bytes, s);
   return true;
 }
 

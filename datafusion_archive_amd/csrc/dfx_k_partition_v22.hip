@@ -1,0 +1,7 @@
+// dfx_k_partition_v22.hip -- pass 1 of the partitioned GROUP BY for one row-source policy: PlanPolicy (the scan plan: range tests on
+// value images, plan words in vector registers), exactly 3 columns (key, routed value, one more predicate column -- e.g.
+// SUM(w) WHERE v ... GROUP BY k, or the second scan of SUM(v), MIN(w)), GENK = 1 (4-byte-columns: bit 0 4-byte columns widened, bit 1 validity bitmaps).
+#include "dfx_k_partition_ws_inl.hpp"
+namespace dfx {
+DFX_PARTITION_VARIANT_WS(22, DFX_ARG(PlanPolicyN<3, 1, 1>), DFX_ARG(PlanPolicyN<3, 1, 1>), DFX_ARG(PlanPolicy1<3, 1, 1>), DFX_ARG(PlanPolicy1<3, 3, 1>))
+}  // namespace dfx

@@ -25,7 +25,8 @@ def demangle(names):
 
 
 def main():
-    units = sys.argv[1:] or ["dfx_k_partition_v0", "dfx_k_partition_v9", "dfx_k_partition_v17"]
+    every = "--all" in sys.argv  # every kernel of the unit, not only k_partition_ws
+    units = [a for a in sys.argv[1:] if not a.startswith("--")] or ["dfx_k_partition_v0", "dfx_k_partition_v9", "dfx_k_partition_v17"]
     hipcc = B._hipcc()
     flags = [f for f in B.CXXFLAGS if f != "-fPIC"]
     for u in units:
@@ -41,7 +42,7 @@ def main():
             body = m.group(2)
             g = lambda k: int(re.search(r"\." + k + r":\s+(\d+)", body).group(1))  # noqa: E731
             meta[m.group(1)] = (g("sgpr_count"), g("sgpr_spill_count"), g("vgpr_count"), g("vgpr_spill_count"), g("private_segment_fixed_size"))
-        names = [n for n in meta if "k_partition_ws" in n]
+        names = [n for n in meta if every or "k_partition_ws" in n]
         pretty = demangle(names)
         print(f"== {u}.hip")
         for n in names:
