@@ -338,6 +338,7 @@ struct DevFusedOut {
   uint8_t slot[kFusedOutCols];   // column slot of the fused program
   uint8_t dtype[kFusedOutCols];
   void* out[kFusedOutCols];      // room for cap_rows rows
+  uint32_t dense;                // the host expects dense tiles (it has seen this stream keep more than a wave can park in LDS)
   uint64_t cap_rows;             // rows past it are not stored (the host sized the buffers from the selectivity it has seen; when
                                  // a batch keeps more, it compacts those columns again from the bitmap: k_compact)
 };

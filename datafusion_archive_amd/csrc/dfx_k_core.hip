@@ -142,6 +142,75 @@ DEV uint64_t wave_sum_u64(uint64_t v) {
   return v;
 }
 
+// The look-back of one super-tile (wave 0 of its workgroup): publish the super-tile's kept count A, add up what the
+// super-tiles before it kept (see above), publish the group words this super-tile owes, leave the exclusive prefix in *s_base.
+DEV void filter_lookback(const int64_t unit, const int64_t n_units, const int64_t n_tiles, const uint32_t A, uint64_t* __restrict__ state,
+                         uint64_t* __restrict__ gstate, uint64_t* __restrict__ sync, uint64_t* __restrict__ tile_offsets,
+                         uint32_t* __restrict__ ctrl, const int lane, uint64_t* s_base, uint32_t& err) {
+  if (lane == 0) __hip_atomic_store(&state[unit], kLbAggregate | (uint64_t)A, RLX_AGENT);
+  const int64_t g = unit / kLbGroup;
+  const int q = (int)(unit % kLbGroup);
+  const bool last_of_group = q == kLbGroup - 1 || unit == n_units - 1;
+  bool need_w = q > 0, need_g = g > 0, agg_pending = last_of_group && g > 0;
+  uint64_t within = 0, before = 0;
+  int64_t ghi = g - 1;  // lane l looks at group ghi - l
+  uint32_t spins = 0;
+  while (need_w || need_g) {
+    uint64_t st = 0, gs = 0;
+    if (need_w) st = __hip_atomic_load(&state[lane < q ? unit - 1 - lane : unit], RLX_AGENT);
+    if (need_g) {
+      const int64_t gj = ghi - lane;
+      gs = __hip_atomic_load(&gstate[gj >= 0 ? gj : 0], RLX_AGENT);
+      if (gj < 0) gs = kLbInclusive;  // before group 0: inclusive prefix 0
+    }
+    bool moved = false;
+    if (need_w) {
+      if (__ballot(lane < q && (st & kLbFlags) == 0) == 0) {  // every unit before this one in its group has published
+        within = wave_sum_u64(lane < q ? (st & ~kLbFlags) : 0ull);
+        need_w = false;
+      }
+    }
+    if (!need_w && agg_pending) {  // the group's aggregate: everybody after this group waits for it
+      if (lane == 0) __hip_atomic_store(&gstate[g], kLbAggregate | (within + (uint64_t)A), RLX_AGENT);
+      agg_pending = false;
+    }
+    if (need_g) {
+      const uint64_t fl = gs & kLbFlags;
+      const uint64_t not_ready = __ballot(fl == 0);
+      const uint64_t incl = __ballot(fl == kLbInclusive);
+      if (incl != 0) {
+        const int pl = __ffsll((unsigned long long)incl) - 1;  // nearest group with an inclusive prefix
+        const uint64_t upto = pl == 63 ? ~0ull : ((1ull << (pl + 1)) - 1ull);
+        if ((not_ready & upto) == 0) {
+          before += wave_sum_u64(((upto >> lane) & 1ull) ? (gs & ~kLbFlags) : 0ull);
+          need_g = false;
+        }
+      } else if (not_ready == 0) {  // 64 aggregates, no prefix among them: add them all, look 64 groups further back
+        before += wave_sum_u64(gs & ~kLbFlags);
+        ghi -= 64;
+        moved = true;
+      }
+    }
+    if (!(need_w || need_g) || moved) continue;
+    if (++spins > (1u << 22)) {  // cannot happen (see above); never hang the device
+      err |= 8u;
+      break;
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+  const uint64_t base = before + within;
+  if (lane == 0) {
+    if (last_of_group) __hip_atomic_store(&gstate[g], kLbInclusive | (base + (uint64_t)A), RLX_AGENT);
+    *s_base = base;
+    if (unit == n_units - 1) {
+      tile_offsets[n_tiles] = base + (uint64_t)A;
+      sync[1] = base + (uint64_t)A;  // kept rows of the batch
+      ctrl[CTRL_PASSED_LO] = (uint32_t)(base + (uint64_t)A);  // ... and next to the error word: ONE read-back per batch
+      ctrl[CTRL_PASSED_HI] = (uint32_t)((base + (uint64_t)A) >> 32);
+    }
+  }
+}
+
 // (a compile-time signature fits 128 VGPRs -- four workgroups per CU --, the generic policies take what they need)
 template <typename POL>
 __global__ __launch_bounds__(kBlock, (POL::kStaticNa == 0 && sizeof(typename POL::COLV) == 16 && POL::U == 8 && POL::kIsStatic) ? 4 : 1) void k_filter_fused(const DevProgram P, const DevFastPlan F, const DevColumns C,
@@ -240,70 +309,7 @@ __global__ __launch_bounds__(kBlock, (POL::kStaticNa == 0 && sizeof(typename POL
       wc[k] = s_wave_cnt[k];
       A += wc[k];
     }
-    if (wave == 0) {
-      if (lane == 0) __hip_atomic_store(&state[unit], kLbAggregate | (uint64_t)A, RLX_AGENT);
-      const int64_t g = unit / kLbGroup;
-      const int q = (int)(unit % kLbGroup);
-      const bool last_of_group = q == kLbGroup - 1 || unit == n_units - 1;
-      bool need_w = q > 0, need_g = g > 0, agg_pending = last_of_group && g > 0;
-      uint64_t within = 0, before = 0;
-      int64_t ghi = g - 1;  // lane l looks at group ghi - l
-      uint32_t spins = 0;
-      while (need_w || need_g) {
-        uint64_t st = 0, gs = 0;
-        if (need_w) st = __hip_atomic_load(&state[lane < q ? unit - 1 - lane : unit], RLX_AGENT);
-        if (need_g) {
-          const int64_t gj = ghi - lane;
-          gs = __hip_atomic_load(&gstate[gj >= 0 ? gj : 0], RLX_AGENT);
-          if (gj < 0) gs = kLbInclusive;  // before group 0: inclusive prefix 0
-        }
-        bool moved = false;
-        if (need_w) {
-          if (__ballot(lane < q && (st & kLbFlags) == 0) == 0) {  // every unit before this one in its group has published
-            within = wave_sum_u64(lane < q ? (st & ~kLbFlags) : 0ull);
-            need_w = false;
-          }
-        }
-        if (!need_w && agg_pending) {  // the group's aggregate: everybody after this group waits for it
-          if (lane == 0) __hip_atomic_store(&gstate[g], kLbAggregate | (within + (uint64_t)A), RLX_AGENT);
-          agg_pending = false;
-        }
-        if (need_g) {
-          const uint64_t fl = gs & kLbFlags;
-          const uint64_t not_ready = __ballot(fl == 0);
-          const uint64_t incl = __ballot(fl == kLbInclusive);
-          if (incl != 0) {
-            const int pl = __ffsll((unsigned long long)incl) - 1;  // nearest group with an inclusive prefix
-            const uint64_t upto = pl == 63 ? ~0ull : ((1ull << (pl + 1)) - 1ull);
-            if ((not_ready & upto) == 0) {
-              before += wave_sum_u64(((upto >> lane) & 1ull) ? (gs & ~kLbFlags) : 0ull);
-              need_g = false;
-            }
-          } else if (not_ready == 0) {  // 64 aggregates, no prefix among them: add them all, look 64 groups further back
-            before += wave_sum_u64(gs & ~kLbFlags);
-            ghi -= 64;
-            moved = true;
-          }
-        }
-        if (!(need_w || need_g) || moved) continue;
-        if (++spins > (1u << 22)) {  // cannot happen (see above); never hang the device
-          err |= 8u;
-          break;
-        }
-        __builtin_amdgcn_s_sleep(1);
-      }
-      const uint64_t base = before + within;
-      if (lane == 0) {
-        if (last_of_group) __hip_atomic_store(&gstate[g], kLbInclusive | (base + (uint64_t)A), RLX_AGENT);
-        s_base = base;
-        if (unit == n_units - 1) {
-          tile_offsets[n_tiles] = base + (uint64_t)A;
-          sync[1] = base + (uint64_t)A;  // kept rows of the batch
-          ctrl[CTRL_PASSED_LO] = (uint32_t)(base + (uint64_t)A);  // ... and next to the error word: ONE read-back per batch
-          ctrl[CTRL_PASSED_HI] = (uint32_t)((base + (uint64_t)A) >> 32);
-        }
-      }
-    }
+    if (wave == 0) filter_lookback(unit, n_units, n_tiles, A, state, gstate, sync, tile_offsets, ctrl, lane, &s_base, err);
     __syncthreads();
     uint64_t my_base = s_base;
 #pragma unroll
@@ -379,6 +385,121 @@ __global__ __launch_bounds__(kBlock, (POL::kStaticNa == 0 && sizeof(typename POL
     case 4 | (3 << 3): run(std::integral_constant<int, (POL::kIsStatic ? (4 | (3 << 3)) : 0)>{}); break;  // x >  a AND x <= b
     case 6 | (3 << 3): run(std::integral_constant<int, (POL::kIsStatic ? (6 | (3 << 3)) : 0)>{}); break;  // x >= a AND x <= b
     default: run(std::integral_constant<int, 0>{}); break;
+  }
+  if (err) atomicOr(&ctrl[CTRL_ERROR], err);
+}
+
+// DENSE flavour (round 4): the tile stays in REGISTERS.  k_filter_fused parks a wave's kept values in LDS -- at most a quarter of
+// its tile -- and a wave that keeps more reads its passing rows a second time after the look-back: 8 + 8 sel + 8 sel bytes of
+// traffic per row, which is all that selectivities of 0.5 / 0.9 could ever reach (0.40 / 0.44 of the roofline).  Here a wave loads
+// its whole 4096-row tile up front -- 64 independent 512-byte loads, 128 vector registers --, evaluates the predicate from the
+// registers, keeps bitmap word i in lane i (one coalesced 512-byte store per tile, `v_readlane` hands the words back after the
+// look-back) and stores the kept values from the same registers: the column is read ONCE whatever the selectivity, nothing is
+// staged in LDS.  Two workgroups per CU (256 registers each): while one waits in its look-back the other streams.
+// For the shape config 2 is written in: a compile-time signature over ONE 8-byte column, which is also the one column the kernel
+// compacts (launch_filter_fused checks); chosen by the host once a stream has kept more than a wave can park (DevFusedOut::dense).
+template <typename POL, int FORM>
+__global__ __launch_bounds__(kBlock, 2) void k_filter_fused_dense(const DevProgram P, const DevFastPlan F, const DevColumns C,
+                                                                  const uint8_t pred, const int64_t n,
+                                                                  uint64_t* __restrict__ mask_words,
+                                                                  uint64_t* __restrict__ tile_offsets,
+                                                                  uint64_t* __restrict__ sync, const DevFusedOut O,
+                                                                  uint32_t* __restrict__ ctrl) {
+  typedef typename POL::COLV COLV;
+  constexpr int BANK = (int)(sizeof(COLV) / 8);
+  constexpr int NW = kFusedTiles;
+  constexpr int kTileWords = kTileRows / 64;
+  static_assert(POL::kIsStatic && kTileWords == 64, "one lane per bitmap word of a tile; straight-line predicate code");
+  __shared__ uint32_t s_wave_cnt[NW];
+  __shared__ uint64_t s_base;
+  const int lane = lane_id();
+  const int wave = threadIdx.x >> 6;
+  const int64_t n_words = (n + 63) >> 6;
+  const int64_t n_tiles = (n + kTileRows - 1) / kTileRows;
+  const int64_t n_units = (n_tiles + NW - 1) / NW;
+  uint64_t* const state = sync + 2;
+  uint64_t* const gstate = state + n_units;
+  const uint64_t* __restrict__ in = (const uint64_t*)C.c[0].values;
+  uint64_t* __restrict__ out = (uint64_t*)O.out[0];
+  uint32_t err = 0;
+  {
+    for (int64_t unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
+      const int64_t tile = unit * NW + wave;
+      const int64_t row0 = tile * kTileRows;
+      const int64_t left = n - row0;  // rows of this tile (<= 0: a wave past the end of the batch: it reads row 0 and keeps nothing)
+      const uint32_t last = left <= 0 ? 0u : (uint32_t)((left < (int64_t)kTileRows ? left : (int64_t)kTileRows) - 1);
+      const uint64_t* base = in + (left <= 0 ? 0 : row0);
+      // (opaque per super-tile: everything derived from the lane number alone -- 64 row indices, 64 lane == i masks -- is loop
+      // invariant, and hoisted out of this loop it occupies 128 vector and 128 scalar registers for the kernel's whole life)
+      uint32_t lv = (uint32_t)lane;
+      asm volatile("" : "+v"(lv));
+      const int32_t left_lane = (int32_t)(left >= (int64_t)kTileRows ? (int64_t)kTileRows : (left < 0 ? 0 : left)) - (int32_t)lv;
+      uint64_t keep[kTileWords];
+      if (left >= (int64_t)kTileRows) {  // (wave-uniform) a whole tile: one lane offset, the row group in the instruction's immediate
+        const uint64_t* mine = base + lv;
+#pragma unroll
+        for (int i = 0; i < kTileWords; ++i) keep[i] = __builtin_nontemporal_load(mine + i * 64);
+      } else {  // the batch's last tile (or none of it): unconditional loads of clamped rows, masked below
+#pragma unroll
+        for (int i = 0; i < kTileWords; ++i) {
+          const uint32_t idx = (uint32_t)(i * 64) + lv;
+          keep[i] = __builtin_nontemporal_load(base + (idx < last ? idx : last));
+          __builtin_amdgcn_sched_barrier(0);  // (one index register at a time: 64 of them at once spill)
+        }
+      }
+      uint32_t cnt = 0;
+      uint32_t my_lo = 0, my_hi = 0;  // lane i: bitmap word i of the tile
+#pragma unroll
+      for (int i = 0; i < kTileWords; ++i) {
+        const bool inb = (int32_t)(i * 64) < left_lane;
+        COLV cur;
+#pragma unroll
+        for (int c = 0; c < BANK; ++c) cur[c] = keep[i];
+        u64x16 reg;
+        uint32_t rv = 0;
+        POL::eval(P, F, cur, 0xFFFFFFFFu, reg, rv, inb, err);
+        const bool pass = inb && POL::template pass_form<FORM>(P, F, pred, cur, 0xFFFFFFFFu, reg, rv);
+        const uint64_t word = __ballot(pass);
+        my_lo = lv == (uint32_t)i ? (uint32_t)word : my_lo;
+        my_hi = lv == (uint32_t)i ? (uint32_t)(word >> 32) : my_hi;
+        cnt += (uint32_t)__popcll(word);
+        __builtin_amdgcn_sched_barrier(0);  // (one ballot at a time: the scheduler would keep all 64 SGPR pairs alive)
+      }
+      {
+        const int64_t w = tile * kTileWords + lane;
+        if (w < n_words) mask_words[w] = ((uint64_t)my_hi << 32) | my_lo;
+      }
+      if (lane == 0) s_wave_cnt[wave] = cnt;
+      __syncthreads();
+      uint32_t wc[NW];
+      uint32_t A = 0;
+#pragma unroll
+      for (int k = 0; k < NW; ++k) {
+        wc[k] = s_wave_cnt[k];
+        A += wc[k];
+      }
+      if (wave == 0) filter_lookback(unit, n_units, n_tiles, A, state, gstate, sync, tile_offsets, ctrl, lane, &s_base, err);
+      __syncthreads();
+      uint64_t my_base = s_base;
+#pragma unroll
+      for (int k = 0; k < NW; ++k)
+        if (k < wave) my_base += wc[k];
+      if (lane == 0 && tile < n_tiles) tile_offsets[tile] = my_base;
+      // (the output buffer holds O.cap_rows rows: what lies beyond is the host's to compact again)
+      const uint32_t room = my_base >= O.cap_rows ? 0u : (O.cap_rows - my_base < (uint64_t)cnt ? (uint32_t)(O.cap_rows - my_base) : cnt);
+      uint64_t* dst = out + my_base;
+      uint32_t run_at = 0;  // (wave-uniform)
+      const uint32_t lo = my_lo, hi = my_hi;
+#pragma unroll
+      for (int i = 0; i < kTileWords; ++i) {
+        const uint64_t word = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)hi, i) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)lo, i);
+        const uint32_t at = run_at + mbcnt_u64(word);
+        if (((word >> lane) & 1ull) && at < room) dst[at] = keep[i];
+        run_at += (uint32_t)__popcll(word);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // (the next super-tile's first barrier separates these reads of s_base / s_wave_cnt from their next writes)
+    }
   }
   if (err) atomicOr(&ctrl[CTRL_ERROR], err);
 }
@@ -951,6 +1072,27 @@ static hipError_t filter_fused_launch(const DevProgram& P, const DevFastPlan& fa
   return hipGetLastError();
 }
 
+template <typename POL, int FORM>
+static hipError_t filter_fused_dense_launch(const DevProgram& P, const DevFastPlan& fast, const DevColumns& C, uint8_t pred, int64_t n,
+                                            uint64_t* mask_words, uint64_t* tile_offsets, uint64_t* sync, const DevFusedOut& O,
+                                            uint32_t* ctrl, hipStream_t s) {
+  static std::atomic<int> per_cu{0};  // (co-resident grid, as above)
+  int wg_per_cu = per_cu.load(std::memory_order_relaxed);
+  if (wg_per_cu == 0) {
+    int nb = 0;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_filter_fused_dense<POL, FORM>, kBlock, 0);
+    if (e != hipSuccess) return e;
+    wg_per_cu = nb > 0 ? nb : 1;
+    per_cu.store(wg_per_cu, std::memory_order_relaxed);
+  }
+  const int64_t tiles = (n + kTileRows - 1) / kTileRows;
+  const int64_t units = (tiles + kFusedTiles - 1) / kFusedTiles;
+  const int64_t cap = (int64_t)device_cu_count() * wg_per_cu;
+  const int grid = (int)(units < cap ? units : cap);
+  hipLaunchKernelGGL((k_filter_fused_dense<POL, FORM>), dim3(grid), dim3(kBlock), 0, s, P, fast, C, pred, n, mask_words, tile_offsets, sync, O, ctrl);
+  return hipGetLastError();
+}
+
 hipError_t launch_filter_fused(const DevProgram& P, const DevFastPlan& fast, const DevColumns& C, uint8_t pred, int64_t n,
                                uint64_t* mask_words, uint64_t* tile_offsets, uint64_t* sync, const DevFusedOut& O,
                                uint32_t* ctrl, double algo_bytes, hipStream_t s) {
@@ -960,7 +1102,23 @@ hipError_t launch_filter_fused(const DevProgram& P, const DevFastPlan& fast, con
 #define DFX_FUSED(POL) return filter_fused_launch<POL>(P, fast, C, pred, n, mask_words, tile_offsets, sync, O, ctrl, s)
   {
     const uint8_t none[kMaxAggs] = {0};
-    if (sig_matches<SigPred2F64>(P, fast, 0, 0, none, none)) DFX_FUSED(DFX_ARG(StaticPolicy<2, 8, SigPred2F64>));
+    if (sig_matches<SigPred2F64>(P, fast, 0, 0, none, none)) {
+      // dense streams: the tile in registers, the column read once (the signature's one column is the one column compacted)
+      const bool one_wide_column = P.n_cols == 1 && O.n == 1 && O.slot[0] == 0 && (O.dtype[0] == T_F64 || O.dtype[0] == T_I64 || O.dtype[0] == T_U64);
+      if (O.dense && one_wide_column) {
+        typedef StaticPolicy<2, 8, SigPred2F64> POLD;
+#define DFX_DENSE(FORM) return filter_fused_dense_launch<POLD, FORM>(P, fast, C, pred, n, mask_words, tile_offsets, sync, O, ctrl, s)
+        switch (POLD::form_of(fast)) {  // the comparison form is a template argument: one loop per kernel
+          case 4 | (1 << 3): DFX_DENSE(4 | (1 << 3));  // x >  a AND x <  b
+          case 6 | (1 << 3): DFX_DENSE(6 | (1 << 3));  // x >= a AND x <  b
+          case 4 | (3 << 3): DFX_DENSE(4 | (3 << 3));  // x >  a AND x <= b
+          case 6 | (3 << 3): DFX_DENSE(6 | (3 << 3));  // x >= a AND x <= b
+          default: DFX_DENSE(0);
+        }
+#undef DFX_DENSE
+      }
+      DFX_FUSED(DFX_ARG(StaticPolicy<2, 8, SigPred2F64>));
+    }
   }
   const bool use_fast = fast.valid && !P.has_nulls;
   if (P.n_cols <= 2) { if (use_fast) DFX_FUSED(DFX_ARG(FastPolicy<2, 8>)); else DFX_FUSED(DFX_ARG(InterpPolicy<2, 8>)); }

@@ -928,6 +928,7 @@ Status FilterRelation::next(DeviceBatch* out, bool* has) {
     const uint64_t fused_cap = sel_seen_ < 0.0 ? (uint64_t)n
                                                : std::min<uint64_t>((uint64_t)n, (uint64_t)((double)n * std::min(1.0, 1.5 * sel_seen_ + 0.02)) + 4096);
     O.cap_rows = fused_cap;
+    O.dense = opt_.get().filter_dense < 0 ? (sel_seen_ > 0.22 ? 1u : 0u) : (uint32_t)(opt_.get().filter_dense != 0);
     const std::vector<int>& pcols = builder_->columns();
     for (size_t slot = 0; slot < pcols.size() && O.n < kFusedOutCols && !any_boolean; ++slot) {
       const int ci = pcols[slot];

@@ -95,6 +95,8 @@ struct AggOptions {
   int host_stage_slots = 6;    // ... slots
   int split_aggregates = 1;    // one key, several aggregates of different operands, many groups: a scan per aggregate through the one-value
                                // kernels of the partitioned strategy (0: one scan that routes a row with every operand)
+  int filter_dense = -1;       // single-pass FilterRelation, tiles kept in registers (k_filter_fused_dense): -1 when the stream has
+                               // been keeping more than a wave can park in LDS (> 22 % of its rows), 0 never, 1 whenever the shape allows
   int filter_single_pass = 1;  // FilterRelation: predicate + bitmap + tile offsets (decoupled look-back) + compaction of the predicate's own
                                // columns in ONE kernel (0: k_predicate_mask -> scan -> k_compact, the column is read twice)
   int replay_in_place = 1;     // 1: rows spilled by a table that is NOT full (region overflow of a heavy key) are replayed into the

@@ -419,6 +419,10 @@ int64_t dfx_relation_explain(struct ArrowArrayStream* stream, char* buf, size_t 
  *                            0 direct routing; "agg.partition_block", "agg.partition_pad", "agg.partition_cap_rows"
  *   "agg.replay_in_place"    experimental, default 0
  *   "agg.dict_capacity_log2" initial slots of a Utf8 key dictionary (0: 2^16)
+ *   "filter.single_pass"     FilterRelation: 1 one kernel per batch (predicate, bitmap, look-back, compaction; default), 0 mask ->
+ *                            scan -> compaction;  "filter.dense": the single-pass kernel's flavour that keeps a tile in registers
+ *                            (one read of the column however many rows pass): -1 once the stream has kept > 22 % of a batch
+ *                            (default), 0 never, 1 whenever the shape allows (one Float64 predicate column)
  *   "scan.fast"              0: always the generic SSA interpreter instead of the shape-specialised kernels
  *   "scan.plan"              scan plans (run-time query shapes evaluated as data: range tests on value images, 4-byte columns
  *                            widened, nulls by arrow's comparison rule): 1 wherever the shape is covered and no compile-time

@@ -287,6 +287,49 @@ def test_filter_single_pass_output_buffers_follow_the_selectivity():
     assert ex.counter_get("filter_output_regrows") >= 1, "the dense batch after the selective ones must have outgrown its buffers"
 
 
+@pytest.mark.parametrize("dense", [1, -1])
+def test_filter_dense_flavour_keeps_the_tile_in_registers(dense):
+    """k_filter_fused_dense (filter.dense): one Float64 predicate column that is also the column compacted -- config 2 as
+    written -- with the wave's whole 4096-row tile in registers: every comparison form, selectivities from nothing to
+    everything (forced on with filter.dense = 1; with -1 the stream switches flavour by itself once it has kept more than
+    22 % of a batch), batches of 0 / 1 / 63 rows, a last tile of every raggedness, more than 64 super-tiles (two-level
+    look-back), a passenger column compacted by k_compact from the kernel's bitmap and tile offsets, output buffers that a
+    denser batch outgrows.  Against fn filter (filter.rs:79-110), batch by batch, bit for bit."""
+    ex.set_option("filter.dense", dense)
+    try:
+        rng = np.random.default_rng(777)
+        n = 300 * 4096 + 1234
+        lat = 49.0 + 10.0 * rng.random(n)
+        lat[::1009] = np.nan
+        lat[5::2003] = np.inf
+        whole = pa.RecordBatch.from_arrays([pa.array(lat), pa.array(rng.integers(0, 1 << 40, n).astype(np.int64))], names=["lat", "k"])
+        one = pa.RecordBatch.from_arrays([pa.array(lat)], names=["lat"])
+        def both(lo_op, lo, hi_op, hi):
+            return BinaryExpr(BinaryExpr(Column(0), lo_op, lit(lo)), Operator.And, BinaryExpr(Column(0), hi_op, lit(hi)))
+        preds = [both(Operator.Gt, 49.5, Operator.Lt, 58.5), both(Operator.GtEq, 51.0, Operator.Lt, 56.0), both(Operator.Gt, 51.0, Operator.LtEq, 53.0),
+                 both(Operator.GtEq, 40.0, Operator.LtEq, 70.0), both(Operator.Gt, 70.0, Operator.Lt, 80.0),
+                 BinaryExpr(BinaryExpr(Column(0), Operator.NotEq, lit(50.0)), Operator.And, BinaryExpr(Column(0), Operator.Lt, lit(58.0)))]  # run-time masks
+        for pred in preds:
+            batches = [whole, whole.slice(777, 4096 * 3 + 5), whole.slice(5, 0), whole.slice(9, 1), whole.slice(100, 63), whole.slice(4096, 4096 * 4),
+                       whole.slice(1, 4095), whole.slice(3, 4097)]
+            got = gpu_filter(pred, whole.schema, batches)
+            for i, (g, b) in enumerate(zip(got, batches)):
+                assert_batches_identical(g, oracle.filter_next(pred, b), f"dense={dense} batch {i} {pred!r}")
+            got1 = gpu_filter(pred, one.schema, [one.slice(0, 70000), one.slice(70000)])
+            assert_batches_identical(got1[0], oracle.filter_next(pred, one.slice(0, 70000)), "one column")
+            assert_batches_identical(got1[1], oracle.filter_next(pred, one.slice(70000)), "one column, second batch")
+        # a stream that starts selective and turns dense: the buffers sized for the first batches are outgrown
+        def batch(lo, hi, m=64 * 4096 + 77):
+            return pa.RecordBatch.from_arrays([pa.array(lo + (hi - lo) * rng.random(m))], names=["lat"])
+        pred = both(Operator.Gt, 51.0, Operator.Lt, 58.0)
+        batches = [batch(40.0, 52.0), batch(40.0, 52.0), batch(51.5, 57.0), batch(49.0, 59.0), batch(10.0, 20.0), batch(49.0, 59.0)]
+        got = gpu_filter(pred, batches[0].schema, batches)
+        for i, (g, b) in enumerate(zip(got, batches)):
+            assert_batches_identical(g, oracle.filter_next(pred, b), f"dense={dense} stream batch {i}")
+    finally:
+        ex.set_option("filter.dense", -1)
+
+
 def test_per_operator_options_override_the_process_defaults_for_one_operator_only():
     """dfx_aggregate_relation_new_with_options / dfx_filter_relation_new_with_options: the option set belongs to the operator.
     Two aggregates over the same rows in one process, one forced to the global-atomic table, one to the partitioned strategy,
