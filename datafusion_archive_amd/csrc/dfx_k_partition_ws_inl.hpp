@@ -140,54 +140,62 @@ __global__ __launch_bounds__(kRingBlock) void k_partition_ws(const DevProgram P,
           cv[u] = ncv[u];
         }
         load_trip<POL>(P, C, w0 + n_waves * U, w0 + n_waves * U < n_groups, n, lane, ncol, ncv);
-        FOR_U {  // (unrolled, like the ring kernel's scan: a run-time loop over the U banks costs a scalar branch chain per group)
-          const COLV cur = col[u];
-          const uint32_t curv = cv[u];
-          const int64_t row = (w0 + u) * 64 + lane;
-          const bool inb = row < n;
-          u64x16 reg;
-          uint32_t rv = 0;
-          POL::eval(P, F, cur, curv, reg, rv, inb, err, prep);
-          bool pass = POL::template pass_form<FORM>(P, F, plan.pred, cur, curv, reg, rv, prep);
-          pass = pass && inb;  // (evaluated for every lane: no branch around the predicate)
-          const uint64_t key = POL::key(P, F, plan.key[0], 0, cur, curv, reg, rv);
-          uint64_t v;
-          bool valid;
-          POL::arg(P, F, plan.arg[0], 0, cur, curv, reg, rv, v, valid);
-          const uint64_t val = transform_value(POL::xform(T, 0), v, valid);
-          passed += (uint64_t)__popcll(__ballot(pass));
-          const bool slow = pass && (key >> 32) != 0;  // no 32-bit form (wide key, or the claim sentinel)
-          if (__ballot(slow) != 0) {
-            ws_slow_rows(T, spill, slow, key, val);
-            pass = pass && !slow;
-          }
-          const uint64_t m = __ballot(pass);
-          const uint32_t c = (uint32_t)__popcll(m);
-          if (c != 0) {
-            // room for c rows?  (the router publishes its position after every batch of 64 it takes)
-            uint32_t spins = 0;
-            // The router only sees the PUBLISHED tail and takes whole batches of 64: rows parked since the last publication
-            // (up to U - 1 groups of this trip) are invisible to it, so a locally dense stretch -- more than ~3/4 of a
-            // 256-row window passing -- could fill the queue with rows nobody may take yet.  Publish before waiting: with
-            // every parked row visible the router leaves fewer than 64 behind, and 64 + c <= 256 always fits.
-            if (tail + c - head_c > (uint32_t)kWsQueueRows && lane == 0) __hip_atomic_store(&my->tail, tail, __ATOMIC_RELEASE, WG_SCOPE);
-            while (tail + c - head_c > (uint32_t)kWsQueueRows) {
-              head_c = __hip_atomic_load(&my->head, __ATOMIC_ACQUIRE, WG_SCOPE);
-              if (tail + c - head_c <= (uint32_t)kWsQueueRows) break;
-              if (++spins > (1u << 22)) {  // cannot happen (a full queue always has 64 rows for its router); never hang the device
-                err |= 4u;
-                break;
+        // One body for whole trips and one for the trip that holds the table's last rows (FULL = false: the lanes past the end
+        // are masked; load_trip let them re-read the last row).  Lane predicates live in SCALAR masks between the steps -- a
+        // bool that is live across a branch is materialised in a vector register and compared again (v_cndmask + v_cmp per
+        // use) --, and the queue positions are scalars as well (readfirstlane of the LDS words).
+        auto trip_body = [&](auto full_tag) {
+          constexpr bool FULL = decltype(full_tag)::value;
+          FOR_U {  // (unrolled, like the ring kernel's scan: a run-time loop over the U banks costs a scalar branch chain per group)
+            const COLV cur = col[u];
+            const uint32_t curv = cv[u];
+            bool inb = true;
+            if constexpr (!FULL) inb = (w0 + u) * 64 + lane < n;
+            u64x16 reg;
+            uint32_t rv = 0;
+            POL::eval(P, F, cur, curv, reg, rv, inb, err, prep);
+            uint64_t pm = POL::template pass_mask<FORM>(P, F, plan.pred, cur, curv, reg, rv, prep);  // (evaluated for every lane)
+            if constexpr (!FULL) pm &= __ballot(inb);
+            const uint64_t key = POL::key(P, F, plan.key[0], 0, cur, curv, reg, rv);
+            uint64_t v;
+            bool valid;
+            POL::arg(P, F, plan.arg[0], 0, cur, curv, reg, rv, v, valid);
+            const uint64_t val = transform_value(POL::xform(T, 0), v, valid);
+            passed += (uint64_t)__popcll(pm);
+            const uint64_t sm = pm & __ballot((key >> 32) != 0);  // no 32-bit form (wide key, or the claim sentinel)
+            if (sm != 0) {
+              ws_slow_rows(T, spill, lane_of_mask(sm), key, val);
+              pm &= ~sm;
+            }
+            const uint32_t c = (uint32_t)__popcll(pm);
+            if (c != 0) {
+              // room for c rows?  (the router publishes its position after every batch of 64 it takes)
+              uint32_t spins = 0;
+              head_c = (uint32_t)__builtin_amdgcn_readfirstlane((int)head_c);  // (wave-uniform by construction: keep the test below scalar)
+              // The router only sees the PUBLISHED tail and takes whole batches of 64: rows parked since the last publication
+              // (up to U - 1 groups of this trip) are invisible to it, so a locally dense stretch -- more than ~3/4 of a
+              // 256-row window passing -- could fill the queue with rows nobody may take yet.  Publish before waiting: with
+              // every parked row visible the router leaves fewer than 64 behind, and 64 + c <= 256 always fits.
+              if (tail + c - head_c > (uint32_t)kWsQueueRows && lane == 0) __hip_atomic_store(&my->tail, tail, __ATOMIC_RELEASE, WG_SCOPE);
+              while (tail + c - head_c > (uint32_t)kWsQueueRows) {
+                head_c = (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&my->head, __ATOMIC_ACQUIRE, WG_SCOPE));
+                if (tail + c - head_c <= (uint32_t)kWsQueueRows) break;
+                if (++spins > (1u << 22)) {  // cannot happen (a full queue always has 64 rows for its router); never hang the device
+                  err |= 4u;
+                  break;
+                }
+                __builtin_amdgcn_s_sleep(1);
               }
-              __builtin_amdgcn_s_sleep(1);
+              if (lane_of_mask(pm)) {
+                const uint32_t at = (tail + mbcnt64(pm)) & (uint32_t)(kWsQueueRows - 1);
+                qk[at] = (uint32_t)key;
+                qv[at] = val;
+              }
+              tail += c;
             }
-            if (pass) {
-              const uint32_t at = (tail + mbcnt64(m)) & (uint32_t)(kWsQueueRows - 1);
-              qk[at] = (uint32_t)key;
-              qv[at] = val;
-            }
-            tail += c;
           }
-        }
+        };
+        if ((w0 + U) * 64 <= n) trip_body(std::true_type{}); else trip_body(std::false_type{});
         if (lane == 0) __hip_atomic_store(&my->tail, tail, __ATOMIC_RELEASE, WG_SCOPE);  // once per trip: the rows above are visible first
       }
     }

@@ -404,6 +404,11 @@ struct InterpPolicy {
   static DEV bool pass_form(const DevProgram& P, const DevFastPlan& F, uint8_t pred, const COLV& cur, uint32_t cv, const u64x16& reg, uint32_t rv, const PREP& prep = PREP()) {
     return pass(P, F, pred, cur, cv, reg, rv, prep);
   }
+  // the wave's lane mask of pass_form (scalar): what the scan loops that keep their predicates in masks call
+  template <int FORM>
+  static DEV uint64_t pass_mask(const DevProgram& P, const DevFastPlan& F, uint8_t pred, const COLV& cur, uint32_t cv, const u64x16& reg, uint32_t rv, const PREP& prep = PREP()) {
+    return __ballot(pass_form<FORM>(P, F, pred, cur, cv, reg, rv, prep));
+  }
   static DEV void load_trip(const DevColumns&, int64_t, bool, int64_t, int, COLV (&)[U_], uint32_t (&)[U_]) {}  // (kIsStatic only)
   static DEV uint64_t key(const DevProgram& P, const DevFastPlan&, uint8_t opnd, int, const COLV& cur, uint32_t curv,
                           const u64x16& reg, uint32_t rv) {
@@ -486,6 +491,11 @@ struct FastPolicy {
   template <int FORM>
   static DEV bool pass_form(const DevProgram& P, const DevFastPlan& F, uint8_t pred, const COLV& cur, uint32_t cv, const u64x16& reg, uint32_t rv, const PREP& prep = PREP()) {
     return pass(P, F, pred, cur, cv, reg, rv, prep);
+  }
+  // the wave's lane mask of pass_form (scalar): what the scan loops that keep their predicates in masks call
+  template <int FORM>
+  static DEV uint64_t pass_mask(const DevProgram& P, const DevFastPlan& F, uint8_t pred, const COLV& cur, uint32_t cv, const u64x16& reg, uint32_t rv, const PREP& prep = PREP()) {
+    return __ballot(pass_form<FORM>(P, F, pred, cur, cv, reg, rv, prep));
   }
   static DEV void load_trip(const DevColumns&, int64_t, bool, int64_t, int, COLV (&)[U_], uint32_t (&)[U_]) {}  // (kIsStatic only)
   static DEV uint64_t key(const DevProgram&, const DevFastPlan& F, uint8_t, int k, const COLV& cur, uint32_t,
@@ -632,6 +642,21 @@ struct StaticPolicy {
       if constexpr (SIG::NP > 1) ok = ok && term_ct<((FORM >> 3) & 7) ? ((FORM >> 3) & 7) : 1>(SIG::term_cls(1), cur[SIG::term_col(1)], F.term_imm[1]);
       if constexpr (SIG::NP > 2) ok = ok && term_ct<((FORM >> 6) & 7) ? ((FORM >> 6) & 7) : 1>(SIG::term_cls(2), cur[SIG::term_col(2)], F.term_imm[2]);
       if constexpr (SIG::NP > 3) ok = ok && term_ct<((FORM >> 9) & 7) ? ((FORM >> 9) & 7) : 1>(SIG::term_cls(3), cur[SIG::term_col(3)], F.term_imm[3]);
+      return ok;
+    }
+  }
+  // ... as the wave's lane mask: one ballot per TERM, the conjunction on the scalar unit.  (The ballot of `a && b` is lowered as
+  // v_cndmask + v_cmp_ne on top of the two compares: each compare can write its SGPR pair directly.)
+  template <int FORM>
+  static DEV uint64_t pass_mask(const DevProgram& P, const DevFastPlan& F, uint8_t pred, const COLV& cur, uint32_t cv, const u64x16& reg, uint32_t rv, const PREP& = PREP()) {
+    if constexpr (FORM == 0) {
+      return __ballot(pass(P, F, pred, cur, cv, reg, rv));
+    } else {
+      uint64_t ok = ~0ull;
+      if constexpr (SIG::NP > 0) ok &= __ballot(term_ct<((FORM >> 0) & 7) ? ((FORM >> 0) & 7) : 1>(SIG::term_cls(0), cur[SIG::term_col(0)], F.term_imm[0]));
+      if constexpr (SIG::NP > 1) ok &= __ballot(term_ct<((FORM >> 3) & 7) ? ((FORM >> 3) & 7) : 1>(SIG::term_cls(1), cur[SIG::term_col(1)], F.term_imm[1]));
+      if constexpr (SIG::NP > 2) ok &= __ballot(term_ct<((FORM >> 6) & 7) ? ((FORM >> 6) & 7) : 1>(SIG::term_cls(2), cur[SIG::term_col(2)], F.term_imm[2]));
+      if constexpr (SIG::NP > 3) ok &= __ballot(term_ct<((FORM >> 9) & 7) ? ((FORM >> 9) & 7) : 1>(SIG::term_cls(3), cur[SIG::term_col(3)], F.term_imm[3]));
       return ok;
     }
   }
@@ -935,6 +960,10 @@ struct PlanPolicy {
   template <int FORM>
   static DEV bool pass_form(const DevProgram& P, const DevFastPlan& F, uint8_t pred, const COLV& cur, uint32_t cv, const u64x16& reg, uint32_t rv, const PREP& W) {
     return pass(P, F, pred, cur, cv, reg, rv, W);
+  }
+  template <int FORM>
+  static DEV uint64_t pass_mask(const DevProgram& P, const DevFastPlan& F, uint8_t pred, const COLV& cur, uint32_t cv, const u64x16& reg, uint32_t rv, const PREP& W) {
+    return __ballot(pass(P, F, pred, cur, cv, reg, rv, W));
   }
   static DEV uint64_t key(const DevProgram&, const DevFastPlan& F, uint8_t, int k, const COLV&, uint32_t, const u64x16& reg, uint32_t) {
     if constexpr (FIXED) return reg[0];
