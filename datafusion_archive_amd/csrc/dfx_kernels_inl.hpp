@@ -757,7 +757,7 @@ struct PlanPolicy {
   static constexpr int kPredTerms = -1;
   static constexpr int U = U_;
   static constexpr int kStaticNa = FIXED ? 1 : 0;
-  static_assert(U_ * 8 + 1 <= 64, "one lane per validity byte of a trip");
+  static_assert(!NULLS || U_ * 8 + 1 <= 64, "one lane per validity byte of a trip");
   typedef PlanBank<NCOL, NULLS> COLV;
   // The terms' plan words, one copy per lane (see plan_word): everything a term needs is a vector operand, the predicate is
   // evaluated without one scalar instruction besides the `t < np` guards.  Five registers per term: the range, and one word
