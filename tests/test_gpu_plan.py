@@ -236,3 +236,42 @@ def test_plan_int32_key_host_batches_at_odd_offsets():
             got = gpu_aggregate([Column(0)], aggs, whole.schema, batches, filter_expr=pred)
             assert_groups_identical(got, want, 1, f"int32 key, odd offsets: {name}, strategy {strategy}")
     ex.set_option("agg.strategy", 0)
+
+
+def test_per_aggregate_scans_under_skew_growth_and_late_wide_keys():
+    """One scan per aggregate (agg.split_aggregates) shares the spill list, the routing scratch and the key plane between the
+    aggregates' scans: Zipf keys (regions overflow into the spill list, hot-key pairs), a table that starts at 2^14 slots and
+    grows by rehash + replay while two scans feed it, and host batches whose later rows carry keys without a 32-bit image
+    (the stream leaves narrow mode between two aggregates' scans).  Against the oracle and against the one-scan form."""
+    # (1) Zipf keys, resident table, automatic strategy and a forced small table
+    syn = [("k", ex.SYNTH_I64_ZIPF, 0, 1000000.0, 0.0), ("v", ex.SYNTH_F64_EXACT, 1, 0.0, 0.0), ("w", ex.SYNTH_I64_UNIFORM, 2, 1000.0, 0.0)]
+    schema = pa.schema([("k", pa.int64()), ("v", pa.float64()), ("w", pa.int64())])
+    n = (1 << 22) + 777
+    aggs = [SUM_V, MAX_W, COUNT_V]
+    _s, _kept, want = oracle.run_synth_query(syn, SEED, 0, n, 1024, HEAD, [Column(0)], aggs)
+    for opts in ((), (("agg.capacity_log2", 14),), (("agg.strategy", 3), ("agg.capacity_log2", 14)), (("agg.split_aggregates", 0),)):
+        for k, v in opts:
+            ex.set_option(k, v)
+        try:
+            t = ex.DeviceTable.synth(syn, SEED, 0, n)
+            got = gpu_aggregate([Column(0)], aggs, schema, [], filter_expr=HEAD, source=t.scan(1 << 20))
+            _assert_bit_exact(got, want, f"zipf keys, options {opts}")
+        finally:
+            for k, _v in opts:
+                ex.set_option(k, {"agg.capacity_log2": 0, "agg.strategy": 0, "agg.split_aggregates": 1}[k])
+    # (2) wide and negative keys from the third host batch on
+    rng = np.random.default_rng(4)
+    m = 3 * 700001
+    k = rng.integers(0, 300000, m).astype(np.int64)
+    k[2 * 700001 + 5::1013] += 1 << 40
+    k[2 * 700001 + 9::2027] = -k[2 * 700001 + 9::2027] - 1
+    v = rng.integers(0, 1 << 20, m).astype(np.float64) / 1024.0
+    w = rng.integers(0, 1000, m).astype(np.int64)
+    whole = pa.RecordBatch.from_arrays([pa.array(k), pa.array(v), pa.array(w)], names=["k", "v", "w"])
+    batches = [whole.slice(i * 700001, 700001) for i in range(3)]
+    want = oracle.aggregate([Column(0)], aggs, [oracle.filter_next(HEAD, b) for b in batches])
+    for strategy in (0, 3):
+        ex.set_option("agg.strategy", strategy)
+        got = gpu_aggregate([Column(0)], aggs, whole.schema, batches, filter_expr=HEAD)
+        assert_groups_identical(got, want, 1, f"late wide keys, strategy {strategy}")
+    ex.set_option("agg.strategy", 0)
