@@ -1813,6 +1813,11 @@ void AggregateRelation::explain(std::string* out, int depth) const {
     if (m.shared_operand())
       text += strfmt("; %d aggregates of ONE operand: the partitioned strategy routes 12-byte rows {hash image, raw operand} while keys are "
                      "narrow and batches have no nulls, pass 2 applies every aggregate to it", m.na);
+    if (m.split_ready && !m.split_done)
+      text += strfmt("; %d aggregates of different operands: if the calibration slice chooses the partitioned strategy, one scan per "
+                     "aggregate (its own fused program and accumulator plane over the same keys: 12-byte routed rows, the one-aggregate "
+                     "kernels; agg.split_aggregates)", m.na_total);
+    if (m.split_done) text += strfmt("; ran one scan per aggregate (%d scans per batch: agg.split_aggregates)", (int)m.chunks.size());
     if (!m.dicts.empty()) text += strfmt(", %d Utf8 keys dictionary-encoded on the device", (int)m.dicts.size());
     if (m.built && m.kw > 0)  // after the input was drained: what actually ran
       text += strfmt("; ran %lld rows: %s, %llu of 2^%d table slots occupied", (long long)m.rows_seen,

@@ -318,6 +318,12 @@ def test_explain_baseline_shapes_hit_their_static_signatures():
     assert "3 aggregates of ONE operand" in _explain_aggregate(kv, None, [Column(0)], [sum_v, AggregateFunction("MIN", [Column(1)], f64), AggregateFunction("MAX", [Column(1)], f64)])
     assert "ONE operand" not in _explain_aggregate(kv, None, [Column(0)], [sum_v, AggregateFunction("MAX", [Column(0)], DataType.Int64)])
     assert "ONE operand" not in _explain_aggregate(kv, pred, [Column(0)], [sum_v])
+    # ... aggregates of DIFFERENT operands under one key: one scan per aggregate if the partitioned strategy is chosen (round 4)
+    text = _explain_aggregate(kvw, pred, [Column(0)], [sum_v, AggregateFunction("MIN", [Column(2)], f64)])
+    assert "2 aggregates of different operands" in text and "one scan per aggregate" in text, text
+    assert "different operands" not in _explain_aggregate(kv, pred, [Column(0)], [sum_v])
+    assert "different operands" not in _explain_aggregate(kv, pred, [Column(0)], [AggregateFunction("AVG", [Column(1)], f64)])
+    assert "different operands" not in _explain_aggregate(kvw, pred, [Column(0), Column(2)], [sum_v, AggregateFunction("MIN", [Column(2)], f64)])  # two keys
     assert "SSA interpreter" in _explain_aggregate(kv, pred, [Column(0)], [AggregateFunction("SUM", [BinaryExpr(Column(1), Operator.Plus, Column(1))], f64)])
 
 
