@@ -101,6 +101,8 @@ struct AggregateRelation::Impl {
   std::vector<std::shared_ptr<void>> import_owners, import_keep;
   void activate(int c);
   DevTable view_of(const DevTable& any_view, uint64_t* full_accs, int c) const;
+  DevTable full_view(const DevTable& any_view, uint64_t* full_accs) const;
+  Status partial_view_check() const;
   Status build_chunk_programs(Chunk& ch);
   std::unique_ptr<ProgramBuilder> builder;
   DevAggPlan plan;
@@ -489,6 +491,28 @@ DevTable AggregateRelation::Impl::view_of(const DevTable& any_view, uint64_t* fu
     v.acc_init[a] = a < ch.n ? acc_init_all[ch.a0 + a] : 0;
   }
   return v;
+}
+
+// EVERY accumulator plane of a table as one view (the planes are contiguous by accumulator index, whatever the chunking):
+// what the public partial_* entry points move.  The drain may have replaced the chunk list (one scan per aggregate,
+// agg.split_aggregates): a chunk's view would then carry one plane of several and the others would be emitted with their
+// init values (round-4 advisor finding).  Valid while all accumulators fit one kernel's view (<= kMaxAggs).
+DevTable AggregateRelation::Impl::full_view(const DevTable& any_view, uint64_t* full_accs) const {
+  DevTable v = any_view;
+  v.accs = full_accs;
+  v.na = na_total;
+  for (int a = 0; a < kMaxAggs; ++a) {
+    v.acc_kind[a] = a < na_total ? acc_kind_all[a] : 0;
+    v.val_xform[a] = a < na_total ? val_xform_all[a] : 0;
+    v.acc_init[a] = a < na_total ? acc_init_all[a] : 0;
+  }
+  return v;
+}
+
+// (after the drain: the chunk list is final)
+Status AggregateRelation::Impl::partial_view_check() const {
+  if (na_total > kMaxAggs) return Status::Err(DFX_NOT_IMPLEMENTED, strfmt("multi-GPU exchange of more than %d accumulators", kMaxAggs));
+  return Status::OK();
 }
 
 // what the calibration slice's outcome depends on: the fused program (predicate, key and argument expressions with
@@ -1284,8 +1308,11 @@ Status AggregateRelation::Impl::consume_batch(const DeviceBatch& b) {
       stop_after_decision = false;
       DFX_RETURN_IF_ERROR(st);
     }
-    split_decided = true;
-    if (use_partition || forced) {
+    // decided = a strategy has been chosen.  An empty first batch (or one a real FilterRelation emptied) chooses nothing:
+    // the next batch comes back here (round-4 advisor finding: a decision recorded before any calibration left a later
+    // "partitioned" verdict with the split pending for good -- every launch on per-row global atomics)
+    split_decided = forced || lds_calibrated || (decided_rows == 0 && b.num_rows > 0);
+    if (split_decided && (use_partition || forced)) {
       DFX_RETURN_IF_ERROR(flush_pass2());
       DFX_RETURN_IF_ERROR(settle_ctrl());
       install_chunks(std::move(single_chunks));
@@ -1855,8 +1882,8 @@ Status AggregateRelation::partial_build(int world, int* n_words, int64_t* counts
   Impl& m = *impl_;
   if (!m.deferred.ok()) return m.deferred;
   if (m.kw == 0) return Status::Err(DFX_NOT_IMPLEMENTED, "partial exchange is for GROUP BY aggregates");
-  if (m.chunks.size() > 1) return Status::Err(DFX_NOT_IMPLEMENTED, strfmt("multi-GPU exchange of more than %d accumulators", kMaxAggs));
   if (world < 1 || world > 1024) return Status::Err(DFX_GENERAL, "world must be in 1..1024");
+  DFX_RETURN_IF_ERROR(m.partial_view_check());  // (by accumulators, not by chunks: the drain may re-chunk -- one scan per aggregate)
   DFX_RETURN_IF_ERROR(m.drain());
   hipStream_t s = ctx().stream;
   Status st;
@@ -1868,7 +1895,7 @@ Status AggregateRelation::partial_build(int world, int* n_words, int64_t* counts
   DFX_HIP(hipMemcpyAsync(m.export_counts.data(), dc.get(), sizeof(uint64_t) * (size_t)world, hipMemcpyDeviceToHost, s));
   DFX_HIP(hipStreamSynchronize(s));
   for (int r = 0; r < world; ++r) counts[r] = (int64_t)m.export_counts[r];
-  *n_words = m.kw + m.na;
+  *n_words = m.kw + m.na_total;
   return Status::OK();
 }
 
@@ -1876,7 +1903,7 @@ Status AggregateRelation::partial_export(void* dst_device, int64_t dst_words) {
   Impl& m = *impl_;
   if (m.export_counts.empty()) return Status::Err(DFX_GENERAL, "partial_build must precede partial_export");
   std::vector<int64_t> counts(m.export_counts.begin(), m.export_counts.end());
-  return partial_export_with(counts, dst_device, dst_words, true);
+  return partial_export_with(counts, dst_device, dst_words, true, /*all_planes=*/true);
 }
 
 // the count step of partial_build with the counts left on the device: d_counts[0, world) = groups per destination
@@ -1887,8 +1914,8 @@ Status AggregateRelation::partial_count_device(int world, int* n_words, uint64_t
   Impl& m = *impl_;
   if (!m.deferred.ok()) return m.deferred;
   if (m.kw == 0) return Status::Err(DFX_INTERNAL_ERROR, "partial_count_device is for GROUP BY aggregates");
-  if (m.chunks.size() > 1) return Status::Err(DFX_NOT_IMPLEMENTED, strfmt("multi-GPU exchange of more than %d accumulators", kMaxAggs));
   if (world < 1 || world > 1024) return Status::Err(DFX_GENERAL, "world must be in 1..1024");
+  DFX_RETURN_IF_ERROR(m.partial_view_check());
   DFX_RETURN_IF_ERROR(m.drain());
   hipStream_t s = ctx().stream;
   Status st;
@@ -1897,14 +1924,18 @@ Status AggregateRelation::partial_count_device(int world, int* n_words, uint64_t
   DFX_HIP(hipMemsetAsync(owner->get(), 0, sizeof(uint64_t) * (size_t)world * 2, s));
   DFX_HIP(launch_partial_count(m.T, world, (uint64_t*)owner->get(), s));
   *d_counts = (uint64_t*)owner->get();
-  *n_words = m.kw + m.na;
+  *n_words = m.kw + m.na_total;
   m.export_counts.assign((size_t)world, 0);  // (filled by partial_export_with)
   return Status::OK();
 }
 
-Status AggregateRelation::partial_export_with(const std::vector<int64_t>& counts, void* dst_device, int64_t dst_words, bool sync) {
+Status AggregateRelation::partial_export_with(const std::vector<int64_t>& counts, void* dst_device, int64_t dst_words, bool sync, bool all_planes) {
   Impl& m = *impl_;
   const int world = (int)counts.size();
+  // all_planes: the public partial_* path -- every accumulator in one row, whatever chunking the drain installed;
+  // otherwise the ACTIVE chunk's planes (the in-library exchange walks the chunks itself)
+  const DevTable Tv = all_planes ? m.full_view(m.T, m.accs_full) : m.T;
+  const int na_v = all_planes ? m.na_total : m.na;
   m.export_counts.assign(counts.begin(), counts.end());
   std::vector<uint64_t> base((size_t)world, 0);
   uint64_t total = 0;
@@ -1912,7 +1943,7 @@ Status AggregateRelation::partial_export_with(const std::vector<int64_t>& counts
     base[r] = total;
     total += m.export_counts[r];
   }
-  if ((uint64_t)dst_words < total * (uint64_t)(m.kw + m.na))
+  if ((uint64_t)dst_words < total * (uint64_t)(m.kw + na_v))
     return Status::Err(DFX_GENERAL, "partial export buffer too small");
   hipStream_t s = ctx().stream;
   Status st;
@@ -1928,7 +1959,7 @@ Status AggregateRelation::partial_export_with(const std::vector<int64_t>& counts
     DFX_HIP(hipMemcpy(d, hw.data(), sizeof(uint64_t) * hw.size(), hipMemcpyHostToDevice));
   }
   if (m.kw == 1) DFX_HIP(launch_fill_u64(m.T.keys + m.T.mask + 1, kEmptyKey, 1, s));
-  DFX_HIP(launch_partial_scatter(m.T, world, d, d + world, d + 2 * world, (uint64_t*)dst_device, s));
+  DFX_HIP(launch_partial_scatter(Tv, world, d, d + world, d + 2 * world, (uint64_t*)dst_device, s));
   if (sync) {
     DFX_HIP(hipStreamSynchronize(s));
   } else {
@@ -1964,7 +1995,7 @@ Status AggregateRelation::exchange_count(int world, uint64_t* d_counts) {
 Status AggregateRelation::exchange_export_chunk(int c, const std::vector<int64_t>& counts, void* dst_device, int64_t dst_words) {
   Impl& m = *impl_;
   if (m.chunks.size() > 1) m.activate(c);
-  return partial_export_with(counts, dst_device, dst_words, /*sync=*/false);
+  return partial_export_with(counts, dst_device, dst_words, /*sync=*/false, /*all_planes=*/false);
 }
 
 Status AggregateRelation::exchange_import_begin(uint64_t total_groups) {
@@ -2172,15 +2203,17 @@ Status AggregateRelation::partial_import(const void* src_device, const int64_t* 
   DevTable Tn;
   std::vector<std::shared_ptr<void>> owners;
   uint64_t* accs_full_new = nullptr;
+  DFX_RETURN_IF_ERROR(m.partial_view_check());
   DFX_RETURN_IF_ERROR(m.alloc_table(cap_log2, &Tn, &owners, true, &accs_full_new));
   DevRows no_spill;
   no_spill.words = nullptr;
   no_spill.capacity = 0;
-  const int nw = m.kw + m.na;
+  const int nw = m.kw + m.na_total;  // rows as partial_export wrote them: every accumulator
+  const DevTable Tall = m.full_view(Tn, accs_full_new);
   uint64_t off = 0;
   for (int b = 0; b < n_buckets; ++b) {
     if (counts[b] > 0)
-      DFX_HIP(launch_merge_bucket((const uint64_t*)src_device + (size_t)nw * off, (uint64_t)counts[b], Tn, no_spill, s));
+      DFX_HIP(launch_merge_bucket((const uint64_t*)src_device + (size_t)nw * off, (uint64_t)counts[b], Tall, no_spill, s));
     off += (uint64_t)counts[b];
   }
   DFX_HIP(hipStreamSynchronize(s));

@@ -156,15 +156,23 @@ static Status all_gather_v_words(dfx_comm* c, const uint64_t* mine, const std::v
 
 constexpr uint64_t kPeerFailed = ~0ull;  // travels instead of a count / a flag: the sender hit an error, every rank gives up together
 
-// test hook (tests/test_gpu_exchange_world2.py): DFX_EXCHANGE_FAIL = "<rank>:<stage>" makes that rank fail locally at that stage
+// test hook (tests/test_gpu_exchange_world2.py): the process-wide switch dfx_set_option("test.exchange_fail", rank << 8 | stage)
+// makes that rank fail locally at that stage (stage numbers: kFailStages below; 0 = off, the default).  A switch the host
+// sets explicitly, not an environment variable the production library would consult in every exchange.
+static int64_t g_exchange_fail = 0;
+void set_exchange_test_failure(int64_t v) { g_exchange_fail = v; }
+static const char* const kFailStages[] = {"", "drain", "count", "payload_alloc", "export", "dict_local", "dict_blob_alloc", "merge"};
 static bool inject_failure(const dfx_comm* c, const char* stage) {
-  const char* e = getenv("DFX_EXCHANGE_FAIL");
-  if (!e) return false;
-  const char* colon = strchr(e, ':');
-  return colon && atoi(e) == c->rank && !strcmp(colon + 1, stage);
+  const int64_t v = g_exchange_fail;
+  if (v <= 0) return false;
+  const int st = (int)(v & 0xFF);
+  return st > 0 && st < (int)(sizeof(kFailStages) / sizeof(kFailStages[0])) && (int)(v >> 8) == c->rank && !strcmp(kFailStages[st], stage);
 }
 static Status injected(const dfx_comm* c, const char* stage) {
-  return inject_failure(c, stage) ? Status::Err(DFX_EXECUTION_ERROR, strfmt("injected failure at stage '%s' (DFX_EXCHANGE_FAIL)", stage)) : Status::OK();
+  return inject_failure(c, stage) ? Status::Err(DFX_EXECUTION_ERROR, strfmt("injected failure at stage '%s' (test.exchange_fail)", stage)) : Status::OK();
+}
+static Status hip_local(hipError_t e) {
+  return e == hipSuccess ? Status::OK() : Status::Err(DFX_EXECUTION_ERROR, strfmt("HIP error %s in the exchange", hipGetErrorString(e)));
 }
 
 // THE rule of this file: between its first and its last collective a rank never returns on a LOCAL failure.  It folds the
@@ -181,14 +189,26 @@ static Status agree(dfx_comm* c, const Status& local, uint64_t shape, const char
   std::vector<uint64_t> hf((size_t)W * 2, 0);
   for (int r = 0; r < W; ++r) hf[(size_t)r] = word;
   uint64_t* d = c->words + slab_flags(W);
-  DFX_HIP(hipMemcpyAsync(d, hf.data(), sizeof(uint64_t) * hf.size(), hipMemcpyHostToDevice, s));
-  DFX_RETURN_IF_ERROR(all_to_all_words(
+  // a local HIP failure here does not excuse this rank from the round: its peers are already waiting in it.  It takes part
+  // with whatever the slab holds (a stale word at worst: the peers then disagree on the shape and leave as well) and
+  // reports its own error afterwards.
+  Status mine = local;
+  {
+    Status cp = hip_local(hipMemcpyAsync(d, hf.data(), sizeof(uint64_t) * hf.size(), hipMemcpyHostToDevice, s));
+    if (!cp.ok()) (void)hipStreamSynchronize(s);
+    if (mine.ok()) mine = cp;
+  }
+  Status coll = all_to_all_words(
       c, [&](int peer, const void** p, size_t* n) { *p = d + peer; *n = 1; },
-      [&](int peer, void** p, size_t* n) { *p = d + W + peer; *n = 1; }, s));
-  DFX_HIP(hipMemcpyAsync(hf.data(), d, sizeof(uint64_t) * hf.size(), hipMemcpyDeviceToHost, s));
-  DFX_HIP(hipStreamSynchronize(s));
+      [&](int peer, void** p, size_t* n) { *p = d + W + peer; *n = 1; }, s);
+  if (!coll.ok()) return mine.ok() ? coll : mine;  // (a collective that fails inside RCCL is RCCL's to report)
+  {
+    Status rb = hip_local(hipMemcpyAsync(hf.data(), d, sizeof(uint64_t) * hf.size(), hipMemcpyDeviceToHost, s));
+    Status sy = hip_local(hipStreamSynchronize(s));
+    if (mine.ok()) mine = rb.ok() ? sy : rb;
+  }
   ++*host_syncs;
-  if (!local.ok()) return local;
+  if (!mine.ok()) return mine;
   for (int r = 0; r < W; ++r)
     if (hf[(size_t)W + r] == kPeerFailed) return Status::Err(DFX_EXECUTION_ERROR, strfmt("multi-GPU exchange: rank %d failed %s", r, what));
   for (int r = 0; r < W; ++r)
@@ -307,11 +327,17 @@ Status AggregateRelation::exchange(dfx_comm* c, int64_t* stats) {
       if (world > 1) {
         DFX_NCCL(rccl().AllGather(mine, all, (size_t)nw, ncclUint64, c->comm, s), "ncclAllGather");
       } else {
-        DFX_HIP(hipMemcpyAsync(all, mine, sizeof(uint64_t) * (size_t)nw, hipMemcpyDeviceToDevice, s));
+        Status cp = hip_local(hipMemcpyAsync(all, mine, sizeof(uint64_t) * (size_t)nw, hipMemcpyDeviceToDevice, s));
+        if (local.ok()) local = cp;
       }
+      // (a local HIP failure is folded into `local`: the peers are about to enter the next chunk's all-gather and the
+      // agree() behind the loop -- this rank goes with them)
       std::vector<uint64_t> host((size_t)nw * (size_t)world);
-      DFX_HIP(hipMemcpyAsync(host.data(), all, sizeof(uint64_t) * host.size(), hipMemcpyDeviceToHost, s));
-      DFX_HIP(hipStreamSynchronize(s));
+      {
+        Status rb = hip_local(hipMemcpyAsync(host.data(), all, sizeof(uint64_t) * host.size(), hipMemcpyDeviceToHost, s));
+        Status sy = hip_local(hipStreamSynchronize(s));
+        if (local.ok()) local = rb.ok() ? sy : rb;
+      }
       ++host_syncs;
       if (local.ok()) local = ungrouped_state_merge(host.data(), world, c->rank);
     }
@@ -352,9 +378,14 @@ Status AggregateRelation::exchange(dfx_comm* c, int64_t* stats) {
         [&](int peer, void** p, size_t* n) { *p = d_counts + world + peer; *n = 1; }, s));
   }
   std::vector<uint64_t> hc((size_t)world * 2);
-  DFX_HIP(hipMemcpyAsync(hc.data(), d_counts, sizeof(uint64_t) * hc.size(), hipMemcpyDeviceToHost, s));
-  DFX_HIP(hipStreamSynchronize(s));  // the ONE read-back of the exchange proper: buffer sizes
+  {  // the ONE read-back of the exchange proper: buffer sizes
+    Status rb = hip_local(hipMemcpyAsync(hc.data(), d_counts, sizeof(uint64_t) * hc.size(), hipMemcpyDeviceToHost, s));
+    Status sy = hip_local(hipStreamSynchronize(s));
+    if (local.ok()) local = rb.ok() ? sy : rb;
+  }
   ++host_syncs;
+  // (every rank has finished the count round -- the last collective before this point -- so leaving here strands nobody:
+  // a rank that failed sent the failure mark, or, if it could not even do that, its peers fail in the agree() they go to next)
   if (!local.ok()) return local;
   for (int r = 0; r < world; ++r)
     if (hc[(size_t)world + r] == kPeerFailed) return Status::Err(DFX_EXECUTION_ERROR, strfmt("multi-GPU exchange: rank %d failed before the exchange", r));

@@ -966,7 +966,7 @@ Status FilterRelation::next(DeviceBatch* out, bool* has) {
     kept = (uint64_t)hc[CTRL_PASSED_LO] | ((uint64_t)hc[CTRL_PASSED_HI] << 32);
     errbits = hc[CTRL_ERROR];
     single_pass_done = true;
-    if (errbits == 8u) {
+    if (errbits & 8u) {  // (also next to another error bit: the fused outputs sit at wrong offsets, and the second pass reports the real error)
       // The look-back gave up waiting (its grid is sized for an EMPTY device: other work on the GPU -- another process, a
       // multi-rank dry run -- can keep a workgroup from becoming resident).  Not an error of the query: this batch takes the
       // two-pass form, which has no inter-workgroup waits.

@@ -234,7 +234,7 @@ class AggregateRelation : public Relation {
   const void* ungrouped_state_device() const;
   Status ungrouped_state_merge(const uint64_t* all_states, int world, int rank);  // fold the ranks' states, in rank order
   Status partial_count_device(int world, int* n_words, uint64_t** d_counts, std::shared_ptr<void>* owner);  // counts stay on the device
-  Status partial_export_with(const std::vector<int64_t>& counts, void* dst_device, int64_t dst_words, bool sync);
+  Status partial_export_with(const std::vector<int64_t>& counts, void* dst_device, int64_t dst_words, bool sync, bool all_planes = false);
   // the pieces of the in-library exchange (dfx_exchange.cpp).  Accumulators beyond kMaxAggs live in several chunks of planes
   // over the same keys: groups are counted once, every chunk is exported / sent / merged with its own planes.  Utf8 keys:
   // the rank-local dictionary ids are turned into ids of a dictionary every rank builds identically (all ranks' strings
@@ -261,5 +261,6 @@ class AggregateRelation : public Relation {
 
 // shared by filter / aggregate: CTRL_ERROR bits -> the reference's error
 Status error_from_ctrl(uint32_t bits);
+void set_exchange_test_failure(int64_t v);  // dfx_exchange.cpp: dfx_set_option("test.exchange_fail", rank << 8 | stage)
 
 }  // namespace dfx

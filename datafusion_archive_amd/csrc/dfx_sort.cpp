@@ -65,6 +65,9 @@ class SortRelation : public Relation {
   RelationKind kind() const override { return REL_SORT; }
   const SchemaInfo& schema() const override { return schema_; }
   Status next(DeviceBatch* out, bool* has) override;
+  // every single-input operator forwards the hint (rule: the FIRST operator with its own option set above a host source
+  // decides how that source moves its batches -- HostStreamRelation::host_stream_options ignores later callers)
+  void host_stream_options(const HostStreamOptions& o) override { if (projected_) projected_->host_stream_options(o); }
   // ORDER BY ... LIMIT k: a LimitRelation directly above tells the sort that only the first k rows will be read
   void set_limit(int64_t k) { limit_ = k; }
   void explain(std::string* out, int depth) const override {

@@ -451,6 +451,10 @@ int32_t dfx_set_option(const char* key, int64_t value) {
     pool_inject_oom((int)value);
     return DFX_OK;
   }
+  if (!strcmp(key, "test.exchange_fail")) {  // test hook: rank << 8 | stage fails locally at that stage of dfx_aggregate_exchange (0: off)
+    set_exchange_test_failure(value);
+    return DFX_OK;
+  }
   return set_option_in(agg_options(), key, value) ? DFX_OK : DFX_GENERAL;
 }
 

@@ -58,7 +58,9 @@ CASES["peer_failure"] = (1000, None, [Column(0)], [agg("sum", BinaryExpr(Column(
 
 # ... the same for ungrouped aggregates: round 3 returned before the all-gather, the peers waited for ever
 CASES["ungrouped_peer_failure"] = (1000, None, [], [agg("sum", BinaryExpr(Column(1), Operator.Divide, Column(2))), agg("count", Column(1), U64)], {})
-# local failures INJECTED at the later stages (DFX_EXCHANGE_FAIL = "1:<stage>", csrc/dfx_exchange.cpp: inject_failure): the
+# stage numbers of dfx_set_option("test.exchange_fail", rank << 8 | stage) (csrc/dfx_exchange.cpp: kFailStages)
+EXCHANGE_FAIL_STAGES = ["", "drain", "count", "payload_alloc", "export", "dict_local", "dict_blob_alloc", "merge"]
+# local failures INJECTED at the later stages (the worker's DFX_EXCHANGE_FAIL = "1:<stage>" -> test.exchange_fail): the
 # count kernel, the payload buffers, the last export, a dictionary's blob buffers, the ungrouped merge -- the query and the
 # data are those of a passing case
 FAILURE_STAGES = {"alloc_failure_before_counts": ("int_keys_4_aggs", "count"), "payload_alloc_failure": ("int_keys_4_aggs", "payload_alloc"),

@@ -18,6 +18,12 @@ n_keys, pred, group, aggs, opts = xc.CASES[case]
 ex.init(0)
 for k, v in opts.items():
     ex.set_option(k, v)
+# the harness names the injected failure as "<rank>:<stage>" in the environment of the worker PROCESSES it starts; the
+# library itself reads no environment variable for it: the worker turns it into the library's test switch
+_fail = os.environ.get("DFX_EXCHANGE_FAIL")
+if _fail:
+    _r, _stage = _fail.split(":")
+    ex.set_option("test.exchange_fail", (int(_r) << 8) | xc.EXCHANGE_FAIL_STAGES.index(_stage))
 uid_path = os.path.join(tmp, f"uid_{case}")
 if rank == 0:
     uid = ex.Communicator.unique_id()

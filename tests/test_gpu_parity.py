@@ -1349,6 +1349,58 @@ def test_device_partial_exchange_emulated_ranks(world, strategy):
         assert min(sizes) > 0.5 * max(sizes), f"owner hash is badly balanced: {sizes}"
 
 
+@pytest.mark.parametrize("world", [1, 2])
+@pytest.mark.parametrize("strategy,batch_rows", [(3, 1 << 18), (0, 1 << 22)])
+def test_device_partial_exchange_after_the_drain_split_the_aggregates(world, strategy, batch_rows):
+    """Round-4 advisor finding: aggregates of DIFFERENT operands over many groups are re-chunked during the drain (one scan
+    per aggregate, agg.split_aggregates), after which the active chunk's view carries ONE accumulator plane.  The public
+    partial_build / partial_export / partial_import path must still move every accumulator: n_words = keys + ALL
+    accumulators, and MIN / MAX / COUNT of the other planes come out as the oracle's, not as their init values."""
+    import torch
+    ex.set_option("agg.strategy", strategy)
+    syn = [("k", ex.SYNTH_I64_UNIFORM, 0, 150000.0, 0.0), ("v", ex.SYNTH_F64_EXACT, 1, 0.0, 0.0), ("w", ex.SYNTH_F64_EXACT, 2, 0.0, 0.0)]
+    n, seed = (3 * (1 << 19)) if strategy == 3 else (1 << 23), 0xDF0A
+    schema = pa.schema([("k", pa.int64()), ("v", pa.float64()), ("w", pa.float64())])
+    aggs = [agg("sum", Column(1), F64), agg("max", Column(2), F64), agg("count", Column(2), DataType.UInt64), agg("min", Column(1), F64)]
+    pred = BinaryExpr(Column(1), Operator.Lt, lit(900.0))
+    per = (n // world) & ~63
+    rels, tables = [], []
+    for r in range(world):
+        t = ex.DeviceTable.synth(syn, seed, r * per, per if r < world - 1 else n - r * per)
+        tables.append(t)
+        rel = ex.FilterRelation(t.scan(batch_rows), ex.compile_scalar_expr(None, pred, schema), schema)
+        rels.append(ex.AggregateRelation(None, rel, [ex.compile_scalar_expr(None, Column(0), schema)],
+                                         [ex.compile_expr(None, a, schema) for a in aggs]))
+    built = [rel.partial_build(world) for rel in rels]
+    n_words = built[0][0]
+    assert all(b[0] == n_words for b in built) and n_words == 1 + len(aggs), n_words
+    assert "ran one scan per aggregate" in ex.explain(rels[0]), ex.explain(rels[0])  # the case under test: the drain did re-chunk
+    dev = torch.device("cuda:0")
+    sends = []
+    for rel, (_, counts) in zip(rels, built):
+        buf = torch.empty(max(1, n_words * sum(counts)), dtype=torch.int64, device=dev)
+        rel.partial_export(buf.data_ptr(), n_words * sum(counts))
+        sends.append(buf)
+    torch.cuda.synchronize()
+    outs = []
+    for r, rel in enumerate(rels):
+        parts, rc = [], []
+        for s_rank, (_, counts) in enumerate(built):
+            lo = n_words * sum(counts[:r])
+            parts.append(sends[s_rank][lo: lo + n_words * counts[r]])
+            rc.append(counts[r])
+        recv = torch.cat(parts) if sum(rc) else torch.empty(1, dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()
+        rel.partial_import(recv.data_ptr(), rc)
+        out = rel.next()
+        assert out is not None and rel.next() is None
+        outs.append(out)
+    got = pa.Table.from_batches(outs).combine_chunks().to_batches()[0]
+    ob = oracle.synth_batch(syn, seed, 0, n)
+    want = oracle.aggregate([Column(0)], aggs, [oracle.filter_next(pred, ob)])
+    assert_groups_identical(got, want, 1, f"emulated exchange after the split, world={world}")
+
+
 @pytest.mark.parametrize("strategy", [0, 1, 3])
 def test_avg_matches_oracle(strategy):
     """AVG (deviation D7) = SUM / COUNT in the argument's type: Float64, Float32, Int64 and Int32 arguments,
