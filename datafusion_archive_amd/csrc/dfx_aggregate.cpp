@@ -680,6 +680,14 @@ Status AggregateRelation::Impl::ensure_partition(int64_t rows, bool nulls_now) {
       PT.ws_scanners = (uint32_t)o.pass1_ws;  // (one split is built: any non-zero value runs it)
       if (partition_ws_bytes(PT.n_parts, 8) <= (size_t)158 * 1024) PT.flags |= PTF_WS;
     }
+    // dense scans (most rows routed): no ring protocol at all -- tiles of 8192 rows counting-sorted by partition in LDS and
+    // copied out in sorted order (dfx_k_partition_tile_inl.hpp).  One routed value (12- or 16-byte rows), contiguous regions,
+    // no hot-key pairs.  agg.pass1_tile: 1 when the calibration slice routed more than half of its rows, 2 whenever the shape allows
+    if (o.pass1_tile > 0 && (dense_seen || o.pass1_tile >= 2) && kw == 1 && na == 1 && PT.n_words == 2 && !(PT.flags & PTF_HOT) &&
+        o.partition_layout != 2 && PT.n_parts <= 512 && !(((uint32_t)o.partition_mode) & ~15u)) {
+      PT.flags |= PTF_TILE;
+      PT.flags &= ~PTF_WS;
+    }
     PT.mode = 2u | ((uint32_t)o.partition_mode & ~15u);
     PT.block = 1024;
     PT.stage_rows = 0;
@@ -1018,6 +1026,7 @@ Status AggregateRelation::Impl::launch_rows(const DeviceBatch& b, const DevProgr
     }
     DFX_HIP(launch_partition(prog, fpp, cols, p, T, pt, spill, n, bytes, s));
     if (pt.flags & PTF_SHARED) ++counters().agg_shared_operand_launches;
+    if (pt.flags & PTF_TILE) ++counters().agg_tile_launches;
     ++pt_pending;
     pt_fill_bound += pt_worst;
     pt_rows_in_flight += n;

@@ -126,6 +126,7 @@ struct Counters {
   long long export_alloc_us = 0;    // ... of which: result buffer allocation (pinned pool)
   long long agg_pass2_launches = 0;
   long long agg_growths = 0;
+  long long agg_tile_launches = 0;            // pass-1 launches asked to run tile-sorted (PTF_TILE)
   long long agg_shared_operand_launches = 0;  // pass-1 launches that routed {image, shared raw operand} rows (PTF_SHARED)
 };
 struct ScopedUs {  // adds the scope's wall time to a counter

@@ -887,6 +887,8 @@ __global__ __launch_bounds__(kBlock) void k_synth(int kind, int column_id, doubl
       ((int64_t*)out)[i] = (int64_t)__umul64hi(r, G);
     } else if (kind == 4) {
       ((int32_t*)out)[i] = (int32_t)__umul64hi(r, G);
+    } else if (kind == 5) {  // DFX_SYNTH_I64_WIDE
+      ((int64_t*)out)[i] = (int64_t)((__umul64hi(r, G) + 1ull) * 0x9E3779B97F4A7C15ull);
     } else {
       const uint64_t b = __umul64hi(r, (uint64_t)zipf_bits + 1ull);
       const uint64_t r2 = mix64(r ^ 0xD6E8FEB86659FD93ull);

@@ -2,5 +2,5 @@
 // value images, plan words in vector registers), <= 2 columns, GENK = 3 (4-byte+bitmaps: bit 0 4-byte columns widened, bit 1 validity bitmaps).
 #include "dfx_k_partition_ws_inl.hpp"
 namespace dfx {
-DFX_PARTITION_VARIANT_WS(10, DFX_ARG(PlanPolicyN<2, 2, 3>), DFX_ARG(PlanPolicyN<2, 2, 3>), DFX_ARG(PlanPolicy1<2, 2, 3>), DFX_ARG(PlanPolicy1<2, 4, 3>))
+DFX_PARTITION_VARIANT_WS(10, DFX_ARG(PlanPolicyN<2, 2, 3>), DFX_ARG(PlanPolicyN<2, 2, 3>), DFX_ARG(PlanPolicy1<2, 2, 3>), DFX_ARG(PlanPolicy1<2, 4, 3>), DFX_ARG(PlanPolicy1<2, 4, 3>))
 }  // namespace dfx

@@ -2,5 +2,5 @@
 // value images, plan words in vector registers), <= 2 columns, GENK = 1 (4-byte: bit 0 4-byte columns widened, bit 1 validity bitmaps).
 #include "dfx_k_partition_ws_inl.hpp"
 namespace dfx {
-DFX_PARTITION_VARIANT_WS(13, DFX_ARG(PlanPolicyN<2, 2, 1>), DFX_ARG(PlanPolicyN<2, 2, 1>), DFX_ARG(PlanPolicy1<2, 2, 1>), DFX_ARG(PlanPolicy1<2, 4, 1>))
+DFX_PARTITION_VARIANT_WS(13, DFX_ARG(PlanPolicyN<2, 2, 1>), DFX_ARG(PlanPolicyN<2, 2, 1>), DFX_ARG(PlanPolicy1<2, 2, 1>), DFX_ARG(PlanPolicy1<2, 4, 1>), DFX_ARG(PlanPolicy1<2, 4, 1>))
 }  // namespace dfx

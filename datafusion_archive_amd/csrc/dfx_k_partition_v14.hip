@@ -2,5 +2,5 @@
 // value images, plan words in vector registers), <= 2 columns, GENK = 2 (bitmaps: bit 0 4-byte columns widened, bit 1 validity bitmaps).
 #include "dfx_k_partition_ws_inl.hpp"
 namespace dfx {
-DFX_PARTITION_VARIANT_WS(14, DFX_ARG(PlanPolicyN<2, 2, 2>), DFX_ARG(PlanPolicyN<2, 2, 2>), DFX_ARG(PlanPolicy1<2, 2, 2>), DFX_ARG(PlanPolicy1<2, 4, 2>))
+DFX_PARTITION_VARIANT_WS(14, DFX_ARG(PlanPolicyN<2, 2, 2>), DFX_ARG(PlanPolicyN<2, 2, 2>), DFX_ARG(PlanPolicy1<2, 2, 2>), DFX_ARG(PlanPolicy1<2, 4, 2>), DFX_ARG(PlanPolicy1<2, 4, 2>))
 }  // namespace dfx

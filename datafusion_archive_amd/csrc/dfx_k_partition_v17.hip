@@ -5,5 +5,5 @@
 // ceiling the 8-byte kernels sit at, and it is the bytes in flight that bound it (431 -> 407 us per 2^27-row launch).
 #include "dfx_k_partition_ws_inl.hpp"
 namespace dfx {
-DFX_PARTITION_VARIANT_WS(17, DFX_ARG(PlanPolicy1<2, 2, 4>), DFX_ARG(PlanPolicy1<2, 2, 4>), DFX_ARG(PlanPolicy1<2, 2, 4>), DFX_ARG(PlanPolicy1<2, 8, 4>))
+DFX_PARTITION_VARIANT_WS(17, DFX_ARG(PlanPolicy1<2, 2, 4>), DFX_ARG(PlanPolicy1<2, 2, 4>), DFX_ARG(PlanPolicy1<2, 2, 4>), DFX_ARG(PlanPolicy1<2, 8, 4>), DFX_ARG(PlanPolicy1<2, 4, 4>))
 }  // namespace dfx

@@ -3,5 +3,5 @@
 // (the multi-value flavours of this unit are never launched: bit 2 belongs to the one-key, one-value binding)
 #include "dfx_k_partition_ws_inl.hpp"
 namespace dfx {
-DFX_PARTITION_VARIANT_WS(20, DFX_ARG(PlanPolicy1<4, 1, 6>), DFX_ARG(PlanPolicy1<4, 1, 6>), DFX_ARG(PlanPolicy1<4, 1, 6>), DFX_ARG(PlanPolicy1<4, 2, 6>))
+DFX_PARTITION_VARIANT_WS(20, DFX_ARG(PlanPolicy1<4, 1, 6>), DFX_ARG(PlanPolicy1<4, 1, 6>), DFX_ARG(PlanPolicy1<4, 1, 6>), DFX_ARG(PlanPolicy1<4, 2, 6>), DFX_ARG(PlanPolicy1<4, 2, 6>))
 }  // namespace dfx

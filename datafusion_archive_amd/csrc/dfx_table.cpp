@@ -255,6 +255,7 @@ bool set_option_in(AggOptions& o, const char* key, int64_t value) {
   else if (!strcmp(key, "export.kernel_copy")) o.export_kernel_copy = (int)value;
   else if (!strcmp(key, "agg.partition_producers")) o.partition_producers = (int)value;
   else if (!strcmp(key, "agg.pass1_ws")) o.pass1_ws = (int)value;
+  else if (!strcmp(key, "agg.pass1_tile")) o.pass1_tile = (int)value;
   else if (!strcmp(key, "agg.merge_scan_batches")) o.merge_scan_batches = (int)value;
   else if (!strcmp(key, "filter.single_pass")) o.filter_single_pass = (int)value;
   else if (!strcmp(key, "filter.dense")) o.filter_dense = (int)value;
@@ -339,9 +340,9 @@ int32_t dfx_table_synth(const dfx_synth_column* cols, int32_t n_cols, uint64_t s
       f.name = cols[c].name ? cols[c].name : strfmt("c%d", c);
       const int kind = DFX_SYNTH_KIND(cols[c].kind);
       const uint32_t permille = (uint32_t)DFX_SYNTH_NULL_PERMILLE(cols[c].kind);
-      f.dtype = (kind == DFX_SYNTH_I64_UNIFORM || kind == DFX_SYNTH_I64_ZIPF) ? DFX_INT64 : kind == DFX_SYNTH_I32_UNIFORM ? DFX_INT32 : DFX_FLOAT64;
+      f.dtype = (kind == DFX_SYNTH_I64_UNIFORM || kind == DFX_SYNTH_I64_ZIPF || kind == DFX_SYNTH_I64_WIDE) ? DFX_INT64 : kind == DFX_SYNTH_I32_UNIFORM ? DFX_INT32 : DFX_FLOAT64;
       f.nullable = permille != 0;
-      if (cols[c].kind < 0 || kind > DFX_SYNTH_I32_UNIFORM || permille > 1000 || (cols[c].kind >> 18) != 0)
+      if (cols[c].kind < 0 || kind > DFX_SYNTH_I64_WIDE || permille > 1000 || (cols[c].kind >> 18) != 0)
         return to_c(Status::Err(DFX_NOT_IMPLEMENTED, "unknown synthetic column kind"), err, errlen);
       t->schema.fields.push_back(f);
       DeviceColumn col;
@@ -435,6 +436,7 @@ int64_t dfx_counter_get(const char* name) {
   if (!strcmp(name, "agg_pass2_launches")) return counters().agg_pass2_launches;
   if (!strcmp(name, "agg_growths")) return counters().agg_growths;
   if (!strcmp(name, "agg_shared_operand_launches")) return counters().agg_shared_operand_launches;
+  if (!strcmp(name, "agg_tile_launches")) return counters().agg_tile_launches;
   if (!strcmp(name, "export_us")) return counters().export_us;
   if (!strcmp(name, "export_alloc_us")) return counters().export_alloc_us;
   return -1;

@@ -396,7 +396,7 @@ class Communicator:
 # ---------------------------------------------------------------------------------------------------
 # HBM-resident tables (the in-memory DataSource)
 # ---------------------------------------------------------------------------------------------------
-SYNTH_F64_UNIFORM, SYNTH_F64_EXACT, SYNTH_I64_UNIFORM, SYNTH_I64_ZIPF, SYNTH_I32_UNIFORM = 0, 1, 2, 3, 4
+SYNTH_F64_UNIFORM, SYNTH_F64_EXACT, SYNTH_I64_UNIFORM, SYNTH_I64_ZIPF, SYNTH_I32_UNIFORM, SYNTH_I64_WIDE = 0, 1, 2, 3, 4, 5
 
 
 def synth_nulls(kind: int, permille: int) -> int:

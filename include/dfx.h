@@ -266,7 +266,10 @@ typedef enum dfx_synth_kind {
   DFX_SYNTH_F64_EXACT = 1,   /* m * 2^-S, m uniform integer in [0,2^B): B = p0 (0: 20), S = p1 (0: 10)  (dtype Float64) */
   DFX_SYNTH_I64_UNIFORM = 2, /* uniform integer in [0, (int64)p0)          (dtype Int64)   */
   DFX_SYNTH_I64_ZIPF = 3,    /* floor(p0 ^ u) - 1 clipped to [0,p0): log-uniform skew (dtype Int64) */
-  DFX_SYNTH_I32_UNIFORM = 4  /* uniform integer in [0, (int32)p0): the same draw as I64_UNIFORM, stored in 4 bytes (dtype Int32) */
+  DFX_SYNTH_I32_UNIFORM = 4, /* uniform integer in [0, (int32)p0): the same draw as I64_UNIFORM, stored in 4 bytes (dtype Int32) */
+  DFX_SYNTH_I64_WIDE = 5     /* (u + 1) * 0x9E3779B97F4A7C15 mod 2^64 with u the I64_UNIFORM draw in [0, (int64)p0): p0 distinct keys
+                              * spread over all of Int64 -- hashed ids, both signs, (almost) none below 2^32 (dtype Int64).  The
+                              * reference takes any Int64 key (aggregate.rs:807-852) */
 } dfx_synth_kind;
 /* Nulls: `kind | (permille << 8)` gives the column a validity bitmap in which a row is NULL with probability permille / 1000
  * (1 .. 1000), decided by a draw of its own -- DFX_SYNTH_NULL_STREAM mixed into the column id -- so the values under the null

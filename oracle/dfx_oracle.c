@@ -994,6 +994,7 @@ int32_t orc_synth_fill(int32_t kind, int32_t column_id, double p0, double p1, ui
       }
       case DFX_SYNTH_I64_UNIFORM: ((int64_t*)out)[i] = (int64_t)mulhi64(r, (uint64_t)(int64_t)p0); break;
       case DFX_SYNTH_I32_UNIFORM: ((int32_t*)out)[i] = (int32_t)mulhi64(r, (uint64_t)(int64_t)p0); break;
+      case DFX_SYNTH_I64_WIDE: ((int64_t*)out)[i] = (int64_t)((mulhi64(r, (uint64_t)(int64_t)p0) + 1ull) * 0x9E3779B97F4A7C15ull); break;
       case DFX_SYNTH_I64_ZIPF: {
         /* log-uniform skew: k = floor(2^(u * log2(G))) - 1, computed in integers:
          * pick a bit-length b uniformly in [0, ceil(log2 G)], then a uniform value below 2^b. */
@@ -1026,7 +1027,7 @@ int64_t orc_synth_validity(int32_t column_id, int32_t permille, uint64_t seed, i
 }
 static int synth_dtype(int32_t kind) {
   const int k = DFX_SYNTH_KIND(kind);
-  return (k == DFX_SYNTH_I64_UNIFORM || k == DFX_SYNTH_I64_ZIPF) ? DFX_INT64 : k == DFX_SYNTH_I32_UNIFORM ? DFX_INT32 : DFX_FLOAT64;
+  return (k == DFX_SYNTH_I64_UNIFORM || k == DFX_SYNTH_I64_ZIPF || k == DFX_SYNTH_I64_WIDE) ? DFX_INT64 : k == DFX_SYNTH_I32_UNIFORM ? DFX_INT32 : DFX_FLOAT64;
 }
 
 /* ------------------------------------------------------------------------------------------ */

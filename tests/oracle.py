@@ -254,12 +254,12 @@ def aggregate(group_exprs: Sequence[Expr], aggr_exprs: Sequence[Expr],
 # ---------------------------------------------------------------------------------------------
 # synthetic data (definition shared with the device generator)
 # ---------------------------------------------------------------------------------------------
-SYNTH_F64_UNIFORM, SYNTH_F64_EXACT, SYNTH_I64_UNIFORM, SYNTH_I64_ZIPF, SYNTH_I32_UNIFORM = 0, 1, 2, 3, 4
+SYNTH_F64_UNIFORM, SYNTH_F64_EXACT, SYNTH_I64_UNIFORM, SYNTH_I64_ZIPF, SYNTH_I32_UNIFORM, SYNTH_I64_WIDE = 0, 1, 2, 3, 4, 5
 
 
 def synth_column(kind: int, column_id: int, p0: float, p1: float, seed: int, row_begin: int, n: int) -> np.ndarray:
     kind &= 0xFF
-    out = np.empty(n, dtype=np.int64 if kind in (SYNTH_I64_UNIFORM, SYNTH_I64_ZIPF) else np.int32 if kind == SYNTH_I32_UNIFORM else np.float64)
+    out = np.empty(n, dtype=np.int64 if kind in (SYNTH_I64_UNIFORM, SYNTH_I64_ZIPF, SYNTH_I64_WIDE) else np.int32 if kind == SYNTH_I32_UNIFORM else np.float64)
     code = lib().orc_synth_fill(kind, column_id, p0, p1, seed, row_begin, n, out.ctypes.data_as(ctypes.c_void_p))
     if code != 0:
         raise OracleError(code, "orc_synth_fill")

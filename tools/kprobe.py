@@ -8,14 +8,16 @@ rows = int(float(sys.argv[1])); groups = float(sys.argv[2]); filt = int(sys.argv
 LO, HI = 204.8, 409.6
 UNGROUPED = False
 ZIPF = False
+WIDE = False
 for kv in sys.argv[4:]:
     if kv == "ungrouped": UNGROUPED = True; continue
     if kv == "zipf": ZIPF = True; continue
+    if kv == "wide": WIDE = True; continue
     if kv.startswith("lo="): LO = float(kv[3:]); continue
     if kv.startswith("hi="): HI = float(kv[3:]); continue
     k, v = kv.split("="); ex.set_option(k, int(v))
 ex.init(0)
-syn = [("k", ex.SYNTH_I64_ZIPF if ZIPF else ex.SYNTH_I64_UNIFORM, 0, groups, 1.0 if ZIPF else 0.0), ("v", ex.SYNTH_F64_EXACT, 1, 0.0, 0.0)]
+syn = [("k", ex.SYNTH_I64_WIDE if WIDE else ex.SYNTH_I64_ZIPF if ZIPF else ex.SYNTH_I64_UNIFORM, 0, groups, 1.0 if ZIPF else 0.0), ("v", ex.SYNTH_F64_EXACT, 1, 0.0, 0.0)]
 schema = pa.schema([("k", pa.int64()), ("v", pa.float64())])
 t = ex.DeviceTable.synth(syn, 0xDF02, 0, rows)
 lit = lambda v: Literal(ScalarValue.Float64(v))
