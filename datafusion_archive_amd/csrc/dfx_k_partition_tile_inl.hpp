@@ -1,4 +1,4 @@
-// dfx_k_partition_tile_inl.hpp -- pass 1 of the partitioned GROUP BY, TILE-SORTED flavour (PTF_TILE): dense scans.
+// dfx_k_partition_tile_inl.hpp -- pass 1 of the partitioned GROUP BY, TILE-BUCKETED flavour (PTF_TILE): dense scans.
 //
 // The ring kernels (dfx_k_partition_inl.hpp, dfx_k_partition_ws_inl.hpp) write-combine routed rows through per-partition LDS
 // rings that any wave may append to at any time; the price is a protocol of dependent LDS round trips per routed batch of 64
@@ -7,43 +7,41 @@
 // is routed) and a DENSE scan does not: config 3 (no predicate, every row routed) spent 414 us per 2^26-row launch where its
 // traffic (1.07 GB read + 0.81 GB written) asks for 300.
 //
-// When most rows are routed there is no need for a protocol: a workgroup takes a TILE of rows (16 waves x U row groups x 64
-// = 8192 rows at U = 8), counting-sorts it by partition in LDS and copies it out in sorted order -- adjacent lanes write
-// adjacent rows of the same region, runs of tile / n_parts rows (32 rows = 384 bytes at 256 partitions).  Per routed row:
-// ONE LDS atomic (its rank inside the tile's partition), one LDS write and one LDS read of the row, two small table reads;
-// two workgroup barriers per tile, none of which waits for global memory (s_waitcnt lgkmcnt(0) + s_barrier: HIP's
-// __syncthreads() would also wait for the NEXT tile's column loads, which are in flight across the whole tile):
+// When most rows are routed there is no need for a protocol.  A workgroup takes a TILE of rows (16 waves x U row groups x 64
+// = 8192 rows at U = 8) and works in two phases separated by workgroup barriers that do not wait for global memory
+// (s_waitcnt lgkmcnt(0) + s_barrier: HIP's __syncthreads() would also wait for the NEXT tile's column loads, which are in
+// flight across the whole tile):
 //
-//   P1(t)   evaluate the rows of tile t (predicate, key -> hash image -> partition, operand); rank = hist[t & 1][part]++
-//   -- B1 -- (every rank of tile t is taken; the sorted buffer of tile t - 1 has been copied out)
-//   P2(t)   every wave, redundantly (identical values, so no barrier between this and its own later reads): exclusive scan
-//           of the tile's histogram -> off[]; delta[] = fill - off (region row = sorted position + delta);
-//           fill[(t + 1) & 1] = fill[t & 1] + count; wave 0 clears hist[(t + 1) & 1]
-//   P3(t)   sorted[off[part] + rank] = row
-//   -- B2 -- (tile t is sorted)
-//   hand-over: the columns of tile t + 1 (loaded one tile ago) become current, the loads of tile t + 2 are issued
-//   P4(t)   lane-contiguous copy-out: sorted position s -> region row s + delta[part of the row]; 12-byte rows {hash image,
-//           operand} (PTF_NARROW) or 16-byte rows {key, operand}
-//   P1(t+1) ...   (the loop is rotated: hand-over | P4(t - 1) | P1(t) | B1 | P2 | P3 | B2 -- one copy of P1, see below)
+//   scatter(t)   every row: predicate, key -> hash image -> partition p, operand; rank = hist[p]++ (ONE returning LDS atomic);
+//                the row's place in its region is fill[p] + rank, known at once.  rank < CAP: the row is parked in partition
+//                p's LDS bucket, slot rank (CAP ~ 1.5 x the expected rows per partition and tile: 48 at 8192 / 256);
+//                rank >= CAP (one row in ~5000 on uniform keys): stored straight to the region from registers.
+//   -- B1 --
+//   hand-over    the columns of tile t + 1 (loaded one tile ago) become current, the loads of tile t + 2 are issued -- BEFORE
+//                this tile's stores: the wait then covers loads only (vmcnt counts loads and stores, in order)
+//   copy-out(t)  wave w owns partitions w, w + 16, ...: lane r < min(hist[p], CAP) reads bucket slot r and writes region row
+//                fill[p] + r -- adjacent lanes, adjacent rows: one run of ~32 rows = 384 bytes per partition and tile, the
+//                partition wave-uniform (a scalar base, no per-row partition arithmetic); then fill[p] += hist[p], hist[p] = 0
+//   -- B2 --
+// Per routed row: one LDS atomic, one LDS write and one LDS read of the row; no scan, no permutation, nothing carried in
+// registers across a barrier.  (The first version of this file counting-SORTED the tile -- histogram, barrier, a 256-entry
+// scan by every wave, scatter to the compact position, barrier, copy-out with a per-row partition look-up: correct, and at
+// 452 us per 2^26-row launch slower than the ring kernel's 414: ~470 SIMD cycles of vector ALU per row group, of which the
+// scan and the per-row bookkeeping were half; profiles/r05_call1_kprobe.txt.)
 // Same regions, counts and padding as the ring flavours (a region is padded to a whole 16-row chunk at the end of the launch),
 // so pass 2 -- and a later launch of another flavour that resumes the window -- cannot tell.  Rows the routed form cannot
 // carry (narrow mode: a key >= 2^32 or a reserved image; the claim sentinel; region overflow) take the spill list as everywhere.
-// One key word, one routed value; no hot-key pairs (skewed streams keep the ring kernel with PTF_HOT).
+// One key word, one routed value; no hot-key pairs (skewed streams keep the ring kernel with PTF_HOT; here a hot key's rows
+// beyond CAP per tile are single stores, correct but slow).
 #pragma once
 #include "dfx_k_partition_inl.hpp"
 
 namespace dfx {
 
 constexpr int kTileBlock = 1024;
-constexpr uint32_t kTileMaxParts = 1024;
 
 // LDS barrier that does not wait for global memory (see above)
 DEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-inline size_t partition_tile_bytes(uint32_t n_parts, int u, bool wide) {
-  const size_t rows = (size_t)(kTileBlock / 64) * (size_t)u * 64;
-  return rows * (wide ? 18 : 12) + (size_t)n_parts * 4 * 6 + 64;
-}
 
 template <typename POL, int WIDE>
 __global__ __launch_bounds__(kTileBlock) void k_partition_tile(const DevProgram P, const DevFastPlan F, const DevColumns C,
@@ -52,27 +50,21 @@ __global__ __launch_bounds__(kTileBlock) void k_partition_tile(const DevProgram 
   typedef typename POL::COLV COLV;
   constexpr int U = POL::U;
   constexpr int NWAVES = kTileBlock / 64;
-  constexpr uint32_t TILE = (uint32_t)NWAVES * U * 64;
   extern __shared__ __attribute__((aligned(16))) uint64_t lds[];
-  // sorted buffer (structure of arrays: every plane is written at random positions, read lane-contiguously)
-  uint64_t* const s_val = lds;                                                  // [TILE]
-  uint64_t* const s_key = lds + TILE;                                           // [TILE]   (WIDE)
-  uint32_t* const s_tag = (uint32_t*)(lds + TILE);                              // [TILE]   (narrow: the hash image)
-  uint16_t* const s_part = (uint16_t*)(lds + 2 * (size_t)TILE);                 // [TILE]   (WIDE: the partition, not derivable without re-hashing)
-  uint32_t* const tab = WIDE ? (uint32_t*)(lds + 2 * (size_t)TILE + TILE / 4) : s_tag + TILE;
   const uint32_t NP = PT.n_parts;
-  uint32_t* const hist = tab;            // [2][NP]
-  uint32_t* const fill = tab + 2 * NP;   // [2][NP]
-  uint32_t* const off = tab + 4 * NP;    // [NP]
-  uint32_t* const delta = tab + 5 * NP;  // [NP]
+  const uint32_t CAP = PT.stage_rows;  // bucket slots per partition
+  // buckets, structure of arrays: slot (p, r) at p * CAP + r
+  uint64_t* const b_val = lds;                                                   // [NP * CAP]
+  uint64_t* const b_key = lds + (size_t)NP * CAP;                                // [NP * CAP]  (WIDE)
+  uint32_t* const b_tag = (uint32_t*)(lds + (size_t)NP * CAP);                   // [NP * CAP]  (narrow: the hash image)
+  uint32_t* const hist = WIDE ? (uint32_t*)(lds + 2 * (size_t)NP * CAP) : b_tag + (size_t)NP * CAP;  // [NP] rows of the tile per partition
+  uint32_t* const fill = hist + NP;                                              // [NP] rows already in this producer's regions
   const int lane = lane_id();
   const int wave = (int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const uint32_t producer = blockIdx.x;
   for (uint32_t p = threadIdx.x; p < NP; p += kTileBlock) {
     hist[p] = 0;
-    hist[NP + p] = 0;
     fill[p] = (PT.flags & PTF_RESUME) ? PT.counts[(uint64_t)p * PT.n_producers + producer] : 0u;
-    fill[NP + p] = 0;
   }
   __syncthreads();
   // this producer's regions: region p starts at prod_base + p * part_bytes, row r at + r * kRowBytes (layouts 0 and 1: regions are contiguous)
@@ -87,169 +79,186 @@ __global__ __launch_bounds__(kTileBlock) void k_partition_tile(const DevProgram 
   uint64_t passed = 0;  // wave-uniform
   typename POL::PREP prep;
   POL::prepare(F, prep);
-  // the current tile's rows between P1 and P3
-  uint32_t r_img[U], r_rank[U];  // rank: 0xFFFFFFFF = no routed row in this lane
-  uint64_t r_val[U], r_key[WIDE ? U : 1];
   COLV col[U], ncol[U];
   uint32_t cv[U], ncv[U];
-  auto part_of_img = [&](uint32_t img) -> uint32_t { return ((img >> tag_shift) & (uint32_t)T.mask) >> PT.part_shift; };
-  // P4 of the tile sorted last (total_rows of them lie in the sorted buffer): lane-contiguous copy-out
-  auto copy_out = [&](uint32_t total_rows) {
-    FOR_U {
-      const uint32_t s = (uint32_t)u * kTileBlock + threadIdx.x;
-      const bool have = s < total_rows;
-      const uint32_t sc = have ? s : 0u;
-      const uint64_t val = s_val[sc];
-      uint32_t part, tag = 0;
-      uint64_t kk = 0;
-      if (WIDE) {
-        kk = s_key[sc];
-        part = s_part[sc];
-      } else {
-        tag = s_tag[sc];
-        part = part_of_img(tag);
-      }
-      if (!have) part = 0;  // (a stale row of an earlier tile: any table index will do)
-      const uint32_t row = s + delta[part];
-      const bool fits = row < PT.cap_rows;
-      if (have && fits) {
-        uint8_t* const dst = prod_base + (uint64_t)part * part_bytes + (uint64_t)row * kRowBytes;
-        if (WIDE) {
-          *(ulonglong2*)dst = make_ulonglong2(kk, val);
-        } else {
-          uint32_t* const o32 = (uint32_t*)dst;
-          o32[0] = tag;
-          o32[1] = (uint32_t)val;
-          o32[2] = (uint32_t)(val >> 32);
-        }
-      }
-      if (__ballot(have && !fits) != 0) {  // region overflow (skewed keys): the general path takes the row -- as a key again
-        uint64_t key[1] = {WIDE ? kk : (uint64_t)unhash_word32(tag)};
-        uint64_t sv[kMaxAggs];
-#pragma unroll
-        for (int a = 0; a < kMaxAggs; ++a) sv[a] = a == 0 ? val : 0ull;
-        spill_row<1>(T, spill, have && !fits, key, sv);
-      }
+  auto store_row = [&](uint32_t part, uint32_t row, uint32_t tag, uint64_t kk, uint64_t val) {
+    uint8_t* const dst = prod_base + (uint64_t)part * part_bytes + (uint64_t)row * kRowBytes;
+    if (WIDE) {
+      *(ulonglong2*)dst = make_ulonglong2(kk, val);
+    } else {
+      uint32_t* const o32 = (uint32_t*)dst;
+      o32[0] = tag;
+      o32[1] = (uint32_t)val;
+      o32[2] = (uint32_t)(val >> 32);
     }
   };
-  // The loop is rotated so that it holds ONE copy of P1 and the column hand-over sits BEFORE the previous tile's stores:
-  //   hand-over(t): tile t's columns (issued a whole tile ago) become current, tile t + 1's loads are issued
-  //   P4(t - 1) | P1(t) | B1 | P2(t) | P3(t) | B2
-  // The wait of the next hand-over then covers loads issued a whole tile earlier and stores issued before P1 -- vmcnt counts
-  // both, in order, and the compiler waits for everything after conditional code with memory operations (the rare spill paths).
+  auto spill_one = [&](bool todo, uint32_t tag, uint64_t kk, uint64_t val) {  // (wave-convergent)
+    uint64_t key[1] = {WIDE ? kk : (uint64_t)unhash_word32(tag)};
+    uint64_t sv[kMaxAggs];
+#pragma unroll
+    for (int a = 0; a < kMaxAggs; ++a) sv[a] = a == 0 ? val : 0ull;
+    spill_row<1>(T, spill, todo, key, sv);
+  };
   int64_t tile = blockIdx.x;
   {
     const int64_t w0 = tile * tile_groups + (int64_t)wave * U;
-    load_trip<POL>(P, C, w0, tile < n_tiles && w0 < n_groups, n, lane, ncol, ncv);
+    load_trip<POL>(P, C, w0, tile < n_tiles && w0 < n_groups, n, lane, col, cv);
+    const int64_t next = tile + gridDim.x;
+    const int64_t w1 = next * tile_groups + (int64_t)wave * U;
+    load_trip<POL>(P, C, w1, next < n_tiles && w1 < n_groups, n, lane, ncol, ncv);
   }
-  int cur = 0;
-  uint32_t total = 0;  // rows of the previous tile still to be copied out
   for (; tile < n_tiles; tile += gridDim.x) {
-    FOR_U {
-      col[u] = ncol[u];
-      cv[u] = ncv[u];
-    }
+    // scatter(t).  Straight-line over the U row groups of the wave -- hashes, then the U rank atomics back to back, then the U
+    // bucket writes -- so that the groups' LDS round trips overlap; the rare rows (no routed form, bucket full) are collected
+    // in lane bit masks and handled behind ONE wave-uniform test each, outside the common path.
     {
-      const int64_t next = tile + gridDim.x;
-      const int64_t w1 = next * tile_groups + (int64_t)wave * U;
-      load_trip<POL>(P, C, w1, next < n_tiles && w1 < n_groups, n, lane, ncol, ncv);
-    }
-    copy_out(total);  // P4(t - 1)
-    uint32_t* const h = hist + (size_t)cur * NP;
-    uint32_t* const f_cur = fill + (size_t)cur * NP;
-    uint32_t* const f_nxt = fill + (size_t)(cur ^ 1) * NP;
-    {  // P1(t)
       const int64_t w0 = tile * tile_groups + (int64_t)wave * U;
+      const bool full = (w0 + U) * 64 <= n;  // (wave-uniform: no lane of this wave's trip lies past the end)
+      uint32_t s_img[U], s_part[U], s_rank[U];
+      uint64_t s_val[U], s_keyw[WIDE ? U : 1];
+      uint32_t passbits = 0, slowbits = 0;
       FOR_U {
         const int64_t row = (w0 + u) * 64 + lane;
-        const bool inb = row < n;
+        const bool inb = full || row < n;
         u64x16 reg;
         uint32_t rv = 0;
         POL::eval(P, F, col[u], cv[u], reg, rv, inb, err, prep);
-        bool pass = inb && POL::pass(P, F, plan.pred, col[u], cv[u], reg, rv, prep);
+        const bool pass = inb && POL::pass(P, F, plan.pred, col[u], cv[u], reg, rv, prep);
         uint64_t key[1];
         key[0] = POL::key(P, F, plan.key[0], 0, col[u], cv[u], reg, rv);
         uint64_t v;
         bool valid;
         POL::arg(P, F, plan.arg[0], 0, col[u], cv[u], reg, rv, v, valid);
-        const uint64_t val0 = transform_value(POL::xform(T, 0), v, valid);
-        passed += (uint64_t)__popcll(__ballot(pass));
-        const uint64_t hk = hash_keys<1>(key);
-        const uint32_t img = (uint32_t)(hk >> 32);
-        // rows the routed form cannot carry go to the spill list and nowhere else (the replay -- launch_merge_rows -> table_apply --
-        // knows the sentinel key's slot): narrow rows without a 32-bit image (the host then leaves narrow mode), the claim sentinel
+        s_val[u] = transform_value(POL::xform(T, 0), v, valid);
+        const uint32_t img = (uint32_t)(hash_keys<1>(key) >> 32);
+        s_img[u] = img;
+        if (WIDE) s_keyw[u] = key[0];
+        s_part[u] = ((img >> tag_shift) & (uint32_t)T.mask) >> PT.part_shift;
+        // rows the routed form cannot carry: narrow rows without a 32-bit image (the host then leaves narrow mode), the claim sentinel
         const bool slow = pass && (WIDE ? key[0] == kEmptyKey : ((key[0] >> 32) != 0 || img >= kTagForeign));
-        if (__ballot(slow) != 0) {
-          if (!WIDE && __hip_atomic_load(&T.ctrl[CTRL_WIDE_KEYS], RLX_AGENT) == 0u) __hip_atomic_store(&T.ctrl[CTRL_WIDE_KEYS], 1u, RLX_AGENT);
-          uint64_t sv[kMaxAggs];
+        passbits |= (pass && !slow ? 1u : 0u) << u;
+        slowbits |= (slow ? 1u : 0u) << u;
+      }
+      if (__ballot(slowbits != 0) != 0) {
+        // they go to the spill list and nowhere else (the replay -- launch_merge_rows -> table_apply -- knows the sentinel key's slot).
+        // Narrow rows: the key is re-read from the column (the image does not stand for it)
+        if (!WIDE && __hip_atomic_load(&T.ctrl[CTRL_WIDE_KEYS], RLX_AGENT) == 0u) __hip_atomic_store(&T.ctrl[CTRL_WIDE_KEYS], 1u, RLX_AGENT);
+        FOR_U {
+          const bool slow = (slowbits >> u) & 1u;
+          if (__ballot(slow) != 0) {
+            u64x16 reg;
+            uint32_t rv = 0;
+            uint32_t e2 = 0;
+            POL::eval(P, F, col[u], cv[u], reg, rv, true, e2, prep);
+            uint64_t key[1];
+            key[0] = POL::key(P, F, plan.key[0], 0, col[u], cv[u], reg, rv);
+            uint64_t sv[kMaxAggs];
 #pragma unroll
-          for (int a = 0; a < kMaxAggs; ++a) sv[a] = a == 0 ? val0 : 0ull;
-          spill_row<1>(T, spill, slow, key, sv);
-          pass = pass && !slow;
+            for (int a = 0; a < kMaxAggs; ++a) sv[a] = a == 0 ? s_val[u] : 0ull;
+            spill_row<1>(T, spill, slow, key, sv);
+          }
         }
-        r_img[u] = img;
-        r_val[u] = val0;
-        if (WIDE) r_key[u] = key[0];
-        r_rank[u] = pass ? atomicAdd(&h[part_of_img(img)], 1u) : 0xFFFFFFFFu;
+      }
+      FOR_U passed += (uint64_t)__popcll(__ballot(((passbits | slowbits) >> u) & 1u));
+      FOR_U {
+        s_rank[u] = 0xFFFFFFFFu;
+        if ((passbits >> u) & 1u) s_rank[u] = atomicAdd(&hist[s_part[u]], 1u);
+      }
+      uint32_t directbits = 0;
+      FOR_U {
+        const bool pass = (passbits >> u) & 1u;
+        const bool staged = pass && s_rank[u] < CAP;
+        if (staged) {
+          const uint32_t at = s_part[u] * CAP + s_rank[u];
+          b_val[at] = s_val[u];
+          if (WIDE) b_key[at] = s_keyw[u];
+          else b_tag[at] = s_img[u];
+        }
+        directbits |= (pass && !staged ? 1u : 0u) << u;
+      }
+      if (__ballot(directbits != 0) != 0) {  // a full bucket: the row's place is known all the same (fill[] is stable until B1)
+        FOR_U {
+          const bool direct = (directbits >> u) & 1u;
+          if (__ballot(direct) != 0) {
+            uint32_t rrow = 0;
+            if (direct) rrow = fill[s_part[u]] + s_rank[u];
+            const bool fits = direct && rrow < PT.cap_rows;
+            if (fits) store_row(s_part[u], rrow, s_img[u], WIDE ? s_keyw[u] : 0ull, s_val[u]);
+            if (__ballot(direct && !fits) != 0) spill_one(direct && !fits, s_img[u], WIDE ? s_keyw[u] : 0ull, s_val[u]);
+          }
+        }
       }
     }
-    lds_barrier();  // B1
-    // P2: per-wave redundant scan of the histogram (lane l owns partitions [l * PPL, (l + 1) * PPL))
+    lds_barrier();  // B1: every row of tile t is in its bucket (or in its region)
+    // hand-over: tile t + 1's columns become current, tile t + 2's loads are issued
     {
-      const uint32_t PPL = (NP + 63u) / 64u;
-      const uint32_t p0 = (uint32_t)lane * PPL;
-      uint32_t sum = 0;
-      for (uint32_t q = 0; q < PPL; ++q)
-        if (p0 + q < NP) sum += h[p0 + q];
-      uint32_t inc = sum;
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t o = (uint32_t)__shfl_up((int)inc, d, 64);
-        if (lane >= d) inc += o;
+      const int64_t next = tile + gridDim.x;
+      FOR_U {
+        col[u] = ncol[u];
+        cv[u] = ncv[u];
       }
-      total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
-      uint32_t excl = inc - sum;
-      for (uint32_t q = 0; q < PPL; ++q) {
-        const uint32_t p = p0 + q;
-        if (p < NP) {
-          const uint32_t c = h[p];
-          const uint32_t f = f_cur[p];
-          off[p] = excl;
-          delta[p] = f - excl;
-          f_nxt[p] = f + c;
-          excl += c;
+      const int64_t w2 = (next + gridDim.x) * tile_groups + (int64_t)wave * U;
+      load_trip<POL>(P, C, w2, next + gridDim.x < n_tiles && w2 < n_groups, n, lane, ncol, ncv);
+    }
+    // copy-out(t): wave w owns partitions w, w + 16, ...  Everything about a partition is wave-uniform (scalar registers):
+    // its row count, its region's next free row, the store's base address; a lane adds its own 12 (16) bytes.
+    {
+      const uint32_t lane_bytes = (uint32_t)lane * kRowBytes;
+      for (uint32_t p = (uint32_t)wave; p < NP; p += (uint32_t)NWAVES) {
+        const uint32_t cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)hist[p]);
+        const uint32_t f = (uint32_t)__builtin_amdgcn_readfirstlane((int)fill[p]);
+        const uint32_t m = cnt < CAP ? cnt : CAP;
+        if (m != 0) {
+          uint8_t* const region = prod_base + (uint64_t)p * part_bytes;  // (scalar)
+          const uint32_t bucket0 = p * CAP;
+          if (f + m <= PT.cap_rows) {  // the common case: no row of this bucket can leave the region
+            uint8_t* const sbase = region + (uint64_t)f * kRowBytes;
+            for (uint32_t r0 = 0; r0 < m; r0 += 64u) {
+              if (r0 + (uint32_t)lane < m) {
+                const uint32_t at = bucket0 + r0 + (uint32_t)lane;
+                const uint64_t val = b_val[at];
+                uint8_t* const dst = sbase + (size_t)(r0 * kRowBytes + lane_bytes);
+                if (WIDE) {
+                  *(ulonglong2*)dst = make_ulonglong2(b_key[at], val);
+                } else {
+                  const uint32_t tag = b_tag[at];
+                  uint32_t* const o32 = (uint32_t*)dst;
+                  o32[0] = tag;
+                  o32[1] = (uint32_t)val;
+                  o32[2] = (uint32_t)(val >> 32);
+                }
+              }
+            }
+          } else {  // region overflow (skewed keys): row by row, the spill list takes what does not fit
+            for (uint32_t r0 = 0; r0 < m; r0 += 64u) {
+              const uint32_t r = r0 + (uint32_t)lane;
+              const bool have = r < m;
+              const uint32_t at = bucket0 + (have ? r : 0u);
+              const uint64_t val = b_val[at];
+              uint64_t kk = 0;
+              uint32_t tag = 0;
+              if (WIDE) kk = b_key[at];
+              else tag = b_tag[at];
+              const uint32_t rrow = f + r;
+              const bool fits = have && rrow < PT.cap_rows;
+              if (fits) store_row(p, rrow, tag, kk, val);
+              if (__ballot(have && !fits) != 0) spill_one(have && !fits, tag, kk, val);
+            }
+          }
+        }
+        if (lane == 0) {
+          fill[p] = f + cnt;
+          hist[p] = 0;
         }
       }
-      if (wave == 0) {
-        uint32_t* const hn = hist + (size_t)(cur ^ 1) * NP;
-        for (uint32_t q = 0; q < PPL; ++q)
-          if (p0 + q < NP) hn[p0 + q] = 0;
-      }
     }
-    // P3: scatter into the sorted buffer
-    FOR_U {
-      if (r_rank[u] != 0xFFFFFFFFu) {
-        const uint32_t part = part_of_img(r_img[u]);
-        const uint32_t pos = off[part] + r_rank[u];
-        s_val[pos] = r_val[u];
-        if (WIDE) {
-          s_key[pos] = r_key[u];
-          s_part[pos] = (uint16_t)part;
-        } else {
-          s_tag[pos] = r_img[u];
-        }
-      }
-    }
-    lds_barrier();  // B2
-    cur ^= 1;
+    lds_barrier();  // B2: the buckets are free, fill[] is current
   }
-  copy_out(total);  // P4 of the last tile
   __syncthreads();
   // region counts; a region is padded to a whole 16-row chunk with rows pass 2 skips (the ring flavours resume at chunk boundaries)
-  const uint32_t* const f_end = fill + (size_t)cur * NP;
   uint32_t max_fill = 0;
   for (uint32_t p = threadIdx.x; p < NP; p += kTileBlock) {
-    uint32_t f = f_end[p];
+    uint32_t f = fill[p];
     if (f > PT.cap_rows) f = PT.cap_rows;
     const uint32_t rem = f % 16u;
     if (rem != 0) {
@@ -274,14 +283,16 @@ __global__ __launch_bounds__(kTileBlock) void k_partition_tile(const DevProgram 
   snapshot_ctrl_if_last(T, PT);
 }
 
-template <typename POLT>
+// POLT: the policy of the narrow flavour (12-byte rows: eight row groups per wave and tile for the signatures), POLTW: of the wide
+// one (16-byte rows: four -- its buckets are a third larger per row)
+template <typename POLT, typename POLTW>
 void launch_partition_tile(const DevProgram& P, const DevFastPlan& fast, const DevColumns& C, const DevAggPlan& plan, const DevTable& T,
                            const DevPartition& PT, const DevRows& spill, int64_t n, hipStream_t s) {
   const int grid = (int)PT.n_producers;  // every producer writes its counts, even with no rows
   if (PT.flags & PTF_NARROW)
-    hipLaunchKernelGGL((k_partition_tile<POLT, 0>), dim3(grid), dim3(kTileBlock), partition_tile_bytes(PT.n_parts, POLT::U, false), s, P, fast, C, plan, T, PT, spill, n);
+    hipLaunchKernelGGL((k_partition_tile<POLT, 0>), dim3(grid), dim3(kTileBlock), partition_tile_bytes(PT.n_parts, PT.stage_rows, false), s, P, fast, C, plan, T, PT, spill, n);
   else
-    hipLaunchKernelGGL((k_partition_tile<POLT, 1>), dim3(grid), dim3(kTileBlock), partition_tile_bytes(PT.n_parts, POLT::U, true), s, P, fast, C, plan, T, PT, spill, n);
+    hipLaunchKernelGGL((k_partition_tile<POLTW, 1>), dim3(grid), dim3(kTileBlock), partition_tile_bytes(PT.n_parts, PT.stage_rows, true), s, P, fast, C, plan, T, PT, spill, n);
 }
 
 }  // namespace dfx

@@ -322,7 +322,7 @@ void launch_partition_ws(const DevProgram& P, const DevFastPlan& fast, const Dev
 #define DFX_PARTITION_VARIANT_WS(ID, POL, POLS, POLN, POLW, POLT)                                                          \
   void launch_partition_variant##ID(DFX_PARTITION_VARIANT_ARGS) {                                                          \
     if (PT.flags & PTF_TILE)                                                                                               \
-      launch_partition_tile<POLT>(P, fast, C, plan, T, PT, spill, n, s);                                                   \
+      launch_partition_tile<POLT, POLW>(P, fast, C, plan, T, PT, spill, n, s);                                             \
     else if (PT.flags & PTF_WS)                                                                                            \
       launch_partition_ws<POLW>(P, fast, C, plan, T, PT, spill, n, lds_bytes, s);                                          \
     else                                                                                                                   \
