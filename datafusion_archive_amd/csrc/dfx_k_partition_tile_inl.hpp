@@ -38,18 +38,18 @@
 
 namespace dfx {
 
-constexpr int kTileBlock = 1024;
+constexpr int kTileBlock = 1024;  // one workgroup per CU (tiles of 16 waves x U row groups); 512: two per CU, out of phase with each other
 
 // LDS barrier that does not wait for global memory (see above)
 DEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <typename POL, int WIDE>
-__global__ __launch_bounds__(kTileBlock) void k_partition_tile(const DevProgram P, const DevFastPlan F, const DevColumns C,
+template <typename POL, int WIDE, int BLOCK = kTileBlock>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_partition_tile(const DevProgram P, const DevFastPlan F, const DevColumns C,
                                                               const DevAggPlan plan, const DevTable T,
                                                               const DevPartition PT, const DevRows spill, const int64_t n) {
   typedef typename POL::COLV COLV;
   constexpr int U = POL::U;
-  constexpr int NWAVES = kTileBlock / 64;
+  constexpr int NWAVES = BLOCK / 64;
   extern __shared__ __attribute__((aligned(16))) uint64_t lds[];
   const uint32_t NP = PT.n_parts;
   const uint32_t CAP = PT.stage_rows;  // bucket slots per partition
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(kTileBlock) void k_partition_tile(const DevProgram 
   const int lane = lane_id();
   const int wave = (int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const uint32_t producer = blockIdx.x;
-  for (uint32_t p = threadIdx.x; p < NP; p += kTileBlock) {
+  for (uint32_t p = threadIdx.x; p < NP; p += BLOCK) {
     hist[p] = 0;
     fill[p] = (PT.flags & PTF_RESUME) ? PT.counts[(uint64_t)p * PT.n_producers + producer] : 0u;
   }
@@ -202,53 +202,89 @@ __global__ __launch_bounds__(kTileBlock) void k_partition_tile(const DevProgram 
     }
     // copy-out(t): wave w owns partitions w, w + 16, ...  Everything about a partition is wave-uniform (scalar registers):
     // its row count, its region's next free row, the store's base address; a lane adds its own 12 (16) bytes.
-    {
-      const uint32_t lane_bytes = (uint32_t)lane * kRowBytes;
-      for (uint32_t p = (uint32_t)wave; p < NP; p += (uint32_t)NWAVES) {
-        const uint32_t cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)hist[p]);
-        const uint32_t f = (uint32_t)__builtin_amdgcn_readfirstlane((int)fill[p]);
+    if (CAP <= 32u) {
+      // small buckets (two workgroups per CU, tiles of 4096 rows): a wave's visit serves TWO partitions, one per half-wave
+      const uint32_t half = (uint32_t)lane >> 5, r = (uint32_t)lane & 31u;
+      for (uint32_t p0 = (uint32_t)wave * 2u; p0 < NP; p0 += 2u * (uint32_t)NWAVES) {
+        const uint32_t p = p0 + half;
+        const bool live = p < NP;
+        const uint32_t pc = live ? p : 0u;
+        const uint32_t cnt = live ? hist[pc] : 0u;
+        const uint32_t f = fill[pc];
         const uint32_t m = cnt < CAP ? cnt : CAP;
-        if (m != 0) {
-          uint8_t* const region = prod_base + (uint64_t)p * part_bytes;  // (scalar)
-          const uint32_t bucket0 = p * CAP;
-          if (f + m <= PT.cap_rows) {  // the common case: no row of this bucket can leave the region
-            uint8_t* const sbase = region + (uint64_t)f * kRowBytes;
-            for (uint32_t r0 = 0; r0 < m; r0 += 64u) {
-              if (r0 + (uint32_t)lane < m) {
-                const uint32_t at = bucket0 + r0 + (uint32_t)lane;
-                const uint64_t val = b_val[at];
-                uint8_t* const dst = sbase + (size_t)(r0 * kRowBytes + lane_bytes);
-                if (WIDE) {
-                  *(ulonglong2*)dst = make_ulonglong2(b_key[at], val);
-                } else {
-                  const uint32_t tag = b_tag[at];
-                  uint32_t* const o32 = (uint32_t*)dst;
-                  o32[0] = tag;
-                  o32[1] = (uint32_t)val;
-                  o32[2] = (uint32_t)(val >> 32);
-                }
+        const bool have = r < m;
+        const uint32_t at = pc * CAP + (have ? r : 0u);
+        const uint64_t val = b_val[at];
+        uint64_t kk = 0;
+        uint32_t tag = 0;
+        if (WIDE) kk = b_key[at];
+        else tag = b_tag[at];
+        const uint32_t rrow = f + r;
+        const bool fits = have && rrow < PT.cap_rows;
+        if (fits) store_row(pc, rrow, tag, kk, val);
+        if (__ballot(have && !fits) != 0) spill_one(have && !fits, tag, kk, val);  // region overflow (skewed keys)
+        if (live && r == 0) {
+          fill[pc] = f + cnt;
+          hist[pc] = 0;
+        }
+      }
+    } else {
+      // ONE LDS round trip gives the wave the counts and fills of all its partitions (lane i <-> partition wave + NWAVES * i; a
+      // visit reads them back with v_readlane), and the bucket reads of four visits are in flight together: counters showed the
+      // first version -- two dependent LDS round trips per visit -- spending 43 % of its wave cycles in s_waitcnt and 35 % at
+      // the barriers behind them (profiles/r05_tile_counters.txt).
+      const uint32_t lane_bytes = (uint32_t)lane * kRowBytes;
+      const uint32_t myp = (uint32_t)wave + (uint32_t)NWAVES * (uint32_t)lane;
+      uint32_t v_cnt = 0, v_fill = 0;
+      if (myp < NP) {
+        v_cnt = hist[myp];
+        v_fill = fill[myp];
+        fill[myp] = v_fill + v_cnt;
+        hist[myp] = 0;
+      }
+      const uint32_t n_visits = (NP - (uint32_t)wave + (uint32_t)NWAVES - 1u) / (uint32_t)NWAVES;
+      constexpr int VB = 4;  // visits per batch
+      for (uint32_t i0 = 0; i0 < n_visits; i0 += VB) {
+        uint32_t cnt[VB], f[VB], m[VB], pp[VB];
+        uint64_t bv[VB], bk[VB];
+        uint32_t bt[VB];
+        bool okv[VB];
+#pragma unroll
+        for (int j = 0; j < VB; ++j) {
+          const uint32_t i = i0 + (uint32_t)j;
+          const uint32_t ic = i < n_visits ? i : 0u;
+          cnt[j] = (uint32_t)__builtin_amdgcn_readlane((int)v_cnt, (int)ic);
+          f[j] = (uint32_t)__builtin_amdgcn_readlane((int)v_fill, (int)ic);
+          if (i >= n_visits) cnt[j] = 0;
+          m[j] = cnt[j] < CAP ? cnt[j] : CAP;
+          pp[j] = (uint32_t)wave + (uint32_t)NWAVES * ic;
+          okv[j] = (uint32_t)lane < m[j];  // (CAP <= 64 on this path: one step per visit)
+          const uint32_t at = pp[j] * CAP + (okv[j] ? (uint32_t)lane : 0u);
+          bv[j] = b_val[at];
+          if (WIDE) bk[j] = b_key[at];
+          else bt[j] = b_tag[at];
+        }
+#pragma unroll
+        for (int j = 0; j < VB; ++j) {
+          uint8_t* const region = prod_base + (uint64_t)pp[j] * part_bytes;  // (scalar)
+          if (f[j] + m[j] <= PT.cap_rows) {  // the common case: no row of this bucket can leave the region
+            if (okv[j]) {
+              uint8_t* const dst = region + (uint64_t)f[j] * kRowBytes + (size_t)lane_bytes;
+              if (WIDE) {
+                *(ulonglong2*)dst = make_ulonglong2(bk[j], bv[j]);
+              } else {
+                uint32_t* const o32 = (uint32_t*)dst;
+                o32[0] = bt[j];
+                o32[1] = (uint32_t)bv[j];
+                o32[2] = (uint32_t)(bv[j] >> 32);
               }
             }
           } else {  // region overflow (skewed keys): row by row, the spill list takes what does not fit
-            for (uint32_t r0 = 0; r0 < m; r0 += 64u) {
-              const uint32_t r = r0 + (uint32_t)lane;
-              const bool have = r < m;
-              const uint32_t at = bucket0 + (have ? r : 0u);
-              const uint64_t val = b_val[at];
-              uint64_t kk = 0;
-              uint32_t tag = 0;
-              if (WIDE) kk = b_key[at];
-              else tag = b_tag[at];
-              const uint32_t rrow = f + r;
-              const bool fits = have && rrow < PT.cap_rows;
-              if (fits) store_row(p, rrow, tag, kk, val);
-              if (__ballot(have && !fits) != 0) spill_one(have && !fits, tag, kk, val);
-            }
+            const uint32_t rrow = f[j] + (uint32_t)lane;
+            const bool fits = okv[j] && rrow < PT.cap_rows;
+            if (fits) store_row(pp[j], rrow, WIDE ? 0u : bt[j], WIDE ? bk[j] : 0ull, bv[j]);
+            if (__ballot(okv[j] && !fits) != 0) spill_one(okv[j] && !fits, WIDE ? 0u : bt[j], WIDE ? bk[j] : 0ull, bv[j]);
           }
-        }
-        if (lane == 0) {
-          fill[p] = f + cnt;
-          hist[p] = 0;
         }
       }
     }
@@ -257,7 +293,7 @@ __global__ __launch_bounds__(kTileBlock) void k_partition_tile(const DevProgram 
   __syncthreads();
   // region counts; a region is padded to a whole 16-row chunk with rows pass 2 skips (the ring flavours resume at chunk boundaries)
   uint32_t max_fill = 0;
-  for (uint32_t p = threadIdx.x; p < NP; p += kTileBlock) {
+  for (uint32_t p = threadIdx.x; p < NP; p += BLOCK) {
     uint32_t f = fill[p];
     if (f > PT.cap_rows) f = PT.cap_rows;
     const uint32_t rem = f % 16u;
@@ -289,10 +325,15 @@ template <typename POLT, typename POLTW>
 void launch_partition_tile(const DevProgram& P, const DevFastPlan& fast, const DevColumns& C, const DevAggPlan& plan, const DevTable& T,
                            const DevPartition& PT, const DevRows& spill, int64_t n, hipStream_t s) {
   const int grid = (int)PT.n_producers;  // every producer writes its counts, even with no rows
-  if (PT.flags & PTF_NARROW)
-    hipLaunchKernelGGL((k_partition_tile<POLT, 0>), dim3(grid), dim3(kTileBlock), partition_tile_bytes(PT.n_parts, PT.stage_rows, false), s, P, fast, C, plan, T, PT, spill, n);
-  else
-    hipLaunchKernelGGL((k_partition_tile<POLTW, 1>), dim3(grid), dim3(kTileBlock), partition_tile_bytes(PT.n_parts, PT.stage_rows, true), s, P, fast, C, plan, T, PT, spill, n);
+  const bool narrow = (PT.flags & PTF_NARROW) != 0;
+  const size_t lds_bytes = partition_tile_bytes(PT.n_parts, PT.stage_rows, !narrow);
+  if (PT.block == 512) {  // two workgroups per CU (agg.tile_block = 512): half the tile, half the bucket, the phases of the two interleave
+    if (narrow) hipLaunchKernelGGL((k_partition_tile<POLT, 0, 512>), dim3(grid), dim3(512), lds_bytes, s, P, fast, C, plan, T, PT, spill, n);
+    else hipLaunchKernelGGL((k_partition_tile<POLTW, 1, 512>), dim3(grid), dim3(512), lds_bytes, s, P, fast, C, plan, T, PT, spill, n);
+  } else {
+    if (narrow) hipLaunchKernelGGL((k_partition_tile<POLT, 0, 1024>), dim3(grid), dim3(1024), lds_bytes, s, P, fast, C, plan, T, PT, spill, n);
+    else hipLaunchKernelGGL((k_partition_tile<POLTW, 1, 1024>), dim3(grid), dim3(1024), lds_bytes, s, P, fast, C, plan, T, PT, spill, n);
+  }
 }
 
 }  // namespace dfx

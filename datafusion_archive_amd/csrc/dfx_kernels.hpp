@@ -159,9 +159,9 @@ size_t partition_ring_bytes(uint32_t n_words, uint32_t n_parts, int ring_rows, b
 size_t partition_ws_bytes(uint32_t n_parts, int scanner_waves);  // LDS of the wave-specialised pass-1 kernel (PTF_WS)
 // tile-bucketed pass 1 (PTF_TILE, dfx_k_partition_tile_inl.hpp): bucket slots per partition (a multiple of 16, <= 4096) that 150 KB
 // of LDS hold next to the two counter arrays, and the LDS bytes of a launch
-inline uint32_t partition_tile_cap(uint32_t n_parts, bool wide) {
+inline uint32_t partition_tile_cap(uint32_t n_parts, bool wide, uint32_t block = 1024) {
   if (n_parts == 0) return 0;
-  const size_t budget = (size_t)150 * 1024 - (size_t)n_parts * 8 - 64;
+  const size_t budget = (size_t)(block == 512 ? 76 : 150) * 1024 - (size_t)n_parts * 8 - 64;  // (512 lanes: two workgroups share a CU's 160 KB)
   size_t cap = budget / ((size_t)n_parts * (wide ? 16 : 12));
   cap = cap / 16 * 16;
   return (uint32_t)(cap > 4096 ? 4096 : cap);

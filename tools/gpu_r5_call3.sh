@@ -1,0 +1,30 @@
+#!/bin/bash
+# round 5, call 3: tile-bucketed pass 1 with one / two workgroups per CU against the ring kernel: times, wait counters, HBM bytes
+R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/r5c3; mkdir -p $OUT; export TMPDIR=/tmp
+cd $R
+export DFX_NO_TORCH=1
+timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q --timeout 600 -x -k "tile_sorted" > $OUT/pytest_tile.log 2>&1; echo "tile tests rc=$?"; tail -n 5 $OUT/pytest_tile.log | cut -c1-400
+for opt in agg.pass1_tile=0 "agg.pass1_tile=1 agg.tile_block=1024" "agg.pass1_tile=1 agg.tile_block=512"; do
+  echo "== cfg3 dense $opt"; timeout 300 python tools/kprobe.py 1073741824 1e6 0 $opt 2>&1 | tail -n 3 | cut -c1-400
+done | tee $OUT/kprobe_dense.txt
+cd /tmp
+i=0
+for opt in "agg.pass1_tile=0" "agg.pass1_tile=1 agg.tile_block=1024" "agg.pass1_tile=1 agg.tile_block=512"; do
+i=$((i+1))
+rocprofv3 --output-format csv --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM -d $OUT/sq_$i -o out -- python $R/tools/prof_query.py cfg3 268435456 1 $opt > /dev/null 2>&1
+rocprofv3 --output-format csv --pmc FETCH_SIZE -d $OUT/fetch_$i -o out -- python $R/tools/prof_query.py cfg3 268435456 1 $opt > /dev/null 2>&1
+rocprofv3 --output-format csv --pmc WRITE_SIZE -d $OUT/write_$i -o out -- python $R/tools/prof_query.py cfg3 268435456 1 $opt > /dev/null 2>&1
+done
+python3 - <<'PY'
+import csv, glob, collections
+for f in sorted(glob.glob("/root/repo/gpurun_out/r5c3/*/**/*counter_collection*.csv", recursive=True)):
+    agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0][:110]
+        if "partition" not in k: continue
+        agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[(k, r["Counter_Name"])] += 1
+    print(f.split("r5c3/")[1].split("/")[0])
+    for k, v in agg.items():
+        print("  ", k, {c: round(x / cnt[(k, c)] / (67108864 / 64.0), 3) for c, x in v.items()}, "dispatches", max(cnt[(k, c)] for c in v))
+PY
+find $OUT -name "*counter_collection*.csv" -size +2000k -delete
