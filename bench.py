@@ -78,6 +78,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--rows-1e10-steps", type=int, default=3, help="timed steps of the north-star size (1e10 rows on one GPU); 0: skip")
+    ap.add_argument("--allow-host-exchange", action="store_true",
+                    help="multi-rank runs: accept the host-driven exchange (torch.distributed around dfx_aggregate_partial_*) when the library's "
+                         "RCCL communicator cannot be created.  Without it such a run exits non-zero: the line of an N-GPU run is about RCCL over xGMI")
     ap.add_argument("--prewarm-steps", type=int, default=0,
                     help="extra untimed steps before the W warmup steps.  Round 1 ran 600 of them (~3.5 s) believing the first seconds of a "
                          "process are slower; round 2 measured the opposite on most boxes -- after seconds of sustained load pass 1 runs "
@@ -169,20 +172,53 @@ def main():
         dist.all_reduce(t_ok, op=dist.ReduceOp.MIN)
         if int(t_ok.item()) == 1:
             exchange_mode = "library: dfx_aggregate_exchange (grouped ncclSend/ncclRecv on the library's stream)"
+            ranks_seen = comm.ranks()
+            if ranks_seen != world:  # (RCCL's own count of the library communicator: anything else is not the job that was asked for)
+                raise SystemExit(f"bench.py: the library communicator reports {ranks_seen} ranks, the job has {world}")
         else:
             comm = None
             exchange_mode = "host: torch.distributed all_to_all_single around dfx_aggregate_partial_* (library communicator unavailable" + \
                             (": " + comm_error if not ok else " on another rank") + ")"
+            if not args.allow_host_exchange:
+                if rank == 0:
+                    print("bench.py: " + exchange_mode + " -- refusing to report a multi-GPU line without RCCL (--allow-host-exchange overrides)", file=sys.stderr, flush=True)
+                dist.destroy_process_group()
+                raise SystemExit(3)
+
+    emit_s = [0.0, 0.0]  # [wall seconds of agg.next() after an exchange, seconds in the host-driven exchange]
 
     def finish(agg):
         """exchange (multi-GPU) + the single result batch"""
         if world > 1 and comm is not None:
             comm.exchange(agg)
         elif world > 1:
+            t_x = time.perf_counter()
             exchange_group_partials(agg, world, device, dist, torch)
+            emit_s[1] += time.perf_counter() - t_x
+        t_e = time.perf_counter()
         out = agg.next()
+        emit_s[0] += time.perf_counter() - t_e
         assert agg.next() is None
         return out
+
+    def phases_begin():
+        ex.counter_reset()
+        emit_s[0] = emit_s[1] = 0.0
+
+    def phases_end(steps):
+        """per-rank phase times of the steps since phases_begin(), reduced to min / max over the ranks (ms per step):
+        local scan + aggregation | wait for the slowest rank | dfx_aggregate_exchange proper (counts, payload, merge) | emit + download"""
+        if world <= 1:
+            return None
+        mine = [ex.counter_get("xchg_local_us") / 1e3 / steps, ex.counter_get("xchg_wait_peers_us") / 1e3 / steps,
+                ex.counter_get("xchg_exchange_us") / 1e3 / steps, emit_s[0] * 1e3 / steps, emit_s[1] * 1e3 / steps]
+        t = torch.tensor(mine, dtype=torch.float64, device=coll_device)
+        lo, hi = t.clone(), t.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        names = ["local_scan_and_aggregate", "wait_for_slowest_rank", "exchange_and_merge", "emit_and_download", "host_driven_exchange"]
+        return {n_: {"min_over_ranks": round(float(lo[i].item()), 3), "max_over_ranks": round(float(hi[i].item()), 3)} for i, n_ in enumerate(names)
+                if i < 4 or float(hi[i].item()) > 0.0}
 
     def step(filter_expr=pred, group=(Column(0),), aggs=(sum_v,)):
         return finish(build(filter_expr, list(group), list(aggs)))
@@ -225,7 +261,9 @@ def main():
         step()
     for _ in range(args.warmup):
         step()
+    phases_begin()
     dt, result = timed(step, args.steps, 0)
+    phases_headline = phases_end(args.steps)
     plan_text = "n/a"
     if world == 1:  # physical plan of the timed query after one more (untimed) run: fusion, kernel family, strategy, groups
         try:
@@ -297,9 +335,20 @@ def main():
                                    "materialised FilterRelation + the interpreter)"),
               "int32_key": (syn_k32, schema_k32, pred, [sum_v], 12, "the headline query with an Int32 key column (12 B/row: the reference's own fixtures group by Int32, aggregate.rs:1033-1127)"),
               "headline_through_scan_plan": (syn, schema, pred, [sum_v], 16, "the headline query with scan.plan = 2: the plan kernels INSTEAD of its compile-time signature (what the signature still buys)")}
+    # round 5: what the headline's numbers do NOT say by themselves -- keys that are not small integers, and other selectivities
+    syn_wide = [("k", ex.SYNTH_I64_WIDE, 0, float(GROUPS), 0.0), syn[1]]
+    pred_s50 = BinaryExpr(BinaryExpr(Column(1), Operator.Gt, l64(LO)), Operator.And, BinaryExpr(Column(1), Operator.Lt, l64(716.8)))
+    pred_s80 = BinaryExpr(BinaryExpr(Column(1), Operator.Gt, l64(LO)), Operator.And, BinaryExpr(Column(1), Operator.Lt, l64(1024.0)))
+    family["wide_int64_keys"] = (syn_wide, schema, pred, [sum_v], 16, "the headline query over 10^6 distinct keys (u + 1) * 0x9E3779B97F4A7C15 mod 2^64: every key >= 2^32, half of them negative "
+                                 "(hashed ids; the reference takes any Int64 key, aggregate.rs:807-852) -- 16-byte routed rows {key, operand}, 64-bit key compares in pass 2")
+    family["wide_int64_keys_no_filter"] = (syn_wide, schema, None, [sum_v], 16, "config 3 as written (no filter, every row routed) over the same wide keys")
+    family["headline_selectivity_50"] = (syn, schema, pred_s50, [sum_v], 16, "the headline query with WHERE v > 204.8 AND v < 716.8: half of the rows pass (the headline keeps a fifth)")
+    family["headline_selectivity_80"] = (syn, schema, pred_s80, [sum_v], 16, "the headline query with WHERE v > 204.8 AND v < 1024.0: 80 % of the rows pass")
     for name_, (cols_, sch_, filt_, aggs_, _b, _w) in family.items():
         neighbours[name_] = (cols_, sch_, filt_, aggs_)
     bg = {}
+    tail_rows = int(min(verify_rows, 100000000))
+    tail_row0 = (10000000000 - tail_rows) // 64 * 64
     if want_oracle:
         import oracle  # tests/oracle.py: the CPU restatement -- the reported baseline AND the checker of the GPU results
         for name, (cols_, _sch, filt_, aggs_) in neighbours.items():
@@ -307,6 +356,13 @@ def main():
         bg["cfg2"] = Background(oracle.run_synth_filter, syn_lat, seed2, 0, verify_rows, 1024, pred2)
         bg["cfg3"] = Background(oracle.run_synth_query, syn, seed, 0, verify_rows, 1024, None, [Column(0)], [sum_v])
         bg["cfg5"] = Background(oracle.run_synth_query, syn5, seed, 0, verify_rows, 1024, pred5, [Column(0), Column(1)], aggs5 + [count_qty])
+        # ... and the EXACT sums of its first truth_rows rows (integer arithmetic, tests/oracle.py: ExactGroupSums): what the device's own
+        # slice result is held to within (sqrt(n) + 8) ULP -- tighter than any comparison with another rounded sum
+        truth_rows = int(min(verify_rows, 1 << 25))
+        bg["cfg5_truth"] = Background(oracle.exact_sums_q1, syn5, seed, 0, truth_rows)
+        if args.rows_1e10_steps > 0 and n_rows < 10000000000:
+            # the LAST verify_rows rows of the 10^10-row table (row indices beyond 2^32: rows 9.9e9 ...): the same generator, seed and rows
+            bg["rows_1e10_tail"] = Background(oracle.run_synth_query, syn, seed, tail_row0, 10000000000 - tail_row0, 1024, pred, [Column(0)], [sum_v])
 
     # dominant kernel = the scan kernel (the one that reads the table) with the largest total time:
     # "partition" (pass 1 of the partitioned strategy: predicate + key/arg evaluation + routing) or
@@ -431,6 +487,14 @@ def main():
 
     extra["prewarm_steps"] = args.prewarm_steps
     extra["cold_first_step_ms"] = cold_first_step_ms
+    if roofline is not None:
+        # `frac` is the DOMINANT KERNEL's (SURVEY.md section 8(d) asks for that); the query's own number is end_to_end_frac, and the first
+        # query of a shape on a table pays the calibration slice on top (cold_first_step_ms, this process's very first step)
+        roofline["frac_is"] = "the dominant kernel alone (pass 1); the whole step: end_to_end_frac"
+        roofline["cold_first_step_ms"] = round(cold_first_step_ms, 3)
+        roofline["ms_per_step"] = round(ms_per_step, 4)
+    if phases_headline is not None:
+        extra["phases_ms"] = phases_headline
     if want_extras:
         k3 = max(2, args.steps // 2)
         # BASELINE config 3 as written: SELECT k, SUM(v) GROUP BY k -- no filter, every row is routed
@@ -662,6 +726,26 @@ def main():
         except Exception as e:  # a measurement, not a gate
             extra["host_streamed_pcie_inclusive"] = {"error": str(e)[:200]}
 
+    # ---- config 4 AS WRITTEN on N GPUs: config 3's query -- no filter, every row routed -- over the ranks' row ranges -----
+    # (the headline above keeps its 20 %-selective predicate at every N, so that the N = 1, 2, 4, 8 values are one curve; the
+    # unfiltered query is 2.3 x slower per row on one GPU, and BASELINE.json's config 4 names it)
+    if world > 1 and not args.no_extras:
+        k4 = max(2, args.steps // 2)
+        step(None)
+        phases_begin()
+        d4, r4 = timed(lambda: step(None), k4, 0)
+        e4 = rate(total_rows * k4, d4, 16, f"BASELINE config 4 as written: SELECT k, SUM(v) GROUP BY k (no filter) over {total_rows} rows on {world} GPUs, "
+                  "group partials exchanged inside the library")
+        e4["roofline"]["achieved"] = round(e4["roofline"]["achieved"] / world, 1)  # per GPU against the per-GPU peak
+        e4["roofline"]["frac"] = round(e4["roofline"]["achieved"] / HBM_PEAK_GBPS, 4)
+        e4["roofline"]["per"] = "GPU"
+        e4["phases_ms"] = phases_end(k4)
+        g4 = torch.tensor([float(r4.num_rows)], dtype=torch.float64, device=coll_device)
+        dist.all_reduce(g4)
+        e4["groups_over_all_ranks"] = int(g4.item())
+        e4["every_group_emitted_once"] = bool(int(g4.item()) == GROUPS)
+        extra["cfg4_as_written"] = e4
+
     # ---- config 5 (TPC-H Q1 shape): one GPU as an extra, N GPUs over the ranks' row ranges -----------------
     if (want_extras or world > 1) and not args.no_extras:
         k3 = max(2, args.steps // 2)
@@ -673,7 +757,10 @@ def main():
 
         def q1():
             return finish(build_on(t5, schema5, pred5, [Column(0), Column(1)], aggs5))
-        d5, r5 = timed(q1, k3, 1)
+        q1()
+        phases_begin()
+        d5, r5 = timed(q1, k3, 0)
+        phases5 = phases_end(k3)
         extra["cfg5_q1_shape"] = rate(n5 * world * k3, d5, 56, "TPC-H Q1 shape: 7 columns, 2 predicates, 2 keys, 4 SUMs of expressions, 6 groups" +
                                       (f"; {n5} rows per rank x {world} ranks, group partials exchanged" if world > 1 else ""))
         if world > 1:  # per GPU against the per-GPU peak
@@ -681,6 +768,7 @@ def main():
             g["achieved"] = round(g["achieved"] / world, 1)
             g["frac"] = round(g["achieved"] / HBM_PEAK_GBPS, 4)
             g["per"] = "GPU"
+            extra["cfg5_q1_shape"]["phases_ms"] = phases5
         extra["cfg5_q1_shape_rows_per_s"] = n5 * world * k3 / d5
         extra["cfg5_q1_shape_GBps_at_56B_per_row"] = n5 * world * k3 * 56 / d5 * 1e-9
         g5 = r5.num_rows
@@ -698,15 +786,31 @@ def main():
             ok = len(g[0]) == len(w[0]) and np.array_equal(g[0], w[0]) and int(w[5].sum()) == kept
             worst, worst_sqrt = 0.0, 0.0
             for i in range(1, 5):  # uniform doubles: a parallel sum cannot reproduce the sequential rounding; every term is positive
-                try:  # n * eps * sum|v| (proven) AND 64 sqrt(n) ULP of the reference's sum (empirical): tests/oracle.py, BASELINE.md section 3
+                try:  # n * eps * sum|v| (proven) AND 8 sqrt(n) ULP of the reference's sum (working bound): tests/oracle.py, BASELINE.md section 3
                     st_ = oracle.check_float_sums(g[i], w[i], w[5], w[i], what=f"cfg5 SUM #{i}")
                     worst, worst_sqrt = max(worst, st_["max_ulp_vs_reference"]), max(worst_sqrt, st_["max_over_sqrt_n"])
                 except AssertionError as e:
                     return {"rows": verify_rows, "ok": False, "error": str(e)[:300]}
+            # the truth column: the same query over the first truth_rows rows against the EXACT sums of those rows
+            worst_exact, ref_exact = 0.0, 0.0
+            try:
+                truth, tcount = bg["cfg5_truth"].get()
+                t_t = ex.DeviceTable.synth(syn5, seed, 0, truth_rows)
+                got_t = build_on(t_t, schema5, pred5, [Column(0), Column(1)], aggs5).next()
+                gt = by_key(got_t, 2)
+                gid = (got_t.column(0).to_numpy() * 2 + got_t.column(1).to_numpy())[np.argsort(got_t.column(0).to_numpy() * 1000003 + got_t.column(1).to_numpy(), kind="stable")]
+                n_t = tcount[gid].astype(np.float64)
+                for i in range(1, 5):
+                    tv = truth[i - 1][gid]
+                    st_ = oracle.check_float_sums(gt[i], tv, n_t, tv, truth=tv, what=f"cfg5 SUM #{i} vs the exact sums of the first {truth_rows} rows")
+                    worst_exact = max(worst_exact, st_["max_ulp_vs_exact"])
+            except AssertionError as e:
+                return {"rows": verify_rows, "ok": False, "error": str(e)[:300]}
             return {"rows": verify_rows, "groups": int(len(w[0])), "rows_passing": int(kept), "ok": bool(ok), "max_ulp_of_reference_sum": worst,
-                    "max_ulp_over_sqrt_rows_of_the_group": worst_sqrt,
-                    "what": "keys exact; the four SUMs per group within n * eps * sum|v| AND within 64 sqrt(n) ULP of the CPU oracle's sequential sums "
-                            "(n = rows of the group, eps = 2^-52; the exact-sum comparison runs in tests/test_gpu_scale.py)"}
+                    "max_ulp_over_sqrt_rows_of_the_group": worst_sqrt, "truth_rows": truth_rows, "max_ulp_of_exact_sum": worst_exact,
+                    "what": "keys exact; the four SUMs per group within n * eps * sum|v| AND within 8 sqrt(n) ULP of the CPU oracle's sequential sums "
+                            "(n = rows of the group, eps = 2^-52); and, over the first truth_rows rows, within (sqrt(n) + 8) ULP of the EXACT sums "
+                            "(integer arithmetic, tests/oracle.py: exact_sums_q1)"}
         if world == 1:
             extra["cfg5_q1_shape"]["verified_vs_oracle"] = checked("cfg5", verify_cfg5)
         del t5
@@ -750,7 +854,20 @@ def main():
                     "pass1_roofline_frac": round(pb["partition"]["algo_bytes"] / pb["partition"]["total_ms"] * 1e-6 / HBM_PEAK_GBPS, 4) if "partition" in pb else None}
             except Exception as be:
                 e["budget_of_one_instrumented_step_ms"] = {"error": str(be)[:200]}
-            e["verified_vs_oracle"] = "see extra.verified_vs_oracle: the first rows of this table ARE the headline table's (same generator, seed, row 0), same batch width and strategy"
+            e["verified_vs_oracle_first_rows"] = "see extra.verified_vs_oracle: the first rows of this table ARE the headline table's (same generator, seed, row 0), same batch width and strategy"
+
+            def verify_tail():
+                # the query over a row-range scan of THIS table (dfx_table_scan_range_new: zero-copy slices that start 158 GB into the columns)
+                rel = tb.scan(args.batch_rows, tail_row0, big_rows - tail_row0)
+                rel = ex.FilterRelation(rel, ex.compile_scalar_expr(None, pred, schema), schema)
+                got = ex.AggregateRelation(None, rel, [ex.compile_scalar_expr(None, Column(0), schema)], [ex.compile_expr(None, sum_v, schema)]).next()
+                _secs, kept, want = bg["rows_1e10_tail"].get()
+                g, w = by_key(got), by_key(want)
+                ok = len(g[0]) == len(w[0]) and np.array_equal(g[0], w[0]) and np.array_equal(g[1].view(np.uint64), w[1].view(np.uint64))
+                return {"rows": int(big_rows - tail_row0), "first_row": int(tail_row0), "groups": int(len(w[0])), "rows_passing": int(kept), "ok": bool(ok),
+                        "what": "the headline query over the LAST rows of the 10^10-row table (row indices > 2^32), scanned in place, every group's SUM bit-exact "
+                                "vs the CPU oracle over the same row range of the same generator"}
+            e["verified_vs_oracle"] = checked("rows_1e10_tail", verify_tail)
             extra["rows_1e10"] = e
             del tb
             ex.set_option("pool.trim", 1)

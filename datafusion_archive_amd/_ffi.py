@@ -70,7 +70,7 @@ EXPORTED_SYMBOLS = [
     "dfx_filter_relation_new", "dfx_project_relation_new", "dfx_aggregate_relation_new",
     "dfx_filter_relation_new_with_options", "dfx_aggregate_relation_new_with_options",
     "dfx_table_from_stream", "dfx_table_synth", "dfx_table_num_rows", "dfx_table_num_columns",
-    "dfx_table_column_device_ptr", "dfx_table_scan_new", "dfx_table_free", "dfx_csv_datasource_new",
+    "dfx_table_column_device_ptr", "dfx_table_scan_new", "dfx_table_scan_range_new", "dfx_table_free", "dfx_csv_datasource_new",
     "dfx_sort_relation_new", "dfx_limit_relation_new",
     "dfx_aggregate_partial_build", "dfx_aggregate_partial_export", "dfx_aggregate_partial_import",
     "dfx_comm_unique_id", "dfx_comm_init", "dfx_comm_destroy", "dfx_comm_ranks", "dfx_aggregate_exchange",
@@ -146,6 +146,7 @@ def lib() -> ctypes.CDLL:
     L.dfx_table_column_device_ptr.argtypes = [ctypes.c_void_p, ctypes.c_int32]
     L.dfx_table_column_device_ptr.restype = ctypes.c_void_p
     L.dfx_table_scan_new.argtypes = [ctypes.c_void_p, ctypes.c_int64, P(ArrowArrayStream)] + c_err
+    L.dfx_table_scan_range_new.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, P(ArrowArrayStream)] + c_err
     L.dfx_table_free.argtypes = [ctypes.c_void_p]
     L.dfx_table_free.restype = None
     L.dfx_sort_relation_new.argtypes = [P(ArrowArrayStream), P(ctypes.c_void_p), P(ctypes.c_int32), ctypes.c_int32,

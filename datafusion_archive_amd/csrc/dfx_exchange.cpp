@@ -311,12 +311,24 @@ Status AggregateRelation::exchange(dfx_comm* c, int64_t* stats) {
   hipStream_t s = ctx().stream;
   int64_t host_syncs = 0;
   if (stats) stats[0] = stats[1] = stats[2] = stats[3] = 0;
+  // phase clocks of this rank (counters xchg_*): the local scan until the stream is idle, the first agreement (the wait for the
+  // slowest rank), everything after
+  ++counters().xchg_calls;
+  const long long t_begin = ScopedUs::now();
   if (is_ungrouped()) {  // one row per rank: all-gather the accumulator states, fold them with the aggregates' algebra
     Status local = ungrouped_state_begin();  // (drains the input: DivideByZero, out of memory ...)
+    if (local.ok()) local = hip_local(hipStreamSynchronize(s));
+    const long long t_local = ScopedUs::now();
+    counters().xchg_local_us += t_local - t_begin;
     if (local.ok()) local = injected(c, "drain");
     const int nw = ungrouped_state_words();
     const int n_chunks = exchange_chunks();
-    DFX_RETURN_IF_ERROR(agree(c, local, 0x100ull | ((uint64_t)n_chunks << 16) | ((uint64_t)nw << 24), "before the exchange", &host_syncs, s));
+    {
+      Status ag = agree(c, local, 0x100ull | ((uint64_t)n_chunks << 16) | ((uint64_t)nw << 24), "before the exchange", &host_syncs, s);
+      counters().xchg_wait_peers_us += ScopedUs::now() - t_local;
+      DFX_RETURN_IF_ERROR(ag);
+    }
+    ScopedUs t_rest(&counters().xchg_exchange_us);
     if (nw > 2 * kMaxAggs) return Status::Err(DFX_INTERNAL_ERROR, "exchange: ungrouped state wider than the communicator's slab");
     uint64_t* all = c->words + slab_state_all(world);
     for (int ch = 0; ch < n_chunks; ++ch) {  // more than kMaxAggs accumulators: one state block per chunk
@@ -353,6 +365,9 @@ Status AggregateRelation::exchange(dfx_comm* c, int64_t* stats) {
   // ---- grouped ----
   uint64_t* d_counts = c->words + slab_flags(world);  // [0, world): send counts, [world, 2 world): received ones
   Status local = exchange_drain();
+  if (local.ok()) local = hip_local(hipStreamSynchronize(s));
+  const long long t_local = ScopedUs::now();
+  counters().xchg_local_us += t_local - t_begin;
   if (local.ok()) local = injected(c, "drain");
   const int n_chunks = exchange_chunks();
   int widest = 0;
@@ -361,7 +376,12 @@ Status AggregateRelation::exchange(dfx_comm* c, int64_t* stats) {
     widest = std::max(widest, exchange_chunk_words(ch));
     shape = shape * 31 + (uint64_t)exchange_chunk_words(ch);
   }
-  DFX_RETURN_IF_ERROR(agree(c, local, shape & 0xFFFFFFFFFFFFull, "before the exchange", &host_syncs, s));
+  {
+    Status ag = agree(c, local, shape & 0xFFFFFFFFFFFFull, "before the exchange", &host_syncs, s);
+    counters().xchg_wait_peers_us += ScopedUs::now() - t_local;
+    DFX_RETURN_IF_ERROR(ag);
+  }
+  ScopedUs t_rest(&counters().xchg_exchange_us);
   if (exchange_dicts() > 0) DFX_RETURN_IF_ERROR(globalise_dictionaries(this, c, &host_syncs));
   // counts: a rank whose count kernel cannot run sends the failure mark instead
   local = exchange_count(world, d_counts);

@@ -126,6 +126,11 @@ struct Counters {
   long long export_alloc_us = 0;    // ... of which: result buffer allocation (pinned pool)
   long long agg_pass2_launches = 0;
   long long agg_growths = 0;
+  // dfx_aggregate_exchange, per rank (bench.py --gpus N: extra.phases_ms): where a multi-GPU step's wall time goes
+  long long xchg_calls = 0;
+  long long xchg_local_us = 0;       // the rank's own scan + local aggregation (drain), until its stream is idle
+  long long xchg_wait_peers_us = 0;  // the first agreement round: mostly waiting for the slowest rank's local phase
+  long long xchg_exchange_us = 0;    // counts, buffers, payload rounds, merge kernels, the closing agreement
   long long agg_tile_launches = 0;            // pass-1 launches asked to run tile-sorted (PTF_TILE)
   long long agg_shared_operand_launches = 0;  // pass-1 launches that routed {image, shared raw operand} rows (PTF_SHARED)
 };

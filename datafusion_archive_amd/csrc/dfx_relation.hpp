@@ -30,12 +30,12 @@ struct TableData {
 };
 class TableScanRelation : public Relation {
  public:
-  TableScanRelation(std::shared_ptr<const TableData> t, int64_t batch_rows);
+  TableScanRelation(std::shared_ptr<const TableData> t, int64_t batch_rows, int64_t row_begin = 0, int64_t n_rows = -1);
   RelationKind kind() const override { return REL_TABLE_SCAN; }
   Status next(DeviceBatch* out, bool* has) override;
   const SchemaInfo& schema() const override { return table_->schema; }
   void explain(std::string* out, int depth) const override;
-  ScanMemo* scan_memo() override { return &table_->memo; }  // every scan starts at row 0
+  ScanMemo* scan_memo() override { return begin_ == 0 ? &table_->memo : nullptr; }  // (the memo describes the table's FIRST rows: a scan that starts elsewhere calibrates for itself)
   void prefer_batch_rows(int64_t rows) override {
     if (!emitted_any_ && rows > batch_rows_) batch_rows_ = rows & ~(int64_t)63;
   }
@@ -43,6 +43,7 @@ class TableScanRelation : public Relation {
  private:
   std::shared_ptr<const TableData> table_;
   int64_t batch_rows_;
+  int64_t begin_ = 0, end_ = 0;  // the rows this scan hands out
   int64_t pos_ = 0;
   bool emitted_any_ = false;
 };

@@ -11,21 +11,25 @@ struct dfx_table {
 
 namespace dfx {
 
-TableScanRelation::TableScanRelation(std::shared_ptr<const TableData> t, int64_t batch_rows)
+TableScanRelation::TableScanRelation(std::shared_ptr<const TableData> t, int64_t batch_rows, int64_t row_begin, int64_t n_rows)
     : table_(std::move(t)), batch_rows_(batch_rows) {
-  if (batch_rows_ <= 0) batch_rows_ = table_->num_rows > 0 ? table_->num_rows : 1;
+  begin_ = std::max<int64_t>(0, std::min(row_begin, table_->num_rows));
+  end_ = n_rows < 0 ? table_->num_rows : std::min(table_->num_rows, begin_ + n_rows);
+  pos_ = begin_;
+  if (batch_rows_ <= 0) batch_rows_ = end_ > begin_ ? end_ - begin_ : 1;
   batch_rows_ = (batch_rows_ + 63) / 64 * 64;  // slices stay byte-aligned in every bitmap
 }
 
 void TableScanRelation::explain(std::string* out, int depth) const {
-  explain_line(out, depth, strfmt("TableScan: %lld rows resident in HBM, %d columns, batches of %lld rows (zero-copy slices)",
-                                  (long long)table_->num_rows, (int)table_->columns.size(), (long long)batch_rows_));
+  std::string range = (begin_ != 0 || end_ != table_->num_rows) ? strfmt(", rows [%lld, %lld) of them", (long long)begin_, (long long)end_) : std::string();
+  explain_line(out, depth, strfmt("TableScan: %lld rows resident in HBM%s, %d columns, batches of %lld rows (zero-copy slices)",
+                                  (long long)table_->num_rows, range.c_str(), (int)table_->columns.size(), (long long)batch_rows_));
 }
 
 Status TableScanRelation::next(DeviceBatch* out, bool* has) {
   *has = false;
-  if (pos_ >= table_->num_rows) return Status::OK();  // Ok(None)
-  const int64_t n = std::min(batch_rows_, table_->num_rows - pos_);
+  if (pos_ >= end_) return Status::OK();  // Ok(None)
+  const int64_t n = std::min(batch_rows_, end_ - pos_);
   out->num_rows = n > 0 ? n : 0;
   out->columns.clear();
   out->columns.reserve(table_->columns.size());
@@ -395,6 +399,18 @@ int32_t dfx_table_scan_new(const dfx_table* t, int64_t batch_rows, struct ArrowA
   });
 }
 
+int32_t dfx_table_scan_range_new(const dfx_table* t, int64_t row_begin, int64_t n_rows, int64_t batch_rows, struct ArrowArrayStream* out,
+                                 char* err, size_t errlen) {
+  return c_abi_guard(err, errlen, [&]() -> int32_t {
+    if (!t || !out) return to_c(Status::Err(DFX_GENERAL, "null argument"), err, errlen);
+    if (row_begin < 0 || (row_begin & 63) != 0 || row_begin > t->data->num_rows)
+      return to_c(Status::Err(DFX_GENERAL, "row_begin must be a multiple of 64 inside the table"), err, errlen);
+    std::unique_ptr<Relation> rel(new TableScanRelation(t->data, batch_rows, row_begin, n_rows));
+    export_relation(std::move(rel), out);
+    return DFX_OK;
+  });
+}
+
 void dfx_table_free(dfx_table* t) { delete t; }
 
 // ---- measurement hooks ---------------------------------------------------------------------------
@@ -438,6 +454,10 @@ int64_t dfx_counter_get(const char* name) {
   if (!strcmp(name, "agg_growths")) return counters().agg_growths;
   if (!strcmp(name, "agg_shared_operand_launches")) return counters().agg_shared_operand_launches;
   if (!strcmp(name, "agg_tile_launches")) return counters().agg_tile_launches;
+  if (!strcmp(name, "xchg_calls")) return counters().xchg_calls;
+  if (!strcmp(name, "xchg_local_us")) return counters().xchg_local_us;
+  if (!strcmp(name, "xchg_wait_peers_us")) return counters().xchg_wait_peers_us;
+  if (!strcmp(name, "xchg_exchange_us")) return counters().xchg_exchange_us;
   if (!strcmp(name, "export_us")) return counters().export_us;
   if (!strcmp(name, "export_alloc_us")) return counters().export_alloc_us;
   return -1;

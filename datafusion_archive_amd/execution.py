@@ -405,10 +405,13 @@ def synth_nulls(kind: int, permille: int) -> int:
 
 
 class _TableScan(Relation):
-    def __init__(self, table: "DeviceTable", batch_rows: int):
+    def __init__(self, table: "DeviceTable", batch_rows: int, row_begin: int = 0, n_rows: int = -1):
         super().__init__()
         err = _errbuf()
-        _check(_ffi.lib().dfx_table_scan_new(table._h, batch_rows, ctypes.byref(self._stream), err, 1024), err)
+        if row_begin == 0 and n_rows < 0:
+            _check(_ffi.lib().dfx_table_scan_new(table._h, batch_rows, ctypes.byref(self._stream), err, 1024), err)
+        else:
+            _check(_ffi.lib().dfx_table_scan_range_new(table._h, row_begin, n_rows, batch_rows, ctypes.byref(self._stream), err, 1024), err)
         self._keep = [table]
 
 
@@ -449,8 +452,9 @@ class DeviceTable:
     def column_device_ptr(self, i: int) -> int:
         return _ffi.lib().dfx_table_column_device_ptr(self._h, i) or 0
 
-    def scan(self, batch_rows: int = 0) -> Relation:
-        return _TableScan(self, batch_rows)
+    def scan(self, batch_rows: int = 0, row_begin: int = 0, n_rows: int = -1) -> Relation:
+        """DataSourceRelation over the table -- or over its rows [row_begin, row_begin + n_rows) (row_begin: a multiple of 64)"""
+        return _TableScan(self, batch_rows, row_begin, n_rows)
 
     def __del__(self):
         try:

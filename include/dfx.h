@@ -296,6 +296,12 @@ const void* dfx_table_column_device_ptr(const dfx_table* t, int32_t column);
  * The table must outlive the stream. */
 int32_t dfx_table_scan_new(const dfx_table* t, int64_t batch_rows, struct ArrowArrayStream* out,
                            char* err, size_t errlen);
+/* ... over the rows [row_begin, row_begin + n_rows) of the table only (row_begin a multiple of 64: slices stay
+ * byte-aligned in every bitmap; n_rows < 0: to the end).  A partition of a resident table as a DataSource of its own
+ * (relation.rs:34-54 wraps whatever DataSource it is given): what bench.py uses to check the last rows of the
+ * 10^10-row table -- row indices beyond 2^32 -- against the oracle. */
+int32_t dfx_table_scan_range_new(const dfx_table* t, int64_t row_begin, int64_t n_rows, int64_t batch_rows,
+                                 struct ArrowArrayStream* out, char* err, size_t errlen);
 void dfx_table_free(dfx_table* t);
 
 /* ------------------------------------------------------------------------------------------

@@ -128,6 +128,8 @@ extern "C" {
                               out: *mut ArrowArrayStream, err: *mut c_char, errlen: usize) -> i32;
     fn dfx_table_from_stream(input: *mut ArrowArrayStream, out: *mut *mut DfxTable, err: *mut c_char, errlen: usize) -> i32;
     fn dfx_table_scan_new(t: *const DfxTable, batch_rows: i64, out: *mut ArrowArrayStream, err: *mut c_char, errlen: usize) -> i32;
+    fn dfx_table_scan_range_new(t: *const DfxTable, row_begin: i64, n_rows: i64, batch_rows: i64, out: *mut ArrowArrayStream,
+                                err: *mut c_char, errlen: usize) -> i32;
     fn dfx_table_num_rows(t: *const DfxTable) -> i64;
     fn dfx_table_free(t: *mut DfxTable);
     fn dfx_synchronize(err: *mut c_char, errlen: usize) -> i32;
@@ -759,6 +761,15 @@ impl GpuTable {
     pub fn scan(&self, batch_rows: usize) -> Result<GpuRelation> {
         let (mut out, mut err) = (GpuRelation::new_out(), [0 as c_char; ERRLEN]);
         check(unsafe { dfx_table_scan_new(self.handle, batch_rows as i64, &mut *out, err.as_mut_ptr(), ERRLEN) }, &err)?;
+        GpuRelation::from_stream(out, self.schema.clone())
+    }
+    /// ... over the rows `[row_begin, row_begin + n_rows)` only (`row_begin` a multiple of 64): one partition of a resident
+    /// table as a DataSource of its own.
+    pub fn scan_range(&self, row_begin: usize, n_rows: usize, batch_rows: usize) -> Result<GpuRelation> {
+        let (mut out, mut err) = (GpuRelation::new_out(), [0 as c_char; ERRLEN]);
+        check(unsafe {
+            dfx_table_scan_range_new(self.handle, row_begin as i64, n_rows as i64, batch_rows as i64, &mut *out, err.as_mut_ptr(), ERRLEN)
+        }, &err)?;
         GpuRelation::from_stream(out, self.schema.clone())
     }
 }

@@ -165,7 +165,7 @@ def _exact_sums_uniform(pred_lo_hi):
 def test_uniform_values_within_tolerance_at_2_28_rows():
     """The `uniform` variant (v in [0, 1): partial sums are NOT exact, so a parallel sum cannot reproduce the
     reference's sequential rounding).  Per group with n rows (tests/oracle.py: check_float_sums):
-    |gpu - reference| <= n * eps * sum|v| (proven: the same n terms in another order, eps = 2^-52), <= 64 sqrt(n) ULP of the
+    |gpu - reference| <= n * eps * sum|v| (proven: the same n terms in another order, eps = 2^-52), <= 8 sqrt(n) ULP of the
     reference's sum (empirical: rounding errors walk randomly), and |gpu - EXACT sum| <= (sqrt(n) + 8) ULP, the exact sums
     computed in integer arithmetic (oracle.ExactGroupSums).  COUNT is exact.  The observed maxima are printed (pytest -s)."""
     with ThreadPoolExecutor(2) as pool:  # (the exact sums: ~40 s of numpy per table, next to the GPU and oracle runs)
@@ -246,26 +246,15 @@ def test_config5_q1_shape_exact_variant_bit_for_bit():
 
 
 def _exact_sums_q1(n_rows):
-    """correctly rounded EXACT sums of the four Q1 aggregates per (rf, ls) group: the arguments are computed as the reference
-    computes them (one IEEE rounding per operator, numpy), then added in integer arithmetic (oracle.ExactGroupSums)"""
-    accs = [oracle.ExactGroupSums(6, scale=52) for _ in range(4)]
-    step = 1 << 23
-    for r0 in range(0, n_rows, step):
-        m = min(step, n_rows - r0)
-        c = [oracle.synth_column(k_, cid, p0, p1, SEED5, r0, m) for (_n, k_, cid, p0, p1) in SYN_Q1_UNIFORM]
-        rf, ls, qty, price, disc, tax, ship = c
-        keep = (ship <= 2436.0) & (disc >= 0.0)
-        g = (rf * 2 + ls)[keep]
-        dp = price * (1.0 - disc)
-        for a_, arg in zip(accs, (qty, price, dp, dp * (1.0 + tax))):
-            a_.add(g, arg[keep])
-    return [a_.result() for a_ in accs]
+    """correctly rounded EXACT sums of the four Q1 aggregates per (rf, ls) group (oracle.exact_sums_q1: the arguments as the reference
+    computes them, added in integer arithmetic)"""
+    return oracle.exact_sums_q1(SYN_Q1_UNIFORM, SEED5, 0, n_rows)[0]
 
 
 def test_config5_q1_shape_uniform_variant_within_tolerance():
     """bench.py's columns (uniform doubles), one 2^27-row batch.  A parallel sum cannot reproduce the reference's sequential
     rounding: per group with n rows the three bounds of check_float_sums -- n * eps * sum|v| (every term
-    is positive, so sum|v| is the sum), 64 sqrt(n) ULP of the reference's sum, and (sqrt(n) + 8) ULP of the EXACT sum
+    is positive, so sum|v| is the sum), 8 sqrt(n) ULP of the reference's sum, and (sqrt(n) + 8) ULP of the EXACT sum
     (oracle.ExactGroupSums over the arguments as the reference computes them).  The observed distances are printed (pytest -s)."""
     with ThreadPoolExecutor(1) as pool:
         truth_f = pool.submit(_exact_sums_q1, N5)
