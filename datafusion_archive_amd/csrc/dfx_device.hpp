@@ -276,7 +276,7 @@ struct DevPartition {
   uint32_t mode;       // pass 1: 0 direct routing (one 16-byte store per row), 1 LDS counting sort + coalesced copy-out
   uint32_t block;      // pass-1 workgroup size (mode 1: 512 or 1024)
   uint32_t flags;      // PTF_*
-  uint32_t ws_scanners;// PTF_WS: the split asked for (agg.pass1_ws); one split is built (8 scanner + 8 router waves), any non-zero value runs it
+  uint32_t ws_scanners;// PTF_WS: scanner waves of the 16: 8 (+ 8 routers: selective scans) or 4 (+ 12 routers: dense scans)
   // Control-block snapshot written BY THE KERNEL (null: none): the last workgroup to finish copies T.ctrl into this
   // host-mapped pinned buffer.  The host reads it after the launch's completion event -- no copy engine, no blit kernel
   // that would have to find room next to 256 persistent 1024-lane workgroups, nothing on a side stream.

@@ -676,7 +676,7 @@ hipError_t launch_probe_wide_keys(const DevTable& T, hipStream_t s) {
 
 size_t partition_stage_bytes(const DevPartition& PT) {
   if ((PT.mode & 15u) == 0) return (size_t)PT.n_parts * 4 + 16;
-  if ((PT.mode & 15u) == 2 && (PT.flags & PTF_WS)) return partition_ws_bytes(PT.n_parts, 8);
+  if ((PT.mode & 15u) == 2 && (PT.flags & PTF_WS)) return partition_ws_bytes(PT.n_parts, PT.ws_scanners == 4 ? 4 : 8);
   if ((PT.mode & 15u) == 2)
     return partition_ring_bytes(PT.n_words, PT.n_parts, (PT.flags & PTF_CHUNK16) ? 32 : (PT.mode & 0x100u) ? 8 : 16, (PT.flags & PTF_HOT) != 0,
                                 (PT.flags & PTF_NARROW) != 0, (PT.flags & PTF_SHARED) ? 128 : 0);

@@ -900,26 +900,37 @@ __global__ __launch_bounds__(kRingBlock) void k_partition_ring(const DevProgram 
         }
       }
       const uint64_t m = __ballot(pass);
-      if (pass) {
+      // A row group whose 64 rows ALL pass, met with an empty queue (dense scans: config 3 has no predicate at all), is routed
+      // straight from registers: the compaction queue would only copy it (two LDS writes, two LDS reads, the rank arithmetic
+      // per row group).  Same call site as the queue's batches, so no second copy of the ring protocol.
+      const bool direct = m == ~0ull && qn == 0;
+      if (pass && !direct) {
         const uint32_t at = qn + mbcnt64(m);
         q[at] = key[0];
 #pragma unroll
         for (int a = 0; a < NV; ++a)
           if (a < na) q[(size_t)(1 + a) * kRingQ + at] = val[a];
       }
-      qn += (uint32_t)__popcll(m);
-      if (kRingQ < 192 || (u & 1) == 1 || u == U - 1) {  // the queue holds < 64 + (kRingQ - 64) rows
-        while (qn >= 64) {
-          qn -= 64;
+      if (!direct) qn += (uint32_t)__popcll(m);
+      if (direct || kRingQ < 192 || (u & 1) == 1 || u == U - 1) {  // the queue holds < 64 + (kRingQ - 64) rows
+        while (direct || qn >= 64) {
           uint64_t k2[1];
           uint64_t v2[kMaxAggs];
-          k2[0] = q[qn + lane];
+          if (direct) {
+            k2[0] = key[0];
 #pragma unroll
-          for (int a = 0; a < kMaxAggs; ++a) v2[a] = (a < NV && a < na) ? q[(size_t)(1 + a) * kRingQ + qn + lane] : 0;
+            for (int a = 0; a < kMaxAggs; ++a) v2[a] = (a < NV && a < na) ? val[a] : 0;
+          } else {
+            qn -= 64;
+            k2[0] = q[qn + lane];
+#pragma unroll
+            for (int a = 0; a < kMaxAggs; ++a) v2[a] = (a < NV && a < na) ? q[(size_t)(1 + a) * kRingQ + qn + lane] : 0;
+          }
           const uint64_t h2 = hash_keys<1>(k2);
           bool have2 = true;
           if (HOT && NV == 1) have2 = !hot_absorb<kHot>(hot_keys, hot_accs, POL::acc_kind(T, 0), h2, k2[0], v2[0]);
           ring_route<NV, kRingCH, kRingRP, NARROW>(T, PT, spill, L, producer, na, have2, k2, v2, h2, err);
+          if (direct) break;
         }
       }
     }

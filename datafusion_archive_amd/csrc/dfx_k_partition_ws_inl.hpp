@@ -28,8 +28,8 @@ namespace dfx {
 constexpr int kWsQueueRows = 256;  // per scanner wave (power of two): 3 KB {u32 key, u64 operand}
 constexpr int kWsCH = 16, kWsRP = 32, kWsNCH = kWsRP / kWsCH;
 
-struct WsCtl {  // one per scanner wave
-  uint32_t tail;  // rows produced (written by the scanner)
+struct WsCtl {  // one per queue (= per router wave)
+  uint32_t tail;  // rows produced (written by the queue's scanner)
   uint32_t head;  // rows consumed (written by its router)
   uint32_t done;  // the scanner has published its last row
   uint32_t pad;
@@ -37,8 +37,9 @@ struct WsCtl {  // one per scanner wave
 
 #ifdef DFX_PARTITION_MAIN_TU
 size_t partition_ws_bytes(uint32_t n_parts, int ns) {
+  const int nq = kRingBlock / 64 - ns;  // one queue per ROUTER wave (a scanner feeds (16 - ns) / ns of them in turn)
   return (size_t)n_parts * kWsRP * 12 + (size_t)(kRingBlock / 64) * 64 * 8 /* jobs */ + (size_t)n_parts * 4 * (1 + 2 * kWsNCH) +
-         (size_t)ns * kWsQueueRows * 12 + (size_t)ns * sizeof(WsCtl) + 64;
+         (size_t)nq * kWsQueueRows * 12 + (size_t)nq * sizeof(WsCtl) + 64;
 }
 #else
 size_t partition_ws_bytes(uint32_t n_parts, int ns);
@@ -74,8 +75,11 @@ __global__ __launch_bounds__(kRingBlock) void k_partition_ws(const DevProgram P,
   constexpr int U = POL::U;
   constexpr int NWAVES = kRingBlock / 64;
   constexpr int NR = NWAVES - NS;             // router waves
-  constexpr int SPR = (NS + NR - 1) / NR;     // scanners per router
-  static_assert(NS >= 1 && NR >= 1, "both roles need a wave");
+  // One single-producer / single-consumer queue per ROUTER.  A scanner owns QPS = NR / NS of them and hands its row groups to
+  // them in turn: with 8 + 8 waves (selective scans) every scanner has its router; with 4 + 12 (dense scans, round 5) three
+  // routers share the rows of one scanner -- routing, a chain of LDS round trips per batch, is what a dense scan has most of.
+  constexpr int QPS = NR / NS;                // queues per scanner
+  static_assert(NS >= 1 && NR >= 1 && NR % NS == 0, "every router has a queue, every scanner the same number of them");
   extern __shared__ __attribute__((aligned(16))) uint64_t lds[];
   RingLds L;
   L.ring = lds;
@@ -85,11 +89,11 @@ __global__ __launch_bounds__(kRingBlock) void k_partition_ws(const DevProgram P,
   L.fill = L.jobs + NWAVES * 64 * 2;
   L.commit = L.fill + PT.n_parts;
   L.gen = L.commit + (size_t)PT.n_parts * kWsNCH;
-  uint32_t* const qkeys = L.gen + (size_t)PT.n_parts * kWsNCH;                   // [NS][kWsQueueRows]
-  WsCtl* const ctl = (WsCtl*)(qkeys + (size_t)NS * kWsQueueRows);                // [NS]
+  uint32_t* const qkeys = L.gen + (size_t)PT.n_parts * kWsNCH;                   // [NR][kWsQueueRows]
+  WsCtl* const ctl = (WsCtl*)(qkeys + (size_t)NR * kWsQueueRows);                // [NR]
   // the operand planes behind everything else, 8-byte aligned (as an offset from `lds`: keeps the LDS address space)
-  const size_t qv_word0 = ring_words + ((size_t)(NWAVES * 64 * 2 + PT.n_parts * (1 + 2 * kWsNCH) + NS * kWsQueueRows) * 4 + (size_t)NS * sizeof(WsCtl) + 7) / 8;
-  uint64_t* const qvals = lds + qv_word0;                                        // [NS][kWsQueueRows]
+  const size_t qv_word0 = ring_words + ((size_t)(NWAVES * 64 * 2 + PT.n_parts * (1 + 2 * kWsNCH) + NR * kWsQueueRows) * 4 + (size_t)NR * sizeof(WsCtl) + 7) / 8;
+  uint64_t* const qvals = lds + qv_word0;                                        // [NR][kWsQueueRows]
   const int lane = lane_id();
   const int wave = (int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const uint32_t producer = blockIdx.x;
@@ -104,7 +108,7 @@ __global__ __launch_bounds__(kRingBlock) void k_partition_ws(const DevProgram P,
       L.gen[p * kWsNCH + sl] = (c0 + (uint32_t)(kWsNCH - 1 - sl)) / (uint32_t)kWsNCH;
     }
   }
-  if (threadIdx.x < (unsigned)NS) {
+  if (threadIdx.x < (unsigned)NR) {
     ctl[threadIdx.x].tail = 0;
     ctl[threadIdx.x].head = 0;
     ctl[threadIdx.x].done = 0;
@@ -113,11 +117,11 @@ __global__ __launch_bounds__(kRingBlock) void k_partition_ws(const DevProgram P,
   uint32_t err = 0;
   if (wave < NS) {
     // ---------------------------------------------------------------- scanner -----------------------------------
-    uint32_t* const qk = qkeys + (size_t)wave * kWsQueueRows;
-    uint64_t* const qv = qvals + (size_t)wave * kWsQueueRows;
-    WsCtl* const my = ctl + wave;
-    uint32_t tail = 0;    // rows produced so far (wave-uniform)
-    uint32_t head_c = 0;  // last consumer position seen
+    // this scanner's queues: q0 .. q0 + QPS - 1.  Lane j of v_tail / v_head holds queue q0 + j's produced / last-seen-consumed count
+    // (read with v_readlane at the wave-uniform index `cq` -- the queue the next row group goes to --, written by compare-and-select)
+    const int q0 = wave * QPS;
+    uint32_t v_tail = 0, v_head = 0;
+    int cq = 0;
     uint64_t passed = 0;  // wave-uniform
     const int64_t n_groups = (n + 63) >> 6;
     const int64_t wave_global = (int64_t)blockIdx.x * NS + wave;
@@ -170,9 +174,13 @@ __global__ __launch_bounds__(kRingBlock) void k_partition_ws(const DevProgram P,
             }
             const uint32_t c = (uint32_t)__popcll(pm);
             if (c != 0) {
+              uint32_t* const qk = qkeys + (size_t)(q0 + cq) * kWsQueueRows;
+              uint64_t* const qv = qvals + (size_t)(q0 + cq) * kWsQueueRows;
+              WsCtl* const my = ctl + (q0 + cq);
+              uint32_t tail = (uint32_t)__builtin_amdgcn_readlane((int)v_tail, cq);
+              uint32_t head_c = (uint32_t)__builtin_amdgcn_readlane((int)v_head, cq);
               // room for c rows?  (the router publishes its position after every batch of 64 it takes)
               uint32_t spins = 0;
-              head_c = (uint32_t)__builtin_amdgcn_readfirstlane((int)head_c);  // (wave-uniform by construction: keep the test below scalar)
               // The router only sees the PUBLISHED tail and takes whole batches of 64: rows parked since the last publication
               // (up to U - 1 groups of this trip) are invisible to it, so a locally dense stretch -- more than ~3/4 of a
               // 256-row window passing -- could fill the queue with rows nobody may take yet.  Publish before waiting: with
@@ -193,73 +201,74 @@ __global__ __launch_bounds__(kRingBlock) void k_partition_ws(const DevProgram P,
                 qv[at] = val;
               }
               tail += c;
+              v_tail = lane == cq ? tail : v_tail;  // (v_writelane by compare-and-select)
+              v_head = lane == cq ? head_c : v_head;
+              if constexpr (QPS > 1) {
+                // the next row group goes to the next router.  With several routers per scanner a group's rows are published at
+                // once: a router that waits for the end of the trip idles while its neighbours work
+                if (lane == 0) __hip_atomic_store(&my->tail, tail, __ATOMIC_RELEASE, WG_SCOPE);
+                cq = cq + 1 == QPS ? 0 : cq + 1;
+              }
             }
           }
         };
         if ((w0 + U) * 64 <= n) trip_body(std::true_type{}); else trip_body(std::false_type{});
-        if (lane == 0) __hip_atomic_store(&my->tail, tail, __ATOMIC_RELEASE, WG_SCOPE);  // once per trip: the rows above are visible first
+        if constexpr (QPS == 1) {
+          if (lane == 0) __hip_atomic_store(&ctl[q0].tail, v_tail, __ATOMIC_RELEASE, WG_SCOPE);  // once per trip: the rows above are visible first
+        }
       }
     }
-    if (lane == 0) {
-      __hip_atomic_store(&my->tail, tail, __ATOMIC_RELEASE, WG_SCOPE);
-      __hip_atomic_store(&my->done, 1u, __ATOMIC_RELEASE, WG_SCOPE);
-      stat_add(T, STAT_PASSED, passed);
+    if (lane < QPS) {  // lane j: queue q0 + j
+      __hip_atomic_store(&ctl[q0 + lane].tail, v_tail, __ATOMIC_RELEASE, WG_SCOPE);
+      __hip_atomic_store(&ctl[q0 + lane].done, 1u, __ATOMIC_RELEASE, WG_SCOPE);
     }
+    if (lane == 0) stat_add(T, STAT_PASSED, passed);
   } else {
     // ---------------------------------------------------------------- router ------------------------------------
-    const int r = wave - NS;
-    uint32_t fin = 0;  // bit j: scanner r + j NR has been drained (or does not exist)
-    for (int j = 0; j < SPR; ++j)
-      if (r + j * NR >= NS) fin |= 1u << j;
-    constexpr uint32_t kAllFin = (1u << SPR) - 1u;
+    // router r drains queue r (its scanner: r / QPS)
+    const int q = wave - NS;
+    WsCtl* const sc = ctl + q;
+    bool fin = false;
     uint32_t idle = 0;
-    while (fin != kAllFin) {
-      bool progress = false;
-#pragma nounroll
-      for (int j = 0; j < SPR; ++j) {  // ONE copy of the routing code: a run-time loop over this router's scanners
-        if ((fin >> j) & 1u) continue;
-        const int s = r + j * NR;
-        WsCtl* const sc = ctl + s;
-        const uint32_t head = sc->head;  // (only this wave writes it)
-        uint32_t tail = __hip_atomic_load(&sc->tail, __ATOMIC_ACQUIRE, WG_SCOPE);
-        uint32_t avail = tail - head;
-        uint32_t take = avail >= 128u ? 128u : avail >= 64u ? 64u : 0u;  // whole batches of 64, two at a time when they are there
-        if (take == 0 && __hip_atomic_load(&sc->done, __ATOMIC_ACQUIRE, WG_SCOPE) != 0u) {
-          tail = __hip_atomic_load(&sc->tail, __ATOMIC_ACQUIRE, WG_SCOPE);  // the final count was published before `done`
-          avail = tail - head;
-          take = avail < 128u ? avail : 128u;
-          if (avail == 0) fin |= 1u << j;
-        }
-        if (take == 0) continue;
-        bool have[2];
-        uint64_t k2[2], v2[2], h2[2];
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {  // (both batches' queue reads in flight together)
-          have[b] = (uint32_t)(b * 64 + lane) < take;
-          const uint32_t at = (head + (uint32_t)(b * 64 + lane)) & (uint32_t)(kWsQueueRows - 1);
-          k2[b] = have[b] ? (uint64_t)qkeys[(size_t)s * kWsQueueRows + at] : 0ull;
-          v2[b] = have[b] ? qvals[(size_t)s * kWsQueueRows + at] : 0ull;
-        }
-        // the slots are free again as soon as the rows sit in registers
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        if (lane == 0) __hip_atomic_store(&sc->head, head + take, __ATOMIC_RELEASE, WG_SCOPE);
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-          uint64_t k1[1] = {k2[b]};
-          h2[b] = hash_keys<1>(k1);
-        }
-        ring_route2<kWsCH, kWsRP, 1>(T, PT, spill, L, producer, have, k2, v2, h2, err);
-        progress = true;
+    while (!fin) {
+      const uint32_t head = sc->head;  // (only this wave writes it)
+      uint32_t tail = __hip_atomic_load(&sc->tail, __ATOMIC_ACQUIRE, WG_SCOPE);
+      uint32_t avail = tail - head;
+      uint32_t take = avail >= 128u ? 128u : avail >= 64u ? 64u : 0u;  // whole batches of 64, two at a time when they are there
+      if (take == 0 && __hip_atomic_load(&sc->done, __ATOMIC_ACQUIRE, WG_SCOPE) != 0u) {
+        tail = __hip_atomic_load(&sc->tail, __ATOMIC_ACQUIRE, WG_SCOPE);  // the final count was published before `done`
+        avail = tail - head;
+        take = avail < 128u ? avail : 128u;
+        if (avail == 0) fin = true;
       }
-      if (!progress) {
+      if (take == 0) {
+        if (fin) break;
         if (++idle > (1u << 24)) {  // a scanner that never finishes: cannot happen; never hang the device
           err |= 4u;
           break;
         }
         __builtin_amdgcn_s_sleep(2);
-      } else {
-        idle = 0;
+        continue;
       }
+      idle = 0;
+      bool have[2];
+      uint64_t k2[2], v2[2], h2[2];
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {  // (both batches' queue reads in flight together)
+        have[b] = (uint32_t)(b * 64 + lane) < take;
+        const uint32_t at = (head + (uint32_t)(b * 64 + lane)) & (uint32_t)(kWsQueueRows - 1);
+        k2[b] = have[b] ? (uint64_t)qkeys[(size_t)q * kWsQueueRows + at] : 0ull;
+        v2[b] = have[b] ? qvals[(size_t)q * kWsQueueRows + at] : 0ull;
+      }
+      // the slots are free again as soon as the rows sit in registers
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      if (lane == 0) __hip_atomic_store(&sc->head, head + take, __ATOMIC_RELEASE, WG_SCOPE);
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        uint64_t k1[1] = {k2[b]};
+        h2[b] = hash_keys<1>(k1);
+      }
+      ring_route2<kWsCH, kWsRP, 1>(T, PT, spill, L, producer, have, k2, v2, h2, err);
     }
   }
   __syncthreads();
@@ -291,17 +300,25 @@ __global__ __launch_bounds__(kRingBlock) void k_partition_ws(const DevProgram P,
   snapshot_ctrl_if_last(T, PT);
 }
 
-// DevPartition::ws_scanners: the split asked for (agg.pass1_ws).  One split is instantiated -- eight scanner waves, eight
-// routers, the policy's own U -- chosen from the table in DESIGN.md section 4 (6 / 8 / 10 / 12 scanners and U = 8 measured
-// in round 3); every non-zero value runs it.  The comparison form is the host's choice: one kernel per form the signature's
-// two-term predicates can take (lower bound > / >=, upper bound < / <=), the run-time form for everything else.
-constexpr uint32_t kWsDefault = 8;
-template <typename POLN>
+// DevPartition::ws_scanners: the split.  Two are instantiated: eight scanner waves + eight routers with the policy's own U
+// (selective scans: the table in DESIGN.md section 4 -- 6 / 8 / 10 / 12 scanners and U = 8 measured in round 3), and four scanners
+// + twelve routers with the dense policy POLD (round 5: scans that route more than half of their rows -- three routers per
+// scanner, eight row groups per trip where the registers allow so that four waves keep the loads in flight).  Any other
+// non-zero value runs eight.  The comparison form is the host's choice: one kernel per form the signature's two-term
+// predicates can take (lower bound > / >=, upper bound < / <=), the run-time form for everything else.
+constexpr uint32_t kWsDefault = 8, kWsDense = 4;
+template <typename POLN, typename POLD>
 void launch_partition_ws(const DevProgram& P, const DevFastPlan& fast, const DevColumns& C, const DevAggPlan& plan, const DevTable& T,
                          const DevPartition& PT, const DevRows& spill, int64_t n, size_t lds_bytes, hipStream_t s) {
   const int grid = (int)PT.n_producers;
-#define DFX_WS_LAUNCH(FORM_) \
-  hipLaunchKernelGGL((k_partition_ws<POLN, (int)kWsDefault, FORM_>), dim3(grid), dim3(kRingBlock), lds_bytes, s, P, fast, C, plan, T, PT, spill, n)
+  const bool dense = PT.ws_scanners == kWsDense;
+#define DFX_WS_LAUNCH(FORM_)                                                                                                             \
+  do {                                                                                                                                   \
+    if (dense)                                                                                                                           \
+      hipLaunchKernelGGL((k_partition_ws<POLD, (int)kWsDense, FORM_>), dim3(grid), dim3(kRingBlock), lds_bytes, s, P, fast, C, plan, T, PT, spill, n);   \
+    else                                                                                                                                 \
+      hipLaunchKernelGGL((k_partition_ws<POLN, (int)kWsDefault, FORM_>), dim3(grid), dim3(kRingBlock), lds_bytes, s, P, fast, C, plan, T, PT, spill, n); \
+  } while (0)
   if constexpr (POLN::kIsStatic && POLN::kPredTerms == 2) {
     switch (POLN::form_of(fast)) {
       case 4 | (1 << 3): DFX_WS_LAUNCH(4 | (1 << 3)); return;  // x >  a AND x <  b
@@ -324,7 +341,7 @@ void launch_partition_ws(const DevProgram& P, const DevFastPlan& fast, const Dev
     if (PT.flags & PTF_TILE)                                                                                               \
       launch_partition_tile<POLT, POLW>(P, fast, C, plan, T, PT, spill, n, s);                                             \
     else if (PT.flags & PTF_WS)                                                                                            \
-      launch_partition_ws<POLW>(P, fast, C, plan, T, PT, spill, n, lds_bytes, s);                                          \
+      launch_partition_ws<POLW, POLT>(P, fast, C, plan, T, PT, spill, n, lds_bytes, s);                                    \
     else                                                                                                                   \
       launch_partition_pol<POL, POLS, POLN>(P, fast, C, plan, T, PT, spill, n, lds_bytes, s);                              \
   }

@@ -261,6 +261,8 @@ bool set_option_in(AggOptions& o, const char* key, int64_t value) {
   else if (!strcmp(key, "agg.pass1_ws")) o.pass1_ws = (int)value;
   else if (!strcmp(key, "agg.pass1_tile")) o.pass1_tile = (int)value;
   else if (!strcmp(key, "agg.tile_block")) o.tile_block = (int)value;
+  else if (!strcmp(key, "agg.pass1_ws_dense")) o.pass1_ws_dense = (int)value;
+  else if (!strcmp(key, "agg.pass1_ws_dense_scanners")) o.pass1_ws_dense_scanners = (int)value;
   else if (!strcmp(key, "agg.merge_scan_batches")) o.merge_scan_batches = (int)value;
   else if (!strcmp(key, "filter.single_pass")) o.filter_single_pass = (int)value;
   else if (!strcmp(key, "filter.dense")) o.filter_dense = (int)value;

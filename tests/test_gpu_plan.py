@@ -140,6 +140,32 @@ def test_plan_family_ring_kernel_and_wide_rows(name):
         ex.set_option("agg.narrow_keys", -1)
 
 
+@pytest.mark.parametrize("name", ["min_only", "int32_key", "int32_key_no_predicate", "nullable_v_10pct", "three_terms", "max_int64_no_predicate", "nullable_key"])
+def test_plan_family_four_scanners_twelve_routers(name):
+    """Round 5: the wave-specialised kernel's DENSE split -- four scanner waves feeding three routers each in turn (one
+    single-producer / single-consumer queue per router), chosen for scans that route more than half of their rows; forced here
+    (agg.pass1_ws = 4) on selective and unfiltered queries alike, plan kernels and 4-byte keys included."""
+    syn, pred, aggs = CASES[name]
+    _check(name + " 4 + 12 waves", syn, pred, aggs, opts=(("agg.pass1_ws", 4),))
+    ex.set_option("agg.pass1_ws", 8)
+
+
+def test_signature_queries_four_scanners_twelve_routers():
+    """... and the compile-time signatures (the headline with each of its four comparison forms, config 3 without a predicate) through
+    the same split, clustered data included (a locally dense stretch after a selective start)"""
+    syn = _syn()
+    lo, hi = f64(204.8), f64(409.6)
+    forms = [AND(BinaryExpr(Column(1), a, lo), BinaryExpr(Column(1), b, hi)) for a in (Operator.Gt, Operator.GtEq) for b in (Operator.Lt, Operator.LtEq)]
+    for pred in forms + [None]:
+        _s, _kept, want = oracle.run_synth_query(syn, SEED, 0, N, 1024, pred, [Column(0)], [SUM_V])
+        ex.set_option("agg.pass1_ws", 4)
+        try:
+            got = _run(syn, pred, [SUM_V], 1)
+        finally:
+            ex.set_option("agg.pass1_ws", 8)
+        _assert_bit_exact(got, want, f"signature query, 4 + 12 waves, predicate {pred is not None}")
+
+
 @pytest.mark.parametrize("strategy", [1, 2])
 @pytest.mark.parametrize("name", ["nullable_v_count", "nullable_w_predicate", "int32_key", "nullable_everything_int32_key", "nullable_v_no_filter_count"])
 def test_plan_family_table_strategies(name, strategy):
@@ -212,6 +238,18 @@ def test_wave_specialised_pass1_on_clustered_data_does_not_stall():
         ex.set_option("scan.plan", 1)
         want = oracle.aggregate([Column(0)], [SUM_V, COUNT_V], [oracle.filter_next(HEAD, b)])
         _assert_bit_exact(got, want, f"clustered data, scan.plan = {plan}")
+    # one aggregate (the one-value kernels: this IS the wave-specialised flavour), both splits of its waves
+    want = oracle.aggregate([Column(0)], [SUM_V], [oracle.filter_next(HEAD, b)])
+    for ws in (8, 4):
+        for plan in (1, 2):
+            ex.set_option("scan.plan", plan)
+            ex.set_option("agg.pass1_ws", ws)
+            try:
+                got = gpu_aggregate([Column(0)], [SUM_V], schema, [], filter_expr=HEAD, source=t.scan(1 << 21))
+            finally:
+                ex.set_option("scan.plan", 1)
+                ex.set_option("agg.pass1_ws", 8)
+            _assert_bit_exact(got, want, f"clustered data, one aggregate, {ws} scanner waves, scan.plan = {plan}")
 
 
 def test_plan_int32_key_host_batches_at_odd_offsets():

@@ -54,6 +54,9 @@ def _sorted_columns(batch: pa.RecordBatch):
 SYN_UNIFORM_KEYS_EXACT = [("k", ex.SYNTH_I64_UNIFORM, 0, 1e6, 0.0), ("v", ex.SYNTH_F64_EXACT, 1, 0.0, 0.0)]
 SYN_UNIFORM_VALUES = [("k", ex.SYNTH_I64_UNIFORM, 0, 1e6, 0.0), ("v", ex.SYNTH_F64_UNIFORM, 1, 0.0, 1.0)]
 SYN_ZIPF = [("k", ex.SYNTH_I64_ZIPF, 0, 1e6, 1.0), ("v", ex.SYNTH_F64_EXACT, 1, 0.0, 0.0)]
+# 10^6 distinct keys (u + 1) * 0x9E3779B97F4A7C15 mod 2^64: every one >= 2^32 (no 32-bit hash image: 16-byte routed rows, 64-bit
+# key compares in pass 2), half of them negative -- the reference takes any Int64 key (aggregate.rs:807-852)
+SYN_WIDE = [("k", ex.SYNTH_I64_WIDE, 0, 1e6, 0.0), ("v", ex.SYNTH_F64_EXACT, 1, 0.0, 0.0)]
 PRED_U = BinaryExpr(BinaryExpr(Column(1), Operator.Gt, lit(0.2)), Operator.And, BinaryExpr(Column(1), Operator.Lt, lit(0.4)))
 MINMAX = [SUM_V, AggregateFunction("MIN", [Column(1)], F64), AggregateFunction("MAX", [Column(1)], F64)]
 QUERIES = {
@@ -63,6 +66,8 @@ QUERIES = {
     "uniform_all": (SYN_UNIFORM_VALUES, None, [SUM_V, COUNT_V]),
     "zipf_filtered": (SYN_ZIPF, PRED, [SUM_V, COUNT_V]),
     "zipf_all": (SYN_ZIPF, None, [SUM_V, COUNT_V]),
+    "wide_filtered": (SYN_WIDE, PRED, [SUM_V, COUNT_V]),
+    "wide_all": (SYN_WIDE, None, [SUM_V]),
 }
 # ---- BASELINE config 2 as written and config 5 (TPC-H Q1 shape) at the benchmark's batch sizes ----------------------
 N2 = 1 << 28                 # config 2: one Float64 column, lat = 49 + 10 u, seed 0xDF01, 2^27-row batches
@@ -182,6 +187,19 @@ def test_uniform_values_within_tolerance_at_2_28_rows():
             print(f"\n{what}: max |gpu - reference| = {stats['max_ulp_vs_reference']:.1f} ULP = {stats['max_over_sqrt_n']:.2f} sqrt(n); "
                   f"|gpu - exact| <= {stats['max_ulp_vs_exact']:.1f} ULP, |reference - exact| <= {stats['reference_max_ulp_vs_exact']:.1f} ULP; "
                   f"rows per group up to {int(wc.max())}")
+
+
+def test_wide_int64_keys_per_group_vs_oracle_at_2_28_rows():
+    """Round 5: keys that are NOT small integers at the benchmark's size -- 10^6 distinct Int64 keys spread over the whole type (none
+    below 2^32, half negative).  The calibration slice sees them, so the stream never enters narrow mode: pass 1 routes 16-byte rows
+    {key, operand} (the ring kernel with 8-row chunks), pass 2 compares 64-bit keys.  With the headline's filter (SUM + COUNT, generic
+    row width) and as config 3 is written (no filter, one aggregate: the lean pass 2); every group bit for bit."""
+    for name in ("wide_filtered", "wide_all"):
+        got = _gpu(name)
+        _secs, kept, want = _oracle_result(name)
+        assert got.num_rows == 1000000
+        assert np.abs(got.column(0).to_numpy().astype(np.float64)).min() >= float(1 << 32)  # no key of the result has a 32-bit form
+        _assert_bit_exact(got, want, name + " 2^28")
 
 
 def test_zipf_keys_per_group_vs_oracle_at_2_28_rows():
