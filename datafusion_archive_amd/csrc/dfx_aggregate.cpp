@@ -140,7 +140,7 @@ struct AggregateRelation::Impl {
   bool narrow = false;          // every key the calibration slice saw is below 2^32: 12-byte routed rows (PTF_NARROW)
   int64_t launch_rows_hint = 0;  // > 0: the current batch is routed in launches of at most this many rows
   bool dense_seen = false;      // more than half of the calibration slice's rows passed the predicate: pass 2 after every batch
-  bool all_pass_seen = false;   // ... more than nine in ten: every wave has rows to route all the time (pass 1: the symmetric ring kernel)
+  bool mostly_seen = false;     // ... more than two thirds: pass 1's wave-specialised kernel runs 4 scanner + 12 router waves instead of 8 + 8
   bool skew_seen = false;       // the calibration slice's front cache absorbed a sizeable share of its rows: heavy keys
   DevPartition PT;
   std::shared_ptr<void> pt_rows, pt_counts;
@@ -677,13 +677,14 @@ Status AggregateRelation::Impl::ensure_partition(int64_t rows, bool nulls_now) {
       PT.flags |= PTF_CHUNK16;
     // selective scans: the scanning and the routing belong to different waves (dfx_k_partition_ws_inl.hpp).  When most rows
     // pass, every wave has rows to route all the time and the ring kernel's symmetric waves are the better fit
-    // (round 5, 2^26-row launches: at selectivity 0.5 the wave-specialised kernel takes 287 us where the ring kernel takes 331, at 0.8
-    // 378 against 404, with every row routed 453 against 426 -- profiles/r05_pass1_ws_by_selectivity.txt; agg.pass1_ws_dense: 1 = also
-    // then, -1 = never above one half as in round 4)
-    const bool ws_fits = o.pass1_ws_dense > 0 || (o.pass1_ws_dense < 0 ? !dense_seen : !all_pass_seen);
+    // (round 5, 2^26-row launches, us per launch: ring kernel / 8 + 8 waves / 4 + 12 waves -- selectivity 0.2: - / 415 / 535; 0.5: 326 /
+    // 261 / 292; 0.8: 403 / 371 / 353; every row routed: 434 / 438 / 417-424 -- profiles/r05_pass1_ws_by_selectivity.txt.  So: always
+    // the wave-specialised kernel, four scanners once more than two thirds of the rows are routed.  agg.pass1_ws_dense = -1: never
+    // above one half, round 4's rule)
+    const bool ws_fits = o.pass1_ws_dense >= 0 || !dense_seen;
     if ((PT.flags & PTF_CHUNK16) && o.pass1_ws > 0 && ws_fits && !(((uint32_t)o.partition_mode) & ~15u)) {
       // the split: 8 scanners + 8 routers; dense scans (more than half of the rows routed): 4 + 12 (agg.pass1_ws_dense_scanners)
-      PT.ws_scanners = (o.pass1_ws == 4 || (dense_seen && o.pass1_ws_dense_scanners == 4)) ? 4u : 8u;  // (agg.pass1_ws = 4: that split whatever the selectivity -- tests)
+      PT.ws_scanners = (o.pass1_ws == 4 || (mostly_seen && o.pass1_ws_dense_scanners == 4)) ? 4u : 8u;  // (agg.pass1_ws = 4: that split whatever the selectivity -- tests)
       if (partition_ws_bytes(PT.n_parts, (int)PT.ws_scanners) <= (size_t)158 * 1024) PT.flags |= PTF_WS;
     }
     // dense scans (most rows routed): no ring protocol at all -- tiles of 8192 rows counting-sorted by partition in LDS and
@@ -1201,7 +1202,7 @@ Status AggregateRelation::Impl::consume_batch_chunk(const DeviceBatch& b) {
     skew_seen = (remembered >> 63) != 0;
     narrow = ((remembered >> 62) & 1) != 0;
     dense_seen = ((remembered >> 61) & 1) != 0;
-    all_pass_seen = ((remembered >> 60) & 1) != 0;
+    mostly_seen = ((remembered >> 60) & 1) != 0;
     remembered &= ~(15ull << 60);
     occupied_known = remembered;
     lds_calibrated = true;
@@ -1241,10 +1242,10 @@ Status AggregateRelation::Impl::consume_batch_chunk(const DeviceBatch& b) {
         passed += hs[(size_t)i * STAT_WORDS + STAT_PASSED];
       }
       dense_seen = passed * 2 > (uint64_t)n0;
-      all_pass_seen = passed * 10 > (uint64_t)n0 * 9;
+      mostly_seen = passed * 3 > (uint64_t)n0 * 2;
       skew_seen = occupied_known >= 16384 && miss > 0 && hit * 8 >= miss;  // (`miss` counts every row that went through the cache) >= 12.5 % reused although the groups do not fit
     }
-    if (memo) memo->remember(program_fingerprint(), occupied_known | (skew_seen ? 1ull << 63 : 0ull) | (narrow ? 1ull << 62 : 0ull) | (dense_seen ? 1ull << 61 : 0ull) | (all_pass_seen ? 1ull << 60 : 0ull));
+    if (memo) memo->remember(program_fingerprint(), occupied_known | (skew_seen ? 1ull << 63 : 0ull) | (narrow ? 1ull << 62 : 0ull) | (dense_seen ? 1ull << 61 : 0ull) | (mostly_seen ? 1ull << 60 : 0ull));
     lds_calibrated = true;
     lds_enabled = occupied_known <= 8192;
     if (!lds_enabled && kw == 1 && occupied_known >= 16384) {
