@@ -1,0 +1,98 @@
+#!/bin/bash
+# The round's evidence on ONE gpurun call each (tools/gpu.sh <timeout> tools/gpu_round.sh <stage> [round tag]):
+#   suite    the whole GPU test suite (what the driver runs at round end)
+#   bench    bench.py with the driver's flags -> gpurun_out/<tag>/bench.json + a one-screen summary
+#   profile  rocprofv3 --kernel-trace --stats of the bench command; FETCH_SIZE / WRITE_SIZE (separate passes) and SQ counters of
+#            pass 1 / pass 2 for the headline and for config 3 -> partition_counters.json; kernel stats of config 3
+#   dry8     bench.py --gpus 8 as eight processes on this ONE GPU over the host-staged RCCL stand-in (plumbing only), and the
+#            same with DFX_RCCL_LIB pointing at a missing file (must exit non-zero)
+# Summaries land in gpurun_out/<tag>/ -- what is cited is copied to profiles/ by hand.
+STAGE=${1:-bench}; TAG=${2:-r05}
+R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp
+cd $R
+case $STAGE in
+suite)
+  timeout 2400 python -m pytest tests -m gpu -q --timeout 900 > $OUT/pytest_gpu.log 2>&1; echo "gpu suite rc=$?"; tail -n 8 $OUT/pytest_gpu.log | cut -c1-300
+  ;;
+bench)
+  timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; tail -n 3 $OUT/bench.err | cut -c1-300
+  python - $OUT/bench.json <<'PY'
+import json, sys
+d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+r = d["roofline"]
+print("ms_per_step", round(d["ms_per_step"], 4), "end to end", r.get("end_to_end_frac"), "dominant kernel", r["frac"], "cold first step ms", r.get("cold_first_step_ms"))
+print("cpu_baseline", d["cpu_baseline"] and round(d["cpu_baseline"]["value"]), "verified", (d["extra"].get("verified_vs_oracle") or {}).get("ok"))
+for k, v in d["extra"].items():
+    if isinstance(v, dict) and ("roofline" in v or "error" in v):
+        rf = v.get("roofline") or {}
+        vo = v.get("verified_vs_oracle")
+        print(f"  {k:38s} frac {rf.get('frac')}  ms {v.get('ms') and round(v['ms'], 2)}  verified {vo.get('ok') if isinstance(vo, dict) else vo}  {v.get('error', '')}")
+PY
+  ;;
+profile)
+  cd /tmp
+  BENCH="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras"
+  rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/stats -o out -- $BENCH > $OUT/bench_under_rocprof.json 2>/dev/null
+  cp $OUT/stats/out_kernel_stats.csv $OUT/bench_kernel_stats.csv 2>/dev/null
+  export DFX_NO_TORCH=1
+  Q="python $R/tools/prof_query.py"
+  rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/stats_cfg3 -o out -- $Q cfg3 1073741824 3 > /dev/null 2>&1
+  cp $OUT/stats_cfg3/out_kernel_stats.csv $OUT/cfg3_kernel_stats.csv 2>/dev/null
+  pmc() { name=$1; wl=$2; opts=$3; shift; shift; shift; rocprofv3 --output-format csv --pmc "$@" -d $OUT/$name -o out -- $Q $wl 268435456 1 batch=134217728 $opts > /dev/null 2>&1; }
+  SQ2="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU"
+  for wl in headline cfg3; do
+    pmc fetch_$wl $wl "" FETCH_SIZE
+    pmc write_$wl $wl "" WRITE_SIZE
+    pmc sq_$wl $wl "" $SQ2
+  done
+  pmc sq_headlineinterp headline "scan.fast=0" $SQ2
+  cd $OUT
+  python3 - <<'PY'
+import csv, glob, collections, json
+res = collections.defaultdict(dict)
+ROWS = 2.0 * 268435456  # rows every run pushes through the kernels (one warm-up + one timed pass)
+for d in sorted(glob.glob("fetch_*") + glob.glob("write_*") + glob.glob("sq_*")):
+    wl = d.split("_", 1)[1]
+    for f in glob.glob(f"{d}/**/*counter_collection*.csv", recursive=True):
+        agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"].split("(")[0]
+            if "partition" not in k:
+                continue
+            k = ("pass2 " if "partition_agg" in k else "pass1 ") + k[:90]
+            agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[(k, r["Counter_Name"])] += 1
+        for k, v in agg.items():
+            for c, x in v.items():
+                e = res[wl + " | " + k]
+                e[c + "_per_dispatch"] = x / cnt[(k, c)]
+                e["dispatches"] = cnt[(k, c)]
+                e["rows_per_dispatch"] = ROWS / cnt[(k, c)]
+                if c.startswith("SQ_"):
+                    e[c + "_per_64_row_group"] = x / cnt[(k, c)] / (ROWS / cnt[(k, c)] / 64.0)
+json.dump(res, open("partition_counters.json", "w"), indent=1, sort_keys=True)
+for k, v in sorted(res.items()): print(k[:70], {a: round(b, 1) for a, b in v.items() if "per_64" in a or a in ("FETCH_SIZE_per_dispatch", "WRITE_SIZE_per_dispatch", "dispatches")})
+PY
+  head -12 bench_kernel_stats.csv | cut -c1-220
+  head -8 cfg3_kernel_stats.csv | cut -c1-220
+  rm -rf stats*/out_kernel_trace.csv */*/*.csv.gz 2>/dev/null
+  find . -name "*counter_collection*.csv" -size +2000k -delete 2>/dev/null
+  find . -name "*kernel_trace*.csv" -size +2000k -delete 2>/dev/null
+  ;;
+dry8)
+  export DFX_BENCH_SHARED_GPU=1 DFX_RCCL_LIB=$R/tests/native/librccl_stub.so
+  timeout 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29518 bench.py --gpus 8 --rows 5e7 --steps 2 --warmup 1 > $OUT/bench_8rank.json 2> $OUT/bench_8rank.err; echo "8-rank dry run rc=$?"; tail -2 $OUT/bench_8rank.err | cut -c1-300
+  python - $OUT/bench_8rank.json <<'PY'
+import json, sys
+d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+print("n_gpus", d["n_gpus"], "rccl_ranks", d["config"]["rccl_ranks"], "exchange", d["config"]["exchange"][:60])
+print("phases_ms", json.dumps(d["extra"].get("phases_ms")))
+for k in ("cfg4_as_written", "cfg5_q1_shape"):
+    v = d["extra"].get(k, {})
+    print(k, "frac/GPU", (v.get("roofline") or {}).get("frac"), "phases", json.dumps(v.get("phases_ms")), "groups ok", v.get("every_group_emitted_once"))
+print("sum-of-sums check", d["extra"]["verified_sum_of_group_sums_equals_ungrouped_sum"])
+PY
+  export DFX_RCCL_LIB=$R/tests/native/no_such_librccl.so
+  timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29519 bench.py --gpus 8 --rows 2e7 --steps 1 --warmup 0 > $OUT/bench_8rank_norccl.json 2> $OUT/bench_8rank_norccl.err; echo "8-rank run without a loadable RCCL rc=$? (must be non-zero)"; grep -m1 "refusing" $OUT/bench_8rank_norccl.err | cut -c1-300
+  timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29520 bench.py --gpus 8 --rows 2e7 --steps 1 --warmup 0 --allow-host-exchange > $OUT/bench_8rank_hostexchange.json 2> $OUT/bench_8rank_hostexchange.err; echo "... with --allow-host-exchange rc=$?"; cut -c1-400 $OUT/bench_8rank_hostexchange.json | head -1
+  ;;
+esac
