@@ -348,6 +348,7 @@ def main():
         neighbours[name_] = (cols_, sch_, filt_, aggs_)
     bg = {}
     tail_rows = int(min(verify_rows, 100000000))
+    truth_rows = int(min(verify_rows, 1 << 24))
     tail_row0 = (10000000000 - tail_rows) // 64 * 64
     if want_oracle:
         import oracle  # tests/oracle.py: the CPU restatement -- the reported baseline AND the checker of the GPU results
@@ -356,10 +357,8 @@ def main():
         bg["cfg2"] = Background(oracle.run_synth_filter, syn_lat, seed2, 0, verify_rows, 1024, pred2)
         bg["cfg3"] = Background(oracle.run_synth_query, syn, seed, 0, verify_rows, 1024, None, [Column(0)], [sum_v])
         bg["cfg5"] = Background(oracle.run_synth_query, syn5, seed, 0, verify_rows, 1024, pred5, [Column(0), Column(1)], aggs5 + [count_qty])
-        # ... and the EXACT sums of its first truth_rows rows (integer arithmetic, tests/oracle.py: ExactGroupSums): what the device's own
-        # slice result is held to within (sqrt(n) + 8) ULP -- tighter than any comparison with another rounded sum
-        truth_rows = int(min(verify_rows, 1 << 25))
-        bg["cfg5_truth"] = Background(oracle.exact_sums_q1, syn5, seed, 0, truth_rows)
+        # (the EXACT sums of its first truth_rows rows -- integer arithmetic, tests/oracle.py: exact_sums_q1 -- are numpy code that holds
+        # the interpreter lock: computed where they are used, not on a thread beside the timed legs)
         if args.rows_1e10_steps > 0 and n_rows < 10000000000:
             # the LAST verify_rows rows of the 10^10-row table (row indices beyond 2^32: rows 9.9e9 ...): the same generator, seed and rows
             bg["rows_1e10_tail"] = Background(oracle.run_synth_query, syn, seed, tail_row0, 10000000000 - tail_row0, 1024, pred, [Column(0)], [sum_v])
@@ -390,12 +389,12 @@ def main():
                     # the whole step (every kernel, the host side, the result on the host) against the same peak
                     "end_to_end_GBps": round(e2e_gbps, 1), "end_to_end_frac": round(e2e_gbps / HBM_PEAK_GBPS, 4)}
 
-    # HBM traffic of the dominant kernel: rocprofv3 PMC passes over the same query (tools/gpu_profile_r4.sh ->
-    # profiles/r04_partition_counters.json; FETCH_SIZE and WRITE_SIZE collected in SEPARATE passes; FETCH_SIZE doubled as
+    # HBM traffic of the dominant kernel: rocprofv3 PMC passes over the same query (tools/gpu_round.sh profile ->
+    # profiles/r05_partition_counters.json; FETCH_SIZE and WRITE_SIZE collected in SEPARATE passes; FETCH_SIZE doubled as
     # MI355X_MICROARCH.md prescribes for gfx950 -- doubled it equals the table bytes read, the calibration point).  It is a
     # committed measurement of this kernel, not something this run collected; null if the file is absent.
     if roofline is not None:
-        for fname in ("r04_partition_counters.json", "r03_partition_counters.json", "r02_partition_counters.json"):
+        for fname in ("r05_partition_counters.json", "r04_partition_counters.json", "r03_partition_counters.json", "r02_partition_counters.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", fname)) as f:
                     ctr = json.load(f)
@@ -794,7 +793,7 @@ def main():
             # the truth column: the same query over the first truth_rows rows against the EXACT sums of those rows
             worst_exact, ref_exact = 0.0, 0.0
             try:
-                truth, tcount = bg["cfg5_truth"].get()
+                truth, tcount = oracle.exact_sums_q1(syn5, seed, 0, truth_rows)
                 t_t = ex.DeviceTable.synth(syn5, seed, 0, truth_rows)
                 got_t = build_on(t_t, schema5, pred5, [Column(0), Column(1)], aggs5).next()
                 gt = by_key(got_t, 2)

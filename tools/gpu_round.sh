@@ -7,9 +7,11 @@
 #   dry8     bench.py --gpus 8 as eight processes on this ONE GPU over the host-staged RCCL stand-in (plumbing only), and the
 #            same with DFX_RCCL_LIB pointing at a missing file (must exit non-zero)
 # Summaries land in gpurun_out/<tag>/ -- what is cited is copied to profiles/ by hand.
-STAGE=${1:-bench}; TAG=${2:-r05}
+STAGES=${1:-bench}; TAG=${2:-r05}   # (several stages: comma-separated, run in order)
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp
+for STAGE in ${STAGES//,/ }; do
 cd $R
+echo "==== stage $STAGE"
 case $STAGE in
 suite)
   timeout 2400 python -m pytest tests -m gpu -q --timeout 900 > $OUT/pytest_gpu.log 2>&1; echo "gpu suite rc=$?"; tail -n 8 $OUT/pytest_gpu.log | cut -c1-300
@@ -96,3 +98,4 @@ PY
   timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29520 bench.py --gpus 8 --rows 2e7 --steps 1 --warmup 0 --allow-host-exchange > $OUT/bench_8rank_hostexchange.json 2> $OUT/bench_8rank_hostexchange.err; echo "... with --allow-host-exchange rc=$?"; cut -c1-400 $OUT/bench_8rank_hostexchange.json | head -1
   ;;
 esac
+done
