@@ -960,7 +960,10 @@ Status FilterRelation::next(DeviceBatch* out, bool* has) {
       ctrl_host_ = pinned_alloc(sizeof(uint32_t) * CTRL_WORDS, &st);
       if (!ctrl_host_) return st;
     }
-    DFX_HIP(hipMemcpyAsync(ctrl_host_.get(), ctrl_.get(), sizeof(uint32_t) * CTRL_WORDS, hipMemcpyDeviceToHost, s));
+    // (by a kernel writing the pinned buffer, not by the copy engine: an SDMA device-to-host copy stalls for 6 - 150 ms once in a few
+    // hundred calls on these boxes -- tools/d2h_probe.py -- and this one runs once per batch: round 5's bench lines showed one or the other
+    // of the dense-filter legs a third slower, never the same one)
+    DFX_HIP(launch_copy_to_host(ctrl_.get(), ctrl_host_.get(), sizeof(uint32_t) * CTRL_WORDS, s));
     DFX_HIP(hipStreamSynchronize(s));
     const uint32_t* hc = (const uint32_t*)ctrl_host_.get();
     kept = (uint64_t)hc[CTRL_PASSED_LO] | ((uint64_t)hc[CTRL_PASSED_HI] << 32);
