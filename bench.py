@@ -45,17 +45,38 @@ GROUPS = 1000000
 LO, HI = 204.8, 409.6
 
 
+def host_cpu_budget():
+    """CPUs this process may actually keep busy: the cgroup's quota when there is one (a box that shows 256 cores to
+    os.cpu_count() may grant a container far fewer -- and throttles EVERY thread of the container, the one that drives the GPU
+    included, for the rest of the scheduling period once the quota is spent), else the affinity mask."""
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            return max(1, int(int(quota) / int(period)))
+    except Exception:
+        pass
+    try:
+        return len(os.sched_getaffinity(0))
+    except Exception:
+        return os.cpu_count() or 1
+
+
 class Background:
-    """One oracle query on its own host thread (the C code holds no global state, ctypes releases the GIL)."""
+    """One oracle query on a host thread of its own (the C code holds no global state, ctypes releases the GIL).  At most
+    `Background.slots` of them run at a time -- the others wait their turn -- so that the oracle runs beside the timed GPU
+    legs never use up the container's CPU quota (round 5: with one thread per query, twenty of them, one or another of the
+    host-latency-bound legs came out a third slower in every run, never the same one)."""
+    slots = threading.Semaphore(max(2, min(10, host_cpu_budget() - 3)))
 
     def __init__(self, fn, *args, **kw):
         self.result, self.error = None, None
 
         def run():
-            try:
-                self.result = fn(*args, **kw)
-            except Exception as e:  # reported in the line, never fatal
-                self.error = str(e)[:300]
+            with Background.slots:
+                try:
+                    self.result = fn(*args, **kw)
+                except Exception as e:  # reported in the line, never fatal
+                    self.error = str(e)[:300]
         self.t = threading.Thread(target=run, daemon=True)
         self.t.start()
 
@@ -352,10 +373,11 @@ def main():
     tail_row0 = (10000000000 - tail_rows) // 64 * 64
     if want_oracle:
         import oracle  # tests/oracle.py: the CPU restatement -- the reported baseline AND the checker of the GPU results
-        for name, (cols_, _sch, filt_, aggs_) in neighbours.items():
-            bg[name] = Background(oracle.run_synth_query, cols_, seed, 0, verify_rows, 1024, filt_, [Column(0)], list(aggs_))
+        # (started in the order their results are wanted: at most Background.slots of them run at a time)
         bg["cfg2"] = Background(oracle.run_synth_filter, syn_lat, seed2, 0, verify_rows, 1024, pred2)
         bg["cfg3"] = Background(oracle.run_synth_query, syn, seed, 0, verify_rows, 1024, None, [Column(0)], [sum_v])
+        for name, (cols_, _sch, filt_, aggs_) in neighbours.items():
+            bg[name] = Background(oracle.run_synth_query, cols_, seed, 0, verify_rows, 1024, filt_, [Column(0)], list(aggs_))
         bg["cfg5"] = Background(oracle.run_synth_query, syn5, seed, 0, verify_rows, 1024, pred5, [Column(0), Column(1)], aggs5 + [count_qty])
         # (the EXACT sums of its first truth_rows rows -- integer arithmetic, tests/oracle.py: exact_sums_q1 -- are numpy code that holds
         # the interpreter lock: computed where they are used, not on a thread beside the timed legs)
@@ -884,7 +906,7 @@ def main():
         cpu_baseline = {"value": sample / secs, "unit": "rows/s", "cores": 1, "kind": "port",
                         "sample": f"first {sample} rows of the same table, same query (+ COUNT), 1024-row batches "
                                   f"(reference-shaped C restatement, oracle/dfx_oracle.c), {secs:.2f} s",
-                        "host_cores_available": os.cpu_count()}
+                        "host_cores_available": os.cpu_count(), "host_cpu_budget_of_this_container": host_cpu_budget()}
         # per-group parity at the benchmark's size: the same row slice through the product path (same batch width, same
         # automatic strategy => partitioned), every group compared with the oracle bit for bit (exact distribution)
         try:
