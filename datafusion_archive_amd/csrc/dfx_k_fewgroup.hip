@@ -69,7 +69,7 @@ __global__ __launch_bounds__(kFGBlock) void k_fewgroup_agg(const DevProgram P, c
   uint32_t err = 0;
   uint64_t passed = 0;
   typename POL::PREP prep;  // (PlanPolicy: the plan words in vector registers; empty otherwise)
-  POL::prepare(F, prep);
+  POL::prepare(P, F, prep);
   for (int64_t w0 = wave_global * U; w0 < n_words; w0 += n_waves * U) {
     COLV col[U];
     uint32_t cv[U];

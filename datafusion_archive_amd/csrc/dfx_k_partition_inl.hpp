@@ -108,7 +108,7 @@ __global__ __launch_bounds__(kPBlock) void k_partition(const DevProgram P, const
   uint32_t err = 0;
   uint64_t passed = 0;
   typename POL::PREP prep;  // (PlanPolicy: the plan words in vector registers; empty otherwise)
-  POL::prepare(F, prep);
+  POL::prepare(P, F, prep);
   for (int64_t w0 = wave_global * U; w0 < n_groups; w0 += n_waves * U) {
     COLV col[U];
     uint32_t cv[U];
@@ -349,7 +349,7 @@ __global__ __launch_bounds__(BLOCK) void k_partition_sorted(const DevProgram P, 
   uint32_t err = 0;
   uint64_t passed = 0;
   typename POL::PREP prep;  // (PlanPolicy: the plan words in vector registers; empty otherwise)
-  POL::prepare(F, prep);
+  POL::prepare(P, F, prep);
   for (int64_t w0 = wave_global * U; w0 < n_groups; w0 += n_waves * U) {
     COLV col[U];
     uint32_t cv[U];
@@ -594,7 +594,9 @@ DEV void ring_route(const DevTable& T, const DevPartition& PT, const DevRows& sp
 // Same protocol, same invariants: positions come from the fill atomics (distinct for all 128 rows), a lane may own up to
 // two flush jobs per turn, every job of the wave is executed before anybody retries, so a row that waits for a chunk
 // slot of this wave's own other batch still gets it.
-template <int kRingCH, int kRingRP, int NARROW>
+// KEY_IS_IMG: `key` holds the row's 32-bit hash IMAGE, not its key (the dense split of the wave-specialised kernel: the scanner has
+// hashed the row and turned away what has no image); a row that leaves the routed path gets its key back (unhash_word32)
+template <int kRingCH, int kRingRP, int NARROW, bool KEY_IS_IMG = false>
 DEV void ring_route2(const DevTable& T, const DevPartition& PT, const DevRows& spill, const RingLds& L, uint32_t producer,
                      const bool (&have)[2], const uint64_t (&key)[2], const uint64_t (&val)[2], const uint64_t (&h)[2], uint32_t& err) {
   constexpr int kRingNCH = kRingRP / kRingCH;
@@ -607,7 +609,7 @@ DEV void ring_route2(const DevTable& T, const DevPartition& PT, const DevRows& s
 #pragma unroll
   for (int b = 0; b < 2; ++b) {
     img[b] = (uint32_t)(h[b] >> 32);
-    narrow_ok[b] = !(NARROW && ((key[b] >> 32) != 0 || img[b] >= kTagForeign));
+    narrow_ok[b] = KEY_IS_IMG || !(NARROW && ((key[b] >> 32) != 0 || img[b] >= kTagForeign));
     part[b] = partition_of(T, PT, h[b]);
   }
   {  // both fill atomics in flight together
@@ -630,7 +632,7 @@ DEV void ring_route2(const DevTable& T, const DevPartition& PT, const DevRows& s
 #pragma unroll
   for (int b = 0; b < 2; ++b) {
     if (__ballot(todo[b]) != 0) {  // (rare)
-      uint64_t k1[1] = {key[b]};
+      uint64_t k1[1] = {KEY_IS_IMG ? (uint64_t)unhash_word32(img[b]) : key[b]};
       uint64_t sv[kMaxAggs];
       if (NARROW && (PT.flags & PTF_SHARED)) {
         expand_shared_operand(T, val[b], sv);
@@ -832,7 +834,7 @@ __global__ __launch_bounds__(kRingBlock) void k_partition_ring(const DevProgram 
   // kernel is not short of bytes in flight; the run-to-run spread (+-6 % on one box) is larger than any difference.
   constexpr int kRingDepth = DFX_RING_DEPTH;
   typename POL::PREP prep;  // (PlanPolicy: the plan words in vector registers; empty otherwise)
-  POL::prepare(F, prep);
+  POL::prepare(P, F, prep);
   COLV ncol[kRingDepth][U];
   uint32_t ncv[kRingDepth][U];
 #pragma unroll

@@ -78,7 +78,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) v
   uint32_t err = 0;
   uint64_t passed = 0;  // wave-uniform
   typename POL::PREP prep;
-  POL::prepare(F, prep);
+  POL::prepare(P, F, prep);
   COLV col[U], ncol[U];
   uint32_t cv[U], ncv[U];
   auto store_row = [&](uint32_t part, uint32_t row, uint32_t tag, uint64_t kk, uint64_t val) {

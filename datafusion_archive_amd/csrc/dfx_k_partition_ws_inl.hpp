@@ -133,7 +133,7 @@ __global__ __launch_bounds__(kRingBlock) void k_partition_ws(const DevProgram P,
     // Software pipeline, one trip deep (as in k_partition_ring: deeper was measured no faster).
     {
       typename POL::PREP prep;  // (PlanPolicy: the plan words in vector registers; empty otherwise)
-      POL::prepare(F, prep);
+      POL::prepare(P, F, prep);
       COLV ncol[U];
       uint32_t ncv[U];
       load_trip<POL>(P, C, wave_global * U, wave_global * U < n_groups, n, lane, ncol, ncv);
@@ -167,7 +167,15 @@ __global__ __launch_bounds__(kRingBlock) void k_partition_ws(const DevProgram P,
             POL::arg(P, F, plan.arg[0], 0, cur, curv, reg, rv, v, valid);
             const uint64_t val = transform_value(POL::xform(T, 0), v, valid);
             passed += (uint64_t)__popcll(pm);
-            const uint64_t sm = pm & __ballot((key >> 32) != 0);  // no 32-bit form (wide key, or the claim sentinel)
+            // dense split (QPS > 1): the SCANNERS hash -- four waves with little else to do, while the twelve routers' chain of
+            // LDS round trips is what bounds the launch -- and the queue carries the row's 32-bit image instead of its key
+            uint32_t qword = (uint32_t)key;
+            uint64_t sm = pm & __ballot((key >> 32) != 0);  // no 32-bit form (wide key, or the claim sentinel)
+            if constexpr (QPS > 1) {
+              uint64_t k1[1] = {key};
+              qword = (uint32_t)(hash_keys<1>(k1) >> 32);
+              sm |= pm & __ballot(qword >= kTagForeign);  // ... or one of the two reserved images
+            }
             if (sm != 0) {
               ws_slow_rows(T, spill, lane_of_mask(sm), key, val);
               pm &= ~sm;
@@ -197,7 +205,7 @@ __global__ __launch_bounds__(kRingBlock) void k_partition_ws(const DevProgram P,
               }
               if (lane_of_mask(pm)) {
                 const uint32_t at = (tail + mbcnt64(pm)) & (uint32_t)(kWsQueueRows - 1);
-                qk[at] = (uint32_t)key;
+                qk[at] = qword;
                 qv[at] = val;
               }
               tail += c;
@@ -265,10 +273,14 @@ __global__ __launch_bounds__(kRingBlock) void k_partition_ws(const DevProgram P,
       if (lane == 0) __hip_atomic_store(&sc->head, head + take, __ATOMIC_RELEASE, WG_SCOPE);
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
-        uint64_t k1[1] = {k2[b]};
-        h2[b] = hash_keys<1>(k1);
+        if constexpr (QPS > 1) {
+          h2[b] = k2[b] << 32;  // (the queue word IS the image)
+        } else {
+          uint64_t k1[1] = {k2[b]};
+          h2[b] = hash_keys<1>(k1);
+        }
       }
-      ring_route2<kWsCH, kWsRP, 1>(T, PT, spill, L, producer, have, k2, v2, h2, err);
+      ring_route2<kWsCH, kWsRP, 1, (QPS > 1)>(T, PT, spill, L, producer, have, k2, v2, h2, err);
     }
   }
   __syncthreads();

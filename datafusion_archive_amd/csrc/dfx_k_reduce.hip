@@ -35,7 +35,7 @@ __global__ __launch_bounds__(kBlock) void k_reduce(const DevProgram P, const Dev
   uint32_t err = 0;
   uint64_t passed = 0;
   typename POL::PREP prep;  // (PlanPolicy: the plan words in vector registers; empty otherwise)
-  POL::prepare(F, prep);
+  POL::prepare(P, F, prep);
   // the scan loop once per comparison FORM (StaticPolicy::pass_form: the operators as compile-time constants; 0: run-time masks)
   auto scan = [&](auto form_tag) {
   constexpr int FORM = decltype(form_tag)::value;

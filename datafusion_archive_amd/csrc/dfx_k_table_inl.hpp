@@ -44,7 +44,7 @@ __global__ __launch_bounds__(kBlock) void k_hash_agg(const DevProgram P, const D
   int iter = 0;
   bool saturated = false;
   typename POL::PREP prep;  // (PlanPolicy: the plan words in vector registers; empty otherwise)
-  POL::prepare(F, prep);
+  POL::prepare(P, F, prep);
   for (int64_t w0 = wave_global * U; w0 < n_words; w0 += n_waves * U, ++iter) {
     if ((iter & 7) == 0) {  // wave-uniform, one request: has the table passed its load limit?
       saturated = __hip_atomic_load(&T.ctrl[CTRL_SATURATED], RLX_AGENT) != 0u;

@@ -209,16 +209,22 @@ DEV void load_columns(const DevProgram& P, const DevColumns& C, int64_t row, boo
   }
 }
 
-template <typename COLV>
+// (Round 5 also tried the program itself in vector registers -- lane j holding SSA instruction j and literal j, decoded with
+// v_readlane instead of scalar loads from the kernel arguments: 1.74 ms per 2^27-row launch of the headline through the interpreter
+// against 1.63 without; the three registers it takes push the ring kernel's allocation over its 128, and the scalar loads were not
+// what the waves waited for.  profiles/r05_interpreter_counters.txt)
+// NULLS == false: the batch's referenced columns carry no nulls (DevProgram::has_nulls, decided at bind time) -- every operand is
+// valid, and `valid` is a compile-time constant for the code around the call
+template <typename COLV, bool NULLS = true>
 DEV void fetch(const DevProgram& P, ROWSTATE_CPARAMS, uint8_t opnd, uint64_t& v, bool& valid) {
   const int idx = opnd & 63;
   const int kind = opnd >> 6;
   if (kind == OPK_REG) {
     v = s_reg[idx];
-    valid = (s_regvalid >> idx) & 1;
+    valid = NULLS ? ((s_regvalid >> idx) & 1) : true;
   } else if (kind == OPK_COL) {
     v = s_col[idx & (int)(sizeof(COLV) / 8 - 1)];
-    valid = (s_colvalid >> idx) & 1;
+    valid = NULLS ? ((s_colvalid >> idx) & 1) : true;
   } else {
     v = P.imm[idx & (kMaxImm - 1)];
     valid = true;
@@ -227,16 +233,18 @@ DEV void fetch(const DevProgram& P, ROWSTATE_CPARAMS, uint8_t opnd, uint64_t& v,
 
 // Executes the SSA program for one row.  Semantics per op are arrow 0.12 array_ops, the same
 // table the oracle restates (oracle/dfx_oracle.c: compare_arrays / boolean_arrays / math_arrays).
-template <typename COLV>
-DEV void run_program(const DevProgram& P, ROWSTATE_PARAMS, bool active, uint32_t& err) {
-  s_regvalid = 0;
+// NULLS == false (round 5): with every operand valid the per-lane validity booleans -- and the divergent control flow the compiler
+// builds around `if (vx && vy)` for arrow's null rules, lane masks saved and restored per SSA instruction -- fold away.
+template <typename COLV, bool NULLS>
+DEV void run_program_impl(const DevProgram& P, ROWSTATE_PARAMS, bool active, uint32_t& err) {
+  s_regvalid = NULLS ? 0u : 0xFFFFFFFFu;
   for (int pc = 0; pc < P.n_ins; ++pc) {
     const DevIns in = P.ins[pc];
     const uint8_t t = in.t;
     uint64_t x, y = 0;
     bool vx, vy = true;
-    fetch(P, ROWSTATE_ARGS(s), in.a, x, vx);
-    if (in.op != DOP_CAST) fetch(P, ROWSTATE_ARGS(s), in.b, y, vy);
+    fetch<COLV, NULLS>(P, ROWSTATE_ARGS(s), in.a, x, vx);
+    if (in.op != DOP_CAST) fetch<COLV, NULLS>(P, ROWSTATE_ARGS(s), in.b, y, vy);
     uint64_t res = 0;
     bool v = vx && vy;
     if (in.op <= DOP_GE) {
@@ -336,9 +344,15 @@ DEV void run_program(const DevProgram& P, ROWSTATE_PARAMS, bool active, uint32_t
     // a null result slot holds zero: arrow 0.12's builders append_null() over zero-initialised buffers, and the grouped
     // aggregates read value(row) of their argument WITHOUT a null check (aggregate.rs:561-603), so the slot's content
     // is observable (MAX(x + x) over a null x sees 0, not raw + raw)
-    s_reg[pc] = v ? res : 0ull;
-    s_regvalid |= (v ? 1u : 0u) << pc;
+    s_reg[pc] = (!NULLS || v) ? res : 0ull;
+    if (NULLS) s_regvalid |= (v ? 1u : 0u) << pc;
   }
+}
+
+template <typename COLV>
+DEV void run_program(const DevProgram& P, ROWSTATE_PARAMS, bool active, uint32_t& err) {
+  if (P.has_nulls) run_program_impl<COLV, true>(P, ROWSTATE_ARGS(s), active, err);  // (wave-uniform: a property of the batch)
+  else run_program_impl<COLV, false>(P, ROWSTATE_ARGS(s), active, err);
 }
 
 template <typename COLV>
@@ -377,7 +391,7 @@ struct InterpPolicy {
   static constexpr bool kIsStatic = false;
   static constexpr bool kHasTripLoad = false;
   struct PREP {};  // per-wave state prepared before the scan loop (PlanPolicy: the plan words in vector registers)
-  static DEV void prepare(const DevFastPlan&, PREP&) {}
+  static DEV void prepare(const DevProgram&, const DevFastPlan&, PREP&) {}
   static constexpr int kPredTerms = -1;  // (run-time)
   static constexpr int U = U_;
   static constexpr int kStaticNa = 0;  // aggregates known at compile time (0: run-time)
@@ -462,7 +476,7 @@ struct FastPolicy {
   static constexpr bool kIsStatic = false;
   static constexpr bool kHasTripLoad = false;
   struct PREP {};
-  static DEV void prepare(const DevFastPlan&, PREP&) {}
+  static DEV void prepare(const DevProgram&, const DevFastPlan&, PREP&) {}
   static constexpr int kPredTerms = -1;  // (run-time)
   static constexpr int U = U_;
   static constexpr int kStaticNa = 0;  // aggregates known at compile time (0: run-time)
@@ -545,7 +559,7 @@ struct StaticPolicy {
   static constexpr bool kIsStatic = true;
   static constexpr bool kHasTripLoad = true;
   struct PREP {};
-  static DEV void prepare(const DevFastPlan&, PREP&) {}
+  static DEV void prepare(const DevProgram&, const DevFastPlan&, PREP&) {}
   static constexpr int kPredTerms = SIG::NP;  // 0: the signature has no predicate (every in-range row passes)
   static constexpr int U = U_;
   static constexpr int kStaticNa = SIG::NA;
@@ -779,7 +793,7 @@ struct PlanPolicy {
     uint32_t vshift[NULLS ? NCOL : 1];  // NULLS: (lane + bit_offset) & 7: the row's bit inside its validity byte
     uint32_t vlane[NULLS ? NCOL : 1];   //        ((lane + bit_offset) >> 3) * 4: ds_bpermute address of the row's byte in group 0 of a trip
   };
-  static DEV void prepare(const DevFastPlan& F, PREP& W) {
+  static DEV void prepare(const DevProgram&, const DevFastPlan& F, PREP& W) {
 #pragma unroll
     for (int t = 0; t < kPlanTerms; ++t) {
       const DevPlanTerm& T = F.scan.term[t];
@@ -893,7 +907,7 @@ struct PlanPolicy {
   static DEV void eval(const DevProgram& P, const DevFastPlan& F, const COLV& cur, uint32_t curv, u64x16& reg, uint32_t& rv, bool inb,
                        uint32_t& err) {
     PREP W;
-    prepare(F, W);
+    prepare(P, F, W);
     eval(P, F, cur, curv, reg, rv, inb, err, W);
   }
   static DEV void eval(const DevProgram&, const DevFastPlan& F, const COLV& cur, uint32_t curv, u64x16& reg, uint32_t& rv, bool,
