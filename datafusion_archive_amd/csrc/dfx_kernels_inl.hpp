@@ -154,6 +154,35 @@ DEV uint64_t cast_value(uint8_t from, uint8_t to, uint64_t v) {
   }
 }
 
+// ... and its casts (the projection kernels inline cast_value; the interpreter's loop calls it)
+__device__ __attribute__((noinline)) uint64_t cast_value_call(uint8_t from, uint8_t to, uint64_t v) { return cast_value(from, to, v); }
+
+// integer Divide of the interpreter (arrow 0.12 array_ops::divide: DivideByZero; Rust's `/`: overflow panic).  Out of line: 64-bit
+// integer division expands to ~150 instructions and a dozen live registers, which the interpreter's loop would carry in every path
+struct IntDivResult {
+  uint64_t value;
+  uint32_t err;  // error bits to OR into the kernel's (returned by value: an `err` passed by reference would live in scratch memory)
+};
+__device__ __attribute__((noinline)) IntDivResult int_divide(uint8_t t, uint64_t x, uint64_t y, bool report) {
+  IntDivResult r = {0, 0};
+  if (y == 0) {
+    if (report) r.err = 1u;
+    return r;
+  }
+  if (is_signed_int(t)) {
+    const uint64_t mn = wrap_to(t, 1ull << (t == T_I8 ? 7 : t == T_I16 ? 15 : t == T_I32 ? 31 : 63));
+    if ((int64_t)y == -1 && x == mn) {
+      if (report) r.err = 2u;
+      r.value = x;
+      return r;
+    }
+    r.value = (uint64_t)((int64_t)x / (int64_t)y);
+    return r;
+  }
+  r.value = x / y;
+  return r;
+}
+
 // ---------------------------------------------------------------------------------------------
 // the per-row expression interpreter
 // ---------------------------------------------------------------------------------------------
@@ -288,7 +317,7 @@ DEV void run_program_impl(const DevProgram& P, ROWSTATE_PARAMS, bool active, uin
     } else if (in.op == DOP_OR) {
       res = (x | y) & 1;
     } else if (in.op == DOP_CAST) {
-      res = cast_value(t, in.b, x);
+      res = cast_value_call(t, in.b, x);
       v = vx;
     } else if (t == T_F64) {
       const double a = as_f64(x), b = as_f64(y);
@@ -322,22 +351,12 @@ DEV void run_program_impl(const DevProgram& P, ROWSTATE_PARAMS, bool active, uin
         case DOP_ADD: o = x + y; break;
         case DOP_SUB: o = x - y; break;
         case DOP_MUL: o = x * y; break;
-        default:
-          if (y == 0) {
-            if (v && active) err |= 1u;
-            o = 0;
-          } else if (is_signed_int(t)) {
-            const uint64_t mn = wrap_to(t, 1ull << (t == T_I8 ? 7 : t == T_I16 ? 15 : t == T_I32 ? 31 : 63));
-            if ((int64_t)y == -1 && x == mn) {
-              if (v && active) err |= 2u;
-              o = x;
-            } else {
-              o = (uint64_t)((int64_t)x / (int64_t)y);
-            }
-          } else {
-            o = x / y;
-          }
+        default: {
+          const IntDivResult dr = int_divide(t, x, y, v && active);
+          o = dr.value;
+          err |= dr.err;
           break;
+        }
       }
       res = wrap_to(t, o);
     }
@@ -435,6 +454,16 @@ struct InterpPolicy {
                       const u64x16& reg, uint32_t rv, uint64_t& v, bool& valid) {
     fetch(P, cur, reg, curv, rv, opnd, v, valid);
   }
+};
+
+// the interpreter for kernels that route ONE value per row (the narrow-row flavours of the partitioned pass 1): as FastPolicy1 --
+// with the aggregate count a compile-time 1 the eight-wide value arrays of the routing code (16 VGPRs per row group, twice) drop
+// out.  Round 5: the narrow ring kernel ran the interpreter at 128 VGPRs with 12 of them spilled to scratch -- and every scratch
+// reload waits for the column loads in flight as well (one in-order counter)
+template <int BANK, int U_>
+struct InterpPolicy1 : InterpPolicy<BANK, U_> {
+  static constexpr int kStaticNa = 1;
+  static DEV int na(const DevTable&) { return 1; }
 };
 
 // three-way compare code of two canonical values of dtype t: 1 less, 2 equal, 4 greater, 0 unordered
