@@ -207,12 +207,13 @@ Status CsvRelation::next(DeviceBatch* out, bool* has) {
   memset(&plan, 0, sizeof(plan));
   plan.n_cols = nc;
   plan.expected_fields = expected_fields_;
-  auto ctrl = device_alloc(sizeof(uint64_t) * (size_t)(nc + 1), &st);
+  auto ctrl = device_alloc(sizeof(uint64_t) * (size_t)(nc + 2), &st);  // null counts, the first error, general-path tiles
   if (!ctrl) return st;
-  DFX_HIP(hipMemsetAsync(ctrl.get(), 0, sizeof(uint64_t) * (size_t)nc, s));
+  DFX_HIP(hipMemsetAsync(ctrl.get(), 0, sizeof(uint64_t) * (size_t)(nc + 2), s));
   DFX_HIP(hipMemsetAsync((uint64_t*)ctrl.get() + nc, 0xFF, sizeof(uint64_t), s));
   plan.null_counts = (uint64_t*)ctrl.get();
   plan.err = (uint64_t*)ctrl.get() + nc;
+  plan.general_tiles = (uint64_t*)ctrl.get() + nc + 1;
   const size_t words = (size_t)(nb + 63) / 64;
   out->num_rows = nb;
   out->columns.clear();
@@ -249,10 +250,13 @@ Status CsvRelation::next(DeviceBatch* out, bool* has) {
   }
   const uint8_t* buf = (const uint8_t*)text_.get();
   const uint64_t* rs = (const uint64_t*)row_start_.get();
-  DFX_HIP(launch_csv_parse(buf, rs, next_record_, nb, plan, 0.0, s));
-  std::vector<uint64_t> hc((size_t)nc + 1);
+  const double avg_record = n_records_ > 0 ? (double)n_bytes_ / (double)n_records_ : 0.0;
+  DFX_HIP(launch_csv_parse(buf, rs, next_record_, nb, plan, avg_record, agg_options().csv_wave_tiles, 0.0, s));
+  std::vector<uint64_t> hc((size_t)nc + 2);
   DFX_HIP(hipMemcpyAsync(hc.data(), ctrl.get(), sizeof(uint64_t) * hc.size(), hipMemcpyDeviceToHost, s));
   DFX_HIP(hipStreamSynchronize(s));
+  counters().csv_tiles += (nb + 63) / 64;
+  counters().csv_general_tiles += (long long)hc[(size_t)nc + 1];
   if (hc[(size_t)nc] != ~0ull) return cell_error(hc[(size_t)nc]);
   for (int c = 0; c < nc; ++c) {
     DeviceColumn& col = out->columns[c];

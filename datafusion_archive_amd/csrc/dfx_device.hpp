@@ -329,6 +329,7 @@ struct DevCsvPlan {
   int32_t n_cols;            // schema columns (cells beyond are ignored)
   uint32_t expected_fields;  // fields of the first record: every record must have as many (csv crate, flexible = false)
   uint64_t* null_counts;     // [n_cols]
+  uint64_t* general_tiles;   // tiles that took the per-lane walk (a counter)
   uint64_t* err;             // min over failing cells of (record << 16 | column << 8 | code); ~0: none
   DevCsvCol col[kCsvMaxCols];
 };

@@ -116,6 +116,8 @@ struct Counters {
   long long filter_output_regrows = 0;      // single-pass FilterRelation: batches that kept more rows than their output buffers were sized for
   long long filter_lookback_fallbacks = 0;  // ... batches redone in two passes because the look-back gave up waiting (a shared GPU)  // ... of which through the pinned staging ring (HostStreamOptions::mode 1)
   long long csv_cells = 0;  // cells converted by the CSV source
+  long long csv_tiles = 0;          // 64-record tiles the CSV cell kernel converted ...
+  long long csv_general_tiles = 0;  // ... of them through the per-lane walk (quotes, ragged records, a tile longer than the LDS window)
   // host-side time accounting of the aggregate (microseconds; tools/kprobe.py): where a query's wall time goes beyond its kernels
   long long agg_ctrl_wait_us = 0;   // blocked on control-block snapshots (one batch behind the launches)
   long long agg_sync_us = 0;        // other synchronous read-backs (calibration, growth, end of input)

@@ -99,7 +99,8 @@ DEV uint32_t csv_chunk_starts(const CsvChunk& c, uint32_t s) {
   return starts;
 }
 
-// exclusive scan of the transition vectors of a 256-thread block; returns the prefix of this thread and the total
+// exclusive scan of the transition vectors of a BLOCK-thread workgroup; returns the prefix of this thread and the total
+template <int BLOCK = kCsvBlock>
 DEV uint32_t csv_block_scan(uint32_t v, uint32_t* lds_wave_tot, uint32_t* total) {
   const int lane = lane_id();
   const int wave = threadIdx.x >> 6;
@@ -115,7 +116,7 @@ DEV uint32_t csv_block_scan(uint32_t v, uint32_t* lds_wave_tot, uint32_t* total)
   if (lane == 0) excl = kCsvTvId;
   uint32_t pre = kCsvTvId, tot = kCsvTvId;
 #pragma unroll
-  for (int w = 0; w < kCsvBlock / 64; ++w) {
+  for (int w = 0; w < BLOCK / 64; ++w) {
     if (w < wave) pre = csv_tv_compose(pre, lds_wave_tot[w]);
     tot = csv_tv_compose(tot, lds_wave_tot[w]);
   }
@@ -134,30 +135,41 @@ __global__ __launch_bounds__(kCsvBlock) void k_csv_tile_trans(const uint8_t* __r
   if (threadIdx.x == 0) tile_trans[blockIdx.x] = total;
 }
 
-// one workgroup: state at the start of every tile (the file starts in StartRecord)
+// one workgroup: state at the start of every tile (the file starts in StartRecord).  Every thread owns a contiguous run of
+// tiles; it reads them eight at a time (independent loads in flight, then eight compositions), the 1024 run totals are scanned
+// with wave shuffles, and a second walk over the run writes the states.
 __global__ __launch_bounds__(1024) void k_csv_tile_scan(const uint32_t* __restrict__ tile_trans, int64_t n_tiles,
                                                          uint8_t* __restrict__ tile_state) {
-  __shared__ uint32_t part[1024];
-  const int64_t per = (n_tiles + 1023) / 1024;
+  __shared__ uint32_t wave_tot[16];
+  const int64_t per = ((n_tiles + 1023) / 1024 + 7) & ~7ll;
   const int64_t t0 = (int64_t)threadIdx.x * per;
   const int64_t t1 = t0 + per < n_tiles ? t0 + per : n_tiles;
   uint32_t v = kCsvTvId;
-  for (int64_t t = t0; t < t1; ++t) v = csv_tv_compose(v, tile_trans[t]);
-  part[threadIdx.x] = v;
-  __syncthreads();
-  if (threadIdx.x == 0) {  // 1024 sequential compositions: ~10 us
-    uint32_t acc = kCsvTvId;
-    for (int i = 0; i < 1024; ++i) {
-      const uint32_t x = part[i];
-      part[i] = acc;
-      acc = csv_tv_compose(acc, x);
-    }
+  for (int64_t t = t0; t < t1; t += 8) {
+    uint32_t x[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = t + j < t1 ? tile_trans[t + j] : kCsvTvId;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v = csv_tv_compose(v, x[j]);
   }
-  __syncthreads();
-  uint32_t s = csv_tv_apply(part[threadIdx.x], 0u);
-  for (int64_t t = t0; t < t1; ++t) {
-    tile_state[t] = (uint8_t)s;
-    s = csv_tv_apply(tile_trans[t], s);
+  uint32_t total;
+  const uint32_t pre = csv_block_scan<1024>(v, wave_tot, &total);
+  uint32_t s = csv_tv_apply(pre, 0u);
+  for (int64_t t = t0; t < t1; t += 8) {
+    uint32_t x[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = t + j < t1 ? tile_trans[t + j] : kCsvTvId;
+    uint64_t out = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      out |= (uint64_t)s << (8 * j);
+      s = csv_tv_apply(x[j], s);
+    }
+    if (t + 8 <= t1) {
+      *(uint64_t*)(tile_state + t) = out;  // t0 is a multiple of 8: aligned
+    } else {
+      for (int j = 0; t + j < t1; ++j) tile_state[t + j] = (uint8_t)(out >> (8 * j));
+    }
   }
 }
 
@@ -222,46 +234,47 @@ __global__ void k_csv_count_fields(const uint8_t* __restrict__ buf, const uint64
   out[0] = (uint32_t)csv_walk_record(buf, row_start[row], row_start[row + 1], [](int, const CsvField&) {});
 }
 
-// Two phases, so that the expensive part runs convergently:
-//   A  every lane walks its record once and only RECORDS where its cells are (LDS: content offset + length/flags per
-//      column) -- lanes reach their cell ends at different bytes, but the walk itself is a few instructions per byte;
-//   B  a wave-uniform loop over the columns: all 64 lanes convert the cell of the SAME column together (one dtype,
-//      one code path).  Converting inside the walk ran the conversions one lane at a time (measured 6.7x slower).
-__global__ __launch_bounds__(kBlock) void k_csv_parse(const uint8_t* __restrict__ buf,
-                                                     const uint64_t* __restrict__ row_start, int64_t r0, int64_t nb,
-                                                     const DevCsvPlan plan) {
-  extern __shared__ uint32_t cell_lds[];  // [n_cols][kBlock] content offset, then [n_cols][kBlock] ulen | quoted << 30 | complex << 31
-  uint32_t* cell_off = cell_lds;
-  uint32_t* cell_len = cell_lds + (size_t)plan.n_cols * kBlock;
-  const int64_t tid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  const bool inb = tid < nb;
+// ---- k_csv_parse: one wave per tile of 64 consecutive records ---------------------------------------------
+// The records of a tile are contiguous text [row_start[first], row_start[first + 64]).  The wave-cooperative path
+// (every tile whose text has no quote, fits the wave's LDS window and has the header's field count in every record):
+//   A  the wave copies the tile's text into LDS with coalesced 16-byte loads; on the way every lane turns its 16 bytes
+//      into SWAR masks (',' / terminator / '"'), a wave prefix sum of the popcounts numbers the STRUCTURAL bytes
+//      (delimiters, and the first terminator after a record's last cell) and their offsets go to an LDS list.  With
+//      `expected_fields` = F, record i owns list entries [i F, (i + 1) F): F - 1 delimiters and one record end.  A lane
+//      checks exactly that for its record; one failing lane sends the tile down the general path below.
+//   B  a wave-uniform loop over the columns: all 64 lanes convert the cell of the SAME column together (one dtype, one
+//      code path), reading its bytes from LDS.
+// The general path (quotes, a tile longer than the window, a record with another field count -- which is the error the
+// reference reports): every lane walks its own record once from global memory and only RECORDS where its cells are
+// (LDS: content offset + length / flags per column), then phase B runs on those, reading global memory.  Converting
+// inside the walk ran the conversions one lane at a time (measured 6.7x slower, round 1).
+constexpr int kCsvTextCapMax = 16384;  // list entries are 15-bit offsets into the window
+
+DEV uint32_t csv_eq_mask16(const uint4& v, uint32_t c4) {
+  return csv_eq_nibble(v.x, c4) | (csv_eq_nibble(v.y, c4) << 4) | (csv_eq_nibble(v.z, c4) << 8) | (csv_eq_nibble(v.w, c4) << 12);
+}
+
+// phase B.  FAST: cells come from the structural list, bytes from the LDS window; else from cell_off / cell_len + global memory
+template <bool FAST>
+DEV void csv_convert_cells(const uint8_t* __restrict__ buf, const DevCsvPlan& plan, int64_t r0, int64_t nb, int64_t tid,
+                           bool inb, int nf, uint64_t begin, uint32_t first_off, const uint8_t* text, const uint16_t* spos,
+                           const uint32_t* cell_off, const uint32_t* cell_len, uint64_t& err) {
   const int lane = lane_id();
-  uint64_t err = ~0ull;
-  uint64_t begin = 0;
-  int nf = 0;
-  if (inb) {
-    begin = row_start[r0 + tid];
-    const uint64_t limit = row_start[r0 + tid + 1];
-    const int n_cols = plan.n_cols;
-    nf = csv_walk_record(buf, begin, limit, [&](int fi, const CsvField& f) {
-      if (fi >= n_cols) return;
-      uint64_t cb, ce;
-      csv_field_span(f, &cb, &ce);
-      (void)ce;
-      cell_off[fi * kBlock + threadIdx.x] = (uint32_t)(cb - begin);
-      cell_len[fi * kBlock + threadIdx.x] = (f.ulen & 0x3FFFFFFFu) | (f.quoted ? 0x40000000u : 0u) | (f.complex ? 0x80000000u : 0u);
-    });
-    if ((uint32_t)nf != plan.expected_fields) {  // csv crate, flexible == false: UnequalLengths
-      const uint64_t e = csv_err_pack(3, 0, r0 + tid);
-      err = e < err ? e : err;
-    }
-  }
+  const uint32_t F = plan.expected_fields;
   for (int c = 0; c < plan.n_cols; ++c) {  // wave-uniform: one column, one dtype for all lanes
     const DevCsvCol col = plan.col[c];
     if (col.dtype == T_NONE) continue;  // projection push-down: nobody reads this column
-    const bool have = inb && c < nf;  // a record shorter than the schema: `rows[i].get(col)` is None
-    const uint32_t off = have ? cell_off[c * kBlock + threadIdx.x] : 0u;
-    const uint32_t lw = have ? cell_len[c * kBlock + threadIdx.x] : 0u;
+    const bool have = inb && c < nf;    // a record shorter than the schema: `rows[i].get(col)` is None
+    uint32_t off = 0, lw = 0;
+    if (have) {
+      if (FAST) {
+        off = c == 0 ? first_off : (uint32_t)(spos[(uint32_t)lane * F + (uint32_t)c - 1u] & 0x7FFFu) + 1u;
+        lw = (uint32_t)(spos[(uint32_t)lane * F + (uint32_t)c] & 0x7FFFu) - off;
+      } else {
+        off = cell_off[c * 64 + lane];
+        lw = cell_len[c * 64 + lane];
+      }
+    }
     const uint32_t ulen = lw & 0x3FFFFFFFu;
     if (col.dtype == T_UTF8) {  // Some(s) => append_string(s): never null ("" when the record is short)
       if (inb) col.lens[tid] = (int32_t)ulen;
@@ -272,19 +285,19 @@ __global__ __launch_bounds__(kBlock) void k_csv_parse(const uint8_t* __restrict_
     if (have && ulen != 0) {  // `Some(s) if s.len() > 0` else append_null
       // a number cannot contain a quote: "12"3 (-> 123 in the csv crate) is rejected here
       int rc = (lw & 0x80000000u) ? NP_INVALID : NP_OK;
-      const uint8_t* s = buf + begin + off;
+      const uint8_t* s = FAST ? text + off : buf + begin + off;
       const int64_t sl = (int64_t)ulen;  // contiguous content: its length is the unescaped length
       if (rc == NP_OK) {
         switch (col.dtype) {
           case T_F64: {
             double d = 0;
-            rc = np_parse_f64(s, sl, &d);
+            rc = FAST ? np_parse_f64_w(s, sl, &d) : np_parse_f64(s, sl, &d);  // the window may be read 8 bytes past a cell
             ((double*)col.values)[tid] = d;
             break;
           }
           case T_F32: {
             float d = 0;
-            rc = np_parse_f32(s, sl, &d);
+            rc = FAST ? np_parse_f32_w(s, sl, &d) : np_parse_f32(s, sl, &d);
             ((float*)col.values)[tid] = d;
             break;
           }
@@ -297,7 +310,7 @@ __global__ __launch_bounds__(kBlock) void k_csv_parse(const uint8_t* __restrict_
             uint64_t v = 0;
             const int bits = (col.dtype == T_I8 || col.dtype == T_U8) ? 8 : (col.dtype == T_I16 || col.dtype == T_U16) ? 16
                              : (col.dtype == T_I32 || col.dtype == T_U32) ? 32 : 64;
-            rc = np_parse_int(s, sl, bits, is_signed_int(col.dtype), &v);
+            rc = FAST ? np_parse_int_w(s, sl, bits, is_signed_int(col.dtype), &v) : np_parse_int(s, sl, bits, is_signed_int(col.dtype), &v);
             store_typed(col.dtype, col.values, tid, v);
             break;
           }
@@ -311,18 +324,132 @@ __global__ __launch_bounds__(kBlock) void k_csv_parse(const uint8_t* __restrict_
     }
     if (inb && !valid && col.dtype != T_BOOL) store_typed(col.dtype, col.values, tid, 0ull);
     const uint64_t vm = __ballot(valid);
-    const bool wave_inb = (tid & ~63ll) < nb;  // waves of the last workgroup that lie wholly past nb own no bitmap word
-    if (lane == 0 && wave_inb) {
+    if (lane == 0) {  // lane 0 of a wave that runs this is always a record of the batch
       col.validity[tid >> 6] = vm;
-      const int64_t rows_here = nb - (tid & ~63ll) < 64 ? nb - (tid & ~63ll) : 64;
+      const int64_t rows_here = nb - tid < 64 ? nb - tid : 64;
       const int nulls = (int)rows_here - __popcll(vm);
       if (nulls > 0) atomicAdd((unsigned long long*)&plan.null_counts[c], (unsigned long long)nulls);
     }
     if (col.dtype == T_BOOL) {
       const uint64_t bm = __ballot(valid && bval);
-      if (lane == 0 && wave_inb) ((uint64_t*)col.values)[tid >> 6] = bm;
+      if (lane == 0) ((uint64_t*)col.values)[tid >> 6] = bm;
     }
   }
+}
+
+__global__ __launch_bounds__(kBlock) void k_csv_parse(const uint8_t* __restrict__ buf,
+                                                     const uint64_t* __restrict__ row_start, int64_t r0, int64_t nb,
+                                                     const DevCsvPlan plan, uint32_t text_cap, uint32_t wave_lds) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t csv_lds[];
+  const int lane = lane_id();
+  uint8_t* wl = csv_lds + (size_t)(threadIdx.x >> 6) * wave_lds;  // this wave's room: no workgroup barrier below
+  const int64_t tid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if ((tid & ~63ll) >= nb) return;  // a wave of the last workgroup that lies wholly past nb
+  const bool inb = tid < nb;
+  const int nrec = (int)(nb - (tid & ~63ll) < 64 ? nb - (tid & ~63ll) : 64);
+  uint64_t err = ~0ull;
+  uint64_t begin = 0, limit = 0;
+  if (inb) {
+    begin = row_start[r0 + tid];
+    limit = row_start[r0 + tid + 1];
+  }
+  const uint32_t F = plan.expected_fields;
+  const uint64_t tb = __shfl(begin, 0, 64);
+  const uint64_t te = __shfl(limit, nrec - 1, 64);
+  const uint64_t base = tb & ~15ull;  // the window starts 16-byte aligned
+  const uint64_t span64 = te - base;
+  bool fast = text_cap != 0 && span64 <= (uint64_t)text_cap;
+  if (fast) {
+    uint8_t* text = wl;
+    uint16_t* spos = (uint16_t*)(wl + text_cap);
+    const uint32_t span = (uint32_t)span64;
+    const uint32_t skew = (uint32_t)(tb - base);
+    const uint32_t cap = (uint32_t)nrec * F;
+    uint32_t total = 0;     // structural bytes so far (wave-uniform)
+    uint32_t prev_top = 0;  // was the last byte of the previous 1 KB step a non-terminator
+    bool quote = false;
+    for (uint32_t o = 0; o < span; o += 1024u) {
+      const uint32_t my = o + (uint32_t)lane * 16u;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      uint32_t vm = 0;  // bytes of [tb, te) among my 16
+      if (my < span) {
+        v = *(const uint4*)(buf + base + my);  // the text buffer is padded to a multiple of 64 bytes
+        *(uint4*)(text + my) = v;
+        vm = span - my >= 16u ? 0xFFFFu : (1u << (span - my)) - 1u;
+        if (my < skew) vm &= 0xFFFFu << skew;
+      }
+      const uint32_t mc = csv_eq_mask16(v, 0x2C2C2C2Cu);
+      const uint32_t mt = csv_eq_mask16(v, 0x0A0A0A0Au) | csv_eq_mask16(v, 0x0D0D0D0Du);
+      quote |= (csv_eq_mask16(v, 0x22222222u) & vm) != 0;
+      const uint32_t nt = ~mt & 0xFFFFu;
+      uint32_t before = (uint32_t)__shfl_up((int)(nt >> 15), 1, 64);
+      if (lane == 0) before = prev_top;
+      const uint32_t rend = mt & ((nt << 1) | before);  // a terminator right after a non-terminator ends a record
+      uint32_t sm = (mc | rend) & vm;
+      const uint32_t cnt = (uint32_t)__popc(sm);
+      uint32_t inc = cnt;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t x = (uint32_t)__shfl_up((int)inc, d, 64);
+        if (lane >= d) inc += x;
+      }
+      uint32_t idx = total + inc - cnt;
+      while (sm) {
+        const uint32_t k = (uint32_t)__ffs((int)sm) - 1u;
+        if (idx < cap) spos[idx] = (uint16_t)((my + k) | (((rend >> k) & 1u) << 15));
+        ++idx;
+        sm &= sm - 1u;
+      }
+      total += (uint32_t)__shfl((int)inc, 63, 64);
+      prev_top = (uint32_t)__shfl((int)(nt >> 15), 63, 64);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // the last record of a file that does not end in a terminator ends at the end of the input
+    const uint8_t last = text[span - 1u];
+    if (last != '\n' && last != '\r') {
+      if (lane == 0 && total < cap) spos[total] = (uint16_t)(span | 0x8000u);
+      ++total;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    fast = __ballot(quote) == 0ull && total == cap;
+    if (fast) {
+      bool okv = true;
+      if (inb)
+        for (uint32_t c = 0; c < F; ++c) okv = okv && (uint32_t)(spos[(uint32_t)lane * F + c] >> 15) == (c + 1u == F ? 1u : 0u);
+      fast = __ballot(!okv) == 0ull;
+    }
+    if (fast) {
+      csv_convert_cells<true>(buf, plan, r0, nb, tid, inb, (int)F, begin, (uint32_t)(begin - base), text, spos, nullptr,
+                              nullptr, err);
+      if (err != ~0ull) atomicMin((unsigned long long*)plan.err, (unsigned long long)err);
+      return;
+    }
+    __builtin_amdgcn_wave_barrier();  // the general path reuses the window
+  }
+  if (lane == 0) atomicAdd((unsigned long long*)plan.general_tiles, 1ull);
+  uint32_t* cell_off = (uint32_t*)wl;  // [n_cols][64] content offset, then [n_cols][64] ulen | quoted << 30 | complex << 31
+  uint32_t* cell_len = cell_off + (size_t)plan.n_cols * 64;
+  int nf = 0;
+  if (inb) {
+    const int n_cols = plan.n_cols;
+    nf = csv_walk_record(buf, begin, limit, [&](int fi, const CsvField& f) {
+      if (fi >= n_cols) return;
+      uint64_t cb, ce;
+      csv_field_span(f, &cb, &ce);
+      (void)ce;
+      cell_off[fi * 64 + lane] = (uint32_t)(cb - begin);
+      cell_len[fi * 64 + lane] = (f.ulen & 0x3FFFFFFFu) | (f.quoted ? 0x40000000u : 0u) | (f.complex ? 0x80000000u : 0u);
+    });
+    if ((uint32_t)nf != F) {  // csv crate, flexible == false: UnequalLengths
+      const uint64_t e = csv_err_pack(3, 0, r0 + tid);
+      err = e < err ? e : err;
+    }
+  }
+  csv_convert_cells<false>(buf, plan, r0, nb, tid, inb, nf, begin, 0u, nullptr, nullptr, cell_off, cell_len, err);
   if (err != ~0ull) atomicMin((unsigned long long*)plan.err, (unsigned long long)err);
 }
 
@@ -370,13 +497,28 @@ hipError_t launch_csv_count_fields(const uint8_t* buf, const uint64_t* row_start
   return hipGetLastError();
 }
 
+// per-wave LDS of k_csv_parse: the text window (1.5 x the average tile, 2..16 KB) + the structural list (64 F 16-bit entries),
+// or the general path's cell table when that is larger.  wave_tiles == 0 (csv.wave_tiles, tests): the general path only.
 hipError_t launch_csv_parse(const uint8_t* buf, const uint64_t* row_start, int64_t r0, int64_t nb,
-                            const DevCsvPlan& plan, double algo_bytes, hipStream_t s) {
+                            const DevCsvPlan& plan, double avg_record_bytes, int wave_tiles, double algo_bytes, hipStream_t s) {
   if (nb <= 0) return hipSuccess;
   Scope sc(KID_CSV, s, algo_bytes);
   const int64_t blocks = (nb + kBlock - 1) / kBlock;
-  const size_t lds = (size_t)plan.n_cols * kBlock * 2 * sizeof(uint32_t);  // <= 32 columns: 64 KB
-  hipLaunchKernelGGL(k_csv_parse, dim3((unsigned)blocks), dim3(kBlock), lds, s, buf, row_start, r0, nb, plan);
+  uint32_t text_cap = 0;
+  if (wave_tiles && plan.expected_fields >= 1 && plan.expected_fields <= 64) {
+    const double want = avg_record_bytes * 64.0 * 1.5 + 64.0;
+    text_cap = want > (double)kCsvTextCapMax ? (uint32_t)kCsvTextCapMax : (uint32_t)want;
+    text_cap = (text_cap + 1023u) & ~1023u;
+    if (text_cap < 2048u) text_cap = 2048u;
+    const uint32_t room = (16384u - 128u * plan.expected_fields) & ~1023u;  // four waves within 64 KB of dynamic LDS
+    if (text_cap > room) text_cap = room;
+  }
+  uint32_t wave_lds = text_cap ? text_cap + 128u * plan.expected_fields : 0u;
+  const uint32_t general = (uint32_t)plan.n_cols * 64u * 2u * (uint32_t)sizeof(uint32_t);  // <= 32 columns: 16 KB
+  if (wave_lds < general) wave_lds = general;
+  wave_lds = (wave_lds + 15u) & ~15u;
+  hipLaunchKernelGGL(k_csv_parse, dim3((unsigned)blocks), dim3(kBlock), (size_t)wave_lds * (kBlock / 64), s, buf, row_start, r0,
+                     nb, plan, text_cap, wave_lds);
   return hipGetLastError();
 }
 

@@ -188,7 +188,7 @@ hipError_t launch_csv_boundaries_write(const uint8_t* buf, uint64_t n, const uin
 hipError_t launch_csv_count_fields(const uint8_t* buf, const uint64_t* row_start, int64_t row, uint32_t* out,
                                    hipStream_t s);
 hipError_t launch_csv_parse(const uint8_t* buf, const uint64_t* row_start, int64_t r0, int64_t nb,
-                            const DevCsvPlan& plan, double algo_bytes, hipStream_t s);
+                            const DevCsvPlan& plan, double avg_record_bytes, int wave_tiles, double algo_bytes, hipStream_t s);
 hipError_t launch_csv_utf8_gather(const uint8_t* buf, const uint64_t* row_start, int64_t r0, int64_t nb, int field,
                                   const int32_t* offsets, uint8_t* out, hipStream_t s);
 

@@ -254,9 +254,161 @@ DFX_NP int np_parse_int(const uint8_t* s, int64_t n, int bits, bool is_signed, u
   for (; i < n; ++i) {
     if (!np_is_digit(s[i])) return NP_INVALID;
     const uint64_t d = (uint64_t)(s[i] - '0');
-    if (v > (limit - d) / 10) return NP_INVALID;  // overflow
-    v = v * 10 + d;
+    if (v > 1844674407370955161ull) return NP_INVALID;  // 10 v would not fit 64 bits
+    const uint64_t t = v * 10;
+    v = t + d;
+    if (v < t) return NP_INVALID;
   }
+  if (v > limit) return NP_INVALID;  // overflow: the magnitude only grows digit by digit, one check at the end decides
+  *out = neg ? (uint64_t)(0 - v) : v;
+  return NP_OK;
+}
+
+// ---- word-at-a-time variants ---------------------------------------------------------------------------
+// Same functions, same results; the caller guarantees that the 8 bytes after the cell, s[n .. n + 8), may be READ (their
+// values are ignored) -- the CSV cell kernel converts out of an LDS copy of the text, where that holds.  A cell is taken
+// eight bytes at a time: the length of the digit run comes from a SWAR mask, its value from three multiplications.  The
+// short forms cover [+-]? digits [. digits] ([eE] [+-]? 1-5 digits)? with at most 19 digits in all (then the integer of
+// all digits fits 64 bits and nothing is dropped); everything else -- inf, NaN, longer literals, errors -- goes through
+// the byte-at-a-time scanner above, so acceptance and values cannot differ (tests/native/numparse_fuzz.cpp holds both
+// against each other on every input).
+DFX_NP uint64_t np_load8(const uint8_t* p) {
+  uint64_t w;
+  __builtin_memcpy(&w, p, 8);
+  return w;
+}
+
+// how many of the first (lowest-address) bytes of w are ASCII digits, 0..8.  A digit has high nibble 3 and, after adding 6,
+// still high nibble 3; a carry out of a byte >= 0xFA only reaches LATER bytes, which a non-digit makes irrelevant.
+DFX_NP int np_digit_run(uint64_t w) {
+  const uint64_t hi = 0xF0F0F0F0F0F0F0F0ull, three = 0x3030303030303030ull;
+  const uint64_t nd = ((w & hi) ^ three) | (((w + 0x0606060606060606ull) & hi) ^ three);
+  if (nd == 0) return 8;
+#if defined(__HIPCC__)
+  return (__ffsll((long long)nd) - 1) >> 3;
+#else
+  return __builtin_ctzll(nd) >> 3;
+#endif
+}
+
+DFX_NP uint32_t np_four_digits(uint32_t v) {  // bytes d0 d1 d2 d3 (d0 lowest, 0..9 or ASCII) -> d0 d1 d2 d3 as a number
+  v = ((v & 0x0F0F0F0Fu) * 2561u) >> 8;
+  return ((v & 0x00FF00FFu) * 6553601u) >> 16;
+}
+
+// value of the first len (1..8) bytes of w, all digits
+DFX_NP uint32_t np_digits_value(uint64_t w, int len) {
+  const uint64_t x = w << (8 * (8 - len));  // the digits move to the high end; zero bytes below them read as leading zeros
+  return np_four_digits((uint32_t)x) * 10000u + np_four_digits((uint32_t)(x >> 32));
+}
+
+DFX_NP uint32_t np_pow10_small(int len) {  // 10^len, len 0..8
+  return ((len & 1) ? 10u : 1u) * ((len & 2) ? 100u : 1u) * ((len & 4) ? 10000u : 1u) * ((len & 8) ? 100000000u : 1u);
+}
+
+// consumes a run of digits at s[*i ..): acc = acc 10^k + value, *nd += k.  Stops after 24 digits (more than any short form has).
+DFX_NP void np_take_digits(const uint8_t* s, int64_t n, int64_t* i, uint64_t* acc, int* nd) {
+  for (int k = 0; k < 3 && *i < n; ++k) {
+    const uint64_t w = np_load8(s + *i);
+    int len = np_digit_run(w);
+    const int64_t left = n - *i;
+    if ((int64_t)len > left) len = (int)left;
+    if (len == 0) return;
+    *acc = *acc * np_pow10_small(len) + np_digits_value(w, len);
+    *nd += len;
+    *i += len;
+    if (len < 8) return;
+  }
+}
+
+// the short forms of a decimal literal; false: not one of them (which says nothing about validity)
+DFX_NP bool np_scan_decimal_short(const uint8_t* s, int64_t n, bool* neg, uint64_t* w_out, int64_t* q_out) {
+  if (n <= 0) return false;
+  int64_t i = 0;
+  const uint8_t c0 = s[0];
+  *neg = c0 == '-';
+  if (c0 == '-' || c0 == '+') i = 1;
+  uint64_t acc = 0;
+  int nd = 0;
+  np_take_digits(s, n, &i, &acc, &nd);
+  const int n_int = nd;
+  if (i < n && s[i] == '.') {
+    ++i;
+    np_take_digits(s, n, &i, &acc, &nd);
+  }
+  if (nd == 0 || nd > 19) return false;
+  int64_t exp10 = 0;
+  if (i < n) {
+    const uint8_t c = s[i];
+    if (c != 'e' && c != 'E') return false;
+    ++i;
+    bool eneg = false;
+    if (i < n && (s[i] == '-' || s[i] == '+')) {
+      eneg = s[i] == '-';
+      ++i;
+    }
+    if (i >= n) return false;
+    const uint64_t w = np_load8(s + i);
+    int len = np_digit_run(w);
+    if ((int64_t)len > n - i) len = (int)(n - i);
+    if (len == 0 || len > 5 || i + len != n) return false;
+    exp10 = (int64_t)np_digits_value(w, len);
+    if (eneg) exp10 = -exp10;
+  }
+  *w_out = acc;
+  *q_out = exp10 - (int64_t)(nd - n_int);
+  return true;
+}
+
+DFX_NP int np_parse_f64_w(const uint8_t* s, int64_t n, double* out) {
+  bool neg;
+  uint64_t w;
+  int64_t q;
+  if (!np_scan_decimal_short(s, n, &neg, &w, &q)) return np_parse_f64(s, n, out);
+  const BiasedFp fp = np_compute_float<52, -1023, 0x7FF, -4, 23, -342, 308>(q, w);
+  if (fp.e < 0) return NP_UNSUPPORTED;
+  uint64_t bits = fp.f | ((uint64_t)fp.e << 52);
+  if (neg) bits |= 0x8000000000000000ull;
+  union {
+    uint64_t u;
+    double d;
+  } c;
+  c.u = bits;
+  *out = c.d;
+  return NP_OK;
+}
+
+DFX_NP int np_parse_f32_w(const uint8_t* s, int64_t n, float* out) {
+  bool neg;
+  uint64_t w;
+  int64_t q;
+  if (!np_scan_decimal_short(s, n, &neg, &w, &q)) return np_parse_f32(s, n, out);
+  const BiasedFp fp = np_compute_float<23, -127, 0xFF, -17, 10, -65, 38>(q, w);
+  if (fp.e < 0) return NP_UNSUPPORTED;
+  uint32_t bits = (uint32_t)fp.f | ((uint32_t)fp.e << 23);
+  if (neg) bits |= 0x80000000u;
+  union {
+    uint32_t u;
+    float f;
+  } c;
+  c.u = bits;
+  *out = c.f;
+  return NP_OK;
+}
+
+DFX_NP int np_parse_int_w(const uint8_t* s, int64_t n, int bits, bool is_signed, uint64_t* out) {
+  if (n <= 0) return NP_INVALID;
+  int64_t i = 0;
+  const uint8_t c0 = s[0];
+  const bool neg = c0 == '-';
+  if (c0 == '-' || c0 == '+') i = 1;
+  uint64_t v = 0;
+  int nd = 0;
+  np_take_digits(s, n, &i, &v, &nd);
+  if (nd == 0 || nd > 19 || i != n) return np_parse_int(s, n, bits, is_signed, out);  // 20 digits, or not a number
+  if (neg && !is_signed) return NP_INVALID;  // u*::from_str rejects '-'
+  const uint64_t maxpos = is_signed ? ((1ull << (bits - 1)) - 1) : (bits == 64 ? ~0ull : ((1ull << bits) - 1));
+  if (v > (neg ? maxpos + 1 : maxpos)) return NP_INVALID;
   *out = neg ? (uint64_t)(0 - v) : v;
   return NP_OK;
 }

@@ -107,6 +107,8 @@ struct AggOptions {
                                // been keeping more than a wave can park in LDS (> 22 % of its rows), 0 never, 1 whenever the shape allows
   int filter_single_pass = 1;  // FilterRelation: predicate + bitmap + tile offsets (decoupled look-back) + compaction of the predicate's own
                                // columns in ONE kernel (0: k_predicate_mask -> scan -> k_compact, the column is read twice)
+  int csv_wave_tiles = 1;      // CsvDataSource cells: one wave per tile of 64 records converts from an LDS copy of the tile's text (0: every
+                               // lane walks its own record in global memory -- the path tiles with quotes or ragged records take anyway)
   int replay_in_place = 1;     // 1: rows spilled by a table that is NOT full (region overflow of a heavy key) are replayed into the
                                // table as it is, and only what it cannot take makes it grow (0: every spill quadruples the table)
 };

@@ -267,6 +267,7 @@ bool set_option_in(AggOptions& o, const char* key, int64_t value) {
   else if (!strcmp(key, "filter.single_pass")) o.filter_single_pass = (int)value;
   else if (!strcmp(key, "filter.dense")) o.filter_dense = (int)value;
   else if (!strcmp(key, "agg.split_aggregates")) o.split_aggregates = (int)value;
+  else if (!strcmp(key, "csv.wave_tiles")) o.csv_wave_tiles = (int)value;
   else if (!strcmp(key, "host.stream")) o.host_stream = (int)value;
   else if (!strcmp(key, "host.stage_threads")) o.host_stage_threads = (int)value;
   else if (!strcmp(key, "host.stage_mb")) o.host_stage_mb = (int)value;
@@ -447,6 +448,8 @@ int64_t dfx_counter_get(const char* name) {
   if (!strcmp(name, "filter_output_regrows")) return counters().filter_output_regrows;
   if (!strcmp(name, "filter_lookback_fallbacks")) return counters().filter_lookback_fallbacks;
   if (!strcmp(name, "csv_cells")) return counters().csv_cells;
+  if (!strcmp(name, "csv_tiles")) return counters().csv_tiles;
+  if (!strcmp(name, "csv_general_tiles")) return counters().csv_general_tiles;
   if (!strcmp(name, "agg_ctrl_wait_us")) return counters().agg_ctrl_wait_us;
   if (!strcmp(name, "agg_sync_us")) return counters().agg_sync_us;
   if (!strcmp(name, "agg_emit_us")) return counters().agg_emit_us;

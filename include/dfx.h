@@ -446,7 +446,8 @@ int64_t dfx_relation_explain(struct ArrowArrayStream* stream, char* buf, size_t 
  *   "pool.trim"              (any value) return the cached device buffers to the driver */
 int32_t dfx_set_option(const char* key, int64_t value);
 /* Measurement counters: "h2d_bytes" (column bytes the uploaders copied host -> device), "h2d_staged_bytes" (of which through
- * the pinned staging ring), "csv_cells" (cells the CSV source converted) -- what projection push-down saves.  -1: unknown name. */
+ * the pinned staging ring), "csv_cells" (cells the CSV source converted) -- what projection push-down saves, "csv_tiles" / "csv_general_tiles"
+ * (64-record tiles converted by the CSV source / those that took the per-lane walk instead of the wave-cooperative path).  -1: unknown name. */
 int64_t dfx_counter_get(const char* name);
 void dfx_counter_reset(void);
 

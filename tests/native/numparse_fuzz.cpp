@@ -1,4 +1,6 @@
 // Host build of csrc/dfx_numparse.hpp checked against glibc strtod / strtof (correctly rounded, like Rust's dec2flt).
+// The word-at-a-time variants (np_parse_*_w, what the CSV cell kernel runs out of LDS) are held against the byte-at-a-time ones on
+// every input, with bytes after the cell that would change the result if they were read as part of it.
 // usage: numparse_fuzz <iterations> <seed>   -> prints "ok ..." or the first mismatch and exits 1
 #include <math.h>
 #include <stdio.h>
@@ -10,11 +12,56 @@
 
 #include "../../datafusion_archive_amd/csrc/dfx_numparse.hpp"
 
-static long long n_ok = 0, n_unsupported = 0;
+static long long n_ok = 0, n_unsupported = 0, n_word = 0;
+
+// the word-at-a-time variants (np_parse_*_w) may read 8 bytes past the cell: the copy is followed by digits and other
+// bytes that would change the value if they were used.  They must return what the byte-at-a-time functions return.
+static const char* const kTails[] = {"77777777", "0e5.1234", ".9999999", "\xff\xfa\xfb\xfc\xfd\xfe\xff\xff", ",\n\"12345"};
+static bool same_as_words64(const std::string& s, int rc, double got) {
+  for (const char* tail : kTails) {
+    std::string b = s + std::string(tail, 8);
+    double g2 = 0;
+    const int rc2 = dfx::np_parse_f64_w((const uint8_t*)b.data(), (int64_t)s.size(), &g2);
+    if (rc2 != rc || (rc == dfx::NP_OK && memcmp(&got, &g2, 8) != 0)) {
+      printf("MISMATCH f64 word-at-a-time: '%s' rc %d/%d got %.17g/%.17g\n", s.c_str(), rc, rc2, got, g2);
+      return false;
+    }
+  }
+  ++n_word;
+  return true;
+}
+static bool same_as_words32(const std::string& s, int rc, float got) {
+  for (const char* tail : kTails) {
+    std::string b = s + std::string(tail, 8);
+    float g2 = 0;
+    const int rc2 = dfx::np_parse_f32_w((const uint8_t*)b.data(), (int64_t)s.size(), &g2);
+    if (rc2 != rc || (rc == dfx::NP_OK && memcmp(&got, &g2, 4) != 0)) {
+      printf("MISMATCH f32 word-at-a-time: '%s' rc %d/%d got %.9g/%.9g\n", s.c_str(), rc, rc2, (double)got, (double)g2);
+      return false;
+    }
+  }
+  return true;
+}
+static bool same_as_words_int(const std::string& s, int bits, bool sg) {
+  uint64_t v = 0;
+  const int rc = dfx::np_parse_int((const uint8_t*)s.data(), (int64_t)s.size(), bits, sg, &v);
+  for (const char* tail : kTails) {
+    std::string b = s + std::string(tail, 8);
+    uint64_t v2 = 0;
+    const int rc2 = dfx::np_parse_int_w((const uint8_t*)b.data(), (int64_t)s.size(), bits, sg, &v2);
+    if (rc2 != rc || (rc == dfx::NP_OK && v != v2)) {
+      printf("MISMATCH int word-at-a-time: '%s' bits=%d signed=%d rc %d/%d v %llu/%llu\n", s.c_str(), bits, (int)sg, rc, rc2,
+             (unsigned long long)v, (unsigned long long)v2);
+      return false;
+    }
+  }
+  return true;
+}
 
 static bool check64(const std::string& s) {
   double got = 0;
   const int rc = dfx::np_parse_f64((const uint8_t*)s.data(), (int64_t)s.size(), &got);
+  if (!same_as_words64(s, rc, got)) return false;
   if (rc == dfx::NP_UNSUPPORTED) {
     ++n_unsupported;
     return true;
@@ -35,6 +82,7 @@ static bool check64(const std::string& s) {
 static bool check32(const std::string& s) {
   float got = 0;
   const int rc = dfx::np_parse_f32((const uint8_t*)s.data(), (int64_t)s.size(), &got);
+  if (!same_as_words32(s, rc, got)) return false;
   if (rc == dfx::NP_UNSUPPORTED) {
     ++n_unsupported;
     return true;
@@ -60,7 +108,7 @@ static bool expect_invalid(const char* s) {
     printf("MISMATCH: '%s' should be invalid\n", s);
     return false;
   }
-  return true;
+  return same_as_words64(s, dfx::NP_INVALID, 0.0) && same_as_words32(s, dfx::NP_INVALID, 0.0f);
 }
 
 static bool check_int(const char* s, int bits, bool sg, bool ok, long long want) {
@@ -70,7 +118,7 @@ static bool check_int(const char* s, int bits, bool sg, bool ok, long long want)
     printf("MISMATCH int: '%s' bits=%d signed=%d rc=%d v=%lld\n", s, bits, (int)sg, rc, (long long)v);
     return false;
   }
-  return true;
+  return same_as_words_int(s, bits, sg);
 }
 
 int main(int argc, char** argv) {
@@ -146,7 +194,24 @@ int main(int argc, char** argv) {
       }
     }
     if (!check64(s) || !check32(s)) return 1;
+    if (kind >= 4) {  // the same digit strings as integers of every width (most are rejected: '.', 'e', overflow), and mangled copies
+      static const int widths[] = {8, 16, 32, 64};
+      std::string t = s.substr(0, s.find_first_of(".eE"));
+      if (rng() % 4 == 0) t = s;
+      if (rng() % 16 == 0 && !t.empty()) t[rng() % t.size()] = "x-+ .e\xfa"[rng() % 7];
+      for (int wd : widths)
+        if (!same_as_words_int(t, wd, true) || !same_as_words_int(t, wd, false)) return 1;
+      if (rng() % 8 == 0 && !s.empty()) {
+        std::string m = s;
+        m[rng() % m.size()] = "x-+ .e\xfa"[rng() % 7];
+        double d = 0;
+        float f = 0;
+        const int rc = dfx::np_parse_f64((const uint8_t*)m.data(), (int64_t)m.size(), &d);
+        const int rcf = dfx::np_parse_f32((const uint8_t*)m.data(), (int64_t)m.size(), &f);
+        if (!same_as_words64(m, rc, d) || !same_as_words32(m, rcf, f)) return 1;
+      }
+    }
   }
-  printf("ok: %lld conversions agree with strtod/strtof, %lld declined (NP_UNSUPPORTED)\n", n_ok, n_unsupported);
+  printf("ok: %lld conversions agree with strtod/strtof, %lld declined (NP_UNSUPPORTED), %lld inputs identical word-at-a-time\n", n_ok, n_unsupported, n_word);
   return 0;
 }

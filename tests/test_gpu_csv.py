@@ -108,6 +108,105 @@ def test_csv_generated_numeric_text_is_bit_exact(tmp_path, crlf, trailing):
     assert check_file(p, schema, 100000) == 20000
 
 
+def _write_plain_csv(path, n, seed, nl="\n", trailing=True, quote_rows=(), long_rows=(), blank_every=0):
+    """Numeric text without quotes (the wave-cooperative cell path) except in `quote_rows`; `long_rows` carry a text cell
+    longer than any LDS window."""
+    rng = np.random.default_rng(seed)
+    f = rng.standard_normal(n) * 10.0 ** rng.integers(-30, 30, n)
+    g = rng.random(n).astype(np.float32)
+    i = rng.integers(-2**63, 2**63 - 1, n)
+    u = rng.integers(0, 65536, n)
+    lines = ["f64,f32,i64,u16,flag,txt"]
+    for r in range(n):
+        cells = [repr(float(f[r])), repr(float(g[r])), str(int(i[r])), str(int(u[r])), "true" if r % 3 else "false", f"r{r}"]
+        if r % 13 == 5:
+            cells[0] = ""
+        if r % 29 == 4:
+            cells[4] = ""
+        if r % 31 == 9:
+            cells[5] = ""
+        if r % 19 == 2:
+            cells[1] = "%.4E" % float(g[r])
+        if r % 23 == 1:
+            cells[0] = "+" + repr(abs(float(f[r])))
+        if r in quote_rows:
+            cells[2] = '"' + cells[2] + '"'
+        if r in long_rows:
+            cells[5] = "x" * 20000
+        lines.append(",".join(cells))
+        if blank_every and r % blank_every == 0:
+            lines.append("")
+    with open(path, "w", newline="") as fh:
+        fh.write(nl.join(lines) + (nl if trailing else ""))
+    return pa.schema([("f64", pa.float64()), ("f32", pa.float32()), ("i64", pa.int64()), ("u16", pa.uint16()), ("flag", pa.bool_()),
+                      ("txt", pa.string())])
+
+
+@pytest.mark.parametrize("nl,trailing,blank_every", [("\n", True, 0), ("\r\n", True, 97), ("\r", False, 0), ("\n", False, 61)])
+def test_csv_wave_tiles_plain_text_is_bit_exact(tmp_path, nl, trailing, blank_every):
+    """Quote-free numeric text takes the wave-cooperative path of k_csv_parse (an LDS copy of a 64-record tile, SWAR
+    delimiter masks, a structural list): every tile, whatever the terminator, the blank lines or the missing last
+    terminator -- and converts to the same bits as the oracle and as the per-lane walk (csv.wave_tiles = 0)."""
+    p = str(tmp_path / "plain.csv")
+    schema = _write_plain_csv(p, 20000, 41, nl, trailing, blank_every=blank_every)
+    for batch in (4096, 1000, 100000):
+        ex.counter_reset()
+        assert check_file(p, schema, batch) == 20000
+        assert ex.counter_get("csv_tiles") == sum((min(batch, 20000 - o) + 63) // 64 for o in range(0, 20000, batch))
+        assert ex.counter_get("csv_general_tiles") == 0
+    ex.set_option("csv.wave_tiles", 0)
+    try:
+        ex.counter_reset()
+        assert check_file(p, schema, 4096) == 20000
+        assert ex.counter_get("csv_general_tiles") == ex.counter_get("csv_tiles") > 0
+    finally:
+        ex.set_option("csv.wave_tiles", 1)
+
+
+def test_csv_wave_tiles_fall_back_per_tile(tmp_path):
+    """A quote or a record longer than the LDS window sends ONLY its own tile down the per-lane walk."""
+    p = str(tmp_path / "mixed.csv")
+    schema = _write_plain_csv(p, 6400, 43, quote_rows={100, 101, 3000}, long_rows={5000})
+    ex.counter_reset()
+    assert check_file(p, schema, 6400) == 6400
+    assert ex.counter_get("csv_tiles") == 100
+    assert ex.counter_get("csv_general_tiles") == 3  # tiles 1, 46 and 78
+    # a schema narrower / wider than the file: cells beyond the schema are ignored, columns beyond the record are null
+    narrow = pa.schema(list(schema)[:3])
+    wide = pa.schema(list(schema) + [pa.field("more", pa.int64())])
+    for sch in (narrow, wide):
+        ex.counter_reset()
+        assert check_file(p, sch, 4096) == 6400
+        assert ex.counter_get("csv_general_tiles") == 3
+
+
+def test_csv_wave_tiles_errors(tmp_path):
+    """Errors out of the wave-cooperative path: a cell that does not parse is reported from it; a ragged record makes its
+    tile take the walk, which reports UnequalLengths for the lowest record as the reference does."""
+    schema = pa.schema([("a", pa.int32()), ("b", pa.float64()), ("c", pa.int64())])
+    rows = [f"{i},{i}.25,{i * 7}" for i in range(1000)]
+    p = tmp_path / "e.csv"
+    cases = []
+    r = list(rows); r[700] = "700,1e,4900"
+    cases.append(("Error while parsing value 1e at line 701", r))
+    r = list(rows); r[650] = "650,9.5,zz"; r[130] = "130,--1,910"
+    cases.append(("Error while parsing value --1 at line 131", r))
+    r = list(rows); r[400] = "400,400.25"; r[100] = "bad,1.0,700"
+    cases.append(("UnequalLengths", r))
+    r = list(rows); r[999] = "999,999.25,6993,1"
+    cases.append(("UnequalLengths", r))
+    r = list(rows); r[320] = "320,0.1,99999999999999999999"
+    cases.append(("Error while parsing value 99999999999999999999 at line 321", r))
+    for want, body in cases:
+        p.write_text("a,b,c\n" + "\n".join(body) + "\n")
+        with pytest.raises(ex.ExecutionError) as ei:
+            list(ex.CsvDataSource(str(p), schema, 4096))
+        assert want in ei.value.message, (want, ei.value.message)
+        with pytest.raises(oracle.OracleError) as oi:
+            oracle.read_csv(str(p), schema, 4096)
+        assert want in oi.value.message, (want, oi.value.message)
+
+
 def test_csv_quoting_fuzz_against_oracle(tmp_path):
     """Random text over the bytes that matter to the automaton ( , " CR LF and fillers): boundaries by parallel DFA
     simulation on the device must equal the oracle's byte-at-a-time reader.  Records keep a fixed field count so that

@@ -4,6 +4,7 @@
 #   bench    bench.py with the driver's flags -> gpurun_out/<tag>/bench.json + a one-screen summary
 #   profile  rocprofv3 --kernel-trace --stats of the bench command; FETCH_SIZE / WRITE_SIZE (separate passes) and SQ counters of
 #            pass 1 / pass 2 for the headline and for config 3 -> partition_counters.json; kernel stats of config 3
+#   csv      the CSV source: its GPU tests, tools/csv_bench.py (1 GB of numeric text) and the rocprofv3 kernel summary of that run
 #   dry8     bench.py --gpus 8 as eight processes on this ONE GPU over the host-staged RCCL stand-in (plumbing only), and the
 #            same with DFX_RCCL_LIB pointing at a missing file (must exit non-zero)
 # Summaries land in gpurun_out/<tag>/ -- what is cited is copied to profiles/ by hand.
@@ -13,6 +14,12 @@ for STAGE in ${STAGES//,/ }; do
 cd $R
 echo "==== stage $STAGE"
 case $STAGE in
+csv)
+  timeout 900 python -m pytest tests/test_gpu_csv.py -m gpu -q --timeout 600 > $OUT/pytest_csv.log 2>&1; echo "csv tests rc=$?"; tail -n 12 $OUT/pytest_csv.log | cut -c1-400
+  timeout 600 python tools/csv_bench.py 1024 > $OUT/csv_bench.txt 2>&1; echo "csv bench rc=$?"; tail -n 4 $OUT/csv_bench.txt | cut -c1-400
+  (cd /tmp && DFX_NO_TORCH=1 timeout 600 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/stats_csv -o out -- python $R/tools/csv_bench.py 1024 > /dev/null 2>&1)
+  cp $OUT/stats_csv/out_kernel_stats.csv $OUT/csv_kernel_stats.csv 2>/dev/null; head -n 12 $OUT/csv_kernel_stats.csv | cut -c1-200
+  ;;
 suite)
   timeout 2400 python -m pytest tests -m gpu -q --timeout 900 > $OUT/pytest_gpu.log 2>&1; echo "gpu suite rc=$?"; tail -n 8 $OUT/pytest_gpu.log | cut -c1-300
   ;;
