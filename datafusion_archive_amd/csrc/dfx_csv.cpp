@@ -136,6 +136,8 @@ Status CsvRelation::index_records() {
   if (!trans) return st;
   auto state = device_alloc((size_t)n_tiles + 8, &st);
   if (!state) return st;
+  auto block_vec = device_alloc(sizeof(uint32_t) * (size_t)(n_tiles / 1024 + 1), &st);  // one word per 1024 tiles
+  if (!block_vec) return st;
   auto counts = device_alloc(sizeof(uint32_t) * (size_t)n_tiles, &st);
   if (!counts) return st;
   auto offsets = device_alloc(sizeof(uint64_t) * (size_t)(n_tiles + 1), &st);
@@ -143,7 +145,7 @@ Status CsvRelation::index_records() {
   auto tmp = device_alloc(sizeof(uint64_t) * (size_t)(n_tiles / 4096 + 4), &st);
   if (!tmp) return st;
   const uint8_t* buf = (const uint8_t*)text_.get();
-  DFX_HIP(launch_csv_boundaries_count(buf, n_bytes_, (uint32_t*)trans.get(), (uint8_t*)state.get(), (uint32_t*)counts.get(), s));
+  DFX_HIP(launch_csv_boundaries_count(buf, n_bytes_, (uint32_t*)trans.get(), (uint32_t*)block_vec.get(), (uint8_t*)state.get(), (uint32_t*)counts.get(), s));
   DFX_HIP(launch_scan_u32((const uint32_t*)counts.get(), (uint64_t*)offsets.get(), n_tiles, (uint64_t*)tmp.get(), s));
   uint64_t total = 0;
   DFX_HIP(hipMemcpyAsync(&total, (uint64_t*)offsets.get() + n_tiles, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
@@ -151,7 +153,7 @@ Status CsvRelation::index_records() {
   n_records_ = (int64_t)total;
   row_start_ = device_alloc(sizeof(uint64_t) * (size_t)(total + 1), &st);
   if (!row_start_) return st;
-  DFX_HIP(launch_csv_boundaries_write(buf, n_bytes_, (const uint8_t*)state.get(), (const uint64_t*)offsets.get(),
+  DFX_HIP(launch_csv_boundaries_write(buf, n_bytes_, (const uint32_t*)trans.get(), (const uint8_t*)state.get(), (const uint64_t*)offsets.get(),
                                       (uint64_t*)row_start_.get(), s));
   DFX_HIP(hipMemcpyAsync((uint64_t*)row_start_.get() + total, &n_bytes_, sizeof(uint64_t), hipMemcpyHostToDevice, s));
   if (total > 0) {

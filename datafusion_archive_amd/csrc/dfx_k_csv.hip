@@ -6,13 +6,17 @@
 //                       32-byte chunk is summarised as a transition vector (end state for each of the 5 start
 //                       states, 15 bits), vectors compose associatively, a scan over chunks / tiles gives every
 //                       chunk its true start state, and a replay marks the bytes where a record starts
-//                       (k_csv_tile_trans -> k_csv_tile_scan -> k_csv_mark<count> -> scan -> k_csv_mark<write>).
-//   cells               one thread per record walks its bytes once and converts every cell: integers and floats with
-//                       Rust's `str::parse` semantics (dfx_numparse.hpp: Eisel-Lemire, correctly rounded), booleans,
-//                       Utf8 lengths; validity bitmaps are wave ballots (k_csv_parse); Utf8 bytes are gathered by a
-//                       second walk after the offset scan (k_csv_utf8_gather).
-// Bound: HBM reads of the text (3 boundary passes + 1..2 cell passes); the cell walk is byte-serial per record, so
-// it is latency- rather than bandwidth-bound for now -- ingest is PCIe-bound (63 GB/s) long before that matters.
+//                       (k_csv_tile_trans -> k_csv_tile_scan_{totals,blocks,apply} -> k_csv_count_unknown -> scan ->
+//                       k_csv_mark_write).  A tile without a quote needs no replay: its record count follows from its own
+//                       bytes and the state it starts in, so only tiles with quotes are read a second time before the write.
+//   cells               one wave per tile of 64 records (k_csv_parse): the tile's text goes to LDS with coalesced loads, SWAR
+//                       masks number its delimiters and record ends, and the wave converts one column at a time out of
+//                       LDS: integers and floats with Rust's `str::parse` semantics (dfx_numparse.hpp: eight bytes at a
+//                       time, Eisel-Lemire, correctly rounded), booleans, Utf8 lengths; validity bitmaps are wave ballots.
+//                       Tiles with quotes or ragged records take a per-lane walk.  Utf8 bytes are gathered by a second
+//                       walk after the offset scan (k_csv_utf8_gather).
+// Bound: HBM reads of the text (2 boundary passes, 3 where there are quotes, + 1..2 cell passes); ingest is PCIe-bound
+// (63 GB/s) long before that matters.
 #include "dfx_csv_walk.hpp"
 #include "dfx_kernels_inl.hpp"
 #include "dfx_launch.hpp"
@@ -125,72 +129,128 @@ DEV uint32_t csv_block_scan(uint32_t v, uint32_t* lds_wave_tot, uint32_t* total)
   return csv_tv_compose(pre, excl);
 }
 
+// The word a tile leaves for the scan: its transition vector (15 bits) and -- when no chunk of the tile holds a quote and the
+// tile is whole -- the number of records that start in it, counted as if its first byte did not follow a terminator, plus
+// whether that first byte could start a record.  Without a quote the state before a byte is a function of the byte before it,
+// so the count needs no scan; kCsvTileUnknown marks the tiles whose starts k_csv_count_unknown has to count by replay.
+constexpr uint32_t kCsvTileVec = 0x7FFFu;
+constexpr uint32_t kCsvTileUnknown = 1u << 15;
+constexpr uint32_t kCsvTileFirstNonT = 1u << 16;
+constexpr int kCsvTileCountShift = 17;
+
+// starts of a quote-free full chunk: a non-terminator right after a terminator (`after_t`: the byte before the chunk is one)
+DEV uint32_t csv_plain_starts(uint32_t t, bool after_t) { return ~t & ((t << 1) | (after_t ? 1u : 0u)); }
+
 __global__ __launch_bounds__(kCsvBlock) void k_csv_tile_trans(const uint8_t* __restrict__ buf, uint64_t n,
                                                              uint32_t* __restrict__ tile_trans) {
   __shared__ uint32_t wave_tot[kCsvBlock / 64];
-  const uint64_t pos = (uint64_t)blockIdx.x * kCsvTile + (uint64_t)threadIdx.x * kCsvChunk;
-  const uint32_t v = csv_chunk_vector(csv_load_chunk(buf, pos, n));
-  uint32_t total;
-  (void)csv_block_scan(v, wave_tot, &total);
-  if (threadIdx.x == 0) tile_trans[blockIdx.x] = total;
-}
-
-// one workgroup: state at the start of every tile (the file starts in StartRecord).  Every thread owns a contiguous run of
-// tiles; it reads them eight at a time (independent loads in flight, then eight compositions), the 1024 run totals are scanned
-// with wave shuffles, and a second walk over the run writes the states.
-__global__ __launch_bounds__(1024) void k_csv_tile_scan(const uint32_t* __restrict__ tile_trans, int64_t n_tiles,
-                                                         uint8_t* __restrict__ tile_state) {
-  __shared__ uint32_t wave_tot[16];
-  const int64_t per = ((n_tiles + 1023) / 1024 + 7) & ~7ll;
-  const int64_t t0 = (int64_t)threadIdx.x * per;
-  const int64_t t1 = t0 + per < n_tiles ? t0 + per : n_tiles;
-  uint32_t v = kCsvTvId;
-  for (int64_t t = t0; t < t1; t += 8) {
-    uint32_t x[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) x[j] = t + j < t1 ? tile_trans[t + j] : kCsvTvId;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) v = csv_tv_compose(v, x[j]);
-  }
-  uint32_t total;
-  const uint32_t pre = csv_block_scan<1024>(v, wave_tot, &total);
-  uint32_t s = csv_tv_apply(pre, 0u);
-  for (int64_t t = t0; t < t1; t += 8) {
-    uint32_t x[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) x[j] = t + j < t1 ? tile_trans[t + j] : kCsvTvId;
-    uint64_t out = 0;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      out |= (uint64_t)s << (8 * j);
-      s = csv_tv_apply(x[j], s);
-    }
-    if (t + 8 <= t1) {
-      *(uint64_t*)(tile_state + t) = out;  // t0 is a multiple of 8: aligned
-    } else {
-      for (int j = 0; t + j < t1; ++j) tile_state[t + j] = (uint8_t)(out >> (8 * j));
-    }
-  }
-}
-
-// WRITE == false: record starts per tile -> tile_counts.  WRITE == true: their byte positions -> row_start.
-template <bool WRITE>
-__global__ __launch_bounds__(kCsvBlock) void k_csv_mark(const uint8_t* __restrict__ buf, uint64_t n,
-                                                       const uint8_t* __restrict__ tile_state,
-                                                       uint32_t* __restrict__ tile_counts,
-                                                       const uint64_t* __restrict__ tile_offsets,
-                                                       uint64_t* __restrict__ row_start) {
-  __shared__ uint32_t wave_tot[kCsvBlock / 64];
+  __shared__ uint32_t wave_last[kCsvBlock / 64];
   __shared__ uint32_t wave_cnt[kCsvBlock / 64];
   const int lane = lane_id();
   const int wave = threadIdx.x >> 6;
   const uint64_t pos = (uint64_t)blockIdx.x * kCsvTile + (uint64_t)threadIdx.x * kCsvChunk;
   const CsvChunk chunk = csv_load_chunk(buf, pos, n);
+  const bool plain = chunk.m == kCsvChunk && !chunk.has_quote;
+  const uint32_t t = csv_chunk_tmask(chunk);
+  if (lane == 63) wave_last[wave] = t >> 31;
+  if (__syncthreads_and(plain ? 1 : 0)) {
+    uint32_t after = (uint32_t)__shfl_up((int)(t >> 31), 1, 64);
+    if (lane == 0) after = wave == 0 ? 0u : wave_last[wave - 1];
+    uint32_t cnt = (uint32_t)__popc(csv_plain_starts(t, after != 0u));
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, d, 64);
+    if (lane == 0) wave_cnt[wave] = cnt;
+    if (threadIdx.x == 0) wave_tot[0] = (t & 1u) ? 0u : kCsvTileFirstNonT;
+    __syncthreads();
+    if (threadIdx.x == kCsvBlock - 1) {
+      uint32_t total = 0;
+#pragma unroll
+      for (int w = 0; w < kCsvBlock / 64; ++w) total += wave_cnt[w];
+      // every start state but InQuoted ends in the state the LAST byte dictates; InQuoted stays InQuoted
+      const uint32_t e = csv_tv_apply(csv_tv_of(csv_class(csv_chunk_byte(chunk, kCsvChunk - 1))), 2u);
+      tile_trans[blockIdx.x] = csv_pack5(e, e, e, 3u, e) | wave_tot[0] | (total << kCsvTileCountShift);
+    }
+    return;
+  }
   const uint32_t v = csv_chunk_vector(chunk);
   uint32_t total;
-  const uint32_t pre = csv_block_scan(v, wave_tot, &total);
-  // replay with the true start state: a record starts at a non-terminator byte met in state StartRecord
-  const uint32_t starts = csv_chunk_starts(chunk, csv_tv_apply(pre, (uint32_t)tile_state[blockIdx.x]));
+  (void)csv_block_scan(v, wave_tot, &total);
+  if (threadIdx.x == 0) tile_trans[blockIdx.x] = total | kCsvTileUnknown;
+}
+
+// State at the start of every tile (the file starts in StartRecord), three launches over blocks of 1024 tiles: the composed
+// vector of every block, one workgroup that scans those (the states at the block starts), and the blocks again -- the state of
+// every tile, and with it the record count of every quote-free tile.
+__global__ __launch_bounds__(1024) void k_csv_tile_scan_totals(const uint32_t* __restrict__ tile_trans, int64_t n_tiles,
+                                                                uint32_t* __restrict__ block_vec) {
+  __shared__ uint32_t wave_tot[16];
+  const int64_t t = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+  uint32_t total;
+  (void)csv_block_scan<1024>(t < n_tiles ? tile_trans[t] & kCsvTileVec : kCsvTvId, wave_tot, &total);
+  if (threadIdx.x == 0) block_vec[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(1024) void k_csv_tile_scan_blocks(uint32_t* __restrict__ block_vec, int64_t n_blocks) {  // vectors in, states out
+  __shared__ uint32_t wave_tot[16];
+  uint32_t s = 0u;
+  for (int64_t b0 = 0; b0 < n_blocks; b0 += 1024) {
+    const int64_t b = b0 + threadIdx.x;
+    uint32_t total;
+    const uint32_t pre = csv_block_scan<1024>(b < n_blocks ? block_vec[b] : kCsvTvId, wave_tot, &total);
+    if (b < n_blocks) block_vec[b] = csv_tv_apply(pre, s);
+    s = csv_tv_apply(total, s);
+  }
+}
+
+__global__ __launch_bounds__(1024) void k_csv_tile_scan_apply(const uint32_t* __restrict__ tile_trans, int64_t n_tiles,
+                                                               const uint32_t* __restrict__ block_state,
+                                                               uint8_t* __restrict__ tile_state, uint32_t* __restrict__ tile_counts) {
+  __shared__ uint32_t wave_tot[16];
+  const int64_t t = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+  const uint32_t x = t < n_tiles ? tile_trans[t] : kCsvTvId;
+  uint32_t total;
+  const uint32_t pre = csv_block_scan<1024>(x & kCsvTileVec, wave_tot, &total);
+  if (t >= n_tiles) return;
+  const uint32_t s = csv_tv_apply(pre, block_state[blockIdx.x]);
+  tile_state[t] = (uint8_t)s;
+  // records that start in a quote-free tile: none inside a quoted field, else the tile's own count (+ its first byte when the
+  // tile begins in StartRecord); tiles with quotes are counted by k_csv_count_unknown
+  if (!(x & kCsvTileUnknown))
+    tile_counts[t] = s == 3u ? 0u : (x >> kCsvTileCountShift) + ((s == 0u && (x & kCsvTileFirstNonT)) ? 1u : 0u);
+}
+
+// Record starts of one tile, by the whole workgroup.  WRITE == false: their number -> tile_counts (the tiles the scan could
+// not count: quotes, the ragged last tile).  WRITE == true: their byte positions -> row_start.  Quote-free tiles skip the
+// transition vectors and their scan: a record starts at a non-terminator that follows a terminator (or the tile's StartRecord).
+template <bool WRITE>
+DEV void csv_mark_tile(int64_t tile, bool known, const uint8_t* __restrict__ buf, uint64_t n, const uint8_t* __restrict__ tile_state,
+                       uint32_t* __restrict__ tile_counts, const uint64_t* __restrict__ tile_offsets,
+                       uint64_t* __restrict__ row_start, uint32_t* wave_tot, uint32_t* wave_cnt) {
+  const int lane = lane_id();
+  const int wave = threadIdx.x >> 6;
+  const uint32_t s_tile = (uint32_t)tile_state[tile];
+  if (known && s_tile == 3u) return;  // a quote-free tile inside a quoted field: no record starts here
+  const uint64_t pos = (uint64_t)tile * kCsvTile + (uint64_t)threadIdx.x * kCsvChunk;
+  const CsvChunk chunk = csv_load_chunk(buf, pos, n);
+  uint32_t starts;
+  if (known) {
+    const uint32_t t = csv_chunk_tmask(chunk);
+    uint32_t after = (uint32_t)__shfl_up((int)(t >> 31), 1, 64);
+    if (lane == 0) {
+      if (threadIdx.x == 0) after = s_tile == 0u ? 1u : 0u;
+      else {
+        const uint8_t c = buf[pos - 1];
+        after = (c == '\n' || c == '\r') ? 1u : 0u;
+      }
+    }
+    starts = csv_plain_starts(t, after != 0u);
+  } else {
+    const uint32_t v = csv_chunk_vector(chunk);
+    uint32_t total;
+    const uint32_t pre = csv_block_scan(v, wave_tot, &total);
+    // replay with the true start state: a record starts at a non-terminator byte met in state StartRecord
+    starts = csv_chunk_starts(chunk, csv_tv_apply(pre, s_tile));
+  }
   const uint32_t cnt = (uint32_t)__popc(starts);
   uint32_t inc = cnt;
 #pragma unroll
@@ -207,9 +267,10 @@ __global__ __launch_bounds__(kCsvBlock) void k_csv_mark(const uint8_t* __restric
     tile_total += wave_cnt[w];
   }
   if (!WRITE) {
-    if (threadIdx.x == 0) tile_counts[blockIdx.x] = tile_total;
+    if (threadIdx.x == 0) tile_counts[tile] = tile_total;
+    __syncthreads();  // wave_cnt is written again for the workgroup's next tile
   } else {
-    uint64_t at = tile_offsets[blockIdx.x] + base + inc - cnt;
+    uint64_t at = tile_offsets[tile] + base + inc - cnt;
     uint32_t b = starts;
     while (b) {
       const int i = __ffs((int)b) - 1;
@@ -217,6 +278,40 @@ __global__ __launch_bounds__(kCsvBlock) void k_csv_mark(const uint8_t* __restric
       b &= b - 1;
     }
   }
+}
+
+// every workgroup looks at kCsvBlock consecutive tiles (one word each) and counts the starts of those the scan left open
+__global__ __launch_bounds__(kCsvBlock) void k_csv_count_unknown(const uint8_t* __restrict__ buf, uint64_t n,
+                                                                const uint32_t* __restrict__ tile_trans, int64_t n_tiles,
+                                                                const uint8_t* __restrict__ tile_state,
+                                                                uint32_t* __restrict__ tile_counts) {
+  __shared__ uint32_t wave_tot[kCsvBlock / 64];
+  __shared__ uint32_t wave_cnt[kCsvBlock / 64];
+  __shared__ uint64_t open_mask[kCsvBlock / 64];
+  const int64_t first = (int64_t)blockIdx.x * kCsvBlock;
+  const int64_t t = first + threadIdx.x;
+  const uint64_t m = __ballot(t < n_tiles && (tile_trans[t < n_tiles ? t : 0] & kCsvTileUnknown) != 0u);
+  if (lane_id() == 0) open_mask[threadIdx.x >> 6] = m;
+  __syncthreads();
+  for (int w = 0; w < kCsvBlock / 64; ++w) {
+    uint64_t open = open_mask[w];  // (workgroup-uniform)
+    while (open) {
+      const int j = __ffsll((long long)open) - 1;
+      open &= open - 1;
+      csv_mark_tile<false>(first + w * 64 + j, false, buf, n, tile_state, tile_counts, nullptr, nullptr, wave_tot, wave_cnt);
+    }
+  }
+}
+
+__global__ __launch_bounds__(kCsvBlock) void k_csv_mark_write(const uint8_t* __restrict__ buf, uint64_t n,
+                                                             const uint32_t* __restrict__ tile_trans,
+                                                             const uint8_t* __restrict__ tile_state,
+                                                             const uint64_t* __restrict__ tile_offsets,
+                                                             uint64_t* __restrict__ row_start) {
+  __shared__ uint32_t wave_tot[kCsvBlock / 64];
+  __shared__ uint32_t wave_cnt[kCsvBlock / 64];
+  csv_mark_tile<true>((int64_t)blockIdx.x, !(tile_trans[blockIdx.x] & kCsvTileUnknown), buf, n, tile_state, nullptr, tile_offsets,
+                      row_start, wave_tot, wave_cnt);
 }
 
 // ---- cells -----------------------------------------------------------------------------------------
@@ -467,25 +562,29 @@ __global__ __launch_bounds__(kBlock) void k_csv_utf8_gather(const uint8_t* __res
 }
 
 // ---- host launchers -----------------------------------------------------------------------------------
-hipError_t launch_csv_boundaries_count(const uint8_t* buf, uint64_t n, uint32_t* tile_trans, uint8_t* tile_state,
+hipError_t launch_csv_boundaries_count(const uint8_t* buf, uint64_t n, uint32_t* tile_trans, uint32_t* block_vec, uint8_t* tile_state,
                                        uint32_t* tile_counts, hipStream_t s) {
   const int64_t n_tiles = (int64_t)((n + kCsvTile - 1) / kCsvTile);
   if (n_tiles <= 0) return hipSuccess;
-  Scope sc(KID_CSV, s, (double)n * 2);
+  Scope sc(KID_CSV, s, (double)n);
+  const int64_t n_blocks = (n_tiles + 1023) / 1024;  // block_vec: one word per 1024 tiles
   hipLaunchKernelGGL(k_csv_tile_trans, dim3((unsigned)n_tiles), dim3(kCsvBlock), 0, s, buf, n, tile_trans);
-  hipLaunchKernelGGL(k_csv_tile_scan, dim3(1), dim3(1024), 0, s, tile_trans, n_tiles, tile_state);
-  hipLaunchKernelGGL(k_csv_mark<false>, dim3((unsigned)n_tiles), dim3(kCsvBlock), 0, s, buf, n, tile_state, tile_counts,
-                     (const uint64_t*)nullptr, (uint64_t*)nullptr);
+  hipLaunchKernelGGL(k_csv_tile_scan_totals, dim3((unsigned)n_blocks), dim3(1024), 0, s, (const uint32_t*)tile_trans, n_tiles, block_vec);
+  hipLaunchKernelGGL(k_csv_tile_scan_blocks, dim3(1), dim3(1024), 0, s, block_vec, n_blocks);
+  hipLaunchKernelGGL(k_csv_tile_scan_apply, dim3((unsigned)n_blocks), dim3(1024), 0, s, (const uint32_t*)tile_trans, n_tiles,
+                     (const uint32_t*)block_vec, tile_state, tile_counts);
+  hipLaunchKernelGGL(k_csv_count_unknown, dim3((unsigned)((n_tiles + kCsvBlock - 1) / kCsvBlock)), dim3(kCsvBlock), 0, s, buf, n,
+                     (const uint32_t*)tile_trans, n_tiles, (const uint8_t*)tile_state, tile_counts);
   return hipGetLastError();
 }
 
-hipError_t launch_csv_boundaries_write(const uint8_t* buf, uint64_t n, const uint8_t* tile_state,
+hipError_t launch_csv_boundaries_write(const uint8_t* buf, uint64_t n, const uint32_t* tile_trans, const uint8_t* tile_state,
                                        const uint64_t* tile_offsets, uint64_t* row_start, hipStream_t s) {
   const int64_t n_tiles = (int64_t)((n + kCsvTile - 1) / kCsvTile);
   if (n_tiles <= 0) return hipSuccess;
   Scope sc(KID_CSV, s, (double)n);
-  hipLaunchKernelGGL(k_csv_mark<true>, dim3((unsigned)n_tiles), dim3(kCsvBlock), 0, s, buf, n, tile_state,
-                     (uint32_t*)nullptr, tile_offsets, row_start);
+  hipLaunchKernelGGL(k_csv_mark_write, dim3((unsigned)n_tiles), dim3(kCsvBlock), 0, s, buf, n, tile_trans, tile_state, tile_offsets,
+                     row_start);
   return hipGetLastError();
 }
 

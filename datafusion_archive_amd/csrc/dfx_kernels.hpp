@@ -181,9 +181,9 @@ hipError_t launch_partition_agg(const DevTable& T, const DevPartition& PT, const
 //   boundaries_count: tile_trans / tile_state / tile_counts have one entry per csv_tile_bytes() of text;
 //   (scan tile_counts into tile_offsets, total = number of records) then boundaries_write fills row_start[0..total).
 int64_t csv_tile_bytes();
-hipError_t launch_csv_boundaries_count(const uint8_t* buf, uint64_t n, uint32_t* tile_trans, uint8_t* tile_state,
+hipError_t launch_csv_boundaries_count(const uint8_t* buf, uint64_t n, uint32_t* tile_trans, uint32_t* block_vec, uint8_t* tile_state,
                                        uint32_t* tile_counts, hipStream_t s);
-hipError_t launch_csv_boundaries_write(const uint8_t* buf, uint64_t n, const uint8_t* tile_state,
+hipError_t launch_csv_boundaries_write(const uint8_t* buf, uint64_t n, const uint32_t* tile_trans, const uint8_t* tile_state,
                                        const uint64_t* tile_offsets, uint64_t* row_start, hipStream_t s);
 hipError_t launch_csv_count_fields(const uint8_t* buf, const uint64_t* row_start, int64_t row, uint32_t* out,
                                    hipStream_t s);
