@@ -220,7 +220,7 @@ Status CsvRelation::next(DeviceBatch* out, bool* has) {
   out->num_rows = nb;
   out->columns.clear();
   out->columns.resize((size_t)nc);
-  std::vector<std::shared_ptr<void>> lens((size_t)nc);
+  std::vector<std::shared_ptr<void>> lens((size_t)nc), starts((size_t)nc);  // Utf8: cell lengths, cell positions in the text
   for (int c = 0; c < nc; ++c) {
     DeviceColumn& col = out->columns[c];
     col.dtype = schema_.fields[c].dtype;
@@ -236,6 +236,9 @@ Status CsvRelation::next(DeviceBatch* out, bool* has) {
       lens[c] = device_alloc(sizeof(int32_t) * (size_t)(nb + 1), &st);
       if (!lens[c]) return st;
       plan.col[c].lens = (int32_t*)lens[c].get();
+      starts[c] = device_alloc(sizeof(uint64_t) * (size_t)nb, &st);
+      if (!starts[c]) return st;
+      plan.col[c].values = starts[c].get();
       continue;
     }
     const size_t vbytes = col.dtype == DFX_BOOLEAN ? words * 8 : (size_t)nb * dtype_width(col.dtype);
@@ -279,7 +282,7 @@ Status CsvRelation::next(DeviceBatch* out, bool* has) {
     if (total < 0) return Status::Err(DFX_EXECUTION_ERROR, "Utf8 column of a CSV batch exceeds 2 GB (Arrow Utf8 offsets are 32-bit)");
     auto data = device_alloc((size_t)std::max<int32_t>(total, 8), &st);
     if (!data) return st;
-    DFX_HIP(launch_csv_utf8_gather(buf, rs, next_record_, nb, c, (const int32_t*)offs.get(), (uint8_t*)data.get(), s));
+    DFX_HIP(launch_csv_utf8_gather(buf, rs, next_record_, nb, c, (const int32_t*)offs.get(), (const uint64_t*)starts[c].get(), (uint8_t*)data.get(), s));
     col.offsets = (const int32_t*)offs.get();
     col.data = (const uint8_t*)data.get();
     col.data_bytes = total;

@@ -320,7 +320,7 @@ struct DevDict {
 // ---- CSV source (dfx_k_csv.hip) -------------------------------------------------------------------------
 constexpr int kCsvMaxCols = 32;
 struct DevCsvCol {
-  void* values;        // fixed width: nb values; Boolean: (nb + 63) / 64 bitmap words
+  void* values;        // fixed width: nb values; Boolean: (nb + 63) / 64 bitmap words; Utf8: u64 per record, where the gather finds the cell
   uint64_t* validity;  // (nb + 63) / 64 words (not used for Utf8: csv cells of a Utf8 column are never null)
   int32_t* lens;       // Utf8: unescaped length per record
   uint8_t dtype;

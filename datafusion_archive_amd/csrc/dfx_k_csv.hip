@@ -332,22 +332,20 @@ __global__ void k_csv_count_fields(const uint8_t* __restrict__ buf, const uint64
 // ---- k_csv_parse: one wave per tile of 64 consecutive records ---------------------------------------------
 // The records of a tile are contiguous text [row_start[first], row_start[first + 64]).  The wave-cooperative path
 // (every tile whose text has no quote, fits the wave's LDS window and has the header's field count in every record):
-//   A  the wave copies the tile's text into LDS with coalesced 16-byte loads; on the way every lane turns its 16 bytes
-//      into SWAR masks (',' / terminator / '"'), a wave prefix sum of the popcounts numbers the STRUCTURAL bytes
-//      (delimiters, and the first terminator after a record's last cell) and their offsets go to an LDS list.  With
-//      `expected_fields` = F, record i owns list entries [i F, (i + 1) F): F - 1 delimiters and one record end.  A lane
-//      checks exactly that for its record; one failing lane sends the tile down the general path below.
+//   A  the wave copies the tile's text into LDS with coalesced 16-byte loads.  Then every lane reads ITS record out of LDS
+//      eight bytes at a time: a SWAR mask of the delimiters gives the cell boundaries (to an LDS list, F entries per record
+//      for `expected_fields` = F: F - 1 delimiters and the record's end), another says whether there is a quote.  Without a
+//      quote a record is its bytes up to the terminators that precede the next record's start, so its end needs no search.
+//      A lane whose record has a quote or not exactly F - 1 delimiters sends the tile down the general path below.
+//      (Round 5 first numbered the structural bytes cooperatively -- per-16-byte masks, a wave prefix sum, a list in text
+//      order: 1 390 vector instructions per tile, the kernel was VALU-bound; the per-lane walk over LDS words needs a third.)
 //   B  a wave-uniform loop over the columns: all 64 lanes convert the cell of the SAME column together (one dtype, one
 //      code path), reading its bytes from LDS.
 // The general path (quotes, a tile longer than the window, a record with another field count -- which is the error the
 // reference reports): every lane walks its own record once from global memory and only RECORDS where its cells are
 // (LDS: content offset + length / flags per column), then phase B runs on those, reading global memory.  Converting
 // inside the walk ran the conversions one lane at a time (measured 6.7x slower, round 1).
-constexpr int kCsvTextCapMax = 16384;  // list entries are 15-bit offsets into the window
-
-DEV uint32_t csv_eq_mask16(const uint4& v, uint32_t c4) {
-  return csv_eq_nibble(v.x, c4) | (csv_eq_nibble(v.y, c4) << 4) | (csv_eq_nibble(v.z, c4) << 8) | (csv_eq_nibble(v.w, c4) << 12);
-}
+constexpr int kCsvTextCapMax = 16384;  // list entries are 16-bit offsets into the window
 
 // phase B.  FAST: cells come from the structural list, bytes from the LDS window; else from cell_off / cell_len + global memory
 template <bool FAST>
@@ -363,8 +361,8 @@ DEV void csv_convert_cells(const uint8_t* __restrict__ buf, const DevCsvPlan& pl
     uint32_t off = 0, lw = 0;
     if (have) {
       if (FAST) {
-        off = c == 0 ? first_off : (uint32_t)(spos[(uint32_t)lane * F + (uint32_t)c - 1u] & 0x7FFFu) + 1u;
-        lw = (uint32_t)(spos[(uint32_t)lane * F + (uint32_t)c] & 0x7FFFu) - off;
+        off = c == 0 ? first_off : (uint32_t)spos[(uint32_t)lane * F + (uint32_t)c - 1u] + 1u;
+        lw = (uint32_t)spos[(uint32_t)lane * F + (uint32_t)c] - off;
       } else {
         off = cell_off[c * 64 + lane];
         lw = cell_len[c * 64 + lane];
@@ -372,7 +370,12 @@ DEV void csv_convert_cells(const uint8_t* __restrict__ buf, const DevCsvPlan& pl
     }
     const uint32_t ulen = lw & 0x3FFFFFFFu;
     if (col.dtype == T_UTF8) {  // Some(s) => append_string(s): never null ("" when the record is short)
-      if (inb) col.lens[tid] = (int32_t)ulen;
+      if (inb) {
+        col.lens[tid] = (int32_t)ulen;
+        // where the gather finds the bytes: the content's position in the text, or (bit 63) "walk the record": doubled quotes
+        // or bytes after the closing quote make the content something other than a span of the text
+        ((uint64_t*)col.values)[tid] = (lw & 0x80000000u) ? (1ull << 63) : (FAST ? begin - first_off : begin) + off;
+      }
       continue;
     }
     bool valid = false;
@@ -458,65 +461,38 @@ __global__ __launch_bounds__(kBlock) void k_csv_parse(const uint8_t* __restrict_
     uint8_t* text = wl;
     uint16_t* spos = (uint16_t*)(wl + text_cap);
     const uint32_t span = (uint32_t)span64;
-    const uint32_t skew = (uint32_t)(tb - base);
-    const uint32_t cap = (uint32_t)nrec * F;
-    uint32_t total = 0;     // structural bytes so far (wave-uniform)
-    uint32_t prev_top = 0;  // was the last byte of the previous 1 KB step a non-terminator
-    bool quote = false;
-    for (uint32_t o = 0; o < span; o += 1024u) {
-      const uint32_t my = o + (uint32_t)lane * 16u;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      uint32_t vm = 0;  // bytes of [tb, te) among my 16
-      if (my < span) {
-        v = *(const uint4*)(buf + base + my);  // the text buffer is padded to a multiple of 64 bytes
-        *(uint4*)(text + my) = v;
-        vm = span - my >= 16u ? 0xFFFFu : (1u << (span - my)) - 1u;
-        if (my < skew) vm &= 0xFFFFu << skew;
-      }
-      const uint32_t mc = csv_eq_mask16(v, 0x2C2C2C2Cu);
-      const uint32_t mt = csv_eq_mask16(v, 0x0A0A0A0Au) | csv_eq_mask16(v, 0x0D0D0D0Du);
-      quote |= (csv_eq_mask16(v, 0x22222222u) & vm) != 0;
-      const uint32_t nt = ~mt & 0xFFFFu;
-      uint32_t before = (uint32_t)__shfl_up((int)(nt >> 15), 1, 64);
-      if (lane == 0) before = prev_top;
-      const uint32_t rend = mt & ((nt << 1) | before);  // a terminator right after a non-terminator ends a record
-      uint32_t sm = (mc | rend) & vm;
-      const uint32_t cnt = (uint32_t)__popc(sm);
-      uint32_t inc = cnt;
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t x = (uint32_t)__shfl_up((int)inc, d, 64);
-        if (lane >= d) inc += x;
-      }
-      uint32_t idx = total + inc - cnt;
-      while (sm) {
-        const uint32_t k = (uint32_t)__ffs((int)sm) - 1u;
-        if (idx < cap) spos[idx] = (uint16_t)((my + k) | (((rend >> k) & 1u) << 15));
-        ++idx;
-        sm &= sm - 1u;
-      }
-      total += (uint32_t)__shfl((int)inc, 63, 64);
-      prev_top = (uint32_t)__shfl((int)(nt >> 15), 63, 64);
-    }
+    for (uint32_t my = (uint32_t)lane * 16u; my < span; my += 1024u)
+      *(uint4*)(text + my) = *(const uint4*)(buf + base + my);  // the text buffer is padded to a multiple of 64 bytes
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // the last record of a file that does not end in a terminator ends at the end of the input
-    const uint8_t last = text[span - 1u];
-    if (last != '\n' && last != '\r') {
-      if (lane == 0 && total < cap) spos[total] = (uint16_t)(span | 0x8000u);
-      ++total;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    bool ok = true;
+    if (inb) {
+      const uint32_t b = (uint32_t)(begin - base);
+      uint32_t e = (uint32_t)(limit - base);
+      // the terminators (and blank lines) between this record and the next; a file may end without one
+      while (e > b && (text[e - 1u] == '\n' || text[e - 1u] == '\r')) --e;
+      const uint64_t ones = 0x0101010101010101ull, low7 = 0x7F7F7F7F7F7F7F7Full, high = 0x8080808080808080ull;
+      uint32_t found = 0;
+      bool quote = false;
+      for (uint32_t p = b; p < e; p += 8u) {
+        const uint64_t w = np_load8(text + p);
+        const uint32_t left = e - p;
+        const uint64_t keep = left >= 8u ? ~0ull : (1ull << (8u * left)) - 1ull;
+        const uint64_t xc = w ^ (ones * 0x2Cu), xq = w ^ (ones * 0x22u);
+        uint64_t zc = ~(((xc & low7) + low7) | xc) & high & keep;  // bit 7 of every byte that is a delimiter (exact)
+        quote = quote || ((xq - ones) & ~xq & high & keep) != 0ull;  // some byte is a quote (a borrow only reaches bytes above one)
+        while (zc) {
+          const uint32_t k = (uint32_t)(__ffsll((long long)zc) - 1) >> 3;
+          if (found + 1u < F) spos[(uint32_t)lane * F + found] = (uint16_t)(p + k);
+          ++found;
+          zc &= zc - 1ull;
+        }
+      }
+      spos[(uint32_t)lane * F + F - 1u] = (uint16_t)e;
+      ok = !quote && found + 1u == F;
     }
-    fast = __ballot(quote) == 0ull && total == cap;
-    if (fast) {
-      bool okv = true;
-      if (inb)
-        for (uint32_t c = 0; c < F; ++c) okv = okv && (uint32_t)(spos[(uint32_t)lane * F + c] >> 15) == (c + 1u == F ? 1u : 0u);
-      fast = __ballot(!okv) == 0ull;
-    }
+    fast = __ballot(!ok) == 0ull;
     if (fast) {
       csv_convert_cells<true>(buf, plan, r0, nb, tid, inb, (int)F, begin, (uint32_t)(begin - base), text, spos, nullptr,
                               nullptr, err);
@@ -548,17 +524,38 @@ __global__ __launch_bounds__(kBlock) void k_csv_parse(const uint8_t* __restrict_
   if (err != ~0ull) atomicMin((unsigned long long*)plan.err, (unsigned long long)err);
 }
 
-// Utf8 column `field`: unescaped bytes of every record's cell -> out + offsets[row]
+// Utf8 column `field`: unescaped bytes of every record's cell -> out + offsets[row].  k_csv_parse left the position of every
+// cell whose content is a span of the text (`starts`): those are copied eight bytes at a time; the others are walked.
 __global__ __launch_bounds__(kBlock) void k_csv_utf8_gather(const uint8_t* __restrict__ buf,
                                                            const uint64_t* __restrict__ row_start, int64_t r0,
                                                            int64_t nb, int field, const int32_t* __restrict__ offsets,
-                                                           uint8_t* __restrict__ out) {
+                                                           const uint64_t* __restrict__ starts, uint8_t* __restrict__ out) {
   const int64_t tid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (tid >= nb) return;
-  uint8_t* dst = out + offsets[tid];
-  csv_walk_record(buf, row_start[r0 + tid], row_start[r0 + tid + 1], [&](int fi, const CsvField& f) {
-    if (fi == field) csv_copy_field(buf, f, dst);
-  });
+  const int32_t o = offsets[tid];
+  uint8_t* dst = out + o;
+  const uint64_t st = starts[tid];
+  if (st >> 63) {
+    csv_walk_record(buf, row_start[r0 + tid], row_start[r0 + tid + 1], [&](int fi, const CsvField& f) {
+      if (fi == field) csv_copy_field(buf, f, dst);
+    });
+    return;
+  }
+  const uint8_t* src = buf + st;
+  const int32_t len = offsets[tid + 1] - o;
+  int32_t i = 0;
+  for (; i + 8 <= len; i += 8) {
+    uint64_t w;
+    __builtin_memcpy(&w, src + i, 8);
+    __builtin_memcpy(dst + i, &w, 8);
+  }
+  if (i + 4 <= len) {
+    uint32_t w;
+    __builtin_memcpy(&w, src + i, 4);
+    __builtin_memcpy(dst + i, &w, 4);
+    i += 4;
+  }
+  for (; i < len; ++i) dst[i] = src[i];
 }
 
 // ---- host launchers -----------------------------------------------------------------------------------
@@ -622,12 +619,12 @@ hipError_t launch_csv_parse(const uint8_t* buf, const uint64_t* row_start, int64
 }
 
 hipError_t launch_csv_utf8_gather(const uint8_t* buf, const uint64_t* row_start, int64_t r0, int64_t nb, int field,
-                                  const int32_t* offsets, uint8_t* out, hipStream_t s) {
+                                  const int32_t* offsets, const uint64_t* starts, uint8_t* out, hipStream_t s) {
   if (nb <= 0) return hipSuccess;
   Scope sc(KID_CSV, s, 0);
   const int64_t blocks = (nb + kBlock - 1) / kBlock;
   hipLaunchKernelGGL(k_csv_utf8_gather, dim3((unsigned)blocks), dim3(kBlock), 0, s, buf, row_start, r0, nb, field,
-                     offsets, out);
+                     offsets, starts, out);
   return hipGetLastError();
 }
 

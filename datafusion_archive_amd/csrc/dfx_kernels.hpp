@@ -190,7 +190,7 @@ hipError_t launch_csv_count_fields(const uint8_t* buf, const uint64_t* row_start
 hipError_t launch_csv_parse(const uint8_t* buf, const uint64_t* row_start, int64_t r0, int64_t nb,
                             const DevCsvPlan& plan, double avg_record_bytes, int wave_tiles, double algo_bytes, hipStream_t s);
 hipError_t launch_csv_utf8_gather(const uint8_t* buf, const uint64_t* row_start, int64_t r0, int64_t nb, int field,
-                                  const int32_t* offsets, uint8_t* out, hipStream_t s);
+                                  const int32_t* offsets, const uint64_t* starts, uint8_t* out, hipStream_t s);
 
 // ORDER BY (dfx_k_sort.hip): order-preserving key images, stable LSD radix sort of (image, row) pairs, gathers
 hipError_t launch_sort_image(const void* values, const uint8_t* validity, int64_t bit_offset, uint8_t dtype, int asc, int64_t n,

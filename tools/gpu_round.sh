@@ -17,8 +17,34 @@ case $STAGE in
 csv)
   timeout 900 python -m pytest tests/test_gpu_csv.py -m gpu -q --timeout 600 > $OUT/pytest_csv.log 2>&1; echo "csv tests rc=$?"; tail -n 12 $OUT/pytest_csv.log | cut -c1-400
   timeout 600 python tools/csv_bench.py 1024 > $OUT/csv_bench.txt 2>&1; echo "csv bench rc=$?"; tail -n 4 $OUT/csv_bench.txt | cut -c1-400
+  (cd /tmp && DFX_NO_TORCH=1 timeout 600 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/stats_csvstr -o out -- python $R/tools/csv_bench.py 1024 4194304 str > $OUT/csv_bench_str.txt 2>&1); grep "MB," $OUT/csv_bench_str.txt | tail -n 2 | cut -c1-400
+  cp $OUT/stats_csvstr/out_kernel_stats.csv $OUT/csv_str_kernel_stats.csv 2>/dev/null; grep -m3 "csv" $OUT/csv_str_kernel_stats.csv | cut -c1-200
   (cd /tmp && DFX_NO_TORCH=1 timeout 600 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/stats_csv -o out -- python $R/tools/csv_bench.py 1024 > /dev/null 2>&1)
   cp $OUT/stats_csv/out_kernel_stats.csv $OUT/csv_kernel_stats.csv 2>/dev/null; head -n 12 $OUT/csv_kernel_stats.csv | cut -c1-200
+  ;;
+csvpmc)
+  # SQ counters of the CSV kernels on 256 MB of text (per 64-record tile for k_csv_parse)
+  cd /tmp; export DFX_NO_TORCH=1
+  for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU" "SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT"; do
+    n=$(echo $set | cut -c1-12 | tr ' ' '_')
+    timeout 600 rocprofv3 --output-format csv --pmc $set -d $OUT/csvpmc_$n -o out -- python $R/tools/csv_bench.py 256 > /dev/null 2>&1
+  done
+  cd $OUT
+  python3 - <<'PY'
+import csv, glob, collections
+agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
+for f in glob.glob("csvpmc_*/**/*counter_collection*.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0]
+        if "csv" not in k: continue
+        agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[(k, r["Counter_Name"])] += 1
+tiles = 3 * (4645000 + 63) // 64  # three passes of csv_bench over 4.645e6 records
+with open("csv_counters.txt", "w") as out:
+    for k, v in sorted(agg.items()):
+        line = k[:60] + "  " + "  ".join(f"{c}={x:.3g}" + (f" ({x / tiles:.1f}/tile)" if "k_csv_parse" in k else "") for c, x in sorted(v.items()))
+        print(line[:1500]); out.write(line + "\n")
+PY
+  find . -name "*counter_collection*.csv" -size +2000k -delete 2>/dev/null
   ;;
 suite)
   timeout 2400 python -m pytest tests -m gpu -q --timeout 900 > $OUT/pytest_gpu.log 2>&1; echo "gpu suite rc=$?"; tail -n 8 $OUT/pytest_gpu.log | cut -c1-300
