@@ -193,6 +193,37 @@ struct AggregateRelation::Impl {
   Status drain();
   Status emit_grouped(DeviceBatch* out, int64_t expected);
   std::shared_ptr<void> emit_total;  // pinned: the scan's group count
+  // The key column ahead of time (agg.early_keys).  The result download is the one part of a query that cannot start before its
+  // last kernel -- except for the keys: once every group exists, the key column is final.  When the group count has not changed
+  // between two consecutive control-block snapshots, the compaction of the key plane and its copy to pinned memory are queued on
+  // the side stream while the scan goes on.  At emit the copy is valid iff no group was added since (groups are never removed: the
+  // count then differs) and the table was not replaced; it is attached to the key column and the exporter hands it out.
+  struct EarlyKeys {
+    bool armed = false;
+    uint64_t occupied = 0;    // group count it was made for
+    uint64_t generation = 0;  // table generation it was made from
+    size_t bytes = 0;
+    std::shared_ptr<void> host, total;          // pinned: the column, the compaction's own group count
+    std::vector<std::shared_ptr<void>> scratch;  // device buffers the side stream is still using
+    hipEvent_t done = nullptr, start = nullptr;
+    void wait() {
+      if (armed && done) (void)hipEventSynchronize(done);
+    }
+    void cancel() {  // before the table it reads is replaced or released
+      wait();
+      armed = false;
+      scratch.clear();
+      host.reset();
+    }
+    ~EarlyKeys() {
+      wait();
+      if (done) (void)hipEventDestroy(done);
+      if (start) (void)hipEventDestroy(start);
+    }
+  } early;
+  uint64_t table_generation = 0;
+  uint64_t early_last_occupied = ~0ull;  // the group count of the previous snapshot
+  Status early_keys_maybe();
   Status emit_ungrouped(DeviceBatch* out);
   Status read_ctrl(uint32_t* host_ctrl);
   Status post_ctrl(int64_t rows);
@@ -978,6 +1009,8 @@ Status AggregateRelation::Impl::grow_and_replay(uint64_t occupied, uint64_t spil
     DFX_HIP(launch_rehash(view_of(Told, accs_full, c), view_of(Tn, accs_full_new, c), no_spill, s));
   }
   if (spilled > replay_from) DFX_HIP(launch_merge_rows(spill, (int64_t)replay_from, (int64_t)(spilled - replay_from), Tn, no_spill, s));
+  early.cancel();  // (its kernels read the old table)
+  ++table_generation;
   T = Tn;
   accs_full = accs_full_new;
   table_owners = owners;  // old buffers return to the pool once the stream has passed them
@@ -1284,6 +1317,7 @@ Status AggregateRelation::Impl::consume_batch_chunk(const DeviceBatch& b) {
     const int prev = (int)((batch_seq & 1) ^ 1);
     DFX_RETURN_IF_ERROR(post_ctrl(n));       // snapshot of THIS batch, examined after the next launch
     DFX_RETURN_IF_ERROR(examine_ctrl(prev)); // the previous batch's snapshot (normally complete by now)
+    DFX_RETURN_IF_ERROR(early_keys_maybe());
   }
   rows_seen += n;
   if (stop_after_decision) decided_rows = n;  // (a batch too small for a calibration slice: it ran whole, decided afterwards)
@@ -1627,6 +1661,70 @@ Status AggregateRelation::Impl::emit_ungrouped(DeviceBatch* out) {  // aggregate
   return Status::OK();
 }
 
+// Queues the key column's compaction and download on the side stream when the group count has stopped changing (see EarlyKeys).
+Status AggregateRelation::Impl::early_keys_maybe() {
+  const uint64_t prev = early_last_occupied;
+  early_last_occupied = occupied_known;
+  if (early.armed && early.generation == table_generation && early.occupied == occupied_known) return Status::OK();  // still good
+  if (!opt().early_keys || !opt().emit_async || !use_partition || kw != 1 || kw_out != 1 || !dicts.empty() || chunks.size() != 1)
+    return Status::OK();
+  if (occupied_known < 32768 || occupied_known != prev) return Status::OK();  // small results are not worth it; still growing
+  early.cancel();
+  hipStream_t aux = ctx().aux;
+  Status st;
+  const int64_t g = (int64_t)occupied_known;
+  const int64_t n_slots = (int64_t)T.mask + 2;
+  const int64_t n_words = (n_slots + 63) / 64;
+  const int64_t n_tiles = (n_slots + kTileRows - 1) / kTileRows;
+  const int dt = key_dtype[0];
+  auto mask = device_alloc(sizeof(uint64_t) * (size_t)n_words, &st);
+  if (!mask) return st;
+  auto counts = device_alloc(sizeof(uint32_t) * (size_t)n_tiles, &st);
+  if (!counts) return st;
+  auto offsets = device_alloc(sizeof(uint64_t) * (size_t)(n_tiles + 1), &st);
+  if (!offsets) return st;
+  auto tmp = device_alloc(sizeof(uint64_t) * (size_t)(n_tiles / 4096 + 4), &st);
+  if (!tmp) return st;
+  auto vals = device_alloc((size_t)g * dtype_width(dt), &st);
+  if (!vals) return st;
+  early.bytes = (size_t)g * dtype_width(dt);
+  early.host = pinned_alloc(early.bytes, &st);
+  if (!early.host) return st;
+  if (!early.total) {
+    early.total = pinned_alloc(sizeof(uint64_t), &st);
+    if (!early.total) return st;
+  }
+  *(uint64_t*)early.total.get() = ~0ull;
+  if (!early.done) DFX_HIP(hipEventCreateWithFlags(&early.done, hipEventDisableTiming));
+  if (!early.start) DFX_HIP(hipEventCreateWithFlags(&early.start, hipEventDisableTiming));
+  early.scratch = {mask, counts, offsets, tmp, vals};
+  // The side stream starts behind everything queued on the main stream so far: the pool hands out blocks whose previous users may
+  // still be queued there.  It is not ordered against what comes LATER: whatever those kernels add to the table makes the final
+  // group count differ from `g`, and the copy is dropped.
+  DFX_HIP(hipEventRecord(early.start, ctx().stream));
+  DFX_HIP(hipStreamWaitEvent(aux, early.start, 0));
+  DFX_HIP(launch_table_mask(T, (uint64_t*)mask.get(), (uint32_t*)counts.get(), aux));
+  DFX_HIP(launch_scan_u32((const uint32_t*)counts.get(), (uint64_t*)offsets.get(), n_tiles, (uint64_t*)tmp.get(), aux));
+  DFX_HIP(hipMemcpyAsync(early.total.get(), (uint64_t*)offsets.get() + n_tiles, sizeof(uint64_t), hipMemcpyDeviceToHost, aux));
+  DFX_HIP(launch_fill_u64(T.keys + T.mask + 1, kEmptyKey, 1, aux));  // (as emit_grouped: the sentinel group's key word; always this constant)
+  if (dtype_width(dt) == 8) {
+    DFX_HIP(launch_compact(T.keys, 8, (const uint64_t*)mask.get(), (const uint64_t*)offsets.get(), n_slots, vals.get(), 0, aux, (uint64_t)g));
+  } else {
+    auto dense = device_alloc(sizeof(uint64_t) * (size_t)g, &st);
+    if (!dense) return st;
+    early.scratch.push_back(dense);
+    DFX_HIP(launch_compact(T.keys, 8, (const uint64_t*)mask.get(), (const uint64_t*)offsets.get(), n_slots, dense.get(), 0, aux, (uint64_t)g));
+    DFX_HIP(launch_finalize((const uint64_t*)dense.get(), g, (uint8_t)dt, (uint8_t)VT_RAW, vals.get(), aux));
+  }
+  DFX_HIP(launch_copy_to_host(vals.get(), early.host.get(), early.bytes, aux));
+  DFX_HIP(hipEventRecord(early.done, aux));
+  early.armed = true;
+  early.occupied = occupied_known;
+  early.generation = table_generation;
+  ++counters().agg_early_keys;
+  return Status::OK();
+}
+
 Status AggregateRelation::Impl::emit_grouped(DeviceBatch* out, int64_t expected) {  // aggregate.rs:877-951
   ScopedUs t_emit(&counters().agg_emit_us);
   hipStream_t s = ctx().stream;
@@ -1730,6 +1828,20 @@ Status AggregateRelation::Impl::emit_grouped(DeviceBatch* out, int64_t expected)
   if ((int64_t)*total != g) {
     if (expected < 0) return Status::Err(DFX_INTERNAL_ERROR, "group count changed during emit");
     return emit_grouped(out, -1);  // the host's count was stale: redo with the table's own
+  }
+  if (early.armed) {  // the key column copied ahead of time: valid iff it was made from this table with this many groups
+    early.wait();
+    DeviceColumn& kc = out->columns[0];
+    if (early.generation == table_generation && early.occupied == (uint64_t)g && *(const uint64_t*)early.total.get() == (uint64_t)g &&
+        early.bytes == (size_t)g * dtype_width(kc.dtype) && kc.values != nullptr) {
+      kc.host_values = early.host;
+      kc.host_values_of = kc.values;
+      kc.host_bytes = early.bytes;
+      ++counters().agg_early_keys_used;
+    }
+    early.armed = false;
+    early.scratch.clear();
+    early.host.reset();
   }
   return Status::OK();
 }
@@ -2240,6 +2352,8 @@ Status AggregateRelation::partial_import(const void* src_device, const int64_t* 
     off += (uint64_t)counts[b];
   }
   DFX_HIP(hipStreamSynchronize(s));
+  m.early.cancel();
+  ++m.table_generation;
   m.T = Tn;
   m.accs_full = accs_full_new;
   m.table_owners = owners;

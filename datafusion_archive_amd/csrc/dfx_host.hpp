@@ -126,6 +126,9 @@ struct Counters {
   long long agg_alloc_us = 0;       // routing scratch / spill list / table allocation
   long long export_us = 0;          // device batch -> host Arrow (allocation of the pinned result buffers, D2H, synchronisation)
   long long export_alloc_us = 0;    // ... of which: result buffer allocation (pinned pool)
+  long long export_host_ready = 0;  // result columns the exporter found already on the host (early key download)
+  long long agg_early_keys = 0;     // speculative key-column downloads started ...
+  long long agg_early_keys_used = 0;  // ... and still valid at emit
   long long agg_pass2_launches = 0;
   long long agg_growths = 0;
   // dfx_aggregate_exchange, per rank (bench.py --gpus N: extra.phases_ms): where a multi-GPU step's wall time goes
@@ -165,6 +168,12 @@ struct DeviceColumn {
   int64_t data_bytes = 0;            // Utf8: bytes referenced (offsets[length] - offsets[0])
   std::vector<std::shared_ptr<void>> owners;  // keeps the buffers alive
   bool absent = false;  // projection push-down: the consumer declared it never reads this column (no buffers)
+  // A COMPLETE pinned host copy of `values` that its producer already made (the aggregate's key column, downloaded while
+  // the scan was still running): the exporter hands it out instead of copying.  Honoured only while `values` still is the
+  // pointer the copy was made from (a slice of the column moves `values` and so drops it).
+  std::shared_ptr<void> host_values;
+  const void* host_values_of = nullptr;
+  size_t host_bytes = 0;
 };
 
 struct DeviceBatch {

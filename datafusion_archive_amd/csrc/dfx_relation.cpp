@@ -607,6 +607,15 @@ Status download_column(const DeviceColumn& c, struct ArrowArray* out, std::vecto
     out->n_buffers = 2;
   } else {
     const size_t bytes = (size_t)n * dtype_width(c.dtype);
+    if (c.host_values && c.host_values_of == c.values && c.host_bytes == bytes && bytes) {  // already on the host (see DeviceColumn)
+      p->pinned.push_back(c.host_values);
+      p->buffer_ptrs.push_back(c.host_values.get());
+      out->n_buffers = 2;
+      out->buffers = p->buffer_ptrs.data();
+      out->null_count = 0;
+      ++counters().export_host_ready;
+      return Status::OK();
+    }
     void* raw = alloc_result(p, bytes);
     if (!raw) return Status::Err(DFX_EXECUTION_ERROR, "host allocation failed");
     // large fixed-width result columns (pinned destination): copied by a kernel on the query's stream when the option

@@ -80,6 +80,8 @@ struct AggOptions {
                                // measured no better for the filtered query and 17 % worse in pass 1 when every row is routed)
   int partition_producers = 0; // pass-1 workgroups of the ring flavour (0: one per CU)
   int hot_keys = -1;           // pass 1 hot-key pairs in LDS: -1 when the calibration slice saw skew, 0 never, 1 always
+  int early_keys = 1;          // 1: once the group count has stopped changing between two batches, the key column is compacted and copied
+                               // to the host on the side stream while the scan goes on; emit hands that copy out if no group was added since
   int emit_async = 1;          // 1: emit queues its compaction kernels with the host's group count and checks the table's afterwards
   int calibration_memo = 1;    // 1: a resident table remembers the outcome of an aggregate's calibration slice per program shape
   int pass2_stream = 1;        // pass 2 of one-aggregate queries: region-streaming kernel (0: the flattened-index kernel)

@@ -250,6 +250,7 @@ bool set_option_in(AggOptions& o, const char* key, int64_t value) {
   else if (!strcmp(key, "agg.pass2_stream")) o.pass2_stream = (int)value;
   else if (!strcmp(key, "agg.calibration_memo")) o.calibration_memo = (int)value;
   else if (!strcmp(key, "agg.emit_async")) o.emit_async = (int)value;
+  else if (!strcmp(key, "agg.early_keys")) o.early_keys = (int)value;
   else if (!strcmp(key, "agg.hot_keys")) o.hot_keys = (int)value;
   else if (!strcmp(key, "agg.partition_layout")) o.partition_layout = (int)value;
   else if (!strcmp(key, "agg.narrow_keys")) o.narrow_keys = (int)value;
@@ -448,6 +449,9 @@ int64_t dfx_counter_get(const char* name) {
   if (!strcmp(name, "filter_output_regrows")) return counters().filter_output_regrows;
   if (!strcmp(name, "filter_lookback_fallbacks")) return counters().filter_lookback_fallbacks;
   if (!strcmp(name, "csv_cells")) return counters().csv_cells;
+  if (!strcmp(name, "export_host_ready")) return counters().export_host_ready;
+  if (!strcmp(name, "agg_early_keys")) return counters().agg_early_keys;
+  if (!strcmp(name, "agg_early_keys_used")) return counters().agg_early_keys_used;
   if (!strcmp(name, "csv_tiles")) return counters().csv_tiles;
   if (!strcmp(name, "csv_general_tiles")) return counters().csv_general_tiles;
   if (!strcmp(name, "agg_ctrl_wait_us")) return counters().agg_ctrl_wait_us;

@@ -960,6 +960,62 @@ def test_partitioned_tile_sorted_pass1(narrow, defer):
     assert_groups_identical(got, oracle.aggregate([Column(0)], [a], [odd]), 1, f"tile pass 1, sentinel / wide / negative keys narrow={narrow}")
 
 
+def test_key_column_downloaded_while_the_scan_runs():
+    """agg.early_keys: once the group count has stopped changing between two batches the key column is compacted and copied
+    to pinned memory on the side stream while the scan goes on; emit hands that copy to the exporter when no group was added
+    since.  Result against the oracle with the copy used (8-byte and 4-byte keys), with the copy DROPPED because new keys
+    arrive in the last batch, and with the option off; the counters say which happened."""
+    ex.set_option("agg.strategy", 3)
+    ex.set_option("agg.partition_defer", 1)  # pass 2 after every batch: the groups exist from the first batch on
+    schema = pa.schema([("k", pa.int64()), ("v", pa.float64())])
+    syn = [("k", ex.SYNTH_I64_UNIFORM, 0, 100000.0, 0.0), ("v", ex.SYNTH_F64_EXACT, 1, 0.0, 0.0)]
+    n, seed = (1 << 23) + 4321, 0xEA51
+    t = ex.DeviceTable.synth(syn, seed, 0, n)
+    ob = oracle.synth_batch(syn, seed, 0, n)
+    aggs = [agg("sum", Column(1), F64)]
+    want = oracle.aggregate([Column(0)], aggs, [ob])
+    for on in (1, 0):
+        ex.set_option("agg.early_keys", on)
+        ex.counter_reset()
+        got = gpu_aggregate([Column(0)], aggs, schema, [], source=t.scan(1 << 20))
+        assert_groups_identical(got, want, 1, f"early keys {on}")
+        assert ex.counter_get("agg_early_keys") == (1 if on else 0)
+        assert ex.counter_get("agg_early_keys_used") == (1 if on else 0)
+        assert ex.counter_get("export_host_ready") == (1 if on else 0)
+    ex.set_option("agg.early_keys", 1)
+    # Int32 keys (the copy is made of the finalised 4-byte column), a predicate in front, MIN
+    rng = np.random.default_rng(77)
+    m = 1 << 21
+    k32 = rng.integers(-20000, 20000, m).astype(np.int32)
+    v = rng.integers(0, 1 << 20, m).astype(np.float64) / 64.0
+    whole = pa.RecordBatch.from_arrays([pa.array(k32), pa.array(v)], names=["k", "v"])
+    parts = [whole.slice(o, 1 << 18) for o in range(0, m, 1 << 18)]
+    pred = BinaryExpr(Column(1), Operator.Gt, lit(100.0))
+    ex.counter_reset()
+    got = gpu_aggregate([Column(0)], [agg("min", Column(1), F64)], whole.schema, parts, filter_expr=pred)
+    assert_groups_identical(got, oracle.aggregate([Column(0)], [agg("min", Column(1), F64)], [oracle.filter_next(pred, whole)]), 1, "early keys, Int32")
+    assert ex.counter_get("agg_early_keys_used") == 1 and ex.counter_get("export_host_ready") == 1
+    # new keys in the last batch: the copy was started and must be dropped
+    k = rng.integers(0, 50000, m).astype(np.int64)
+    k[-1000:] = rng.integers(50000, 50100, 1000)
+    whole = pa.RecordBatch.from_arrays([pa.array(k), pa.array(v)], names=["k", "v"])
+    parts = [whole.slice(o, 1 << 18) for o in range(0, m, 1 << 18)]
+    ex.counter_reset()
+    got = gpu_aggregate([Column(0)], aggs, whole.schema, parts)
+    assert_groups_identical(got, oracle.aggregate([Column(0)], aggs, [whole]), 1, "early keys dropped")
+    assert ex.counter_get("agg_early_keys") >= 1
+    assert ex.counter_get("agg_early_keys_used") == 0 and ex.counter_get("export_host_ready") == 0
+    # ... in the middle: a second copy is started once the count has settled again, and that one is used
+    k = rng.integers(0, 50000, m).astype(np.int64)
+    k[5 << 18:(5 << 18) + 1000] = rng.integers(50000, 50100, 1000)
+    whole = pa.RecordBatch.from_arrays([pa.array(k), pa.array(v)], names=["k", "v"])
+    parts = [whole.slice(o, 1 << 18) for o in range(0, m, 1 << 18)]
+    ex.counter_reset()
+    got = gpu_aggregate([Column(0)], aggs, whole.schema, parts)
+    assert_groups_identical(got, oracle.aggregate([Column(0)], aggs, [whole]), 1, "early keys restarted")
+    assert ex.counter_get("agg_early_keys") == 2 and ex.counter_get("agg_early_keys_used") == 1
+
+
 @pytest.mark.parametrize("hot", [0, 1])
 @pytest.mark.parametrize("layout", [0, 1])
 def test_partitioned_narrow_rows_hot_keys_and_deferred_pass2(hot, layout):
