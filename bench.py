@@ -142,6 +142,9 @@ def main():
                                                     Operator, ScalarValue)
 
     ex.init(dev_index)
+    for kv in filter(None, os.environ.get("DFX_BENCH_OPTIONS", "").split(",")):  # A/B runs: library options, e.g. agg.early_keys=0
+        k_, v_ = kv.split("=")
+        ex.set_option(k_.strip(), int(v_))
     coll_device = torch.device("cpu") if shared_gpu else device  # where the tiny bookkeeping collectives run
     info = ex.device_info()
     if args.rows > 0:
@@ -459,6 +462,59 @@ def main():
              "kernels": {k: {"launches": v["launches"], "total_ms": round(v["total_ms"], 3)} for k, v in prof.items()},
              "verified_sum_of_group_sums_equals_ungrouped_sum": verified, "device": info["name"],
              "groups": GROUPS, "selectivity": 0.2, "instrumented_ms_per_step": dt_instr / args.steps * 1e3}
+
+    def csv_leg(megabytes=1024, batch_rows=1 << 22):
+        import tempfile
+        rng_c = np.random.default_rng(1)
+        nb = 20000
+        cols_c = (rng_c.integers(0, 10**6, nb), rng_c.random(nb) * 100, rng_c.standard_normal(nb), rng_c.integers(-10**9, 10**9, nb))
+        block = "\n".join(f"{int(a)},{float(b)!r},{float(c)!r},{int(d)}" for a, b, c, d in zip(*cols_c)) + "\n"
+        reps = max(1, megabytes * 1000000 // len(block))
+        schema_c = pa.schema([("k", pa.int64()), ("lat", pa.float64()), ("lng", pa.float64()), ("w", pa.int64())])
+        aggs_c = [AggregateFunction("SUM", [Column(1)], DataType.Float64), AggregateFunction("COUNT", [Column(0)], DataType.UInt64),
+                  AggregateFunction("SUM", [Column(3)], DataType.Int64)]
+        with tempfile.NamedTemporaryFile("w", suffix=".csv", dir="/tmp", delete=False) as fh:
+            path = fh.name
+            fh.write("k,lat,lng,w\n")
+            for _ in range(reps):
+                fh.write(block)
+        try:
+            size, records = os.path.getsize(path), reps * nb
+            best = None
+            for _ in range(3):
+                ex.profile_reset()
+                ex.profile_enable(True)
+                t0 = time.perf_counter()
+                src = ex.CsvDataSource(path, schema_c, batch_rows)
+                t1 = time.perf_counter()
+                out = ex.AggregateRelation(None, src, [], [ex.compile_expr(None, a, schema_c) for a in aggs_c]).next()
+                ex.synchronize()
+                t2 = time.perf_counter()
+                ex.profile_enable(False)
+                k_ms = {p_["kernel"]: p_ for p_ in ex.profile_snapshot()}.get("csv", {"total_ms": 0.0})["total_ms"]
+                if best is None or k_ms < best[0]:
+                    best = (k_ms, (t1 - t0) * 1e3, (t2 - t1) * 1e3)
+            first = ex.CsvDataSource(path, schema_c, nb).next()
+            exact = (np.array_equal(first.column(0).to_numpy(), cols_c[0].astype(np.int64)) and
+                     np.array_equal(first.column(1).to_numpy().view(np.uint64), np.array([float(repr(float(b))) for b in cols_c[1]]).view(np.uint64)) and
+                     np.array_equal(first.column(2).to_numpy().view(np.uint64), np.array([float(repr(float(c))) for c in cols_c[2]]).view(np.uint64)) and
+                     np.array_equal(first.column(3).to_numpy(), cols_c[3].astype(np.int64)))
+            want_sum = float(np.sum(cols_c[1])) * reps
+            ok = (bool(exact) and out.column(1)[0].as_py() == records and out.column(2)[0].as_py() == int(np.sum(cols_c[3])) * reps and
+                  abs(out.column(0)[0].as_py() - want_sum) <= 1e-9 * abs(want_sum))
+            algo = size + 32.0 * records  # the text once in, four 8-byte columns out
+            gbps = algo / (best[0] * 1e-3) * 1e-9
+            return {"what": "CsvDataSource over 1 GB of numeric text (4 columns; tools/csv_bench.py's file): record boundaries, cell conversion "
+                            "(Rust str::parse semantics, bit-exact doubles), SUM / COUNT over the columns; all device kernels of the source",
+                    "file_bytes": size, "records": records, "csv_kernels_ms": round(best[0], 3), "text_GBps": round(size / (best[0] * 1e-3) * 1e-9, 1),
+                    "open_read_and_h2d_ms": round(best[1], 1), "index_parse_aggregate_ms": round(best[2], 2),
+                    "csv_tiles": ex.counter_get("csv_tiles"), "csv_general_tiles": ex.counter_get("csv_general_tiles"),
+                    "algorithmic_bytes": "text once + 32 bytes of columns per record",
+                    "roofline": {"bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBPS, 4)},
+                    "verified_vs_oracle": {"ok": bool(ok), "what": "the first 20 000 records bit-exact against Python's float() / int() of the same text; COUNT and "
+                                           "the Int64 SUM of all records exact, the Float64 SUM within 1e-9 relative"}}
+        finally:
+            os.remove(path)
 
     def rate(rows, secs, bytes_per_row, what):
         """One extra measurement with its own roofline: algorithmic bytes per row x rows/s against the 8 TB/s HBM peak."""
@@ -835,6 +891,15 @@ def main():
         if world == 1:
             extra["cfg5_q1_shape"]["verified_vs_oracle"] = checked("cfg5", verify_cfg5)
         del t5
+
+        # ---- CSV text -> Arrow columns on the device (CsvDataSource, datasource.rs:33-58): 1 GB of numeric
+        # text -- the file of tools/csv_bench.py -- indexed, converted and summed; the first records bit-exact against Python's
+        # float() / int() (correctly rounded, like Rust's parse)
+        if world == 1:
+            try:
+                extra["csv_ingest_1gb"] = csv_leg()
+            except Exception as e:  # noqa: BLE001
+                extra["csv_ingest_1gb"] = {"error": str(e)[:300]}
 
     # ---- the north-star size: 1e10 rows (160 GB) on ONE GPU, same query, same code path ------------------------------
     if want_extras and args.rows_1e10_steps > 0 and n_rows < 10000000000:

@@ -1716,7 +1716,9 @@ Status AggregateRelation::Impl::early_keys_maybe() {
     DFX_HIP(launch_compact(T.keys, 8, (const uint64_t*)mask.get(), (const uint64_t*)offsets.get(), n_slots, dense.get(), 0, aux, (uint64_t)g));
     DFX_HIP(launch_finalize((const uint64_t*)dense.get(), g, (uint8_t)dt, (uint8_t)VT_RAW, vals.get(), aux));
   }
-  DFX_HIP(launch_copy_to_host(vals.get(), early.host.get(), early.bytes, aux));
+  // by the copy engine, not by a kernel: pass 1's workgroups take a CU's whole register file, so a copy kernel's waves and a pass-1
+  // workgroup cannot share a CU -- measured: the kernel copy made the pass-1 launches it met 0.2 ms longer, more than it saved
+  DFX_HIP(hipMemcpyAsync(early.host.get(), vals.get(), early.bytes, hipMemcpyDeviceToHost, aux));
   DFX_HIP(hipEventRecord(early.done, aux));
   early.armed = true;
   early.occupied = occupied_known;
