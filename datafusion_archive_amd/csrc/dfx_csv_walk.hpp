@@ -173,4 +173,79 @@ DFX_HD void csv_copy_field(const uint8_t* buf, const CsvField& f, uint8_t* out) 
   }
 }
 
+// ---- quote-free text, word at a time (round 5) ------------------------------------------------------------
+// Without a quote the automaton collapses: the state before a byte is a function of the byte before it (terminator ->
+// StartRecord, delimiter -> StartField, other -> InField), a record is its bytes up to the first terminator, and every
+// byte between that terminator and the next record's start is a terminator.  The device kernels use that for tiles
+// (k_csv_tile_trans / k_csv_mark_write: record starts from terminator masks) and for records (k_csv_parse: cell
+// boundaries from delimiter masks); the host build of these functions is held against the walker above by
+// tests/native/csv_walk_fuzz.cpp.
+
+// exact per-byte "== c" flags of a 32-bit word, gathered into 4 bits (bit k: byte k)
+DFX_HD uint32_t csv_eq_nibble(uint32_t w, uint32_t c4) {
+  const uint32_t x = w ^ c4;
+  const uint32_t t = ((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x;  // bit 7 of every byte: byte != 0
+  const uint32_t z = ~(t | 0x7F7F7F7Fu) >> 7;                // bits 0, 8, 16, 24: byte == 0
+  return ((z * 0x00204081u) >> 21) & 0xFu;
+}
+
+// bit i: byte i of the 32 bytes w[0..8) is a record terminator (\n or \r)
+DFX_HD uint32_t csv_tmask32(const uint32_t* w) {
+  uint32_t t = 0;
+  for (int i = 0; i < 8; ++i) t |= (csv_eq_nibble(w[i], 0x0A0A0A0Au) | csv_eq_nibble(w[i], 0x0D0D0D0Du)) << (4 * i);
+  return t;
+}
+
+// record starts of 32 quote-free bytes outside a quoted field: a non-terminator right after a terminator
+// (`after_t`: the byte before the 32 is a terminator, or the text starts here)
+DFX_HD uint32_t csv_plain_starts(uint32_t t, bool after_t) { return ~t & ((t << 1) | (after_t ? 1u : 0u)); }
+
+DFX_HD uint64_t csv_load8(const uint8_t* p) {
+  uint64_t w;
+  __builtin_memcpy(&w, p, 8);
+  return w;
+}
+
+// bit 7 of every byte among the first `left` (>= 1) bytes of w that is a delimiter -- exact: no carry crosses a byte
+DFX_HD uint64_t csv_delims8(uint64_t w, uint32_t left) {
+  const uint64_t low7 = 0x7F7F7F7F7F7F7F7Full, high = 0x8080808080808080ull;
+  const uint64_t keep = left >= 8u ? ~0ull : (1ull << (8u * left)) - 1ull;
+  const uint64_t x = w ^ 0x2C2C2C2C2C2C2C2Cull;
+  return ~(((x & low7) + low7) | x) & high & keep;
+}
+
+// is one of the first `left` (>= 1) bytes of w a quote?  (x - 1) & ~x & 0x80 flags every zero byte and, through the
+// borrow, possibly bytes ABOVE one: existence is exact, and the bytes that `left` cuts off are the upper ones
+DFX_HD bool csv_any_quote8(uint64_t w, uint32_t left) {
+  const uint64_t ones = 0x0101010101010101ull, high = 0x8080808080808080ull;
+  const uint64_t keep = left >= 8u ? ~0ull : (1ull << (8u * left)) - 1ull;
+  const uint64_t x = w ^ 0x2222222222222222ull;
+  return ((x - ones) & ~x & high & keep) != 0ull;
+}
+
+// Cell boundaries of the record text[b, limit) -- limit: the next record's start, or the end of the input -- when it holds
+// no quote and exactly F fields: cells[i] (i < F - 1) = offset of the i-th delimiter, cells[F - 1] = the record's end (the
+// terminators and blank lines before `limit` stripped).  false: a quote, or another field count -- the caller walks the
+// record with csv_walk_record.  text[limit .. limit + 7] must be readable.  POS: an unsigned type that holds the offsets.
+template <typename POS>
+DFX_HD bool csv_plain_record(const uint8_t* text, uint32_t b, uint32_t limit, uint32_t F, POS* cells) {
+  uint32_t e = limit;
+  while (e > b && (text[e - 1u] == '\n' || text[e - 1u] == '\r')) --e;
+  uint32_t found = 0;
+  bool quote = false;
+  for (uint32_t p = b; p < e; p += 8u) {
+    const uint64_t w = csv_load8(text + p);
+    uint64_t zc = csv_delims8(w, e - p);
+    quote = quote || csv_any_quote8(w, e - p);
+    while (zc) {
+      const uint32_t k = (uint32_t)__builtin_ctzll(zc) >> 3;
+      if (found + 1u < F) cells[found] = (POS)(p + k);
+      ++found;
+      zc &= zc - 1ull;
+    }
+  }
+  cells[F - 1u] = (POS)e;
+  return !quote && found + 1u == F;
+}
+
 }  // namespace dfx

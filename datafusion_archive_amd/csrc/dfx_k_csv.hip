@@ -35,14 +35,6 @@ struct CsvChunk {
   bool has_quote;  // any '"' among the valid bytes (false also when m < 32: those chunks take the general path)
 };
 
-// exact per-byte "== c" flags of a 32-bit word, gathered into 4 bits (bit k: byte k)
-DEV uint32_t csv_eq_nibble(uint32_t w, uint32_t c4) {
-  const uint32_t x = w ^ c4;
-  const uint32_t t = ((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x;  // bit 7 of every byte: byte != 0
-  const uint32_t z = ~(t | 0x7F7F7F7Fu) >> 7;                // bits 0, 8, 16, 24: byte == 0
-  return ((z * 0x00204081u) >> 21) & 0xFu;
-}
-
 DEV CsvChunk csv_load_chunk(const uint8_t* __restrict__ buf, uint64_t pos, uint64_t n) {
   CsvChunk c;
   c.m = pos >= n ? 0 : (int)((n - pos) < (uint64_t)kCsvChunk ? (n - pos) : (uint64_t)kCsvChunk);
@@ -65,12 +57,7 @@ DEV CsvChunk csv_load_chunk(const uint8_t* __restrict__ buf, uint64_t pos, uint6
 DEV uint8_t csv_chunk_byte(const CsvChunk& c, int i) { return (uint8_t)(c.w[i >> 2] >> ((i & 3) * 8)); }
 
 // bit i: byte i is a record terminator (\n or \r) -- only meaningful for the general bytes of a full chunk
-DEV uint32_t csv_chunk_tmask(const CsvChunk& c) {
-  uint32_t t = 0;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) t |= (csv_eq_nibble(c.w[i], 0x0A0A0A0Au) | csv_eq_nibble(c.w[i], 0x0D0D0D0Du)) << (4 * i);
-  return t;
-}
+DEV uint32_t csv_chunk_tmask(const CsvChunk& c) { return csv_tmask32(c.w); }
 
 // transition vector of the chunk
 DEV uint32_t csv_chunk_vector(const CsvChunk& c) {
@@ -137,9 +124,6 @@ constexpr uint32_t kCsvTileVec = 0x7FFFu;
 constexpr uint32_t kCsvTileUnknown = 1u << 15;
 constexpr uint32_t kCsvTileFirstNonT = 1u << 16;
 constexpr int kCsvTileCountShift = 17;
-
-// starts of a quote-free full chunk: a non-terminator right after a terminator (`after_t`: the byte before the chunk is one)
-DEV uint32_t csv_plain_starts(uint32_t t, bool after_t) { return ~t & ((t << 1) | (after_t ? 1u : 0u)); }
 
 __global__ __launch_bounds__(kCsvBlock) void k_csv_tile_trans(const uint8_t* __restrict__ buf, uint64_t n,
                                                              uint32_t* __restrict__ tile_trans) {
@@ -467,31 +451,7 @@ __global__ __launch_bounds__(kBlock) void k_csv_parse(const uint8_t* __restrict_
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     bool ok = true;
-    if (inb) {
-      const uint32_t b = (uint32_t)(begin - base);
-      uint32_t e = (uint32_t)(limit - base);
-      // the terminators (and blank lines) between this record and the next; a file may end without one
-      while (e > b && (text[e - 1u] == '\n' || text[e - 1u] == '\r')) --e;
-      const uint64_t ones = 0x0101010101010101ull, low7 = 0x7F7F7F7F7F7F7F7Full, high = 0x8080808080808080ull;
-      uint32_t found = 0;
-      bool quote = false;
-      for (uint32_t p = b; p < e; p += 8u) {
-        const uint64_t w = np_load8(text + p);
-        const uint32_t left = e - p;
-        const uint64_t keep = left >= 8u ? ~0ull : (1ull << (8u * left)) - 1ull;
-        const uint64_t xc = w ^ (ones * 0x2Cu), xq = w ^ (ones * 0x22u);
-        uint64_t zc = ~(((xc & low7) + low7) | xc) & high & keep;  // bit 7 of every byte that is a delimiter (exact)
-        quote = quote || ((xq - ones) & ~xq & high & keep) != 0ull;  // some byte is a quote (a borrow only reaches bytes above one)
-        while (zc) {
-          const uint32_t k = (uint32_t)(__ffsll((long long)zc) - 1) >> 3;
-          if (found + 1u < F) spos[(uint32_t)lane * F + found] = (uint16_t)(p + k);
-          ++found;
-          zc &= zc - 1ull;
-        }
-      }
-      spos[(uint32_t)lane * F + F - 1u] = (uint16_t)e;
-      ok = !quote && found + 1u == F;
-    }
+    if (inb) ok = csv_plain_record(text, (uint32_t)(begin - base), (uint32_t)(limit - base), F, spos + (uint32_t)lane * F);
     fast = __ballot(!ok) == 0ull;
     if (fast) {
       csv_convert_cells<true>(buf, plan, r0, nb, tid, inb, (int)F, begin, (uint32_t)(begin - base), text, spos, nullptr,

@@ -2,11 +2,14 @@
 // independent byte-at-a-time reader (oracle/dfx_oracle.c: orc_csv_*), on random text over the bytes that matter to the
 // automaton.  Also checks the PARALLEL formulation: composing the per-chunk transition vectors of random chunkings gives
 // the same record starts as the sequential walk.
+// Round 5: the word-at-a-time functions for quote-free text (csv_plain_starts over 32-byte terminator masks, csv_plain_record's
+// delimiter masks -- what k_csv_tile_trans / k_csv_mark_write / k_csv_parse run) against the same sequential walk.
 // usage: csv_walk_fuzz <iterations> <seed> <tmpdir>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <random>
 #include <string>
 #include <vector>
@@ -49,12 +52,90 @@ static std::vector<uint64_t> starts_parallel(const std::string& t, std::mt19937_
   return out;
 }
 
+// record starts of a quote-free text from 32-byte terminator masks (k_csv_tile_trans / k_csv_mark_write without the scan)
+static std::vector<uint64_t> starts_plain_masks(const std::string& t) {
+  std::string pad = t;
+  pad.append(64 - pad.size() % 64 + 64, '\n');  // whole chunks; the padding is terminators: no start in it
+  std::vector<uint64_t> out;
+  for (size_t c = 0; c + 32 <= pad.size(); c += 32) {
+    uint32_t w[8];
+    memcpy(w, pad.data() + c, 32);
+    const bool after_t = c == 0 || pad[c - 1] == '\n' || pad[c - 1] == '\r';
+    uint32_t st = csv_plain_starts(csv_tmask32(w), after_t);
+    for (; st; st &= st - 1) out.push_back(c + (size_t)__builtin_ctz(st));
+  }
+  while (!out.empty() && out.back() >= t.size()) out.pop_back();
+  return out;
+}
+
+// every record of a text through csv_plain_record, against the walker
+static bool check_plain_records(const std::string& t, const std::vector<uint64_t>& seq, long* n_plain, long* n_declined) {
+  std::string pad = t + std::string(8, '"');  // readable past the end; quotes there must not be seen
+  for (size_t r = 0; r < seq.size(); ++r) {
+    const uint64_t begin = seq[r], limit = r + 1 < seq.size() ? seq[r + 1] : t.size();
+    std::vector<CsvField> fields;
+    bool any_quote = false;
+    const int nf = csv_walk_record((const uint8_t*)t.data(), begin, limit, [&](int, const CsvField& f) { fields.push_back(f); });
+    uint64_t rec_end = fields.back().end;
+    for (uint64_t i = begin; i < rec_end; ++i) any_quote = any_quote || t[i] == '"';
+    for (int F = std::max(1, nf - 1); F <= nf + 1; ++F) {
+      std::vector<uint16_t> cells((size_t)F + 1, 0xFFFF);
+      const bool ok = csv_plain_record((const uint8_t*)pad.data(), (uint32_t)begin, (uint32_t)limit, (uint32_t)F, cells.data());
+      if (cells[(size_t)F] != 0xFFFF) {
+        printf("MISMATCH csv_plain_record wrote past its %d entries on '%s'\n", F, t.c_str());
+        return false;
+      }
+      // (a quote inside the trailing terminator run cannot be: those bytes are terminators)
+      const bool want = !any_quote && F == nf;
+      if (ok != want) {
+        printf("MISMATCH csv_plain_record accepts=%d want=%d (F=%d, walker %d fields, quote=%d) record at %llu of '%s'\n", (int)ok, (int)want, F, nf,
+               (int)any_quote, (unsigned long long)begin, t.c_str());
+        return false;
+      }
+      if (!ok) {
+        ++*n_declined;
+        continue;
+      }
+      for (int i = 0; i < nf; ++i) {
+        if ((uint64_t)cells[(size_t)i] != fields[(size_t)i].end) {
+          printf("MISMATCH csv_plain_record cell %d ends at %u, walker at %llu, in '%s'\n", i, (unsigned)cells[(size_t)i],
+                 (unsigned long long)fields[(size_t)i].end, t.c_str());
+          return false;
+        }
+      }
+      ++*n_plain;
+    }
+  }
+  return true;
+}
+
 int main(int argc, char** argv) {
   const long iters = argc > 1 ? atol(argv[1]) : 2000;
   std::mt19937_64 rng(argc > 2 ? strtoull(argv[2], nullptr, 10) : 1);
   const std::string dir = argc > 3 ? argv[3] : "/tmp";
   const char* pieces[] = {"\"", "\"\"", ",", "\n", "\r", "\r\n", "a", "bc", " ", "1", "\"x\"", "\",\"", "\"\n\"", "'"};
-  long records = 0, fields = 0;
+  long records = 0, fields = 0, n_plain = 0, n_declined = 0, plain_texts = 0;
+  // quote-free texts (and a share with a few quotes sprinkled in, which csv_plain_record must decline record by record)
+  const char* plain_pieces[] = {",", ",", "\n", "\r", "\r\n", "a", "bc", " ", "1", "-2.5e3", "12345678", "'", ",,", "\n\n", "\xfa", "+"};
+  for (long it = 0; it < iters * 4; ++it) {
+    std::string t = "h\n";
+    const int np = 1 + (int)(rng() % 200);
+    for (int i = 0; i < np; ++i) t += plain_pieces[rng() % (sizeof(plain_pieces) / sizeof(plain_pieces[0]))];
+    const std::vector<uint64_t> seq = starts_sequential(t);
+    if (seq != starts_plain_masks(t)) {
+      printf("MISMATCH terminator-mask record starts on quote-free text '%s'\n", t.c_str());
+      return 1;
+    }
+    ++plain_texts;
+    if (it % 4 == 3) {  // quotes in the middle of fields are literals for the automaton's boundaries only when not at a field start:
+      std::string q = t;  // put them after a letter, so the record structure the walker sees stays what the masks assume
+      for (size_t i = 2; i + 1 < q.size(); ++i)
+        if (q[i] == 'a' && rng() % 6 == 0) q.insert(i + 1, "\"");
+      if (!check_plain_records(q, starts_sequential(q), &n_plain, &n_declined)) return 1;
+    } else if (!check_plain_records(t, seq, &n_plain, &n_declined)) {
+      return 1;
+    }
+  }
   for (long it = 0; it < iters; ++it) {
     std::string t = "h\n";  // a one-field header: every record of the fuzz then has its own field count (flexible walk)
     const int np = 1 + (int)(rng() % 60);
@@ -110,6 +191,7 @@ int main(int argc, char** argv) {
       fields += nf;
     }
   }
-  printf("ok: %ld records, %ld fields agree with the oracle; parallel == sequential boundaries on %ld texts\n", records, fields, iters);
+  printf("ok: %ld records, %ld fields agree with the oracle; parallel == sequential boundaries on %ld texts; quote-free: mask starts == sequential on "
+         "%ld texts, csv_plain_record == walker on %ld records (%ld declined as it must)\n", records, fields, iters, plain_texts, n_plain, n_declined);
   return 0;
 }
