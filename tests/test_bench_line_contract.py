@@ -1,0 +1,59 @@
+"""The bench line the driver parses (ROUND contract: one JSON line from rank 0): the committed line of the final tree,
+profiles/r05_bench_line.json, carries every field of the contract with consistent values -- metric / unit of BASELINE.json,
+whole-job value = rows / time, the roofline object of the dominant kernel (frac = achieved / peak, algorithmic bytes, PMC
+traffic), the CPU baseline of the oracle port -- and every extra leg that claims a roofline also says whether it was checked
+against the oracle.  CPU only: it guards the shape of what bench.py prints, not the numbers."""
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _line(name):
+    with open(os.path.join(ROOT, "profiles", name)) as fh:
+        return json.loads(fh.read().strip().splitlines()[-1])
+
+
+def test_committed_bench_line_has_the_contract_fields():
+    d = _line("r05_bench_line.json")
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    assert base["metric"].startswith(d["metric"]) and d["unit"] == "rows/s"  # BASELINE.json's metric (its qualifiers are the roofline object and --gpus)
+    for key in ("value", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert "workload" in d["config"] and "model" not in d["config"]
+    rows = float(d["config"].get("rows_per_gpu", d["config"].get("rows", 0)) or 1e9)
+    assert abs(d["value"] - rows / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]  # whole-job throughput = rows / step time
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["traffic"] is None or r["traffic"] > 0
+    for key in ("end_to_end_frac", "cold_first_step_ms", "avg_launch_ms", "frac_is"):
+        assert key in r, key
+    assert 0.0 < r["end_to_end_frac"] <= r["frac"] < 1.0  # the whole step cannot beat its dominant kernel
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+    assert d["extra"]["verified_vs_oracle"]["ok"] is True
+
+
+def test_every_extra_leg_with_a_roofline_says_whether_it_was_checked():
+    d = _line("r05_bench_line.json")
+    unchecked = []
+    for name, leg in d["extra"].items():
+        if not isinstance(leg, dict) or "roofline" not in leg:
+            continue
+        assert 0.0 < leg["roofline"]["frac"] < 1.0, name
+        v = leg.get("verified_vs_oracle")
+        if v is None:
+            unchecked.append(name)
+        else:
+            assert (v.get("ok") if isinstance(v, dict) else v) is True, name
+    # the two legs that re-time an already checked query with other options carry no second check
+    assert set(unchecked) <= {"cfg2_filter_two_pass", "host_streamed_staged_ring"}, unchecked
+    assert d["extra"]["csv_ingest_1gb"]["csv_general_tiles"] == 0  # the whole file went through the wave-cooperative path
+
+
+def test_eight_rank_dry_run_line_used_the_library_exchange():
+    d = _line("r05_bench_line_8rank_dryrun_one_gpu.json")
+    assert d["n_gpus"] == 8 and d["config"]["rccl_ranks"] == 8
+    assert "phases_ms" in d["extra"] and d["extra"]["verified_sum_of_group_sums_equals_ungrouped_sum"] is True
