@@ -5,6 +5,7 @@
 #   profile  rocprofv3 --kernel-trace --stats of the bench command; FETCH_SIZE / WRITE_SIZE (separate passes) and SQ counters of
 #            pass 1 / pass 2 for the headline and for config 3 -> partition_counters.json; kernel stats of config 3
 #   csv      the CSV source: its GPU tests, tools/csv_bench.py (1 GB of numeric text) and the rocprofv3 kernel summary of that run
+#   csvpmc   SQ counters of the CSV kernels (256 MB of text; per 64-record tile for k_csv_parse) -> csv_counters.txt
 #   dry8     bench.py --gpus 8 as eight processes on this ONE GPU over the host-staged RCCL stand-in (plumbing only), and the
 #            same with DFX_RCCL_LIB pointing at a missing file (must exit non-zero)
 # Summaries land in gpurun_out/<tag>/ -- what is cited is copied to profiles/ by hand.
