@@ -27,7 +27,9 @@ COUNT; config 5: the Q1 shape), each with a `verified_vs_oracle` object: the sam
 same product path, compared with the CPU oracle (bit for bit; config 5's uniform doubles within n * eps * sum|v|), and the
 north-star size, 1e10 rows on one GPU, as extra.rows_1e10.
 
-Prints ONE JSON line on rank 0.
+Prints ONE compact JSON line (< 4 KB) on rank 0 as the last line of stdout: the contract's fields, `roofline`, `cpu_baseline`
+and one {frac, ms, ok} per extra leg; the full object (every leg's description and verification record) goes to
+gpurun_out/bench_extra.json and to stderr.
 """
 import argparse
 import json
@@ -43,6 +45,99 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 GROUPS = 1000000
 LO, HI = 204.8, 409.6
+
+
+COMPACT_LINE_LIMIT = 4096  # bytes: the driver keeps the tail of stdout and parses its last line (round 5's 20 KB line came back unparsed)
+
+
+def _leg_summary(leg):
+    """One extra leg -> {"frac": end-to-end fraction of the 8 TB/s roofline, "ok": checked against the oracle?, "ms": step time}."""
+    out = {}
+    r = leg.get("roofline") if isinstance(leg.get("roofline"), dict) else None
+    if r is not None and r.get("frac") is not None:
+        out["frac"] = round(float(r["frac"]), 4)
+    ms = leg.get("ms_per_step", leg.get("ms"))  # "ms" is the leg's whole timed region, "ms_per_step" (where present) one step of it
+    if ms is not None:
+        out["ms"] = round(float(ms), 3)
+    v = leg.get("verified_vs_oracle")
+    if v is not None:
+        out["ok"] = bool(v.get("ok")) if isinstance(v, dict) else bool(v)
+    if "error" in leg:
+        out["error"] = str(leg["error"])[:80]
+    return out
+
+
+def compact_line(full, limit=COMPACT_LINE_LIMIT):
+    """The line bench.py prints LAST: the contract's fields, the roofline and cpu_baseline objects without their prose, and
+    one {frac, ms, ok} per extra leg.  The full object (every leg's description, its verification record, budgets, plans) goes
+    to gpurun_out/bench_extra.json and to stderr.  Always shorter than `limit` bytes: legs are dropped from the end, never
+    a contract field (tests/test_bench_line_contract.py)."""
+    keep_roofline = ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic", "end_to_end_frac",
+                     "launches", "avg_launch_ms", "algo_bytes_per_launch", "cold_first_step_ms", "frac_is", "kernel")
+    line = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                 "scaling", "vs_baseline", "dtype", "data") if k in full}
+    cfg = dict(full.get("config") or {})
+    line["config"] = {k: cfg[k] for k in ("workload", "rows_per_gpu", "rows_total", "batch_rows", "algorithmic_bytes_per_row",
+                                          "parallelism", "exchange", "rccl_ranks") if k in cfg}
+    r = full.get("roofline")
+    if isinstance(r, dict):
+        rr = {k: r[k] for k in keep_roofline if k in r}
+        if isinstance(rr.get("kernel"), str):
+            rr["kernel"] = rr["kernel"][:60]
+        if isinstance(rr.get("frac_is"), str):
+            rr["frac_is"] = "dominant kernel alone; whole step = end_to_end_frac"
+        line["roofline"] = rr
+    else:
+        line["roofline"] = r
+    c = full.get("cpu_baseline")
+    if isinstance(c, dict):
+        cc = {k: c[k] for k in ("value", "unit", "cores", "kind", "sample") if k in c}
+        cc["sample"] = str(cc.get("sample", ""))[:160]
+        line["cpu_baseline"] = cc
+    else:
+        line["cpu_baseline"] = c
+    ex_full = full.get("extra") or {}
+    ex = {}
+    for k in ("verified_sum_of_group_sums_equals_ungrouped_sum", "groups", "selectivity", "cold_first_step_ms", "scaling_anchor_rows_per_s"):
+        if k in ex_full:
+            v = ex_full[k]
+            ex[k] = round(v, 3) if isinstance(v, float) else v
+    if isinstance(ex_full.get("verified_vs_oracle"), dict):
+        v = ex_full["verified_vs_oracle"]
+        ex["verified_vs_oracle"] = {k: v[k] for k in ("rows", "groups", "ok") if k in v}
+    if isinstance(ex_full.get("phases_ms"), dict):
+        ex["phases_ms"] = ex_full["phases_ms"]
+    legs = [(k, v) for k, v in ex_full.items() if isinstance(v, dict) and ("roofline" in v or "error" in v) and k != "verified_vs_oracle"]
+    # the legs the review reads first stay when the line has to shrink
+    first = ["rows_1e10", "cfg3_groupby_sum_no_filter", "cfg4_as_written", "cfg5_q1_shape", "headline_selectivity_50", "headline_selectivity_80",
+             "headline_through_interpreter", "different_operand_sum_min", "cfg2_filter_mask_and_compact", "cfg2_predicate_count"]
+    legs.sort(key=lambda kv: first.index(kv[0]) if kv[0] in first else len(first))
+    line["extra"] = ex
+    line["extra_full"] = "gpurun_out/bench_extra.json"
+    ex["legs"] = {}
+    for k, v in legs:
+        ex["legs"][k] = _leg_summary(v)
+        if len(json.dumps(line, separators=(",", ":"))) > limit - 64:
+            del ex["legs"][k]
+            ex["legs_dropped"] = len(legs) - len(ex["legs"])
+            break
+    return line
+
+
+def emit_line(full, full_out=None):
+    """Full object -> gpurun_out/bench_extra.json (or --full-out) + stderr; compact object -> the LAST line of stdout."""
+    text = json.dumps(full)
+    path = full_out or os.path.join(ROOT, "gpurun_out", "bench_extra.json")
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as fh:
+            fh.write(text + "\n")
+    except OSError:
+        pass
+    print("bench.py full line: " + text, file=sys.stderr, flush=True)
+    out = json.dumps(compact_line(full), separators=(",", ":"))
+    assert len(out) < COMPACT_LINE_LIMIT, len(out)
+    print(out, flush=True)
 
 
 def host_cpu_budget():
@@ -98,6 +193,7 @@ def main():
     ap.add_argument("--verify-rows", type=float, default=1e8, help="rows of the slice every extra configuration is checked on against the oracle")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--full-out", default=None, help="where the full (uncompacted) line object is written; default gpurun_out/bench_extra.json")
     ap.add_argument("--rows-1e10-steps", type=int, default=3, help="timed steps of the north-star size (1e10 rows on one GPU); 0: skip")
     ap.add_argument("--allow-host-exchange", action="store_true",
                     help="multi-rank runs: accept the host-driven exchange (torch.distributed around dfx_aggregate_partial_*) when the library's "
@@ -1011,7 +1107,7 @@ def main():
                        "rccl_ranks": (comm.ranks() if comm is not None else None)},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "extra": extra,
         }
-        print(json.dumps(line), flush=True)
+        emit_line(line, args.full_out)
     if world > 1:
         dist.destroy_process_group()
 

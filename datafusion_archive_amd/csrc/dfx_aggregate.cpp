@@ -1677,27 +1677,27 @@ Status AggregateRelation::Impl::early_keys_maybe() {
   const int64_t n_words = (n_slots + 63) / 64;
   const int64_t n_tiles = (n_slots + kTileRows - 1) / kTileRows;
   const int dt = key_dtype[0];
+  // Speculative work: a buffer that cannot be had (memory pressure, the tests' allocation-failure injection) drops the
+  // attempt -- the query itself does not need it and must not fail because of it.
   auto mask = device_alloc(sizeof(uint64_t) * (size_t)n_words, &st);
-  if (!mask) return st;
-  auto counts = device_alloc(sizeof(uint32_t) * (size_t)n_tiles, &st);
-  if (!counts) return st;
-  auto offsets = device_alloc(sizeof(uint64_t) * (size_t)(n_tiles + 1), &st);
-  if (!offsets) return st;
-  auto tmp = device_alloc(sizeof(uint64_t) * (size_t)(n_tiles / 4096 + 4), &st);
-  if (!tmp) return st;
-  auto vals = device_alloc((size_t)g * dtype_width(dt), &st);
-  if (!vals) return st;
+  auto counts = mask ? device_alloc(sizeof(uint32_t) * (size_t)n_tiles, &st) : nullptr;
+  auto offsets = counts ? device_alloc(sizeof(uint64_t) * (size_t)(n_tiles + 1), &st) : nullptr;
+  auto tmp = offsets ? device_alloc(sizeof(uint64_t) * (size_t)(n_tiles / 4096 + 4), &st) : nullptr;
+  auto vals = tmp ? device_alloc((size_t)g * dtype_width(dt), &st) : nullptr;
   early.bytes = (size_t)g * dtype_width(dt);
-  early.host = pinned_alloc(early.bytes, &st);
-  if (!early.host) return st;
-  if (!early.total) {
-    early.total = pinned_alloc(sizeof(uint64_t), &st);
-    if (!early.total) return st;
+  if (vals) early.host = pinned_alloc(early.bytes, &st);
+  if (vals && early.host && !early.total) early.total = pinned_alloc(sizeof(uint64_t), &st);
+  std::shared_ptr<void> dense;  // 4-byte keys: the compacted 8-byte key words before narrowing
+  if (vals && dtype_width(dt) != 8) dense = device_alloc(sizeof(uint64_t) * (size_t)g, &st);
+  if (!vals || !early.host || !early.total || (dtype_width(dt) != 8 && !dense)) {
+    early.host.reset();
+    return Status::OK();
   }
   *(uint64_t*)early.total.get() = ~0ull;
   if (!early.done) DFX_HIP(hipEventCreateWithFlags(&early.done, hipEventDisableTiming));
   if (!early.start) DFX_HIP(hipEventCreateWithFlags(&early.start, hipEventDisableTiming));
   early.scratch = {mask, counts, offsets, tmp, vals};
+  if (dense) early.scratch.push_back(dense);
   // The side stream starts behind everything queued on the main stream so far: the pool hands out blocks whose previous users may
   // still be queued there.  It is not ordered against what comes LATER: whatever those kernels add to the table makes the final
   // group count differ from `g`, and the copy is dropped.
@@ -1710,9 +1710,6 @@ Status AggregateRelation::Impl::early_keys_maybe() {
   if (dtype_width(dt) == 8) {
     DFX_HIP(launch_compact(T.keys, 8, (const uint64_t*)mask.get(), (const uint64_t*)offsets.get(), n_slots, vals.get(), 0, aux, (uint64_t)g));
   } else {
-    auto dense = device_alloc(sizeof(uint64_t) * (size_t)g, &st);
-    if (!dense) return st;
-    early.scratch.push_back(dense);
     DFX_HIP(launch_compact(T.keys, 8, (const uint64_t*)mask.get(), (const uint64_t*)offsets.get(), n_slots, dense.get(), 0, aux, (uint64_t)g));
     DFX_HIP(launch_finalize((const uint64_t*)dense.get(), g, (uint8_t)dt, (uint8_t)VT_RAW, vals.get(), aux));
   }
@@ -2169,6 +2166,11 @@ Status AggregateRelation::exchange_import_chunk(int c, const void* src_device, c
 Status AggregateRelation::exchange_import_finish() {
   Impl& m = *impl_;
   DFX_HIP(hipStreamSynchronize(ctx().stream));
+  // the table is replaced: a key column copied ahead of time (agg.early_keys) was made from the OLD table's slot order and its
+  // side-stream kernels may still read the old planes -- wait for them, drop the copy, and make any later validity check fail
+  m.early.cancel();
+  ++m.table_generation;
+  m.early_last_occupied = ~0ull;
   m.T = m.import_T;
   m.accs_full = m.import_accs_full;
   m.table_owners = m.import_owners;

@@ -14,7 +14,7 @@ namespace dfx {
 TableScanRelation::TableScanRelation(std::shared_ptr<const TableData> t, int64_t batch_rows, int64_t row_begin, int64_t n_rows)
     : table_(std::move(t)), batch_rows_(batch_rows) {
   begin_ = std::max<int64_t>(0, std::min(row_begin, table_->num_rows));
-  end_ = n_rows < 0 ? table_->num_rows : std::min(table_->num_rows, begin_ + n_rows);
+  end_ = (n_rows < 0 || n_rows > table_->num_rows - begin_) ? table_->num_rows : begin_ + n_rows;  // (no begin_ + n_rows overflow for an `everything` n_rows)
   pos_ = begin_;
   if (batch_rows_ <= 0) batch_rows_ = end_ > begin_ ? end_ - begin_ : 1;
   batch_rows_ = (batch_rows_ + 63) / 64 * 64;  // slices stay byte-aligned in every bitmap

@@ -57,3 +57,62 @@ def test_eight_rank_dry_run_line_used_the_library_exchange():
     d = _line("r05_bench_line_8rank_dryrun_one_gpu.json")
     assert d["n_gpus"] == 8 and d["config"]["rccl_ranks"] == 8
     assert "phases_ms" in d["extra"] and d["extra"]["verified_sum_of_group_sums_equals_ungrouped_sum"] is True
+
+
+def _check_contract(d):
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+                "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    r = d["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "end_to_end_frac", "avg_launch_ms"):
+        assert key in r, key
+    c = d["cpu_baseline"]
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in c, key
+    assert "workload" in d["config"] and "model" not in d["config"]
+
+
+def test_the_line_bench_py_prints_last_is_compact():
+    """Round 5's line was 20 KB and the driver could not parse it (BENCH_r05.json: parsed null).  The LAST stdout line is now
+    built by bench.compact_line from the full object: the contract's fields, roofline, cpu_baseline and one {frac, ms, ok}
+    per leg, under 4 KB whatever the full object holds.  Checked on bench.py's own line builder, not on a committed file."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    full = _line("r05_bench_line_final_commit.json")
+    assert len(json.dumps(full)) > 16000  # the object that failed to parse
+    small = bench.compact_line(full)
+    text = json.dumps(small, separators=(",", ":"))
+    assert len(text) < 4096 and "\n" not in text
+    assert json.loads(text) == small  # strict JSON round trip (no NaN / Infinity)
+    _check_contract(small)
+    for key in ("metric", "value", "unit", "ms_per_step", "n_gpus", "steps", "warmup", "scaling", "dtype"):
+        assert small[key] == full[key], key
+    assert small["roofline"]["frac"] == full["roofline"]["frac"] and small["cpu_baseline"]["value"] == full["cpu_baseline"]["value"]
+    legs = small["extra"]["legs"]
+    for name in ("rows_1e10", "cfg3_groupby_sum_no_filter", "cfg5_q1_shape", "headline_selectivity_50", "headline_selectivity_80"):
+        assert set(legs[name]) >= {"frac", "ok"} and legs[name]["ok"] is True, name
+    # a pathological full object (hundreds of legs, long strings) still yields a line under the limit with every contract field
+    fat = json.loads(json.dumps(full))
+    for i in range(400):
+        fat["extra"][f"leg_{i}"] = {"roofline": {"frac": 0.1}, "ms": 1.0, "verified_vs_oracle": {"ok": True}, "what": "x" * 500}
+    fat["roofline"]["kernel"] = "k" * 5000
+    fat["cpu_baseline"]["sample"] = "s" * 5000
+    small2 = bench.compact_line(fat)
+    assert len(json.dumps(small2, separators=(",", ":"))) < 4096
+    _check_contract(small2)
+    assert small2["extra"]["legs_dropped"] > 0
+
+
+def test_emit_line_prints_the_compact_line_last(tmp_path, capsys, monkeypatch):
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    full = _line("r05_bench_line_final_commit.json")
+    bench.emit_line(full)
+    out = capsys.readouterr()
+    last = out.out.strip().splitlines()[-1]
+    assert len(out.out.strip().splitlines()) == 1 and len(last) < 4096
+    _check_contract(json.loads(last))
+    assert json.loads(open(tmp_path / "gpurun_out" / "bench_extra.json").read()) == full  # the full object is kept beside it

@@ -1365,6 +1365,40 @@ def test_library_exchange_over_rccl_world_1():
         comm.close()
 
 
+def test_library_exchange_world_1_drops_the_key_column_copied_ahead_of_time():
+    """The exchange replaces the GROUP BY table (the import table has its own slot order).  A key column copied ahead of time
+    from the OLD table (agg.early_keys, armed because the group count had settled during the scan) must not be attached to the
+    NEW table's aggregate columns: with one rank the group count before and after the exchange is the same, so nothing but the
+    table generation tells them apart (round-5 advisor finding: keys silently paired with other groups' sums).  Key / value
+    pairs against the oracle, >= 32768 groups, partitioned strategy."""
+    from datafusion_archive_amd.distributed import library_communicator
+    ex.set_option("agg.strategy", 3)
+    ex.set_option("agg.partition_defer", 1)
+    ex.set_option("agg.early_keys", 1)
+    comm = library_communicator(1, 0)
+    try:
+        schema = pa.schema([("k", pa.int64()), ("v", pa.float64())])
+        syn = [("k", ex.SYNTH_I64_UNIFORM, 0, 100000.0, 0.0), ("v", ex.SYNTH_F64_EXACT, 1, 0.0, 0.0)]
+        n, seed = (1 << 23) + 4321, 0xEA52
+        t = ex.DeviceTable.synth(syn, seed, 0, n)
+        aggs = [agg("sum", Column(1), F64)]
+        want = oracle.aggregate([Column(0)], aggs, [oracle.synth_batch(syn, seed, 0, n)])
+        ex.counter_reset()
+        rel = ex.AggregateRelation(None, t.scan(1 << 20), [ex.compile_scalar_expr(None, Column(0), schema)],
+                                   [ex.compile_expr(None, a, schema) for a in aggs])
+        stats = comm.exchange(rel)
+        got = rel.next()
+        assert rel.next() is None
+        assert stats["sent_groups"] == stats["received_groups"] == want.num_rows >= 32768
+        assert ex.counter_get("agg_early_keys") >= 1          # the copy was started during the scan ...
+        assert ex.counter_get("agg_early_keys_used") == 0     # ... and dropped when the table was replaced
+        assert_groups_identical(got, want, 1, "library exchange, world 1, early keys armed")
+    finally:
+        comm.close()
+        ex.set_option("agg.strategy", 0)
+        ex.set_option("agg.partition_defer", 0)
+
+
 def test_aggregate_errors_mirror_reference():
     b = _exact_batch(np.random.default_rng(1), 100, 5)
     fb = pa.RecordBatch.from_arrays([pa.array([1.5, 2.5]), pa.array([1.0, 2.0])], names=["k", "v"])

@@ -9,7 +9,7 @@
 #   dry8     bench.py --gpus 8 as eight processes on this ONE GPU over the host-staged RCCL stand-in (plumbing only), and the
 #            same with DFX_RCCL_LIB pointing at a missing file (must exit non-zero)
 # Summaries land in gpurun_out/<tag>/ -- what is cited is copied to profiles/ by hand.
-STAGES=${1:-bench}; TAG=${2:-r05}   # (several stages: comma-separated, run in order)
+STAGES=${1:-bench}; TAG=${2:-r06}   # (several stages: comma-separated, run in order)
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp
 for STAGE in ${STAGES//,/ }; do
 cd $R
@@ -51,8 +51,8 @@ suite)
   timeout 2400 python -m pytest tests -m gpu -q --timeout 900 > $OUT/pytest_gpu.log 2>&1; echo "gpu suite rc=$?"; tail -n 8 $OUT/pytest_gpu.log | cut -c1-300
   ;;
 bench)
-  timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; tail -n 3 $OUT/bench.err | cut -c1-300
-  python - $OUT/bench.json <<'PY'
+  timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 --full-out $OUT/bench_full.json > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?  last stdout line: $(tail -n 1 $OUT/bench.json | wc -c) bytes"; tail -n 3 $OUT/bench.err | cut -c1-300
+  python - $OUT/bench_full.json <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
 r = d["roofline"]
@@ -67,7 +67,7 @@ PY
   ;;
 profile)
   cd /tmp
-  BENCH="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras"
+  BENCH="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --full-out $OUT/bench_under_rocprof_full.json"
   rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/stats -o out -- $BENCH > $OUT/bench_under_rocprof.json 2>/dev/null
   cp $OUT/stats/out_kernel_stats.csv $OUT/bench_kernel_stats.csv 2>/dev/null
   export DFX_NO_TORCH=1
@@ -116,8 +116,8 @@ PY
   ;;
 dry8)
   export DFX_BENCH_SHARED_GPU=1 DFX_RCCL_LIB=$R/tests/native/librccl_stub.so
-  timeout 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29518 bench.py --gpus 8 --rows 5e7 --steps 2 --warmup 1 > $OUT/bench_8rank.json 2> $OUT/bench_8rank.err; echo "8-rank dry run rc=$?"; tail -2 $OUT/bench_8rank.err | cut -c1-300
-  python - $OUT/bench_8rank.json <<'PY'
+  timeout 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29518 bench.py --gpus 8 --rows 5e7 --steps 2 --warmup 1 --full-out $OUT/bench_8rank_full.json > $OUT/bench_8rank.json 2> $OUT/bench_8rank.err; echo "8-rank dry run rc=$?"; tail -2 $OUT/bench_8rank.err | cut -c1-300
+  python - $OUT/bench_8rank_full.json <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
 print("n_gpus", d["n_gpus"], "rccl_ranks", d["config"]["rccl_ranks"], "exchange", d["config"]["exchange"][:60])
