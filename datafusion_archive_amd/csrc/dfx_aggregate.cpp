@@ -718,23 +718,10 @@ Status AggregateRelation::Impl::ensure_partition(int64_t rows, bool nulls_now) {
       PT.ws_scanners = (o.pass1_ws == 4 || (mostly_seen && o.pass1_ws_dense_scanners == 4)) ? 4u : 8u;  // (agg.pass1_ws = 4: that split whatever the selectivity -- tests)
       if (partition_ws_bytes(PT.n_parts, (int)PT.ws_scanners) <= (size_t)158 * 1024) PT.flags |= PTF_WS;
     }
-    // dense scans (most rows routed): no ring protocol at all -- tiles of 8192 rows counting-sorted by partition in LDS and
-    // copied out in sorted order (dfx_k_partition_tile_inl.hpp).  One routed value (12- or 16-byte rows), contiguous regions,
-    // no hot-key pairs.  agg.pass1_tile: 1 when the calibration slice routed more than half of its rows, 2 whenever the shape allows
-    if (o.pass1_tile > 0 && (dense_seen || o.pass1_tile >= 2) && kw == 1 && na == 1 && PT.n_words == 2 && !(PT.flags & PTF_HOT) &&
-        o.partition_layout != 2 && PT.n_parts <= 512 && partition_tile_cap(PT.n_parts, (PT.flags & PTF_NARROW) == 0, o.tile_block == 512 ? 512u : 1024u) >= 16 && !(((uint32_t)o.partition_mode) & ~15u)) {
-      PT.flags |= PTF_TILE;
-      PT.flags &= ~PTF_WS;
-    }
     PT.mode = 2u | ((uint32_t)o.partition_mode & ~15u);
     PT.block = 1024;
     PT.stage_rows = 0;
     PT.n_producers = (uint32_t)std::min(1024, device_cu_count());
-    if (PT.flags & PTF_TILE) {  // bucket slots per partition; agg.tile_block = 512: two 512-lane workgroups per CU
-      PT.block = o.tile_block == 512 ? 512u : 1024u;
-      PT.stage_rows = partition_tile_cap(PT.n_parts, (PT.flags & PTF_NARROW) == 0, PT.block);
-      if (PT.block == 512) PT.n_producers = (uint32_t)std::min(1024, 2 * device_cu_count());
-    }
     if (o.partition_producers > 0) PT.n_producers = (uint32_t)std::min(1024, o.partition_producers);
   } else if (want == 2 && partition_ring_bytes(PT.n_words, PT.n_parts, 8) <= (size_t)158 * 1024) {
     // several aggregates: rows of 3+ words.  8-row rings (two 4-row chunks) still fit where 16-row ones do not
@@ -1071,7 +1058,6 @@ Status AggregateRelation::Impl::launch_rows(const DeviceBatch& b, const DevProgr
     }
     DFX_HIP(launch_partition(prog, fpp, cols, p, T, pt, spill, n, bytes, s));
     if (pt.flags & PTF_SHARED) ++counters().agg_shared_operand_launches;
-    if (pt.flags & PTF_TILE) ++counters().agg_tile_launches;
     ++pt_pending;
     pt_fill_bound += pt_worst;
     pt_rows_in_flight += n;

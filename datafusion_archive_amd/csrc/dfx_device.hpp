@@ -293,9 +293,6 @@ enum : uint32_t {
   PTF_CHUNK16 = 16u,      // narrow rows, no hot keys: 16-row chunks (sector-aligned 192-byte runs), 32-row rings
   PTF_WS = 64u,           // pass 1, wave-specialised flavour (dfx_k_partition_ws_inl.hpp): DevPartition::ws_scanners of the 16 waves scan,
                           // the others route; needs PTF_NARROW | PTF_CHUNK16, no PTF_HOT / PTF_SHARED
-  PTF_TILE = 128u,        // pass 1, tile-sorted flavour (dfx_k_partition_tile_inl.hpp): a workgroup counting-sorts tiles of 8192 rows by
-                          // partition in LDS and copies them out in sorted order -- dense scans (most rows routed); one key word,
-                          // one routed value (12-byte rows with PTF_NARROW, else 16-byte rows), contiguous regions, no PTF_HOT
   PTF_NARROW = 8u         // keys below 2^32 (seen by the calibration slice): 12-byte routed rows {hash image, operand}, pass 2
                           // works on 32-bit images; needs ring flavour, one key word, one aggregate
 };

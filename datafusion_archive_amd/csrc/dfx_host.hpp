@@ -136,7 +136,6 @@ struct Counters {
   long long xchg_local_us = 0;       // the rank's own scan + local aggregation (drain), until its stream is idle
   long long xchg_wait_peers_us = 0;  // the first agreement round: mostly waiting for the slowest rank's local phase
   long long xchg_exchange_us = 0;    // counts, buffers, payload rounds, merge kernels, the closing agreement
-  long long agg_tile_launches = 0;            // pass-1 launches asked to run tile-sorted (PTF_TILE)
   long long agg_shared_operand_launches = 0;  // pass-1 launches that routed {image, shared raw operand} rows (PTF_SHARED)
 };
 struct ScopedUs {  // adds the scope's wall time to a counter

@@ -727,7 +727,7 @@ static bool launch_partition_plan(const DevProgram& P, const DevFastPlan& fast, 
                                   const DevTable& T, const DevPartition& PT, const DevRows& spill, int64_t n, size_t lds_bytes,
                                   hipStream_t s) {
   const bool shared = (PT.flags & PTF_SHARED) != 0;
-  const bool one_value = (PT.flags & (PTF_WS | PTF_TILE)) || ((PT.mode & 15u) == 2 && (PT.flags & PTF_NARROW));
+  const bool one_value = (PT.flags & PTF_WS) || ((PT.mode & 15u) == 2 && (PT.flags & PTF_NARROW));
   if (one_value && !shared && T.na != 1) return false;
   const uint8_t raw_xf[kMaxAggs] = {VT_RAW};
   DevFastPlan fp;
@@ -786,7 +786,7 @@ hipError_t launch_partition(const DevProgram& P, const DevFastPlan& fast, const 
   // symmetric ones can (measured with PTF_WS on every policy: FastPolicy queries -25 %, the interpreter -28 %).  Same regions,
   // counts and padding either way, so the choice is made per launch.
   DevPartition PTg = PT;
-  PTg.flags &= ~(PTF_WS | PTF_TILE);  // (the tile-sorted flavour likewise: it is built for the signatures and the scan plans)
+  PTg.flags &= ~PTF_WS;
   const size_t lds_g = partition_stage_bytes(PTg);
   if (P.n_cols <= 2) { if (use_fast) launch_partition_variant2(P, fast, C, plan, T, PTg, spill, n, lds_g, s); else launch_partition_variant3(P, fast, C, plan, T, PTg, spill, n, lds_g, s); }
   else if (P.n_cols <= 4) { if (use_fast) launch_partition_variant4(P, fast, C, plan, T, PTg, spill, n, lds_g, s); else launch_partition_variant5(P, fast, C, plan, T, PTg, spill, n, lds_g, s); }

@@ -21,7 +21,6 @@
 #include <type_traits>
 
 #include "dfx_k_partition_inl.hpp"
-#include "dfx_k_partition_tile_inl.hpp"
 
 namespace dfx {
 
@@ -347,13 +346,11 @@ void launch_partition_ws(const DevProgram& P, const DevFastPlan& fast, const Dev
 // one pass-1 variant = one translation unit: the ring / sorted / direct kernels of the policy plus its wave-specialised kernel
 // (POLW: the one-value policy of the wave-specialised kernel -- the scanners can afford more row groups per trip than the
 // ring kernels, whose routing state competes for the same 128 registers)
-// POLT: the one-value policy of the tile-sorted kernel (PTF_TILE: dense scans; eight row groups per wave and tile = 8192-row tiles)
-#define DFX_PARTITION_VARIANT_WS(ID, POL, POLS, POLN, POLW, POLT)                                                          \
+// POLD: the one-value policy of the DENSE wave-specialised split (four scanners: eight row groups per trip)
+#define DFX_PARTITION_VARIANT_WS(ID, POL, POLS, POLN, POLW, POLD)                                                          \
   void launch_partition_variant##ID(DFX_PARTITION_VARIANT_ARGS) {                                                          \
-    if (PT.flags & PTF_TILE)                                                                                               \
-      launch_partition_tile<POLT, POLW>(P, fast, C, plan, T, PT, spill, n, s);                                             \
-    else if (PT.flags & PTF_WS)                                                                                            \
-      launch_partition_ws<POLW, POLT>(P, fast, C, plan, T, PT, spill, n, lds_bytes, s);                                    \
+    if (PT.flags & PTF_WS)                                                                                                 \
+      launch_partition_ws<POLW, POLD>(P, fast, C, plan, T, PT, spill, n, lds_bytes, s);                                    \
     else                                                                                                                   \
       launch_partition_pol<POL, POLS, POLN>(P, fast, C, plan, T, PT, spill, n, lds_bytes, s);                              \
   }

@@ -157,18 +157,6 @@ size_t partition_stage_bytes(const DevPartition& PT);
 hipError_t launch_probe_wide_keys(const DevTable& T, hipStream_t s);
 size_t partition_ring_bytes(uint32_t n_words, uint32_t n_parts, int ring_rows, bool hot = false, bool narrow = false, int queue_rows = 0);
 size_t partition_ws_bytes(uint32_t n_parts, int scanner_waves);  // LDS of the wave-specialised pass-1 kernel (PTF_WS)
-// tile-bucketed pass 1 (PTF_TILE, dfx_k_partition_tile_inl.hpp): bucket slots per partition (a multiple of 16, <= 4096) that 150 KB
-// of LDS hold next to the two counter arrays, and the LDS bytes of a launch
-inline uint32_t partition_tile_cap(uint32_t n_parts, bool wide, uint32_t block = 1024) {
-  if (n_parts == 0) return 0;
-  const size_t budget = (size_t)(block == 512 ? 76 : 150) * 1024 - (size_t)n_parts * 8 - 64;  // (512 lanes: two workgroups share a CU's 160 KB)
-  size_t cap = budget / ((size_t)n_parts * (wide ? 16 : 12));
-  cap = cap / 16 * 16;
-  return (uint32_t)(cap > 4096 ? 4096 : cap);
-}
-inline size_t partition_tile_bytes(uint32_t n_parts, uint32_t cap, bool wide) {
-  return (size_t)n_parts * cap * (wide ? 16 : 12) + (size_t)n_parts * 8 + 64;
-}
 uint32_t partition_sort_capacity(uint32_t n_words, uint32_t n_parts, uint32_t block, size_t lds_budget);
 hipError_t launch_partition(const DevProgram& P, const DevFastPlan& fast, const DevColumns& C, const DevAggPlan& plan,
                             const DevTable& T, const DevPartition& PT, const DevRows& spill, int64_t n,

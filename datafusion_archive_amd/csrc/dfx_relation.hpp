@@ -89,13 +89,9 @@ struct AggOptions {
   int pass1_ws = 8;            // pass 1 of selective scans over narrow keys: non-zero = the wave-specialised kernel (8 scanner +
                                // 8 router waves: the split DESIGN.md section 4 measured best of 6 / 8 / 10 / 12 / 14); 0: the ring
                                // kernel, every wave scans and routes
-  int pass1_tile = 0;          // pass 1 of DENSE scans (one key, one routed value): the tile-bucketed kernel -- 0 never (default: measured
-                               // equal to the ring kernel at best, round 5), 1 when the calibration slice routed more than half of its
-                               // rows, 2 whenever the shape allows (tests, A/B)
   int pass1_ws_dense = 0;      // the wave-specialised pass 1 when more than half of the rows are routed: 0 / 1 yes (default), -1 no (round 4's
                                // rule: the symmetric ring kernel)
   int pass1_ws_dense_scanners = 4;  // ... its split once more than two thirds are routed: 4 scanner + 12 router waves (8: always 8 + 8)
-  int tile_block = 1024;       // ... lanes per workgroup of the tile-bucketed kernel: 1024 (one per CU), 512 (two per CU)
   int merge_scan_batches = 1;  // an aggregate over a scan of a resident table asks for slices of >= 2^27 rows (one per routing window)
                                // whatever batch width the scan was created with; 0: the caller's batch width is kept
   int host_stream = 0;         // host Arrow batches -> HBM (HostStreamOptions::mode): 0 in-order pageable copies (default: measured fastest),

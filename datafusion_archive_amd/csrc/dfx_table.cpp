@@ -260,8 +260,6 @@ bool set_option_in(AggOptions& o, const char* key, int64_t value) {
   else if (!strcmp(key, "export.kernel_copy")) o.export_kernel_copy = (int)value;
   else if (!strcmp(key, "agg.partition_producers")) o.partition_producers = (int)value;
   else if (!strcmp(key, "agg.pass1_ws")) o.pass1_ws = (int)value;
-  else if (!strcmp(key, "agg.pass1_tile")) o.pass1_tile = (int)value;
-  else if (!strcmp(key, "agg.tile_block")) o.tile_block = (int)value;
   else if (!strcmp(key, "agg.pass1_ws_dense")) o.pass1_ws_dense = (int)value;
   else if (!strcmp(key, "agg.pass1_ws_dense_scanners")) o.pass1_ws_dense_scanners = (int)value;
   else if (!strcmp(key, "agg.merge_scan_batches")) o.merge_scan_batches = (int)value;
@@ -462,7 +460,6 @@ int64_t dfx_counter_get(const char* name) {
   if (!strcmp(name, "agg_pass2_launches")) return counters().agg_pass2_launches;
   if (!strcmp(name, "agg_growths")) return counters().agg_growths;
   if (!strcmp(name, "agg_shared_operand_launches")) return counters().agg_shared_operand_launches;
-  if (!strcmp(name, "agg_tile_launches")) return counters().agg_tile_launches;
   if (!strcmp(name, "xchg_calls")) return counters().xchg_calls;
   if (!strcmp(name, "xchg_local_us")) return counters().xchg_local_us;
   if (!strcmp(name, "xchg_wait_peers_us")) return counters().xchg_wait_peers_us;

@@ -23,7 +23,7 @@ _OPTION_DEFAULTS = {
     "agg.partition_pad": 0, "agg.dict_capacity_log2": 0, "agg.partition_cap_rows": 0, "agg.partition_defer": 0, "agg.partition_split_rows": 1 << 26,
     "agg.partition_defer_batches": 8, "agg.pass2_stream": 1, "agg.calibration_memo": 1, "agg.emit_async": 1,
     "agg.hot_keys": -1, "agg.partition_layout": 1, "agg.partition_producers": 0, "agg.narrow_keys": -1,
-    "agg.ctrl_snapshot": 1, "filter.single_pass": 1, "agg.pass1_ws": 8, "agg.pass1_tile": 0, "agg.tile_block": 1024, "agg.pass1_ws_dense": 0, "agg.pass1_ws_dense_scanners": 4,
+    "agg.ctrl_snapshot": 1, "filter.single_pass": 1, "agg.pass1_ws": 8, "agg.pass1_ws_dense": 0, "agg.pass1_ws_dense_scanners": 4,
     # tests scan resident tables in SMALL batches on purpose (multi-batch paths, deferred pass 2 ...): the library's default
     # (one slice per routing window for an aggregate over a table scan) would merge them away
     "agg.merge_scan_batches": 0, "agg.early_keys": 1, "csv.wave_tiles": 1, "export.kernel_copy": 1, "agg.narrow_chunk16": 1, "agg.shared_operand": 1,

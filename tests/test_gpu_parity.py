@@ -897,69 +897,6 @@ def test_partitioned_pass1_flavours(mode, skew):
     assert_groups_identical(got, want, 1, f"partition_mode={mode} sentinel key")
 
 
-@pytest.mark.parametrize("narrow", [1, 0])
-@pytest.mark.parametrize("defer", [1, 4])
-def test_partitioned_tile_sorted_pass1(narrow, defer):
-    """Round 5: the tile-sorted pass 1 (PTF_TILE, dfx_k_partition_tile_inl.hpp: tiles of rows counting-sorted by partition in
-    LDS, copied out in sorted order) against the oracle, forced on (agg.pass1_tile = 2; by default dense scans take it):
-    12-byte rows {hash image, operand} and 16-byte rows {key, operand}; with and without a predicate (compile-time signatures),
-    a MIN (scan plan), a nullable value column (scan plan with bitmaps), an Int32 key (4-byte key flavour); uniform keys and
-    Zipf keys (region overflow -> spill list); pass 2 after every batch and deferred over several (regions resumed);
-    ragged last batch; tiny regions (every tile overflows); the claim-sentinel key, wide and negative keys in a host batch."""
-    ex.set_option("agg.strategy", 3)
-    ex.set_option("agg.pass1_tile", 2)
-    ex.set_option("agg.narrow_keys", 1 if narrow else 0)
-    ex.set_option("agg.hot_keys", 0)
-    ex.set_option("agg.partition_defer", defer)
-    schema = pa.schema([("k", pa.int64()), ("v", pa.float64())])
-    pred = BinaryExpr(BinaryExpr(Column(1), Operator.Gt, lit(100.0)), Operator.And, BinaryExpr(Column(1), Operator.Lt, lit(900.0)))
-    for kind, groups in ((ex.SYNTH_I64_UNIFORM, 300000.0), (ex.SYNTH_I64_ZIPF, 1000000.0)):
-        syn = [("k", kind, 0, groups, 1.0), ("v", ex.SYNTH_F64_EXACT, 1, 0.0, 0.0)]
-        n, seed = (1 << 22) + 12345, 0xDF51
-        t = ex.DeviceTable.synth(syn, seed, 0, n)
-        ob = oracle.synth_batch(syn, seed, 0, n)
-        for a in (agg("sum", Column(1), F64), agg("min", Column(1), F64)):
-            for f in (None, pred):
-                before = ex.counter_get("agg_tile_launches")
-                got = gpu_aggregate([Column(0)], [a], schema, [], source=t.scan(1 << 20), filter_expr=f)
-                want = oracle.aggregate([Column(0)], [a], [oracle.filter_next(f, ob) if f is not None else ob])
-                assert_groups_identical(got, want, 1, f"tile pass 1 narrow={narrow} defer={defer} kind={kind} {a.name} pred={f is not None}")
-                assert ex.counter_get("agg_tile_launches") > before
-    # tiny regions: most rows of every tile overflow into the spill list
-    ex.set_option("agg.partition_cap_rows", 64)
-    syn = [("k", ex.SYNTH_I64_UNIFORM, 0, 100000.0, 0.0), ("v", ex.SYNTH_F64_EXACT, 1, 0.0, 0.0)]
-    n, seed = (1 << 21) + 777, 0xDF52
-    t = ex.DeviceTable.synth(syn, seed, 0, n)
-    ob = oracle.synth_batch(syn, seed, 0, n)
-    a = agg("sum", Column(1), F64)
-    got = gpu_aggregate([Column(0)], [a], schema, [], source=t.scan(1 << 19))
-    assert_groups_identical(got, oracle.aggregate([Column(0)], [a], [ob]), 1, f"tile pass 1, tiny regions narrow={narrow}")
-    ex.set_option("agg.partition_cap_rows", 0)
-    # host batches: nullable values (scan plan + bitmaps), Int32 keys, the claim sentinel, wide and negative keys arriving later
-    rng = np.random.default_rng(51)
-    m = 300001
-    k = rng.integers(0, 60000, m).astype(np.int64)
-    v = rng.integers(0, 1 << 20, m).astype(np.float64) / 1024.0
-    vmask = rng.random(m) < 0.1
-    whole = pa.RecordBatch.from_arrays([pa.array(k), pa.array(v, mask=vmask)], names=["k", "v"])
-    for a in (agg("sum", Column(1), F64), agg("count", Column(1), DataType.UInt64), agg("max", Column(1), F64)):
-        got = gpu_aggregate([Column(0)], [a], whole.schema, [whole.slice(0, 100001), whole.slice(100001)])
-        assert_groups_identical(got, oracle.aggregate([Column(0)], [a], [whole]), 1, f"tile pass 1, nullable values narrow={narrow} {a.name}")
-    k32 = pa.RecordBatch.from_arrays([pa.array(k.astype(np.int32)), pa.array(v)], names=["k", "v"])
-    a = agg("sum", Column(1), F64)
-    got = gpu_aggregate([Column(0)], [a], k32.schema, [k32.slice(0, 200000), k32.slice(200000)],
-                        filter_expr=BinaryExpr(Column(1), Operator.LtEq, lit(800.0)))
-    want = oracle.aggregate([Column(0)], [a], [oracle.filter_next(BinaryExpr(Column(1), Operator.LtEq, lit(800.0)), k32)])
-    assert_groups_identical(got, want, 1, f"tile pass 1, Int32 key narrow={narrow}")
-    k2 = k.copy()
-    k2[::97] = np.iinfo(np.int64).min
-    k2[100001::53] = (1 << 40) + k2[100001::53]
-    k2[100002::59] = -1 - k2[100002::59]
-    odd = pa.RecordBatch.from_arrays([pa.array(k2), pa.array(v)], names=["k", "v"])
-    got = gpu_aggregate([Column(0)], [a], odd.schema, [odd.slice(0, 100001), odd.slice(100001, 100000), odd.slice(200001)])
-    assert_groups_identical(got, oracle.aggregate([Column(0)], [a], [odd]), 1, f"tile pass 1, sentinel / wide / negative keys narrow={narrow}")
-
-
 def test_key_column_downloaded_while_the_scan_runs():
     """agg.early_keys: once the group count has stopped changing between two batches the key column is compacted and copied
     to pinned memory on the side stream while the scan goes on; emit hands that copy to the exporter when no group was added
