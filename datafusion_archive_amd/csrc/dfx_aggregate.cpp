@@ -704,7 +704,8 @@ Status AggregateRelation::Impl::ensure_partition(int64_t rows, bool nulls_now) {
     if (want_narrow && chunks8) PT.flags |= PTF_NARROW;
     if (hot && na == 1 && chunks8 && partition_ring_bytes(PT.n_words, PT.n_parts, 16, true, (PT.flags & PTF_NARROW) != 0) <= (size_t)158 * 1024)
       PT.flags |= PTF_HOT;
-    if ((PT.flags & PTF_NARROW) && !(PT.flags & PTF_HOT) && o.narrow_chunk16 && partition_ring_bytes(PT.n_words, PT.n_parts, 32, false, true) <= (size_t)158 * 1024)
+    if ((PT.flags & PTF_NARROW) && !(PT.flags & PTF_HOT) && o.narrow_chunk16 && !(kNarrowLine && o.partition_layout == 2) /* LINE chunks: contiguous regions */ &&
+        partition_ring_bytes(PT.n_words, PT.n_parts, kNarrowRingRows, false, true) <= (size_t)158 * 1024)
       PT.flags |= PTF_CHUNK16;
     // selective scans: the scanning and the routing belong to different waves (dfx_k_partition_ws_inl.hpp).  When most rows
     // pass, every wave has rows to route all the time and the ring kernel's symmetric waves are the better fit
@@ -743,7 +744,9 @@ Status AggregateRelation::Impl::ensure_partition(int64_t rows, bool nulls_now) {
     PT.n_producers = (uint32_t)std::min(1024, device_cu_count());
   }
   const uint64_t avg = (uint64_t)rows / ((uint64_t)PT.n_producers * PT.n_parts) + 1;
-  pt_worst = (uint32_t)((2 * avg + 64 + 63) / 64 * 64);
+  // capacities are whole 64-row trips; LINE chunks (ten rows per 128-byte line, PTF_CHUNK16): whole lines as well
+  const uint64_t capq = ((PT.flags & PTF_CHUNK16) && kNarrowLine) ? (uint64_t)kNarrowCapQuantum : 64ull;
+  pt_worst = (uint32_t)((2 * avg + 64 + capq - 1) / capq * capq);
   // regions hold `window` worst-case batches.  Deferral pays when few rows are routed (headline, 20 %: 2 batches per
   // pass 2 = -3 % per query); when most rows are, the twice-as-long regions cost pass 1 more than the saved launches
   // give back (config 3, 1e9 rows: 11.05 ms at 2, 10.08 ms at 1)
@@ -751,14 +754,18 @@ Status AggregateRelation::Impl::ensure_partition(int64_t rows, bool nulls_now) {
   if (dense_seen) window = 1;
   PT.cap_rows = pt_worst * (uint32_t)window;
   if (o.partition_cap_rows > 0) {  // tests: tiny regions (overflow -> spill list); no deferral
-    PT.cap_rows = (uint32_t)((o.partition_cap_rows + 63) / 64 * 64);
+    PT.cap_rows = (uint32_t)(((uint64_t)o.partition_cap_rows + capq - 1) / capq * capq);
     pt_worst = PT.cap_rows;
   }
   if (o.pass2_stream && na == 1 && kw == 1) PT.flags |= PTF_STREAM_PASS2;
-  const uint64_t pad_words = (uint64_t)(o.partition_pad >= 0 ? o.partition_pad : 0) / 8;
+  uint64_t pad_words = (uint64_t)(o.partition_pad >= 0 ? o.partition_pad : 0) / 8;
+  if ((PT.flags & PTF_CHUNK16) && kNarrowLine) pad_words = (pad_words + 15) / 16 * 16;  // (every region starts on a 128-byte line)
   size_t row_bytes;
-  const uint64_t region_words = (PT.flags & PTF_NARROW) ? (uint64_t)PT.cap_rows * 12 / 8 : (uint64_t)PT.cap_rows * PT.n_words;
-  PT.win_stride = region_words / (PT.cap_rows / 64);  // 64 rows' worth: regions are contiguous (layouts 0 and 1)
+  const bool line_chunks = (PT.flags & PTF_CHUNK16) && kNarrowLine;  // a region is cap_rows / 10 lines of 128 bytes
+  const uint64_t region_words = line_chunks ? (uint64_t)(PT.cap_rows / (uint32_t)kNarrowChunkRows) * (kNarrowSlotBytes / 8)
+                                : (PT.flags & PTF_NARROW) ? (uint64_t)PT.cap_rows * 12 / 8 : (uint64_t)PT.cap_rows * PT.n_words;
+  // one pass-2 trip's worth (64 contiguous rows, or six LINE chunks = 60 rows: 768 bytes either way): regions are contiguous (layouts 0 and 1)
+  PT.win_stride = line_chunks ? 96u : region_words / (PT.cap_rows / 64);
   if (o.partition_layout == 2) {  // windowed: window w of every partition of a producer side by side
     PT.part_stride = PT.win_stride;
     PT.win_stride = (uint64_t)PT.n_parts * PT.part_stride;

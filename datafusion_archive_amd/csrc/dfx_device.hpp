@@ -290,12 +290,33 @@ enum : uint32_t {
   PTF_SHARED = 32u,       // with PTF_NARROW, 2..3 aggregates that all take the SAME null-free operand (AVG = SUM + COUNT,
                           // SUM + MIN + MAX of one column ...): routed rows stay {hash image, RAW operand}; pass 2 applies every
                           // aggregate's own transform and atomic to it (n_words is 2 whatever the aggregate count)
-  PTF_CHUNK16 = 16u,      // narrow rows, no hot keys: 16-row chunks (sector-aligned 192-byte runs), 32-row rings
+  PTF_CHUNK16 = 16u,      // narrow rows, no hot keys: the large-chunk geometry (kNarrowChunkRows / kNarrowRingRows below) -- round 6:
+                          // LINE chunks, ten 12-byte rows + 8 bytes of padding = ONE whole 128-byte line per chunk, three-slot rings
   PTF_WS = 64u,           // pass 1, wave-specialised flavour (dfx_k_partition_ws_inl.hpp): DevPartition::ws_scanners of the 16 waves scan,
                           // the others route; needs PTF_NARROW | PTF_CHUNK16, no PTF_HOT / PTF_SHARED
   PTF_NARROW = 8u         // keys below 2^32 (seen by the calibration slice): 12-byte routed rows {hash image, operand}, pass 2
                           // works on 32-bit images; needs ring flavour, one key word, one aggregate
 };
+
+// Geometry of the large narrow chunks (PTF_CHUNK16).  tools/ubench5.hip (profiles/r06_ubench5_mi355x.jsonl): the memory system
+// takes appended chunks at 4.86 TB/s when every chunk is a whole number of 128-byte lines (128, 256, 384, 768 bytes alike) and
+// at 3.44 TB/s when it is not (64 and 192 bytes alike: rounds 2-5 wrote 192-byte chunks of sixteen rows, i.e. a line and a HALF),
+// and a scan's reads and its appends do not overlap in time (t = read bytes / 7.2 TB/s + written bytes / that rate, within a few
+// percent of every measured launch).  Twelve-byte rows do not tile a line, so a chunk is TEN rows + 8 bytes of padding:
+//   row r of a region lives at byte (r / 10) * 128 + (r % 10) * 12; a region's rows are counted in row SLOTS (a multiple of ten);
+//   pass 2 reads trips of SIX chunks = 60 rows = 768 bytes (the same trip stride as 64 contiguous rows);
+//   the LDS ring of a partition is three 128-byte slots (96 KB for 256 partitions, as the two 16-row slots were).
+// -DDFX_LINE_CHUNKS=0 builds the round-5 geometry (sixteen contiguous rows, two slots) for A/B runs (tools/build_variant.py).
+#ifndef DFX_LINE_CHUNKS
+#define DFX_LINE_CHUNKS 1
+#endif
+constexpr bool kNarrowLine = DFX_LINE_CHUNKS != 0;
+constexpr int kNarrowChunkRows = kNarrowLine ? 10 : 16;  // rows per chunk
+constexpr int kNarrowRingSlots = kNarrowLine ? 3 : 2;    // chunk slots per partition ring
+constexpr int kNarrowRingRows = kNarrowChunkRows * kNarrowRingSlots;
+constexpr int kNarrowSlotBytes = kNarrowLine ? 128 : 192;  // LDS bytes (and region bytes) per chunk
+constexpr int kNarrowTripRows = kNarrowLine ? 60 : 64;     // rows of one 768-byte pass-2 trip
+constexpr uint32_t kNarrowCapQuantum = kNarrowLine ? 320u : 64u;  // cap_rows of a PTF_CHUNK16 layout is a multiple of this
 
 // ---- Utf8 GROUP BY keys: device string dictionary (dfx_k_dict.hip) ---------------------------------
 enum : int { DICT_POOL = 0, DICT_IDS = 1, DICT_OVERFLOW = 2, DICT_WORDS = 4 };

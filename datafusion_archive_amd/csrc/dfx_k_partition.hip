@@ -442,7 +442,12 @@ __global__ __launch_bounds__(kABlock) __attribute__((amdgpu_num_vgpr(kP2Vgprs)))
   uint32_t s_j = 0;
   uint32_t s_rem = (uint32_t)__builtin_amdgcn_readlane((int)v_cnt, 0);
   const uint8_t* s_ptr = safe_ptr;
-  const uint32_t voff = (uint32_t)lane * kRowBytes;  // (lanes past the trip's rows re-read its first row: measured 11 % over-fetch otherwise)
+  // LINE chunks (PTF_CHUNK16 with kNarrowLine, dfx_device.hpp): a trip is six 128-byte lines of ten rows -- lane L < 60 reads row
+  // L % 10 of line L / 10 --, else 64 contiguous rows; 768 bytes either way
+  const bool line_chunks = NARROW != 0 && kNarrowLine && (PT.flags & PTF_CHUNK16) != 0;
+  const uint32_t trip_rows = line_chunks ? (uint32_t)kNarrowTripRows : 64u;
+  const uint32_t voff = line_chunks ? ((uint32_t)lane / 10u) * 128u + ((uint32_t)lane % 10u) * 12u
+                                    : (uint32_t)lane * kRowBytes;  // (lanes past the trip's rows re-read its first row: measured 11 % over-fetch otherwise)
   uint32_t take[kPF];
   auto advance = [&]() -> uint32_t {  // rows of the next trip (0: exhausted); leaves its address in s_ptr_trip
     while (s_rem == 0 && s_j < n_mine) {
@@ -452,7 +457,7 @@ __global__ __launch_bounds__(kABlock) __attribute__((amdgpu_num_vgpr(kP2Vgprs)))
         s_ptr = part_bytes + (uint64_t)(wave + (uint32_t)(kABlock / 64) * s_j) * prod_bytes;
       }
     }
-    return s_rem < 64u ? s_rem : 64u;
+    return s_rem < trip_rows ? s_rem : trip_rows;
   };
 #define DFX_P2_FETCH(D)                                                   \
   {                                                                       \
@@ -678,7 +683,7 @@ size_t partition_stage_bytes(const DevPartition& PT) {
   if ((PT.mode & 15u) == 0) return (size_t)PT.n_parts * 4 + 16;
   if ((PT.mode & 15u) == 2 && (PT.flags & PTF_WS)) return partition_ws_bytes(PT.n_parts, PT.ws_scanners == 4 ? 4 : 8);
   if ((PT.mode & 15u) == 2)
-    return partition_ring_bytes(PT.n_words, PT.n_parts, (PT.flags & PTF_CHUNK16) ? 32 : (PT.mode & 0x100u) ? 8 : 16, (PT.flags & PTF_HOT) != 0,
+    return partition_ring_bytes(PT.n_words, PT.n_parts, (PT.flags & PTF_CHUNK16) ? kNarrowRingRows : (PT.mode & 0x100u) ? 8 : 16, (PT.flags & PTF_HOT) != 0,
                                 (PT.flags & PTF_NARROW) != 0, (PT.flags & PTF_SHARED) ? 128 : 0);
   return (size_t)PT.stage_rows * ((size_t)PT.n_words * 8 + 4) + (size_t)PT.n_parts * 12 + (2 + 16) * 4 + 16;
 }

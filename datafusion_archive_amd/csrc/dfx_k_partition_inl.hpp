@@ -42,6 +42,33 @@ DEV uint32_t* region_row12(const DevPartition& PT, uint32_t part, uint32_t produ
          (uint64_t)(row & 63u) * 3u;
 }
 
+// Narrow rows of the large-chunk geometry (PTF_CHUNK16; dfx_device.hpp: kNarrowLine): with LINE chunks a chunk of CH = 10 rows
+// is one 128-byte line, in the region and in the LDS ring alike.  Regions of this geometry are contiguous (layouts 0 and 1).
+template <int CH, int NARROW>
+constexpr bool ring_is_line() { return kNarrowLine && NARROW != 0 && CH == kNarrowChunkRows; }
+// dword index (from the ring's first dword) of row r of chunk slot sl of partition `part`
+template <int CH, int RP, int NARROW>
+DEV uint32_t ring_dword12(uint32_t part, uint32_t sl, uint32_t r) {
+  if constexpr (ring_is_line<CH, NARROW>()) return (part * (uint32_t)(RP / CH) + sl) * 32u + r * 3u;
+  else return (part * (uint32_t)RP + sl * (uint32_t)CH + r) * 3u;
+}
+// dwords of a narrow ring
+template <int CH, int RP, int NARROW>
+DEV size_t ring_dwords12(uint32_t n_parts) {
+  if constexpr (ring_is_line<CH, NARROW>()) return (size_t)n_parts * (size_t)(RP / CH) * 32u;
+  else return (size_t)n_parts * RP * 3u;
+}
+// row slot `row` of a narrow region
+template <int CH, int NARROW>
+DEV uint32_t* region_row12g(const DevPartition& PT, uint32_t part, uint32_t producer, uint32_t row) {
+  if constexpr (ring_is_line<CH, NARROW>()) {
+    const uint32_t c = row / (uint32_t)CH;
+    return (uint32_t*)(PT.rows + (uint64_t)part * PT.part_stride + (uint64_t)producer * PT.prod_stride) + (uint64_t)c * 32u + (uint64_t)(row - c * (uint32_t)CH) * 3u;
+  } else {
+    return region_row12(PT, part, producer, row);
+  }
+}
+
 DEV uint32_t partition_of(const DevTable& T, const DevPartition& PT, uint64_t h) {
   return (uint32_t)(((h >> T.shift) & T.mask) >> PT.part_shift);
 }
@@ -448,7 +475,7 @@ __global__ __launch_bounds__(BLOCK) void k_partition_sorted(const DevProgram P, 
 // Leftover partial chunks are written row by row at the end.
 // ring rows per partition kRingRP = rows per chunk (CH: 4 or 8) x chunks (NCH).  (An 8-row ring with two
 // workgroups per CU -- 32 waves -- was measured ~20 % slower than 16 rows and one workgroup.)
-constexpr int ring_queue_rows(int rp) { return rp == 16 ? 192 : 128; }  // (32-row rings: 16-row chunks of 12-byte rows need the LDS)
+constexpr int ring_queue_rows(int rp) { return rp == 16 ? 192 : 128; }  // (32- and 30-row rings: 96 KB of ring, 128-row queues)  // (32-row rings: 16-row chunks of 12-byte rows need the LDS)
 constexpr int kRingBlock = 1024;
 constexpr int kHotSlots = 1024;        // hot-key pairs per pass-1 workgroup, 16-byte rows
 constexpr int kHotSlotsNarrow = 2048;  // ... with 12-byte rows (the ring is 16 KB smaller)
@@ -468,7 +495,9 @@ struct RingLds {
 #ifdef DFX_PARTITION_MAIN_TU  // a plain function: defined once, in dfx_k_partition.hip
 size_t partition_ring_bytes(uint32_t n_words, uint32_t n_parts, int kRingRP, bool hot, bool narrow, int queue_rows) {
   const int kRingQ = queue_rows > 0 ? queue_rows : ring_queue_rows(kRingRP);
-  return (size_t)n_parts * kRingRP * (narrow ? 12 : n_words * 8) + (size_t)(kRingBlock / 64) * kRingQ * n_words * 8 +
+  const size_t ring = (narrow && kNarrowLine && kRingRP == kNarrowRingRows) ? (size_t)n_parts * kNarrowRingSlots * kNarrowSlotBytes
+                                                                            : (size_t)n_parts * kRingRP * (narrow ? 12 : n_words * 8);
+  return ring + (size_t)(kRingBlock / 64) * kRingQ * n_words * 8 +
          (size_t)(kRingBlock / 64) * 64 * (kRingRP >= 16 ? 8 : 4) + (size_t)n_parts * 4 * (1 + 2 * 4) + 64 +
          (hot ? (size_t)(narrow ? kHotSlotsNarrow : kHotSlots) * 16 : 0);
 }
@@ -528,7 +557,7 @@ DEV void ring_route(const DevTable& T, const DevPartition& PT, const DevRows& sp
     if (pending && __hip_atomic_load(&L.gen[cs], __ATOMIC_ACQUIRE, WG_SCOPE) == g) {
       uint64_t* dst = L.ring + ((size_t)part * kRingRP + sl * kRingCH + r) * NW;
       if (NARROW) {
-        uint32_t* d32 = (uint32_t*)L.ring + ((size_t)part * kRingRP + sl * kRingCH + r) * 3;
+        uint32_t* d32 = (uint32_t*)L.ring + ring_dword12<kRingCH, kRingRP, NARROW>(part, sl, r);
         d32[0] = img;
         d32[1] = (uint32_t)val[0];
         d32[2] = (uint32_t)(val[0] >> 32);
@@ -549,12 +578,21 @@ DEV void ring_route(const DevTable& T, const DevPartition& PT, const DevRows& sp
       const uint32_t njobs = (uint32_t)__popcll(jm);
       if (job) jobs[mbcnt64(jm)] = (part << 20) | c;
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      for (uint32_t j0 = 0; j0 < njobs; j0 += 64 / kRingCH) {
-        const uint32_t j = j0 + (uint32_t)lane / kRingCH;
+      // lanes that copy one chunk out: a 128-byte LINE chunk is eight 16-byte pieces (ten rows and the padding, as they lie in the
+      // ring slot), any other chunk one lane per row
+      constexpr bool LINE = ring_is_line<kRingCH, NARROW>();
+      constexpr uint32_t kJobLanes = LINE ? 8u : (uint32_t)kRingCH;
+      for (uint32_t j0 = 0; j0 < njobs; j0 += 64 / kJobLanes) {
+        const uint32_t j = j0 + (uint32_t)lane / kJobLanes;
         if (j < njobs) {
           const uint32_t jw = jobs[j];
           const uint2 jb = make_uint2(jw >> 20, jw & 0xFFFFFu);
-          const uint32_t rr = (uint32_t)lane % kRingCH;
+          const uint32_t rr = (uint32_t)lane % kJobLanes;
+          if constexpr (LINE) {
+            const uint4 piece = *(const uint4*)((const uint32_t*)L.ring + ring_dword12<kRingCH, kRingRP, NARROW>(jb.x, jb.y % kRingNCH, 0) + rr * 4u);
+            *(uint4*)(region_row12g<kRingCH, NARROW>(PT, jb.x, producer, jb.y * kRingCH) + rr * 4u) = piece;
+            continue;
+          }
           const uint64_t* src = L.ring + ((size_t)jb.x * kRingRP + (jb.y % kRingNCH) * kRingCH + rr) * NW;
           uint64_t* out = region_row(PT, jb.x, producer, jb.y * kRingCH + rr);
           if (NARROW) {
@@ -666,7 +704,7 @@ DEV void ring_route2(const DevTable& T, const DevPartition& PT, const DevRows& s
       park[b] = pending[b] && gen_now[b] == g[b];
       if (park[b]) {
         if (NARROW) {
-          uint32_t* d32 = (uint32_t*)L.ring + ((size_t)part[b] * kRingRP + sl[b] * kRingCH + r[b]) * 3;
+          uint32_t* d32 = (uint32_t*)L.ring + ring_dword12<kRingCH, kRingRP, NARROW>(part[b], sl[b], r[b]);
           d32[0] = img[b];
           d32[1] = (uint32_t)val[b];
           d32[2] = (uint32_t)(val[b] >> 32);
@@ -695,13 +733,19 @@ DEV void ring_route2(const DevTable& T, const DevPartition& PT, const DevRows& s
       if (job[0]) jobs[mbcnt64(jm0)] = (part[0] << 20) | c[0];
       if (job[1]) jobs[n0 + mbcnt64(jm1)] = (part[1] << 20) | c[1];
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      for (uint32_t j0 = 0; j0 < njobs; j0 += 64 / kRingCH) {
-        const uint32_t j = j0 + (uint32_t)lane / kRingCH;
+      constexpr bool LINE = ring_is_line<kRingCH, NARROW>();  // (see ring_route)
+      constexpr uint32_t kJobLanes = LINE ? 8u : (uint32_t)kRingCH;
+      for (uint32_t j0 = 0; j0 < njobs; j0 += 64 / kJobLanes) {
+        const uint32_t j = j0 + (uint32_t)lane / kJobLanes;
         if (j < njobs) {
           const uint32_t jw = jobs[j];
           const uint2 jb = make_uint2(jw >> 20, jw & 0xFFFFFu);
-          const uint32_t rr = (uint32_t)lane % kRingCH;
-          if (NARROW) {
+          const uint32_t rr = (uint32_t)lane % kJobLanes;
+          if constexpr (LINE) {
+            // one global_store_dwordx4 per lane, eight adjacent lanes = one whole 128-byte line
+            const uint4 piece = *(const uint4*)((const uint32_t*)L.ring + ring_dword12<kRingCH, kRingRP, NARROW>(jb.x, jb.y % kRingNCH, 0) + rr * 4u);
+            *(uint4*)(region_row12g<kRingCH, NARROW>(PT, jb.x, producer, jb.y * kRingCH) + rr * 4u) = piece;
+          } else if (NARROW) {
             const uint32_t* s32 = (const uint32_t*)L.ring + ((size_t)jb.x * kRingRP + (jb.y % kRingNCH) * kRingCH + rr) * 3;
             uint32_t* o32 = region_row12(PT, jb.x, producer, jb.y * kRingCH + rr);
             const uint32_t a = s32[0], b2 = s32[1], c3 = s32[2];
@@ -783,7 +827,7 @@ __global__ __launch_bounds__(kRingBlock) void k_partition_ring(const DevProgram 
   const int NW = (int)PT.n_words;
   RingLds L;
   L.ring = lds;
-  const size_t ring_words = NARROW ? (size_t)PT.n_parts * kRingRP * 3 / 2 : (size_t)PT.n_parts * kRingRP * NW;  // 12-byte rows
+  const size_t ring_words = NARROW ? ring_dwords12<kRingCH, kRingRP, NARROW>(PT.n_parts) / 2 : (size_t)PT.n_parts * kRingRP * NW;  // 12-byte rows
   L.queue = L.ring + ring_words;
   L.jobs = (uint32_t*)(L.queue + (size_t)NWAVES * kRingQ * NW);
   L.fill = (uint32_t*)(L.jobs + NWAVES * 64 * (kRingRP >= 16 ? 2 : 1));
@@ -973,8 +1017,8 @@ __global__ __launch_bounds__(kRingBlock) void k_partition_ring(const DevProgram 
     const uint32_t rem = f % kRingCH;
     for (uint32_t r = 0; r < rem; ++r) {
       if (NARROW) {
-        const uint32_t* s32 = (const uint32_t*)L.ring + ((size_t)p * kRingRP + (c % kRingNCH) * kRingCH + r) * 3;
-        uint32_t* o32 = region_row12(PT, p, producer, c * kRingCH + r);
+        const uint32_t* s32 = (const uint32_t*)L.ring + ring_dword12<kRingCH, kRingRP, NARROW>(p, c % kRingNCH, r);
+        uint32_t* o32 = region_row12g<kRingCH, NARROW>(PT, p, producer, c * kRingCH + r);
         for (int w = 0; w < 3; ++w) o32[w] = s32[w];
       } else {
         const uint64_t* src = L.ring + ((size_t)p * kRingRP + (c % kRingNCH) * kRingCH + r) * NW;
@@ -985,7 +1029,7 @@ __global__ __launch_bounds__(kRingBlock) void k_partition_ring(const DevProgram 
     if (rem != 0) {
       for (uint32_t r = rem; r < (uint32_t)kRingCH; ++r) {
         if (NARROW) {
-          uint32_t* o32 = region_row12(PT, p, producer, c * kRingCH + r);
+          uint32_t* o32 = region_row12g<kRingCH, NARROW>(PT, p, producer, c * kRingCH + r);
           o32[0] = kTagEmpty;
           o32[1] = o32[2] = 0;
         } else {
@@ -1025,9 +1069,9 @@ void launch_partition_pol(const DevProgram& P, const DevFastPlan& fast, const De
   else if ((PT.mode & 15u) == 2 && (PT.flags & PTF_NARROW) && (PT.flags & PTF_HOT))
     hipLaunchKernelGGL((k_partition_ring<POLN, 8, 16, true, 1>), dim3(grid), dim3(kRingBlock), lds_bytes, s, P, fast, C, plan, T, PT, spill, n);
   else if ((PT.mode & 15u) == 2 && (PT.flags & PTF_NARROW) && (PT.flags & PTF_CHUNK16))
-    // 16-row chunks: 192 bytes = three whole 64-byte sectors (a 96-byte chunk of 8 rows straddles sectors: WRITE_SIZE was
-    // 1.26 x the routed bytes)
-    hipLaunchKernelGGL((k_partition_ring<POLN, 16, 32, false, 1>), dim3(grid), dim3(kRingBlock), lds_bytes, s, P, fast, C, plan, T, PT, spill, n);
+    // the large-chunk geometry (dfx_device.hpp: kNarrowLine): whole 128-byte lines of ten rows; rounds 3-5: 16-row chunks of 192 bytes
+    // (three whole 64-byte sectors; a 96-byte chunk of 8 rows straddles sectors: WRITE_SIZE was 1.26 x the routed bytes)
+    hipLaunchKernelGGL((k_partition_ring<POLN, kNarrowChunkRows, kNarrowRingRows, false, 1>), dim3(grid), dim3(kRingBlock), lds_bytes, s, P, fast, C, plan, T, PT, spill, n);
   else if ((PT.mode & 15u) == 2 && (PT.flags & PTF_NARROW))  // narrow keys: 12-byte rows
     hipLaunchKernelGGL((k_partition_ring<POLN, 8, 16, false, 1>), dim3(grid), dim3(kRingBlock), lds_bytes, s, P, fast, C, plan, T, PT, spill, n);
   else if ((PT.mode & 15u) == 2 && (PT.flags & PTF_HOT))  // skewed keys: hot-key pairs in LDS

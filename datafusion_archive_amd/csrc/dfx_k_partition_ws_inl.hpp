@@ -14,7 +14,7 @@
 //     atomic -> ring -> commit -> cooperative 192-byte flushes.
 // A scanner stalls only when its queue is full (the router then has >= 64 rows to take, so it cannot be a deadlock);
 // a router waits only for rows or for another router's flush of a LOWER chunk -- the argument of the ring kernel.
-// Narrow 12-byte rows in 16-row chunks only (PTF_NARROW | PTF_CHUNK16: one routed value, keys below 2^32, no hot-key
+// Narrow 12-byte rows in the large-chunk geometry only (PTF_NARROW | PTF_CHUNK16 -- round 6: LINE chunks, dfx_device.hpp --: one routed value, keys below 2^32, no hot-key
 // pairs); rows the narrow form cannot carry (wide keys, the claim sentinel, reserved images, region overflow) take the
 // spill list exactly as in the ring kernel.  Same scratch layout, counts and padding: pass 2 cannot tell the flavours apart.
 #pragma once
@@ -25,7 +25,7 @@
 namespace dfx {
 
 constexpr int kWsQueueRows = 256;  // per scanner wave (power of two): 3 KB {u32 key, u64 operand}
-constexpr int kWsCH = 16, kWsRP = 32, kWsNCH = kWsRP / kWsCH;
+constexpr int kWsCH = kNarrowChunkRows, kWsRP = kNarrowRingRows, kWsNCH = kWsRP / kWsCH;  // (dfx_device.hpp: LINE chunks of ten rows, three slots)
 
 struct WsCtl {  // one per queue (= per router wave)
   uint32_t tail;  // rows produced (written by the queue's scanner)
@@ -37,7 +37,7 @@ struct WsCtl {  // one per queue (= per router wave)
 #ifdef DFX_PARTITION_MAIN_TU
 size_t partition_ws_bytes(uint32_t n_parts, int ns) {
   const int nq = kRingBlock / 64 - ns;  // one queue per ROUTER wave (a scanner feeds (16 - ns) / ns of them in turn)
-  return (size_t)n_parts * kWsRP * 12 + (size_t)(kRingBlock / 64) * 64 * 8 /* jobs */ + (size_t)n_parts * 4 * (1 + 2 * kWsNCH) +
+  return (size_t)n_parts * kNarrowRingSlots * kNarrowSlotBytes + (size_t)(kRingBlock / 64) * 64 * 8 /* jobs */ + (size_t)n_parts * 4 * (1 + 2 * kWsNCH) +
          (size_t)nq * kWsQueueRows * 12 + (size_t)nq * sizeof(WsCtl) + 64;
 }
 #else
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(kRingBlock) void k_partition_ws(const DevProgram P,
   extern __shared__ __attribute__((aligned(16))) uint64_t lds[];
   RingLds L;
   L.ring = lds;
-  const size_t ring_words = (size_t)PT.n_parts * kWsRP * 3 / 2;  // 12-byte rows
+  const size_t ring_words = ring_dwords12<kWsCH, kWsRP, 1>(PT.n_parts) / 2;  // 12-byte rows (LINE chunks: 128-byte slots)
   L.queue = nullptr;                                             // (the ring kernel's wave queues: not used here)
   L.jobs = (uint32_t*)(L.ring + ring_words);
   L.fill = L.jobs + NWAVES * 64 * 2;
@@ -291,13 +291,13 @@ __global__ __launch_bounds__(kRingBlock) void k_partition_ws(const DevProgram P,
     const uint32_t c = f / kWsCH;
     const uint32_t rem = f % kWsCH;
     for (uint32_t rr = 0; rr < rem; ++rr) {
-      const uint32_t* s32 = (const uint32_t*)L.ring + ((size_t)p * kWsRP + (c % kWsNCH) * kWsCH + rr) * 3;
-      uint32_t* o32 = region_row12(PT, p, producer, c * kWsCH + rr);
+      const uint32_t* s32 = (const uint32_t*)L.ring + ring_dword12<kWsCH, kWsRP, 1>(p, c % kWsNCH, rr);
+      uint32_t* o32 = region_row12g<kWsCH, 1>(PT, p, producer, c * kWsCH + rr);
       for (int w = 0; w < 3; ++w) o32[w] = s32[w];
     }
     if (rem != 0) {
       for (uint32_t rr = rem; rr < (uint32_t)kWsCH; ++rr) {
-        uint32_t* o32 = region_row12(PT, p, producer, c * kWsCH + rr);
+        uint32_t* o32 = region_row12g<kWsCH, 1>(PT, p, producer, c * kWsCH + rr);
         o32[0] = kTagEmpty;
         o32[1] = o32[2] = 0;
       }

@@ -16,14 +16,16 @@ vdir = os.path.join(b.LIBDIR, "variants")
 odir = os.path.join(b.OBJDIR, "variant_" + name)
 os.makedirs(vdir, exist_ok=True)
 os.makedirs(odir, exist_ok=True)
-objs = []
+objs, jobs = [], []
 for src in b.SOURCES:
     obj = os.path.join(b.OBJDIR, os.path.splitext(src)[0] + ".o")
     if src in tus:
         obj = os.path.join(odir, os.path.splitext(src)[0] + ".o")
-        cmd = [b._hipcc()] + b.CXXFLAGS + flags + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", os.path.join(b.CSRC, src), "-o", obj]
-        subprocess.check_call(cmd)
+        jobs.append([b._hipcc()] + b.CXXFLAGS + flags + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", os.path.join(b.CSRC, src), "-o", obj])
     objs.append(obj)
+from concurrent.futures import ThreadPoolExecutor  # noqa: E402
+with ThreadPoolExecutor(max_workers=int(os.environ.get("DFX_BUILD_JOBS", "8"))) as ex:  # (the translation units compile side by side, as in build.py)
+    list(ex.map(subprocess.check_call, jobs))
 out = os.path.join(vdir, f"libdfx_{name}.so")
 subprocess.check_call([b._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
 print(out)

@@ -25,6 +25,7 @@ struct Geo {
   uint32_t nt_store;
   uint32_t read_groups;   // 64-row groups to scan (0: writers only)
   uint32_t parts;         // regions per workgroup
+  uint32_t wrap;          // > 0: a region is a ring of this many chunks (the scratch stays small enough for the 256 MB Infinity Cache)
 };
 
 __global__ __launch_bounds__(1024) void k_rw(const uint64_t* __restrict__ a, const uint64_t* __restrict__ b, uint8_t* regions, uint64_t wg_bytes, Geo g, uint64_t* out) {
@@ -74,6 +75,7 @@ __global__ __launch_bounds__(1024) void k_rw(const uint64_t* __restrict__ a, con
       uint32_t pos = 0;
       if (rr == 0) pos = atomicAdd(&cursor[part], 1u);
       pos = __shfl(pos, (int)(sub * g.chunk_lanes), 64);
+      if (g.wrap) pos %= g.wrap;
       uint8_t* o = my + (uint64_t)part * g.region_bytes + (uint64_t)pos * chunk_bytes + rr * g.row_bytes;
       if ((uint64_t)(pos + 1) * chunk_bytes > g.region_bytes) continue;  // (a region that is full: skew of the generator)
       if (g.row_bytes == 12) {
@@ -100,9 +102,17 @@ int main() {
   CK(hipMemset(regions, 0, reg_total));
   hipStream_t s; CK(hipStreamCreate(&s));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  struct Case { const char* name; uint32_t lanes, rb, pad, nt; double sel; int read; uint32_t parts; };
+  struct Case { const char* name; uint32_t lanes, rb, pad, nt; double sel; int read; uint32_t parts; uint32_t wrap = 0; };
   std::vector<Case> cases = {
       {"read_only", 16, 12, 0, 0, 0.0, 1, 256},
+      // full-line chunks: 8 lanes x 16 B = one 128-byte line; 16 x 16 = two lines; 4 lanes x 16 B = 64 bytes (half a line)
+      {"write_only_dense_64B_rows16", 4, 16, 0, 0, 0.75, 0, 256},
+      {"write_only_dense_128B_rows16", 8, 16, 0, 0, 0.75, 0, 256},
+      {"write_only_dense_256B_rows16_same_bytes", 16, 16, 0, 0, 0.75, 0, 256},
+      {"dense_128B_rows16_same_bytes", 8, 16, 0, 0, 0.75, 1, 256},
+      {"dense_256B_rows16_same_bytes", 16, 16, 0, 0, 0.75, 1, 256},
+      {"sel20_256B_rows16_same_bytes", 16, 16, 0, 0, 0.15, 1, 256},
+      {"sel20_128B_rows16_same_bytes", 8, 16, 0, 0, 0.15, 1, 256},
       {"write_only_dense_192B", 16, 12, 0, 0, 1.0, 0, 256},
       {"write_only_dense_384B", 32, 12, 0, 0, 1.0, 0, 256},
       {"write_only_dense_768B", 64, 12, 0, 0, 1.0, 0, 256},
@@ -127,15 +137,24 @@ int main() {
       {"sel20_192B", 16, 12, 0, 0, 0.2, 1, 256},
       {"sel20_384B", 32, 12, 0, 0, 0.2, 1, 256},
       {"sel20_768B", 64, 12, 0, 0, 0.2, 1, 256},
+      // the scratch as a small ring per region: 8 chunks x 192 B x 65536 regions = 100 MB (fits the Infinity Cache), 4 chunks = 50 MB, 2 = 25 MB (fits L2)
+      {"write_only_dense_192B_wrap8", 16, 12, 0, 0, 1.0, 0, 256, 8},
+      {"write_only_dense_384B_wrap4", 32, 12, 0, 0, 1.0, 0, 256, 4},
+      {"dense_192B_wrap8", 16, 12, 0, 0, 1.0, 1, 256, 8},
+      {"dense_192B_wrap2", 16, 12, 0, 0, 1.0, 1, 256, 2},
+      {"dense_384B_wrap4", 32, 12, 0, 0, 1.0, 1, 256, 4},
+      {"dense_384B_wrap16", 32, 12, 0, 0, 1.0, 1, 256, 16},
+      {"sel20_192B_wrap8", 16, 12, 0, 0, 0.2, 1, 256, 8},
+      {"sel20_384B_wrap4", 32, 12, 0, 0, 0.2, 1, 256, 4},
   };
   for (const Case& c : cases) {
     Geo g;
-    g.chunk_lanes = c.lanes; g.row_bytes = c.rb; g.nt_store = c.nt; g.parts = c.parts;
+    g.chunk_lanes = c.lanes; g.row_bytes = c.rb; g.nt_store = c.nt; g.parts = c.parts; g.wrap = c.wrap;
     const uint32_t chunk_bytes = c.lanes * c.rb;
     const double routed_rows_per_wg = c.sel * (double)rows / 256.0;
     const uint32_t chunks_per_wg = (uint32_t)(routed_rows_per_wg / c.lanes);
     g.chunks_per_wave = chunks_per_wg / 8;
-    const uint32_t chunks_per_region = (uint32_t)(1.3 * chunks_per_wg / c.parts) + 8;
+    const uint32_t chunks_per_region = c.wrap ? c.wrap : (uint32_t)(1.3 * chunks_per_wg / c.parts) + 8;
     g.region_bytes = chunks_per_region * chunk_bytes + c.pad;
     g.read_groups = c.read ? (uint32_t)(rows / 64) : 0;
     const uint64_t wg_bytes = ((uint64_t)g.region_bytes * c.parts + 255) / 256 * 256;
