@@ -337,8 +337,14 @@ def main():
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         names = ["local_scan_and_aggregate", "wait_for_slowest_rank", "exchange_and_merge", "emit_and_download", "host_driven_exchange"]
-        return {n_: {"min_over_ranks": round(float(lo[i].item()), 3), "max_over_ranks": round(float(hi[i].item()), 3)} for i, n_ in enumerate(names)
-                if i < 4 or float(hi[i].item()) > 0.0}
+        out = {n_: {"min_over_ranks": round(float(lo[i].item()), 3), "max_over_ranks": round(float(hi[i].item()), 3)} for i, n_ in enumerate(names)
+               if i < 4 or float(hi[i].item()) > 0.0}
+        # what the library's exchange cost in protocol terms (rank 0's counters; grouped queries): collective rounds and host
+        # synchronisations per query -- round 6: 2 and 2 (the all-gather of states + counts, the buckets)
+        calls = max(1, ex.counter_get("xchg_calls"))
+        out["collective_rounds"] = round(ex.counter_get("xchg_rounds") / calls, 2)
+        out["host_syncs"] = round(ex.counter_get("xchg_host_syncs") / calls, 2)
+        return out
 
     def step(filter_expr=pred, group=(Column(0),), aggs=(sum_v,)):
         return finish(build(filter_expr, list(group), list(aggs)))
@@ -1051,6 +1057,10 @@ def main():
                                 "vs the CPU oracle over the same row range of the same generator"}
             e["verified_vs_oracle"] = checked("rows_1e10_tail", verify_tail)
             extra["rows_1e10"] = e
+            # the N = 1 anchor of the multi-GPU curve: N > 1 ranks share config 4's 10^10 rows, so their line divides by THIS rate
+            # (one GPU over the same 10^10 rows), not by the 10^9-row headline above
+            if e.get("rows_per_s"):
+                extra["scaling_anchor_rows_per_s"] = e["rows_per_s"]
             del tb
             ex.set_option("pool.trim", 1)
         except Exception as e:  # e.g. a box with less free HBM: a measurement, not a gate

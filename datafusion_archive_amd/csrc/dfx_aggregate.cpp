@@ -2110,6 +2110,10 @@ Status AggregateRelation::exchange_drain() {
   return m.drain();
 }
 
+// the groups of the drained table as the host knows them (the control block's count after the drain's last check) + the
+// sentinel group's slot: what partial_count can find at most
+uint64_t AggregateRelation::exchange_group_bound() const { return impl_->occupied_known + 1; }
+
 Status AggregateRelation::exchange_count(int world, uint64_t* d_counts) {
   Impl& m = *impl_;
   if (world < 1 || world > 1024) return Status::Err(DFX_GENERAL, "world must be in 1..1024");

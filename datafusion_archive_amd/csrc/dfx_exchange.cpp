@@ -112,11 +112,14 @@ static size_t slab_dict_mine(int W) { return 2 * (size_t)W; }                  /
 static size_t slab_dict_all(int W) { return 2 * (size_t)W + 4; }               // [3 W]
 static size_t slab_state_mine(int W) { return 5 * (size_t)W + 8; }             // [2 kMaxAggs]  (ungrouped)
 static size_t slab_state_all(int W) { return 5 * (size_t)W + 8 + 2 * kMaxAggs; }  // [2 kMaxAggs x W]
-static size_t slab_words(int W) { return slab_state_all(W) + (size_t)2 * kMaxAggs * (size_t)W + 8; }
+static size_t slab_gather_mine(int W) { return slab_state_all(W) + (size_t)2 * kMaxAggs * (size_t)W + 8; }  // [W + 3]  (grouped, round 1)
+static size_t slab_gather_all(int W) { return slab_gather_mine(W) + (size_t)W + 4; }                      // [W][W + 3]
+static size_t slab_words(int W) { return slab_gather_all(W) + (size_t)W * ((size_t)W + 3) + 8; }
 
 // all-to-all of `count_of(peer)` 64-bit words per peer; peer == rank is a device-to-device copy
+// t_out / t_in (may be null): one TRAILER word more per peer -- t_out[peer] travels behind the bucket, lands in t_in[peer]
 template <typename SendAt, typename RecvAt>
-static Status all_to_all_words(dfx_comm* c, SendAt send_at, RecvAt recv_at, hipStream_t s) {
+static Status all_to_all_words(dfx_comm* c, SendAt send_at, RecvAt recv_at, hipStream_t s, const uint64_t* t_out = nullptr, uint64_t* t_in = nullptr) {
   Rccl& r = rccl();
   if (c->world > 1) DFX_NCCL(r.GroupStart(), "ncclGroupStart");
   Status st = Status::OK();
@@ -132,10 +135,16 @@ static Status all_to_all_words(dfx_comm* c, SendAt send_at, RecvAt recv_at, hipS
         hipError_t e = hipMemcpyAsync(rp, sp, sn * sizeof(uint64_t), hipMemcpyDeviceToDevice, s);
         if (e != hipSuccess) st = Status::Err(DFX_EXECUTION_ERROR, strfmt("HIP error %s in the exchange", hipGetErrorString(e)));
       }
+      if (st.ok() && t_out) {
+        hipError_t e = hipMemcpyAsync(t_in + peer, t_out + peer, sizeof(uint64_t), hipMemcpyDeviceToDevice, s);
+        if (e != hipSuccess) st = Status::Err(DFX_EXECUTION_ERROR, strfmt("HIP error %s in the exchange", hipGetErrorString(e)));
+      }
       continue;
     }
     if (sn) st = nccl_status(r.Send(sp, sn, ncclUint64, peer, c->comm, s), "ncclSend");
+    if (st.ok() && t_out) st = nccl_status(r.Send(t_out + peer, 1, ncclUint64, peer, c->comm, s), "ncclSend");
     if (st.ok() && rn) st = nccl_status(r.Recv(rp, rn, ncclUint64, peer, c->comm, s), "ncclRecv");
+    if (st.ok() && t_in) st = nccl_status(r.Recv(t_in + peer, 1, ncclUint64, peer, c->comm, s), "ncclRecv");
   }
   if (c->world > 1) {
     Status ge = nccl_status(r.GroupEnd(), "ncclGroupEnd");
@@ -363,7 +372,26 @@ Status AggregateRelation::exchange(dfx_comm* c, int64_t* stats) {
     return Status::OK();
   }
   // ---- grouped ----
-  uint64_t* d_counts = c->words + slab_flags(world);  // [0, world): send counts, [world, 2 world): received ones
+  // Round 6: TWO collective rounds and TWO host synchronisations in the common case (rounds 4-5: agree -> counts -> read-back ->
+  // agree -> payload -> agree, four read-backs).
+  //   round 1  ONE all-gather of world + 3 words per rank: {how the rank is | what it is about to exchange, the groups it can
+  //            receive and the groups it can send without allocating anything more, its group count per destination rank}.  Every rank then holds the whole
+  //            count matrix and every rank's state -- the first agreement, the count round and the buffer agreement in one.
+  //            Everything a rank needs for the payload round is allocated BEFORE this round (send buffer: its own group count,
+  //            exact; receive buffer and import table: capacity for twice its own group count -- ranks that scanned row ranges
+  //            of one table own about as many groups as each holds), so a rank that cannot allocate says so here.
+  //   (extra)  only if some rank receives (or holds) more than the capacity it announced -- every rank computes that from the same matrix,
+  //            so all of them take this branch or none does -- that rank allocates again and the ranks agree() on the outcome.
+  //   round 2  the buckets, chunk by chunk as before; the LAST chunk's message to every peer carries one trailer word more: how
+  //            the sender was when it sent.  A rank that failed locally has kept sending well-formed buckets; its mark ends the
+  //            exchange on every rank after the one synchronisation of the payload rounds (no closing agree()).
+  // What a rank does after its last collective (the merge of what it received, the control block's read-back) can only fail
+  // that rank: nobody waits for it any more.
+  const int W = world;
+  constexpr size_t H = 3;                                       // header words of a rank's round-1 message: state, receive capacity, send capacity
+  const size_t MW = (size_t)W + H;                              // ... + its counts
+  uint64_t* d_mine = c->words + slab_gather_mine(W);            // [W + 3]
+  uint64_t* d_all = c->words + slab_gather_all(W);              // [W][W + 3]
   Status local = exchange_drain();
   if (local.ok()) local = hip_local(hipStreamSynchronize(s));
   const long long t_local = ScopedUs::now();
@@ -376,79 +404,151 @@ Status AggregateRelation::exchange(dfx_comm* c, int64_t* stats) {
     widest = std::max(widest, exchange_chunk_words(ch));
     shape = shape * 31 + (uint64_t)exchange_chunk_words(ch);
   }
-  {
-    Status ag = agree(c, local, shape & 0xFFFFFFFFFFFFull, "before the exchange", &host_syncs, s);
-    counters().xchg_wait_peers_us += ScopedUs::now() - t_local;
+  shape &= 0xFFFFFFFFFFFFull;
+  int64_t rounds = 0;
+  if (exchange_dicts() > 0) {
+    // Utf8 keys: the dictionaries are globalised first (rounds of their own: sizes, blobs, agreements); a rank that failed its
+    // drain must not enter them, so this form keeps round 4's agreement in front
+    Status ag = agree(c, local, shape, "before the exchange", &host_syncs, s);
+    ++rounds;
     DFX_RETURN_IF_ERROR(ag);
+    DFX_RETURN_IF_ERROR(globalise_dictionaries(this, c, &host_syncs));
   }
-  ScopedUs t_rest(&counters().xchg_exchange_us);
-  if (exchange_dicts() > 0) DFX_RETURN_IF_ERROR(globalise_dictionaries(this, c, &host_syncs));
-  // counts: a rank whose count kernel cannot run sends the failure mark instead
-  local = exchange_count(world, d_counts);
-  if (local.ok()) local = injected(c, "count");
+  // everything the payload round needs, before anybody commits to it
+  const uint64_t own_groups = local.ok() ? exchange_group_bound() : 0;  // (what the host knows; the count kernel has the last word)
+  uint64_t send_cap = own_groups + 64;
+  uint64_t cap_groups = 2 * own_groups + 4096;
+  Status st;
+  std::shared_ptr<void> send, recv;
+  if (local.ok()) {
+    send = device_alloc(sizeof(uint64_t) * (size_t)(send_cap * (uint64_t)widest + (uint64_t)W), &st);   // (+ W trailer words)
+    if (send) recv = device_alloc(sizeof(uint64_t) * (size_t)(cap_groups * (uint64_t)widest + (uint64_t)W), &st);
+    if (!send || !recv) local = st;
+  }
+  if (local.ok()) local = injected(c, "payload_alloc");
+  if (local.ok()) local = exchange_import_begin(cap_groups);
+  // round 1
   {
-    std::vector<uint64_t> init((size_t)world, kPeerFailed);
-    hipError_t e = hipSuccess;
-    if (!local.ok()) e = hipMemcpyAsync(d_counts, init.data(), sizeof(uint64_t) * (size_t)world, hipMemcpyHostToDevice, s);
-    if (e == hipSuccess) e = hipMemsetAsync(d_counts + world, 0, sizeof(uint64_t) * (size_t)world, s);
-    if (e != hipSuccess && local.ok()) local = Status::Err(DFX_EXECUTION_ERROR, strfmt("HIP error %s in the exchange", hipGetErrorString(e)));
-    if (e != hipSuccess) (void)hipStreamSynchronize(s);  // (`init` is a stack vector)
-    DFX_RETURN_IF_ERROR(all_to_all_words(
-        c, [&](int peer, const void** p, size_t* n) { *p = d_counts + peer; *n = 1; },
-        [&](int peer, void** p, size_t* n) { *p = d_counts + world + peer; *n = 1; }, s));
+    if (local.ok()) {
+      local = exchange_count(W, d_mine + H);
+      if (local.ok()) local = injected(c, "count");
+    }
+    if (!local.ok()) {  // a rank that is not well sends zeros behind its failure mark (its table may not even exist)
+      Status z = hip_local(hipMemsetAsync(d_mine + H, 0, sizeof(uint64_t) * (size_t)W, s));
+      (void)z;
+    }
+    const uint64_t word = local.ok() ? (1ull | (shape << 8)) : kPeerFailed;
+    Status f0 = hip_local(launch_fill_u64(d_mine, word, 1, s));
+    Status f1 = hip_local(launch_fill_u64(d_mine + 1, cap_groups, 1, s));
+    Status f2 = hip_local(launch_fill_u64(d_mine + 2, send_cap, 1, s));
+    if (local.ok()) local = f0.ok() ? (f1.ok() ? f2 : f1) : f0;
+    if (W > 1) {
+      DFX_NCCL(rccl().AllGather(d_mine, d_all, MW, ncclUint64, c->comm, s), "ncclAllGather");
+    } else {
+      Status cp = hip_local(hipMemcpyAsync(d_all, d_mine, sizeof(uint64_t) * MW, hipMemcpyDeviceToDevice, s));
+      if (local.ok()) local = cp;
+    }
+    ++rounds;
   }
-  std::vector<uint64_t> hc((size_t)world * 2);
-  {  // the ONE read-back of the exchange proper: buffer sizes
-    Status rb = hip_local(hipMemcpyAsync(hc.data(), d_counts, sizeof(uint64_t) * hc.size(), hipMemcpyDeviceToHost, s));
+  std::vector<uint64_t> M((size_t)W * MW);
+  {  // the ONE read-back before the payload: every rank's state, capacity and counts
+    Status rb = hip_local(hipMemcpyAsync(M.data(), d_all, sizeof(uint64_t) * M.size(), hipMemcpyDeviceToHost, s));
     Status sy = hip_local(hipStreamSynchronize(s));
     if (local.ok()) local = rb.ok() ? sy : rb;
   }
   ++host_syncs;
-  // (every rank has finished the count round -- the last collective before this point -- so leaving here strands nobody:
-  // a rank that failed sent the failure mark, or, if it could not even do that, its peers fail in the agree() they go to next)
+  counters().xchg_wait_peers_us += ScopedUs::now() - t_local;
+  ScopedUs t_rest(&counters().xchg_exchange_us);
+  // (every rank has finished round 1 -- the last collective before this point -- so leaving here strands nobody)
   if (!local.ok()) return local;
-  for (int r = 0; r < world; ++r)
-    if (hc[(size_t)world + r] == kPeerFailed) return Status::Err(DFX_EXECUTION_ERROR, strfmt("multi-GPU exchange: rank %d failed before the exchange", r));
-  std::vector<int64_t> send_counts((size_t)world, 0), recv_counts((size_t)world, 0);
-  std::vector<uint64_t> sbase((size_t)world + 1, 0), rbase((size_t)world + 1, 0);
-  for (int r = 0; r < world; ++r) {
-    send_counts[r] = (int64_t)hc[r];
-    recv_counts[r] = (int64_t)hc[(size_t)world + r];
-    sbase[r + 1] = sbase[r] + hc[r];
-    rbase[r + 1] = rbase[r] + hc[(size_t)world + r];
+  const uint64_t my_word = 1ull | (shape << 8);
+  for (int r = 0; r < W; ++r)
+    if (M[(size_t)r * MW] == kPeerFailed) return Status::Err(DFX_EXECUTION_ERROR, strfmt("multi-GPU exchange: rank %d failed before the exchange", r));
+  for (int r = 0; r < W; ++r)
+    if (M[(size_t)r * MW] != my_word)
+      return Status::Err(DFX_EXECUTION_ERROR, strfmt("multi-GPU exchange: rank %d is exchanging a different query (keys / accumulator chunks / dictionaries)", r));
+  std::vector<int64_t> send_counts((size_t)W, 0), recv_counts((size_t)W, 0);
+  std::vector<uint64_t> sbase((size_t)W + 1, 0), rbase((size_t)W + 1, 0);
+  bool need_more = false;  // (the same verdict on every rank: it is computed from the same matrix)
+  for (int r = 0; r < W; ++r) {
+    uint64_t into_r = 0, from_r = 0;
+    for (int q = 0; q < W; ++q) {
+      into_r += M[(size_t)q * MW + H + (size_t)r];
+      from_r += M[(size_t)r * MW + H + (size_t)q];
+    }
+    if (into_r > M[(size_t)r * MW + 1] || from_r > M[(size_t)r * MW + 2]) need_more = true;
   }
-  // every allocation of the payload rounds happens BEFORE them, and the ranks tell each other whether it worked
-  Status st;
-  auto send = device_alloc(sizeof(uint64_t) * (size_t)std::max<uint64_t>(1, sbase[world] * (uint64_t)widest), &st);
-  std::shared_ptr<void> recv;
-  if (send) recv = device_alloc(sizeof(uint64_t) * (size_t)std::max<uint64_t>(1, rbase[world] * (uint64_t)widest), &st);
-  local = (send && recv) ? Status::OK() : st;
-  if (local.ok()) local = injected(c, "payload_alloc");
-  if (local.ok()) local = exchange_import_begin(rbase[world]);
-  DFX_RETURN_IF_ERROR(agree(c, local, 0x201ull, "while it allocated its exchange buffers", &host_syncs, s));
-  if (!local.ok()) return local;  // (world == 1: agree() is the identity)
+  for (int r = 0; r < W; ++r) {
+    send_counts[(size_t)r] = (int64_t)M[(size_t)c->rank * MW + H + (size_t)r];
+    recv_counts[(size_t)r] = (int64_t)M[(size_t)r * MW + H + (size_t)c->rank];
+    sbase[(size_t)r + 1] = sbase[(size_t)r] + (uint64_t)send_counts[(size_t)r];
+    rbase[(size_t)r + 1] = rbase[(size_t)r] + (uint64_t)recv_counts[(size_t)r];
+  }
+  if (need_more) {  // some rank owns (or holds) more groups than it made room for: allocate again, agree on the outcome (round 5's form)
+    local = Status::OK();
+    if (sbase[(size_t)W] > send_cap) {
+      send.reset();
+      send_cap = sbase[(size_t)W];
+      send = device_alloc(sizeof(uint64_t) * (size_t)(send_cap * (uint64_t)widest + (uint64_t)W), &st);
+      if (!send) local = st;
+    }
+    if (local.ok() && rbase[(size_t)W] > cap_groups) {
+      recv.reset();
+      cap_groups = rbase[(size_t)W];
+      recv = device_alloc(sizeof(uint64_t) * (size_t)(cap_groups * (uint64_t)widest + (uint64_t)W), &st);
+      if (!recv) local = st;
+      if (local.ok()) local = exchange_import_begin(cap_groups);
+    }
+    Status ag = agree(c, local, 0x201ull, "while it allocated its exchange buffers", &host_syncs, s);
+    ++rounds;
+    DFX_RETURN_IF_ERROR(ag);
+    if (!local.ok()) return local;  // (world == 1: agree() is the identity)
+  }
+  // round 2: the buckets
   uint64_t* sw = (uint64_t*)send.get();
   uint64_t* rw = (uint64_t*)recv.get();
+  uint64_t* t_out = sw + send_cap * (uint64_t)widest;            // [W] how this rank was when it sent its last bucket
+  uint64_t* t_in = rw + cap_groups * (uint64_t)widest;           // [W] ... and its peers
   int64_t sent_words = 0;
   for (int ch = 0; ch < n_chunks; ++ch) {  // accumulators beyond kMaxAggs: one round per chunk of planes, the same keys every time
     const uint64_t nw = (uint64_t)exchange_chunk_words(ch);
+    const bool last = ch == n_chunks - 1;
     // a rank whose scatter / merge kernels fail keeps sending and receiving what was agreed (its peers merge rows they will
-    // throw away): the agree() behind the rounds ends the exchange on every rank
-    if (local.ok()) local = exchange_export_chunk(ch, send_counts, send.get(), (int64_t)(sbase[world] * nw));
-    if (local.ok() && ch == n_chunks - 1) local = injected(c, "export");
+    // throw away): the trailer of the last round ends the exchange on every rank
+    if (local.ok()) local = exchange_export_chunk(ch, send_counts, send.get(), (int64_t)(sbase[(size_t)W] * nw));
+    if (local.ok() && last) local = injected(c, "export");
+    if (last) {
+      Status f = hip_local(launch_fill_u64(t_out, local.ok() ? 1ull : kPeerFailed, W, s));
+      if (local.ok()) local = f;
+      Status z = hip_local(hipMemsetAsync(t_in, 0, sizeof(uint64_t) * (size_t)W, s));
+      if (local.ok()) local = z;
+    }
     DFX_RETURN_IF_ERROR(all_to_all_words(
-        c, [&](int peer, const void** p, size_t* n) { *p = sw + sbase[peer] * nw; *n = (size_t)(hc[peer] * nw); },
-        [&](int peer, void** p, size_t* n) { *p = rw + rbase[peer] * nw; *n = (size_t)(hc[(size_t)world + peer] * nw); }, s));
-    if (local.ok()) local = exchange_import_chunk(ch, recv.get(), recv_counts.data(), world);  // merges on the same stream
-    sent_words += (int64_t)(sbase[world] * nw);
+        c, [&](int peer, const void** p, size_t* n) { *p = sw + sbase[(size_t)peer] * nw; *n = (size_t)((uint64_t)send_counts[(size_t)peer] * nw); },
+        [&](int peer, void** p, size_t* n) { *p = rw + rbase[(size_t)peer] * nw; *n = (size_t)((uint64_t)recv_counts[(size_t)peer] * nw); }, s,
+        last ? t_out : nullptr, last ? t_in : nullptr));
+    ++rounds;
+    if (local.ok()) local = exchange_import_chunk(ch, recv.get(), recv_counts.data(), W);  // merges on the same stream
+    sent_words += (int64_t)(sbase[(size_t)W] * nw);
   }
-  if (local.ok()) local = exchange_import_finish();  // the one synchronisation of the payload rounds
+  std::vector<uint64_t> trailers((size_t)W, 0);
+  {
+    Status rb = hip_local(hipMemcpyAsync(trailers.data(), t_in, sizeof(uint64_t) * (size_t)W, hipMemcpyDeviceToHost, s));
+    if (local.ok()) local = rb;
+  }
+  {
+    Status fin = exchange_import_finish();  // the one synchronisation of the payload rounds (also when this rank is not well: the trailers)
+    if (local.ok()) local = fin;
+  }
   ++host_syncs;
-  DFX_RETURN_IF_ERROR(agree(c, local, 0x202ull, "during the payload rounds", &host_syncs, s));
+  counters().xchg_rounds += rounds;
+  counters().xchg_host_syncs += host_syncs;
   if (!local.ok()) return local;
+  for (int r = 0; r < W; ++r)
+    if (trailers[(size_t)r] == kPeerFailed) return Status::Err(DFX_EXECUTION_ERROR, strfmt("multi-GPU exchange: rank %d failed during the payload rounds", r));
   if (stats) {
-    stats[0] = (int64_t)sbase[world];
-    stats[1] = (int64_t)rbase[world];
+    stats[0] = (int64_t)sbase[(size_t)W];
+    stats[1] = (int64_t)rbase[(size_t)W];
     stats[2] = (int64_t)sizeof(uint64_t) * sent_words;
     stats[3] = host_syncs;
   }

@@ -135,6 +135,8 @@ struct Counters {
   long long xchg_calls = 0;
   long long xchg_local_us = 0;       // the rank's own scan + local aggregation (drain), until its stream is idle
   long long xchg_wait_peers_us = 0;  // the first agreement round: mostly waiting for the slowest rank's local phase
+  long long xchg_rounds = 0;         // collective rounds of the grouped exchanges (2 per query: the all-gather of states + counts, the buckets)
+  long long xchg_host_syncs = 0;     // ... and their host synchronisations (2 per query)
   long long xchg_exchange_us = 0;    // counts, buffers, payload rounds, merge kernels, the closing agreement
   long long agg_shared_operand_launches = 0;  // pass-1 launches that routed {image, shared raw operand} rows (PTF_SHARED)
 };

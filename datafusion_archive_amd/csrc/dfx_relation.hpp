@@ -250,6 +250,7 @@ class AggregateRelation : public Relation {
   int exchange_chunks() const;
   int exchange_chunk_words(int c) const;           // key words + accumulators of chunk c
   Status exchange_drain();                          // drains the input (grouped), no device work otherwise
+  uint64_t exchange_group_bound() const;            // after the drain: an upper bound of the groups the count kernel will find
   Status exchange_count(int world, uint64_t* d_counts);  // groups per destination rank into d_counts[0, world) (zeroed here)
   Status exchange_export_chunk(int c, const std::vector<int64_t>& counts, void* dst_device, int64_t dst_words);
   Status exchange_import_begin(uint64_t total_groups);

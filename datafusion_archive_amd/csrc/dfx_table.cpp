@@ -464,6 +464,8 @@ int64_t dfx_counter_get(const char* name) {
   if (!strcmp(name, "xchg_local_us")) return counters().xchg_local_us;
   if (!strcmp(name, "xchg_wait_peers_us")) return counters().xchg_wait_peers_us;
   if (!strcmp(name, "xchg_exchange_us")) return counters().xchg_exchange_us;
+  if (!strcmp(name, "xchg_rounds")) return counters().xchg_rounds;
+  if (!strcmp(name, "xchg_host_syncs")) return counters().xchg_host_syncs;
   if (!strcmp(name, "export_us")) return counters().export_us;
   if (!strcmp(name, "export_alloc_us")) return counters().export_alloc_us;
   return -1;

@@ -43,6 +43,9 @@ CASES = {
     # name: (n_keys, filter, group, aggregates, force options)
     "int_keys_4_aggs": (100000, PRED, [Column(0)], [agg("sum", Column(1)), agg("count", Column(1), U64), agg("min", Column(1)), agg("max", Column(2))], {}),
     "int_keys_partitioned": (100000, PRED, [Column(0)], [agg("sum", Column(1))], {"agg.strategy": 3}),
+    # ranks above 0 hold seven keys but OWN half (a third ...) of rank 0's hundred thousand: they receive far more groups than the
+    # capacity they announced in round 1, so every rank takes the extra allocate-and-agree round (round 6's protocol)
+    "int_keys_lopsided": (100000, None, [Column(0)], [agg("sum", Column(1)), agg("max", Column(2))], {}),
     "ungrouped": (1000, PRED, [], [agg("sum", Column(1)), agg("count", Column(1), U64), agg("min", Column(2)), agg("max", Column(1))], {}),
     "eleven_accumulators": (3000, PRED, [Column(0)], _Q11, {}),
     "eleven_accumulators_ungrouped": (3000, None, [], _Q11, {}),
@@ -73,7 +76,7 @@ FAILURE_CASES = ["peer_failure", "ungrouped_peer_failure"] + list(FAILURE_STAGES
 
 def batches_of_rank(case, rank):
     n_keys = CASES[case][0]
-    b = _table(rank, n_keys)
+    b = _table(rank, 7 if (case == "int_keys_lopsided" and rank > 0) else n_keys)
     if case in ("peer_failure", "ungrouped_peer_failure"):
         w = np.ones(ROWS)
         if rank == 1:

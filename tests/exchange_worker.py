@@ -55,4 +55,5 @@ assert rel.next() is None
 with pa.OSFile(os.path.join(tmp, f"out_{case}_{rank}.arrow"), "wb") as sink:
     with pa.ipc.new_file(sink, out.schema) as w:
         w.write_batch(out)
-print(f"rank {rank}: {out.num_rows} groups emitted, exchange stats {stats}")
+print(f"rank {rank}: {out.num_rows} groups emitted, exchange stats {stats}, collective rounds {ex.counter_get('xchg_rounds')}, "
+      f"host syncs {ex.counter_get('xchg_host_syncs')}")

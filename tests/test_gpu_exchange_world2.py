@@ -91,7 +91,7 @@ def test_a_local_failure_at_any_stage_ends_the_exchange_on_every_rank(case, worl
 @pytest.mark.parametrize("world", [2, 3])
 @pytest.mark.parametrize("case", [c for c in xc.CASES if c not in xc.FAILURE_CASES])
 def test_library_exchange_between_processes(case, world, tmp_path):
-    if world == 3 and case not in ("int_keys_4_aggs", "utf8_key"):
+    if world == 3 and case not in ("int_keys_4_aggs", "utf8_key", "int_keys_lopsided"):
         pytest.skip("three ranks: one integer-key and one Utf8-key case")
     _n_keys, pred, group, aggs, _opts = xc.CASES[case]
     got, logs = _run_ranks(case, world, tmp_path)
@@ -109,3 +109,11 @@ def test_library_exchange_between_processes(case, world, tmp_path):
     assert sum(b.num_rows for b in present) == want.num_rows, f"{case}: {[b.num_rows for b in present]} groups emitted, oracle has {want.num_rows}\n" + "\n".join(logs)
     assert_groups_identical(union, want, len(group), f"{case} world={world}")
     assert all(b.num_rows > 0 for b in present) and len(present) == world, "every rank owns some groups"
+    # round 6: the grouped exchange is TWO collective rounds (the all-gather of states + counts, the buckets) and two host
+    # synchronisations; a round more per further chunk of accumulators (more than 8); Utf8 keys add their dictionary rounds
+    if case in ("int_keys_4_aggs", "int_keys_partitioned"):
+        for r in range(world):
+            assert "collective rounds 2, host syncs 2" in logs[r], logs[r]
+    if case == "int_keys_lopsided":  # + the agreement after the second allocation (one round, one read-back)
+        for r in range(world):
+            assert "collective rounds 3, host syncs 3" in logs[r], logs[r]
