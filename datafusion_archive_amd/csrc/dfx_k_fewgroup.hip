@@ -70,10 +70,31 @@ __global__ __launch_bounds__(kFGBlock) void k_fewgroup_agg(const DevProgram P, c
   uint64_t passed = 0;
   typename POL::PREP prep;  // (PlanPolicy: the plan words in vector registers; empty otherwise)
   POL::prepare(P, F, prep);
+  // Software pipeline, one trip deep (round 6): the columns of trip t + 1 are in flight while trip t is evaluated.  One
+  // 512-lane workgroup per CU (the accumulators take the registers: two waves per SIMD) issued its 14 loads and waited for
+  // all of them before it evaluated anything -- 57 KB per CU in flight at best, nothing while it computed: 4.8-5.0 TB/s on the
+  // Q1 shape against the 7.2 TB/s two nt streams reach (tools/ubench4.hip).
+#ifndef DFX_FG_PREFETCH
+#define DFX_FG_PREFETCH 1  // (0: round 5's form -- load, wait, evaluate -- for A/B builds)
+#endif
+#if DFX_FG_PREFETCH
+  COLV ncol[U];
+  uint32_t ncv[U];
+  load_trip<POL>(P, C, wave_global * U, wave_global * U < n_words, n, lane, ncol, ncv);
+  for (int64_t w0 = wave_global * U; w0 < n_words; w0 += n_waves * U) {
+    COLV col[U];
+    uint32_t cv[U];
+    FOR_U {
+      col[u] = ncol[u];
+      cv[u] = ncv[u];
+    }
+    load_trip<POL>(P, C, w0 + n_waves * U, w0 + n_waves * U < n_words, n, lane, ncol, ncv);
+#else
   for (int64_t w0 = wave_global * U; w0 < n_words; w0 += n_waves * U) {
     COLV col[U];
     uint32_t cv[U];
     load_trip<POL>(P, C, w0, true, n, lane, col, cv);
+#endif
 #pragma nounroll
     for (int uu = 0; uu < U; ++uu) {  // ONE copy of the evaluation + accumulation code
       COLV cur;

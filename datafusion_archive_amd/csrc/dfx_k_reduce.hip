@@ -39,10 +39,28 @@ __global__ __launch_bounds__(kBlock) void k_reduce(const DevProgram P, const Dev
   // the scan loop once per comparison FORM (StaticPolicy::pass_form: the operators as compile-time constants; 0: run-time masks)
   auto scan = [&](auto form_tag) {
   constexpr int FORM = decltype(form_tag)::value;
+  // software pipeline, one trip deep (round 6, as the partitioned scans): the next trip's columns are in flight while this one is folded
+#ifndef DFX_REDUCE_PREFETCH
+#define DFX_REDUCE_PREFETCH 1  // (0: round 5's form -- load, wait, evaluate -- for A/B builds)
+#endif
+#if DFX_REDUCE_PREFETCH
+  COLV ncol[U];
+  uint32_t ncv[U];
+  load_trip<POL>(P, C, wave_global * U, wave_global * U < n_words, n, lane, ncol, ncv);
+  for (int64_t w0 = wave_global * U; w0 < n_words; w0 += n_waves * U) {
+    COLV col[U];
+    uint32_t cv[U];
+    FOR_U {
+      col[u] = ncol[u];
+      cv[u] = ncv[u];
+    }
+    load_trip<POL>(P, C, w0 + n_waves * U, w0 + n_waves * U < n_words, n, lane, ncol, ncv);
+#else
   for (int64_t w0 = wave_global * U; w0 < n_words; w0 += n_waves * U) {
     COLV col[U];
     uint32_t cv[U];
     load_trip<POL>(P, C, w0, true, n, lane, col, cv);
+#endif
     auto body = [&](const COLV& cur, const uint32_t curv, const int64_t row) {
       const bool inb = row < n;
       u64x16 reg;
