@@ -75,20 +75,39 @@ __global__ __launch_bounds__(kFGBlock) void k_fewgroup_agg(const DevProgram P, c
   // all of them before it evaluated anything -- 57 KB per CU in flight at best, nothing while it computed: 4.8-5.0 TB/s on the
   // Q1 shape against the 7.2 TB/s two nt streams reach (tools/ubench4.hip).
 #ifndef DFX_FG_PREFETCH
-#define DFX_FG_PREFETCH 1  // (0: round 5's form -- load, wait, evaluate -- for A/B builds)
+#define DFX_FG_PREFETCH 1  // trips in flight ahead of the one being evaluated (0: round 5's form -- load, wait, evaluate -- for A/B builds)
 #endif
 #if DFX_FG_PREFETCH
-  COLV ncol[U];
-  uint32_t ncv[U];
-  load_trip<POL>(P, C, wave_global * U, wave_global * U < n_words, n, lane, ncol, ncv);
+  // Software pipeline (round 6): the columns of trips t + 1 .. t + D are in flight while trip t is evaluated.  One 512-lane
+  // workgroup per CU (the accumulators take the registers: two waves per SIMD) issued its 14 loads and waited for all of them
+  // before it evaluated anything -- 57 KB per CU in flight at best, nothing while it computed: 4.85 TB/s on the Q1 shape
+  // against the 7.2 TB/s two nt streams reach (tools/ubench4.hip).  D = 1: 5.7-5.8 TB/s; D = 2 (206 VGPRs) measured 5.6: not short of bytes in flight any more.
+  constexpr int D = DFX_FG_PREFETCH;
+  COLV ncol[D][U];
+  uint32_t ncv[D][U];
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    const int64_t wd = wave_global * U + (int64_t)d * n_waves * U;
+    load_trip<POL>(P, C, wd, wd < n_words, n, lane, ncol[d], ncv[d]);
+  }
   for (int64_t w0 = wave_global * U; w0 < n_words; w0 += n_waves * U) {
     COLV col[U];
     uint32_t cv[U];
     FOR_U {
-      col[u] = ncol[u];
-      cv[u] = ncv[u];
+      col[u] = ncol[0][u];
+      cv[u] = ncv[0][u];
     }
-    load_trip<POL>(P, C, w0 + n_waves * U, w0 + n_waves * U < n_words, n, lane, ncol, ncv);
+#pragma unroll
+    for (int d = 0; d + 1 < D; ++d) {
+      FOR_U {
+        ncol[d][u] = ncol[d + 1][u];
+        ncv[d][u] = ncv[d + 1][u];
+      }
+    }
+    {
+      const int64_t w1 = w0 + (int64_t)D * n_waves * U;
+      load_trip<POL>(P, C, w1, w1 < n_words, n, lane, ncol[D - 1], ncv[D - 1]);
+    }
 #else
   for (int64_t w0 = wave_global * U; w0 < n_words; w0 += n_waves * U) {
     COLV col[U];
