@@ -381,6 +381,41 @@ DEV int p2_match(const Group4& g, uint32_t img, uint64_t kk) {
   return idx;
 }
 
+// The two rows' tag compares of look2 as ONE block (narrow rows).  The compiler's form is v_cmp -> vcc, s_nop 1, v_cndmask, four
+// times per row and row after row: a VALU read of a lane mask needs two wait states behind the VALU that wrote it, so eight
+// s_nop per pair of trips (5 % of the loop's issue slots).  Here the two rows' compares alternate and go to four scalar pairs,
+// every select reads a mask written at least three instructions earlier: sixteen instructions, no wait states.
+// idx = the first of the group's four tags that equals the row's image, -1 if none.
+#ifndef DFX_P2_ASM_MATCH
+#define DFX_P2_ASM_MATCH 1
+#endif
+DEV void p2_match2_narrow(const uint4& a, uint32_t img0, const uint4& b, uint32_t img1, int& i0, int& i1) {
+  uint64_t mA, mB, mC, mD;
+  int x0, x1;
+  asm volatile(
+      "v_cmp_eq_u32_e64 %[mA], %[aw], %[g0]\n\t"
+      "v_cmp_eq_u32_e64 %[mB], %[bw], %[g1]\n\t"
+      "v_cmp_eq_u32_e64 %[mC], %[az], %[g0]\n\t"
+      "v_cmp_eq_u32_e64 %[mD], %[bz], %[g1]\n\t"
+      "v_cndmask_b32_e64 %[x0], -1, 3, %[mA]\n\t"
+      "v_cndmask_b32_e64 %[x1], -1, 3, %[mB]\n\t"
+      "v_cmp_eq_u32_e64 %[mA], %[ay], %[g0]\n\t"
+      "v_cmp_eq_u32_e64 %[mB], %[by], %[g1]\n\t"
+      "v_cndmask_b32_e64 %[x0], %[x0], 2, %[mC]\n\t"
+      "v_cndmask_b32_e64 %[x1], %[x1], 2, %[mD]\n\t"
+      "v_cmp_eq_u32_e64 %[mC], %[ax], %[g0]\n\t"
+      "v_cmp_eq_u32_e64 %[mD], %[bx], %[g1]\n\t"
+      "v_cndmask_b32_e64 %[x0], %[x0], 1, %[mA]\n\t"
+      "v_cndmask_b32_e64 %[x1], %[x1], 1, %[mB]\n\t"
+      "v_cndmask_b32_e64 %[x0], %[x0], 0, %[mC]\n\t"
+      "v_cndmask_b32_e64 %[x1], %[x1], 0, %[mD]"
+      : [mA] "=&s"(mA), [mB] "=&s"(mB), [mC] "=&s"(mC), [mD] "=&s"(mD), [x0] "=&v"(x0), [x1] "=&v"(x1)
+      : [ax] "v"(a.x), [ay] "v"(a.y), [az] "v"(a.z), [aw] "v"(a.w), [bx] "v"(b.x), [by] "v"(b.y), [bz] "v"(b.z), [bw] "v"(b.w),
+        [g0] "v"(img0), [g1] "v"(img1));
+  i0 = x0;
+  i1 = x1;
+}
+
 template <int NARROW, int KIND>
 __global__ __launch_bounds__(kABlock) __attribute__((amdgpu_num_vgpr(kP2Vgprs))) void k_partition_agg_lean(const DevTable T, const DevPartition PT,
                                                                                                              const DevRows spill) {
@@ -449,12 +484,19 @@ __global__ __launch_bounds__(kABlock) __attribute__((amdgpu_num_vgpr(kP2Vgprs)))
   const uint32_t voff = line_chunks ? ((uint32_t)lane / 10u) * 128u + ((uint32_t)lane % 10u) * 12u
                                     : (uint32_t)lane * kRowBytes;  // (lanes past the trip's rows re-read its first row: measured 11 % over-fetch otherwise)
   uint32_t take[kPF];
-  auto advance = [&]() -> uint32_t {  // rows of the next trip (0: exhausted); leaves its address in s_ptr_trip
-    while (s_rem == 0 && s_j < n_mine) {
-      ++s_j;
-      if (s_j < n_mine) {
-        s_rem = (uint32_t)__builtin_amdgcn_readlane((int)v_cnt, (int)(s_j & 63u));
-        s_ptr = part_bytes + (uint64_t)(wave + (uint32_t)(kABlock / 64) * s_j) * prod_bytes;
+  uint64_t s_win = win_bytes;  // (0 once the wave's regions are exhausted: the remaining loads of the pipeline re-read safe_ptr)
+  auto advance = [&]() -> uint32_t {  // rows of the next trip (0: exhausted); leaves its address in s_ptr
+    if (s_rem == 0) {  // the next region that holds rows -- off the common path
+      while (s_rem == 0 && s_j < n_mine) {
+        ++s_j;
+        if (s_j < n_mine) {
+          s_rem = (uint32_t)__builtin_amdgcn_readlane((int)v_cnt, (int)(s_j & 63u));
+          s_ptr = part_bytes + (uint64_t)(wave + (uint32_t)(kABlock / 64) * s_j) * prod_bytes;
+        }
+      }
+      if (s_rem == 0) {
+        s_ptr = safe_ptr;
+        s_win = 0;
       }
     }
     return s_rem < trip_rows ? s_rem : trip_rows;
@@ -463,8 +505,8 @@ __global__ __launch_bounds__(kABlock) __attribute__((amdgpu_num_vgpr(kP2Vgprs)))
   {                                                                       \
     const uint32_t tk = advance();                                        \
     take[D] = tk;                                                         \
-    p2_issue<D, NARROW>((uint32_t)lane < tk ? voff : 0u, tk ? (const void*)s_ptr : (const void*)safe_ptr); \
-    s_ptr += win_bytes;                                                   \
+    p2_issue<D, NARROW>((uint32_t)lane < tk ? voff : 0u, (const void*)s_ptr);                               \
+    s_ptr += s_win;                                                       \
     s_rem -= tk;                                                          \
   }
   DFX_P2_FETCH(0) DFX_P2_FETCH(1) DFX_P2_FETCH(2) DFX_P2_FETCH(3) DFX_P2_FETCH(4) DFX_P2_FETCH(5) DFX_P2_FETCH(6) DFX_P2_FETCH(7)
@@ -479,8 +521,9 @@ __global__ __launch_bounds__(kABlock) __attribute__((amdgpu_num_vgpr(kP2Vgprs)))
   // the probe loop was bound by that latency: 3.9 us per million rows whatever the instruction count).
   struct Probe {
     uint64_t val, kk;
-    uint32_t home4, at, img;
-    bool real, hit;
+    uint32_t home4, img;
+    int j;  // after look2: the row's slot within its home group (0..3), -1: a row whose key is not there (parked), 4: not a row
+    bool real;
   };
   auto decode = [&](const Row4& r, uint32_t tk, Probe& q) {
     const bool inb = (uint32_t)lane < tk;
@@ -498,23 +541,23 @@ __global__ __launch_bounds__(kABlock) __attribute__((amdgpu_num_vgpr(kP2Vgprs)))
       uint64_t key1[1] = {q.kk};
       q.home4 = (uint32_t)(hash_keys<1>(key1) >> T.shift) & mask4;
     }
-    q.at = 0;
-    q.hit = false;
+    q.j = 4;
   };
   auto look2 = [&](Probe& q0, uint32_t g0, Probe& q1, uint32_t g1) {  // both rows' groups: two LDS reads in flight, then the compares
     Group4 a, b;
     p2_read_group<NARROW>(ltags, lkeys, g0, a);
     p2_read_group<NARROW>(ltags, lkeys, g1, b);
-    p2_pin<NARROW>(a, b);
-    const int i0 = p2_match<NARROW>(a, q0.img, q0.kk), i1 = p2_match<NARROW>(b, q1.img, q1.kk);
-    if (!q0.hit && q0.real && i0 >= 0) {
-      q0.at = g0 + (uint32_t)i0;
-      q0.hit = true;
+    int i0, i1;
+    if constexpr (NARROW != 0 && DFX_P2_ASM_MATCH != 0) {
+      p2_match2_narrow(a.t, q0.img, b.t, q1.img, i0, i1);  // (also pins both reads in front of the compares)
+    } else {
+      p2_pin<NARROW>(a, b);
+      i0 = p2_match<NARROW>(a, q0.img, q0.kk);
+      i1 = p2_match<NARROW>(b, q1.img, q1.kk);
     }
-    if (!q1.hit && q1.real && i1 >= 0) {
-      q1.at = g1 + (uint32_t)i1;
-      q1.hit = true;
-    }
+    // hit and miss are then ONE compare each on j (a bool that is the AND of two lane masks costs a v_cndmask + v_cmp to ballot)
+    q0.j = q0.real ? i0 : 4;
+    q1.j = q1.real ? i1 : 4;
   };
   // Rows whose home group does not hold their key (4 % at load 0.5, every row of a block's first batch) are parked in a
   // per-wave LDS queue and go through the general find-or-claim up to 64 at a time.  Handling them in place costs the
@@ -559,10 +602,9 @@ __global__ __launch_bounds__(kABlock) __attribute__((amdgpu_num_vgpr(kP2Vgprs)))
     }
   };
   auto park = [&](const Probe& q) {
-    const bool miss = q.real && !q.hit;
-    const uint64_t m = __ballot(miss);
+    const uint64_t m = __ballot(q.j < 0);
     if (m != 0) {
-      if (miss) {
+      if (q.j < 0) {
         const uint32_t at = rqn + mbcnt64(m);
         if (NARROW) {
           rq[at * kRW] = q.img;
@@ -589,8 +631,8 @@ __global__ __launch_bounds__(kABlock) __attribute__((amdgpu_num_vgpr(kP2Vgprs)))
     decode(r0, tk0, q0);
     decode(r1, tk1, q1);
     look2(q0, q0.home4, q1, q1.home4);
-    if (q0.hit) apply(q0.at, q0.val);
-    if (q1.hit) apply(q1.at, q1.val);
+    if ((uint32_t)q0.j < 4u) apply(q0.home4 + (uint32_t)q0.j, q0.val);
+    if ((uint32_t)q1.j < 4u) apply(q1.home4 + (uint32_t)q1.j, q1.val);
     park(q0);
     park(q1);
   };
