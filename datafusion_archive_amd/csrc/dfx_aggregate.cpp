@@ -1456,7 +1456,7 @@ Status AggregateRelation::Impl::dict_encode(DictKey& d, const DeviceColumn& src,
   }
   for (int attempt = 0; n > 0; ++attempt) {
     if (attempt > 16) return Status::Err(DFX_INTERNAL_ERROR, "Utf8 key dictionary does not converge");
-    DFX_HIP(launch_dict_encode(src.offsets, src.data, n, d.D, (uint64_t*)ids.get(), s));
+    DFX_HIP(launch_dict_encode(src.offsets, src.data, n, d.D, d.ids_used, (uint64_t*)ids.get(), s));
     uint64_t hc[DICT_WORDS];
     DFX_HIP(hipMemcpyAsync(hc, d.D.cursors, sizeof(hc), hipMemcpyDeviceToHost, s));
     DFX_HIP(hipStreamSynchronize(s));

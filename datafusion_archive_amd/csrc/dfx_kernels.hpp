@@ -143,8 +143,8 @@ hipError_t launch_merge_bucket(const uint64_t* bucket, uint64_t count, const Dev
                                const DevRows& spill, hipStream_t s);
 
 // Utf8 GROUP BY keys (dfx_k_dict.hip): strings -> stable 64-bit ids and back
-hipError_t launch_dict_encode(const int32_t* offsets, const uint8_t* data, int64_t n, const DevDict& D, uint64_t* ids,
-                              hipStream_t s);
+hipError_t launch_dict_encode(const int32_t* offsets, const uint8_t* data, int64_t n, const DevDict& D, uint64_t n_known, uint64_t* ids,
+                              hipStream_t s);  // n_known: ids the dictionary already holds (complete: written by earlier launches)
 hipError_t launch_dict_rebuild(const DevDict& D, uint64_t n_ids, hipStream_t s);
 hipError_t launch_dict_remap_plane(uint64_t* plane, uint64_t n_slots, const uint64_t* remap, uint64_t n_ids, hipStream_t s);
 hipError_t launch_dict_lengths(const uint64_t* ids, int64_t g, const DevDict& D, uint32_t* lens, hipStream_t s);

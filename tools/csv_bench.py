@@ -47,4 +47,5 @@ for it in range(3):
     print(f"{size / 1e6:.0f} MB, {rows} rows: open (read + H2D) {1e3 * (t1 - t0):.1f} ms = {size / (t1 - t0) / 1e9:.2f} GB/s; "
           f"index + parse + aggregate {1e3 * (t2 - t1):.1f} ms = {size / (t2 - t1) / 1e9:.2f} GB/s; "
           f"csv kernels {csv['total_ms']:.2f} ms in {csv['launches']} launches = {size / max(csv['total_ms'], 1e-9) / 1e6:.1f} GB/s of text")
+    print("   kernels: " + "  ".join(f"{k}:{v['launches']}x{v['total_ms']:.3f}ms" for k, v in prof.items()))
 os.remove(path)
