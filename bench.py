@@ -517,11 +517,11 @@ def main():
                     "end_to_end_GBps": round(e2e_gbps, 1), "end_to_end_frac": round(e2e_gbps / HBM_PEAK_GBPS, 4)}
 
     # HBM traffic of the dominant kernel: rocprofv3 PMC passes over the same query (tools/gpu_round.sh profile ->
-    # profiles/r05_partition_counters.json; FETCH_SIZE and WRITE_SIZE collected in SEPARATE passes; FETCH_SIZE doubled as
+    # profiles/r06_partition_counters.json; FETCH_SIZE and WRITE_SIZE collected in SEPARATE passes; FETCH_SIZE doubled as
     # MI355X_MICROARCH.md prescribes for gfx950 -- doubled it equals the table bytes read, the calibration point).  It is a
     # committed measurement of this kernel, not something this run collected; null if the file is absent.
     if roofline is not None:
-        for fname in ("r05_partition_counters.json", "r04_partition_counters.json", "r03_partition_counters.json", "r02_partition_counters.json"):
+        for fname in ("r06_partition_counters.json", "r05_partition_counters.json", "r04_partition_counters.json", "r03_partition_counters.json", "r02_partition_counters.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", fname)) as f:
                     ctr = json.load(f)
