@@ -22,6 +22,7 @@ pytestmark = pytest.mark.gpu
 
 F64 = DataType.Float64
 N = 1 << 28
+N_DENSE = 1 << 27  # the unfiltered variants (every row routed: two routing windows of 2^26 rows; the oracle needs 30 s per 2^27 such rows)
 BATCH = 1 << 26
 SEED = 0xDF02
 SCHEMA = pa.schema([("k", pa.int64()), ("v", pa.float64())])
@@ -98,13 +99,18 @@ _pool = None
 _futures = {}
 
 
+def _rows(name):
+    """rows of QUERIES[name]: the filtered queries run at the size bench.py's headline is checked at (2^28), the unfiltered ones at 2^27"""
+    return N_DENSE if QUERIES[name][1] is None else N
+
+
 def _oracle_result(name):
     """(seconds, rows kept, result batch) of the oracle for QUERIES[name]; every query is started on first use."""
     global _pool
     if _pool is None:
         _pool = ThreadPoolExecutor(len(QUERIES) + 3)
         for q, (syn, pred, aggs) in QUERIES.items():
-            _futures[q] = _pool.submit(oracle.run_synth_query, syn, SEED, 0, N, 1024, pred, [Column(0)], aggs)
+            _futures[q] = _pool.submit(oracle.run_synth_query, syn, SEED, 0, _rows(q), 1024, pred, [Column(0)], aggs)
         # config 2: FilterRelation reference-shaped, 1024-row batches, compacted column + the predicate's BooleanArray
         _futures["cfg2_filter"] = _pool.submit(oracle.run_synth_filter, SYN_LAT, SEED2, 0, N2, 1024, PRED2)
         for q, syn in (("q1_exact", SYN_Q1_EXACT), ("q1_uniform", SYN_Q1_UNIFORM)):  # + COUNT: rows per group for the tolerance
@@ -114,7 +120,7 @@ def _oracle_result(name):
 
 def _gpu(name):
     syn, pred, aggs = QUERIES[name]
-    t = ex.DeviceTable.synth(syn, SEED, 0, N)
+    t = ex.DeviceTable.synth(syn, SEED, 0, _rows(name))
     return gpu_aggregate([Column(0)], aggs, SCHEMA, [], filter_expr=pred, source=t.scan(BATCH))
 
 
@@ -145,21 +151,21 @@ def test_headline_query_per_group_vs_oracle_at_2_28_rows():
     _assert_bit_exact(got, want, "headline 2^28")
 
 
-def test_config3_no_filter_per_group_vs_oracle_at_2_28_rows():
+def test_config3_no_filter_per_group_vs_oracle_at_2_27_rows():
     """BASELINE config 3 as written (SELECT k, SUM(v) GROUP BY k, no filter: every row is routed), plus MIN/MAX."""
     got = _gpu("config3")
     _secs, kept, want = _oracle_result("config3")
-    assert kept == N and got.num_rows == 1000000
-    _assert_bit_exact(got, want, "config 3 2^28")
+    assert kept == _rows("config3") and got.num_rows == 1000000
+    _assert_bit_exact(got, want, "config 3 2^27")
 
 
-def _exact_sums_uniform(pred_lo_hi):
-    """correctly rounded EXACT SUM(v) of every group of the `uniform` table (oracle.ExactGroupSums), slice by slice"""
+def _exact_sums_uniform(pred_lo_hi, n):
+    """correctly rounded EXACT SUM(v) of every group of the first n rows of the `uniform` table (oracle.ExactGroupSums), slice by slice"""
     ex_ = oracle.ExactGroupSums(1000000)
     step = 1 << 24
-    for r0 in range(0, N, step):
-        k = oracle.synth_column(oracle.SYNTH_I64_UNIFORM, 0, 1e6, 0.0, SEED, r0, min(step, N - r0))
-        v = oracle.synth_column(oracle.SYNTH_F64_UNIFORM, 1, 0.0, 1.0, SEED, r0, min(step, N - r0))
+    for r0 in range(0, n, step):
+        k = oracle.synth_column(oracle.SYNTH_I64_UNIFORM, 0, 1e6, 0.0, SEED, r0, min(step, n - r0))
+        v = oracle.synth_column(oracle.SYNTH_F64_UNIFORM, 1, 0.0, 1.0, SEED, r0, min(step, n - r0))
         if pred_lo_hi is not None:
             keep = (v > pred_lo_hi[0]) & (v < pred_lo_hi[1])
             k, v = k[keep], v[keep]
@@ -174,7 +180,8 @@ def test_uniform_values_within_tolerance_at_2_28_rows():
     reference's sum (empirical: rounding errors walk randomly), and |gpu - EXACT sum| <= (sqrt(n) + 8) ULP, the exact sums
     computed in integer arithmetic (oracle.ExactGroupSums).  COUNT is exact.  The observed maxima are printed (pytest -s)."""
     with ThreadPoolExecutor(2) as pool:  # (the exact sums: ~40 s of numpy per table, next to the GPU and oracle runs)
-        truths = {"uniform_filtered": pool.submit(_exact_sums_uniform, (0.2, 0.4)), "uniform_all": pool.submit(_exact_sums_uniform, None)}
+        truths = {"uniform_filtered": pool.submit(_exact_sums_uniform, (0.2, 0.4), _rows("uniform_filtered")),
+                  "uniform_all": pool.submit(_exact_sums_uniform, None, _rows("uniform_all"))}
         for name, what in (("uniform_filtered", "uniform v, filtered"), ("uniform_all", "uniform v, no filter")):
             got = _gpu(name)
             want = _oracle_result(name)[2]
