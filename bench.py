@@ -161,7 +161,8 @@ class Background:
     `Background.slots` of them run at a time -- the others wait their turn -- so that the oracle runs beside the timed GPU
     legs never use up the container's CPU quota (round 5: with one thread per query, twenty of them, one or another of the
     host-latency-bound legs came out a third slower in every run, never the same one)."""
-    slots = threading.Semaphore(max(2, min(10, host_cpu_budget() - 3)))
+    slots = threading.Semaphore(max(2, min(6, host_cpu_budget() - 4)))  # (round 6: six, not ten -- on a box with a slower host ten oracle threads still cost
+    # the host-latency-bound legs a third: FilterRelation 0.58 -> 0.39, the 10^10-row leg 0.53 -> 0.48, profiles/r06_bench_line_slow_host_box.json)
 
     def __init__(self, fn, *args, **kw):
         self.result, self.error = None, None

@@ -361,9 +361,12 @@ int32_t dfx_aggregate_partial_import(struct ArrowArrayStream* agg, const void* s
  *   rank 0:      dfx_comm_unique_id(id)           -- ncclGetUniqueId; the host plumbing hands `id` to every rank
  *   every rank:  dfx_comm_init(id, world, rank)   -- ncclCommInitRank on the library's device (dfx_init)
  *   per query:   dfx_aggregate_exchange(agg, comm, stats)  then get_next() emits the groups this rank owns
- * dfx_aggregate_exchange drains the input, counts the groups per owner rank, exchanges counts and buckets, and replaces
- * the stream's table by the merge of what it received -- one host read-back (the buffer sizes) plus the final
- * synchronisation.  Ungrouped aggregates are combined with an all-gather of the per-rank scalars (every rank then emits
+ * dfx_aggregate_exchange drains the input, counts the groups per owner rank, and replaces the stream's table by the merge
+ * of what it received in TWO collective rounds: one all-gather of world + 3 words per rank (its state and query shape, the
+ * groups it can receive / send without allocating more, its group count per destination rank: every buffer of the second
+ * round is allocated before the first), then the buckets, the last of them with a trailer word (the sender's state) --
+ * one host read-back (the count matrix) plus the final synchronisation.  Only if some rank receives or holds more groups
+ * than it announced do the ranks allocate again and agree in a round of their own.  Ungrouped aggregates are combined with an all-gather of the per-rank scalars (every rank then emits
  * the global row).  stats (may be NULL): [0] groups sent, [1] groups received, [2] bytes sent, [3] host synchronisations.
  * RCCL is bound at run time (dlopen librccl.so.1); without it these calls return ExecutionError.  Utf8 keys:
  * NotImplemented (dictionary ids are rank-local). */

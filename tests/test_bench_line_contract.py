@@ -1,5 +1,5 @@
-"""The bench line the driver parses (ROUND contract: one JSON line from rank 0): the committed line of the final tree,
-profiles/r05_bench_line.json, carries every field of the contract with consistent values -- metric / unit of BASELINE.json,
+"""The bench line the driver parses (ROUND contract: one JSON line from rank 0): the committed FULL object of the final tree,
+profiles/r06_bench_full.json (bench.py --full-out; the line itself is its compact form, profiles/r06_bench_line.json), carries every field of the contract with consistent values -- metric / unit of BASELINE.json,
 whole-job value = rows / time, the roofline object of the dominant kernel (frac = achieved / peak, algorithmic bytes, PMC
 traffic), the CPU baseline of the oracle port -- and every extra leg that claims a roofline also says whether it was checked
 against the oracle.  CPU only: it guards the shape of what bench.py prints, not the numbers."""
@@ -15,7 +15,7 @@ def _line(name):
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    d = _line("r05_bench_line.json")
+    d = _line("r06_bench_full.json")
     base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
     assert base["metric"].startswith(d["metric"]) and d["unit"] == "rows/s"  # BASELINE.json's metric (its qualifiers are the roofline object and --gpus)
     for key in ("value", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
@@ -37,7 +37,7 @@ def test_committed_bench_line_has_the_contract_fields():
 
 
 def test_every_extra_leg_with_a_roofline_says_whether_it_was_checked():
-    d = _line("r05_bench_line.json")
+    d = _line("r06_bench_full.json")
     unchecked = []
     for name, leg in d["extra"].items():
         if not isinstance(leg, dict) or "roofline" not in leg:
@@ -54,9 +54,13 @@ def test_every_extra_leg_with_a_roofline_says_whether_it_was_checked():
 
 
 def test_eight_rank_dry_run_line_used_the_library_exchange():
-    d = _line("r05_bench_line_8rank_dryrun_one_gpu.json")
+    d = _line("r06_bench_full_8rank_dryrun_one_gpu.json")
     assert d["n_gpus"] == 8 and d["config"]["rccl_ranks"] == 8
     assert "phases_ms" in d["extra"] and d["extra"]["verified_sum_of_group_sums_equals_ungrouped_sum"] is True
+    ph = d["extra"]["phases_ms"]
+    assert ph["collective_rounds"] == 2.0 and ph["host_syncs"] == 2.0  # round 6: the all-gather of states + counts, the buckets
+    small = _line("r06_bench_line_8rank_dryrun_one_gpu.json")  # what that run printed last
+    assert small["n_gpus"] == 8 and small["extra"]["phases_ms"]["collective_rounds"] == 2.0
 
 
 def _check_contract(d):
@@ -116,3 +120,14 @@ def test_emit_line_prints_the_compact_line_last(tmp_path, capsys, monkeypatch):
     assert len(out.out.strip().splitlines()) == 1 and len(last) < 4096
     _check_contract(json.loads(last))
     assert json.loads(open(tmp_path / "gpurun_out" / "bench_extra.json").read()) == full  # the full object is kept beside it
+
+
+def test_the_committed_compact_line_is_what_the_driver_gets():
+    d = _line("r06_bench_line.json")
+    assert len(json.dumps(d, separators=(",", ":"))) < 4096
+    _check_contract(d)
+    full = _line("r06_bench_full.json")
+    assert d["value"] == full["value"] and d["roofline"]["frac"] == full["roofline"]["frac"]
+    assert d["extra"]["scaling_anchor_rows_per_s"] == round(full["extra"]["rows_1e10"]["rows_per_s"], 3)
+    assert all(leg.get("ok", True) is True for leg in d["extra"]["legs"].values())
+    assert full["extra"]["csv_ingest_1gb"]["verified_vs_oracle"]["every_record"]["columns_bit_exact"] is True

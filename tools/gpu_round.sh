@@ -51,7 +51,7 @@ suite)
   timeout 2400 python -m pytest tests -m gpu -q --timeout 900 > $OUT/pytest_gpu.log 2>&1; echo "gpu suite rc=$?"; tail -n 8 $OUT/pytest_gpu.log | cut -c1-300
   ;;
 bench)
-  timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 --full-out $OUT/bench_full.json > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?  last stdout line: $(tail -n 1 $OUT/bench.json | wc -c) bytes"; tail -n 3 $OUT/bench.err | cut -c1-300
+  SECONDS=0; timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 --full-out $OUT/bench_full.json > $OUT/bench.json 2> $OUT/bench.err; echo "bench took $SECONDS s"; echo "bench rc=$?  last stdout line: $(tail -n 1 $OUT/bench.json | wc -c) bytes"; tail -n 3 $OUT/bench.err | cut -c1-300
   python - $OUT/bench_full.json <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
