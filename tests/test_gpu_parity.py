@@ -153,7 +153,9 @@ def test_group_by_utf8_keys_vs_oracle(strategy, dict_log2):
     ex.set_option("agg.dict_capacity_log2", dict_log2)
     rng = np.random.default_rng(77)
     words = ["", "a", "b", "ab", "ba", "München", "東京", "x" * 40] + \
-            ["city_%d" % i for i in range(3000)] + ["city_%d_suffix" % i for i in range(0, 3000, 7)]
+            ["city_%d" % i for i in range(3000)] + ["city_%d_suffix" % i for i in range(0, 3000, 7)] + \
+            ["w%015d" % i for i in range(40)] + ["w%016d" % i for i in range(40)] + ["w%07d" % i for i in range(40)]  # 16 / 17 / 8 bytes: the
+    # edges of the dictionary kernel's LDS front cache (strings of at most 16 bytes, read as aligned 8-byte words; round 6)
     n = 60000
     ks = rng.integers(0, len(words), n)
     keys = pa.array([words[i] for i in ks], type=pa.string())
