@@ -974,12 +974,12 @@ def test_partitioned_narrow_rows_hot_keys_and_deferred_pass2(hot, layout):
         pred = BinaryExpr(Column(1), Operator.Lt, lit(700.0))
         for kind, groups in ((ex.SYNTH_I64_UNIFORM, 300000.0), (ex.SYNTH_I64_ZIPF, 1000000.0)):
             syn = [("k", kind, 0, groups, 1.0), ("v", ex.SYNTH_F64_EXACT, 1, 0.0, 0.0)]
-            n, seed = (1 << 22) + 12345, 0xDF21
+            n, seed = (1 << 21) + 12345, 0xDF21  # (four batches of 2^18 rows per pass 2 + a ragged one; the oracle needs a second per 3 M rows)
             t = ex.DeviceTable.synth(syn, seed, 0, n)
             ob = oracle.synth_batch(syn, seed, 0, n)
             for a in (agg("sum", Column(1), F64), agg("min", Column(1), F64)):
                 for f in (pred, None):
-                    got = gpu_aggregate([Column(0)], [a], schema, [], source=t.scan(1 << 19), filter_expr=f)
+                    got = gpu_aggregate([Column(0)], [a], schema, [], source=t.scan(1 << 18), filter_expr=f)
                     want = oracle.aggregate([Column(0)], [a], [oracle.filter_next(f, ob) if f is not None else ob])
                     assert_groups_identical(got, want, 1, f"narrow rows hot={hot} layout={layout} kind={kind} {a.name}")
     finally:
@@ -1034,7 +1034,7 @@ def test_aggregates_of_one_operand_share_the_routed_value():
         pred = BinaryExpr(Column(1), Operator.Lt, lit(800.0))
         for kind in (ex.SYNTH_I64_UNIFORM, ex.SYNTH_I64_ZIPF):
             syn = [("k", kind, 0, 200000.0, 1.0), ("v", ex.SYNTH_F64_EXACT, 1, 0.0, 0.0), ("w", ex.SYNTH_I64_UNIFORM, 2, 1e9, 0.0)]
-            n, seed = (1 << 21) + 777, 0xDF41
+            n, seed = (1 << 20) + 777, 0xDF41
             t = ex.DeviceTable.synth(syn, seed, 0, n)
             ob = oracle.synth_batch(syn, seed, 0, n)
             for name, _col, aggs in _shared_operand_sets():
@@ -1043,7 +1043,7 @@ def test_aggregates_of_one_operand_share_the_routed_value():
                     for shared in (1, 0):
                         ex.set_option("agg.shared_operand", shared)
                         ex.counter_reset()
-                        got = gpu_aggregate([Column(0)], aggs, schema, [], source=t.scan(1 << 19), filter_expr=filt)
+                        got = gpu_aggregate([Column(0)], aggs, schema, [], source=t.scan(1 << 18), filter_expr=filt)
                         launches = ex.counter_get("agg_shared_operand_launches")
                         assert (launches > 0) == (shared == 1), f"{name}: shared={shared} but {launches} shared-operand launches"
                         assert_groups_identical(got, want, 1, f"{name}, kind {kind}, filter {filt is not None}, shared {shared}")
