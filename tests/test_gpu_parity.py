@@ -923,6 +923,7 @@ def test_key_column_downloaded_while_the_scan_runs():
         assert ex.counter_get("agg_early_keys") == (1 if on else 0)
         assert ex.counter_get("agg_early_keys_used") == (1 if on else 0)
         assert ex.counter_get("export_host_ready") == (1 if on else 0)
+        assert ex.counter_get("agg_emit_reused_early") == (1 if on else 0)  # round 6: emit also reuses its mask, offsets and device key column
     ex.set_option("agg.early_keys", 1)
     # Int32 keys (the copy is made of the finalised 4-byte column), a predicate in front, MIN
     rng = np.random.default_rng(77)
@@ -936,6 +937,7 @@ def test_key_column_downloaded_while_the_scan_runs():
     got = gpu_aggregate([Column(0)], [agg("min", Column(1), F64)], whole.schema, parts, filter_expr=pred)
     assert_groups_identical(got, oracle.aggregate([Column(0)], [agg("min", Column(1), F64)], [oracle.filter_next(pred, whole)]), 1, "early keys, Int32")
     assert ex.counter_get("agg_early_keys_used") == 1 and ex.counter_get("export_host_ready") == 1
+    assert ex.counter_get("agg_emit_reused_early") == 1
     # new keys in the last batch: the copy was started and must be dropped
     k = rng.integers(0, 50000, m).astype(np.int64)
     k[-1000:] = rng.integers(50000, 50100, 1000)
@@ -946,6 +948,7 @@ def test_key_column_downloaded_while_the_scan_runs():
     assert_groups_identical(got, oracle.aggregate([Column(0)], aggs, [whole]), 1, "early keys dropped")
     assert ex.counter_get("agg_early_keys") >= 1
     assert ex.counter_get("agg_early_keys_used") == 0 and ex.counter_get("export_host_ready") == 0
+    assert ex.counter_get("agg_emit_reused_early") == 0
     # ... in the middle: a second copy is started once the count has settled again, and that one is used
     k = rng.integers(0, 50000, m).astype(np.int64)
     k[5 << 18:(5 << 18) + 1000] = rng.integers(50000, 50100, 1000)
