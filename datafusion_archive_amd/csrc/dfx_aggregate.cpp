@@ -198,6 +198,11 @@ struct AggregateRelation::Impl {
   // between two consecutive control-block snapshots, the compaction of the key plane and its copy to pinned memory are queued on
   // the side stream while the scan goes on.  At emit the copy is valid iff no group was added since (groups are never removed: the
   // count then differs) and the table was not replaced; it is attached to the key column and the exporter hands it out.
+  // Round 6: NOBODY WAITS for the copy.  The DMA engine's device-to-host copies stall once in a few hundred calls -- tools/stall_probe.py:
+  // one step of fifty over 10^10 rows took 159 ms instead of 37 with the copy, none without -- and emit used to sit in
+  // hipEventSynchronize behind it.  Now emit asks (hipEventQuery): a copy that has not finished is RETIRED -- its event, its
+  // buffers and the table it reads (`keep`) move to a list that is emptied as the events complete -- and the step takes the path
+  // it would have taken without the copy (+0.17 ms instead of +120).
   struct EarlyKeys {
     bool armed = false;
     uint64_t occupied = 0;    // group count it was made for
@@ -205,18 +210,47 @@ struct AggregateRelation::Impl {
     size_t bytes = 0;
     std::shared_ptr<void> host, total;          // pinned: the column, the compaction's own group count
     std::vector<std::shared_ptr<void>> scratch;  // device buffers the side stream is still using
+    std::vector<std::shared_ptr<void>> keep;     // the table planes its kernels read (alive until they have run)
     hipEvent_t done = nullptr, start = nullptr;
-    void wait() {
-      if (armed && done) (void)hipEventSynchronize(done);
+    struct Retired {
+      hipEvent_t done;
+      std::vector<std::shared_ptr<void>> buffers;
+    };
+    std::vector<Retired> retired;
+    bool ready() const { return !armed || !done || hipEventQuery(done) == hipSuccess; }
+    void reap(bool block) {  // retired copies whose side-stream work has finished give their buffers back
+      for (size_t i = 0; i < retired.size();) {
+        if (block) (void)hipEventSynchronize(retired[i].done);
+        if (block || hipEventQuery(retired[i].done) == hipSuccess) {
+          (void)hipEventDestroy(retired[i].done);
+          retired.erase(retired.begin() + (long)i);
+        } else {
+          ++i;
+        }
+      }
     }
-    void cancel() {  // before the table it reads is replaced or released
-      wait();
+    void drop() {  // forget the copy without waiting for it (before the table it reads is replaced, or when emit finds it unfinished)
+      if (armed && done && hipEventQuery(done) != hipSuccess) {
+        Retired r;
+        r.done = done;
+        done = nullptr;  // (a new event next time)
+        r.buffers = std::move(scratch);
+        r.buffers.insert(r.buffers.end(), keep.begin(), keep.end());
+        r.buffers.push_back(host);
+        r.buffers.push_back(total);  // (the pending copies write both)
+        total.reset();
+        retired.push_back(std::move(r));
+      }
       armed = false;
       scratch.clear();
+      keep.clear();
       host.reset();
+      reap(false);
     }
+    void cancel() { drop(); }
     ~EarlyKeys() {
-      wait();
+      drop();
+      reap(true);
       if (done) (void)hipEventDestroy(done);
       if (start) (void)hipEventDestroy(start);
     }
@@ -1691,6 +1725,8 @@ Status AggregateRelation::Impl::early_keys_maybe() {
   if (!early.start) DFX_HIP(hipEventCreateWithFlags(&early.start, hipEventDisableTiming));
   early.scratch = {mask, counts, offsets, tmp, vals};
   if (dense) early.scratch.push_back(dense);
+  early.keep = table_owners;  // (the side stream reads the key plane: it stays allocated until that has happened, whatever replaces the table)
+  early.keep.push_back(ctrl);
   // The side stream starts behind everything queued on the main stream so far: the pool hands out blocks whose previous users may
   // still be queued there.  It is not ordered against what comes LATER: whatever those kernels add to the table makes the final
   // group count differ from `g`, and the copy is dropped.
@@ -1737,8 +1773,8 @@ Status AggregateRelation::Impl::emit_grouped(DeviceBatch* out, int64_t expected)
   bool reuse_early = false;
   if (expected >= 0 && early.armed && early.generation == table_generation && early.occupied == (uint64_t)expected &&
       early.scratch.size() >= 5 && kw_out == 1 && dicts.empty()) {
-    early.wait();  // (its kernels and copies ran on the side stream while the scan went on: long finished)
-    if (*(const uint64_t*)early.total.get() == (uint64_t)expected && early.bytes == (size_t)expected * dtype_width(key_dtype[0])) {
+    // (its kernels and copies ran on the side stream while the scan went on: long finished -- unless the copy engine stalled)
+    if (early.ready() && *(const uint64_t*)early.total.get() == (uint64_t)expected && early.bytes == (size_t)expected * dtype_width(key_dtype[0])) {
       mask = early.scratch[0];
       offsets = early.scratch[2];
       early_keys_dev = early.scratch[4];
@@ -1846,19 +1882,18 @@ Status AggregateRelation::Impl::emit_grouped(DeviceBatch* out, int64_t expected)
     if (expected < 0) return Status::Err(DFX_INTERNAL_ERROR, "group count changed during emit");
     return emit_grouped(out, -1);  // the host's count was stale: redo with the table's own
   }
-  if (early.armed) {  // the key column copied ahead of time: valid iff it was made from this table with this many groups
-    early.wait();
+  if (early.armed) {  // the key column copied ahead of time: valid iff it was made from this table with this many groups -- and has arrived
     DeviceColumn& kc = out->columns[0];
-    if (early.generation == table_generation && early.occupied == (uint64_t)g && *(const uint64_t*)early.total.get() == (uint64_t)g &&
+    if (!early.ready()) {
+      ++counters().agg_early_keys_late;
+    } else if (early.generation == table_generation && early.occupied == (uint64_t)g && *(const uint64_t*)early.total.get() == (uint64_t)g &&
         early.bytes == (size_t)g * dtype_width(kc.dtype) && kc.values != nullptr) {
       kc.host_values = early.host;
       kc.host_values_of = kc.values;
       kc.host_bytes = early.bytes;
       ++counters().agg_early_keys_used;
     }
-    early.armed = false;
-    early.scratch.clear();
-    early.host.reset();
+    early.drop();
   }
   return Status::OK();
 }

@@ -129,6 +129,7 @@ struct Counters {
   long long export_host_ready = 0;  // result columns the exporter found already on the host (early key download)
   long long agg_early_keys = 0;     // speculative key-column downloads started ...
   long long agg_early_keys_used = 0;  // ... and still valid at emit
+  long long agg_early_keys_late = 0;        // ... copies that had not arrived when emit asked (a stalled copy engine): retired, not waited for
   long long agg_emit_reused_early = 0;     // ... and emits that also reused its occupancy mask, tile offsets and device key column
   long long agg_pass2_launches = 0;
   long long agg_growths = 0;

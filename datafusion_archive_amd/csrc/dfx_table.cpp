@@ -451,6 +451,7 @@ int64_t dfx_counter_get(const char* name) {
   if (!strcmp(name, "agg_early_keys")) return counters().agg_early_keys;
   if (!strcmp(name, "agg_early_keys_used")) return counters().agg_early_keys_used;
   if (!strcmp(name, "agg_emit_reused_early")) return counters().agg_emit_reused_early;
+  if (!strcmp(name, "agg_early_keys_late")) return counters().agg_early_keys_late;
   if (!strcmp(name, "csv_tiles")) return counters().csv_tiles;
   if (!strcmp(name, "csv_general_tiles")) return counters().csv_general_tiles;
   if (!strcmp(name, "agg_ctrl_wait_us")) return counters().agg_ctrl_wait_us;
