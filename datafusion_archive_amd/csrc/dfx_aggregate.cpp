@@ -198,11 +198,11 @@ struct AggregateRelation::Impl {
   // between two consecutive control-block snapshots, the compaction of the key plane and its copy to pinned memory are queued on
   // the side stream while the scan goes on.  At emit the copy is valid iff no group was added since (groups are never removed: the
   // count then differs) and the table was not replaced; it is attached to the key column and the exporter hands it out.
-  // Round 6: NOBODY WAITS for the copy.  The DMA engine's device-to-host copies stall once in a few hundred calls -- tools/stall_probe.py:
-  // one step of fifty over 10^10 rows took 159 ms instead of 37 with the copy, none without -- and emit used to sit in
-  // hipEventSynchronize behind it.  Now emit asks (hipEventQuery): a copy that has not finished is RETIRED -- its event, its
-  // buffers and the table it reads (`keep`) move to a list that is emptied as the events complete -- and the step takes the path
-  // it would have taken without the copy (+0.17 ms instead of +120).
+  // Round 6: NOBODY WAITS for the copy.  Round 2 found the DMA engine's device-to-host copies stalling for 6-150 ms once in a few
+  // hundred calls (that is why the result itself is downloaded by a kernel), and emit used to sit in hipEventSynchronize behind
+  // this one.  Now emit asks (hipEventQuery): a copy that has not finished is RETIRED -- its event, its buffers and the table
+  // it reads (`keep`) move to a list that is emptied as the events complete -- and the step takes the path it would have taken
+  // without the copy (+0.15 ms, not +100).
   struct EarlyKeys {
     bool armed = false;
     uint64_t occupied = 0;    // group count it was made for

@@ -19,7 +19,7 @@ def run():
     rel = ex.FilterRelation(t.scan(1 << 27), ex.compile_scalar_expr(None, pred, schema), schema)
     rel = ex.AggregateRelation(None, rel, [ex.compile_scalar_expr(None, Column(0), schema)], [ex.compile_expr(None, AggregateFunction("SUM", [Column(1)], DataType.Float64), schema)])
     return rel.next()
-for early in (1, 0, 1, 0):
+for early in ((0, 1, 0, 1) if os.environ.get('STALL_ORDER') == '0101' else (1, 0, 1, 0)):
     ex.set_option("agg.early_keys", early)
     run(); ex.synchronize()
     per = []
@@ -27,4 +27,5 @@ for early in (1, 0, 1, 0):
         t0 = time.perf_counter(); run(); ex.synchronize(); per.append((time.perf_counter() - t0) * 1e3)
     s = sorted(per)
     print(f"early_keys={early} rows={rows}: median {s[len(s)//2]:.2f} ms, min {s[0]:.2f}, max {s[-1]:.2f}; steps over 1.15 x median: "
-          + " ".join(f"{x:.1f}" for x in per if x > 1.15 * s[len(s)//2]), flush=True)
+          + " ".join(f"#{i}:{x:.1f}" for i, x in enumerate(per) if x > 1.15 * s[len(s)//2]) + "  first five: " + " ".join(f"{x:.1f}" for x in per[:5])
+          + f"  late copies {ex.counter_get('agg_early_keys_late')}", flush=True)
