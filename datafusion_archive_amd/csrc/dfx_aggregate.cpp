@@ -160,6 +160,14 @@ struct AggregateRelation::Impl {
   std::shared_ptr<void> snap_done;  // device word of DevPartition::snap_done
   bool snap_armed = false;          // the batch just launched writes its own control-block snapshot (no copy on the side stream)
   int64_t rows_seen = 0;
+  // Several chunks of accumulators over ONE table (more than 8 aggregates, or one scan per aggregate): every chunk's scan of a batch
+  // ends with a host check of the control block -- rows spilled under chunk c must be replayed while chunk c is active -- i.e. with
+  // an idle device for a host round trip.  Round 6: up to chunk_hold batches are HELD and each chunk scans all of them in a row
+  // (between batches of one chunk the checks run one batch behind, as in a single-chunk stream): one round trip per chunk and
+  // hold, not per chunk and batch (two aggregates of different operands over 10^9 rows: 16 -> 4).
+  std::vector<DeviceBatch> held;
+  size_t held_bytes = 0;
+  Status run_held();
   uint64_t occupied_known = 0;
   // control block checks run ONE BATCH BEHIND the launches: after batch i its control block is copied to
   // pinned memory asynchronously, batch i + 1 is launched, and only then is batch i's copy examined, so
@@ -1408,6 +1416,14 @@ Status AggregateRelation::Impl::consume_batch(const DeviceBatch& b) {
     return consume_batch(rows_from(b, decided_rows));
   }
   if (chunks.size() <= 1) return consume_batch_chunk(b);
+  if (kw > 0 && opt().chunk_hold > 1) {  // grouped, several chunks: hold the batch (see `held`)
+    size_t bytes = 0;
+    for (const DeviceColumn& c : b.columns) bytes += (size_t)std::max<int64_t>(c.length, 0) * (size_t)std::max(1, dtype_width(c.dtype));
+    held.push_back(b);
+    held_bytes += bytes;
+    if ((int)held.size() < opt().chunk_hold && held_bytes < ((size_t)8 << 30)) return Status::OK();
+    return run_held();
+  }
   for (int c = 0; c < (int)chunks.size(); ++c) {
     activate(c);
     const int64_t seen = rows_seen;
@@ -1423,6 +1439,30 @@ Status AggregateRelation::Impl::consume_batch(const DeviceBatch& b) {
   }
   activate(0);
   rows_seen += b.num_rows;
+  return Status::OK();
+}
+
+// every chunk over every held batch, one control-block check per chunk
+Status AggregateRelation::Impl::run_held() {
+  if (held.empty()) return Status::OK();
+  std::vector<DeviceBatch> hb;
+  hb.swap(held);
+  held_bytes = 0;
+  const int64_t seen = rows_seen;
+  int64_t total = 0;
+  for (const DeviceBatch& b : hb) total += b.num_rows;
+  for (int c = 0; c < (int)chunks.size(); ++c) {
+    activate(c);
+    rows_seen = seen;
+    for (const DeviceBatch& b : hb) DFX_RETURN_IF_ERROR(consume_batch_chunk(b));
+    DFX_RETURN_IF_ERROR(flush_pass2());
+    DFX_RETURN_IF_ERROR(settle_ctrl());
+    uint32_t hc[CTRL_WORDS];
+    DFX_RETURN_IF_ERROR(read_ctrl(hc));
+    DFX_RETURN_IF_ERROR(handle_ctrl(hc, total));
+  }
+  activate(0);
+  rows_seen = seen + total;
   return Status::OK();
 }
 
@@ -1622,6 +1662,7 @@ Status AggregateRelation::Impl::drain() {
     if (!has) break;
     DFX_RETURN_IF_ERROR(consume_batch(b));
   }
+  DFX_RETURN_IF_ERROR(run_held());  // (batches a multi-chunk aggregate was still holding)
   if (kw == 0) {
     uint32_t hc[CTRL_WORDS];
     DFX_RETURN_IF_ERROR(read_ctrl(hc));

@@ -99,6 +99,8 @@ struct AggOptions {
   int host_stage_threads = 8;  // ... threads that fill the ring
   int host_stage_mb = 16;      // ... bytes per slot
   int host_stage_slots = 6;    // ... slots
+  int chunk_hold = 4;          // several chunks of accumulators over one table: batches held so that every chunk scans them in a row (one host check per
+                               // chunk and hold; 1: per chunk and batch, rounds 3-5)
   int split_aggregates = 1;    // one key, several aggregates of different operands, many groups: a scan per aggregate through the one-value
                                // kernels of the partitioned strategy (0: one scan that routes a row with every operand)
   int filter_dense = -1;       // single-pass FilterRelation, tiles kept in registers (k_filter_fused_dense): -1 when the stream has

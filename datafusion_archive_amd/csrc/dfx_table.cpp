@@ -266,6 +266,7 @@ bool set_option_in(AggOptions& o, const char* key, int64_t value) {
   else if (!strcmp(key, "filter.single_pass")) o.filter_single_pass = (int)value;
   else if (!strcmp(key, "filter.dense")) o.filter_dense = (int)value;
   else if (!strcmp(key, "agg.split_aggregates")) o.split_aggregates = (int)value;
+  else if (!strcmp(key, "agg.chunk_hold")) o.chunk_hold = (int)value;
   else if (!strcmp(key, "csv.wave_tiles")) o.csv_wave_tiles = (int)value;
   else if (!strcmp(key, "host.stream")) o.host_stream = (int)value;
   else if (!strcmp(key, "host.stage_threads")) o.host_stage_threads = (int)value;
