@@ -86,6 +86,14 @@ struct AggregateRelation::Impl {
   // rows against 2 x 0.43).  `single_chunks` holds that chunking, built at set-up; it replaces `chunks` when the strategy decision
   // (calibration slice or the resident table's memo) says "partitioned" -- few groups keep the one scan for all aggregates.
   std::vector<Chunk> single_chunks;
+  // Round 6, late: the PAIR scan.  Two aggregates, narrow keys, a program the scan plan binds with three columns: the all-aggregates
+  // program keeps running -- ONE scan routes {operand 0, image, operand 1} (20-byte rows, six per 128-byte line: PTF_PAIR) and pass 2
+  // runs once per accumulator plane over the same regions, each launch the one-value kernel with its 96 KB block.  16 + 24 bytes read
+  // per row become 24.  `single_chunks` stays in reserve: the stream falls back to it at a batch boundary when the pair kernels no
+  // longer apply (the table outgrew 256 partitions, a batch the plan cannot bind).
+  bool pair_mode = false;
+  bool pair_batch_ok(const DeviceBatch& b);
+  Status pair_fall_back();
   bool split_ready = false;     // single_chunks is built (used if agg.split_aggregates allows it when the operator runs)
   bool split_done = false;      // ... and installed
   bool split_decided = false;   // the strategy decision has been taken (whichever way)
@@ -708,10 +716,15 @@ Status AggregateRelation::Impl::ensure_partition(int64_t rows, bool nulls_now) {
   const bool want_shared = narrow && opt().narrow_keys != 0 && !nulls_now && shared_operand() &&
                            ((uint32_t)opt().partition_mode & 0x8Fu) == 2u &&
                            partition_ring_bytes(2, (uint32_t)((T.mask + 1) / S), 16, false, true, 128) <= (size_t)158 * 1024;
-  const bool want_narrow = narrow && kw == 1 && (na == 1 || want_shared) && opt().narrow_keys != 0;
+  const bool want_pair = pair_mode && !want_shared && narrow && kw == 1 && na == 2 && kNarrowLine && opt().narrow_keys != 0 && opt().narrow_chunk16 &&
+                         opt().pass1_ws > 0 && opt().partition_layout != 2 && ((uint32_t)opt().partition_mode & 0x8Fu) == 2u &&
+                         partition_ws_bytes((uint32_t)((T.mask + 1) / S), 8, 2) <= (size_t)158 * 1024;
+  if (pair_mode && !want_pair)  // (a table block holds ONE accumulator plane in this mode: no other routed form fits; until the
+    return Status::Err(DFX_NOT_IMPLEMENTED, "pair scan: not for this table");  // next batch boundary the rows go through the global table)
+  const bool want_narrow = narrow && kw == 1 && (na == 1 || want_shared || want_pair) && opt().narrow_keys != 0;
   const uint32_t n_words = want_shared ? 2u : (uint32_t)(kw + na);
   if (pt_layout_valid && rows <= pt_layout_rows && PT.n_parts == (uint32_t)((T.mask + 1) / S) && PT.n_words == n_words &&
-      ((PT.flags & PTF_NARROW) != 0) == want_narrow && ((PT.flags & PTF_SHARED) != 0) == want_shared)
+      ((PT.flags & PTF_NARROW) != 0) == want_narrow && ((PT.flags & PTF_SHARED) != 0) == want_shared && ((PT.flags & PTF_PAIR) != 0) == want_pair)
     return Status::OK();  // same table, a batch the regions were sized for: keep appending
   DFX_RETURN_IF_ERROR(flush_pass2());  // rows routed under the old layout
   pt_layout_valid = false;
@@ -735,6 +748,14 @@ Status AggregateRelation::Impl::ensure_partition(int64_t rows, bool nulls_now) {
   const int want = o.partition_mode & 15;
   if (want_shared) {
     PT.flags |= PTF_NARROW | PTF_SHARED;
+    PT.mode = 2u;
+    PT.block = 1024;
+    PT.stage_rows = 0;
+    PT.n_producers = (uint32_t)std::min(1024, device_cu_count());
+    if (o.partition_producers > 0) PT.n_producers = (uint32_t)std::min(1024, o.partition_producers);
+  } else if (want_pair) {
+    PT.flags |= PTF_NARROW | PTF_CHUNK16 | PTF_WS | PTF_PAIR;
+    PT.ws_scanners = 8u;
     PT.mode = 2u;
     PT.block = 1024;
     PT.stage_rows = 0;
@@ -787,7 +808,7 @@ Status AggregateRelation::Impl::ensure_partition(int64_t rows, bool nulls_now) {
   }
   const uint64_t avg = (uint64_t)rows / ((uint64_t)PT.n_producers * PT.n_parts) + 1;
   // capacities are whole 64-row trips; LINE chunks (ten rows per 128-byte line, PTF_CHUNK16): whole lines as well
-  const uint64_t capq = ((PT.flags & PTF_CHUNK16) && kNarrowLine) ? (uint64_t)kNarrowCapQuantum : 64ull;
+  const uint64_t capq = (PT.flags & PTF_PAIR) ? (uint64_t)kPairCapQuantum : ((PT.flags & PTF_CHUNK16) && kNarrowLine) ? (uint64_t)kNarrowCapQuantum : 64ull;
   pt_worst = (uint32_t)((2 * avg + 64 + capq - 1) / capq * capq);
   // regions hold `window` worst-case batches.  Deferral pays when few rows are routed (headline, 20 %: 2 batches per
   // pass 2 = -3 % per query); when most rows are, the twice-as-long regions cost pass 1 more than the saved launches
@@ -804,10 +825,12 @@ Status AggregateRelation::Impl::ensure_partition(int64_t rows, bool nulls_now) {
   if ((PT.flags & PTF_CHUNK16) && kNarrowLine) pad_words = (pad_words + 15) / 16 * 16;  // (every region starts on a 128-byte line)
   size_t row_bytes;
   const bool line_chunks = (PT.flags & PTF_CHUNK16) && kNarrowLine;  // a region is cap_rows / 10 lines of 128 bytes
-  const uint64_t region_words = line_chunks ? (uint64_t)(PT.cap_rows / (uint32_t)kNarrowChunkRows) * (kNarrowSlotBytes / 8)
+  const bool pair_rows = (PT.flags & PTF_PAIR) != 0;  // ... cap_rows / 6 lines
+  const uint64_t region_words = pair_rows ? (uint64_t)(PT.cap_rows / (uint32_t)kPairChunkRows) * 16u
+                                : line_chunks ? (uint64_t)(PT.cap_rows / (uint32_t)kNarrowChunkRows) * (kNarrowSlotBytes / 8)
                                 : (PT.flags & PTF_NARROW) ? (uint64_t)PT.cap_rows * 12 / 8 : (uint64_t)PT.cap_rows * PT.n_words;
   // one pass-2 trip's worth (64 contiguous rows, or six LINE chunks = 60 rows: 768 bytes either way): regions are contiguous (layouts 0 and 1)
-  PT.win_stride = line_chunks ? 96u : region_words / (PT.cap_rows / 64);
+  PT.win_stride = pair_rows ? (uint64_t)(kPairTripBytes / 8u) : line_chunks ? 96u : region_words / (PT.cap_rows / 64);
   if (o.partition_layout == 2) {  // windowed: window w of every partition of a producer side by side
     PT.part_stride = PT.win_stride;
     PT.win_stride = (uint64_t)PT.n_parts * PT.part_stride;
@@ -911,7 +934,8 @@ Status AggregateRelation::Impl::post_ctrl(int64_t rows) {
 // errors, growth: what the per-batch check has always done, on a (possibly one batch old) snapshot
 Status AggregateRelation::Impl::handle_ctrl(const uint32_t* hc, int64_t n) {
   if (hc[CTRL_ERROR]) return error_from_ctrl(hc[CTRL_ERROR]);
-  if (narrow && hc[CTRL_WIDE_KEYS]) {  // a key without a 32-bit image turned up (it went to the spill list): 16-byte rows from now on
+  if (narrow && hc[CTRL_WIDE_KEYS] && !pair_mode) {  // (pair scan: such rows keep taking the spill list -- a table block holds one plane, no wide form fits)
+    // a key without a 32-bit image turned up (it went to the spill list): 16-byte rows from now on
     DFX_RETURN_IF_ERROR(flush_pass2());
     narrow = false;
     pt_layout_valid = false;
@@ -1071,7 +1095,7 @@ Status AggregateRelation::Impl::launch_rows(const DeviceBatch& b, const DevProgr
   DevAggPlan p = plan;
   // (while the per-aggregate chunking is pending -- the table's blocks are sized for one accumulator per scan -- the all-aggregates
   // program never takes the partitioned strategy: its pass 2 would not fit a block into LDS)
-  bool partition_now = use_partition && !(split_ready && !split_done && opt().split_aggregates);
+  bool partition_now = use_partition && (pair_mode || !(split_ready && !split_done && opt().split_aggregates));
   if (partition_now) {
     Status pst = ensure_partition(launch_rows_hint > 0 ? std::max<int64_t>(n, std::min<int64_t>(launch_rows_hint, b.num_rows)) : std::max<int64_t>(n, b.num_rows), prog.has_nulls != 0);  // (the slice after the calibration rows: size for the whole batch)
     if (!pst.ok() && pst.code == DFX_NOT_IMPLEMENTED) partition_now = false;  // global-atomic path instead
@@ -1107,6 +1131,7 @@ Status AggregateRelation::Impl::launch_rows(const DeviceBatch& b, const DevProgr
     }
     DFX_HIP(launch_partition(prog, fpp, cols, p, T, pt, spill, n, bytes, s));
     if (pt.flags & PTF_SHARED) ++counters().agg_shared_operand_launches;
+    if (pt.flags & PTF_PAIR) ++counters().agg_pair_launches;
     ++pt_pending;
     pt_fill_bound += pt_worst;
     pt_rows_in_flight += n;
@@ -1256,7 +1281,8 @@ Status AggregateRelation::Impl::consume_batch_chunk(const DeviceBatch& b) {
   const bool may_spill = use_partition || occupied_known + unconfirmed_rows + (uint64_t)n > T.load_limit;
   // two batches can be in flight unchecked; with a deferred pass 2 every row of the window may still be spilled (by pass 2
   // itself, when its block is full)
-  const int64_t window_rows = use_partition ? (int64_t)std::max(1, opt().partition_defer_batches) * std::max(n, pt_layout_rows) : 0;
+  // (pair scan: a row whose key finds no slot in its block is spilled by BOTH planes' pass 2)
+  const int64_t window_rows = use_partition ? (int64_t)std::max(1, opt().partition_defer_batches) * std::max(n, pt_layout_rows) * (pair_mode ? 2 : 1) : 0;
   if (may_spill) DFX_RETURN_IF_ERROR(ensure_spill(2 * n + window_rows + 65536));
   T.max_probe = may_spill ? 128 : (int)std::min<uint64_t>(T.mask + 1, 1u << 30);
   int64_t row0 = 0;
@@ -1407,14 +1433,19 @@ Status AggregateRelation::Impl::consume_batch(const DeviceBatch& b) {
     if (split_decided && (use_partition || forced)) {
       DFX_RETURN_IF_ERROR(flush_pass2());
       DFX_RETURN_IF_ERROR(settle_ctrl());
-      install_chunks(std::move(single_chunks));
-      single_chunks.clear();
-      split_done = true;
+      if (opt().pair_scan && use_partition && pair_batch_ok(b)) {
+        pair_mode = true;  // the all-aggregates program goes on: one scan for both operands (single_chunks stays in reserve)
+      } else {
+        install_chunks(std::move(single_chunks));
+        single_chunks.clear();
+        split_done = true;
+      }
     }
     if (decided_rows >= b.num_rows) return Status::OK();
     if (decided_rows == 0) return consume_batch(b);
     return consume_batch(rows_from(b, decided_rows));
   }
+  if (pair_mode && !pair_batch_ok(b)) DFX_RETURN_IF_ERROR(pair_fall_back());
   if (chunks.size() <= 1) return consume_batch_chunk(b);
   if (kw > 0 && opt().chunk_hold > 1) {  // grouped, several chunks: hold the batch (see `held`)
     size_t bytes = 0;
@@ -1439,6 +1470,42 @@ Status AggregateRelation::Impl::consume_batch(const DeviceBatch& b) {
   }
   activate(0);
   rows_seen += b.num_rows;
+  return Status::OK();
+}
+
+// Can this batch go through the pair scan (see pair_mode)?  Host work only: the program is bound to the batch and the scan plan to that.
+bool AggregateRelation::Impl::pair_batch_ok(const DeviceBatch& b) {
+  const bool dbg = getenv("DFX_DEBUG") != nullptr;
+  auto no = [&](const char* why) {
+    if (dbg) fprintf(stderr, "[dfx] pair scan: no (%s)\n", why);
+    return false;
+  };
+  if (!kNarrowLine || !narrow || kw != 1 || na != 2 || chunks.size() != 1 || single_chunks.size() != 2 || !dicts.empty()) return no("shape");
+  if (single_chunks[0].n != 1 || single_chunks[1].n != 1 || unfused_now) return no("chunks");
+  const AggOptions& o = opt();
+  if (!o.plan || !o.fast || o.narrow_keys == 0 || !o.narrow_chunk16 || o.pass1_ws <= 0 || o.partition_layout == 2 || ((uint32_t)o.partition_mode & 0x8Fu) != 2u) return no("options");
+  if (!scan_plan_shape_ok(builder->program(), fast, kw, na, val_xform)) return no("scan plan shape");  // (also: a predicate over nulls stays fused, consume_batch_chunk)
+  const uint64_t S = (uint64_t)T.block_mask + 1;
+  if (S != 8192 || partition_ws_bytes((uint32_t)((T.mask + 1) / S), 8, 2) > (size_t)158 * 1024) return no("table blocks");
+  if (b.num_rows <= 0) return true;
+  DevProgram prog;
+  DevColumns cols;
+  if (!builder->bind(b, &prog, &cols).ok()) return no("bind");
+  DevFastPlan fp = fast;
+  fp.plan_mode = o.plan;
+  if (!partition_pair_supported(prog, fp, cols, T)) return no("plan binding");
+  return true;
+}
+
+// the pair scan no longer applies: one scan per aggregate from the next batch on (a batch boundary: nothing is half launched)
+Status AggregateRelation::Impl::pair_fall_back() {
+  DFX_RETURN_IF_ERROR(flush_pass2());
+  DFX_RETURN_IF_ERROR(settle_ctrl());
+  ++counters().agg_pair_fallbacks;
+  pair_mode = false;
+  install_chunks(std::move(single_chunks));
+  single_chunks.clear();
+  split_done = true;
   return Status::OK();
 }
 

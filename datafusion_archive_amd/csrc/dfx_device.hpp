@@ -277,6 +277,7 @@ struct DevPartition {
   uint32_t block;      // pass-1 workgroup size (mode 1: 512 or 1024)
   uint32_t flags;      // PTF_*
   uint32_t ws_scanners;// PTF_WS: scanner waves of the 16: 8 (+ 8 routers: selective scans) or 4 (+ 12 routers: dense scans)
+  uint32_t pair_plane; // PTF_PAIR, pass 2: the operand / accumulator plane (0 or 1) this launch aggregates
   // Control-block snapshot written BY THE KERNEL (null: none): the last workgroup to finish copies T.ctrl into this
   // host-mapped pinned buffer.  The host reads it after the launch's completion event -- no copy engine, no blit kernel
   // that would have to find room next to 256 persistent 1024-lane workgroups, nothing on a side stream.
@@ -294,6 +295,9 @@ enum : uint32_t {
                           // LINE chunks, ten 12-byte rows + 8 bytes of padding = ONE whole 128-byte line per chunk, three-slot rings
   PTF_WS = 64u,           // pass 1, wave-specialised flavour (dfx_k_partition_ws_inl.hpp): DevPartition::ws_scanners of the 16 waves scan,
                           // the others route; needs PTF_NARROW | PTF_CHUNK16, no PTF_HOT / PTF_SHARED
+  PTF_PAIR = 128u,        // with PTF_NARROW | PTF_CHUNK16 | PTF_WS (LINE chunks only): TWO aggregates of DIFFERENT operands, one scan -- routed
+                          // rows are 20 bytes {operand 0, hash image, operand 1} (kPair* below), pass 2 runs once per accumulator plane
+                          // (DevPartition::pair_plane) over the same regions: each launch is the one-value kernel with its 96 KB block
   PTF_NARROW = 8u         // keys below 2^32 (seen by the calibration slice): 12-byte routed rows {hash image, operand}, pass 2
                           // works on 32-bit images; needs ring flavour, one key word, one aggregate
 };
@@ -317,6 +321,17 @@ constexpr int kNarrowRingRows = kNarrowChunkRows * kNarrowRingSlots;
 constexpr int kNarrowSlotBytes = kNarrowLine ? 128 : 192;  // LDS bytes (and region bytes) per chunk
 constexpr int kNarrowTripRows = kNarrowLine ? 60 : 64;     // rows of one 768-byte pass-2 trip
 constexpr uint32_t kNarrowCapQuantum = kNarrowLine ? 320u : 64u;  // cap_rows of a PTF_CHUNK16 layout is a multiple of this
+
+// PTF_PAIR: a routed row is five dwords {operand 0 lo, operand 0 hi, hash image, operand 1 lo, operand 1 hi}: pass 2 of plane 0
+// reads {operand 0, image} at byte 0, pass 2 of plane 1 reads {image, operand 1} at byte 8 -- twelve bytes either way, as of a
+// one-value row.  SIX rows + 8 bytes of padding are one 128-byte line (a chunk); row r of a region lives at byte
+// (r / 6) * 128 + (r % 6) * 20; pass 2 reads trips of TEN lines = 60 rows = 1280 bytes; three ring slots per partition as above.
+constexpr int kPairRowDwords = 5;
+constexpr int kPairChunkRows = 6;
+constexpr int kPairRingRows = kPairChunkRows * kNarrowRingSlots;
+constexpr int kPairTripRows = 60;
+constexpr uint32_t kPairTripBytes = 1280u;
+constexpr uint32_t kPairCapQuantum = 60u;  // cap_rows of a PTF_PAIR layout: whole chunks and whole trips
 
 // ---- Utf8 GROUP BY keys: device string dictionary (dfx_k_dict.hip) ---------------------------------
 enum : int { DICT_POOL = 0, DICT_IDS = 1, DICT_OVERFLOW = 2, DICT_WORDS = 4 };

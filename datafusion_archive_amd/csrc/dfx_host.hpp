@@ -132,6 +132,8 @@ struct Counters {
   long long agg_early_keys_late = 0;        // ... copies that had not arrived when emit asked (a stalled copy engine): retired, not waited for
   long long agg_emit_reused_early = 0;     // ... and emits that also reused its occupancy mask, tile offsets and device key column
   long long agg_pass2_launches = 0;
+  long long agg_pair_launches = 0;    // pass-1 launches that routed two operands per row (PTF_PAIR)
+  long long agg_pair_fallbacks = 0;   // streams that left the pair scan for one scan per aggregate (the table outgrew the pair kernels' partitions, a batch the plan cannot bind)
   long long agg_growths = 0;
   // dfx_aggregate_exchange, per rank (bench.py --gpus N: extra.phases_ms): where a multi-GPU step's wall time goes
   long long xchg_calls = 0;

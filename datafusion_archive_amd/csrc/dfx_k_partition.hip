@@ -427,6 +427,12 @@ __global__ __launch_bounds__(kABlock) __attribute__((amdgpu_num_vgpr(kP2Vgprs)))
   static_assert(!MULTI || NARROW != 0, "shared-operand rows are narrow rows");
   const uint32_t NA = MULTI ? (uint32_t)T.na : 1u;
   const uint32_t S = T.block_mask + 1;
+  // PTF_PAIR (two aggregates of different operands, 20-byte routed rows): this launch aggregates operand / accumulator plane
+  // PT.pair_plane -- the block holds the tags and THAT plane, the row's other operand is not even loaded.  NARROW == 2: the
+  // twelve bytes a lane reads are {operand lo, operand hi, image} (plane 0); plane 1 reads {image, operand} like any narrow row.
+  const bool pair = NARROW != 0 && !MULTI && (PT.flags & PTF_PAIR) != 0;
+  const uint32_t plane = pair ? PT.pair_plane : 0u;
+  uint64_t* const t_accs = T.accs + (uint64_t)plane * T.stride;
   // wide: keys[S] accs[S]; narrow: accs[NA][S] tags[S]
   uint64_t* lkeys = lds;
   uint64_t* laccs = NARROW ? lds : lds + S;
@@ -452,7 +458,7 @@ __global__ __launch_bounds__(kABlock) __attribute__((amdgpu_num_vgpr(kP2Vgprs)))
   for (uint32_t i0 = threadIdx.x * 2; i0 < S; i0 += kABlock * 2) {
     const ulonglong2 kk = *(const ulonglong2*)(T.keys + slot0 + i0);
     for (uint32_t a = 0; a < NA; ++a)
-      *(ulonglong2*)(laccs + (size_t)a * S + i0) = *(const ulonglong2*)(T.accs + (uint64_t)a * T.stride + slot0 + i0);
+      *(ulonglong2*)(laccs + (size_t)a * S + i0) = *(const ulonglong2*)(t_accs + (uint64_t)a * T.stride + slot0 + i0);
     if (NARROW) {
       uint32_t tg[2];
       const uint64_t k2[2] = {kk.x, kk.y};
@@ -480,9 +486,12 @@ __global__ __launch_bounds__(kABlock) __attribute__((amdgpu_num_vgpr(kP2Vgprs)))
   // LINE chunks (PTF_CHUNK16 with kNarrowLine, dfx_device.hpp): a trip is six 128-byte lines of ten rows -- lane L < 60 reads row
   // L % 10 of line L / 10 --, else 64 contiguous rows; 768 bytes either way
   const bool line_chunks = NARROW != 0 && kNarrowLine && (PT.flags & PTF_CHUNK16) != 0;
-  const uint32_t trip_rows = line_chunks ? (uint32_t)kNarrowTripRows : 64u;
-  const uint32_t voff = line_chunks ? ((uint32_t)lane / 10u) * 128u + ((uint32_t)lane % 10u) * 12u
-                                    : (uint32_t)lane * kRowBytes;  // (lanes past the trip's rows re-read its first row: measured 11 % over-fetch otherwise)
+  const uint32_t trip_rows = line_chunks ? (uint32_t)kNarrowTripRows : 64u;  // (PTF_PAIR: ten lines of six rows = 60 as well)
+  static_assert(kPairTripRows == kNarrowTripRows || !kNarrowLine, "one trip length for both line geometries");
+  const uint32_t pair_off = plane != 0u ? 8u : 0u;  // plane 1's twelve bytes start at the image
+  const uint32_t voff = pair ? ((uint32_t)lane / (uint32_t)kPairChunkRows) * 128u + ((uint32_t)lane % (uint32_t)kPairChunkRows) * (4u * kPairRowDwords) + pair_off
+                        : line_chunks ? ((uint32_t)lane / 10u) * 128u + ((uint32_t)lane % 10u) * 12u
+                                      : (uint32_t)lane * kRowBytes;  // (lanes past the trip's rows re-read its first row: measured 11 % over-fetch otherwise)
   uint32_t take[kPF];
   uint64_t s_win = win_bytes;  // (0 once the wave's regions are exhausted: the remaining loads of the pipeline re-read safe_ptr)
   auto advance = [&]() -> uint32_t {  // rows of the next trip (0: exhausted); leaves its address in s_ptr
@@ -505,7 +514,7 @@ __global__ __launch_bounds__(kABlock) __attribute__((amdgpu_num_vgpr(kP2Vgprs)))
   {                                                                       \
     const uint32_t tk = advance();                                        \
     take[D] = tk;                                                         \
-    p2_issue<D, NARROW>((uint32_t)lane < tk ? voff : 0u, (const void*)s_ptr);                               \
+    p2_issue<D, NARROW>((uint32_t)lane < tk ? voff : pair_off, (const void*)s_ptr);                         \
     s_ptr += s_win;                                                       \
     s_rem -= tk;                                                          \
   }
@@ -527,7 +536,13 @@ __global__ __launch_bounds__(kABlock) __attribute__((amdgpu_num_vgpr(kP2Vgprs)))
   };
   auto decode = [&](const Row4& r, uint32_t tk, Probe& q) {
     const bool inb = (uint32_t)lane < tk;
-    if (NARROW) {
+    if (NARROW == 2) {  // {operand lo, operand hi, image}
+      q.val = ((uint64_t)r.y << 32) | r.x;
+      q.img = r.z;
+      q.kk = 0;
+      q.real = inb && r.z != kTagEmpty;
+      q.home4 = (uint32_t)(r.z >> tag_shift) & mask4;
+    } else if (NARROW) {
       q.val = ((uint64_t)r.z << 32) | r.y;
       q.img = r.x;
       q.kk = 0;
@@ -596,8 +611,9 @@ __global__ __launch_bounds__(kABlock) __attribute__((amdgpu_num_vgpr(kP2Vgprs)))
       uint64_t key[1] = {NARROW ? (uint64_t)unhash_word32(img) : kk};
       uint64_t sv[kMaxAggs];
 #pragma unroll
-      for (int j = 0; j < kMaxAggs; ++j)
-        sv[j] = MULTI ? ((uint32_t)j < NA ? transform_value(T.val_xform[j], val, true) : 0ull) : (j == 0 ? val : 0ull);
+      for (int j = 0; j < kMaxAggs; ++j)  // (PTF_PAIR: T is the two-plane view -- the other plane's launch brings that operand, here its identity)
+        sv[j] = MULTI ? ((uint32_t)j < NA ? transform_value(T.val_xform[j], val, true) : 0ull)
+                : pair ? ((uint32_t)j == plane ? val : (j < 2 ? T.acc_init[j] : 0ull)) : (j == 0 ? val : 0ull);
       spill_row<1>(T, spill, todo, key, sv);
     }
   };
@@ -666,7 +682,7 @@ __global__ __launch_bounds__(kABlock) __attribute__((amdgpu_num_vgpr(kP2Vgprs)))
   const bool claimed = __syncthreads_or(new_keys != 0) != 0;
   for (uint32_t i0 = threadIdx.x * 2; i0 < S; i0 += kABlock * 2) {
     for (uint32_t a = 0; a < NA; ++a)
-      *(ulonglong2*)(T.accs + (uint64_t)a * T.stride + slot0 + i0) = *(const ulonglong2*)(laccs + (size_t)a * S + i0);
+      *(ulonglong2*)(t_accs + (uint64_t)a * T.stride + slot0 + i0) = *(const ulonglong2*)(laccs + (size_t)a * S + i0);
     if (!claimed) continue;
     if (NARROW) {
       const uint2 tg = *(const uint2*)(ltags + i0);
@@ -681,14 +697,15 @@ __global__ __launch_bounds__(kABlock) __attribute__((amdgpu_num_vgpr(kP2Vgprs)))
 #pragma unroll
   for (int mm = 32; mm >= 1; mm >>= 1) new_keys += __shfl_xor(new_keys, mm, 64);
   if (lane == 0 && new_keys) atomicAdd(&T.ctrl[CTRL_OCCUPIED], new_keys);
+  if (pair && plane == 0u) return;  // (plane 1's launch reads the same regions: it is the one that ends the window)
   if (p == 0 && threadIdx.x == 0) __hip_atomic_store(&T.ctrl[CTRL_MAX_FILL], 0u, RLX_AGENT);  // the regions are empty again
   snapshot_ctrl_if_last(T, PT);
 }
 
 template <int NARROW>
-static void launch_agg_lean(const DevTable& T, const DevPartition& PT, const DevRows& spill, size_t lds_bytes, hipStream_t s) {
+static void launch_agg_lean(const DevTable& T, const DevPartition& PT, const DevRows& spill, size_t lds_bytes, hipStream_t s, int plane = 0) {
 #define DFX_LEAN(K) hipLaunchKernelGGL((k_partition_agg_lean<NARROW, K>), dim3(PT.n_parts), dim3(kABlock), lds_bytes, s, T, PT, spill)
-  switch (T.acc_kind[0]) {
+  switch (T.acc_kind[plane]) {
     case ACC_ADD_F64: DFX_LEAN(ACC_ADD_F64); break;
     case ACC_ADD_F32: DFX_LEAN(ACC_ADD_F32); break;
     case ACC_ADD_U64: DFX_LEAN(ACC_ADD_U64); break;
@@ -723,7 +740,7 @@ hipError_t launch_probe_wide_keys(const DevTable& T, hipStream_t s) {
 
 size_t partition_stage_bytes(const DevPartition& PT) {
   if ((PT.mode & 15u) == 0) return (size_t)PT.n_parts * 4 + 16;
-  if ((PT.mode & 15u) == 2 && (PT.flags & PTF_WS)) return partition_ws_bytes(PT.n_parts, PT.ws_scanners == 4 ? 4 : 8);
+  if ((PT.mode & 15u) == 2 && (PT.flags & PTF_WS)) return partition_ws_bytes(PT.n_parts, PT.ws_scanners == 4 ? 4 : 8, (PT.flags & PTF_PAIR) ? 2 : 1);
   if ((PT.mode & 15u) == 2)
     return partition_ring_bytes(PT.n_words, PT.n_parts, (PT.flags & PTF_CHUNK16) ? kNarrowRingRows : (PT.mode & 0x100u) ? 8 : 16, (PT.flags & PTF_HOT) != 0,
                                 (PT.flags & PTF_NARROW) != 0, (PT.flags & PTF_SHARED) ? 128 : 0);
@@ -774,8 +791,10 @@ static bool launch_partition_plan(const DevProgram& P, const DevFastPlan& fast, 
                                   const DevTable& T, const DevPartition& PT, const DevRows& spill, int64_t n, size_t lds_bytes,
                                   hipStream_t s) {
   const bool shared = (PT.flags & PTF_SHARED) != 0;
-  const bool one_value = (PT.flags & PTF_WS) || ((PT.mode & 15u) == 2 && (PT.flags & PTF_NARROW));
+  const bool pair = (PT.flags & PTF_PAIR) != 0;  // two operands per routed row: the multi-value binding (slot look-ups) in the wave-specialised kernel
+  const bool one_value = !pair && ((PT.flags & PTF_WS) || ((PT.mode & 15u) == 2 && (PT.flags & PTF_NARROW)));
   if (one_value && !shared && T.na != 1) return false;
+  if (pair && (T.na != 2 || T.kw != 1 || !(PT.flags & PTF_WS))) return false;
   const uint8_t raw_xf[kMaxAggs] = {VT_RAW};
   DevFastPlan fp;
   DevColumns cp;
@@ -790,8 +809,18 @@ static bool launch_partition_plan(const DevProgram& P, const DevFastPlan& fast, 
       {launch_partition_variant11, launch_partition_variant15, launch_partition_variant16, launch_partition_variant12,
        launch_partition_variant19, launch_partition_variant15, launch_partition_variant20, launch_partition_variant12}};
   if (!one_value && (fp.scan.gen & 4)) return false;  // (cannot happen: bind_scan_plan gives bit 2 to fixed-slot bindings only)
+  if (pair && fp.scan.n_cols != 3) return false;      // (the pair kernels exist for key + two operand columns: variants 21-24)
   by_need[fp.scan.n_cols <= 2 ? 0 : fp.scan.n_cols == 3 ? 1 : 2][fp.scan.gen & 7](P, fp, cp, plan, T, PT, spill, n, lds_bytes, s);
   return true;
+}
+
+// PTF_PAIR: can THIS bound batch go through the pair kernels?  (the plan binds it, three plan columns; host only, no launch)
+bool partition_pair_supported(const DevProgram& P, const DevFastPlan& fast, const DevColumns& C, const DevTable& T) {
+  if (!kNarrowLine || T.na != 2 || T.kw != 1) return false;
+  DevFastPlan fp;
+  DevColumns cp;
+  if (!bind_scan_plan(P, fast, C, 1, 2, T.val_xform, false, &fp, &cp)) return false;
+  return fp.scan.n_cols == 3 && !(fp.scan.gen & 4);
 }
 
 hipError_t launch_partition(const DevProgram& P, const DevFastPlan& fast, const DevColumns& C, const DevAggPlan& plan,
@@ -810,6 +839,8 @@ hipError_t launch_partition(const DevProgram& P, const DevFastPlan& fast, const 
   const bool shared = (PT.flags & PTF_SHARED) != 0;
   const uint8_t raw_kind0[1] = {SigKeySumPred2F64::acc(0)}, raw_kind1[1] = {SigKeySum::acc(0)}, raw_xf[1] = {VT_RAW};
   static_assert(SigKeySumPred2F64::xf(0) == VT_RAW && SigKeySum::xf(0) == VT_RAW, "the one-aggregate signatures route the raw operand");
+  if (PT.flags & PTF_PAIR)  // (the host asked partition_pair_supported first: a batch the plan cannot bind is its error to handle)
+    return launch_partition_plan(P, fast, C, plan, T, PT, spill, n, lds_bytes, s) ? hipGetLastError() : hipErrorNotSupported;
   if ((fast.plan_mode & 3) == 2 && launch_partition_plan(P, fast, C, plan, T, PT, spill, n, lds_bytes, s)) return hipGetLastError();  // (A/B: scan.plan = 2)
   if (shared ? sig_matches<SigKeySumPred2F64>(P, fast, 1, 1, raw_kind0, raw_xf) : sig_matches<SigKeySumPred2F64>(P, fast, 1, T.na, T.acc_kind, T.val_xform)) {
     launch_partition_variant0(P, fast, C, plan, T, PT, spill, n, lds_bytes, s);
@@ -845,11 +876,22 @@ hipError_t launch_partition_agg(const DevTable& T, const DevPartition& PT, const
                                 hipStream_t s) {
   Scope sc(KID_PARTITION_AGG, s, algo_bytes);
   size_t lds_bytes = (size_t)(T.block_mask + 1) * (size_t)(1 + T.na) * 8 + (size_t)(PT.n_producers + 1) * 4 + 16;
-  if (lds_bytes > 160 * 1024 - 256 || PT.n_producers > 1024) return hipErrorInvalidValue;
+  if (((lds_bytes > 160 * 1024 - 256) && !(PT.flags & PTF_PAIR)) || PT.n_producers > 1024) return hipErrorInvalidValue;
   if ((PT.flags & PTF_NARROW) && (PT.flags & PTF_SHARED)) {
     const size_t shared_lds = (size_t)(T.block_mask + 1) * (size_t)(4 + 8 * T.na) + (size_t)(kABlock / 64) * kP2RetryRows * 12;
     if (T.na < 2 || T.na > kSharedMaxAggs || T.kw != 1 || shared_lds > 160 * 1024 - 256) return hipErrorInvalidValue;
     hipLaunchKernelGGL((k_partition_agg_lean<1, -1>), dim3(PT.n_parts), dim3(kABlock), shared_lds, s, T, PT, spill);
+  } else if ((PT.flags & PTF_NARROW) && (PT.flags & PTF_PAIR)) {
+    // two launches of the one-value kernel over the same regions, one per operand / accumulator plane; the first claims the
+    // window's new keys, the second finds them, resets CTRL_MAX_FILL and publishes the control block
+    if (T.na != 2 || T.kw != 1 || !kNarrowLine) return hipErrorInvalidValue;
+    const size_t pair_lds = (size_t)(T.block_mask + 1) * 12 + (size_t)(kABlock / 64) * kP2RetryRows * 12;
+    DevPartition P0 = PT, P1 = PT;
+    P0.pair_plane = 0;
+    P0.snap_host = nullptr;
+    P1.pair_plane = 1;
+    launch_agg_lean<2>(T, P0, spill, pair_lds, s, 0);
+    launch_agg_lean<1>(T, P1, spill, pair_lds, s, 1);
   } else if (PT.flags & PTF_NARROW) {
     if (T.na != 1 || T.kw != 1) return hipErrorInvalidValue;
     launch_agg_lean<1>(T, PT, spill, (size_t)(T.block_mask + 1) * 12 + (size_t)(kABlock / 64) * kP2RetryRows * 12, s);

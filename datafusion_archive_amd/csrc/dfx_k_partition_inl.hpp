@@ -44,26 +44,28 @@ DEV uint32_t* region_row12(const DevPartition& PT, uint32_t part, uint32_t produ
 
 // Narrow rows of the large-chunk geometry (PTF_CHUNK16; dfx_device.hpp: kNarrowLine): with LINE chunks a chunk of CH = 10 rows
 // is one 128-byte line, in the region and in the LDS ring alike.  Regions of this geometry are contiguous (layouts 0 and 1).
-template <int CH, int NARROW>
-constexpr bool ring_is_line() { return kNarrowLine && NARROW != 0 && CH == kNarrowChunkRows; }
-// dword index (from the ring's first dword) of row r of chunk slot sl of partition `part`
-template <int CH, int RP, int NARROW>
+template <int CH, int NARROW, int DW = 3>
+constexpr bool ring_is_line() {
+  return kNarrowLine && NARROW != 0 && ((DW == 3 && CH == kNarrowChunkRows) || (DW == kPairRowDwords && CH == kPairChunkRows));
+}
+// dword index (from the ring's first dword) of row r of chunk slot sl of partition `part`  (DW: dwords per row -- 3, or 5: PTF_PAIR)
+template <int CH, int RP, int NARROW, int DW = 3>
 DEV uint32_t ring_dword12(uint32_t part, uint32_t sl, uint32_t r) {
-  if constexpr (ring_is_line<CH, NARROW>()) return (part * (uint32_t)(RP / CH) + sl) * 32u + r * 3u;
+  if constexpr (ring_is_line<CH, NARROW, DW>()) return (part * (uint32_t)(RP / CH) + sl) * 32u + r * (uint32_t)DW;
   else return (part * (uint32_t)RP + sl * (uint32_t)CH + r) * 3u;
 }
 // dwords of a narrow ring
-template <int CH, int RP, int NARROW>
+template <int CH, int RP, int NARROW, int DW = 3>
 DEV size_t ring_dwords12(uint32_t n_parts) {
-  if constexpr (ring_is_line<CH, NARROW>()) return (size_t)n_parts * (size_t)(RP / CH) * 32u;
+  if constexpr (ring_is_line<CH, NARROW, DW>()) return (size_t)n_parts * (size_t)(RP / CH) * 32u;
   else return (size_t)n_parts * RP * 3u;
 }
 // row slot `row` of a narrow region
-template <int CH, int NARROW>
+template <int CH, int NARROW, int DW = 3>
 DEV uint32_t* region_row12g(const DevPartition& PT, uint32_t part, uint32_t producer, uint32_t row) {
-  if constexpr (ring_is_line<CH, NARROW>()) {
+  if constexpr (ring_is_line<CH, NARROW, DW>()) {
     const uint32_t c = row / (uint32_t)CH;
-    return (uint32_t*)(PT.rows + (uint64_t)part * PT.part_stride + (uint64_t)producer * PT.prod_stride) + (uint64_t)c * 32u + (uint64_t)(row - c * (uint32_t)CH) * 3u;
+    return (uint32_t*)(PT.rows + (uint64_t)part * PT.part_stride + (uint64_t)producer * PT.prod_stride) + (uint64_t)c * 32u + (uint64_t)(row - c * (uint32_t)CH) * (uint32_t)DW;
   } else {
     return region_row12(PT, part, producer, row);
   }
@@ -634,9 +636,12 @@ DEV void ring_route(const DevTable& T, const DevPartition& PT, const DevRows& sp
 // slot of this wave's own other batch still gets it.
 // KEY_IS_IMG: `key` holds the row's 32-bit hash IMAGE, not its key (the dense split of the wave-specialised kernel: the scanner has
 // hashed the row and turned away what has no image); a row that leaves the routed path gets its key back (unhash_word32)
-template <int kRingCH, int kRingRP, int NARROW, bool KEY_IS_IMG = false>
+// DW = 5 (PTF_PAIR): the row carries a second operand, val2 (20-byte rows, six per 128-byte line: dfx_device.hpp)
+template <int kRingCH, int kRingRP, int NARROW, bool KEY_IS_IMG = false, int DW = 3>
 DEV void ring_route2(const DevTable& T, const DevPartition& PT, const DevRows& spill, const RingLds& L, uint32_t producer,
-                     const bool (&have)[2], const uint64_t (&key)[2], const uint64_t (&val)[2], const uint64_t (&h)[2], uint32_t& err) {
+                     const bool (&have)[2], const uint64_t (&key)[2], const uint64_t (&val)[2], const uint64_t (&h)[2], uint32_t& err,
+                     const uint64_t (&val2)[2]) {
+  static_assert(DW == 3 || (DW == kPairRowDwords && NARROW != 0), "rows of three dwords, or the narrow pair rows");
   constexpr int kRingNCH = kRingRP / kRingCH;
   const int lane = lane_id();
   const int wave = threadIdx.x >> 6;
@@ -676,7 +681,7 @@ DEV void ring_route2(const DevTable& T, const DevPartition& PT, const DevRows& s
         expand_shared_operand(T, val[b], sv);
       } else {
 #pragma unroll
-        for (int a = 0; a < kMaxAggs; ++a) sv[a] = a == 0 ? val[b] : 0ull;
+        for (int a = 0; a < kMaxAggs; ++a) sv[a] = a == 0 ? val[b] : (DW == kPairRowDwords && a == 1) ? val2[b] : 0ull;
       }
       spill_row<1>(T, spill, todo[b], k1, sv);
     }
@@ -704,10 +709,18 @@ DEV void ring_route2(const DevTable& T, const DevPartition& PT, const DevRows& s
       park[b] = pending[b] && gen_now[b] == g[b];
       if (park[b]) {
         if (NARROW) {
-          uint32_t* d32 = (uint32_t*)L.ring + ring_dword12<kRingCH, kRingRP, NARROW>(part[b], sl[b], r[b]);
-          d32[0] = img[b];
-          d32[1] = (uint32_t)val[b];
-          d32[2] = (uint32_t)(val[b] >> 32);
+          uint32_t* d32 = (uint32_t*)L.ring + ring_dword12<kRingCH, kRingRP, NARROW, DW>(part[b], sl[b], r[b]);
+          if constexpr (DW == kPairRowDwords) {
+            d32[0] = (uint32_t)val[b];
+            d32[1] = (uint32_t)(val[b] >> 32);
+            d32[2] = img[b];
+            d32[3] = (uint32_t)val2[b];
+            d32[4] = (uint32_t)(val2[b] >> 32);
+          } else {
+            d32[0] = img[b];
+            d32[1] = (uint32_t)val[b];
+            d32[2] = (uint32_t)(val[b] >> 32);
+          }
         } else {
           uint64_t* dst = L.ring + ((size_t)part[b] * kRingRP + sl[b] * kRingCH + r[b]) * NW;
           *(ulonglong2*)dst = make_ulonglong2(key[b], val[b]);
@@ -733,7 +746,7 @@ DEV void ring_route2(const DevTable& T, const DevPartition& PT, const DevRows& s
       if (job[0]) jobs[mbcnt64(jm0)] = (part[0] << 20) | c[0];
       if (job[1]) jobs[n0 + mbcnt64(jm1)] = (part[1] << 20) | c[1];
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      constexpr bool LINE = ring_is_line<kRingCH, NARROW>();  // (see ring_route)
+      constexpr bool LINE = ring_is_line<kRingCH, NARROW, DW>();  // (see ring_route)
       constexpr uint32_t kJobLanes = LINE ? 8u : (uint32_t)kRingCH;
       for (uint32_t j0 = 0; j0 < njobs; j0 += 64 / kJobLanes) {
         const uint32_t j = j0 + (uint32_t)lane / kJobLanes;
@@ -743,8 +756,8 @@ DEV void ring_route2(const DevTable& T, const DevPartition& PT, const DevRows& s
           const uint32_t rr = (uint32_t)lane % kJobLanes;
           if constexpr (LINE) {
             // one global_store_dwordx4 per lane, eight adjacent lanes = one whole 128-byte line
-            const uint4 piece = *(const uint4*)((const uint32_t*)L.ring + ring_dword12<kRingCH, kRingRP, NARROW>(jb.x, jb.y % kRingNCH, 0) + rr * 4u);
-            *(uint4*)(region_row12g<kRingCH, NARROW>(PT, jb.x, producer, jb.y * kRingCH) + rr * 4u) = piece;
+            const uint4 piece = *(const uint4*)((const uint32_t*)L.ring + ring_dword12<kRingCH, kRingRP, NARROW, DW>(jb.x, jb.y % kRingNCH, 0) + rr * 4u);
+            *(uint4*)(region_row12g<kRingCH, NARROW, DW>(PT, jb.x, producer, jb.y * kRingCH) + rr * 4u) = piece;
           } else if (NARROW) {
             const uint32_t* s32 = (const uint32_t*)L.ring + ((size_t)jb.x * kRingRP + (jb.y % kRingNCH) * kRingCH + rr) * 3;
             uint32_t* o32 = region_row12(PT, jb.x, producer, jb.y * kRingCH + rr);
@@ -778,6 +791,12 @@ DEV void ring_route2(const DevTable& T, const DevPartition& PT, const DevRows& s
     }
     __builtin_amdgcn_s_sleep(1);
   }
+}
+
+template <int kRingCH, int kRingRP, int NARROW, bool KEY_IS_IMG = false>
+DEV void ring_route2(const DevTable& T, const DevPartition& PT, const DevRows& spill, const RingLds& L, uint32_t producer,
+                     const bool (&have)[2], const uint64_t (&key)[2], const uint64_t (&val)[2], const uint64_t (&h)[2], uint32_t& err) {
+  ring_route2<kRingCH, kRingRP, NARROW, KEY_IS_IMG, 3>(T, PT, spill, L, producer, have, key, val, h, err, val);
 }
 
 // ---- hot keys (skewed inputs) --------------------------------------------------------------------------

@@ -3,5 +3,6 @@
 // SUM(w) WHERE v ... GROUP BY k, or the second scan of SUM(v), MIN(w)), GENK = 0 (none: bit 0 4-byte columns widened, bit 1 validity bitmaps).
 #include "dfx_k_partition_ws_inl.hpp"
 namespace dfx {
-DFX_PARTITION_VARIANT_WS(21, DFX_ARG(PlanPolicyN<3, 1, 0>), DFX_ARG(PlanPolicyN<3, 1, 0>), DFX_ARG(PlanPolicy1<3, 1, 0>), DFX_ARG(PlanPolicy1<3, 3, 0>), DFX_ARG(PlanPolicy1<3, 3, 0>))
+// (+ the PAIR flavour: two aggregates of different operands routed by ONE scan -- PTF_PAIR, dfx_device.hpp)
+DFX_PARTITION_VARIANT_WS_PAIR(21, DFX_ARG(PlanPolicyN<3, 1, 0>), DFX_ARG(PlanPolicyN<3, 1, 0>), DFX_ARG(PlanPolicy1<3, 1, 0>), DFX_ARG(PlanPolicy1<3, 3, 0>), DFX_ARG(PlanPolicy1<3, 3, 0>), DFX_ARG(PlanPolicyN<3, 3, 0>))
 }  // namespace dfx

@@ -3,5 +3,6 @@
 // SUM(w) WHERE v ... GROUP BY k, or the second scan of SUM(v), MIN(w)), GENK = 3 (4-byte-columns+bitmaps: bit 0 4-byte columns widened, bit 1 validity bitmaps).
 #include "dfx_k_partition_ws_inl.hpp"
 namespace dfx {
-DFX_PARTITION_VARIANT_WS(24, DFX_ARG(PlanPolicyN<3, 1, 3>), DFX_ARG(PlanPolicyN<3, 1, 3>), DFX_ARG(PlanPolicy1<3, 1, 3>), DFX_ARG(PlanPolicy1<3, 3, 3>), DFX_ARG(PlanPolicy1<3, 3, 3>))
+// (+ the PAIR flavour: two aggregates of different operands routed by ONE scan -- PTF_PAIR, dfx_device.hpp)
+DFX_PARTITION_VARIANT_WS_PAIR(24, DFX_ARG(PlanPolicyN<3, 1, 3>), DFX_ARG(PlanPolicyN<3, 1, 3>), DFX_ARG(PlanPolicy1<3, 1, 3>), DFX_ARG(PlanPolicy1<3, 3, 3>), DFX_ARG(PlanPolicy1<3, 3, 3>), DFX_ARG(PlanPolicyN<3, 3, 3>))
 }  // namespace dfx

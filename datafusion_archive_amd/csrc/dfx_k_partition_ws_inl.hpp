@@ -35,13 +35,13 @@ struct WsCtl {  // one per queue (= per router wave)
 };
 
 #ifdef DFX_PARTITION_MAIN_TU
-size_t partition_ws_bytes(uint32_t n_parts, int ns) {
+size_t partition_ws_bytes(uint32_t n_parts, int ns, int nv) {  // nv: routed operands per row (2: PTF_PAIR -- a second operand plane per queue)
   const int nq = kRingBlock / 64 - ns;  // one queue per ROUTER wave (a scanner feeds (16 - ns) / ns of them in turn)
   return (size_t)n_parts * kNarrowRingSlots * kNarrowSlotBytes + (size_t)(kRingBlock / 64) * 64 * 8 /* jobs */ + (size_t)n_parts * 4 * (1 + 2 * kWsNCH) +
-         (size_t)nq * kWsQueueRows * 12 + (size_t)nq * sizeof(WsCtl) + 64;
+         (size_t)nq * kWsQueueRows * (4 + 8 * (size_t)nv) + (size_t)nq * sizeof(WsCtl) + 64;
 }
 #else
-size_t partition_ws_bytes(uint32_t n_parts, int ns);
+size_t partition_ws_bytes(uint32_t n_parts, int ns, int nv);
 #endif
 
 // rows the narrow routed form cannot carry: a key >= 2^32 (the claim sentinel i64::MIN among them).  No row of a stream whose
@@ -49,7 +49,8 @@ size_t partition_ws_bytes(uint32_t n_parts, int ns);
 // nowhere else: the replay (launch_merge_rows -> table_apply) knows the sentinel key's slot, CTRL_WIDE_KEYS makes the host
 // leave narrow mode, and the scan loop carries a few dozen instructions for them instead of the accumulator algebra
 // (sentinel_apply inlined four times per loop was 600 instructions and most of this kernel's scalar-register pressure).
-DEV void ws_slow_rows(const DevTable& T, const DevRows& spill, bool slow, uint64_t key0, uint64_t val0) {
+template <int NV = 1>
+DEV void ws_slow_rows(const DevTable& T, const DevRows& spill, bool slow, uint64_t key0, uint64_t val0, uint64_t val1 = 0) {
   if (__hip_atomic_load(&T.ctrl[CTRL_WIDE_KEYS], RLX_AGENT) == 0u) __hip_atomic_store(&T.ctrl[CTRL_WIDE_KEYS], 1u, RLX_AGENT);
   const uint64_t m = __ballot(slow);
   const int lane = lane_id();
@@ -59,14 +60,17 @@ DEV void ws_slow_rows(const DevTable& T, const DevRows& spill, bool slow, uint64
   base = __shfl(base, leader, 64);
   if (slow) {
     const uint64_t pos = base + (uint64_t)__popcll(m & ((1ull << lane) - 1ull));
-    if (pos < spill.capacity) {  // (one key word, one value: the only rows this kernel routes)
+    if (pos < spill.capacity) {  // (one key word, one value -- two under PTF_PAIR: the only rows this kernel routes)
       spill.words[pos] = key0;
       spill.words[spill.capacity + pos] = val0;
+      if constexpr (NV == 2) spill.words[2 * spill.capacity + pos] = val1;
     }
   }
 }
 
-template <typename POL, int NS, int FORM>
+// NV = 2 (PTF_PAIR): two aggregates of different operands -- the scanners evaluate both arguments, the queues carry a second
+// operand plane, the routers write 20-byte rows into LINE chunks of six (dfx_device.hpp: kPair*); everything else is the same code.
+template <typename POL, int NS, int FORM, int NV = 1>
 __global__ __launch_bounds__(kRingBlock) void k_partition_ws(const DevProgram P, const DevFastPlan F, const DevColumns C,
                                                             const DevAggPlan plan, const DevTable T,
                                                             const DevPartition PT, const DevRows spill, const int64_t n) {
@@ -79,10 +83,14 @@ __global__ __launch_bounds__(kRingBlock) void k_partition_ws(const DevProgram P,
   // routers share the rows of one scanner -- routing, a chain of LDS round trips per batch, is what a dense scan has most of.
   constexpr int QPS = NR / NS;                // queues per scanner
   static_assert(NS >= 1 && NR >= 1 && NR % NS == 0, "every router has a queue, every scanner the same number of them");
+  static_assert(NV == 1 || NV == 2, "one routed operand, or the pair");
+  // chunk geometry: rows per chunk (= per 128-byte line), rows per ring, dwords per row
+  constexpr int CH = NV == 2 ? kPairChunkRows : kWsCH, RP = NV == 2 ? kPairRingRows : kWsRP, DW = NV == 2 ? kPairRowDwords : 3;
+  static_assert(NV == 1 || !kNarrowLine || RP / CH == kWsNCH, "three slots either way");
   extern __shared__ __attribute__((aligned(16))) uint64_t lds[];
   RingLds L;
   L.ring = lds;
-  const size_t ring_words = ring_dwords12<kWsCH, kWsRP, 1>(PT.n_parts) / 2;  // 12-byte rows (LINE chunks: 128-byte slots)
+  const size_t ring_words = ring_dwords12<CH, RP, 1, DW>(PT.n_parts) / 2;  // 12-byte rows (LINE chunks: 128-byte slots)
   L.queue = nullptr;                                             // (the ring kernel's wave queues: not used here)
   L.jobs = (uint32_t*)(L.ring + ring_words);
   L.fill = L.jobs + NWAVES * 64 * 2;
@@ -93,13 +101,14 @@ __global__ __launch_bounds__(kRingBlock) void k_partition_ws(const DevProgram P,
   // the operand planes behind everything else, 8-byte aligned (as an offset from `lds`: keeps the LDS address space)
   const size_t qv_word0 = ring_words + ((size_t)(NWAVES * 64 * 2 + PT.n_parts * (1 + 2 * kWsNCH) + NR * kWsQueueRows) * 4 + (size_t)NR * sizeof(WsCtl) + 7) / 8;
   uint64_t* const qvals = lds + qv_word0;                                        // [NR][kWsQueueRows]
+  uint64_t* const qvals2 = qvals + (size_t)NR * kWsQueueRows;                    // NV == 2: the second operand, same indexing
   const int lane = lane_id();
   const int wave = (int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const uint32_t producer = blockIdx.x;
   // fill, commit, gen exactly as k_partition_ring initialises them (PTF_RESUME: chunk numbering goes on from counts[])
   for (uint32_t p = threadIdx.x; p < PT.n_parts; p += kRingBlock) {
     const uint32_t f0 = (PT.flags & PTF_RESUME) ? PT.counts[(uint64_t)p * PT.n_producers + producer] : 0u;
-    const uint32_t c0 = f0 / kWsCH;
+    const uint32_t c0 = f0 / (uint32_t)CH;
     L.fill[p] = f0;
 #pragma unroll
     for (int sl = 0; sl < kWsNCH; ++sl) {
@@ -165,6 +174,13 @@ __global__ __launch_bounds__(kRingBlock) void k_partition_ws(const DevProgram P,
             bool valid;
             POL::arg(P, F, plan.arg[0], 0, cur, curv, reg, rv, v, valid);
             const uint64_t val = transform_value(POL::xform(T, 0), v, valid);
+            uint64_t val1 = 0;
+            if constexpr (NV == 2) {
+              uint64_t v1;
+              bool valid1;
+              POL::arg(P, F, plan.arg[1], 1, cur, curv, reg, rv, v1, valid1);
+              val1 = transform_value(POL::xform(T, 1), v1, valid1);
+            }
             passed += (uint64_t)__popcll(pm);
             // dense split (QPS > 1): the SCANNERS hash -- four waves with little else to do, while the twelve routers' chain of
             // LDS round trips is what bounds the launch -- and the queue carries the row's 32-bit image instead of its key
@@ -176,7 +192,7 @@ __global__ __launch_bounds__(kRingBlock) void k_partition_ws(const DevProgram P,
               sm |= pm & __ballot(qword >= kTagForeign);  // ... or one of the two reserved images
             }
             if (sm != 0) {
-              ws_slow_rows(T, spill, lane_of_mask(sm), key, val);
+              ws_slow_rows<NV>(T, spill, lane_of_mask(sm), key, val, val1);
               pm &= ~sm;
             }
             const uint32_t c = (uint32_t)__popcll(pm);
@@ -206,6 +222,7 @@ __global__ __launch_bounds__(kRingBlock) void k_partition_ws(const DevProgram P,
                 const uint32_t at = (tail + mbcnt64(pm)) & (uint32_t)(kWsQueueRows - 1);
                 qk[at] = qword;
                 qv[at] = val;
+                if constexpr (NV == 2) qvals2[(size_t)(q0 + cq) * kWsQueueRows + at] = val1;
               }
               tail += c;
               v_tail = lane == cq ? tail : v_tail;  // (v_writelane by compare-and-select)
@@ -259,13 +276,14 @@ __global__ __launch_bounds__(kRingBlock) void k_partition_ws(const DevProgram P,
       }
       idle = 0;
       bool have[2];
-      uint64_t k2[2], v2[2], h2[2];
+      uint64_t k2[2], v2[2], h2[2], w2[2] = {0, 0};
 #pragma unroll
       for (int b = 0; b < 2; ++b) {  // (both batches' queue reads in flight together)
         have[b] = (uint32_t)(b * 64 + lane) < take;
         const uint32_t at = (head + (uint32_t)(b * 64 + lane)) & (uint32_t)(kWsQueueRows - 1);
         k2[b] = have[b] ? (uint64_t)qkeys[(size_t)q * kWsQueueRows + at] : 0ull;
         v2[b] = have[b] ? qvals[(size_t)q * kWsQueueRows + at] : 0ull;
+        if constexpr (NV == 2) w2[b] = have[b] ? qvals2[(size_t)q * kWsQueueRows + at] : 0ull;
       }
       // the slots are free again as soon as the rows sit in registers
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -279,7 +297,7 @@ __global__ __launch_bounds__(kRingBlock) void k_partition_ws(const DevProgram P,
           h2[b] = hash_keys<1>(k1);
         }
       }
-      ring_route2<kWsCH, kWsRP, 1, (QPS > 1)>(T, PT, spill, L, producer, have, k2, v2, h2, err);
+      ring_route2<CH, RP, 1, (QPS > 1), DW>(T, PT, spill, L, producer, have, k2, v2, h2, err, w2);
     }
   }
   __syncthreads();
@@ -288,20 +306,19 @@ __global__ __launch_bounds__(kRingBlock) void k_partition_ws(const DevProgram P,
   for (uint32_t p = threadIdx.x; p < PT.n_parts; p += kRingBlock) {
     uint32_t f = L.fill[p];
     if (f > PT.cap_rows) f = PT.cap_rows;
-    const uint32_t c = f / kWsCH;
-    const uint32_t rem = f % kWsCH;
+    const uint32_t c = f / (uint32_t)CH;
+    const uint32_t rem = f % (uint32_t)CH;
     for (uint32_t rr = 0; rr < rem; ++rr) {
-      const uint32_t* s32 = (const uint32_t*)L.ring + ring_dword12<kWsCH, kWsRP, 1>(p, c % kWsNCH, rr);
-      uint32_t* o32 = region_row12g<kWsCH, 1>(PT, p, producer, c * kWsCH + rr);
-      for (int w = 0; w < 3; ++w) o32[w] = s32[w];
+      const uint32_t* s32 = (const uint32_t*)L.ring + ring_dword12<CH, RP, 1, DW>(p, c % kWsNCH, rr);
+      uint32_t* o32 = region_row12g<CH, 1, DW>(PT, p, producer, c * CH + rr);
+      for (int w = 0; w < DW; ++w) o32[w] = s32[w];
     }
     if (rem != 0) {
-      for (uint32_t rr = rem; rr < (uint32_t)kWsCH; ++rr) {
-        uint32_t* o32 = region_row12g<kWsCH, 1>(PT, p, producer, c * kWsCH + rr);
-        o32[0] = kTagEmpty;
-        o32[1] = o32[2] = 0;
+      for (uint32_t rr = rem; rr < (uint32_t)CH; ++rr) {
+        uint32_t* o32 = region_row12g<CH, 1, DW>(PT, p, producer, c * CH + rr);
+        for (int w = 0; w < DW; ++w) o32[w] = w == (NV == 2 ? 2 : 0) ? kTagEmpty : 0u;  // (the image dword: kTagEmpty = not a row)
       }
-      f = (c + 1) * kWsCH;
+      f = (c + 1) * CH;
     }
     PT.counts[(uint64_t)p * PT.n_producers + producer] = f;
     max_fill = f > max_fill ? f : max_fill;
@@ -350,6 +367,19 @@ void launch_partition_ws(const DevProgram& P, const DevFastPlan& fast, const Dev
 #define DFX_PARTITION_VARIANT_WS(ID, POL, POLS, POLN, POLW, POLD)                                                          \
   void launch_partition_variant##ID(DFX_PARTITION_VARIANT_ARGS) {                                                          \
     if (PT.flags & PTF_WS)                                                                                                 \
+      launch_partition_ws<POLW, POLD>(P, fast, C, plan, T, PT, spill, n, lds_bytes, s);                                    \
+    else                                                                                                                   \
+      launch_partition_pol<POL, POLS, POLN>(P, fast, C, plan, T, PT, spill, n, lds_bytes, s);                              \
+  }
+
+
+// ... and, for the policies that can evaluate two arguments (POLP: slot look-ups, PlanPolicyN), the PAIR flavour (PTF_PAIR): always
+// eight scanners + eight routers (twelve routers' queues with two operand planes do not fit the LDS), the run-time comparison form
+#define DFX_PARTITION_VARIANT_WS_PAIR(ID, POL, POLS, POLN, POLW, POLD, POLP)                                               \
+  void launch_partition_variant##ID(DFX_PARTITION_VARIANT_ARGS) {                                                          \
+    if ((PT.flags & PTF_WS) && (PT.flags & PTF_PAIR))                                                                      \
+      hipLaunchKernelGGL((k_partition_ws<POLP, (int)kWsDefault, 0, 2>), dim3((int)PT.n_producers), dim3(kRingBlock), lds_bytes, s, P, fast, C, plan, T, PT, spill, n); \
+    else if (PT.flags & PTF_WS)                                                                                            \
       launch_partition_ws<POLW, POLD>(P, fast, C, plan, T, PT, spill, n, lds_bytes, s);                                    \
     else                                                                                                                   \
       launch_partition_pol<POL, POLS, POLN>(P, fast, C, plan, T, PT, spill, n, lds_bytes, s);                              \

@@ -154,9 +154,10 @@ hipError_t launch_dict_gather(const uint64_t* ids, int64_t g, const DevDict& D, 
 // partitioned GROUP BY (dfx_k_partition.hip): pass 1 routes passing rows to per-(producer, partition)
 // regions, pass 2 aggregates every partition in an LDS copy of its table block.  Single-word keys.
 size_t partition_stage_bytes(const DevPartition& PT);
+bool partition_pair_supported(const DevProgram& P, const DevFastPlan& fast, const DevColumns& C, const DevTable& T);  // PTF_PAIR: this bound batch fits the pair kernels
 hipError_t launch_probe_wide_keys(const DevTable& T, hipStream_t s);
 size_t partition_ring_bytes(uint32_t n_words, uint32_t n_parts, int ring_rows, bool hot = false, bool narrow = false, int queue_rows = 0);
-size_t partition_ws_bytes(uint32_t n_parts, int scanner_waves);  // LDS of the wave-specialised pass-1 kernel (PTF_WS)
+size_t partition_ws_bytes(uint32_t n_parts, int scanner_waves, int operands = 1);  // LDS of the wave-specialised pass-1 kernel (PTF_WS)
 uint32_t partition_sort_capacity(uint32_t n_words, uint32_t n_parts, uint32_t block, size_t lds_budget);
 hipError_t launch_partition(const DevProgram& P, const DevFastPlan& fast, const DevColumns& C, const DevAggPlan& plan,
                             const DevTable& T, const DevPartition& PT, const DevRows& spill, int64_t n,

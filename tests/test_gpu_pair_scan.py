@@ -1,0 +1,138 @@
+"""The PAIR scan (csrc/dfx_device.hpp: PTF_PAIR): two aggregates of DIFFERENT operands over one narrow key and
+many groups are served by ONE scan that routes 20-byte rows {operand 0, hash image, operand 1} -- six per 128-byte line -- and a pass
+2 per accumulator plane over the same regions, instead of one scan per aggregate (agg.pair_scan = 0: rounds 4-6).  Every query runs
+both ways and against the CPU oracle (reference-shaped, 1024-row batches), group by group and bit for bit; the counters say which
+path ran.  Covered: the accumulator kinds in either plane, no predicate (every row routed), nulls in the key / an operand / the
+predicate column (validity bitmaps: the plan's NULLS kernels), an Int32 key (widened columns), Zipf keys with tiny regions (overflow
+-> spill list with two value planes), a table that grows past the pair kernels' 256 partitions (fall back to a scan per aggregate at
+a batch boundary), keys without a 32-bit image arriving late (they keep taking the spill list)."""
+import numpy as np
+import pyarrow as pa
+import pytest
+
+import oracle
+from datafusion_archive_amd import execution as ex
+from datafusion_archive_amd.logicalplan import AggregateFunction, BinaryExpr, Column, DataType, Literal, Operator, ScalarValue
+from gpu_util import assert_groups_identical, gpu_aggregate
+from test_gpu_scale import _assert_bit_exact
+
+pytestmark = pytest.mark.gpu
+
+F64, I64, U64 = DataType.Float64, DataType.Int64, DataType.UInt64
+N = (1 << 23) + 12345  # three batches, the last one ragged
+BATCH = (1 << 22) - 64   # > 2^21 rows: the first batch's calibration slice decides the strategy
+GROUPS = 200000.0
+SEED = 0xDF06
+
+
+def f64(v):
+    return Literal(ScalarValue.Float64(v))
+
+
+def AND(a, b):
+    return BinaryExpr(a, Operator.And, b)
+
+
+HEAD = AND(BinaryExpr(Column(1), Operator.Gt, f64(204.8)), BinaryExpr(Column(1), Operator.Lt, f64(409.6)))
+SUM_V = AggregateFunction("SUM", [Column(1)], F64)
+MIN_V = AggregateFunction("MIN", [Column(1)], F64)
+COUNT_V = AggregateFunction("COUNT", [Column(1)], U64)
+SUM_W = AggregateFunction("SUM", [Column(2)], I64)
+MIN_W = AggregateFunction("MIN", [Column(2)], I64)
+MAX_W = AggregateFunction("MAX", [Column(2)], I64)
+COUNT_W = AggregateFunction("COUNT", [Column(2)], U64)
+
+
+def _syn(key_kind=None, groups=GROUPS, k_nulls=0, v_nulls=0, w_nulls=0):
+    key_kind = ex.SYNTH_I64_UNIFORM if key_kind is None else key_kind
+    return [("k", ex.synth_nulls(key_kind, k_nulls), 0, groups, 0.0), ("v", ex.synth_nulls(ex.SYNTH_F64_EXACT, v_nulls), 1, 0.0, 0.0),
+            ("w", ex.synth_nulls(ex.SYNTH_I64_UNIFORM, w_nulls), 2, 1000.0, 0.0)]
+
+
+def _schema(syn):
+    t = {ex.SYNTH_I64_UNIFORM: pa.int64(), ex.SYNTH_I64_ZIPF: pa.int64(), ex.SYNTH_I32_UNIFORM: pa.int32()}
+    return pa.schema([(c[0], t.get(c[1] & 0xFF, pa.float64())) for c in syn])
+
+
+@pytest.fixture(autouse=True)
+def _defaults():
+    ex.set_option("agg.pair_scan", 1)
+    yield
+    for k, v in (("agg.pair_scan", 1), ("agg.partition_cap_rows", 0), ("agg.capacity_log2", 0)):
+        ex.set_option(k, v)
+
+
+def _both_ways(name, syn, pred, aggs, n=N, batch=BATCH, opts=(), expect_pair=True, expect_fallback=False):
+    _s, _kept, want = oracle.run_synth_query(syn, SEED, 0, n, 1024, pred, [Column(0)], aggs)
+    for k, v in opts:
+        ex.set_option(k, v)
+    for pair in (1, 0):
+        ex.set_option("agg.pair_scan", pair)
+        before = ex.counter_get("agg_pair_launches"), ex.counter_get("agg_pair_fallbacks")
+        t = ex.DeviceTable.synth(syn, SEED, 0, n)
+        got = gpu_aggregate([Column(0)], aggs, _schema(syn), [], filter_expr=pred, source=t.scan(batch))
+        _assert_bit_exact(got, want, f"{name} (agg.pair_scan = {pair})")
+        launched = ex.counter_get("agg_pair_launches") - before[0]
+        fell_back = ex.counter_get("agg_pair_fallbacks") - before[1]
+        if pair and expect_pair:
+            assert launched > 0, f"{name}: the pair scan did not run"
+            assert (fell_back > 0) == expect_fallback, f"{name}: fall-backs {fell_back}"
+        if not pair:
+            assert launched == 0 and fell_back == 0
+
+
+CASES = {
+    "sum_f64_min_i64": (_syn(), HEAD, [SUM_V, MIN_W]),
+    "min_i64_sum_f64": (_syn(), HEAD, [MIN_W, SUM_V]),           # the planes the other way round
+    "min_f64_sum_i64": (_syn(), HEAD, [MIN_V, SUM_W]),
+    "count_v_max_w": (_syn(), HEAD, [COUNT_V, MAX_W]),
+    "sum_f64_count_w_no_predicate": (_syn(), None, [SUM_V, COUNT_W]),  # every row routed
+    "nulls_in_operand_w": (_syn(w_nulls=3), HEAD, [SUM_V, MAX_W]),
+    "nulls_in_predicate_column_v": (_syn(v_nulls=3), HEAD, [SUM_W, MIN_V]),
+    "nulls_in_key": (_syn(k_nulls=5), HEAD, [SUM_V, MIN_W]),
+    "nulls_no_predicate_counts": (_syn(v_nulls=3, w_nulls=4), None, [COUNT_V, COUNT_W]),
+    "int32_key": (_syn(ex.SYNTH_I32_UNIFORM), HEAD, [SUM_V, MIN_W]),
+}
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_pair_scan_matches_oracle_and_the_per_aggregate_scans(name):
+    syn, pred, aggs = CASES[name]
+    _both_ways(name, syn, pred, aggs)
+
+
+def test_pair_scan_region_overflow_goes_through_the_two_plane_spill_list():
+    """Zipf keys and regions of 120 row slots: most of a hot key's rows overflow their region and take the spill list with BOTH
+    operands; the replay applies them to the two-plane table."""
+    syn = _syn(ex.SYNTH_I64_ZIPF, groups=200000.0)
+    _both_ways("zipf, tiny regions", syn, HEAD, [SUM_V, MAX_W], opts=(("agg.partition_cap_rows", 100),))
+    ex.set_option("agg.partition_cap_rows", 0)
+    _both_ways("zipf", syn, HEAD, [SUM_V, MAX_W])
+
+
+def test_pair_scan_falls_back_when_the_table_outgrows_its_partitions():
+    """3 * 10^6 uniform keys: the table grows to 2^23 slots = 1024 blocks of 8192; the pair kernels route to at most 256.  The rows of
+    the batch in hand go through the global table, the next batch starts the per-aggregate scans (agg_pair_fallbacks)."""
+    syn = _syn(groups=3000000.0)
+    _both_ways("table outgrows the pair kernels", syn, None, [SUM_V, MIN_W], n=(1 << 24) + 999, batch=(1 << 22) - 64, expect_fallback=True)
+
+
+def test_pair_scan_keeps_going_when_wide_keys_arrive_late():
+    rng = np.random.default_rng(6)
+    per = (1 << 21) + 4096  # > 2^21 rows in the first batch: the calibration slice sees narrow keys only
+    m = 3 * per
+    k = rng.integers(0, 300000, m).astype(np.int64)
+    k[2 * per + 5::1013] += 1 << 40
+    k[2 * per + 9::2027] = -k[2 * per + 9::2027] - 1
+    v = rng.integers(0, 1 << 20, m).astype(np.float64) / 1024.0
+    w = rng.integers(0, 1000, m).astype(np.int64)
+    whole = pa.RecordBatch.from_arrays([pa.array(k), pa.array(v), pa.array(w)], names=["k", "v", "w"])
+    batches = [whole.slice(i * per, per) for i in range(3)]
+    aggs = [SUM_V, MIN_W]
+    want = oracle.aggregate([Column(0)], aggs, [oracle.filter_next(HEAD, b) for b in batches])
+    for pair in (1, 0):
+        ex.set_option("agg.pair_scan", pair)
+        before = ex.counter_get("agg_pair_launches")
+        got = gpu_aggregate([Column(0)], aggs, whole.schema, batches, filter_expr=HEAD)
+        assert_groups_identical(got, want, 1, f"late wide keys, agg.pair_scan = {pair}")
+        assert (ex.counter_get("agg_pair_launches") - before > 0) == bool(pair)

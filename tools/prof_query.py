@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Runs one workload a few times (no CPU baseline): the target of rocprofv3 runs.
-usage: prof_query.py <headline|cfg3|cfg2|q1|neighbour|oneterm|threeterm|threecol|diffop|product> [rows] [iters] [option=value ...]
+usage: prof_query.py <headline|selNN|cfg3|cfg2|q1|neighbour|oneterm|threeterm|threecol|diffop|product> [rows] [iters] [option=value ...]
 (neighbour: SELECT k, SUM(v), MIN(v) WHERE v >= lo AND v < hi GROUP BY k -- two aggregates of one operand;
  oneterm: SELECT k, SUM(v) WHERE v < 204.8 GROUP BY k; threecol: SELECT k, SUM(w) WHERE v > lo AND v < hi GROUP BY k;
  product: SELECT k, SUM(v * 2.0) WHERE v > lo AND v < hi GROUP BY k -- shapes without a static signature: FastPolicy)"""
@@ -76,6 +76,9 @@ else:
         bytes_per_row = 24
     if wl == "product":
         aggs = [AggregateFunction("SUM", [BinaryExpr(Column(1), Operator.Multiply, lit(2.0))], f64)]
+    if wl.startswith("sel"):  # sel50 / sel80 / sel35 ...: the headline query keeping that share of the rows (v is uniform on [0, 1024))
+        pred = BinaryExpr(BinaryExpr(Column(1), Operator.Gt, lit(204.8)), Operator.And,
+                          BinaryExpr(Column(1), Operator.Lt, lit(204.8 + 10.24 * float(wl[3:]))))
     if wl == "cfg3":
         pred = None
     if wl == "cfg2":
