@@ -809,7 +809,7 @@ static bool launch_partition_plan(const DevProgram& P, const DevFastPlan& fast, 
       {launch_partition_variant11, launch_partition_variant15, launch_partition_variant16, launch_partition_variant12,
        launch_partition_variant19, launch_partition_variant15, launch_partition_variant20, launch_partition_variant12}};
   if (!one_value && (fp.scan.gen & 4)) return false;  // (cannot happen: bind_scan_plan gives bit 2 to fixed-slot bindings only)
-  if (pair && fp.scan.n_cols != 3) return false;      // (the pair kernels exist for key + two operand columns: variants 21-24)
+  if (pair && fp.scan.n_cols != 3 && fp.scan.n_cols != 4) return false;  // (the pair kernels: key + two operand columns, and one more predicate column -- variants 21-24, 11 / 15 / 16 / 12)
   by_need[fp.scan.n_cols <= 2 ? 0 : fp.scan.n_cols == 3 ? 1 : 2][fp.scan.gen & 7](P, fp, cp, plan, T, PT, spill, n, lds_bytes, s);
   return true;
 }
@@ -820,7 +820,7 @@ bool partition_pair_supported(const DevProgram& P, const DevFastPlan& fast, cons
   DevFastPlan fp;
   DevColumns cp;
   if (!bind_scan_plan(P, fast, C, 1, 2, T.val_xform, false, &fp, &cp)) return false;
-  return fp.scan.n_cols == 3 && !(fp.scan.gen & 4);
+  return (fp.scan.n_cols == 3 || fp.scan.n_cols == 4) && !(fp.scan.gen & 4);
 }
 
 hipError_t launch_partition(const DevProgram& P, const DevFastPlan& fast, const DevColumns& C, const DevAggPlan& plan,

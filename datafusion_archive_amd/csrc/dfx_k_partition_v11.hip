@@ -2,5 +2,6 @@
 // value images, plan words in vector registers), <= 4 columns, GENK = 0 (8-byte-null-free: bit 0 4-byte columns widened, bit 1 validity bitmaps).
 #include "dfx_k_partition_ws_inl.hpp"
 namespace dfx {
-DFX_PARTITION_VARIANT_WS(11, DFX_ARG(PlanPolicyN<4, 1, 0>), DFX_ARG(PlanPolicyN<4, 1, 0>), DFX_ARG(PlanPolicy1<4, 1, 0>), DFX_ARG(PlanPolicy1<4, 2, 0>), DFX_ARG(PlanPolicy1<4, 2, 0>))
+// (+ the PAIR flavour: two aggregates of different operands routed by ONE scan -- PTF_PAIR, dfx_device.hpp)
+DFX_PARTITION_VARIANT_WS_PAIR(11, DFX_ARG(PlanPolicyN<4, 1, 0>), DFX_ARG(PlanPolicyN<4, 1, 0>), DFX_ARG(PlanPolicy1<4, 1, 0>), DFX_ARG(PlanPolicy1<4, 2, 0>), DFX_ARG(PlanPolicy1<4, 2, 0>), DFX_ARG(PlanPolicyN<4, 2, 0>))
 }  // namespace dfx

@@ -92,6 +92,9 @@ CASES = {
     "nulls_in_key": (_syn(k_nulls=5), HEAD, [SUM_V, MIN_W]),
     "nulls_no_predicate_counts": (_syn(v_nulls=3, w_nulls=4), None, [COUNT_V, COUNT_W]),
     "int32_key": (_syn(ex.SYNTH_I32_UNIFORM), HEAD, [SUM_V, MIN_W]),
+    # a fourth plan column: the predicate is on x, neither operand
+    "predicate_on_a_fourth_column": (_syn() + [("x", ex.SYNTH_F64_UNIFORM, 3, 0.0, 1.0)], BinaryExpr(Column(3), Operator.Lt, f64(0.3)), [SUM_V, MAX_W]),
+    "fourth_column_with_nulls": (_syn(w_nulls=2) + [("x", ex.synth_nulls(ex.SYNTH_F64_UNIFORM, 3), 3, 0.0, 1.0)], BinaryExpr(Column(3), Operator.Lt, f64(0.3)), [MIN_V, SUM_W]),
 }
 
 

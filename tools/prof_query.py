@@ -100,6 +100,7 @@ def run():
 
 run()
 ex.synchronize()
+ex.counter_reset()
 ex.profile_reset()
 ex.profile_enable(os.environ.get('NOPROF') != '1')
 t0 = time.perf_counter()
@@ -110,5 +111,6 @@ dt = (time.perf_counter() - t0) / iters
 ex.profile_enable(False)
 prof = " ".join(f"{p['kernel']}:{p['launches'] // iters}x{p['total_ms'] / iters:.3f}ms" for p in ex.profile_snapshot()
                 if p["total_ms"] / iters > 0.02)
+print("   host us/iter: " + " ".join(f"{c[4:-3]}:{ex.counter_get(c) / iters:.0f}" for c in ("agg_drain_us", "agg_emit_us", "agg_ctrl_wait_us", "agg_sync_us", "agg_alloc_us")))
 print(f"   kernels/iter: {prof}")
 print(f"{wl}: rows={rows} {dt*1e3:.3f} ms/iter  {rows/dt/1e9:.2f} Grows/s  {rows*bytes_per_row/dt/1e9:.1f} GB/s  groups={out.num_rows}")
