@@ -91,7 +91,13 @@ struct AggregateRelation::Impl {
   // runs once per accumulator plane over the same regions, each launch the one-value kernel with its 96 KB block.  16 + 24 bytes read
   // per row become 24.  `single_chunks` stays in reserve: the stream falls back to it at a batch boundary when the pair kernels no
   // longer apply (the table outgrew 256 partitions, a batch the plan cannot bind).
+  // The same host logic serves 2..3 aggregates of ONE operand (split_is_shared; PTF_PLANES, agg.shared_planes): the raw operand goes
+  // through the one-value pass 1 exactly as the headline's does, pass 2 runs once per accumulator plane with that aggregate's
+  // transform.  Rounds 3-6 gave such queries 4096-slot blocks holding every plane (twice the partitions, 8-row chunks of 96 bytes).
   bool pair_mode = false;
+  bool pair_is_planes = false;   // pair_mode: the shared-operand flavour
+  bool split_is_shared = false;  // the aggregates single_chunks splits all take the same operand
+  bool split_applies() const { return split_ready && opt().split_aggregates && (!split_is_shared || opt().shared_planes); }
   bool pair_batch_ok(const DeviceBatch& b);
   Status pair_fall_back();
   bool split_ready = false;     // single_chunks is built (used if agg.split_aggregates allows it when the operator runs)
@@ -383,7 +389,7 @@ Status AggregateRelation::Impl::setup(const SchemaInfo& input_schema) {
   }
   // one key, two or more aggregates that do not all take the same operand: the per-aggregate chunking for the partitioned
   // strategy (see single_chunks).  Built now so that a shape the one-aggregate programs cannot take shows up here, not mid-stream.
-  if (kw == 1 && kw_out == 1 && na_total >= 2 && chunks.size() == 1 && !shared_operand()) {  // (agg.split_aggregates is read when the operator runs: options freeze at first use)
+  if (kw == 1 && kw_out == 1 && na_total >= 2 && chunks.size() == 1) {  // (agg.split_aggregates / agg.shared_planes are read when the operator runs: options freeze at first use)
     std::vector<Chunk> singles;
     bool ok = true;
     for (int a = 0; a < na_total && ok; ++a) {
@@ -396,6 +402,11 @@ Status AggregateRelation::Impl::setup(const SchemaInfo& input_schema) {
     if (ok) {
       single_chunks = std::move(singles);
       split_ready = true;
+      {  // (shared_operand() without the option: options are not frozen yet)
+        split_is_shared = na >= 2 && na <= 3;
+        for (int a = 1; a < na; ++a)
+          if (plan.arg[a] != plan.arg[0]) split_is_shared = false;
+      }
     }
   }
   return Status::OK();
@@ -637,7 +648,7 @@ Status AggregateRelation::Impl::alloc_table(int cap_log2, DevTable* Tn, std::vec
   {  // probing block = what one workgroup can hold in 128 KB of LDS (keys + the accumulators of the widest chunk)
     int widest = 1;
     for (const Chunk& ch : chunks) widest = std::max(widest, ch.n);
-    if (split_ready && opt().split_aggregates) widest = 1;  // (the partitioned strategy will run one accumulator per scan: blocks of 8192 slots, 256 partitions)
+    if (split_applies()) widest = 1;  // (the partitioned strategy will run one accumulator per scan: blocks of 8192 slots, 256 partitions)
     uint64_t blk = 16384 / (uint64_t)(std::max(kw, 1) + widest);  // 128 KB of LDS per block (pass 2: one workgroup per CU)
     uint64_t p2 = 64;
     while (p2 * 2 <= blk) p2 *= 2;
@@ -713,18 +724,22 @@ bool AggregateRelation::Impl::shared_operand() const {
 
 Status AggregateRelation::Impl::ensure_partition(int64_t rows, bool nulls_now) {
   const uint64_t S = (uint64_t)T.block_mask + 1;
-  const bool want_shared = narrow && opt().narrow_keys != 0 && !nulls_now && shared_operand() &&
+  const bool want_planes = pair_mode && pair_is_planes && narrow && opt().narrow_keys != 0 && !nulls_now && shared_operand() && kNarrowLine && opt().narrow_chunk16 &&
+                           opt().pass1_ws > 0 && opt().partition_layout != 2 && ((uint32_t)opt().partition_mode & 0x8Fu) == 2u &&
+                           partition_ws_bytes((uint32_t)((T.mask + 1) / S), 4, 1) <= (size_t)158 * 1024;
+  const bool want_shared = !pair_mode && narrow && opt().narrow_keys != 0 && !nulls_now && shared_operand() &&
                            ((uint32_t)opt().partition_mode & 0x8Fu) == 2u &&
                            partition_ring_bytes(2, (uint32_t)((T.mask + 1) / S), 16, false, true, 128) <= (size_t)158 * 1024;
-  const bool want_pair = pair_mode && !want_shared && narrow && kw == 1 && na == 2 && kNarrowLine && opt().narrow_keys != 0 && opt().narrow_chunk16 &&
+  const bool want_pair = pair_mode && !pair_is_planes && !want_shared && narrow && kw == 1 && na == 2 && kNarrowLine && opt().narrow_keys != 0 && opt().narrow_chunk16 &&
                          opt().pass1_ws > 0 && opt().partition_layout != 2 && ((uint32_t)opt().partition_mode & 0x8Fu) == 2u &&
                          partition_ws_bytes((uint32_t)((T.mask + 1) / S), 8, 2) <= (size_t)158 * 1024;
-  if (pair_mode && !want_pair)  // (a table block holds ONE accumulator plane in this mode: no other routed form fits; until the
+  if (pair_mode && !want_pair && !want_planes)  // (a table block holds ONE accumulator plane in this mode: no other routed form fits; until the
     return Status::Err(DFX_NOT_IMPLEMENTED, "pair scan: not for this table");  // next batch boundary the rows go through the global table)
-  const bool want_narrow = narrow && kw == 1 && (na == 1 || want_shared || want_pair) && opt().narrow_keys != 0;
-  const uint32_t n_words = want_shared ? 2u : (uint32_t)(kw + na);
+  const bool want_narrow = narrow && kw == 1 && (na == 1 || want_shared || want_pair || want_planes) && opt().narrow_keys != 0;
+  const uint32_t n_words = (want_shared || want_planes) ? 2u : (uint32_t)(kw + na);
   if (pt_layout_valid && rows <= pt_layout_rows && PT.n_parts == (uint32_t)((T.mask + 1) / S) && PT.n_words == n_words &&
-      ((PT.flags & PTF_NARROW) != 0) == want_narrow && ((PT.flags & PTF_SHARED) != 0) == want_shared && ((PT.flags & PTF_PAIR) != 0) == want_pair)
+      ((PT.flags & PTF_NARROW) != 0) == want_narrow && ((PT.flags & PTF_SHARED) != 0) == (want_shared || want_planes) && ((PT.flags & PTF_PAIR) != 0) == want_pair &&
+      ((PT.flags & PTF_PLANES) != 0) == want_planes)
     return Status::OK();  // same table, a batch the regions were sized for: keep appending
   DFX_RETURN_IF_ERROR(flush_pass2());  // rows routed under the old layout
   pt_layout_valid = false;
@@ -748,6 +763,14 @@ Status AggregateRelation::Impl::ensure_partition(int64_t rows, bool nulls_now) {
   const int want = o.partition_mode & 15;
   if (want_shared) {
     PT.flags |= PTF_NARROW | PTF_SHARED;
+    PT.mode = 2u;
+    PT.block = 1024;
+    PT.stage_rows = 0;
+    PT.n_producers = (uint32_t)std::min(1024, device_cu_count());
+    if (o.partition_producers > 0) PT.n_producers = (uint32_t)std::min(1024, o.partition_producers);
+  } else if (want_planes) {
+    PT.flags |= PTF_NARROW | PTF_CHUNK16 | PTF_WS | PTF_SHARED | PTF_PLANES;
+    PT.ws_scanners = (o.pass1_ws == 4 || (mostly_seen && o.pass1_ws_dense_scanners == 4)) ? 4u : 8u;  // (as for one aggregate)
     PT.mode = 2u;
     PT.block = 1024;
     PT.stage_rows = 0;
@@ -1095,7 +1118,7 @@ Status AggregateRelation::Impl::launch_rows(const DeviceBatch& b, const DevProgr
   DevAggPlan p = plan;
   // (while the per-aggregate chunking is pending -- the table's blocks are sized for one accumulator per scan -- the all-aggregates
   // program never takes the partitioned strategy: its pass 2 would not fit a block into LDS)
-  bool partition_now = use_partition && (pair_mode || !(split_ready && !split_done && opt().split_aggregates));
+  bool partition_now = use_partition && (pair_mode || !(split_applies() && !split_done));
   if (partition_now) {
     Status pst = ensure_partition(launch_rows_hint > 0 ? std::max<int64_t>(n, std::min<int64_t>(launch_rows_hint, b.num_rows)) : std::max<int64_t>(n, b.num_rows), prog.has_nulls != 0);  // (the slice after the calibration rows: size for the whole batch)
     if (!pst.ok() && pst.code == DFX_NOT_IMPLEMENTED) partition_now = false;  // global-atomic path instead
@@ -1132,6 +1155,7 @@ Status AggregateRelation::Impl::launch_rows(const DeviceBatch& b, const DevProgr
     DFX_HIP(launch_partition(prog, fpp, cols, p, T, pt, spill, n, bytes, s));
     if (pt.flags & PTF_SHARED) ++counters().agg_shared_operand_launches;
     if (pt.flags & PTF_PAIR) ++counters().agg_pair_launches;
+    if (pt.flags & PTF_PLANES) ++counters().agg_plane_launches;
     ++pt_pending;
     pt_fill_bound += pt_worst;
     pt_rows_in_flight += n;
@@ -1282,7 +1306,7 @@ Status AggregateRelation::Impl::consume_batch_chunk(const DeviceBatch& b) {
   // two batches can be in flight unchecked; with a deferred pass 2 every row of the window may still be spilled (by pass 2
   // itself, when its block is full)
   // (pair scan: a row whose key finds no slot in its block is spilled by BOTH planes' pass 2)
-  const int64_t window_rows = use_partition ? (int64_t)std::max(1, opt().partition_defer_batches) * std::max(n, pt_layout_rows) * (pair_mode ? 2 : 1) : 0;
+  const int64_t window_rows = use_partition ? (int64_t)std::max(1, opt().partition_defer_batches) * std::max(n, pt_layout_rows) * (pair_mode ? na : 1) : 0;
   if (may_spill) DFX_RETURN_IF_ERROR(ensure_spill(2 * n + window_rows + 65536));
   T.max_probe = may_spill ? 128 : (int)std::min<uint64_t>(T.mask + 1, 1u << 30);
   int64_t row0 = 0;
@@ -1413,7 +1437,7 @@ static DeviceBatch rows_from(const DeviceBatch& b, int64_t row0) {  // rows [row
 }
 
 Status AggregateRelation::Impl::consume_batch(const DeviceBatch& b) {
-  if (split_ready && !split_done && !split_decided && opt().split_aggregates) {
+  if (split_applies() && !split_done && !split_decided) {
     // The strategy decision first (calibration slice, the resident table's memo, a forced strategy), with the all-aggregates
     // program and nothing else of the batch; if it says "partitioned", the per-aggregate chunking takes over from there.
     const bool forced = opt().strategy == 3;  // (no decision to wait for: the chunk loop below turns the strategy on itself)
@@ -1433,7 +1457,7 @@ Status AggregateRelation::Impl::consume_batch(const DeviceBatch& b) {
     if (split_decided && (use_partition || forced)) {
       DFX_RETURN_IF_ERROR(flush_pass2());
       DFX_RETURN_IF_ERROR(settle_ctrl());
-      if (opt().pair_scan && use_partition && pair_batch_ok(b)) {
+      if ((split_is_shared ? opt().shared_planes : opt().pair_scan) && use_partition && pair_batch_ok(b)) {
         pair_mode = true;  // the all-aggregates program goes on: one scan for both operands (single_chunks stays in reserve)
       } else {
         install_chunks(std::move(single_chunks));
@@ -1480,20 +1504,26 @@ bool AggregateRelation::Impl::pair_batch_ok(const DeviceBatch& b) {
     if (dbg) fprintf(stderr, "[dfx] pair scan: no (%s)\n", why);
     return false;
   };
-  if (!kNarrowLine || !narrow || kw != 1 || na != 2 || chunks.size() != 1 || single_chunks.size() != 2 || !dicts.empty()) return no("shape");
-  if (single_chunks[0].n != 1 || single_chunks[1].n != 1 || unfused_now) return no("chunks");
+  if (!kNarrowLine || !narrow || kw != 1 || chunks.size() != 1 || (int)single_chunks.size() != na || !dicts.empty() || unfused_now) return no("shape");
+  if (split_is_shared ? !(na >= 2 && na <= 3 && shared_operand()) : na != 2) return no("aggregates");
   const AggOptions& o = opt();
-  if (!o.plan || !o.fast || o.narrow_keys == 0 || !o.narrow_chunk16 || o.pass1_ws <= 0 || o.partition_layout == 2 || ((uint32_t)o.partition_mode & 0x8Fu) != 2u) return no("options");
-  if (!scan_plan_shape_ok(builder->program(), fast, kw, na, val_xform)) return no("scan plan shape");  // (also: a predicate over nulls stays fused, consume_batch_chunk)
+  if ((!split_is_shared && (!o.plan || !o.fast)) || o.narrow_keys == 0 || !o.narrow_chunk16 || o.pass1_ws <= 0 || o.partition_layout == 2 || ((uint32_t)o.partition_mode & 0x8Fu) != 2u) return no("options");
+  if (!split_is_shared && !scan_plan_shape_ok(builder->program(), fast, kw, na, val_xform)) return no("scan plan shape");  // (also: a predicate over nulls stays fused, consume_batch_chunk)
   const uint64_t S = (uint64_t)T.block_mask + 1;
-  if (S != 8192 || partition_ws_bytes((uint32_t)((T.mask + 1) / S), 8, 2) > (size_t)158 * 1024) return no("table blocks");
+  if (S != 8192 || partition_ws_bytes((uint32_t)((T.mask + 1) / S), split_is_shared ? 4 : 8, split_is_shared ? 1 : 2) > (size_t)158 * 1024) return no("table blocks");
+  pair_is_planes = split_is_shared;
   if (b.num_rows <= 0) return true;
   DevProgram prog;
   DevColumns cols;
   if (!builder->bind(b, &prog, &cols).ok()) return no("bind");
   DevFastPlan fp = fast;
+  if (!o.fast) fp.valid = 0;
   fp.plan_mode = o.plan;
-  if (!partition_pair_supported(prog, fp, cols, T)) return no("plan binding");
+  if (split_is_shared) {  // the raw operand through the one-value kernels: a null-free batch, a signature or the plan's fixed-slot binding
+    if (!partition_planes_supported(prog, fp, cols, T)) return no("one-value binding of the shared operand");
+  } else if (!partition_pair_supported(prog, fp, cols, T)) {
+    return no("plan binding");
+  }
   return true;
 }
 
@@ -2134,8 +2164,10 @@ void AggregateRelation::explain(std::string* out, int depth) const {
     else text += ", strategy chosen on the first 2^18 rows: register accumulators (<= 8 groups) / LDS front cache (<= 8192) / table";
     if (m.shared_operand())
       text += strfmt("; %d aggregates of ONE operand: the partitioned strategy routes 12-byte rows {hash image, raw operand} while keys are "
-                     "narrow and batches have no nulls, pass 2 applies every aggregate to it", m.na);
-    if (m.split_ready && !m.split_done)
+                     "narrow and batches have no nulls; pass 2 runs once per accumulator plane with that aggregate's transform "
+                     "(agg.shared_planes; 0: one pass 2 over 4096-slot blocks that hold every plane)", m.na);
+    if (m.pair_mode) text += m.pair_is_planes ? "; ran the one-value pass 1 with a pass 2 per accumulator plane" : "; ran the pair scan (both operands routed by one scan, a pass 2 per accumulator plane: agg.pair_scan)";
+    if (m.split_ready && !m.split_done && !m.split_is_shared)
       text += strfmt("; %d aggregates of different operands: if the calibration slice chooses the partitioned strategy, one scan per "
                      "aggregate (its own fused program and accumulator plane over the same keys: 12-byte routed rows, the one-aggregate "
                      "kernels; agg.split_aggregates)", m.na_total);

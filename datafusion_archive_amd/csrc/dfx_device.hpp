@@ -277,7 +277,7 @@ struct DevPartition {
   uint32_t block;      // pass-1 workgroup size (mode 1: 512 or 1024)
   uint32_t flags;      // PTF_*
   uint32_t ws_scanners;// PTF_WS: scanner waves of the 16: 8 (+ 8 routers: selective scans) or 4 (+ 12 routers: dense scans)
-  uint32_t pair_plane; // PTF_PAIR, pass 2: the operand / accumulator plane (0 or 1) this launch aggregates
+  uint32_t pair_plane; // PTF_PAIR / PTF_PLANES, pass 2: the accumulator plane this launch aggregates (PTF_PAIR: and the operand, 0 or 1)
   // Control-block snapshot written BY THE KERNEL (null: none): the last workgroup to finish copies T.ctrl into this
   // host-mapped pinned buffer.  The host reads it after the launch's completion event -- no copy engine, no blit kernel
   // that would have to find room next to 256 persistent 1024-lane workgroups, nothing on a side stream.
@@ -295,6 +295,9 @@ enum : uint32_t {
                           // LINE chunks, ten 12-byte rows + 8 bytes of padding = ONE whole 128-byte line per chunk, three-slot rings
   PTF_WS = 64u,           // pass 1, wave-specialised flavour (dfx_k_partition_ws_inl.hpp): DevPartition::ws_scanners of the 16 waves scan,
                           // the others route; needs PTF_NARROW | PTF_CHUNK16, no PTF_HOT / PTF_SHARED
+  PTF_PLANES = 256u,      // with PTF_SHARED | PTF_NARROW | PTF_CHUNK16 | PTF_WS: the aggregates' common RAW operand travels through the one-value
+                          // pass 1 (LINE chunks, table blocks of 8192 slots) and pass 2 runs once per accumulator plane, applying that
+                          // aggregate's transform to the operand (DevPartition::pair_plane) -- instead of 4096-slot blocks with every plane
   PTF_PAIR = 128u,        // with PTF_NARROW | PTF_CHUNK16 | PTF_WS (LINE chunks only): TWO aggregates of DIFFERENT operands, one scan -- routed
                           // rows are 20 bytes {operand 0, hash image, operand 1} (kPair* below), pass 2 runs once per accumulator plane
                           // (DevPartition::pair_plane) over the same regions: each launch is the one-value kernel with its 96 KB block

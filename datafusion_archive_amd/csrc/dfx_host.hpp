@@ -132,6 +132,7 @@ struct Counters {
   long long agg_early_keys_late = 0;        // ... copies that had not arrived when emit asked (a stalled copy engine): retired, not waited for
   long long agg_emit_reused_early = 0;     // ... and emits that also reused its occupancy mask, tile offsets and device key column
   long long agg_pass2_launches = 0;
+  long long agg_plane_launches = 0;   // pass-1 launches whose pass 2 runs once per accumulator plane of a shared operand (PTF_PLANES)
   long long agg_pair_launches = 0;    // pass-1 launches that routed two operands per row (PTF_PAIR)
   long long agg_pair_fallbacks = 0;   // streams that left the pair scan for one scan per aggregate (the table outgrew the pair kernels' partitions, a batch the plan cannot bind)
   long long agg_growths = 0;

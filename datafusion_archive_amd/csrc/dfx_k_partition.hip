@@ -430,8 +430,13 @@ __global__ __launch_bounds__(kABlock) __attribute__((amdgpu_num_vgpr(kP2Vgprs)))
   // PTF_PAIR (two aggregates of different operands, 20-byte routed rows): this launch aggregates operand / accumulator plane
   // PT.pair_plane -- the block holds the tags and THAT plane, the row's other operand is not even loaded.  NARROW == 2: the
   // twelve bytes a lane reads are {operand lo, operand hi, image} (plane 0); plane 1 reads {image, operand} like any narrow row.
-  const bool pair = NARROW != 0 && !MULTI && (PT.flags & PTF_PAIR) != 0;
-  const uint32_t plane = pair ? PT.pair_plane : 0u;
+  // PTF_PLANES (NARROW == 3: aggregates of ONE operand, one launch per accumulator plane): ordinary narrow rows {image, RAW operand};
+  // this launch applies plane PT.pair_plane's transform to the operand and aggregates into that plane.
+  const bool pair = NARROW != 0 && NARROW != 3 && !MULTI && (PT.flags & PTF_PAIR) != 0;
+  constexpr bool PLANES = NARROW == 3;
+  const uint32_t plane = (pair || PLANES) ? PT.pair_plane : 0u;
+  const uint32_t last_plane = pair ? 1u : PLANES ? (uint32_t)T.na - 1u : 0u;
+  const uint8_t plane_xf = PLANES ? T.val_xform[plane < (uint32_t)kMaxAggs ? plane : 0u] : (uint8_t)VT_RAW;
   uint64_t* const t_accs = T.accs + (uint64_t)plane * T.stride;
   // wide: keys[S] accs[S]; narrow: accs[NA][S] tags[S]
   uint64_t* lkeys = lds;
@@ -544,6 +549,7 @@ __global__ __launch_bounds__(kABlock) __attribute__((amdgpu_num_vgpr(kP2Vgprs)))
       q.home4 = (uint32_t)(r.z >> tag_shift) & mask4;
     } else if (NARROW) {
       q.val = ((uint64_t)r.z << 32) | r.y;
+      if constexpr (PLANES) q.val = transform_value(plane_xf, q.val, true);
       q.img = r.x;
       q.kk = 0;
       q.real = inb && r.x != kTagEmpty;
@@ -613,7 +619,7 @@ __global__ __launch_bounds__(kABlock) __attribute__((amdgpu_num_vgpr(kP2Vgprs)))
 #pragma unroll
       for (int j = 0; j < kMaxAggs; ++j)  // (PTF_PAIR: T is the two-plane view -- the other plane's launch brings that operand, here its identity)
         sv[j] = MULTI ? ((uint32_t)j < NA ? transform_value(T.val_xform[j], val, true) : 0ull)
-                : pair ? ((uint32_t)j == plane ? val : (j < 2 ? T.acc_init[j] : 0ull)) : (j == 0 ? val : 0ull);
+                : (pair || PLANES) ? ((uint32_t)j == plane ? val : (j < T.na ? T.acc_init[j] : 0ull)) : (j == 0 ? val : 0ull);
       spill_row<1>(T, spill, todo, key, sv);
     }
   };
@@ -697,7 +703,7 @@ __global__ __launch_bounds__(kABlock) __attribute__((amdgpu_num_vgpr(kP2Vgprs)))
 #pragma unroll
   for (int mm = 32; mm >= 1; mm >>= 1) new_keys += __shfl_xor(new_keys, mm, 64);
   if (lane == 0 && new_keys) atomicAdd(&T.ctrl[CTRL_OCCUPIED], new_keys);
-  if (pair && plane == 0u) return;  // (plane 1's launch reads the same regions: it is the one that ends the window)
+  if ((pair || PLANES) && plane != last_plane) return;  // (the last plane's launch reads the same regions: it is the one that ends the window)
   if (p == 0 && threadIdx.x == 0) __hip_atomic_store(&T.ctrl[CTRL_MAX_FILL], 0u, RLX_AGENT);  // the regions are empty again
   snapshot_ctrl_if_last(T, PT);
 }
@@ -823,6 +829,19 @@ bool partition_pair_supported(const DevProgram& P, const DevFastPlan& fast, cons
   return (fp.scan.n_cols == 3 || fp.scan.n_cols == 4) && !(fp.scan.gen & 4);
 }
 
+// PTF_PLANES: does THIS bound batch take the wave-specialised one-value pass 1 with the aggregates' common raw operand?
+// (a compile-time signature of the raw shape, or the scan plan's fixed-slot binding; host only, no launch)
+bool partition_planes_supported(const DevProgram& P, const DevFastPlan& fast, const DevColumns& C, const DevTable& T) {
+  if (!kNarrowLine || T.na < 2 || T.na > kSharedMaxAggs || T.kw != 1 || P.has_nulls) return false;
+  const uint8_t raw_kind0[1] = {SigKeySumPred2F64::acc(0)}, raw_kind1[1] = {SigKeySum::acc(0)}, raw_xf[kMaxAggs] = {VT_RAW};
+  if ((fast.plan_mode & 3) != 2 && (sig_matches<SigKeySumPred2F64>(P, fast, 1, 1, raw_kind0, raw_xf) || sig_matches<SigKeySum>(P, fast, 1, 1, raw_kind1, raw_xf) ||
+                                    sig_matches<SigKeyAffSumPred2F64>(P, fast, 1, 1, raw_kind0, raw_xf)))
+    return true;
+  DevFastPlan fp;
+  DevColumns cp;
+  return bind_scan_plan(P, fast, C, 1, 1, raw_xf, true, &fp, &cp);
+}
+
 hipError_t launch_partition(const DevProgram& P, const DevFastPlan& fast, const DevColumns& C, const DevAggPlan& plan,
                             const DevTable& T, const DevPartition& PT, const DevRows& spill, int64_t n,
                             double algo_bytes, hipStream_t s) {
@@ -857,6 +876,7 @@ hipError_t launch_partition(const DevProgram& P, const DevFastPlan& fast, const 
   // everything else the plan covers: any single MIN / MAX / COUNT / SUM, one to four terms over Int32 ... Float64 columns,
   // nullable columns -- same kernels, the query is data (the wave-specialised flavour included: its scan loop stays short)
   if (launch_partition_plan(P, fast, C, plan, T, PT, spill, n, lds_bytes, s)) return hipGetLastError();
+  if (PT.flags & PTF_PLANES) return hipErrorNotSupported;  // (the host asked partition_planes_supported first; the ring kernels below write another geometry)
   if (fast.plan_mode & 4) return hipErrorNotSupported;  // (the host fused a predicate over nulls counting on a plan)
   const bool use_fast = fast.valid && !P.has_nulls;
   // The wave-specialised flavour pays when the scan loop is short (compile-time signatures).  The run-time decoded shapes and
@@ -876,11 +896,21 @@ hipError_t launch_partition_agg(const DevTable& T, const DevPartition& PT, const
                                 hipStream_t s) {
   Scope sc(KID_PARTITION_AGG, s, algo_bytes);
   size_t lds_bytes = (size_t)(T.block_mask + 1) * (size_t)(1 + T.na) * 8 + (size_t)(PT.n_producers + 1) * 4 + 16;
-  if (((lds_bytes > 160 * 1024 - 256) && !(PT.flags & PTF_PAIR)) || PT.n_producers > 1024) return hipErrorInvalidValue;
-  if ((PT.flags & PTF_NARROW) && (PT.flags & PTF_SHARED)) {
+  if (((lds_bytes > 160 * 1024 - 256) && !(PT.flags & (PTF_PAIR | PTF_PLANES))) || PT.n_producers > 1024) return hipErrorInvalidValue;
+  if ((PT.flags & PTF_NARROW) && (PT.flags & PTF_SHARED) && !(PT.flags & PTF_PLANES)) {
     const size_t shared_lds = (size_t)(T.block_mask + 1) * (size_t)(4 + 8 * T.na) + (size_t)(kABlock / 64) * kP2RetryRows * 12;
     if (T.na < 2 || T.na > kSharedMaxAggs || T.kw != 1 || shared_lds > 160 * 1024 - 256) return hipErrorInvalidValue;
     hipLaunchKernelGGL((k_partition_agg_lean<1, -1>), dim3(PT.n_parts), dim3(kABlock), shared_lds, s, T, PT, spill);
+  } else if ((PT.flags & PTF_NARROW) && (PT.flags & PTF_SHARED) && (PT.flags & PTF_PLANES)) {
+    // aggregates of one operand, one launch of the one-value kernel per accumulator plane (the plane's own transform and atomic)
+    if (T.na < 2 || T.na > kSharedMaxAggs || T.kw != 1) return hipErrorInvalidValue;
+    const size_t plane_lds = (size_t)(T.block_mask + 1) * 12 + (size_t)(kABlock / 64) * kP2RetryRows * 12;
+    for (int a = 0; a < T.na; ++a) {
+      DevPartition Pa = PT;
+      Pa.pair_plane = (uint32_t)a;
+      if (a + 1 < T.na) Pa.snap_host = nullptr;
+      launch_agg_lean<3>(T, Pa, spill, plane_lds, s, a);
+    }
   } else if ((PT.flags & PTF_NARROW) && (PT.flags & PTF_PAIR)) {
     // two launches of the one-value kernel over the same regions, one per operand / accumulator plane; the first claims the
     // window's new keys, the second finds them, resets CTRL_MAX_FILL and publishes the control block

@@ -50,7 +50,7 @@ size_t partition_ws_bytes(uint32_t n_parts, int ns, int nv);
 // leave narrow mode, and the scan loop carries a few dozen instructions for them instead of the accumulator algebra
 // (sentinel_apply inlined four times per loop was 600 instructions and most of this kernel's scalar-register pressure).
 template <int NV = 1>
-DEV void ws_slow_rows(const DevTable& T, const DevRows& spill, bool slow, uint64_t key0, uint64_t val0, uint64_t val1 = 0) {
+DEV void ws_slow_rows(const DevTable& T, const DevPartition& PT, const DevRows& spill, bool slow, uint64_t key0, uint64_t val0, uint64_t val1 = 0) {
   if (__hip_atomic_load(&T.ctrl[CTRL_WIDE_KEYS], RLX_AGENT) == 0u) __hip_atomic_store(&T.ctrl[CTRL_WIDE_KEYS], 1u, RLX_AGENT);
   const uint64_t m = __ballot(slow);
   const int lane = lane_id();
@@ -60,10 +60,16 @@ DEV void ws_slow_rows(const DevTable& T, const DevRows& spill, bool slow, uint64
   base = __shfl(base, leader, 64);
   if (slow) {
     const uint64_t pos = base + (uint64_t)__popcll(m & ((1ull << lane) - 1ull));
-    if (pos < spill.capacity) {  // (one key word, one value -- two under PTF_PAIR: the only rows this kernel routes)
+    if (pos < spill.capacity) {  // (one key word, one value -- two under PTF_PAIR, one per aggregate under PTF_SHARED: the only rows this kernel routes)
       spill.words[pos] = key0;
-      spill.words[spill.capacity + pos] = val0;
-      if constexpr (NV == 2) spill.words[2 * spill.capacity + pos] = val1;
+      if (NV == 1 && (PT.flags & PTF_SHARED)) {  // val0 is the aggregates' common RAW operand: every plane gets its own transform of it
+#pragma unroll
+        for (int a = 0; a < kMaxAggs; ++a)
+          if (a < T.na) spill.words[(uint64_t)(1 + a) * spill.capacity + pos] = transform_value(T.val_xform[a], val0, true);
+      } else {
+        spill.words[spill.capacity + pos] = val0;
+        if constexpr (NV == 2) spill.words[2 * spill.capacity + pos] = val1;
+      }
     }
   }
 }
@@ -173,7 +179,8 @@ __global__ __launch_bounds__(kRingBlock) void k_partition_ws(const DevProgram P,
             uint64_t v;
             bool valid;
             POL::arg(P, F, plan.arg[0], 0, cur, curv, reg, rv, v, valid);
-            const uint64_t val = transform_value(POL::xform(T, 0), v, valid);
+            // (PTF_SHARED: the row carries the aggregates' common RAW operand -- pass 2 applies every aggregate's own transform)
+            const uint64_t val = transform_value((NV == 1 && (PT.flags & PTF_SHARED)) ? (uint8_t)VT_RAW : POL::xform(T, 0), v, valid);
             uint64_t val1 = 0;
             if constexpr (NV == 2) {
               uint64_t v1;
@@ -192,7 +199,7 @@ __global__ __launch_bounds__(kRingBlock) void k_partition_ws(const DevProgram P,
               sm |= pm & __ballot(qword >= kTagForeign);  // ... or one of the two reserved images
             }
             if (sm != 0) {
-              ws_slow_rows<NV>(T, spill, lane_of_mask(sm), key, val, val1);
+              ws_slow_rows<NV>(T, PT, spill, lane_of_mask(sm), key, val, val1);
               pm &= ~sm;
             }
             const uint32_t c = (uint32_t)__popcll(pm);

@@ -154,6 +154,7 @@ hipError_t launch_dict_gather(const uint64_t* ids, int64_t g, const DevDict& D, 
 // partitioned GROUP BY (dfx_k_partition.hip): pass 1 routes passing rows to per-(producer, partition)
 // regions, pass 2 aggregates every partition in an LDS copy of its table block.  Single-word keys.
 size_t partition_stage_bytes(const DevPartition& PT);
+bool partition_planes_supported(const DevProgram& P, const DevFastPlan& fast, const DevColumns& C, const DevTable& T);  // PTF_PLANES: ... the one-value kernels with the raw operand
 bool partition_pair_supported(const DevProgram& P, const DevFastPlan& fast, const DevColumns& C, const DevTable& T);  // PTF_PAIR: this bound batch fits the pair kernels
 hipError_t launch_probe_wide_keys(const DevTable& T, hipStream_t s);
 size_t partition_ring_bytes(uint32_t n_words, uint32_t n_parts, int ring_rows, bool hot = false, bool narrow = false, int queue_rows = 0);

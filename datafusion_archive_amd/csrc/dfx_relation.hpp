@@ -101,6 +101,9 @@ struct AggOptions {
   int host_stage_slots = 6;    // ... slots
   int chunk_hold = 4;          // several chunks of accumulators over one table: batches held so that every chunk scans them in a row (one host check per
                                // chunk and hold; 1: per chunk and batch, rounds 3-5)
+  int shared_planes = 1;       // 2..3 aggregates of ONE operand (AVG = SUM + COUNT, SUM + MIN + MAX of a column ...), narrow key, many groups: the raw operand
+                               // goes through the one-value pass 1 (whole-line chunks, 8192-slot table blocks) and pass 2 runs once per accumulator
+                               // plane (PTF_PLANES); 0: rounds 3-6 -- 4096-slot blocks that hold every plane, 8-row chunks
   int pair_scan = 1;           // two aggregates of different operands, one narrow key, many groups: ONE scan routes both operands (20-byte rows,
                                // PTF_PAIR) and pass 2 runs once per accumulator plane, instead of a scan per aggregate (0: always the scans)
   int split_aggregates = 1;    // one key, several aggregates of different operands, many groups: a scan per aggregate through the one-value

@@ -268,6 +268,7 @@ bool set_option_in(AggOptions& o, const char* key, int64_t value) {
   else if (!strcmp(key, "agg.split_aggregates")) o.split_aggregates = (int)value;
   else if (!strcmp(key, "agg.chunk_hold")) o.chunk_hold = (int)value;
   else if (!strcmp(key, "agg.pair_scan")) o.pair_scan = (int)value;
+  else if (!strcmp(key, "agg.shared_planes")) o.shared_planes = (int)value;
   else if (!strcmp(key, "csv.wave_tiles")) o.csv_wave_tiles = (int)value;
   else if (!strcmp(key, "host.stream")) o.host_stream = (int)value;
   else if (!strcmp(key, "host.stage_threads")) o.host_stage_threads = (int)value;
@@ -463,6 +464,7 @@ int64_t dfx_counter_get(const char* name) {
   if (!strcmp(name, "agg_alloc_us")) return counters().agg_alloc_us;
   if (!strcmp(name, "agg_pass2_launches")) return counters().agg_pass2_launches;
   if (!strcmp(name, "agg_pair_launches")) return counters().agg_pair_launches;
+  if (!strcmp(name, "agg_plane_launches")) return counters().agg_plane_launches;
   if (!strcmp(name, "agg_pair_fallbacks")) return counters().agg_pair_fallbacks;
   if (!strcmp(name, "agg_growths")) return counters().agg_growths;
   if (!strcmp(name, "agg_shared_operand_launches")) return counters().agg_shared_operand_launches;

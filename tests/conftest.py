@@ -26,7 +26,7 @@ _OPTION_DEFAULTS = {
     "agg.ctrl_snapshot": 1, "filter.single_pass": 1, "agg.pass1_ws": 8, "agg.pass1_ws_dense": 0, "agg.pass1_ws_dense_scanners": 4,
     # tests scan resident tables in SMALL batches on purpose (multi-batch paths, deferred pass 2 ...): the library's default
     # (one slice per routing window for an aggregate over a table scan) would merge them away
-    "agg.merge_scan_batches": 0, "agg.early_keys": 1, "csv.wave_tiles": 1, "export.kernel_copy": 1, "agg.narrow_chunk16": 1, "agg.shared_operand": 1, "agg.chunk_hold": 4, "agg.pair_scan": 1,
+    "agg.merge_scan_batches": 0, "agg.early_keys": 1, "csv.wave_tiles": 1, "export.kernel_copy": 1, "agg.narrow_chunk16": 1, "agg.shared_operand": 1, "agg.chunk_hold": 4, "agg.pair_scan": 1, "agg.shared_planes": 1,
 }
 
 

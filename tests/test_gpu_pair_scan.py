@@ -37,6 +37,7 @@ HEAD = AND(BinaryExpr(Column(1), Operator.Gt, f64(204.8)), BinaryExpr(Column(1),
 SUM_V = AggregateFunction("SUM", [Column(1)], F64)
 MIN_V = AggregateFunction("MIN", [Column(1)], F64)
 COUNT_V = AggregateFunction("COUNT", [Column(1)], U64)
+MAX_V = AggregateFunction("MAX", [Column(1)], F64)
 SUM_W = AggregateFunction("SUM", [Column(2)], I64)
 MIN_W = AggregateFunction("MIN", [Column(2)], I64)
 MAX_W = AggregateFunction("MAX", [Column(2)], I64)
@@ -57,22 +58,24 @@ def _schema(syn):
 @pytest.fixture(autouse=True)
 def _defaults():
     ex.set_option("agg.pair_scan", 1)
+    ex.set_option("agg.shared_planes", 1)
     yield
-    for k, v in (("agg.pair_scan", 1), ("agg.partition_cap_rows", 0), ("agg.capacity_log2", 0)):
+    for k, v in (("agg.pair_scan", 1), ("agg.shared_planes", 1), ("agg.partition_cap_rows", 0), ("agg.capacity_log2", 0)):
         ex.set_option(k, v)
 
 
-def _both_ways(name, syn, pred, aggs, n=N, batch=BATCH, opts=(), expect_pair=True, expect_fallback=False):
+def _both_ways(name, syn, pred, aggs, n=N, batch=BATCH, opts=(), expect_pair=True, expect_fallback=False, option="agg.pair_scan",
+               counter="agg_pair_launches"):
     _s, _kept, want = oracle.run_synth_query(syn, SEED, 0, n, 1024, pred, [Column(0)], aggs)
     for k, v in opts:
         ex.set_option(k, v)
     for pair in (1, 0):
-        ex.set_option("agg.pair_scan", pair)
-        before = ex.counter_get("agg_pair_launches"), ex.counter_get("agg_pair_fallbacks")
+        ex.set_option(option, pair)
+        before = ex.counter_get(counter), ex.counter_get("agg_pair_fallbacks")
         t = ex.DeviceTable.synth(syn, SEED, 0, n)
         got = gpu_aggregate([Column(0)], aggs, _schema(syn), [], filter_expr=pred, source=t.scan(batch))
-        _assert_bit_exact(got, want, f"{name} (agg.pair_scan = {pair})")
-        launched = ex.counter_get("agg_pair_launches") - before[0]
+        _assert_bit_exact(got, want, f"{name} ({option} = {pair})")
+        launched = ex.counter_get(counter) - before[0]
         fell_back = ex.counter_get("agg_pair_fallbacks") - before[1]
         if pair and expect_pair:
             assert launched > 0, f"{name}: the pair scan did not run"
@@ -139,3 +142,57 @@ def test_pair_scan_keeps_going_when_wide_keys_arrive_late():
         got = gpu_aggregate([Column(0)], aggs, whole.schema, batches, filter_expr=HEAD)
         assert_groups_identical(got, want, 1, f"late wide keys, agg.pair_scan = {pair}")
         assert (ex.counter_get("agg_pair_launches") - before > 0) == bool(pair)
+
+
+# ---- aggregates of ONE operand: the raw operand through the one-value pass 1, a pass 2 per accumulator plane (PTF_PLANES) ----------
+# agg.shared_planes = 0 is rounds 3-6: 4096-slot blocks that hold every plane, 8-row chunks, one pass 2 for all planes.
+PLANES = dict(option="agg.shared_planes", counter="agg_plane_launches")
+PLANE_CASES = {
+    "sum_min_of_v": (_syn(), HEAD, [SUM_V, MIN_V]),                      # bench.py's neighbour query
+    "avg_parts_of_v": (_syn(), HEAD, [SUM_V, COUNT_V]),                  # AVG = SUM + COUNT
+    "sum_min_max_of_v": (_syn(), HEAD, [SUM_V, MIN_V, MAX_V]),           # three planes
+    "min_sum_of_w_no_predicate": (_syn(), None, [MIN_W, SUM_W]),         # every row routed, Int64 operand
+    "count_max_of_w_int32_key": (_syn(ex.SYNTH_I32_UNIFORM), HEAD, [COUNT_W, MAX_W]),
+}
+
+
+@pytest.mark.parametrize("name", sorted(PLANE_CASES))
+def test_planes_of_a_shared_operand_match_oracle_and_the_all_planes_blocks(name):
+    syn, pred, aggs = PLANE_CASES[name]
+    _both_ways(name, syn, pred, aggs, **PLANES)
+
+
+def test_planes_of_a_shared_operand_leave_for_a_scan_per_aggregate_on_nulls():
+    """The shared operand has nulls: no raw-operand rows (COUNT needs the validity, the others the reference's all-valid slots) -- the
+    stream takes one scan per aggregate from the first batch on; same results."""
+    syn = _syn(v_nulls=4)
+    _s, _kept, want = oracle.run_synth_query(syn, SEED, 0, N, 1024, HEAD, [Column(0)], [SUM_V, COUNT_V])
+    before = ex.counter_get("agg_plane_launches")
+    t = ex.DeviceTable.synth(syn, SEED, 0, N)
+    got = gpu_aggregate([Column(0)], [SUM_V, COUNT_V], _schema(syn), [], filter_expr=HEAD, source=t.scan(BATCH))
+    _assert_bit_exact(got, want, "nulls in the shared operand")
+    assert ex.counter_get("agg_plane_launches") == before
+
+
+def test_planes_of_a_shared_operand_overflow_growth_and_late_wide_keys():
+    syn = _syn(ex.SYNTH_I64_ZIPF, groups=200000.0)
+    _both_ways("zipf, tiny regions", syn, HEAD, [SUM_V, MIN_V, COUNT_V], opts=(("agg.partition_cap_rows", 100),), **PLANES)
+    ex.set_option("agg.partition_cap_rows", 0)
+    _both_ways("table outgrows 256 partitions", _syn(groups=3000000.0), None, [SUM_V, MIN_V], n=(1 << 24) + 999, expect_fallback=True, **PLANES)
+    rng = np.random.default_rng(7)
+    per = (1 << 21) + 4096
+    m = 3 * per
+    k = rng.integers(0, 300000, m).astype(np.int64)
+    k[2 * per + 5::1013] += 1 << 40
+    k[2 * per + 9::2027] = -k[2 * per + 9::2027] - 1
+    v = rng.integers(0, 1 << 20, m).astype(np.float64) / 1024.0
+    whole = pa.RecordBatch.from_arrays([pa.array(k), pa.array(v)], names=["k", "v"])
+    batches = [whole.slice(i * per, per) for i in range(3)]
+    aggs = [SUM_V, MIN_V]
+    want = oracle.aggregate([Column(0)], aggs, [oracle.filter_next(HEAD, b) for b in batches])
+    for on in (1, 0):
+        ex.set_option("agg.shared_planes", on)
+        before = ex.counter_get("agg_plane_launches")
+        got = gpu_aggregate([Column(0)], aggs, whole.schema, batches, filter_expr=HEAD)
+        assert_groups_identical(got, want, 1, f"late wide keys, agg.shared_planes = {on}")
+        assert (ex.counter_get("agg_plane_launches") - before > 0) == bool(on)
