@@ -1132,7 +1132,7 @@ Status AggregateRelation::Impl::launch_rows(const DeviceBatch& b, const DevProgr
     if (pt_pending > 0) pt.flags |= PTF_RESUME;
     // close the window when one more batch could overflow a region (or the batch budget is used up; the calibration
     // slice is aggregated at once: the strategy decision reads the group count)
-    const int max_batches = std::max(1, opt().partition_defer_batches);
+    const int max_batches = pair_mode ? std::min(2, std::max(1, opt().partition_defer_batches)) : std::max(1, opt().partition_defer_batches);  // (pair_mode: the spill list's sizing)
     const bool close_window = calibrating || pt_pending + 1 >= max_batches || pt_fill_bound + 2 * (uint64_t)pt_worst > PT.cap_rows;
     // the LAST kernel of this batch publishes the control block itself (examined one batch later, see post_ctrl)
     snap_armed = false;
@@ -1305,8 +1305,10 @@ Status AggregateRelation::Impl::consume_batch_chunk(const DeviceBatch& b) {
   const bool may_spill = use_partition || occupied_known + unconfirmed_rows + (uint64_t)n > T.load_limit;
   // two batches can be in flight unchecked; with a deferred pass 2 every row of the window may still be spilled (by pass 2
   // itself, when its block is full)
-  // (pair scan: a row whose key finds no slot in its block is spilled by BOTH planes' pass 2)
-  const int64_t window_rows = use_partition ? (int64_t)std::max(1, opt().partition_defer_batches) * std::max(n, pt_layout_rows) * (pair_mode ? na : 1) : 0;
+  // (pair scan / planes: a row whose key finds no slot in its block is spilled by EVERY plane's pass 2; their windows hold at most
+  // two batches -- launch_rows -- so that the worst case stays below what one aggregate reserves)
+  const int64_t window_rows = use_partition ? (pair_mode ? (int64_t)std::min(2, std::max(1, opt().partition_defer_batches)) * na
+                                                         : (int64_t)std::max(1, opt().partition_defer_batches)) * std::max(n, pt_layout_rows) : 0;
   if (may_spill) DFX_RETURN_IF_ERROR(ensure_spill(2 * n + window_rows + 65536));
   T.max_probe = may_spill ? 128 : (int)std::min<uint64_t>(T.mask + 1, 1u << 30);
   int64_t row0 = 0;
@@ -1454,6 +1456,10 @@ Status AggregateRelation::Impl::consume_batch(const DeviceBatch& b) {
     // the next batch comes back here (round-4 advisor finding: a decision recorded before any calibration left a later
     // "partitioned" verdict with the split pending for good -- every launch on per-row global atomics)
     split_decided = forced || lds_calibrated || (decided_rows == 0 && b.num_rows > 0);
+    if (forced && kw == 1) {  // (what consume_batch_chunk does for a forced strategy, before the choice below looks at `narrow`)
+      if (!use_partition && opt().narrow_keys > 0) narrow = true;
+      use_partition = true;
+    }
     if (split_decided && (use_partition || forced)) {
       DFX_RETURN_IF_ERROR(flush_pass2());
       DFX_RETURN_IF_ERROR(settle_ctrl());
