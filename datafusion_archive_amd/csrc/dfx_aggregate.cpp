@@ -97,6 +97,11 @@ struct AggregateRelation::Impl {
   bool pair_mode = false;
   bool pair_is_planes = false;   // pair_mode: the shared-operand flavour
   bool split_is_shared = false;  // the aggregates single_chunks splits all take the same operand
+  // ... or exactly TWO different operands between them (SUM(v), COUNT(v), MAX(w) ...): split_ops bit a = the operand (0 / 1) of
+  // accumulator a, split_arg1 = the first accumulator of operand 1.  Two aggregates: the pair scan as described; three and more: the
+  // operands travel RAW in the pair row (null-free batches only) and every accumulator gets its own pass 2 with its transform
+  int split_distinct = 0;        // distinct operands among the aggregates (3: more than two)
+  uint32_t split_ops = 0, split_arg1 = 0;
   bool split_applies() const { return split_ready && opt().split_aggregates && (!split_is_shared || opt().shared_planes); }
   bool pair_batch_ok(const DeviceBatch& b);
   Status pair_fall_back();
@@ -406,6 +411,17 @@ Status AggregateRelation::Impl::setup(const SchemaInfo& input_schema) {
         split_is_shared = na >= 2 && na <= 3;
         for (int a = 1; a < na; ++a)
           if (plan.arg[a] != plan.arg[0]) split_is_shared = false;
+        split_distinct = 1;
+        split_ops = 0;
+        for (int a = 1; a < na; ++a) {
+          if (plan.arg[a] == plan.arg[0]) continue;
+          if (split_distinct == 1) {
+            split_distinct = 2;
+            split_arg1 = (uint32_t)a;
+          }
+          if (plan.arg[a] == plan.arg[split_arg1]) split_ops |= 1u << a;
+          else split_distinct = 3;
+        }
       }
     }
   }
@@ -730,7 +746,7 @@ Status AggregateRelation::Impl::ensure_partition(int64_t rows, bool nulls_now) {
   const bool want_shared = !pair_mode && narrow && opt().narrow_keys != 0 && !nulls_now && shared_operand() &&
                            ((uint32_t)opt().partition_mode & 0x8Fu) == 2u &&
                            partition_ring_bytes(2, (uint32_t)((T.mask + 1) / S), 16, false, true, 128) <= (size_t)158 * 1024;
-  const bool want_pair = pair_mode && !pair_is_planes && !want_shared && narrow && kw == 1 && na == 2 && kNarrowLine && opt().narrow_keys != 0 && opt().narrow_chunk16 &&
+  const bool want_pair = pair_mode && !pair_is_planes && !want_shared && narrow && kw == 1 && na >= 2 && split_distinct == 2 && (na == 2 || !nulls_now) && kNarrowLine && opt().narrow_keys != 0 && opt().narrow_chunk16 &&
                          opt().pass1_ws > 0 && opt().partition_layout != 2 && ((uint32_t)opt().partition_mode & 0x8Fu) == 2u &&
                          partition_ws_bytes((uint32_t)((T.mask + 1) / S), 8, 2) <= (size_t)158 * 1024;
   if (pair_mode && !want_pair && !want_planes)  // (a table block holds ONE accumulator plane in this mode: no other routed form fits; until the
@@ -739,7 +755,7 @@ Status AggregateRelation::Impl::ensure_partition(int64_t rows, bool nulls_now) {
   const uint32_t n_words = (want_shared || want_planes) ? 2u : (uint32_t)(kw + na);
   if (pt_layout_valid && rows <= pt_layout_rows && PT.n_parts == (uint32_t)((T.mask + 1) / S) && PT.n_words == n_words &&
       ((PT.flags & PTF_NARROW) != 0) == want_narrow && ((PT.flags & PTF_SHARED) != 0) == (want_shared || want_planes) && ((PT.flags & PTF_PAIR) != 0) == want_pair &&
-      ((PT.flags & PTF_PLANES) != 0) == want_planes)
+      ((PT.flags & PTF_PLANES) != 0) == (want_planes || (want_pair && na > 2)))
     return Status::OK();  // same table, a batch the regions were sized for: keep appending
   DFX_RETURN_IF_ERROR(flush_pass2());  // rows routed under the old layout
   pt_layout_valid = false;
@@ -778,6 +794,9 @@ Status AggregateRelation::Impl::ensure_partition(int64_t rows, bool nulls_now) {
     if (o.partition_producers > 0) PT.n_producers = (uint32_t)std::min(1024, o.partition_producers);
   } else if (want_pair) {
     PT.flags |= PTF_NARROW | PTF_CHUNK16 | PTF_WS | PTF_PAIR;
+    if (na > 2) PT.flags |= PTF_PLANES;  // raw operands, a transform per accumulator in pass 2
+    PT.pair_ops = split_ops;
+    PT.pair_arg1 = split_arg1;
     PT.ws_scanners = 8u;
     PT.mode = 2u;
     PT.block = 1024;
@@ -1511,7 +1530,7 @@ bool AggregateRelation::Impl::pair_batch_ok(const DeviceBatch& b) {
     return false;
   };
   if (!kNarrowLine || !narrow || kw != 1 || chunks.size() != 1 || (int)single_chunks.size() != na || !dicts.empty() || unfused_now) return no("shape");
-  if (split_is_shared ? !(na >= 2 && na <= 3 && shared_operand()) : na != 2) return no("aggregates");
+  if (split_is_shared ? !(na >= 2 && na <= 3 && shared_operand()) : !(split_distinct == 2 && na >= 2 && na <= kMaxAggs)) return no("aggregates");
   const AggOptions& o = opt();
   if ((!split_is_shared && (!o.plan || !o.fast)) || o.narrow_keys == 0 || !o.narrow_chunk16 || o.pass1_ws <= 0 || o.partition_layout == 2 || ((uint32_t)o.partition_mode & 0x8Fu) != 2u) return no("options");
   if (!split_is_shared && !scan_plan_shape_ok(builder->program(), fast, kw, na, val_xform)) return no("scan plan shape");  // (also: a predicate over nulls stays fused, consume_batch_chunk)

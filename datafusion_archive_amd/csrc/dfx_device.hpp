@@ -277,7 +277,14 @@ struct DevPartition {
   uint32_t block;      // pass-1 workgroup size (mode 1: 512 or 1024)
   uint32_t flags;      // PTF_*
   uint32_t ws_scanners;// PTF_WS: scanner waves of the 16: 8 (+ 8 routers: selective scans) or 4 (+ 12 routers: dense scans)
-  uint32_t pair_plane; // PTF_PAIR / PTF_PLANES, pass 2: the accumulator plane this launch aggregates (PTF_PAIR: and the operand, 0 or 1)
+  uint32_t pair_plane; // PTF_PAIR / PTF_PLANES, pass 2: the accumulator plane this launch aggregates
+  uint32_t pair_operand;  // PTF_PAIR, pass 2: which of the row's two operands that plane takes (0 or 1)
+  uint32_t pair_ops;   // PTF_PAIR: bit a = the operand (0 / 1) of accumulator a.  Two aggregates: 0b10, each operand transformed by the scan.
+                       // PTF_PAIR | PTF_PLANES: three and more aggregates over the two columns -- the operands travel RAW (null-free
+                       // batches), every accumulator's pass 2 applies its own transform
+  uint32_t pair_arg1;  // PTF_PAIR: an accumulator whose argument is operand 1 (pass 1 evaluates that argument; operand 0 is accumulator 0's)
+  uint32_t pair_slot1; // ... its plan column slot and its operand transform, filled in by the launcher once the scan plan is bound (the kernel
+  uint32_t pair_xf1;   //     indexes nothing by a run-time accumulator number)
   // Control-block snapshot written BY THE KERNEL (null: none): the last workgroup to finish copies T.ctrl into this
   // host-mapped pinned buffer.  The host reads it after the launch's completion event -- no copy engine, no blit kernel
   // that would have to find room next to 256 persistent 1024-lane workgroups, nothing on a side stream.

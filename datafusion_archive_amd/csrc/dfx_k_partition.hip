@@ -432,10 +432,13 @@ __global__ __launch_bounds__(kABlock) __attribute__((amdgpu_num_vgpr(kP2Vgprs)))
   // twelve bytes a lane reads are {operand lo, operand hi, image} (plane 0); plane 1 reads {image, operand} like any narrow row.
   // PTF_PLANES (NARROW == 3: aggregates of ONE operand, one launch per accumulator plane): ordinary narrow rows {image, RAW operand};
   // this launch applies plane PT.pair_plane's transform to the operand and aggregates into that plane.
-  const bool pair = NARROW != 0 && NARROW != 3 && !MULTI && (PT.flags & PTF_PAIR) != 0;
-  constexpr bool PLANES = NARROW == 3;
-  const uint32_t plane = (pair || PLANES) ? PT.pair_plane : 0u;
-  const uint32_t last_plane = pair ? 1u : PLANES ? (uint32_t)T.na - 1u : 0u;
+  // NARROW == 4: as 2 with the plane's transform (PTF_PAIR | PTF_PLANES: three and more aggregates over two RAW operands).
+  const bool pair = NARROW != 0 && !MULTI && (PT.flags & PTF_PAIR) != 0;  // (20-byte rows)
+  constexpr bool PLANES = NARROW == 3 || NARROW == 4;                      // (apply the plane's transform to the operand)
+  constexpr bool FMT2 = NARROW == 2 || NARROW == 4;                        // ({operand lo, operand hi, image})
+  const bool per_plane = pair || PLANES;
+  const uint32_t plane = per_plane ? PT.pair_plane : 0u;
+  const uint32_t last_plane = per_plane ? (uint32_t)T.na - 1u : 0u;
   const uint8_t plane_xf = PLANES ? T.val_xform[plane < (uint32_t)kMaxAggs ? plane : 0u] : (uint8_t)VT_RAW;
   uint64_t* const t_accs = T.accs + (uint64_t)plane * T.stride;
   // wide: keys[S] accs[S]; narrow: accs[NA][S] tags[S]
@@ -493,7 +496,7 @@ __global__ __launch_bounds__(kABlock) __attribute__((amdgpu_num_vgpr(kP2Vgprs)))
   const bool line_chunks = NARROW != 0 && kNarrowLine && (PT.flags & PTF_CHUNK16) != 0;
   const uint32_t trip_rows = line_chunks ? (uint32_t)kNarrowTripRows : 64u;  // (PTF_PAIR: ten lines of six rows = 60 as well)
   static_assert(kPairTripRows == kNarrowTripRows || !kNarrowLine, "one trip length for both line geometries");
-  const uint32_t pair_off = plane != 0u ? 8u : 0u;  // plane 1's twelve bytes start at the image
+  const uint32_t pair_off = (pair && PT.pair_operand != 0u) ? 8u : 0u;  // operand 1's twelve bytes start at the image
   const uint32_t voff = pair ? ((uint32_t)lane / (uint32_t)kPairChunkRows) * 128u + ((uint32_t)lane % (uint32_t)kPairChunkRows) * (4u * kPairRowDwords) + pair_off
                         : line_chunks ? ((uint32_t)lane / 10u) * 128u + ((uint32_t)lane % 10u) * 12u
                                       : (uint32_t)lane * kRowBytes;  // (lanes past the trip's rows re-read its first row: measured 11 % over-fetch otherwise)
@@ -541,8 +544,9 @@ __global__ __launch_bounds__(kABlock) __attribute__((amdgpu_num_vgpr(kP2Vgprs)))
   };
   auto decode = [&](const Row4& r, uint32_t tk, Probe& q) {
     const bool inb = (uint32_t)lane < tk;
-    if (NARROW == 2) {  // {operand lo, operand hi, image}
+    if (FMT2) {  // {operand lo, operand hi, image}
       q.val = ((uint64_t)r.y << 32) | r.x;
+      if constexpr (PLANES) q.val = transform_value(plane_xf, q.val, true);
       q.img = r.z;
       q.kk = 0;
       q.real = inb && r.z != kTagEmpty;
@@ -619,7 +623,7 @@ __global__ __launch_bounds__(kABlock) __attribute__((amdgpu_num_vgpr(kP2Vgprs)))
 #pragma unroll
       for (int j = 0; j < kMaxAggs; ++j)  // (PTF_PAIR: T is the two-plane view -- the other plane's launch brings that operand, here its identity)
         sv[j] = MULTI ? ((uint32_t)j < NA ? transform_value(T.val_xform[j], val, true) : 0ull)
-                : (pair || PLANES) ? ((uint32_t)j == plane ? val : (j < T.na ? T.acc_init[j] : 0ull)) : (j == 0 ? val : 0ull);
+                : per_plane ? ((uint32_t)j == plane ? val : (j < T.na ? T.acc_init[j] : 0ull)) : (j == 0 ? val : 0ull);
       spill_row<1>(T, spill, todo, key, sv);
     }
   };
@@ -703,7 +707,7 @@ __global__ __launch_bounds__(kABlock) __attribute__((amdgpu_num_vgpr(kP2Vgprs)))
 #pragma unroll
   for (int mm = 32; mm >= 1; mm >>= 1) new_keys += __shfl_xor(new_keys, mm, 64);
   if (lane == 0 && new_keys) atomicAdd(&T.ctrl[CTRL_OCCUPIED], new_keys);
-  if ((pair || PLANES) && plane != last_plane) return;  // (the last plane's launch reads the same regions: it is the one that ends the window)
+  if (per_plane && plane != last_plane) return;  // (the last plane's launch reads the same regions: it is the one that ends the window)
   if (p == 0 && threadIdx.x == 0) __hip_atomic_store(&T.ctrl[CTRL_MAX_FILL], 0u, RLX_AGENT);  // the regions are empty again
   snapshot_ctrl_if_last(T, PT);
 }
@@ -800,7 +804,7 @@ static bool launch_partition_plan(const DevProgram& P, const DevFastPlan& fast, 
   const bool pair = (PT.flags & PTF_PAIR) != 0;  // two operands per routed row: the multi-value binding (slot look-ups) in the wave-specialised kernel
   const bool one_value = !pair && ((PT.flags & PTF_WS) || ((PT.mode & 15u) == 2 && (PT.flags & PTF_NARROW)));
   if (one_value && !shared && T.na != 1) return false;
-  if (pair && (T.na != 2 || T.kw != 1 || !(PT.flags & PTF_WS))) return false;
+  if (pair && (T.na < 2 || T.kw != 1 || !(PT.flags & PTF_WS))) return false;
   const uint8_t raw_xf[kMaxAggs] = {VT_RAW};
   DevFastPlan fp;
   DevColumns cp;
@@ -816,16 +820,23 @@ static bool launch_partition_plan(const DevProgram& P, const DevFastPlan& fast, 
        launch_partition_variant19, launch_partition_variant15, launch_partition_variant20, launch_partition_variant12}};
   if (!one_value && (fp.scan.gen & 4)) return false;  // (cannot happen: bind_scan_plan gives bit 2 to fixed-slot bindings only)
   if (pair && fp.scan.n_cols != 3 && fp.scan.n_cols != 4) return false;  // (the pair kernels: key + two operand columns, and one more predicate column -- variants 21-24, 11 / 15 / 16 / 12)
-  by_need[fp.scan.n_cols <= 2 ? 0 : fp.scan.n_cols == 3 ? 1 : 2][fp.scan.gen & 7](P, fp, cp, plan, T, PT, spill, n, lds_bytes, s);
+  DevPartition PTp = PT;
+  if (pair) {  // operand 1: the plan slot and the transform of its first accumulator
+    const uint32_t a1 = PT.pair_arg1 < (uint32_t)kMaxAggs ? PT.pair_arg1 : 1u;
+    PTp.pair_slot1 = fp.scan.argslot[a1];
+    PTp.pair_xf1 = T.val_xform[a1];
+  }
+  by_need[fp.scan.n_cols <= 2 ? 0 : fp.scan.n_cols == 3 ? 1 : 2][fp.scan.gen & 7](P, fp, cp, plan, T, PTp, spill, n, lds_bytes, s);
   return true;
 }
 
 // PTF_PAIR: can THIS bound batch go through the pair kernels?  (the plan binds it, three plan columns; host only, no launch)
 bool partition_pair_supported(const DevProgram& P, const DevFastPlan& fast, const DevColumns& C, const DevTable& T) {
-  if (!kNarrowLine || T.na != 2 || T.kw != 1) return false;
+  if (!kNarrowLine || T.na < 2 || T.kw != 1) return false;
+  if (T.na > 2 && P.has_nulls) return false;  // (three and more aggregates: the operands travel raw)
   DevFastPlan fp;
   DevColumns cp;
-  if (!bind_scan_plan(P, fast, C, 1, 2, T.val_xform, false, &fp, &cp)) return false;
+  if (!bind_scan_plan(P, fast, C, 1, T.na, T.val_xform, false, &fp, &cp)) return false;
   return (fp.scan.n_cols == 3 || fp.scan.n_cols == 4) && !(fp.scan.gen & 4);
 }
 
@@ -914,14 +925,20 @@ hipError_t launch_partition_agg(const DevTable& T, const DevPartition& PT, const
   } else if ((PT.flags & PTF_NARROW) && (PT.flags & PTF_PAIR)) {
     // two launches of the one-value kernel over the same regions, one per operand / accumulator plane; the first claims the
     // window's new keys, the second finds them, resets CTRL_MAX_FILL and publishes the control block
-    if (T.na != 2 || T.kw != 1 || !kNarrowLine) return hipErrorInvalidValue;
+    if (T.na < 2 || T.kw != 1 || !kNarrowLine) return hipErrorInvalidValue;
     const size_t pair_lds = (size_t)(T.block_mask + 1) * 12 + (size_t)(kABlock / 64) * kP2RetryRows * 12;
-    DevPartition P0 = PT, P1 = PT;
-    P0.pair_plane = 0;
-    P0.snap_host = nullptr;
-    P1.pair_plane = 1;
-    launch_agg_lean<2>(T, P0, spill, pair_lds, s, 0);
-    launch_agg_lean<1>(T, P1, spill, pair_lds, s, 1);
+    const bool raw_ops = (PT.flags & PTF_PLANES) != 0;  // (three and more aggregates: the launch applies the accumulator's transform)
+    for (int a = 0; a < T.na; ++a) {
+      DevPartition Pa = PT;
+      Pa.pair_plane = (uint32_t)a;
+      Pa.pair_operand = (PT.pair_ops >> a) & 1u;
+      if (a + 1 < T.na) Pa.snap_host = nullptr;
+      if (Pa.pair_operand == 0u) {
+        if (raw_ops) launch_agg_lean<4>(T, Pa, spill, pair_lds, s, a); else launch_agg_lean<2>(T, Pa, spill, pair_lds, s, a);
+      } else {
+        if (raw_ops) launch_agg_lean<3>(T, Pa, spill, pair_lds, s, a); else launch_agg_lean<1>(T, Pa, spill, pair_lds, s, a);
+      }
+    }
   } else if (PT.flags & PTF_NARROW) {
     if (T.na != 1 || T.kw != 1) return hipErrorInvalidValue;
     launch_agg_lean<1>(T, PT, spill, (size_t)(T.block_mask + 1) * 12 + (size_t)(kABlock / 64) * kP2RetryRows * 12, s);

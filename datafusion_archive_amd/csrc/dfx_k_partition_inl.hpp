@@ -626,6 +626,38 @@ DEV void ring_route(const DevTable& T, const DevPartition& PT, const DevRows& sp
   }
 }
 
+// Rows that leave the routed path for the spill list, as a real function (one copy per kernel, called from the wave-specialised scan
+// loop's unrolled bodies and from the pair flavour of ring_route2): inlined, its per-accumulator transforms cost
+// the headline's kernel 3 000 instructions and 23 more spilled scalar registers for rows that do not occur (round 6: found by
+// tools/kernel_meta.py after a bench line came out 5 % slow).  Scalars only -- a struct by reference would have to live in scratch.
+// mode: 0 one value as it is; 1 one RAW value, every accumulator's own transform of it (PTF_SHARED); 2 two values as they are
+// (PTF_PAIR); 3 two RAW values, accumulator a takes operand (ops >> a) & 1 (PTF_PAIR | PTF_PLANES).  xf: val_xform[0..7], a byte each.
+__device__ __attribute__((noinline)) void ws_slow_rows_call(uint32_t* ctrl, uint64_t* words, uint64_t capacity, uint32_t mode, uint32_t na, uint64_t xf,
+                                                            uint32_t ops, bool mark_wide, bool slow, uint64_t key0, uint64_t val0, uint64_t val1) {
+  if (mark_wide && __hip_atomic_load(&ctrl[CTRL_WIDE_KEYS], RLX_AGENT) == 0u) __hip_atomic_store(&ctrl[CTRL_WIDE_KEYS], 1u, RLX_AGENT);
+  const uint64_t m = __ballot(slow);
+  const int lane = lane_id();
+  const int leader = __ffsll((unsigned long long)m) - 1;
+  uint64_t base = 0;
+  if (lane == leader) base = atomicAdd((unsigned long long*)&ctrl[CTRL_SPILL_LO], (unsigned long long)__popcll(m));
+  base = __shfl(base, leader, 64);
+  if (slow) {
+    const uint64_t pos = base + (uint64_t)__popcll(m & ((1ull << lane) - 1ull));
+    if (pos < capacity) {
+      words[pos] = key0;
+      if (mode == 0u) {
+        words[capacity + pos] = val0;
+      } else if (mode == 2u) {
+        words[capacity + pos] = val0;
+        words[2 * capacity + pos] = val1;
+      } else {
+#pragma unroll 1
+        for (uint32_t a = 0; a < na; ++a)
+          words[(uint64_t)(1u + a) * capacity + pos] = transform_value((uint8_t)(xf >> (8u * a)), (mode == 3u && ((ops >> a) & 1u)) ? val1 : val0, true);
+      }
+    }
+  }
+}
 // ring_route for TWO batches of up to 64 rows at once (one routed value per row).  A call of ring_route is a chain of
 // dependent LDS round trips -- fill atomic -> generation word -> ring row -> commit atomic -> job list -> ring read ->
 // store: ~1 us per call whatever the row count, and a wave executes it alone.  When every wave has rows to route all the
@@ -676,12 +708,19 @@ DEV void ring_route2(const DevTable& T, const DevPartition& PT, const DevRows& s
   for (int b = 0; b < 2; ++b) {
     if (__ballot(todo[b]) != 0) {  // (rare)
       uint64_t k1[1] = {KEY_IS_IMG ? (uint64_t)unhash_word32(img[b]) : key[b]};
+      if constexpr (DW == kPairRowDwords) {  // two operands: the spill function (every accumulator's transform when the operands are raw)
+        uint64_t xf = 0;
+#pragma unroll
+        for (int a = 0; a < kMaxAggs; ++a) xf |= (uint64_t)T.val_xform[a] << (8 * a);
+        ws_slow_rows_call(T.ctrl, spill.words, spill.capacity, (PT.flags & PTF_PLANES) ? 3u : 2u, (uint32_t)T.na, xf, PT.pair_ops, false, todo[b], k1[0], val[b], val2[b]);
+        continue;
+      }
       uint64_t sv[kMaxAggs];
       if (NARROW && (PT.flags & PTF_SHARED)) {
         expand_shared_operand(T, val[b], sv);
       } else {
 #pragma unroll
-        for (int a = 0; a < kMaxAggs; ++a) sv[a] = a == 0 ? val[b] : (DW == kPairRowDwords && a == 1) ? val2[b] : 0ull;
+        for (int a = 0; a < kMaxAggs; ++a) sv[a] = a == 0 ? val[b] : 0ull;
       }
       spill_row<1>(T, spill, todo[b], k1, sv);
     }

@@ -51,27 +51,11 @@ size_t partition_ws_bytes(uint32_t n_parts, int ns, int nv);
 // (sentinel_apply inlined four times per loop was 600 instructions and most of this kernel's scalar-register pressure).
 template <int NV = 1>
 DEV void ws_slow_rows(const DevTable& T, const DevPartition& PT, const DevRows& spill, bool slow, uint64_t key0, uint64_t val0, uint64_t val1 = 0) {
-  if (__hip_atomic_load(&T.ctrl[CTRL_WIDE_KEYS], RLX_AGENT) == 0u) __hip_atomic_store(&T.ctrl[CTRL_WIDE_KEYS], 1u, RLX_AGENT);
-  const uint64_t m = __ballot(slow);
-  const int lane = lane_id();
-  const int leader = __ffsll((unsigned long long)m) - 1;
-  uint64_t base = 0;
-  if (lane == leader) base = atomicAdd((unsigned long long*)&T.ctrl[CTRL_SPILL_LO], (unsigned long long)__popcll(m));
-  base = __shfl(base, leader, 64);
-  if (slow) {
-    const uint64_t pos = base + (uint64_t)__popcll(m & ((1ull << lane) - 1ull));
-    if (pos < spill.capacity) {  // (one key word, one value -- two under PTF_PAIR, one per aggregate under PTF_SHARED: the only rows this kernel routes)
-      spill.words[pos] = key0;
-      if (NV == 1 && (PT.flags & PTF_SHARED)) {  // val0 is the aggregates' common RAW operand: every plane gets its own transform of it
+  uint64_t xf = 0;
 #pragma unroll
-        for (int a = 0; a < kMaxAggs; ++a)
-          if (a < T.na) spill.words[(uint64_t)(1 + a) * spill.capacity + pos] = transform_value(T.val_xform[a], val0, true);
-      } else {
-        spill.words[spill.capacity + pos] = val0;
-        if constexpr (NV == 2) spill.words[2 * spill.capacity + pos] = val1;
-      }
-    }
-  }
+  for (int a = 0; a < kMaxAggs; ++a) xf |= (uint64_t)T.val_xform[a] << (8 * a);
+  const uint32_t mode = NV == 1 ? ((PT.flags & PTF_SHARED) ? 1u : 0u) : ((PT.flags & PTF_PLANES) ? 3u : 2u);
+  ws_slow_rows_call(T.ctrl, spill.words, spill.capacity, mode, (uint32_t)T.na, xf, PT.pair_ops, true, slow, key0, val0, val1);
 }
 
 // NV = 2 (PTF_PAIR): two aggregates of different operands -- the scanners evaluate both arguments, the queues carry a second
@@ -180,13 +164,14 @@ __global__ __launch_bounds__(kRingBlock) void k_partition_ws(const DevProgram P,
             bool valid;
             POL::arg(P, F, plan.arg[0], 0, cur, curv, reg, rv, v, valid);
             // (PTF_SHARED: the row carries the aggregates' common RAW operand -- pass 2 applies every aggregate's own transform)
-            const uint64_t val = transform_value((NV == 1 && (PT.flags & PTF_SHARED)) ? (uint8_t)VT_RAW : POL::xform(T, 0), v, valid);
+            const bool raw_ops = NV == 1 ? (PT.flags & PTF_SHARED) != 0 : (PT.flags & PTF_PLANES) != 0;  // (pass 2 applies the transforms)
+            const uint64_t val = transform_value(raw_ops ? (uint8_t)VT_RAW : POL::xform(T, 0), v, valid);
             uint64_t val1 = 0;
-            if constexpr (NV == 2) {
+            if constexpr (NV == 2) {  // operand 1 = the argument of accumulator pair_arg1 (1 when there are two aggregates)
               uint64_t v1;
               bool valid1;
-              POL::arg(P, F, plan.arg[1], 1, cur, curv, reg, rv, v1, valid1);
-              val1 = transform_value(POL::xform(T, 1), v1, valid1);
+              POL::arg_slot(F, PT.pair_slot1, reg, rv, v1, valid1);
+              val1 = transform_value(raw_ops ? (uint8_t)VT_RAW : (uint8_t)PT.pair_xf1, v1, valid1);
             }
             passed += (uint64_t)__popcll(pm);
             // dense split (QPS > 1): the SCANNERS hash -- four waves with little else to do, while the twelve routers' chain of

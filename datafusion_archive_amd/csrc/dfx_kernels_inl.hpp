@@ -1034,6 +1034,11 @@ struct PlanPolicy {
       }
     }
   }
+  // the argument in plan column `slot` (wave-uniform, run-time: the pair scan's second operand, DevPartition::pair_slot1)
+  static DEV void arg_slot(const DevFastPlan& F, uint32_t slot, const u64x16& reg, uint32_t rv, uint64_t& v, bool& valid) {
+    v = plan_sel<NCOL>(reg, slot);
+    valid = (NULLS && F.scan.count_valid) ? ((rv >> slot) & 1u) != 0u : true;
+  }
 };
 template <int NCOL, int U, int GENK> using PlanPolicyN = PlanPolicy<NCOL, U, GENK, false>;  // any keys / arguments
 template <int NCOL, int U, int GENK> using PlanPolicy1 = PlanPolicy<NCOL, U, GENK, true>;   // key in slot 0, one routed value in slot 1

@@ -196,3 +196,36 @@ def test_planes_of_a_shared_operand_overflow_growth_and_late_wide_keys():
         got = gpu_aggregate([Column(0)], aggs, whole.schema, batches, filter_expr=HEAD)
         assert_groups_identical(got, want, 1, f"late wide keys, agg.shared_planes = {on}")
         assert (ex.counter_get("agg_plane_launches") - before > 0) == bool(on)
+
+
+# ---- three and more aggregates over TWO columns: raw operands in the pair row, a pass 2 per accumulator with its transform -----------
+AVG_V = AggregateFunction("AVG", [Column(1)], F64)
+MULTI_CASES = {
+    "sum_count_of_v_max_of_w": (_syn(), HEAD, [SUM_V, COUNT_V, MAX_W]),
+    "interleaved_operands": (_syn(), HEAD, [MAX_W, SUM_V, MIN_W, MIN_V]),            # operand 0 is w here
+    "avg_v_min_max_w_no_predicate": (_syn(), None, [AVG_V, MIN_W, MAX_W]),           # AVG = SUM + COUNT: four accumulators
+    "five_accumulators_int32_key": (_syn(ex.SYNTH_I32_UNIFORM), HEAD, [SUM_V, MIN_V, MAX_V, SUM_W, COUNT_W]),
+    "predicate_on_a_fourth_column": (_syn() + [("x", ex.SYNTH_F64_UNIFORM, 3, 0.0, 1.0)], BinaryExpr(Column(3), Operator.Lt, f64(0.3)), [SUM_V, COUNT_V, MAX_W]),
+}
+
+
+@pytest.mark.parametrize("name", sorted(MULTI_CASES))
+def test_pair_scan_with_several_aggregates_per_operand(name):
+    syn, pred, aggs = MULTI_CASES[name]
+    _both_ways(name, syn, pred, aggs)
+
+
+def test_pair_scan_with_several_aggregates_per_operand_off_the_routed_path():
+    """Nulls in an operand (the raw operands cannot carry a validity: a scan per aggregate from the first batch on), Zipf keys with
+    tiny regions (overflow -> every accumulator's own transform of its operand in the spill list), a table that outgrows the kernels."""
+    aggs = [SUM_V, COUNT_V, MAX_W]
+    syn = _syn(w_nulls=4)
+    _s, _kept, want = oracle.run_synth_query(syn, SEED, 0, N, 1024, HEAD, [Column(0)], aggs)
+    before = ex.counter_get("agg_pair_launches")
+    t = ex.DeviceTable.synth(syn, SEED, 0, N)
+    got = gpu_aggregate([Column(0)], aggs, _schema(syn), [], filter_expr=HEAD, source=t.scan(BATCH))
+    _assert_bit_exact(got, want, "nulls in an operand")
+    assert ex.counter_get("agg_pair_launches") == before
+    _both_ways("zipf, tiny regions", _syn(ex.SYNTH_I64_ZIPF, groups=200000.0), HEAD, aggs, opts=(("agg.partition_cap_rows", 100),))
+    ex.set_option("agg.partition_cap_rows", 0)
+    _both_ways("table outgrows the pair kernels", _syn(groups=3000000.0), None, aggs, n=(1 << 24) + 999, expect_fallback=True)

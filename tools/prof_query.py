@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Runs one workload a few times (no CPU baseline): the target of rocprofv3 runs.
-usage: prof_query.py <headline|selNN|cfg3|cfg2|q1|neighbour|oneterm|threeterm|threecol|diffop|product> [rows] [iters] [option=value ...]
+usage: prof_query.py <headline|selNN|cfg3|cfg2|q1|neighbour|oneterm|threeterm|threecol|diffop|avgmax|product> [rows] [iters] [option=value ...]
 (neighbour: SELECT k, SUM(v), MIN(v) WHERE v >= lo AND v < hi GROUP BY k -- two aggregates of one operand;
  oneterm: SELECT k, SUM(v) WHERE v < 204.8 GROUP BY k; threecol: SELECT k, SUM(w) WHERE v > lo AND v < hi GROUP BY k;
  product: SELECT k, SUM(v * 2.0) WHERE v > lo AND v < hi GROUP BY k -- shapes without a static signature: FastPolicy)"""
@@ -73,6 +73,11 @@ else:
         syn = syn + [("w", ex.SYNTH_F64_EXACT, 2, 0.0, 0.0)]
         schema = pa.schema([("k", pa.int64()), ("v", pa.float64()), ("w", pa.float64())])
         aggs = [AggregateFunction("SUM", [Column(1)], f64), AggregateFunction("MIN", [Column(2)], f64)]
+        bytes_per_row = 24
+    if wl == "avgmax":  # three accumulators over two columns: AVG(v) = SUM + COUNT, MAX(w)
+        syn = syn + [("w", ex.SYNTH_F64_EXACT, 2, 0.0, 0.0)]
+        schema = pa.schema([("k", pa.int64()), ("v", pa.float64()), ("w", pa.float64())])
+        aggs = [AggregateFunction("AVG", [Column(1)], f64), AggregateFunction("MAX", [Column(2)], f64)]
         bytes_per_row = 24
     if wl == "product":
         aggs = [AggregateFunction("SUM", [BinaryExpr(Column(1), Operator.Multiply, lit(2.0))], f64)]
