@@ -1447,14 +1447,17 @@ def test_device_partial_exchange_emulated_ranks(world, strategy):
 
 
 @pytest.mark.parametrize("world", [1, 2])
-@pytest.mark.parametrize("strategy,batch_rows", [(3, 1 << 18), (0, 1 << 22)])
-def test_device_partial_exchange_after_the_drain_split_the_aggregates(world, strategy, batch_rows):
+@pytest.mark.parametrize("strategy,batch_rows,pair", [(3, 1 << 18, 0), (0, 1 << 22, 0), (0, 1 << 22, 1)])
+def test_device_partial_exchange_after_the_drain_split_the_aggregates(world, strategy, batch_rows, pair):
     """Round-4 advisor finding: aggregates of DIFFERENT operands over many groups are re-chunked during the drain (one scan
     per aggregate, agg.split_aggregates), after which the active chunk's view carries ONE accumulator plane.  The public
     partial_build / partial_export / partial_import path must still move every accumulator: n_words = keys + ALL
-    accumulators, and MIN / MAX / COUNT of the other planes come out as the oracle's, not as their init values."""
+    accumulators, and MIN / MAX / COUNT of the other planes come out as the oracle's, not as their init values.
+    pair = 1 (round 6): the four aggregates over two columns stay ONE chunk -- the pair scan routes both raw operands and pass 2 runs
+    per accumulator --; the same entry points must move the same planes."""
     import torch
     ex.set_option("agg.strategy", strategy)
+    ex.set_option("agg.pair_scan", pair)
     syn = [("k", ex.SYNTH_I64_UNIFORM, 0, 150000.0, 0.0), ("v", ex.SYNTH_F64_EXACT, 1, 0.0, 0.0), ("w", ex.SYNTH_F64_EXACT, 2, 0.0, 0.0)]
     n, seed = (3 * (1 << 19)) if strategy == 3 else (1 << 23), 0xDF0A
     schema = pa.schema([("k", pa.int64()), ("v", pa.float64()), ("w", pa.float64())])
@@ -1471,7 +1474,7 @@ def test_device_partial_exchange_after_the_drain_split_the_aggregates(world, str
     built = [rel.partial_build(world) for rel in rels]
     n_words = built[0][0]
     assert all(b[0] == n_words for b in built) and n_words == 1 + len(aggs), n_words
-    assert "ran one scan per aggregate" in ex.explain(rels[0]), ex.explain(rels[0])  # the case under test: the drain did re-chunk
+    assert ("ran the pair scan" if pair else "ran one scan per aggregate") in ex.explain(rels[0]), ex.explain(rels[0])  # the case under test: the drain did re-chunk (or kept the pair scan)
     dev = torch.device("cuda:0")
     sends = []
     for rel, (_, counts) in zip(rels, built):
