@@ -48,7 +48,8 @@ schema3 = pa.schema([("k", pa.int64()), ("v", pa.float64()), ("w", pa.float64())
 #  by rehash + spill replay; regions that overflow into the spill list; hot-key pairs forced on)
 ALTERNATIVES = [("agg.capacity_log2", 9, 0), ("agg.capacity_log2", 14, 0), ("agg.hot_keys", 1, -1), ("scan.fast", 0, 1), ("agg.strategy", 1, 0), ("agg.strategy", 3, 0), ("agg.pass1_ws", 0, 8), ("filter.single_pass", 0, 1),
                 ("agg.narrow_keys", 0, -1), ("agg.shared_operand", 0, 1), ("agg.merge_scan_batches", 0, 1), ("agg.partition_defer", 1, 0),
-                ("scan.plan", 0, 1), ("scan.plan", 2, 1), ("agg.split_aggregates", 0, 1)]  # round 4: scan plans off / before the signatures; one scan for all aggregates
+                ("scan.plan", 0, 1), ("scan.plan", 2, 1), ("agg.split_aggregates", 0, 1),
+                ("agg.pair_scan", 0, 1), ("agg.shared_planes", 0, 1)]  # round 6: a scan per aggregate instead of the pair scan; all planes in one block  # round 4: scan plans off / before the signatures; one scan for all aggregates
 
 
 def aggregate_sets():
