@@ -740,13 +740,14 @@ bool AggregateRelation::Impl::shared_operand() const {
 
 Status AggregateRelation::Impl::ensure_partition(int64_t rows, bool nulls_now) {
   const uint64_t S = (uint64_t)T.block_mask + 1;
-  const bool want_planes = pair_mode && pair_is_planes && narrow && opt().narrow_keys != 0 && !nulls_now && shared_operand() && kNarrowLine && opt().narrow_chunk16 &&
+  const bool raw_ok = !nulls_now || (has_pred && !unfused_now);  // (a raw operand has no validity: fine under an absorbed predicate -- every surviving slot is valid)
+  const bool want_planes = pair_mode && pair_is_planes && narrow && opt().narrow_keys != 0 && raw_ok && shared_operand() && kNarrowLine && opt().narrow_chunk16 &&
                            opt().pass1_ws > 0 && opt().partition_layout != 2 && ((uint32_t)opt().partition_mode & 0x8Fu) == 2u &&
                            partition_ws_bytes((uint32_t)((T.mask + 1) / S), 4, 1) <= (size_t)158 * 1024;
   const bool want_shared = !pair_mode && narrow && opt().narrow_keys != 0 && !nulls_now && shared_operand() &&
                            ((uint32_t)opt().partition_mode & 0x8Fu) == 2u &&
                            partition_ring_bytes(2, (uint32_t)((T.mask + 1) / S), 16, false, true, 128) <= (size_t)158 * 1024;
-  const bool want_pair = pair_mode && !pair_is_planes && !want_shared && narrow && kw == 1 && na >= 2 && split_distinct == 2 && (na == 2 || !nulls_now) && kNarrowLine && opt().narrow_keys != 0 && opt().narrow_chunk16 &&
+  const bool want_pair = pair_mode && !pair_is_planes && !want_shared && narrow && kw == 1 && na >= 2 && split_distinct == 2 && (na == 2 || raw_ok) && kNarrowLine && opt().narrow_keys != 0 && opt().narrow_chunk16 &&
                          opt().pass1_ws > 0 && opt().partition_layout != 2 && ((uint32_t)opt().partition_mode & 0x8Fu) == 2u &&
                          partition_ws_bytes((uint32_t)((T.mask + 1) / S), 8, 2) <= (size_t)158 * 1024;
   if (pair_mode && !want_pair && !want_planes)  // (a table block holds ONE accumulator plane in this mode: no other routed form fits; until the

@@ -833,7 +833,7 @@ static bool launch_partition_plan(const DevProgram& P, const DevFastPlan& fast, 
 // PTF_PAIR: can THIS bound batch go through the pair kernels?  (the plan binds it, three plan columns; host only, no launch)
 bool partition_pair_supported(const DevProgram& P, const DevFastPlan& fast, const DevColumns& C, const DevTable& T) {
   if (!kNarrowLine || T.na < 2 || T.kw != 1) return false;
-  if (T.na > 2 && P.has_nulls) return false;  // (three and more aggregates: the operands travel raw)
+  if (T.na > 2 && P.has_nulls && fast.np == 0) return false;  // (three and more aggregates: the operands travel raw -- see partition_planes_supported)
   DevFastPlan fp;
   DevColumns cp;
   if (!bind_scan_plan(P, fast, C, 1, T.na, T.val_xform, false, &fp, &cp)) return false;
@@ -843,7 +843,9 @@ bool partition_pair_supported(const DevProgram& P, const DevFastPlan& fast, cons
 // PTF_PLANES: does THIS bound batch take the wave-specialised one-value pass 1 with the aggregates' common raw operand?
 // (a compile-time signature of the raw shape, or the scan plan's fixed-slot binding; host only, no launch)
 bool partition_planes_supported(const DevProgram& P, const DevFastPlan& fast, const DevColumns& C, const DevTable& T) {
-  if (!kNarrowLine || T.na < 2 || T.na > kSharedMaxAggs || T.kw != 1 || P.has_nulls) return false;
+  // (nulls: a raw operand carries no validity.  Under an absorbed predicate nobody asks for it -- every surviving slot is valid,
+  // filter.rs:83-92, DevScanPlan::count_valid --; without one COUNT would)
+  if (!kNarrowLine || T.na < 2 || T.na > kSharedMaxAggs || T.kw != 1 || (P.has_nulls && fast.np == 0)) return false;
   const uint8_t raw_kind0[1] = {SigKeySumPred2F64::acc(0)}, raw_kind1[1] = {SigKeySum::acc(0)}, raw_xf[kMaxAggs] = {VT_RAW};
   if ((fast.plan_mode & 3) != 2 && (sig_matches<SigKeySumPred2F64>(P, fast, 1, 1, raw_kind0, raw_xf) || sig_matches<SigKeySum>(P, fast, 1, 1, raw_kind1, raw_xf) ||
                                     sig_matches<SigKeyAffSumPred2F64>(P, fast, 1, 1, raw_kind0, raw_xf)))

@@ -162,15 +162,16 @@ def test_planes_of_a_shared_operand_match_oracle_and_the_all_planes_blocks(name)
     _both_ways(name, syn, pred, aggs, **PLANES)
 
 
-def test_planes_of_a_shared_operand_leave_for_a_scan_per_aggregate_on_nulls():
-    """The shared operand has nulls: no raw-operand rows (COUNT needs the validity, the others the reference's all-valid slots) -- the
-    stream takes one scan per aggregate from the first batch on; same results."""
+def test_planes_of_a_shared_operand_and_nulls():
+    """Nulls in the shared operand.  Under a predicate every surviving slot is valid (filter.rs:83-92): the raw operand needs no
+    validity and the planes run.  Without one COUNT needs the validity: one scan per aggregate from the first batch on."""
     syn = _syn(v_nulls=4)
-    _s, _kept, want = oracle.run_synth_query(syn, SEED, 0, N, 1024, HEAD, [Column(0)], [SUM_V, COUNT_V])
+    _both_ways("nulls in the shared operand, predicate", syn, HEAD, [SUM_V, COUNT_V], **PLANES)
+    _s, _kept, want = oracle.run_synth_query(syn, SEED, 0, N, 1024, None, [Column(0)], [SUM_V, COUNT_V])
     before = ex.counter_get("agg_plane_launches")
     t = ex.DeviceTable.synth(syn, SEED, 0, N)
-    got = gpu_aggregate([Column(0)], [SUM_V, COUNT_V], _schema(syn), [], filter_expr=HEAD, source=t.scan(BATCH))
-    _assert_bit_exact(got, want, "nulls in the shared operand")
+    got = gpu_aggregate([Column(0)], [SUM_V, COUNT_V], _schema(syn), [], filter_expr=None, source=t.scan(BATCH))
+    _assert_bit_exact(got, want, "nulls in the shared operand, no predicate")
     assert ex.counter_get("agg_plane_launches") == before
 
 
@@ -216,15 +217,16 @@ def test_pair_scan_with_several_aggregates_per_operand(name):
 
 
 def test_pair_scan_with_several_aggregates_per_operand_off_the_routed_path():
-    """Nulls in an operand (the raw operands cannot carry a validity: a scan per aggregate from the first batch on), Zipf keys with
+    """Nulls in the operands (with a predicate: fine; without one the raw operands cannot carry the validity COUNT needs: a scan per aggregate from the first batch on), Zipf keys with
     tiny regions (overflow -> every accumulator's own transform of its operand in the spill list), a table that outgrows the kernels."""
     aggs = [SUM_V, COUNT_V, MAX_W]
-    syn = _syn(w_nulls=4)
-    _s, _kept, want = oracle.run_synth_query(syn, SEED, 0, N, 1024, HEAD, [Column(0)], aggs)
+    syn = _syn(v_nulls=3, w_nulls=4)
+    _both_ways("nulls in both operands, predicate", syn, HEAD, aggs)  # (under a predicate every surviving slot is valid: raw operands do)
+    _s, _kept, want = oracle.run_synth_query(syn, SEED, 0, N, 1024, None, [Column(0)], aggs)
     before = ex.counter_get("agg_pair_launches")
     t = ex.DeviceTable.synth(syn, SEED, 0, N)
-    got = gpu_aggregate([Column(0)], aggs, _schema(syn), [], filter_expr=HEAD, source=t.scan(BATCH))
-    _assert_bit_exact(got, want, "nulls in an operand")
+    got = gpu_aggregate([Column(0)], aggs, _schema(syn), [], filter_expr=None, source=t.scan(BATCH))
+    _assert_bit_exact(got, want, "nulls in an operand, no predicate")
     assert ex.counter_get("agg_pair_launches") == before
     _both_ways("zipf, tiny regions", _syn(ex.SYNTH_I64_ZIPF, groups=200000.0), HEAD, aggs, opts=(("agg.partition_cap_rows", 100),))
     ex.set_option("agg.partition_cap_rows", 0)
