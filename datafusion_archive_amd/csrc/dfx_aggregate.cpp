@@ -102,7 +102,15 @@ struct AggregateRelation::Impl {
   // operands travel RAW in the pair row (null-free batches only) and every accumulator gets its own pass 2 with its transform
   int split_distinct = 0;        // distinct operands among the aggregates (3: more than two)
   uint32_t split_ops = 0, split_arg1 = 0;
-  bool split_applies() const { return split_ready && opt().split_aggregates && (!split_is_shared || opt().shared_planes); }
+  // (four and more aggregates of one operand never had the all-planes block -- shared_operand() stops at three --: they keep the scans per
+  // aggregate when the planes are switched off)
+  bool split_applies() const { return split_ready && opt().split_aggregates && (!split_is_shared || opt().shared_planes || na_total > 3); }
+  bool same_operand_all() const {  // shared_operand() without its limit of three
+    if (kw != 1 || na < 2 || !opt().shared_operand) return false;
+    for (int a = 1; a < na; ++a)
+      if (plan.arg[a] != plan.arg[0]) return false;
+    return true;
+  }
   bool pair_batch_ok(const DeviceBatch& b);
   Status pair_fall_back();
   bool split_ready = false;     // single_chunks is built (used if agg.split_aggregates allows it when the operator runs)
@@ -408,7 +416,7 @@ Status AggregateRelation::Impl::setup(const SchemaInfo& input_schema) {
       single_chunks = std::move(singles);
       split_ready = true;
       {  // (shared_operand() without the option: options are not frozen yet)
-        split_is_shared = na >= 2 && na <= 3;
+        split_is_shared = na >= 2;  // (any number of aggregates of one operand: a pass 2 per plane has no limit of three)
         for (int a = 1; a < na; ++a)
           if (plan.arg[a] != plan.arg[0]) split_is_shared = false;
         split_distinct = 1;
@@ -741,7 +749,7 @@ bool AggregateRelation::Impl::shared_operand() const {
 Status AggregateRelation::Impl::ensure_partition(int64_t rows, bool nulls_now) {
   const uint64_t S = (uint64_t)T.block_mask + 1;
   const bool raw_ok = !nulls_now || (has_pred && !unfused_now);  // (a raw operand has no validity: fine under an absorbed predicate -- every surviving slot is valid)
-  const bool want_planes = pair_mode && pair_is_planes && narrow && opt().narrow_keys != 0 && raw_ok && shared_operand() && kNarrowLine && opt().narrow_chunk16 &&
+  const bool want_planes = pair_mode && pair_is_planes && narrow && opt().narrow_keys != 0 && raw_ok && same_operand_all() && kNarrowLine && opt().narrow_chunk16 &&
                            opt().pass1_ws > 0 && opt().partition_layout != 2 && ((uint32_t)opt().partition_mode & 0x8Fu) == 2u &&
                            partition_ws_bytes((uint32_t)((T.mask + 1) / S), 4, 1) <= (size_t)158 * 1024;
   const bool want_shared = !pair_mode && narrow && opt().narrow_keys != 0 && !nulls_now && shared_operand() &&
@@ -1325,9 +1333,9 @@ Status AggregateRelation::Impl::consume_batch_chunk(const DeviceBatch& b) {
   const bool may_spill = use_partition || occupied_known + unconfirmed_rows + (uint64_t)n > T.load_limit;
   // two batches can be in flight unchecked; with a deferred pass 2 every row of the window may still be spilled (by pass 2
   // itself, when its block is full)
-  // (pair scan / planes: a row whose key finds no slot in its block is spilled by EVERY plane's pass 2; their windows hold at most
-  // two batches -- launch_rows -- so that the worst case stays below what one aggregate reserves)
-  const int64_t window_rows = use_partition ? (pair_mode ? (int64_t)std::min(2, std::max(1, opt().partition_defer_batches)) * na
+  // (pair scan: a row whose key finds no slot in its block is spilled once per OPERAND -- by the last plane of each, dfx_k_partition.hip --;
+  // planes of a shared operand: once.  Their windows hold at most two batches, launch_rows)
+  const int64_t window_rows = use_partition ? (pair_mode ? (int64_t)std::min(2, std::max(1, opt().partition_defer_batches)) * (pair_is_planes ? 1 : 2)
                                                          : (int64_t)std::max(1, opt().partition_defer_batches)) * std::max(n, pt_layout_rows) : 0;
   if (may_spill) DFX_RETURN_IF_ERROR(ensure_spill(2 * n + window_rows + 65536));
   T.max_probe = may_spill ? 128 : (int)std::min<uint64_t>(T.mask + 1, 1u << 30);
@@ -1531,7 +1539,7 @@ bool AggregateRelation::Impl::pair_batch_ok(const DeviceBatch& b) {
     return false;
   };
   if (!kNarrowLine || !narrow || kw != 1 || chunks.size() != 1 || (int)single_chunks.size() != na || !dicts.empty() || unfused_now) return no("shape");
-  if (split_is_shared ? !(na >= 2 && na <= 3 && shared_operand()) : !(split_distinct == 2 && na >= 2 && na <= kMaxAggs)) return no("aggregates");
+  if (split_is_shared ? !(na >= 2 && na <= kMaxAggs && same_operand_all() && opt().shared_planes) : !(split_distinct == 2 && na >= 2 && na <= kMaxAggs)) return no("aggregates");
   const AggOptions& o = opt();
   if ((!split_is_shared && (!o.plan || !o.fast)) || o.narrow_keys == 0 || !o.narrow_chunk16 || o.pass1_ws <= 0 || o.partition_layout == 2 || ((uint32_t)o.partition_mode & 0x8Fu) != 2u) return no("options");
   if (!split_is_shared && !scan_plan_shape_ok(builder->program(), fast, kw, na, val_xform)) return no("scan plan shape");  // (also: a predicate over nulls stays fused, consume_batch_chunk)

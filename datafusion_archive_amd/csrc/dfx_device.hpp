@@ -279,6 +279,10 @@ struct DevPartition {
   uint32_t ws_scanners;// PTF_WS: scanner waves of the 16: 8 (+ 8 routers: selective scans) or 4 (+ 12 routers: dense scans)
   uint32_t pair_plane; // PTF_PAIR / PTF_PLANES, pass 2: the accumulator plane this launch aggregates
   uint32_t pair_operand;  // PTF_PAIR, pass 2: which of the row's two operands that plane takes (0 or 1)
+  uint32_t plane_xf;   // pass 2 of a RAW operand (PTF_PLANES): that accumulator's operand transform (VT_*), filled in by the launcher
+  uint32_t plane_spills;  // pass 2, one launch per plane: 1 = this launch is the LAST plane of its operand -- it alone puts the rows whose key
+                          // finds no slot in a full block into the spill list, with every accumulator of that operand (the block is as
+                          // full for every plane: the earlier launches fail on exactly the same rows and drop them)
   uint32_t pair_ops;   // PTF_PAIR: bit a = the operand (0 / 1) of accumulator a.  Two aggregates: 0b10, each operand transformed by the scan.
                        // PTF_PAIR | PTF_PLANES: three and more aggregates over the two columns -- the operands travel RAW (null-free
                        // batches), every accumulator's pass 2 applies its own transform

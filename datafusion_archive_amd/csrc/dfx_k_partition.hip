@@ -439,13 +439,14 @@ __global__ __launch_bounds__(kABlock) __attribute__((amdgpu_num_vgpr(kP2Vgprs)))
   const bool per_plane = pair || PLANES;
   const uint32_t plane = per_plane ? PT.pair_plane : 0u;
   const uint32_t last_plane = per_plane ? (uint32_t)T.na - 1u : 0u;
-  const uint8_t plane_xf = PLANES ? T.val_xform[plane < (uint32_t)kMaxAggs ? plane : 0u] : (uint8_t)VT_RAW;
+  const uint8_t plane_xf = PLANES ? (uint8_t)PT.plane_xf : (uint8_t)VT_RAW;  // (a scalar from the launcher: no kernel-argument array is indexed at run time)
   uint64_t* const t_accs = T.accs + (uint64_t)plane * T.stride;
   // wide: keys[S] accs[S]; narrow: accs[NA][S] tags[S]
   uint64_t* lkeys = lds;
   uint64_t* laccs = NARROW ? lds : lds + S;
   uint32_t* ltags = (uint32_t*)(lds + (size_t)(NARROW ? NA : 1u) * S);
-  auto apply = [&](uint32_t at, uint64_t val) {
+  auto apply = [&](uint32_t at, uint64_t val) {  // (PLANES: `val` is the RAW operand -- this plane's transform here, so that a row that ends in the spill list still has it raw)
+    if constexpr (PLANES) val = transform_value(plane_xf, val, true);
     if constexpr (MULTI) {
 #pragma unroll
       for (uint32_t a = 0; a < (uint32_t)kSharedMaxAggs; ++a)
@@ -546,14 +547,12 @@ __global__ __launch_bounds__(kABlock) __attribute__((amdgpu_num_vgpr(kP2Vgprs)))
     const bool inb = (uint32_t)lane < tk;
     if (FMT2) {  // {operand lo, operand hi, image}
       q.val = ((uint64_t)r.y << 32) | r.x;
-      if constexpr (PLANES) q.val = transform_value(plane_xf, q.val, true);
       q.img = r.z;
       q.kk = 0;
       q.real = inb && r.z != kTagEmpty;
       q.home4 = (uint32_t)(r.z >> tag_shift) & mask4;
     } else if (NARROW) {
       q.val = ((uint64_t)r.z << 32) | r.y;
-      if constexpr (PLANES) q.val = transform_value(plane_xf, q.val, true);
       q.img = r.x;
       q.kk = 0;
       q.real = inb && r.x != kTagEmpty;
@@ -617,13 +616,23 @@ __global__ __launch_bounds__(kABlock) __attribute__((amdgpu_num_vgpr(kP2Vgprs)))
         todo = false;
       }
     }
-    if (__ballot(todo) != 0) {  // block full: grow-and-replay takes the row (as a key again)
+    if (__ballot(todo) != 0 && (!per_plane || PT.plane_spills != 0u)) {  // block full: grow-and-replay takes the row (as a key again)
+      // one launch per plane: only the LAST plane of an operand spills -- the block is as full for every plane, so the others fail on
+      // exactly these rows -- and it writes every accumulator of its operand (raw operand: each one's transform; the pair of two
+      // aggregates: the one value the scan transformed), the other operand's accumulators get their identity (adding it is a no-op)
       uint64_t key[1] = {NARROW ? (uint64_t)unhash_word32(img) : kk};
       uint64_t sv[kMaxAggs];
 #pragma unroll
-      for (int j = 0; j < kMaxAggs; ++j)  // (PTF_PAIR: T is the two-plane view -- the other plane's launch brings that operand, here its identity)
-        sv[j] = MULTI ? ((uint32_t)j < NA ? transform_value(T.val_xform[j], val, true) : 0ull)
-                : per_plane ? ((uint32_t)j == plane ? val : (j < T.na ? T.acc_init[j] : 0ull)) : (j == 0 ? val : 0ull);
+      for (int j = 0; j < kMaxAggs; ++j) {
+        if (MULTI) {
+          sv[j] = (uint32_t)j < NA ? transform_value(T.val_xform[j], val, true) : 0ull;
+        } else if (per_plane) {
+          const bool mine = pair ? ((PT.pair_ops >> j) & 1u) == PT.pair_operand : true;  // (planes of a shared operand: every accumulator)
+          sv[j] = j >= T.na ? 0ull : !mine ? T.acc_init[j] : PLANES ? transform_value(T.val_xform[j], val, true) : val;
+        } else {
+          sv[j] = j == 0 ? val : 0ull;
+        }
+      }
       spill_row<1>(T, spill, todo, key, sv);
     }
   };
@@ -845,7 +854,7 @@ bool partition_pair_supported(const DevProgram& P, const DevFastPlan& fast, cons
 bool partition_planes_supported(const DevProgram& P, const DevFastPlan& fast, const DevColumns& C, const DevTable& T) {
   // (nulls: a raw operand carries no validity.  Under an absorbed predicate nobody asks for it -- every surviving slot is valid,
   // filter.rs:83-92, DevScanPlan::count_valid --; without one COUNT would)
-  if (!kNarrowLine || T.na < 2 || T.na > kSharedMaxAggs || T.kw != 1 || (P.has_nulls && fast.np == 0)) return false;
+  if (!kNarrowLine || T.na < 2 || T.na > kMaxAggs || T.kw != 1 || (P.has_nulls && fast.np == 0)) return false;
   const uint8_t raw_kind0[1] = {SigKeySumPred2F64::acc(0)}, raw_kind1[1] = {SigKeySum::acc(0)}, raw_xf[kMaxAggs] = {VT_RAW};
   if ((fast.plan_mode & 3) != 2 && (sig_matches<SigKeySumPred2F64>(P, fast, 1, 1, raw_kind0, raw_xf) || sig_matches<SigKeySum>(P, fast, 1, 1, raw_kind1, raw_xf) ||
                                     sig_matches<SigKeyAffSumPred2F64>(P, fast, 1, 1, raw_kind0, raw_xf)))
@@ -916,11 +925,13 @@ hipError_t launch_partition_agg(const DevTable& T, const DevPartition& PT, const
     hipLaunchKernelGGL((k_partition_agg_lean<1, -1>), dim3(PT.n_parts), dim3(kABlock), shared_lds, s, T, PT, spill);
   } else if ((PT.flags & PTF_NARROW) && (PT.flags & PTF_SHARED) && (PT.flags & PTF_PLANES)) {
     // aggregates of one operand, one launch of the one-value kernel per accumulator plane (the plane's own transform and atomic)
-    if (T.na < 2 || T.na > kSharedMaxAggs || T.kw != 1) return hipErrorInvalidValue;
+    if (T.na < 2 || T.na > kMaxAggs || T.kw != 1) return hipErrorInvalidValue;
     const size_t plane_lds = (size_t)(T.block_mask + 1) * 12 + (size_t)(kABlock / 64) * kP2RetryRows * 12;
     for (int a = 0; a < T.na; ++a) {
       DevPartition Pa = PT;
       Pa.pair_plane = (uint32_t)a;
+      Pa.plane_xf = T.val_xform[a];
+      Pa.plane_spills = a + 1 == T.na ? 1u : 0u;
       if (a + 1 < T.na) Pa.snap_host = nullptr;
       launch_agg_lean<3>(T, Pa, spill, plane_lds, s, a);
     }
@@ -934,6 +945,10 @@ hipError_t launch_partition_agg(const DevTable& T, const DevPartition& PT, const
       DevPartition Pa = PT;
       Pa.pair_plane = (uint32_t)a;
       Pa.pair_operand = (PT.pair_ops >> a) & 1u;
+      Pa.plane_xf = T.val_xform[a];
+      Pa.plane_spills = 1u;  // the last accumulator of this operand?
+      for (int b = a + 1; b < T.na; ++b)
+        if (((PT.pair_ops >> b) & 1u) == Pa.pair_operand) Pa.plane_spills = 0u;
       if (a + 1 < T.na) Pa.snap_host = nullptr;
       if (Pa.pair_operand == 0u) {
         if (raw_ops) launch_agg_lean<4>(T, Pa, spill, pair_lds, s, a); else launch_agg_lean<2>(T, Pa, spill, pair_lds, s, a);

@@ -153,6 +153,7 @@ PLANE_CASES = {
     "sum_min_max_of_v": (_syn(), HEAD, [SUM_V, MIN_V, MAX_V]),           # three planes
     "min_sum_of_w_no_predicate": (_syn(), None, [MIN_W, SUM_W]),         # every row routed, Int64 operand
     "count_max_of_w_int32_key": (_syn(ex.SYNTH_I32_UNIFORM), HEAD, [COUNT_W, MAX_W]),
+    "five_planes_of_v": (_syn(), HEAD, [SUM_V, MIN_V, MAX_V, COUNT_V, AggregateFunction("AVG", [Column(1)], F64)]),  # AVG = two more planes: six accumulators
 }
 
 
