@@ -19,7 +19,7 @@ from test_gpu_scale import _assert_bit_exact
 pytestmark = pytest.mark.gpu
 
 F64, I64, U64 = DataType.Float64, DataType.Int64, DataType.UInt64
-N = (1 << 23) + 12345  # three batches, the last one ragged
+N = (1 << 22) + (1 << 21) + 12345  # two batches, the second one ragged
 BATCH = (1 << 22) - 64   # > 2^21 rows: the first batch's calibration slice decides the strategy
 GROUPS = 200000.0
 SEED = 0xDF06
@@ -120,7 +120,7 @@ def test_pair_scan_falls_back_when_the_table_outgrows_its_partitions():
     """3 * 10^6 uniform keys: the table grows to 2^23 slots = 1024 blocks of 8192; the pair kernels route to at most 256.  The rows of
     the batch in hand go through the global table, the next batch starts the per-aggregate scans (agg_pair_fallbacks)."""
     syn = _syn(groups=3000000.0)
-    _both_ways("table outgrows the pair kernels", syn, None, [SUM_V, MIN_W], n=(1 << 24) + 999, batch=(1 << 22) - 64, expect_fallback=True)
+    _both_ways("table outgrows the pair kernels", syn, None, [SUM_V, MIN_W], n=3 * (1 << 22) + 999, batch=(1 << 22) - 64, expect_fallback=True)
 
 
 def test_pair_scan_keeps_going_when_wide_keys_arrive_late():
@@ -180,7 +180,7 @@ def test_planes_of_a_shared_operand_overflow_growth_and_late_wide_keys():
     syn = _syn(ex.SYNTH_I64_ZIPF, groups=200000.0)
     _both_ways("zipf, tiny regions", syn, HEAD, [SUM_V, MIN_V, COUNT_V], opts=(("agg.partition_cap_rows", 100),), **PLANES)
     ex.set_option("agg.partition_cap_rows", 0)
-    _both_ways("table outgrows 256 partitions", _syn(groups=3000000.0), None, [SUM_V, MIN_V], n=(1 << 24) + 999, expect_fallback=True, **PLANES)
+    _both_ways("table outgrows 256 partitions", _syn(groups=3000000.0), None, [SUM_V, MIN_V], n=3 * (1 << 22) + 999, expect_fallback=True, **PLANES)
     rng = np.random.default_rng(7)
     per = (1 << 21) + 4096
     m = 3 * per
@@ -231,4 +231,4 @@ def test_pair_scan_with_several_aggregates_per_operand_off_the_routed_path():
     assert ex.counter_get("agg_pair_launches") == before
     _both_ways("zipf, tiny regions", _syn(ex.SYNTH_I64_ZIPF, groups=200000.0), HEAD, aggs, opts=(("agg.partition_cap_rows", 100),))
     ex.set_option("agg.partition_cap_rows", 0)
-    _both_ways("table outgrows the pair kernels", _syn(groups=3000000.0), None, aggs, n=(1 << 24) + 999, expect_fallback=True)
+    _both_ways("table outgrows the pair kernels", _syn(groups=3000000.0), None, aggs, n=3 * (1 << 22) + 999, expect_fallback=True)

@@ -12,8 +12,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.gpu
-def test_twelve_seconds_of_random_queries_keep_their_invariants():
+def test_eight_seconds_of_random_queries_keep_their_invariants():
     env = dict(os.environ, DFX_NO_TORCH="1")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "soak.py"), "12", "11"], capture_output=True, text=True, timeout=600, env=env)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "soak.py"), "8", "11"], capture_output=True, text=True, timeout=600, env=env)
     tail = (r.stdout + r.stderr)[-1500:]
     assert r.returncode == 0 and "soak ok:" in r.stdout, tail
