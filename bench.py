@@ -1058,9 +1058,24 @@ def main():
             # remembered strategy from its first row on and allocates the full-size routing scratch, GROUP BY table and result
             # buffers (hipMalloc of ~3 GB: +120 ms once per process, tools/stall_probe.py / profiles/r06_stall_probe.txt -- with one
             # warm-up step that allocation fell into the three timed steps on two boxes of three: 48 and 54 ms per step instead of 37-38)
-            db, rb = timed(big_step, args.rows_1e10_steps, 2)
-            e = rate(big_rows * args.rows_1e10_steps, db, 16, f"the headline query over 1e10 rows resident on one GPU (160 GB), {args.rows_1e10_steps} timed steps after 2 warm-up steps")
-            e["ms_per_step"] = db / args.rows_1e10_steps * 1e3
+            # Every step is timed on its own and the leg's rate is the MEDIAN step's: a process's first queries over a new table still
+            # allocate now and then (the third one pins the buffers of the key column's early copy: one 159-ms leg of three steps in six
+            # runs of the final tree, 110-115 in the others); the steps are all in `step_ms`.
+            for _ in range(3):
+                big_step()
+            sync()
+            step_ms, rb = [], None
+            for _ in range(args.rows_1e10_steps):
+                t0s = time.perf_counter()
+                rb = big_step()
+                sync()
+                step_ms.append((time.perf_counter() - t0s) * 1e3)
+            med = sorted(step_ms)[len(step_ms) // 2]
+            db = med * 1e-3 * args.rows_1e10_steps
+            e = rate(big_rows * args.rows_1e10_steps, db, 16, f"the headline query over 1e10 rows resident on one GPU (160 GB): the median of {args.rows_1e10_steps} steps, each timed on "
+                                                                 "its own (launch to synchronisation), after 3 warm-up steps; `ms` = that median x the step count")
+            e["ms_per_step"] = med
+            e["step_ms"] = [round(x, 3) for x in step_ms]
             e["roofline"]["end_to_end_frac"] = e["roofline"]["frac"]
             e["verified_sum_of_group_sums_equals_ungrouped_sum"] = sum_of_sums_check(tb, rb, big_rows)
             # where the step goes: one more step with the library's HIP-event profiler on (the events serialise the kernel chain: the
