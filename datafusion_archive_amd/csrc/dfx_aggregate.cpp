@@ -1371,6 +1371,17 @@ Status AggregateRelation::Impl::consume_batch_chunk(const DeviceBatch& b) {
     if (kw == 1) DFX_HIP(launch_probe_wide_keys(T, ctx().stream));  // does any key of the slice lack a 32-bit image?
     uint32_t hc[CTRL_WORDS];
     DFX_RETURN_IF_ERROR(read_ctrl(hc));
+    if (hc[CTRL_ERROR]) return error_from_ctrl(hc[CTRL_ERROR]);
+    if ((((uint64_t)hc[CTRL_SPILL_HI] << 32) | hc[CTRL_SPILL_LO]) > 0 || hc[CTRL_SATURATED]) {
+      // The slice did not fit the table (a table that starts very small: agg.capacity_log2): its spilled rows sit in the spill list
+      // that the strategy decision below is about to REPLACE by a larger one.  Round 6, found by a test of the pair scan at 2^14
+      // slots: nothing replayed them first -- the spill cursor went on counting them, the rebuild after the batch replayed whatever
+      // the new list's memory held in their place (60-80 of 200 000 groups missing, or keys that never were in the data).  Grow /
+      // replay now; the decision then reads the real group count of the slice.
+      DFX_RETURN_IF_ERROR(handle_ctrl(hc, n0));
+      DFX_RETURN_IF_ERROR(read_ctrl(hc));
+      if (hc[CTRL_ERROR]) return error_from_ctrl(hc[CTRL_ERROR]);
+    }
     // (a property of the KEYS: whether a launch routes 12-byte rows also depends on the aggregates of the chunk it serves --
     // ensure_partition -- and a query that is split into one scan per aggregate has one-aggregate chunks after this point)
     narrow = kw == 1 && hc[CTRL_WIDE_KEYS] == 0;
