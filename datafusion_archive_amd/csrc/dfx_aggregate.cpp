@@ -1574,8 +1574,14 @@ bool AggregateRelation::Impl::pair_batch_ok(const DeviceBatch& b) {
 
 // the pair scan no longer applies: one scan per aggregate from the next batch on (a batch boundary: nothing is half launched)
 Status AggregateRelation::Impl::pair_fall_back() {
+  const bool flushed = pt_pending > 0;
   DFX_RETURN_IF_ERROR(flush_pass2());
   DFX_RETURN_IF_ERROR(settle_ctrl());
+  if (flushed) {  // the pass 2 just launched has no snapshot of its own: rows it spilled carry EVERY accumulator -- replay them under this view
+    uint32_t hc[CTRL_WORDS];
+    DFX_RETURN_IF_ERROR(read_ctrl(hc));
+    DFX_RETURN_IF_ERROR(handle_ctrl(hc, 0));
+  }
   ++counters().agg_pair_fallbacks;
   pair_mode = false;
   install_chunks(std::move(single_chunks));
