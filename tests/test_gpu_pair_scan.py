@@ -253,3 +253,31 @@ def test_planes_and_pair_rows_of_a_table_that_starts_small_and_grows(name):
     by rehash + replay, the stream goes on in the same mode."""
     aggs, kw = GROW_CASES[name]
     _both_ways(name + ", 2^14 slots", _syn(), HEAD, aggs, opts=(("agg.capacity_log2", 14),), **kw)
+
+
+def test_fall_back_with_a_window_pending_and_a_table_that_is_full():
+    """Forced partitioned strategy, 2^14 slots, 50 000 keys, three host batches of which the SECOND has nulls in an operand and there is no
+    predicate: batch 1 runs the pair scan with raw operands and leaves its window pending (two batches per window), batch 2 cannot (COUNT
+    needs the validity) -- the stream leaves for a scan per aggregate with that window still to aggregate.  Its pass 2 finds the blocks
+    full and spills rows that carry EVERY accumulator: they have to be replayed under the all-aggregates view, before the chunks change."""
+    rng = np.random.default_rng(29)
+    n = 300000
+    k = rng.integers(0, 50000, n).astype(np.int64)
+    v = rng.integers(0, 1 << 20, n).astype(np.float64) / 1024.0
+    w = rng.integers(0, 1000, n).astype(np.int64)
+    plain = pa.RecordBatch.from_arrays([pa.array(k), pa.array(v), pa.array(w)], names=["k", "v", "w"])
+    nulls = pa.RecordBatch.from_arrays([pa.array(k), pa.array(v, mask=rng.random(n) < 0.1), pa.array(w)], names=["k", "v", "w"])
+    aggs = [SUM_V, COUNT_V, MAX_W]
+    batches = [plain, nulls, plain]
+    want = oracle.aggregate([Column(0)], aggs, batches)
+    for k_, v_ in (("agg.strategy", 3), ("agg.narrow_keys", 1), ("agg.capacity_log2", 14)):
+        ex.set_option(k_, v_)
+    try:
+        before = ex.counter_get("agg_pair_launches"), ex.counter_get("agg_pair_fallbacks"), ex.counter_get("agg_growths")
+        got = gpu_aggregate([Column(0)], aggs, plain.schema, batches)
+        assert_groups_identical(got, want, 1, "fall back with a window pending")
+        assert ex.counter_get("agg_pair_launches") > before[0] and ex.counter_get("agg_pair_fallbacks") == before[1] + 1
+        assert ex.counter_get("agg_growths") > before[2]
+    finally:
+        for k_, v_ in (("agg.strategy", 0), ("agg.narrow_keys", -1), ("agg.capacity_log2", 0)):
+            ex.set_option(k_, v_)
