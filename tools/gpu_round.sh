@@ -6,6 +6,7 @@
 #            pass 1 / pass 2 for the headline and for config 3 -> partition_counters.json; kernel stats of config 3
 #   csv      the CSV source: its GPU tests, tools/csv_bench.py (1 GB of numeric text) and the rocprofv3 kernel summary of that run
 #   csvpmc   SQ counters of the CSV kernels (256 MB of text; per 64-record tile for k_csv_parse) -> csv_counters.txt
+#   pairpmc  FETCH_SIZE / WRITE_SIZE of pass 1 / pass 2 of the pair scan and of the planes (tools/prof_query.py diffop / avgmax / neighbour)
 #   dry8     bench.py --gpus 8 as eight processes on this ONE GPU over the host-staged RCCL stand-in (plumbing only), and the
 #            same with DFX_RCCL_LIB pointing at a missing file (must exit non-zero)
 # Summaries land in gpurun_out/<tag>/ -- what is cited is copied to profiles/ by hand.
@@ -113,6 +114,39 @@ PY
   rm -rf stats*/out_kernel_trace.csv */*/*.csv.gz 2>/dev/null
   find . -name "*counter_collection*.csv" -size +2000k -delete 2>/dev/null
   find . -name "*kernel_trace*.csv" -size +2000k -delete 2>/dev/null
+  ;;
+pairpmc)
+  # FETCH_SIZE / WRITE_SIZE (separate passes) of the pair scan (two aggregates of different columns), of three accumulators over two
+  # columns and of the planes of a shared operand: 2^28 rows, one warm-up + one timed pass -> pair_counters.json
+  cd /tmp; export DFX_NO_TORCH=1
+  Q="python $R/tools/prof_query.py"
+  for wl in diffop avgmax neighbour; do
+    for c in FETCH_SIZE WRITE_SIZE; do
+      rocprofv3 --output-format csv --pmc $c -d $OUT/pmc_${wl}_$c -o out -- $Q $wl 268435456 1 batch=134217728 > /dev/null 2>&1
+    done
+  done
+  cd $OUT
+  python3 - <<'PY'
+import csv, glob, collections, json
+res = {}
+for d in sorted(glob.glob("pmc_*")):
+    _, wl, c = d.split("_", 2)
+    for f in glob.glob(f"{d}/**/*counter_collection*.csv", recursive=True):
+        agg = collections.defaultdict(float); cnt = collections.Counter()
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"].split("(")[0]
+            if "partition" not in k or r["Counter_Name"] != c:
+                continue
+            k = ("pass2 " if "partition_agg" in k else "pass1 ") + k[:100]
+            agg[k] += float(r["Counter_Value"]); cnt[k] += 1
+        for k, x in agg.items():
+            e = res.setdefault(wl + " | " + k, {})
+            e[c + "_KB_per_dispatch"] = x / cnt[k]
+            e["dispatches"] = cnt[k]
+json.dump(res, open("pair_counters.json", "w"), indent=1, sort_keys=True)
+for k, v in sorted(res.items()): print(k[:120], {a: round(b, 1) for a, b in v.items()})
+PY
+  find . -name "*counter_collection*.csv" -size +2000k -delete 2>/dev/null
   ;;
 dry8)
   export DFX_BENCH_SHARED_GPU=1 DFX_RCCL_LIB=$R/tests/native/librccl_stub.so
