@@ -1556,8 +1556,10 @@ bool AggregateRelation::Impl::pair_batch_ok(const DeviceBatch& b) {
   if (!split_is_shared && !scan_plan_shape_ok(builder->program(), fast, kw, na, val_xform)) return no("scan plan shape");  // (also: a predicate over nulls stays fused, consume_batch_chunk)
   const uint64_t S = (uint64_t)T.block_mask + 1;
   if (S != 8192 || partition_ws_bytes((uint32_t)((T.mask + 1) / S), split_is_shared ? 4 : 8, split_is_shared ? 1 : 2) > (size_t)158 * 1024) return no("table blocks");
-  pair_is_planes = split_is_shared;
-  if (b.num_rows <= 0) return true;
+  if (b.num_rows <= 0) {
+    pair_is_planes = split_is_shared;
+    return true;
+  }
   DevProgram prog;
   DevColumns cols;
   if (!builder->bind(b, &prog, &cols).ok()) return no("bind");
@@ -1569,6 +1571,7 @@ bool AggregateRelation::Impl::pair_batch_ok(const DeviceBatch& b) {
   } else if (!partition_pair_supported(prog, fp, cols, T)) {
     return no("plan binding");
   }
+  pair_is_planes = split_is_shared;
   return true;
 }
 
@@ -2218,7 +2221,7 @@ void AggregateRelation::explain(std::string* out, int depth) const {
                      "narrow and batches have no nulls; pass 2 runs once per accumulator plane with that aggregate's transform "
                      "(agg.shared_planes; 0: one pass 2 over 4096-slot blocks that hold every plane)", m.na);
     if (m.pair_mode) text += m.pair_is_planes ? "; ran the one-value pass 1 with a pass 2 per accumulator plane" : "; ran the pair scan (both operands routed by one scan, a pass 2 per accumulator plane: agg.pair_scan)";
-    if (m.split_ready && !m.split_done && !m.split_is_shared)
+    if (m.split_ready && !m.split_done && !m.split_is_shared && !m.pair_mode)
       text += strfmt("; %d aggregates of different operands: if the calibration slice chooses the partitioned strategy, one scan per "
                      "aggregate (its own fused program and accumulator plane over the same keys: 12-byte routed rows, the one-aggregate "
                      "kernels; agg.split_aggregates)", m.na_total);
