@@ -1552,6 +1552,11 @@ bool AggregateRelation::Impl::pair_batch_ok(const DeviceBatch& b) {
   if (!kNarrowLine || !narrow || kw != 1 || chunks.size() != 1 || (int)single_chunks.size() != na || !dicts.empty() || unfused_now) return no("shape");
   if (split_is_shared ? !(na >= 2 && na <= kMaxAggs && same_operand_all() && opt().shared_planes) : !(split_distinct == 2 && na >= 2 && na <= kMaxAggs)) return no("aggregates");
   const AggOptions& o = opt();
+  // Skewed keys (the calibration slice's front cache absorbed a sizeable share of its rows): the one-value scans keep the heavy keys
+  // in LDS (PTF_HOT) -- the pair rows and the planes have no such thing, a heavy key overflows its regions into the spill list and
+  // the replay queues on a few addresses (Zipf(1.0), 10^9 rows: SUM(v), MIN(w) 51 ms against 12.2 for a scan per aggregate;
+  // SUM(v), MIN(v) 43 ms, 96 with the all-planes blocks).  One scan per aggregate then.
+  if (o.hot_keys > 0 || (o.hot_keys < 0 && skew_seen)) return no("skewed keys: the one-value scans have the hot-key pairs");
   if ((!split_is_shared && (!o.plan || !o.fast)) || o.narrow_keys == 0 || !o.narrow_chunk16 || o.pass1_ws <= 0 || o.partition_layout == 2 || ((uint32_t)o.partition_mode & 0x8Fu) != 2u) return no("options");
   if (!split_is_shared && !scan_plan_shape_ok(builder->program(), fast, kw, na, val_xform)) return no("scan plan shape");  // (also: a predicate over nulls stays fused, consume_batch_chunk)
   const uint64_t S = (uint64_t)T.block_mask + 1;

@@ -60,7 +60,7 @@ def _defaults():
     ex.set_option("agg.pair_scan", 1)
     ex.set_option("agg.shared_planes", 1)
     yield
-    for k, v in (("agg.pair_scan", 1), ("agg.shared_planes", 1), ("agg.partition_cap_rows", 0), ("agg.capacity_log2", 0)):
+    for k, v in (("agg.pair_scan", 1), ("agg.shared_planes", 1), ("agg.partition_cap_rows", 0), ("agg.capacity_log2", 0), ("agg.hot_keys", -1)):
         ex.set_option(k, v)
 
 
@@ -111,9 +111,17 @@ def test_pair_scan_region_overflow_goes_through_the_two_plane_spill_list():
     """Zipf keys and regions of 120 row slots: most of a hot key's rows overflow their region and take the spill list with BOTH
     operands; the replay applies them to the two-plane table."""
     syn = _syn(ex.SYNTH_I64_ZIPF, groups=200000.0)
-    _both_ways("zipf, tiny regions", syn, HEAD, [SUM_V, MAX_W], opts=(("agg.partition_cap_rows", 100),))
+    _both_ways("zipf, tiny regions", syn, HEAD, [SUM_V, MAX_W], opts=(("agg.partition_cap_rows", 100), ("agg.hot_keys", 0)))
     ex.set_option("agg.partition_cap_rows", 0)
-    _both_ways("zipf", syn, HEAD, [SUM_V, MAX_W])
+    _both_ways("zipf", syn, HEAD, [SUM_V, MAX_W])  # (agg.hot_keys is still 0: the pair scan although the keys are skewed)
+    ex.set_option("agg.hot_keys", -1)
+    # default options: the calibration slice sees the skew and the stream takes one scan per aggregate -- those keep the heavy keys in LDS
+    before = ex.counter_get("agg_pair_launches")
+    _s, _kept, want = oracle.run_synth_query(syn, SEED, 0, N, 1024, HEAD, [Column(0)], [SUM_V, MAX_W])
+    t = ex.DeviceTable.synth(syn, SEED, 0, N)
+    got = gpu_aggregate([Column(0)], [SUM_V, MAX_W], _schema(syn), [], filter_expr=HEAD, source=t.scan(BATCH))
+    _assert_bit_exact(got, want, "zipf, default options")
+    assert ex.counter_get("agg_pair_launches") == before, "skewed keys: a scan per aggregate (hot-key pairs), not the pair scan"
 
 
 def test_pair_scan_falls_back_when_the_table_outgrows_its_partitions():
@@ -178,7 +186,7 @@ def test_planes_of_a_shared_operand_and_nulls():
 
 def test_planes_of_a_shared_operand_overflow_growth_and_late_wide_keys():
     syn = _syn(ex.SYNTH_I64_ZIPF, groups=200000.0)
-    _both_ways("zipf, tiny regions", syn, HEAD, [SUM_V, MIN_V, COUNT_V], opts=(("agg.partition_cap_rows", 100),), **PLANES)
+    _both_ways("zipf, tiny regions", syn, HEAD, [SUM_V, MIN_V, COUNT_V], opts=(("agg.partition_cap_rows", 100), ("agg.hot_keys", 0)), **PLANES)
     ex.set_option("agg.partition_cap_rows", 0)
     _both_ways("table outgrows 256 partitions", _syn(groups=3000000.0), None, [SUM_V, MIN_V], n=3 * (1 << 22) + 999, expect_fallback=True, **PLANES)
     rng = np.random.default_rng(7)
@@ -229,7 +237,7 @@ def test_pair_scan_with_several_aggregates_per_operand_off_the_routed_path():
     got = gpu_aggregate([Column(0)], aggs, _schema(syn), [], filter_expr=None, source=t.scan(BATCH))
     _assert_bit_exact(got, want, "nulls in an operand, no predicate")
     assert ex.counter_get("agg_pair_launches") == before
-    _both_ways("zipf, tiny regions", _syn(ex.SYNTH_I64_ZIPF, groups=200000.0), HEAD, aggs, opts=(("agg.partition_cap_rows", 100),))
+    _both_ways("zipf, tiny regions", _syn(ex.SYNTH_I64_ZIPF, groups=200000.0), HEAD, aggs, opts=(("agg.partition_cap_rows", 100), ("agg.hot_keys", 0)))
     ex.set_option("agg.partition_cap_rows", 0)
     _both_ways("table outgrows the pair kernels", _syn(groups=3000000.0), None, aggs, n=3 * (1 << 22) + 999, expect_fallback=True)
 

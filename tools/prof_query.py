@@ -50,6 +50,8 @@ if wl == "q1":
     bytes_per_row = 56
 else:
     syn = [("k", ex.SYNTH_I64_UNIFORM, 0, 1e6, 0.0), ("v", ex.SYNTH_F64_EXACT, 1, 0.0, 0.0)]
+    if os.environ.get("ZIPF") == "1":  # Zipf(1.0)-distributed keys (bench.py's zipf_keys leg)
+        syn[0] = ("k", ex.SYNTH_I64_ZIPF, 0, 1e6, 1.0)
     schema = pa.schema([("k", pa.int64()), ("v", pa.float64())])
     pred = BinaryExpr(BinaryExpr(Column(1), Operator.Gt, lit(204.8)), Operator.And,
                       BinaryExpr(Column(1), Operator.Lt, lit(409.6)))
