@@ -86,7 +86,7 @@ else:
     if wl.startswith("sel"):  # sel50 / sel80 / sel35 ...: the headline query keeping that share of the rows (v is uniform on [0, 1024))
         pred = BinaryExpr(BinaryExpr(Column(1), Operator.Gt, lit(204.8)), Operator.And,
                           BinaryExpr(Column(1), Operator.Lt, lit(204.8 + 10.24 * float(wl[3:]))))
-    if wl == "cfg3":
+    if wl == "cfg3" or os.environ.get("NOPRED") == "1":  # (NOPRED=1: any of the workloads above without its predicate: every row routed)
         pred = None
     if wl == "cfg2":
         group = []
