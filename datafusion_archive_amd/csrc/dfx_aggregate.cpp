@@ -95,6 +95,8 @@ struct AggregateRelation::Impl {
   // through the one-value pass 1 exactly as the headline's does, pass 2 runs once per accumulator plane with that aggregate's
   // transform.  Rounds 3-6 gave such queries 4096-slot blocks holding every plane (twice the partitions, 8-row chunks of 96 bytes).
   bool pair_mode = false;
+  bool pair_wide_seen = false;   // a key without a 32-bit image turned up under pair_mode: its rows take the spill list until the next batch
+                                 // boundary, where the stream leaves for the scans per aggregate (they have a wide routed form)
   bool pair_is_planes = false;   // pair_mode: the shared-operand flavour
   bool split_is_shared = false;  // the aggregates single_chunks splits all take the same operand
   // ... or exactly TWO different operands between them (SUM(v), COUNT(v), MAX(w) ...): split_ops bit a = the operand (0 / 1) of
@@ -985,7 +987,8 @@ Status AggregateRelation::Impl::post_ctrl(int64_t rows) {
 // errors, growth: what the per-batch check has always done, on a (possibly one batch old) snapshot
 Status AggregateRelation::Impl::handle_ctrl(const uint32_t* hc, int64_t n) {
   if (hc[CTRL_ERROR]) return error_from_ctrl(hc[CTRL_ERROR]);
-  if (narrow && hc[CTRL_WIDE_KEYS] && !pair_mode) {  // (pair scan: such rows keep taking the spill list -- a table block holds one plane, no wide form fits)
+  if (narrow && hc[CTRL_WIDE_KEYS] && pair_mode) pair_wide_seen = true;  // (no wide form fits a block that holds one plane: consume_batch falls back)
+  if (narrow && hc[CTRL_WIDE_KEYS] && !pair_mode) {
     // a key without a 32-bit image turned up (it went to the spill list): 16-byte rows from now on
     DFX_RETURN_IF_ERROR(flush_pass2());
     narrow = false;
@@ -1514,7 +1517,7 @@ Status AggregateRelation::Impl::consume_batch(const DeviceBatch& b) {
     if (decided_rows == 0) return consume_batch(b);
     return consume_batch(rows_from(b, decided_rows));
   }
-  if (pair_mode && !pair_batch_ok(b)) DFX_RETURN_IF_ERROR(pair_fall_back());
+  if (pair_mode && (pair_wide_seen || !pair_batch_ok(b))) DFX_RETURN_IF_ERROR(pair_fall_back());
   if (chunks.size() <= 1) return consume_batch_chunk(b);
   if (kw > 0 && opt().chunk_hold > 1) {  // grouped, several chunks: hold the batch (see `held`)
     size_t bytes = 0;
@@ -1595,6 +1598,7 @@ Status AggregateRelation::Impl::pair_fall_back() {
   install_chunks(std::move(single_chunks));
   single_chunks.clear();
   split_done = true;
+  if (pair_wide_seen) narrow = false;  // (16-byte routed rows from here on; install_chunks has invalidated the layout)
   return Status::OK();
 }
 

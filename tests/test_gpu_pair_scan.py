@@ -131,25 +131,28 @@ def test_pair_scan_falls_back_when_the_table_outgrows_its_partitions():
     _both_ways("table outgrows the pair kernels", syn, None, [SUM_V, MIN_W], n=3 * (1 << 22) + 999, batch=(1 << 22) - 64, expect_fallback=True)
 
 
-def test_pair_scan_keeps_going_when_wide_keys_arrive_late():
+def test_pair_scan_hands_over_when_wide_keys_arrive_late():
+    """Keys without a 32-bit image from the third of five batches on: that batch's wide rows take the spill list (two value planes); at the
+    next batch boundary the stream leaves for the scans per aggregate, which route 16-byte rows {key, operand} from there on."""
     rng = np.random.default_rng(6)
     per = (1 << 21) + 4096  # > 2^21 rows in the first batch: the calibration slice sees narrow keys only
-    m = 3 * per
+    m = 5 * per
     k = rng.integers(0, 300000, m).astype(np.int64)
     k[2 * per + 5::1013] += 1 << 40
     k[2 * per + 9::2027] = -k[2 * per + 9::2027] - 1
     v = rng.integers(0, 1 << 20, m).astype(np.float64) / 1024.0
     w = rng.integers(0, 1000, m).astype(np.int64)
     whole = pa.RecordBatch.from_arrays([pa.array(k), pa.array(v), pa.array(w)], names=["k", "v", "w"])
-    batches = [whole.slice(i * per, per) for i in range(3)]
+    batches = [whole.slice(i * per, per) for i in range(5)]
     aggs = [SUM_V, MIN_W]
     want = oracle.aggregate([Column(0)], aggs, [oracle.filter_next(HEAD, b) for b in batches])
     for pair in (1, 0):
         ex.set_option("agg.pair_scan", pair)
-        before = ex.counter_get("agg_pair_launches")
+        before = ex.counter_get("agg_pair_launches"), ex.counter_get("agg_pair_fallbacks")
         got = gpu_aggregate([Column(0)], aggs, whole.schema, batches, filter_expr=HEAD)
         assert_groups_identical(got, want, 1, f"late wide keys, agg.pair_scan = {pair}")
-        assert (ex.counter_get("agg_pair_launches") - before > 0) == bool(pair)
+        assert (ex.counter_get("agg_pair_launches") - before[0] > 0) == bool(pair)
+        assert ex.counter_get("agg_pair_fallbacks") - before[1] == (1 if pair else 0)
 
 
 # ---- aggregates of ONE operand: the raw operand through the one-value pass 1, a pass 2 per accumulator plane (PTF_PLANES) ----------
