@@ -309,9 +309,11 @@ enum : uint32_t {
   PTF_PLANES = 256u,      // with PTF_SHARED | PTF_NARROW | PTF_CHUNK16 | PTF_WS: the aggregates' common RAW operand travels through the one-value
                           // pass 1 (LINE chunks, table blocks of 8192 slots) and pass 2 runs once per accumulator plane, applying that
                           // aggregate's transform to the operand (DevPartition::pair_plane) -- instead of 4096-slot blocks with every plane
-  PTF_PAIR = 128u,        // with PTF_NARROW | PTF_CHUNK16 | PTF_WS (LINE chunks only): TWO aggregates of DIFFERENT operands, one scan -- routed
+  PTF_PAIR = 128u,        // with PTF_NARROW | PTF_CHUNK16 | PTF_WS (LINE chunks only): aggregates over TWO operand columns, one scan -- routed
                           // rows are 20 bytes {operand 0, hash image, operand 1} (kPair* below), pass 2 runs once per accumulator plane
-                          // (DevPartition::pair_plane) over the same regions: each launch is the one-value kernel with its 96 KB block
+                          // (DevPartition::pair_plane / pair_operand) over the same regions: each launch is the one-value kernel with its
+                          // 96 KB block.  Two aggregates: the scan transforms each operand for its accumulator; more (+ PTF_PLANES): raw
+                          // operands, the transform in pass 2 (DevPartition::pair_ops)
   PTF_NARROW = 8u         // keys below 2^32 (seen by the calibration slice): 12-byte routed rows {hash image, operand}, pass 2
                           // works on 32-bit images; needs ring flavour, one key word, one aggregate
 };

@@ -101,11 +101,13 @@ struct AggOptions {
   int host_stage_slots = 6;    // ... slots
   int chunk_hold = 4;          // several chunks of accumulators over one table: batches held so that every chunk scans them in a row (one host check per
                                // chunk and hold; 1: per chunk and batch, rounds 3-5)
-  int shared_planes = 1;       // 2..3 aggregates of ONE operand (AVG = SUM + COUNT, SUM + MIN + MAX of a column ...), narrow key, many groups: the raw operand
+  int shared_planes = 1;       // two and more aggregates of ONE operand (AVG = SUM + COUNT, SUM + MIN + MAX of a column ...), narrow key, many groups, keys
+                               // not skewed: the raw operand
                                // goes through the one-value pass 1 (whole-line chunks, 8192-slot table blocks) and pass 2 runs once per accumulator
                                // plane (PTF_PLANES); 0: rounds 3-6 -- 4096-slot blocks that hold every plane, 8-row chunks
-  int pair_scan = 1;           // two aggregates of different operands, one narrow key, many groups: ONE scan routes both operands (20-byte rows,
-                               // PTF_PAIR) and pass 2 runs once per accumulator plane, instead of a scan per aggregate (0: always the scans)
+  int pair_scan = 1;           // aggregates over TWO plain columns (two or more accumulators: SUM(v), MIN(w); AVG(v), MAX(w) ...), one narrow key, many
+                               // groups, keys not skewed: ONE scan routes both operands (20-byte rows, PTF_PAIR) and pass 2 runs once per
+                               // accumulator plane, instead of a scan per aggregate (0: always the scans)
   int split_aggregates = 1;    // one key, several aggregates of different operands, many groups: a scan per aggregate through the one-value
                                // kernels of the partitioned strategy (0: one scan that routes a row with every operand)
   int filter_dense = -1;       // single-pass FilterRelation, tiles kept in registers (k_filter_fused_dense): -1 when the stream has
